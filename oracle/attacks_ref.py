@@ -1,0 +1,306 @@
+"""CPU oracle: restatement of the adversarial generators behind AddNoise (torch-CPU fp32).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Paths cited are relative to
+/root/reference/RobustART/noise/utils/adv/.
+
+Every attack takes ``grad_fn(x) -> (logits, loss_indiv, grad)`` style callables built from a
+torch model on CPU (autograd is plumbing here, the arithmetic under test is the
+step/projection/bookkeeping), and takes its random start as an explicit tensor so the HIP
+path can be driven with the same draws.
+
+Pinned against unmodified reference code (tests/golden/make_golden.py): apgd (Linf, L2, ce and
+dlr), apgd_targeted, mim_linf.  UNPINNED (foolbox 3.3.1 is not installed, the reference has no
+tests): pgd_linf, pgd_l2, fgsm -- these follow foolbox's BaseGradientDescent.run as recalled in
+SURVEY.md Appendix B, and are cross-checked only through identities (||delta|| <= eps, range).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def normalize(x):
+    """Attacks/imfgsm_attack.py:14-23 / Attacks/autoattack/autoattack.py:17-20."""
+    mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=x.dtype).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+def _grad_of_sum(loss_fn, model_fn, x, y):
+    x = x.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        logits = model_fn(x)
+        loss_indiv = loss_fn(logits, y)
+        loss = loss_indiv.sum()
+    g = torch.autograd.grad(loss, [x])[0].detach()
+    return logits.detach(), loss_indiv.detach(), g
+
+
+def ce_indiv(logits, y):
+    return F.cross_entropy(logits, y, reduction='none')
+
+
+# ---------------------------------------------------------------------------------------
+# foolbox 3.3.1 BaseGradientDescent (attack.py:20-33) -- UNPINNED
+# ---------------------------------------------------------------------------------------
+
+def pgd_linf_step(x, g, x0, eps, stepsize):
+    x = x + stepsize * torch.sign(g)
+    x = x0 + torch.clamp(x - x0, -eps, eps)
+    return torch.clamp(x, 0.0, 1.0)
+
+
+def pgd_linf(model_fn, x0, y, eps, rel_stepsize, steps, init_u=None, random_start=True):
+    """attack.py:20-23.  init_u: the U(-eps, eps) start perturbation (same shape as x0)."""
+    stepsize = rel_stepsize * eps
+    x = x0.clone()
+    if random_start:
+        x = torch.clamp(x0 + init_u, 0.0, 1.0)
+    for _ in range(steps):
+        _, _, g = _grad_of_sum(ce_indiv, model_fn, x, y)
+        x = pgd_linf_step(x, g, x0, eps, stepsize)
+    return x
+
+
+def fgsm(model_fn, x0, y, eps):
+    """attack.py:30-33: LinfFastGradientAttack = 1 step of size eps, no random start."""
+    return pgd_linf(model_fn, x0, y, eps, 1.0, 1, random_start=False)
+
+
+def _l2norms(v):
+    return v.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+
+
+def pgd_l2_step(x, g, x0, eps, stepsize):
+    g = g / torch.clamp(_l2norms(g), min=1e-12)
+    x = x + stepsize * g
+    d = x - x0
+    factor = torch.clamp(eps / torch.clamp(_l2norms(d), min=1e-12), max=1.0)
+    x = x0 + d * factor
+    return torch.clamp(x, 0.0, 1.0)
+
+
+def l2_ball_start(gauss_np2, eps):
+    """foolbox L2 random start: uniform point in the eps-ball from an (n+2)-dim gaussian
+    (B, n+2) -> normalise -> keep first n coordinates."""
+    s = gauss_np2 / gauss_np2.norm(dim=1, keepdim=True)
+    return eps * s[:, :-2]
+
+
+def pgd_l2(model_fn, x0, y, eps, rel_stepsize, steps, init_delta=None, random_start=True):
+    """attack.py:25-28.  init_delta: start perturbation inside the eps-ball, shaped like x0."""
+    stepsize = rel_stepsize * eps
+    x = x0.clone()
+    if random_start:
+        x = torch.clamp(x0 + init_delta, 0.0, 1.0)
+    for _ in range(steps):
+        _, _, g = _grad_of_sum(ce_indiv, model_fn, x, y)
+        x = pgd_l2_step(x, g, x0, eps, stepsize)
+    return x
+
+
+# ---------------------------------------------------------------------------------------
+# MIM (Attacks/imfgsm_attack.py:62-93) -- pinned
+# ---------------------------------------------------------------------------------------
+
+def mim_step(x, g, m, x0, eps, step_size, decay):
+    """imfgsm_attack.py:85-90."""
+    g = g / torch.mean(torch.abs(g), [1, 2, 3], keepdim=True)
+    m = decay * m + g
+    x = x + step_size * m.sign()
+    x = x0 + torch.clamp(x - x0, -eps, eps)
+    return torch.clamp(x, 0.0, 1.0), m
+
+
+def mim_linf(model, X, y, epsilon, num_steps, step_size, decay_factor, init_noise):
+    """`model` takes NORMALISED input (imfgsm_attack.py:69,83); CE mean loss (:83);
+    the start X + U(-eps,eps) is not clipped before the first forward (:73-74)."""
+    x = X + init_noise
+    m = torch.zeros_like(X)
+    for _ in range(num_steps):
+        xr = x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            loss = F.cross_entropy(model(normalize(xr)), y)
+        g = torch.autograd.grad(loss, [xr])[0].detach()
+        x, m = mim_step(x, g, m, X, epsilon, step_size, decay_factor)
+    return x
+
+
+# ---------------------------------------------------------------------------------------
+# AutoPGD (Attacks/autoattack/autopgd_base.py) -- pinned
+# ---------------------------------------------------------------------------------------
+
+def dlr_loss(x, y):
+    """autopgd_base.py:198-204."""
+    x_sorted, ind_sorted = x.sort(dim=1)
+    ind = (ind_sorted[:, -1] == y).float()
+    u = torch.arange(x.shape[0])
+    return -(x[u, y] - x_sorted[:, -2] * ind - x_sorted[:, -1] * (1. - ind)) / (
+        x_sorted[:, -1] - x_sorted[:, -3] + 1e-12)
+
+
+def dlr_loss_targeted(x, y, y_target):
+    """autopgd_base.py:599-604."""
+    x_sorted, _ = x.sort(dim=1)
+    u = torch.arange(x.shape[0])
+    return -(x[u, y] - x[u, y_target]) / (x_sorted[:, -1] - .5 * (x_sorted[:, -3] + x_sorted[:, -4]) + 1e-12)
+
+
+def _apgd_normalize(x, norm):
+    """autopgd_base.py:177-184."""
+    nd = x.dim() - 1
+    if norm == 'Linf':
+        t = x.abs().reshape(x.shape[0], -1).max(1)[0]
+    else:
+        t = (x ** 2).reshape(x.shape[0], -1).sum(-1).sqrt()
+    return x / (t.view(-1, *([1] * nd)) + 1e-12)
+
+
+def _apgd_lp_norm(x):
+    """autopgd_base.py:193-196 (L2)."""
+    nd = x.dim() - 1
+    return (x ** 2).reshape(x.shape[0], -1).sum(-1).sqrt().view(-1, *([1] * nd))
+
+
+def apgd_checkpoints(n_iter):
+    """autopgd_base.py:163-165."""
+    return max(int(0.22 * n_iter), 1), max(int(0.06 * n_iter), 1), max(int(0.03 * n_iter), 1)
+
+
+def apgd_step_linf(x_adv, x_adv_old, grad, x, eps, step_size, a):
+    """autopgd_base.py:327-338; returns (x_new, x_adv_old_new)."""
+    grad2 = x_adv - x_adv_old
+    x_adv_1 = x_adv + step_size * torch.sign(grad)
+    x_adv_1 = torch.clamp(torch.min(torch.max(x_adv_1, x - eps), x + eps), 0.0, 1.0)
+    x_adv_1 = torch.clamp(torch.min(torch.max(x_adv + (x_adv_1 - x_adv) * a + grad2 * (1 - a),
+                                              x - eps), x + eps), 0.0, 1.0)
+    return x_adv_1
+
+
+def apgd_step_l2(x_adv, x_adv_old, grad, x, eps, step_size, a):
+    """autopgd_base.py:340-348."""
+    grad2 = x_adv - x_adv_old
+    x_adv_1 = x_adv + step_size * _apgd_normalize(grad, 'L2')
+    x_adv_1 = torch.clamp(x + _apgd_normalize(x_adv_1 - x, 'L2') * torch.min(
+        eps * torch.ones_like(x), _apgd_lp_norm(x_adv_1 - x)), 0.0, 1.0)
+    x_adv_1 = x_adv + (x_adv_1 - x_adv) * a + grad2 * (1 - a)
+    x_adv_1 = torch.clamp(x + _apgd_normalize(x_adv_1 - x, 'L2') * torch.min(
+        eps * torch.ones_like(x), _apgd_lp_norm(x_adv_1 - x)), 0.0, 1.0)
+    return x_adv_1
+
+
+def apgd_single_run(model_fn, x, y, norm, eps, n_iter, loss, init_t, y_target=None, rho=0.75, trace=None):
+    """autopgd_base.py:208-448 (eot_iter = 1, Linf / L2).  init_t = the torch.rand*2-1 (Linf)
+    or torch.randn (L2) start direction.  Returns (x_best, acc, loss_best, x_best_adv)."""
+    if loss == 'ce':
+        crit = ce_indiv
+    elif loss == 'dlr':
+        crit = dlr_loss
+    elif loss == 'dlr-targeted':
+        crit = lambda lg, yy: dlr_loss_targeted(lg, yy, y_target)
+    else:
+        raise ValueError(loss)
+    nd = x.dim() - 1
+    n_iter_2, n_iter_min, size_decr = apgd_checkpoints(n_iter)
+
+    x_adv = x + eps * torch.ones_like(x) * _apgd_normalize(init_t, norm)       # :213-220
+    x_adv = x_adv.clamp(0., 1.)                                                # :237
+    x_best = x_adv.clone()
+    x_best_adv = x_adv.clone()
+    B = x.shape[0]
+    loss_steps = torch.zeros([n_iter, B])
+
+    logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y)          # :271-289
+    grad_best = grad.clone()
+    acc = logits.max(1)[1] == y
+    loss_best = loss_indiv.clone()
+    step_size = 2. * eps * torch.ones([B, *([1] * nd)])                        # :296-298
+    x_adv_old = x_adv.clone()
+    k = n_iter_2 + 0
+    counter3 = 0
+    loss_best_last_check = loss_best.clone()
+    reduced_last_check = torch.ones_like(loss_best)
+
+    for i in range(n_iter):
+        x_adv = x_adv.detach()
+        a = 0.75 if i > 0 else 1.0
+        step = apgd_step_linf if norm == 'Linf' else apgd_step_l2
+        x_new = step(x_adv, x_adv_old, grad, x, eps, step_size, a)
+        x_adv_old = x_adv.clone()
+        x_adv = x_new + 0.
+
+        logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y)      # :367-384
+        pred = logits.max(1)[1] == y
+        acc = torch.min(acc, pred)
+        ind_pred = ~pred
+        x_best_adv[ind_pred] = x_adv[ind_pred] + 0.                            # :389-390
+
+        y1 = loss_indiv.clone()                                                # :399-406
+        loss_steps[i] = y1 + 0
+        ind = y1 > loss_best
+        x_best[ind] = x_adv[ind].clone()
+        grad_best[ind] = grad[ind].clone()
+        loss_best[ind] = y1[ind] + 0
+        if trace is not None:
+            trace.append(dict(x_adv=x_adv.clone(), grad=grad.clone(), loss=y1.clone(),
+                              step_size=step_size.flatten().clone()))
+        counter3 += 1
+        if counter3 == k:                                                      # :410-429
+            t = torch.zeros(B)
+            for c5 in range(k):                                                # check_oscillation :167-172
+                t += (loss_steps[i - c5] > loss_steps[i - c5 - 1]).float()
+            fl_osc = (t <= k * rho * torch.ones_like(t)).float()
+            fl_no_impr = (1. - reduced_last_check) * (loss_best_last_check >= loss_best).float()
+            fl_osc = torch.max(fl_osc, fl_no_impr)
+            reduced_last_check = fl_osc.clone()
+            loss_best_last_check = loss_best.clone()
+            if fl_osc.sum() > 0:
+                sel = fl_osc > 0
+                step_size[sel] /= 2.0
+                x_adv[sel] = x_best[sel].clone()
+                grad[sel] = grad_best[sel].clone()
+            k = max(k - size_decr, n_iter_min)
+            counter3 = 0
+    return x_best, acc, loss_best, x_best_adv
+
+
+def apgd_perturb(model_fn, x, y, norm, eps, n_iter, loss, init_ts, n_restarts=1):
+    """autopgd_base.py:450-529 (best_loss=False).  init_ts[r] = start direction for restart r,
+    shaped like the still-robust subset at that restart."""
+    x = x.detach().clone().float()
+    y_pred = model_fn(x).max(1)[1]
+    adv = x.clone()
+    acc = y_pred == y
+    for counter in range(n_restarts):
+        ind_to_fool = acc.nonzero().flatten()
+        if ind_to_fool.numel() != 0:
+            _, acc_curr, _, adv_curr = apgd_single_run(model_fn, x[ind_to_fool].clone(), y[ind_to_fool].clone(),
+                                                       norm, eps, n_iter, loss, init_ts[counter])
+            ind_curr = (acc_curr == 0).nonzero().flatten()
+            acc[ind_to_fool[ind_curr]] = False
+            adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
+    return adv
+
+
+def apgd_targeted_perturb(model_fn, x, y, norm, eps, n_iter, init_ts, n_target_classes=9):
+    """autopgd_base.py:610-690 (n_restarts = 1).  init_ts[j] for target_class j+2."""
+    x = x.detach().clone().float()
+    y_pred = model_fn(x).max(1)[1]
+    adv = x.clone()
+    acc = y_pred == y
+    for j, target_class in enumerate(range(2, n_target_classes + 2)):
+        ind_to_fool = acc.nonzero().flatten()
+        if ind_to_fool.numel() != 0:
+            x_to_fool = x[ind_to_fool].clone()
+            y_to_fool = y[ind_to_fool].clone()
+            output = model_fn(x_to_fool)
+            y_target = output.sort(dim=1)[1][:, -target_class]
+            _, acc_curr, _, adv_curr = apgd_single_run(model_fn, x_to_fool, y_to_fool, norm, eps, n_iter,
+                                                       'dlr-targeted', init_ts[j], y_target=y_target)
+            ind_curr = (acc_curr == 0).nonzero().flatten()
+            acc[ind_to_fool[ind_curr]] = False
+            adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
+    return adv

@@ -1,0 +1,100 @@
+"""Generate the committed golden fixtures by running UNMODIFIED reference code
+(/root/reference, imported with stubs for absent wheels -- see _ref_import.py).
+
+Run in the build container only:  python tests/golden/make_golden.py
+Outputs (data only: inputs are regenerated from seeds by tests/_inputs.py):
+  tests/golden/corruptions_ref.npz   sha256 + 64x64 crop of reference outputs, 8 corruptions x 5 severities
+  tests/golden/attacks_ref.npz       reference APGD / APGD-T / MIM outputs on tests/_tinynet.TinyNet
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from _ref_import import import_reference_noise  # noqa: E402
+
+ref_noise = import_reference_noise()
+from PIL import Image  # noqa: E402
+from RobustART.noise.utils.imagenet_c import corrupt as ref_corrupt  # noqa: E402
+from RobustART.noise.utils.adv.Attacks.autoattack.autopgd_base import APGDAttack, APGDAttack_targeted  # noqa: E402
+from RobustART.noise.utils.adv.Attacks.imfgsm_attack import _mim_whitebox  # noqa: E402
+
+from _inputs import RUNNABLE, make_image, case_seed  # noqa: E402
+from _tinynet import make_tinynet, make_batch  # noqa: E402
+from oracle.attacks_ref import normalize  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_corruptions():
+    out = {}
+    for name in RUNNABLE:
+        for sev in range(1, 6):
+            x = make_image(sev)
+            np.random.seed(case_seed(name, sev))
+            y = np.asarray(ref_corrupt(Image.fromarray(x), severity=sev, corruption_name=name))
+            out[f'{name}/{sev}/sha'] = np.array(sha(y))
+            out[f'{name}/{sev}/crop'] = y[80:144, 80:144].copy()
+    # the AddNoise('imagenet-c') batch path: in-place, per-image loop, one random stream
+    A = ref_noise.AddNoise('imagenet-c')
+    A.set_config(corruption_name='gaussian_noise', severity=3)
+    batch = np.stack([make_image(i) for i in (1, 2, 3)])
+    np.random.seed(4242)
+    ret = A.add_noise(batch)
+    assert ret is batch
+    out['batch/gaussian_noise/3/sha'] = np.array(sha(ret))
+    out['batch/gaussian_noise/3/crop'] = ret[:, 80:112, 80:112].copy()
+    A.set_config(corruption_name=None, corruption_number=1, severity=2)   # shot_noise by index
+    batch = np.stack([make_image(i) for i in (4, 5)])
+    np.random.seed(4243)
+    ret = A.add_noise(batch)
+    out['batch/number1/2/sha'] = np.array(sha(ret))
+    np.savez_compressed(os.path.join(HERE, 'corruptions_ref.npz'), **out)
+    print('corruptions_ref.npz', len(out), 'entries')
+
+
+def gen_attacks():
+    net = make_tinynet()
+    model_fn = lambda x: net(normalize(x))  # noqa: E731
+    x = make_batch()
+    y = model_fn(x).max(1)[1]          # every sample starts "correct"
+    out = {f'net/{k}': v.numpy() for k, v in net.state_dict().items()}
+    out['x'] = x.numpy()
+    out['y'] = y.numpy()
+    for norm, eps in (('Linf', 8 / 255), ('L2', 0.5)):
+        for loss in ('ce', 'dlr'):
+            att = APGDAttack(model_fn, n_iter=10, norm=norm, n_restarts=1, eps=eps, seed=0, loss=loss,
+                             device='cpu')
+            adv = att.perturb(x.clone(), y.clone())
+            out[f'apgd/{norm}/{loss}/adv'] = adv.detach().numpy()
+            # single run internals (best-loss point and flags) for a tighter pin
+            att.init_hyperparam(x)
+            torch.random.manual_seed(0)
+            xb, acc, lb, xba = att.attack_single_run(x.clone(), y.clone())
+            out[f'apgd/{norm}/{loss}/x_best'] = xb.detach().numpy()
+            out[f'apgd/{norm}/{loss}/acc'] = acc.numpy()
+            out[f'apgd/{norm}/{loss}/loss_best'] = lb.detach().numpy()
+            out[f'apgd/{norm}/{loss}/x_best_adv'] = xba.detach().numpy()
+    att = APGDAttack_targeted(model_fn, n_iter=8, norm='Linf', n_restarts=1, eps=4 / 255, seed=0,
+                              n_target_classes=3, device='cpu')
+    out['apgdt/Linf/adv'] = att.perturb(x.clone(), y.clone()).detach().numpy()
+    torch.manual_seed(11)
+    adv = _mim_whitebox(net, x.clone(), y.clone(), epsilon=8 / 255, num_steps=5, step_size=0.002,
+                        decay_factor=1.0)
+    out['mim/adv'] = adv.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, 'attacks_ref.npz'), **out)
+    print('attacks_ref.npz', len(out), 'entries')
+
+
+if __name__ == '__main__':
+    gen_corruptions()
+    gen_attacks()
