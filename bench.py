@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the AddNoise hot path on MI355X.
+
+Metric (BASELINE.json): corrupted + attacked images/sec/node (ResNet-50, PGD-7 + IN-C x5).
+One "step" = one pass of the hot path over one resident batch of B = 256 uint8 NHWC images:
+
+  * IN-C x5 : gaussian_noise at severities 1..5 (5*B corrupted images), each normalised and
+              evaluated by ResNet-50 (forward, top-1);
+  * PGD-7   : PGD-Linf (eps 2/255, rel_stepsize 3/40, 7 steps, random start) on the B clean images
+              = 7 x (forward + backward-to-input + fused sign/project kernel) + 1 final forward.
+
+images per step = 6*B.  Inputs are resident in HBM before the timed region.  Weak scaling: every
+rank processes its own B images (global sample indices keep the noise field rank-invariant); the
+only collective is the 3-scalar metric all-reduce after the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_DEFAULT = 256
+H = W = 224
+ELEMS = H * W * 3
+BYTES_PER_IMAGE = 2 * ELEMS            # uint8 in + uint8 out
+FLOP_FWD = 8.2e9                        # ResNet-50 forward, 2 x 4.09 GMAC
+HBM_PEAK = 8.0e12
+MFMA_BF16_PEAK = 2.5e15
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=B_DEFAULT)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=8, help='images in the bounded CPU baseline sample')
+    return ap.parse_args()
+
+
+def build_workload(B, device, rank):
+    from robustart_amd.model import get_model
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(device)
+    labels = torch.randint(0, 1000, (B,), generator=g).to(device)
+    torch.manual_seed(0)
+    model = get_model({'type': 'resnet50_official', 'kwargs': {'num_classes': 1000}}).eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return images, labels, model
+
+
+class Scaffold:
+    """Model path used until the hand-written HIP engine covers ResNet-50: bf16 channels_last
+    ResNet-50 on PyTorch-ROCm (MIOpen/hipBLASLt).  Reported as such in `config.model_path`."""
+    name = 'torch-rocm-bf16-scaffold'
+
+    def __init__(self, model, device):
+        self.m = model.to(device).to(torch.bfloat16).to(memory_format=torch.channels_last)
+        self.mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
+        self.std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
+
+    def logits_from_normalized_bf16_nhwc(self, xn):
+        # xn: (B,H,W,3) bf16 normalised (channels_last storage of an NCHW view)
+        with torch.no_grad():
+            return self.m(xn.permute(0, 3, 1, 2)).float()
+
+    def f_model(self, x01):
+        xn = ((x01 - self.mean) / self.std).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        return self.m(xn)
+
+
+def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
+    from robustart_amd import _lib
+    from robustart_amd.noise import imagenet_c as C, adv
+    lib = _lib.load()
+    correct = 0
+    base = (step_idx * 1_000_003 + rank * B)          # global sample index of this rank's first image
+    for sev in range(1, 6):
+        C.corrupt_batch_(images, 0, sev, seed=0, sample_offset=base, out=scratch_u8)
+        _lib.check(lib.rart_u8_to_normalized(_lib.ptr(scratch_u8), _lib.ptr(norm_buf), B, H, W, 1, 1,
+                                             _lib.stream_ptr()))
+        logits = path.logits_from_normalized_bf16_nhwc(norm_buf)
+        _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
+        correct = correct + (pred.long() == labels).sum()
+    x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
+    x_adv = adv.pgd_linf(x01, labels, path.f_model, 2 / 255, 3 / 40, 7, seed=1, sample_offset=base)
+    with torch.no_grad():
+        logits = path.f_model(x_adv).float()
+    _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
+    correct_adv = (pred.long() == labels).sum()
+    return correct, correct_adv
+
+
+def measure_gaussian_roofline(B, device, launches=40):
+    """HBM roofline of the dominant hand-written kernel of the corruption half
+    (k_normal_noise_native<0>): rotate > 600 MB of distinct buffer pairs so the 256 MiB Infinity
+    Cache cannot serve the stream, time with events on the launch stream."""
+    from robustart_amd.noise import imagenet_c as C
+    npairs = 9
+    g = torch.Generator().manual_seed(7)
+    src = [torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(device) for _ in range(npairs)]
+    dst = [torch.empty_like(s) for s in src]
+    for i in range(npairs):
+        C.corrupt_batch_(src[i], 0, 3, seed=0, sample_offset=0, out=dst[i])
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for i in range(launches):
+        ev[i][0].record()
+        C.corrupt_batch_(src[i % npairs], 0, 3, seed=0, sample_offset=i * B, out=dst[i % npairs])
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    avg = sum(ms) / len(ms)
+    return avg * 1e-3, ms[len(ms) // 2] * 1e-3
+
+
+def cpu_baseline(sample, model_fp32):
+    """Oracle (numpy restatement, asserted equal to the reference) + torch-CPU ResNet-50 on the host
+    cores, on `sample` images of the same workload: IN-C x5 + PGD-7."""
+    import numpy as np
+    from oracle import corruptions_np as O
+    from oracle import attacks_ref as A
+    rs = np.random.RandomState(0)
+    imgs = rs.randint(0, 256, (sample, H, W, 3)).astype(np.uint8)
+    y = torch.from_numpy(rs.randint(0, 1000, (sample,)))
+    m = model_fp32.float().eval()
+    f = lambda z: m(A.normalize(z))  # noqa: E731
+    t0 = time.time()
+    for sev in range(1, 6):
+        out = O.corrupt_batch('gaussian_noise', imgs, sev, rs)
+        with torch.no_grad():
+            f(torch.from_numpy(out).permute(0, 3, 1, 2).float() / 255).argmax(1)
+    x = torch.from_numpy(imgs).permute(0, 3, 1, 2).float() / 255
+    u = (torch.rand(x.shape) * 2 - 1) * (2 / 255)
+    adv_x = A.pgd_linf(f, x, y, 2 / 255, 3 / 40, 7, init_u=u)
+    with torch.no_grad():
+        f(adv_x).argmax(1)
+    dt = time.time() - t0
+    return 6 * sample / dt, dt
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)       # "nccl" == RCCL on ROCm
+    B = args.batch
+    images, labels, model = build_workload(B, device, rank)
+    import copy
+    model_cpu = copy.deepcopy(model) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    path = Scaffold(model, device)
+    scratch = torch.empty_like(images)
+    norm_buf = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=device)
+
+    for i in range(args.warmup):
+        one_step(images, labels, path, scratch, norm_buf, i, rank, B)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    acc = None
+    for i in range(args.steps):
+        acc = one_step(images, labels, path, scratch, norm_buf, args.warmup + i, rank, B)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        stats = torch.stack([acc[0], acc[1], torch.tensor(B, device=device)]).to(torch.int64)
+        dist.all_reduce(stats)                                   # the eval metric exchange
+    imgs_per_step = 6 * B * world
+    value = imgs_per_step * args.steps / dt
+
+    out = {
+        'metric': 'corrupted+attacked images/sec/node (ResNet-50, PGD-7 + IN-C x5)',
+        'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'per step and GPU: gaussian_noise sev 1..5 on 256 u8 224x224 images -> normalise -> '
+                               'ResNet-50 eval (1280 img) + PGD-Linf-7 eps 2/255 ResNet-50 eval (256 img)',
+                   'global_batch': B * world, 'images_per_step': imgs_per_step,
+                   'model_path': path.name, 'parallelism': 'dp%d' % world},
+    }
+    if rank == 0:
+        if world == 1:
+            avg, med = measure_gaussian_roofline(B, device)
+            algo = BYTES_PER_IMAGE * B
+            out['roofline'] = {'kernel': 'k_normal_noise_native<0> (gaussian_noise, B=256, u8 NHWC in/out)',
+                               'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
+                               'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': None,
+                               'avg_launch_us': avg * 1e6, 'median_launch_us': med * 1e6,
+                               'algorithmic_bytes_per_launch': algo}
+            step_flops = (5 + 15) * B * FLOP_FWD
+            out['model_roofline'] = {'bound': 'mfma', 'achieved': step_flops * args.steps / dt / 1e12,
+                                     'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                                     'frac': step_flops * args.steps / dt / MFMA_BF16_PEAK,
+                                     'note': 'whole-step algorithmic FLOPs / step time (20 forward-equivalents per image batch)'}
+            if model_cpu is not None:
+                v, secs = cpu_baseline(args.cpu_sample, model_cpu)
+                out['cpu_baseline'] = {'value': v, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                       'sample': '%d images: oracle gaussian_noise sev 1..5 + torch-CPU fp32 ResNet-50 '
+                                                 'eval + PGD-Linf-7 (%.1f s)' % (args.cpu_sample, secs)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,170 @@
+/*
+ * robustart_hip.h -- C-ABI of the MI355X (gfx950) hot path of RobustART's AddNoise:
+ * ImageNet-C corruption kernels, adversarial step kernels and the eval-mode
+ * ResNet-50 forward / backward-to-input engine.
+ *
+ * The reference (DIG-Beihang/RobustART) is pure Python and has no FFI of its own; this
+ * header is the boundary a maintainer would bind with ctypes.  Each
+ * entry point cites the reference function it replaces (paths relative to
+ * RobustART/noise/utils/ unless stated).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *  - the library never allocates or frees caller memory; scratch comes from the caller's
+ *    `workspace` (size from the matching *_workspace_bytes query);
+ *  - all work is enqueued on `stream` (a hipStream_t); no hidden device synchronisation;
+ *  - return value: 0 = RART_OK, otherwise an rart_status; rart_last_error_string() gives
+ *    the thread-local message.  Nothing throws across the boundary or calls exit();
+ *  - randomness is counter based: a draw is a pure function of
+ *    (seed, global sample index = sample_offset + i, element index), independent of launch
+ *    geometry and of how samples are sharded over GPUs.  When `injected` is non-NULL the
+ *    kernels consume the caller's draws instead (parity mode, fp64 where the reference is
+ *    fp64) -- layouts are listed per corruption below.
+ */
+#ifndef ROBUSTART_HIP_H
+#define ROBUSTART_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rart_stream_t; /* hipStream_t */
+
+typedef enum rart_status {
+  RART_OK = 0,
+  RART_ERR_INVALID = 1,     /* bad argument (null pointer, severity outside 1..5, unknown id ...) */
+  RART_ERR_UNSUPPORTED = 2, /* valid request the library does not implement (e.g. spatter severity 1-3) */
+  RART_ERR_WORKSPACE = 3,   /* workspace missing or too small */
+  RART_ERR_HIP = 4          /* a HIP runtime call failed */
+} rart_status;
+
+/* corruption ids == index into corruption_tuple (imagenet_c/__init__.py:5-8) */
+enum {
+  RART_GAUSSIAN_NOISE = 0, RART_SHOT_NOISE = 1, RART_IMPULSE_NOISE = 2, RART_DEFOCUS_BLUR = 3,
+  RART_GLASS_BLUR = 4, RART_MOTION_BLUR = 5, RART_ZOOM_BLUR = 6, RART_SNOW = 7, RART_FROST = 8,
+  RART_FOG = 9, RART_BRIGHTNESS = 10, RART_CONTRAST = 11, RART_ELASTIC_TRANSFORM = 12,
+  RART_PIXELATE = 13, RART_JPEG_COMPRESSION = 14, RART_SPECKLE_NOISE = 15, RART_GAUSSIAN_BLUR = 16,
+  RART_SPATTER = 17, RART_SATURATE = 18, RART_NUM_CORRUPTIONS = 19
+};
+
+int rart_version(void);
+const char* rart_last_error_string(void);
+/* name of corruption id (static string), NULL if out of range */
+const char* rart_corruption_name(int corruption_id);
+
+/* ---------------------------------------------------------------------------------------
+ * ImageNet-C corruptions.  Replaces corrupt() + the per-image Python loop of
+ * add_noise_for_imagenet_c (add_noise_utils.py:22-31, imagenet_c/__init__.py:13-35,
+ * imagenet_c/corruptions.py:122-424).
+ *
+ * in / out : uint8 NHWC (n, h, w, 3); may alias (in-place, as the reference mutates its input).
+ *            Corruptions the reference hard-codes to 224x224 (glass_blur, fog, frost, snow,
+ *            pixelate, elastic_transform) require h == w == 224 here too.
+ * severity : 1..5.
+ * injected : NULL (native counter-based RNG) or an array of device pointers holding what
+ *            np.random returned inside the reference function, per image, C order:
+ *   gaussian_noise, speckle_noise : [0] double noise[n][h][w][3]   (np.random.normal(scale=c))
+ *   shot_noise                    : [0] int32  counts[n][h][w][3]  (np.random.poisson)
+ *   impulse_noise                 : [0] uint8  code[n][h][w][3]    (0 keep, 1 salt, 2 pepper)
+ *   glass_blur                    : [0] int8   dxdy[n][iters][224-2d][224-2d][2]
+ *   motion_blur                   : [0] double angle[n]
+ *   snow                          : [0] double layer[n][224][224]  [1] double angle[n]
+ *   frost                         : [0] uint8  texture_crop[n][224][224][3]  (REQUIRED always: the
+ *                                       reference's frost photos are not in its repository)
+ *   fog                           : [0] double uniform[n][65535]   (plasma_fractal draws, call order)
+ *   elastic_transform             : [0] float  jitter[n][3][2]  [1] double field_x[n][224][224]
+ *                                   [2] double field_y[n][224][224]
+ *   spatter                       : [0] double layer[n][224][224]
+ *   others                        : ignored
+ * workspace: rart_corrupt_workspace_bytes(...) bytes, 256-byte aligned.
+ * ------------------------------------------------------------------------------------- */
+size_t rart_corrupt_workspace_bytes(int corruption_id, int severity, int n, int h, int w);
+
+int rart_corrupt_u8(const uint8_t* in, uint8_t* out, int n, int h, int w,
+                    int corruption_id, int severity,
+                    uint64_t seed, uint64_t sample_offset,
+                    const void* const* injected_host_array, int n_injected,
+                    void* workspace, size_t workspace_bytes, rart_stream_t stream);
+
+/* uint8 NHWC -> ImageNet-normalised tensor for the model ((x/255 - mean)/std), i.e. the ToTensor +
+ * Normalize step that follows AddNoise in the reference's eval pipeline
+ * (exprs/exp/imagenet_c_loop_mini/config_vit_base.yaml:85-99).
+ * out_dtype : 0 = fp32, 1 = bf16.   out_layout : 0 = NCHW, 1 = NHWC. */
+int rart_u8_to_normalized(const uint8_t* in, void* out, int n, int h, int w,
+                          int out_dtype, int out_layout, rart_stream_t stream);
+
+/* Fill helpers exposing the library's counter-based generator (used by the parity tests to
+ * replay the native noise field on the host oracle, and by the attack random starts).
+ * stream_id selects an independent sub-stream (0..15). */
+int rart_rng_uniform_u32(uint32_t* out, int n_samples, size_t elems_per_sample,
+                         uint64_t seed, uint64_t sample_offset, int stream_id, rart_stream_t stream);
+int rart_rng_normal_f32(float* out, int n_samples, size_t elems_per_sample,
+                        uint64_t seed, uint64_t sample_offset, int stream_id, rart_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Adversarial step kernels (x, x0, g: fp32, batch-major, n_per_sample elements per sample,
+ * values of x in [0,1] BEFORE normalisation, as in the reference).
+ * ------------------------------------------------------------------------------------- */
+
+/* Workspace size (bytes) that satisfies every attack entry point below for `batch` samples. */
+size_t rart_attack_workspace_bytes(int batch);
+
+/* x = clip(x0 + U(-eps, eps), lo, hi).  foolbox LinfPGD random start (adv/attack.py:20-23);
+ * with clip_lo > clip_hi the clip is skipped = MIM start (Attacks/imfgsm_attack.py:73-74).
+ * injected_u: NULL or fp32 U(-eps,eps) draws shaped like x. */
+int rart_attack_init_linf(float* x, const float* x0, int batch, size_t n_per_sample, float eps,
+                          float clip_lo, float clip_hi, uint64_t seed, uint64_t sample_offset,
+                          const float* injected_u, rart_stream_t stream);
+
+/* x <- clip(x0 + clip(x + alpha*sign(g) - x0, -eps, eps), 0, 1): one fused PGD-Linf / FGSM step
+ * (foolbox BaseGradientDescent.run, adv/attack.py:20-23,30-33). */
+int rart_pgd_step_linf(float* x, const float* g, const float* x0, size_t n_elems,
+                       float eps, float alpha, rart_stream_t stream);
+
+/* PGD-L2 step (adv/attack.py:25-28): x += alpha*g/max(|g|_2,1e-12); delta *= min(1, eps/max(|delta|_2,1e-12));
+ * clip [0,1].  workspace: rart_attack_workspace_bytes(batch). */
+int rart_pgd_step_l2(float* x, const float* g, const float* x0, int batch, size_t n_per_sample,
+                     float eps, float alpha, void* workspace, size_t workspace_bytes, rart_stream_t stream);
+
+/* MIM step (Attacks/imfgsm_attack.py:85-90): g/=mean|g| per sample; m = decay*m + g;
+ * x = clip(x0 + clip(x + step*sign(m) - x0, +-eps), 0, 1).  workspace: rart_attack_workspace_bytes(batch). */
+int rart_mim_step(float* x, float* momentum, const float* g, const float* x0, int batch,
+                  size_t n_per_sample, float eps, float step_size, float decay,
+                  void* workspace, size_t workspace_bytes, rart_stream_t stream);
+
+/* APGD random start (Attacks/autoattack/autopgd_base.py:213-220,237):
+ * x = clip(x0 + eps * t / (max|t| + 1e-12), 0, 1) for Linf, t ~ U(-1,1);
+ * x = clip(x0 + eps * t / (|t|_2 + 1e-12), 0, 1) for L2, t ~ N(0,1).
+ * norm: 0 = Linf, 1 = L2.  injected_t: NULL or the fp32 draws.  workspace: rart_attack_workspace_bytes(batch). */
+int rart_apgd_init(float* x, const float* x0, int batch, size_t n_per_sample, int norm, float eps,
+                   uint64_t seed, uint64_t sample_offset, const float* injected_t,
+                   void* workspace, size_t workspace_bytes, rart_stream_t stream);
+
+/* APGD step with momentum and double projection (autopgd_base.py:327-348).
+ * x_adv (in/out), x_adv_old (in/out: receives the pre-step x_adv), grad, x0; step_size: per-sample
+ * fp32[batch]; a = 1.0 on the first iteration, 0.75 afterwards.  norm: 0 = Linf, 1 = L2.
+ * workspace: rart_attack_workspace_bytes(batch) (L2 only). */
+int rart_apgd_step(float* x_adv, float* x_adv_old, const float* grad, const float* x0,
+                   const float* step_size, int batch, size_t n_per_sample, int norm, float eps, float a,
+                   void* workspace, size_t workspace_bytes, rart_stream_t stream);
+
+/* Per-sample select: dst[i] = src[i] where mask[i] != 0 (rows of n_per_sample floats).
+ * The x_best / x_best_adv / grad_best bookkeeping of autopgd_base.py:389-406,426-427. */
+int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batch, size_t n_per_sample,
+                     rart_stream_t stream);
+
+/* Row-wise losses on logits [batch][classes] fp32 (autopgd_base.py:198-204,599-604; CE of
+ * foolbox / imfgsm_attack.py:83).  kind: 0 = CE, 1 = DLR, 2 = targeted DLR (y_target required).
+ * loss_out[batch] (nullable), dlogits_out[batch][classes] = d(sum_i loss_i * scale)/dlogits (nullable),
+ * pred_out[batch] int32 argmax (nullable). */
+int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* y_target, int batch, int classes,
+                    int kind, float scale, float* loss_out, float* dlogits_out, int32_t* pred_out,
+                    rart_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBUSTART_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of librobustart_hip.so (the C-ABI in include/robustart_hip.h).
+
+PyTorch is used only as plumbing: device memory (tensor.data_ptr()), the current HIP stream
+and torch.distributed.  Fails loudly when the shared library is absent -- never falls back.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'librobustart_hip.so')
+
+c_void_p, c_int, c_size_t, c_u64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
+                                              ctypes.c_uint64, ctypes.c_float)
+
+# name -> (restype, argtypes); every symbol include/robustart_hip.h declares
+SIGNATURES = {
+    'rart_version': (c_int, []),
+    'rart_last_error_string': (ctypes.c_char_p, []),
+    'rart_corruption_name': (ctypes.c_char_p, [c_int]),
+    'rart_corrupt_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'rart_corrupt_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_u64, c_u64,
+                                ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
+    'rart_u8_to_normalized': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_rng_uniform_u32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),
+    'rart_rng_normal_f32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),
+    'rart_attack_workspace_bytes': (c_size_t, [c_int]),
+    'rart_attack_init_linf': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, c_float, c_float,
+                                      c_u64, c_u64, c_void_p, c_void_p]),
+    'rart_pgd_step_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
+    'rart_pgd_step_l2': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
+                                 c_void_p, c_size_t, c_void_p]),
+    'rart_mim_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
+                              c_float, c_void_p, c_size_t, c_void_p]),
+    'rart_apgd_init': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_int, c_float, c_u64, c_u64,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rart_apgd_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int,
+                               c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    'rart_select_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'rart_logit_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class RartError(RuntimeError):
+    """A C-ABI call returned a non-zero rart_status."""
+
+    def __init__(self, status, message):
+        super().__init__('robustart_hip status %d: %s' % (status, message))
+        self.status = status
+
+
+def load():
+    """Load the shared library and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'robustart_amd: %s is missing -- build it with `python robustart_amd/csrc/build.py` '
+            '(or __graft_entry__.build()).  There is no CPU fallback for the product path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise RartError(status, load().rart_last_error_string().decode('utf-8', 'replace'))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('robustart_amd: no GPU visible (torch.cuda.is_available() is False); '
+                           'the HIP hot path has no CPU fallback')
+    return torch
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """A cached, grow-only scratch buffer per device (torch's allocator owns the memory)."""
+    import torch
+    if nbytes <= 0:
+        return None
+    key = str(device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

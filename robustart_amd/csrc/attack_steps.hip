@@ -1,0 +1,552 @@
+// Adversarial step kernels for gfx950: PGD-Linf / FGSM, PGD-L2, MIM, APGD (Linf, L2),
+// random starts, per-sample row selection and the row-wise logit losses.
+// Reference: RobustART/noise/utils/adv/attack.py:20-42,
+//            RobustART/noise/utils/adv/Attacks/imfgsm_attack.py:62-93,
+//            RobustART/noise/utils/adv/Attacks/autoattack/autopgd_base.py:167-448,599-604.
+//
+// Every kernel is HBM-bound elementwise work (16 B/element for a PGD step); per-sample norms
+// use a deterministic two-level reduction: RCH partial sums per sample written to the caller's
+// workspace, re-summed in fixed order by the consuming kernel (no float atomics, so results
+// do not depend on scheduling).  FMA contraction is off so each kernel reproduces the
+// op-by-op fp32 rounding of the reference's unfused torch expressions.
+#include "rart_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int RCH = 32;  // reduction chunks per sample
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float signf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float u01(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = rart_wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
+  }
+  __syncthreads();
+  return t;  // valid on thread 0
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = rart_wave_max(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) {
+    t = sh[0];
+    for (int i = 1; i < kBlock / 64; ++i) t = fmaxf(t, sh[i]);
+  }
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ float sum_partials(const float* part) {
+  float t = 0.f;
+  for (int i = 0; i < RCH; ++i) t += part[i];
+  return t;
+}
+__device__ __forceinline__ float max_partials(const float* part) {
+  float t = part[0];
+  for (int i = 1; i < RCH; ++i) t = fmaxf(t, part[i]);
+  return t;
+}
+
+// chunk geometry: grid = (RCH, batch); chunk c of sample b covers [c*len, min((c+1)*len, n))
+struct Chunk {
+  size_t begin, end;
+};
+__device__ __forceinline__ Chunk chunk_of(size_t n) {
+  const size_t len = (n + RCH - 1) / RCH;
+  Chunk c;
+  c.begin = (size_t)blockIdx.x * len;
+  c.end = c.begin + len < n ? c.begin + len : n;
+  if (c.begin > n) c.begin = n;
+  return c;
+}
+
+// uniform in (-1, 1) for element e of a sample (2 elements per Threefry call)
+__device__ __forceinline__ float native_pm1(uint32_t k0, uint32_t k1, size_t e, uint32_t sample) {
+  const uint2 w = threefry2x32(k0, k1, rart_ctr0((uint32_t)(e >> 1), 1), sample);
+  return 2.0f * u01((e & 1) ? w.y : w.x) - 1.0f;
+}
+__device__ __forceinline__ float native_normal(uint32_t k0, uint32_t k1, size_t e, uint32_t sample) {
+  const float4 z = rart_normal4(k0, k1, (uint32_t)(e >> 2), 2, sample);
+  const int j = (int)(e & 3);
+  return j == 0 ? z.x : (j == 1 ? z.y : (j == 2 ? z.z : z.w));
+}
+
+// ---- random starts -------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_init_linf(float* __restrict__ x, const float* __restrict__ x0,
+                                                      size_t nps, float eps, float lo, float hi, uint32_t k0,
+                                                      uint32_t k1, uint32_t sbase, const float* __restrict__ inj) {
+  const uint32_t b = blockIdx.y;
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const float u = inj ? inj[base + e] : eps * native_pm1(k0, k1, e, sbase + b);
+    float v = x0[base + e] + u;
+    if (lo <= hi) v = clampf(v, lo, hi);
+    x[base + e] = v;
+  }
+}
+
+// APGD start, pass 1: per-sample max|t| (Linf) or sum t^2 (L2) partials
+template <int NORM>
+__global__ __launch_bounds__(kBlock) void k_apgd_init_reduce(float* __restrict__ part, size_t nps, uint32_t k0,
+                                                             uint32_t k1, uint32_t sbase,
+                                                             const float* __restrict__ inj) {
+  __shared__ float sh[kBlock / 64];
+  const uint32_t b = blockIdx.y;
+  const Chunk c = chunk_of(nps);
+  float acc = 0.f;
+  for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
+    const float t = inj ? inj[(size_t)b * nps + e]
+                        : (NORM == 0 ? native_pm1(k0, k1, e, sbase + b) : native_normal(k0, k1, e, sbase + b));
+    acc = NORM == 0 ? fmaxf(acc, fabsf(t)) : acc + t * t;
+  }
+  const float r = NORM == 0 ? block_max(acc, sh) : block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(size_t)b * RCH + blockIdx.x] = r;
+}
+template <int NORM>
+__global__ __launch_bounds__(kBlock) void k_apgd_init_apply(float* __restrict__ x, const float* __restrict__ x0,
+                                                            const float* __restrict__ part, size_t nps, float eps,
+                                                            uint32_t k0, uint32_t k1, uint32_t sbase,
+                                                            const float* __restrict__ inj) {
+  const uint32_t b = blockIdx.y;
+  const float red = NORM == 0 ? max_partials(part + (size_t)b * RCH) : sqrtf(sum_partials(part + (size_t)b * RCH));
+  const float denom = red + 1e-12f;
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const float t = inj ? inj[base + e]
+                        : (NORM == 0 ? native_pm1(k0, k1, e, sbase + b) : native_normal(k0, k1, e, sbase + b));
+    const float tn = t / denom;
+    const float v = x0[base + e] + eps * tn;  // eps * ones_like(x) * normalize(t)
+    x[base + e] = clampf(v, 0.f, 1.f);
+  }
+}
+
+// ---- PGD-Linf / FGSM step: 16 B/element, float4 lanes ----------------------------------
+__global__ __launch_bounds__(kBlock) void k_pgd_linf(float4* __restrict__ x, const float4* __restrict__ g,
+                                                     const float4* __restrict__ x0, size_t nvec, float eps,
+                                                     float alpha) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (size_t)gridDim.x * kBlock) {
+    const float4 xv = x[i], gv = g[i], ov = x0[i];
+    float4 r;
+#define STEP(c)                                              \
+  {                                                          \
+    const float s = alpha * signf(gv.c);                     \
+    const float x1 = xv.c + s;                               \
+    const float d = clampf(x1 - ov.c, -eps, eps);            \
+    r.c = clampf(ov.c + d, 0.f, 1.f);                        \
+  }
+    STEP(x) STEP(y) STEP(z) STEP(w)
+#undef STEP
+    x[i] = r;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_pgd_linf_tail(float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ x0, size_t begin, size_t n,
+                                                          float eps, float alpha) {
+  const size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    const float x1 = x[i] + alpha * signf(g[i]);
+    const float d = clampf(x1 - x0[i], -eps, eps);
+    x[i] = clampf(x0[i] + d, 0.f, 1.f);
+  }
+}
+
+// ---- generic per-sample sum-of-squares / sum-abs partials -----------------------------
+// MODE 0: sum g^2     MODE 1: sum |g|
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_reduce_rows(const float* __restrict__ g, float* __restrict__ part,
+                                                        size_t nps) {
+  __shared__ float sh[kBlock / 64];
+  const uint32_t b = blockIdx.y;
+  const Chunk c = chunk_of(nps);
+  float acc = 0.f;
+  for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
+    const float v = g[(size_t)b * nps + e];
+    acc += MODE == 0 ? v * v : fabsf(v);
+  }
+  const float r = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(size_t)b * RCH + blockIdx.x] = r;
+}
+
+// ---- PGD-L2 (foolbox) ------------------------------------------------------------------
+// pass B: x <- x + alpha * g / max(|g|,1e-12)   and partial sums of (x - x0)^2
+__global__ __launch_bounds__(kBlock) void k_pgd_l2_move(float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ x0,
+                                                        const float* __restrict__ gpart, float* __restrict__ dpart,
+                                                        size_t nps, float alpha) {
+  __shared__ float sh[kBlock / 64];
+  const uint32_t b = blockIdx.y;
+  const float gn = fmaxf(sqrtf(sum_partials(gpart + (size_t)b * RCH)), 1e-12f);
+  const Chunk c = chunk_of(nps);
+  float acc = 0.f;
+  for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
+    const size_t i = (size_t)b * nps + e;
+    const float gg = g[i] / gn;
+    const float x1 = x[i] + alpha * gg;
+    x[i] = x1;
+    const float d = x1 - x0[i];
+    acc += d * d;
+  }
+  const float r = block_sum(acc, sh);
+  if (threadIdx.x == 0) dpart[(size_t)b * RCH + blockIdx.x] = r;
+}
+__global__ __launch_bounds__(kBlock) void k_pgd_l2_project(float* __restrict__ x, const float* __restrict__ x0,
+                                                           const float* __restrict__ dpart, size_t nps, float eps) {
+  const uint32_t b = blockIdx.y;
+  const float dn = fmaxf(sqrtf(sum_partials(dpart + (size_t)b * RCH)), 1e-12f);
+  const float factor = fminf(eps / dn, 1.0f);
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const float d = x[base + e] - x0[base + e];
+    x[base + e] = clampf(x0[base + e] + d * factor, 0.f, 1.f);
+  }
+}
+
+// ---- MIM -------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_mim_apply(float* __restrict__ x, float* __restrict__ m,
+                                                      const float* __restrict__ g, const float* __restrict__ x0,
+                                                      const float* __restrict__ part, size_t nps, float eps,
+                                                      float step, float decay) {
+  const uint32_t b = blockIdx.y;
+  const float mean_abs = sum_partials(part + (size_t)b * RCH) / (float)nps;
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const size_t i = base + e;
+    const float gn = g[i] / mean_abs;
+    const float mm = decay * m[i] + gn;
+    m[i] = mm;
+    const float x1 = x[i] + step * signf(mm);
+    const float eta = clampf(x1 - x0[i], -eps, eps);
+    x[i] = clampf(x0[i] + eta, 0.f, 1.f);
+  }
+}
+
+// ---- APGD step -------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_apgd_linf(float* __restrict__ xa, float* __restrict__ xold,
+                                                      const float* __restrict__ grad, const float* __restrict__ x0,
+                                                      const float* __restrict__ step, size_t nps, float eps, float a) {
+  const uint32_t b = blockIdx.y;
+  const float ss = step[b];
+  const float oma = 1.0f - a;
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const size_t i = base + e;
+    const float xv = xa[i], xo = xold[i], x = x0[i];
+    const float grad2 = xv - xo;
+    float x1 = xv + ss * signf(grad[i]);
+    x1 = clampf(fminf(fmaxf(x1, x - eps), x + eps), 0.f, 1.f);
+    const float t1 = (x1 - xv) * a;
+    const float t2 = grad2 * oma;
+    float x2 = (xv + t1) + t2;
+    x2 = clampf(fminf(fmaxf(x2, x - eps), x + eps), 0.f, 1.f);
+    xold[i] = xv;
+    xa[i] = x2;
+  }
+}
+
+// L2 variant, 4 passes.  STAGE 0: partial |x1' - x|^2 ; STAGE 1: partial |x2' - x|^2 ; STAGE 2: apply.
+__device__ __forceinline__ float apgd_l2_x1(float xv, float g, float x, float ss, float gnorm, float n1, float eps) {
+  // x_adv_1 = clamp(x + normalize(x1' - x) * min(eps, |x1' - x|), 0, 1), x1' = x_adv + step*g/(|g|+1e-12)
+  const float x1p = xv + ss * (g / (gnorm + 1e-12f));
+  const float d = x1p - x;
+  return clampf(x + (d / (n1 + 1e-12f)) * fminf(eps, n1), 0.f, 1.f);
+}
+template <int STAGE>
+__global__ __launch_bounds__(kBlock) void k_apgd_l2(float* __restrict__ xa, float* __restrict__ xold,
+                                                    const float* __restrict__ grad, const float* __restrict__ x0,
+                                                    const float* __restrict__ step, float* __restrict__ ws,
+                                                    int batch, size_t nps, float eps, float a) {
+  __shared__ float sh[kBlock / 64];
+  const uint32_t b = blockIdx.y;
+  const float ss = step[b];
+  const float* gpart = ws;
+  float* n1part = ws + (size_t)batch * RCH;
+  float* n2part = ws + (size_t)2 * batch * RCH;
+  const float gnorm = sqrtf(sum_partials(gpart + (size_t)b * RCH));
+  const float n1 = STAGE >= 1 ? sqrtf(sum_partials(n1part + (size_t)b * RCH)) : 0.f;
+  const float n2 = STAGE >= 2 ? sqrtf(sum_partials(n2part + (size_t)b * RCH)) : 0.f;
+  const float oma = 1.0f - a;
+  const Chunk c = chunk_of(nps);
+  float acc = 0.f;
+  for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
+    const size_t i = (size_t)b * nps + e;
+    const float xv = xa[i], x = x0[i], g = grad[i];
+    if (STAGE == 0) {
+      const float x1p = xv + ss * (g / (gnorm + 1e-12f));
+      const float d = x1p - x;
+      acc += d * d;
+    } else {
+      const float x1 = apgd_l2_x1(xv, g, x, ss, gnorm, n1, eps);
+      const float grad2 = xv - xold[i];
+      const float x2p = (xv + (x1 - xv) * a) + grad2 * oma;
+      const float d = x2p - x;
+      if (STAGE == 1) {
+        acc += d * d;
+      } else {
+        xold[i] = xv;
+        xa[i] = clampf(x + (d / (n2 + 1e-12f)) * fminf(eps, n2), 0.f, 1.f);
+      }
+    }
+  }
+  if (STAGE < 2) {
+    const float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) (STAGE == 0 ? n1part : n2part)[(size_t)b * RCH + blockIdx.x] = r;
+  }
+}
+
+// ---- per-sample masked row copy ----------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_select_rows(float* __restrict__ dst, const float* __restrict__ src,
+                                                        const uint8_t* __restrict__ mask, size_t nps) {
+  const uint32_t b = blockIdx.y;
+  if (!mask[b]) return;
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock)
+    dst[base + e] = src[base + e];
+}
+
+// ---- row-wise logit losses: one wave per row ------------------------------------------------
+struct Top {
+  float v;
+  int i;
+};
+__device__ __forceinline__ Top wave_argmax(Top t) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(t.v, off, 64);
+    const int oi = __shfl_xor(t.i, off, 64);
+    if (ov > t.v || (ov == t.v && oi < t.i)) {
+      t.v = ov;
+      t.i = oi;
+    }
+  }
+  return t;
+}
+
+// kind 0 CE, 1 DLR, 2 targeted DLR
+__global__ __launch_bounds__(kBlock) void k_logit_loss(const float* __restrict__ logits, const int64_t* __restrict__ y,
+                                                       const int64_t* __restrict__ yt, int batch, int classes,
+                                                       int kind, float scale, float* __restrict__ loss_out,
+                                                       float* __restrict__ dl, int32_t* __restrict__ pred_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= batch) return;
+  const float* z = logits + (size_t)row * classes;
+  const int yy = (int)y[row];
+  // top-4 of the row by repeated wave argmax with exclusion (classes ~1000: 4 cheap passes)
+  Top top[4];
+  int excl[4] = {-1, -1, -1, -1};
+  for (int r = 0; r < 4; ++r) {
+    Top best{-INFINITY, 0x7fffffff};
+    for (int c = lane; c < classes; c += 64) {
+      if (c == excl[0] || c == excl[1] || c == excl[2]) continue;
+      const float v = z[c];
+      if (v > best.v || (v == best.v && c < best.i)) {
+        best.v = v;
+        best.i = c;
+      }
+    }
+    best = wave_argmax(best);
+    top[r] = best;
+    excl[r] = best.i;
+    if (kind == 0) break;               // CE only needs the max
+    if (kind == 1 && r == 2) break;     // DLR needs top-3
+  }
+  if (pred_out && lane == 0) pred_out[row] = top[0].i;
+  const float zy = z[yy];
+  if (kind == 0) {
+    const float mx = top[0].v;
+    float s = 0.f;
+    for (int c = lane; c < classes; c += 64) s += expf(z[c] - mx);
+    s = rart_wave_sum(s);
+    const float lse = logf(s) + mx;
+    if (loss_out && lane == 0) loss_out[row] = lse - zy;
+    if (dl) {
+      for (int c = lane; c < classes; c += 64) {
+        const float p = expf(z[c] - lse);
+        dl[(size_t)row * classes + c] = scale * (p - (c == yy ? 1.f : 0.f));
+      }
+    }
+    return;
+  }
+  float N, D, loss;
+  // gradient contributions as (index, weight) pairs, applied additively
+  int gi[5];
+  float gw[5];
+  int ng = 0;
+  if (kind == 1) {
+    const bool ind = top[0].i == yy;
+    const float other = ind ? top[1].v : top[0].v;
+    N = zy - other;
+    D = top[0].v - top[2].v + 1e-12f;
+    loss = -N / D;
+    gi[ng] = yy; gw[ng++] = -1.f / D;
+    gi[ng] = ind ? top[1].i : top[0].i; gw[ng++] = 1.f / D;
+    gi[ng] = top[0].i; gw[ng++] = N / (D * D);
+    gi[ng] = top[2].i; gw[ng++] = -N / (D * D);
+  } else {
+    const int tt = (int)yt[row];
+    N = zy - z[tt];
+    D = top[0].v - 0.5f * (top[2].v + top[3].v) + 1e-12f;
+    loss = -N / D;
+    gi[ng] = yy; gw[ng++] = -1.f / D;
+    gi[ng] = tt; gw[ng++] = 1.f / D;
+    gi[ng] = top[0].i; gw[ng++] = N / (D * D);
+    gi[ng] = top[2].i; gw[ng++] = -0.5f * N / (D * D);
+    gi[ng] = top[3].i; gw[ng++] = -0.5f * N / (D * D);
+  }
+  if (loss_out && lane == 0) loss_out[row] = loss;
+  if (dl) {
+    for (int c = lane; c < classes; c += 64) {
+      float w = 0.f;
+      for (int k = 0; k < ng; ++k)
+        if (gi[k] == c) w += gw[k];
+      dl[(size_t)row * classes + c] = scale * w;
+    }
+  }
+}
+
+dim3 grid_rows(size_t nps, int batch) {
+  size_t gx = (nps + kBlock - 1) / kBlock;
+  size_t cap = 4096 / (batch < 1 ? 1 : batch);
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  return dim3((uint32_t)gx, (uint32_t)batch, 1);
+}
+
+int need_ws(const char* who, void* ws, size_t have, size_t floats) {
+  if (!ws || have < floats * sizeof(float)) {
+    rart_set_error("%s: workspace of %zu bytes required, got %zu", who, floats * sizeof(float), have);
+    return RART_ERR_WORKSPACE;
+  }
+  return RART_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t rart_attack_workspace_bytes(int batch) { return (size_t)(batch < 1 ? 1 : batch) * RCH * 4 * sizeof(float); }
+
+int rart_attack_init_linf(float* x, const float* x0, int batch, size_t nps, float eps, float lo, float hi,
+                          uint64_t seed, uint64_t sample_offset, const float* injected_u, rart_stream_t stream) {
+  RART_CHECK_ARG(x && x0 && batch > 0 && nps > 0 && nps < (1ull << 29), "rart_attack_init_linf: bad arguments");
+  hipLaunchKernelGGL(k_init_linf, grid_rows(nps, batch), dim3(kBlock), 0, (hipStream_t)stream, x, x0, nps, eps, lo,
+                     hi, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset, injected_u);
+  RART_CHECK_LAUNCH("rart_attack_init_linf");
+  return RART_OK;
+}
+
+int rart_pgd_step_linf(float* x, const float* g, const float* x0, size_t n, float eps, float alpha,
+                       rart_stream_t stream) {
+  RART_CHECK_ARG(x && g && x0, "rart_pgd_step_linf: null pointer");
+  if (n == 0) return RART_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool al = (((uintptr_t)x | (uintptr_t)g | (uintptr_t)x0) & 15) == 0;
+  const size_t nvec = al ? n / 4 : 0;
+  if (nvec)
+    hipLaunchKernelGGL(k_pgd_linf, dim3(rart_grid_for(nvec)), dim3(kBlock), 0, s, (float4*)x, (const float4*)g,
+                       (const float4*)x0, nvec, eps, alpha);
+  const size_t rest = n - nvec * 4;
+  if (rest)
+    hipLaunchKernelGGL(k_pgd_linf_tail, dim3((uint32_t)((rest + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, x, g, x0,
+                       nvec * 4, n, eps, alpha);
+  RART_CHECK_LAUNCH("rart_pgd_step_linf");
+  return RART_OK;
+}
+
+int rart_pgd_step_l2(float* x, const float* g, const float* x0, int batch, size_t nps, float eps, float alpha,
+                     void* ws, size_t ws_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(x && g && x0 && batch > 0 && nps > 0, "rart_pgd_step_l2: bad arguments");
+  if (int e = need_ws("rart_pgd_step_l2", ws, ws_bytes, (size_t)batch * RCH * 2)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  float* gpart = (float*)ws;
+  float* dpart = gpart + (size_t)batch * RCH;
+  hipLaunchKernelGGL(k_reduce_rows<0>, dim3(RCH, batch), dim3(kBlock), 0, s, g, gpart, nps);
+  hipLaunchKernelGGL(k_pgd_l2_move, dim3(RCH, batch), dim3(kBlock), 0, s, x, g, x0, gpart, dpart, nps, alpha);
+  hipLaunchKernelGGL(k_pgd_l2_project, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, dpart, nps, eps);
+  RART_CHECK_LAUNCH("rart_pgd_step_l2");
+  return RART_OK;
+}
+
+int rart_mim_step(float* x, float* m, const float* g, const float* x0, int batch, size_t nps, float eps,
+                  float step, float decay, void* ws, size_t ws_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(x && m && g && x0 && batch > 0 && nps > 0, "rart_mim_step: bad arguments");
+  if (int e = need_ws("rart_mim_step", ws, ws_bytes, (size_t)batch * RCH)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_reduce_rows<1>, dim3(RCH, batch), dim3(kBlock), 0, s, g, (float*)ws, nps);
+  hipLaunchKernelGGL(k_mim_apply, grid_rows(nps, batch), dim3(kBlock), 0, s, x, m, g, x0, (const float*)ws, nps,
+                     eps, step, decay);
+  RART_CHECK_LAUNCH("rart_mim_step");
+  return RART_OK;
+}
+
+int rart_apgd_init(float* x, const float* x0, int batch, size_t nps, int norm, float eps, uint64_t seed,
+                   uint64_t sample_offset, const float* inj, void* ws, size_t ws_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(x && x0 && batch > 0 && nps > 0 && nps < (1ull << 29), "rart_apgd_init: bad arguments");
+  RART_CHECK_ARG(norm == 0 || norm == 1, "rart_apgd_init: norm must be 0 (Linf) or 1 (L2)");
+  if (int e = need_ws("rart_apgd_init", ws, ws_bytes, (size_t)batch * RCH)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), sb = (uint32_t)sample_offset;
+  float* part = (float*)ws;
+  if (norm == 0) {
+    hipLaunchKernelGGL(k_apgd_init_reduce<0>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj);
+    hipLaunchKernelGGL(k_apgd_init_apply<0>, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, part, nps, eps, k0,
+                       k1, sb, inj);
+  } else {
+    hipLaunchKernelGGL(k_apgd_init_reduce<1>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj);
+    hipLaunchKernelGGL(k_apgd_init_apply<1>, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, part, nps, eps, k0,
+                       k1, sb, inj);
+  }
+  RART_CHECK_LAUNCH("rart_apgd_init");
+  return RART_OK;
+}
+
+int rart_apgd_step(float* xa, float* xold, const float* grad, const float* x0, const float* step, int batch,
+                   size_t nps, int norm, float eps, float a, void* ws, size_t ws_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(xa && xold && grad && x0 && step && batch > 0 && nps > 0, "rart_apgd_step: bad arguments");
+  RART_CHECK_ARG(norm == 0 || norm == 1, "rart_apgd_step: norm must be 0 (Linf) or 1 (L2)");
+  hipStream_t s = (hipStream_t)stream;
+  if (norm == 0) {
+    hipLaunchKernelGGL(k_apgd_linf, grid_rows(nps, batch), dim3(kBlock), 0, s, xa, xold, grad, x0, step, nps, eps, a);
+  } else {
+    if (int e = need_ws("rart_apgd_step", ws, ws_bytes, (size_t)batch * RCH * 3)) return e;
+    float* w = (float*)ws;
+    hipLaunchKernelGGL(k_reduce_rows<0>, dim3(RCH, batch), dim3(kBlock), 0, s, grad, w, nps);
+    hipLaunchKernelGGL(k_apgd_l2<0>, dim3(RCH, batch), dim3(kBlock), 0, s, xa, xold, grad, x0, step, w, batch, nps, eps, a);
+    hipLaunchKernelGGL(k_apgd_l2<1>, dim3(RCH, batch), dim3(kBlock), 0, s, xa, xold, grad, x0, step, w, batch, nps, eps, a);
+    hipLaunchKernelGGL(k_apgd_l2<2>, dim3(RCH, batch), dim3(kBlock), 0, s, xa, xold, grad, x0, step, w, batch, nps, eps, a);
+  }
+  RART_CHECK_LAUNCH("rart_apgd_step");
+  return RART_OK;
+}
+
+int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batch, size_t nps, rart_stream_t stream) {
+  RART_CHECK_ARG(dst && src && mask && batch > 0 && nps > 0, "rart_select_rows: bad arguments");
+  hipLaunchKernelGGL(k_select_rows, grid_rows(nps, batch), dim3(kBlock), 0, (hipStream_t)stream, dst, src, mask, nps);
+  RART_CHECK_LAUNCH("rart_select_rows");
+  return RART_OK;
+}
+
+int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* yt, int batch, int classes, int kind,
+                    float scale, float* loss_out, float* dl, int32_t* pred_out, rart_stream_t stream) {
+  RART_CHECK_ARG(logits && y && batch > 0 && classes > 0, "rart_logit_loss: bad arguments");
+  RART_CHECK_ARG(kind >= 0 && kind <= 2, "rart_logit_loss: kind must be 0 (CE), 1 (DLR), 2 (targeted DLR)");
+  RART_CHECK_ARG(kind != 2 || yt != nullptr, "rart_logit_loss: targeted DLR needs y_target");
+  RART_CHECK_ARG(kind == 0 || classes >= (kind == 1 ? 3 : 4), "rart_logit_loss: too few classes for DLR");
+  const int rows_per_block = kBlock / 64;
+  hipLaunchKernelGGL(k_logit_loss, dim3((batch + rows_per_block - 1) / rows_per_block), dim3(kBlock), 0,
+                     (hipStream_t)stream, logits, y, yt, batch, classes, kind, scale, loss_out, dl, pred_out);
+  RART_CHECK_LAUNCH("rart_logit_loss");
+  return RART_OK;
+}
+
+}  // extern "C"

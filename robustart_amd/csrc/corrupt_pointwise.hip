@@ -1,0 +1,514 @@
+// Pointwise ImageNet-C corruptions for gfx950: gaussian / speckle / shot / impulse noise,
+// contrast, brightness, saturate, frost blend.
+// Reference: RobustART/noise/utils/imagenet_c/corruptions.py:122-147,244-262,345-372.
+//
+// Two paths per noise corruption:
+//  * native  : counter-based Threefry draws generated in-kernel, fp32 arithmetic in 0..255
+//              scale, 16-byte coalesced loads/stores (HBM-roofline path);
+//  * injected: the caller supplies what np.random returned; arithmetic follows the
+//              reference's fp64 operation order exactly (bit-exact parity path).
+#include "rart_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// =====================================================================================
+// native noise kernels (fp32, 16 B per lane)
+// =====================================================================================
+
+__device__ __forceinline__ uint32_t pack4_trunc(float a, float b, float c, float d) {
+  // inputs already clamped to [0,255]; (unsigned) cast truncates toward zero like np.uint8()
+  return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+
+__device__ __forceinline__ float clamp255(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f); }
+
+// KIND 0: gaussian_noise  y = clip(x + 255*c*z)          (corruptions.py:122-126)
+// KIND 1: speckle_noise   y = clip(x + x*c*z)            (corruptions.py:143-147)
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_normal_noise_native(
+    const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t vec_per_sample, float c,
+    uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  const uint32_t sample = blockIdx.y;
+  const uint4* src = in + (size_t)sample * vec_per_sample;
+  uint4* dst = out + (size_t)sample * vec_per_sample;
+  const uint32_t gsample = sample_base + sample;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < vec_per_sample; v += gridDim.x * kBlock) {
+    const uint4 p = src[v];
+    const uint32_t wi[4] = {p.x, p.y, p.z, p.w};
+    uint32_t wo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 z = rart_normal4(k0, k1, v * 4u + j, 0, gsample);
+      const float x0 = (float)(wi[j] & 0xFFu), x1 = (float)((wi[j] >> 8) & 0xFFu);
+      const float x2 = (float)((wi[j] >> 16) & 0xFFu), x3 = (float)(wi[j] >> 24);
+      float y0, y1, y2, y3;
+      if (KIND == 0) {
+        const float s = 255.0f * c;
+        y0 = fmaf(s, z.x, x0); y1 = fmaf(s, z.y, x1); y2 = fmaf(s, z.z, x2); y3 = fmaf(s, z.w, x3);
+      } else {
+        y0 = fmaf(x0 * c, z.x, x0); y1 = fmaf(x1 * c, z.y, x1);
+        y2 = fmaf(x2 * c, z.z, x2); y3 = fmaf(x3 * c, z.w, x3);
+      }
+      wo[j] = pack4_trunc(clamp255(y0), clamp255(y1), clamp255(y2), clamp255(y3));
+    }
+    dst[v] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+  }
+}
+
+// scalar tail / odd-size path: one quad (4 elements) per thread, byte accesses
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_normal_noise_native_scalar(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t elems_per_sample,
+    uint32_t first_quad, float c, uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  const uint32_t sample = blockIdx.y;
+  const uint8_t* src = in + (size_t)sample * elems_per_sample;
+  uint8_t* dst = out + (size_t)sample * elems_per_sample;
+  const uint32_t nquad = (elems_per_sample + 3) / 4;
+  for (uint32_t q = first_quad + blockIdx.x * kBlock + threadIdx.x; q < nquad; q += gridDim.x * kBlock) {
+    const float4 z = rart_normal4(k0, k1, q, 0, sample_base + sample);
+    const float zz[4] = {z.x, z.y, z.z, z.w};
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t e = q * 4 + j;
+      if (e < elems_per_sample) {
+        const float x = (float)src[e];
+        const float y = KIND == 0 ? fmaf(255.0f * c, zz[j], x) : fmaf(x * c, zz[j], x);
+        dst[e] = (uint8_t)(uint32_t)clamp255(y);
+      }
+    }
+  }
+}
+
+// impulse_noise (corruptions.py:136-140 -> skimage random_noise 's&p'): each element flips with
+// probability `amount` (24-bit threshold compare on the raw word), salt/pepper by one more bit.
+// One Threefry call (2 words) serves 2 elements: word>>8 = flip uniform, bit 0 = salt.
+__global__ __launch_bounds__(kBlock) void k_impulse_native(
+    const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t vec_per_sample, uint32_t thresh24,
+    uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  const uint32_t sample = blockIdx.y;
+  const uint4* src = in + (size_t)sample * vec_per_sample;
+  uint4* dst = out + (size_t)sample * vec_per_sample;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < vec_per_sample; v += gridDim.x * kBlock) {
+    const uint4 p = src[v];
+    uint32_t wi[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // pair index within the sample: element e = v*16 + j*4 + h*2 (+0, +1)
+        const uint2 w = threefry2x32(k0, k1, rart_ctr0(v * 8u + j * 2u + h, 0), sample_base + sample);
+        const uint32_t ww[2] = {w.x, w.y};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int sh = (h * 2 + t) * 8;
+          if ((ww[t] >> 8) < thresh24) {
+            const uint32_t val = (ww[t] & 1u) ? 0xFFu : 0u;
+            wi[j] = (wi[j] & ~(0xFFu << sh)) | (val << sh);
+          }
+        }
+      }
+    }
+    dst[v] = make_uint4(wi[0], wi[1], wi[2], wi[3]);
+  }
+}
+
+// shot_noise (corruptions.py:129-133): k ~ Poisson(x/255*c); y = clip(k/c, 0, 1)*255.
+// lambda takes only 256 values (one per input byte), so each workgroup builds per-lambda
+// constants in LDS.  lambda < 10: inversion by sequential search; otherwise Hormann's PTRS
+// transformed rejection (the same split numpy's legacy generator uses).
+struct PoissonEntry {
+  float lam, explam, loglam, b, a, invalpha, vr, pad;
+};
+
+__global__ __launch_bounds__(kBlock) void k_shot_native(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t elems_per_sample, float c,
+    uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  __shared__ PoissonEntry tab[256];
+  __shared__ float logfact[256];
+  {
+    const int t = threadIdx.x;
+    const float lam = (float)t / 255.0f * c;
+    PoissonEntry e;
+    e.lam = lam;
+    e.explam = expf(-lam);
+    e.loglam = logf(fmaxf(lam, 1e-30f));
+    const float slam = sqrtf(lam);
+    e.b = 0.931f + 2.53f * slam;
+    e.a = -0.059f + 0.02483f * e.b;
+    e.invalpha = 1.1239f + 1.1328f / (e.b - 3.4f);
+    e.vr = 0.9277f - 3.6224f / (e.b - 2.0f);
+    e.pad = 0.f;
+    tab[t] = e;
+    logfact[t] = lgammaf((float)t + 1.0f);
+  }
+  __syncthreads();
+  const uint32_t sample = blockIdx.y;
+  const uint8_t* src = in + (size_t)sample * elems_per_sample;
+  uint8_t* dst = out + (size_t)sample * elems_per_sample;
+  const float inv_c255 = 255.0f / c;
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < elems_per_sample; e += gridDim.x * kBlock) {
+    const uint32_t xb = src[e];
+    const PoissonEntry pe = tab[xb];
+    int k = 0;
+    if (xb != 0) {
+      if (pe.lam < 10.0f) {
+        const uint2 w = threefry2x32(k0, k1, rart_ctr0(e, 0), sample_base + sample);
+        const float uu = ((float)(w.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float p = pe.explam, F = p;
+        // stop once the remaining tail mass is below float resolution (F can stall just under 1)
+        while (uu > F && (p > 1e-10f || (float)k < pe.lam)) {
+          ++k;
+          p *= pe.lam / (float)k;
+          F += p;
+        }
+      } else {
+        bool done = false;
+        for (int attempt = 0; attempt < 16 && !done; ++attempt) {
+          const uint2 w = threefry2x32(k0, k1, rart_ctr0(e, attempt), sample_base + sample);
+          const float U = ((float)(w.x >> 8) + 0.5f) * (1.0f / 16777216.0f) - 0.5f;
+          const float V = ((float)(w.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
+          const float us = 0.5f - fabsf(U);
+          const float kf = floorf((2.0f * pe.a / us + pe.b) * U + pe.lam + 0.43f);
+          k = (int)kf;
+          if (us >= 0.07f && V <= pe.vr) { done = true; break; }
+          if (k < 0 || (us < 0.013f && V > us)) continue;
+          const int kk = k > 255 ? 255 : k;
+          if (logf(V) + logf(pe.invalpha) - logf(pe.a / (us * us) + pe.b) <=
+              -pe.lam + kf * pe.loglam - logfact[kk]) {
+            done = true;
+          }
+        }
+        if (k < 0) k = 0;
+      }
+    }
+    const float y = fminf((float)k * inv_c255, 255.0f);
+    dst[e] = (uint8_t)(uint32_t)y;
+  }
+}
+
+// per-image per-channel integer sums for contrast (corruptions.py:349 np.mean over H,W)
+__global__ __launch_bounds__(kBlock) void k_channel_sums(const uint8_t* __restrict__ in,
+                                                         unsigned long long* __restrict__ sums,
+                                                         uint32_t pixels_per_sample) {
+  const uint32_t sample = blockIdx.y;
+  const uint8_t* src = in + (size_t)sample * pixels_per_sample * 3;
+  uint32_t s0 = 0, s1 = 0, s2 = 0;
+  const uint32_t nquad = pixels_per_sample / 4;  // 4 pixels = 12 bytes = 3 dwords
+  const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
+  const bool aligned = ((pixels_per_sample * 3) % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 3) == 0);
+  if (aligned) {
+    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < nquad; q += gridDim.x * kBlock) {
+      const uint32_t a = src32[q * 3], b = src32[q * 3 + 1], c = src32[q * 3 + 2];
+      // bytes: a = r0 g0 b0 r1 | b = g1 b1 r2 g2 | c = b2 r3 g3 b3
+      s0 += (a & 0xFF) + (a >> 24) + ((b >> 16) & 0xFF) + ((c >> 8) & 0xFF);
+      s1 += ((a >> 8) & 0xFF) + (b & 0xFF) + (b >> 24) + ((c >> 16) & 0xFF);
+      s2 += ((a >> 16) & 0xFF) + ((b >> 8) & 0xFF) + (c & 0xFF) + (c >> 24);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      for (uint32_t p = nquad * 4; p < pixels_per_sample; ++p) {
+        s0 += src[p * 3]; s1 += src[p * 3 + 1]; s2 += src[p * 3 + 2];
+      }
+    }
+  } else {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < pixels_per_sample; p += gridDim.x * kBlock) {
+      s0 += src[p * 3]; s1 += src[p * 3 + 1]; s2 += src[p * 3 + 2];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_xor(s0, off, 64);
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&sums[sample * 3 + 0], (unsigned long long)s0);
+    atomicAdd(&sums[sample * 3 + 1], (unsigned long long)s1);
+    atomicAdd(&sums[sample * 3 + 2], (unsigned long long)s2);
+  }
+}
+
+}  // namespace
+
+// =====================================================================================
+// fp64 parity kernels: follow the reference's operation order, no FMA contraction
+// =====================================================================================
+#pragma clang fp contract(off)
+namespace {
+
+__device__ __forceinline__ uint8_t finish_unit(double v) {
+  // np.clip(v, 0, 1) * 255 -> np.uint8 (truncation)
+  v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+  return (uint8_t)(uint32_t)(v * 255.0);
+}
+
+// KIND 0 gaussian, 1 speckle; noise = what np.random.normal(scale=c) returned
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_normal_noise_injected(const uint8_t* __restrict__ in,
+                                                                  uint8_t* __restrict__ out,
+                                                                  const double* __restrict__ noise,
+                                                                  size_t total) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const double x = (double)in[i] / 255.0;
+    const double nz = noise[i];
+    double v;
+    if (KIND == 0) {
+      v = x + nz;
+    } else {
+      const double xn = x * nz;
+      v = x + xn;
+    }
+    out[i] = finish_unit(v);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shot_injected(uint8_t* __restrict__ out,
+                                                          const int32_t* __restrict__ counts, double c,
+                                                          size_t total) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    out[i] = finish_unit((double)counts[i] / c);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_impulse_injected(const uint8_t* __restrict__ in,
+                                                             uint8_t* __restrict__ out,
+                                                             const uint8_t* __restrict__ code, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const uint8_t cd = code[i];
+    // x/255*255 truncated == x for every byte value (checked in tests), salt -> 255, pepper -> 0
+    out[i] = cd == 1 ? 255 : (cd == 2 ? 0 : finish_unit((double)in[i] / 255.0));
+  }
+}
+
+// contrast (corruptions.py:345-350): (x - m)*c + m with m the per-channel mean of x/255
+__global__ __launch_bounds__(kBlock) void k_contrast_apply(const uint8_t* __restrict__ in,
+                                                           uint8_t* __restrict__ out,
+                                                           const unsigned long long* __restrict__ sums,
+                                                           uint32_t pixels_per_sample, double c) {
+  const uint32_t sample = blockIdx.y;
+  const size_t base = (size_t)sample * pixels_per_sample * 3;
+  const double npx = (double)pixels_per_sample;
+  const double m0 = (double)sums[sample * 3 + 0] / 255.0 / npx;
+  const double m1 = (double)sums[sample * 3 + 1] / 255.0 / npx;
+  const double m2 = (double)sums[sample * 3 + 2] / 255.0 / npx;
+  const uint32_t elems = pixels_per_sample * 3;
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < elems; e += gridDim.x * kBlock) {
+    const uint32_t ch = e % 3;
+    const double m = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
+    const double x = (double)in[base + e] / 255.0;
+    const double d = x - m;
+    const double dc = d * c;
+    out[base + e] = finish_unit(dc + m);
+  }
+}
+
+// brightness / saturate (corruptions.py:353-372): skimage rgb2hsv -> edit V or S -> hsv2rgb, fp64.
+// MODE 0: V = clip(V + p0, 0, 1);  MODE 1: S = clip(S*p0 + p1, 0, 1)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_hsv_edit(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                     size_t pixels, double p0, double p1) {
+  for (size_t px = (size_t)blockIdx.x * kBlock + threadIdx.x; px < pixels; px += (size_t)gridDim.x * kBlock) {
+    const double r = (double)in[px * 3] / 255.0, g = (double)in[px * 3 + 1] / 255.0,
+                 b = (double)in[px * 3 + 2] / 255.0;
+    double v = fmax(fmax(r, g), b);
+    const double mn = fmin(fmin(r, g), b);
+    const double delta = v - mn;
+    double s = 0.0, h = 0.0;
+    if (delta != 0.0) {
+      s = delta / v;
+      double hh;
+      if (b == v) {
+        const double t = (r - g) / delta;
+        hh = 4.0 + t;
+      } else if (g == v) {
+        const double t = (b - r) / delta;
+        hh = 2.0 + t;
+      } else {
+        hh = (g - b) / delta;
+      }
+      hh = hh / 6.0;
+      double m = fmod(hh, 1.0);
+      if (m != 0.0 && m < 0.0) m += 1.0;
+      h = m;
+    }
+    if (MODE == 0) {
+      v = v + p0;
+      v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    } else {
+      const double sp = s * p0;
+      s = sp + p1;
+      s = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+    }
+    const double h6 = h * 6.0;
+    const double hi = floor(h6);
+    const double f = h6 - hi;
+    const double one_s = 1.0 - s;
+    const double p = v * one_s;
+    const double fs = f * s;
+    const double q = v * (1.0 - fs);
+    const double omf = 1.0 - f;
+    const double omfs = omf * s;
+    const double t = v * (1.0 - omfs);
+    const int sector = ((int)hi) % 6;
+    double ro, go, bo;
+    switch (sector) {
+      case 0: ro = v; go = t; bo = p; break;
+      case 1: ro = q; go = v; bo = p; break;
+      case 2: ro = p; go = v; bo = t; break;
+      case 3: ro = p; go = q; bo = v; break;
+      case 4: ro = t; go = p; bo = v; break;
+      default: ro = v; go = p; bo = q; break;
+    }
+    out[px * 3] = finish_unit(ro);
+    out[px * 3 + 1] = finish_unit(go);
+    out[px * 3 + 2] = finish_unit(bo);
+  }
+}
+
+// frost (corruptions.py:262): clip(a*x + b*texture, 0, 255) -> uint8
+__global__ __launch_bounds__(kBlock) void k_frost_blend(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        const uint8_t* __restrict__ tex, double a, double b,
+                                                        size_t total) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const double ax = a * (double)in[i];
+    const double bt = b * (double)tex[i];
+    double v = ax + bt;
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    out[i] = (uint8_t)(uint32_t)v;
+  }
+}
+
+}  // namespace
+#pragma clang fp contract(fast)
+
+// =====================================================================================
+// host launchers
+// =====================================================================================
+
+static dim3 grid2d(uint32_t items_per_sample, int n) {
+  uint32_t gx = (items_per_sample + kBlock - 1) / kBlock;
+  uint32_t cap = (uint32_t)(2048 / (n < 1 ? 1 : n));
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  return dim3(gx, (uint32_t)n, 1);
+}
+
+size_t rart_ws_pointwise(int corruption_id, int /*severity*/, int n, int /*h*/, int /*w*/) {
+  if (corruption_id == RART_CONTRAST) return rart_align_up((size_t)n * 3 * sizeof(unsigned long long), 256);
+  return 0;
+}
+
+int rart_launch_pointwise(int id, const RartCorruptArgs& a) {
+  const int s = a.severity - 1;
+  const size_t pixels = (size_t)a.h * a.w;
+  const size_t eps = pixels * 3;  // elements per sample
+  const size_t total = eps * a.n;
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  const uint32_t sbase = (uint32_t)a.sample_offset;
+  const bool vec_ok = (eps % 16 == 0) && ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+  RART_CHECK_ARG(eps < (1u << 28) * 4ull, "image too large for the counter layout (h*w*3 must be < 2^30)");
+  const void* inj0 = (a.injected && a.n_injected > 0) ? a.injected[0] : nullptr;
+
+  switch (id) {
+    case RART_GAUSSIAN_NOISE:
+    case RART_SPECKLE_NOISE: {
+      const double c = id == RART_GAUSSIAN_NOISE ? RartSeverity::gaussian_noise[s] : RartSeverity::speckle_noise[s];
+      if (inj0) {
+        const int g = rart_grid_for(total);
+        if (id == RART_GAUSSIAN_NOISE)
+          hipLaunchKernelGGL(k_normal_noise_injected<0>, dim3(g), dim3(kBlock), 0, a.stream, a.in, a.out,
+                             (const double*)inj0, total);
+        else
+          hipLaunchKernelGGL(k_normal_noise_injected<1>, dim3(g), dim3(kBlock), 0, a.stream, a.in, a.out,
+                             (const double*)inj0, total);
+      } else if (vec_ok) {
+        const uint32_t vps = (uint32_t)(eps / 16);
+        const dim3 g = grid2d(vps, a.n);
+        if (id == RART_GAUSSIAN_NOISE)
+          hipLaunchKernelGGL(k_normal_noise_native<0>, g, dim3(kBlock), 0, a.stream, (const uint4*)a.in,
+                             (uint4*)a.out, vps, (float)c, k0, k1, sbase);
+        else
+          hipLaunchKernelGGL(k_normal_noise_native<1>, g, dim3(kBlock), 0, a.stream, (const uint4*)a.in,
+                             (uint4*)a.out, vps, (float)c, k0, k1, sbase);
+      } else {
+        const dim3 g = grid2d((uint32_t)((eps + 3) / 4), a.n);
+        if (id == RART_GAUSSIAN_NOISE)
+          hipLaunchKernelGGL(k_normal_noise_native_scalar<0>, g, dim3(kBlock), 0, a.stream, a.in, a.out,
+                             (uint32_t)eps, 0u, (float)c, k0, k1, sbase);
+        else
+          hipLaunchKernelGGL(k_normal_noise_native_scalar<1>, g, dim3(kBlock), 0, a.stream, a.in, a.out,
+                             (uint32_t)eps, 0u, (float)c, k0, k1, sbase);
+      }
+      break;
+    }
+    case RART_SHOT_NOISE: {
+      const double c = RartSeverity::shot_noise[s];
+      if (inj0) {
+        hipLaunchKernelGGL(k_shot_injected, dim3(rart_grid_for(total)), dim3(kBlock), 0, a.stream, a.out,
+                           (const int32_t*)inj0, c, total);
+      } else {
+        hipLaunchKernelGGL(k_shot_native, grid2d((uint32_t)eps, a.n), dim3(kBlock), 0, a.stream, a.in, a.out,
+                           (uint32_t)eps, (float)c, k0, k1, sbase);
+      }
+      break;
+    }
+    case RART_IMPULSE_NOISE: {
+      if (inj0) {
+        hipLaunchKernelGGL(k_impulse_injected, dim3(rart_grid_for(total)), dim3(kBlock), 0, a.stream, a.in,
+                           a.out, (const uint8_t*)inj0, total);
+      } else {
+        RART_CHECK_ARG(vec_ok, "impulse_noise native path needs h*w*3 %% 16 == 0 and 16-byte aligned buffers");
+        const uint32_t thresh = (uint32_t)(RartSeverity::impulse_noise[s] * 16777216.0);
+        const uint32_t vps = (uint32_t)(eps / 16);
+        hipLaunchKernelGGL(k_impulse_native, grid2d(vps, a.n), dim3(kBlock), 0, a.stream, (const uint4*)a.in,
+                           (uint4*)a.out, vps, thresh, k0, k1, sbase);
+      }
+      break;
+    }
+    case RART_CONTRAST: {
+      const size_t need = rart_ws_pointwise(id, a.severity, a.n, a.h, a.w);
+      if (!a.workspace || a.workspace_bytes < need) {
+        rart_set_error("contrast: workspace of %zu bytes required", need);
+        return RART_ERR_WORKSPACE;
+      }
+      unsigned long long* sums = (unsigned long long*)a.workspace;
+      if (hipMemsetAsync(sums, 0, (size_t)a.n * 3 * sizeof(unsigned long long), a.stream) != hipSuccess) {
+        rart_set_error("contrast: hipMemsetAsync failed");
+        return RART_ERR_HIP;
+      }
+      hipLaunchKernelGGL(k_channel_sums, grid2d((uint32_t)(pixels / 4 + 1), a.n), dim3(kBlock), 0, a.stream,
+                         a.in, sums, (uint32_t)pixels);
+      hipLaunchKernelGGL(k_contrast_apply, grid2d((uint32_t)eps, a.n), dim3(kBlock), 0, a.stream, a.in, a.out,
+                         sums, (uint32_t)pixels, RartSeverity::contrast[s]);
+      break;
+    }
+    case RART_BRIGHTNESS: {
+      hipLaunchKernelGGL(k_hsv_edit<0>, dim3(rart_grid_for(pixels * a.n)), dim3(kBlock), 0, a.stream, a.in,
+                         a.out, pixels * a.n, RartSeverity::brightness[s], 0.0);
+      break;
+    }
+    case RART_SATURATE: {
+      static const double sat[5][2] = {{0.3, 0}, {0.1, 0}, {2, 0}, {5, 0.1}, {20, 0.2}};
+      hipLaunchKernelGGL(k_hsv_edit<1>, dim3(rart_grid_for(pixels * a.n)), dim3(kBlock), 0, a.stream, a.in,
+                         a.out, pixels * a.n, sat[s][0], sat[s][1]);
+      break;
+    }
+    case RART_FROST: {
+      RART_CHECK_ARG(a.h == 224 && a.w == 224, "frost: reference hard-codes 224x224 (corruptions.py:259-260)");
+      RART_CHECK_ARG(inj0 != nullptr,
+                     "frost: injected[0] (uint8 texture crops [n][224][224][3]) is required: the reference's "
+                     "frost photos are not part of its repository");
+      static const double fr[5][2] = {{1, 0.4}, {0.8, 0.6}, {0.7, 0.7}, {0.65, 0.7}, {0.6, 0.75}};
+      hipLaunchKernelGGL(k_frost_blend, dim3(rart_grid_for(total)), dim3(kBlock), 0, a.stream, a.in, a.out,
+                         (const uint8_t*)inj0, fr[s][0], fr[s][1], total);
+      break;
+    }
+    default:
+      rart_set_error("rart_launch_pointwise: corruption id %d is not pointwise", id);
+      return RART_ERR_INVALID;
+  }
+  RART_CHECK_LAUNCH("pointwise corruption launch");
+  return RART_OK;
+}

@@ -1,0 +1,170 @@
+"""ImageNet-C corruptions on MI355X -- host side of rart_corrupt_u8.
+
+Mirrors RobustART/noise/utils/imagenet_c/__init__.py:5-35: the same `corruption_tuple` order,
+`corruption_dict`, and `corrupt(x, severity, corruption_name, corruption_number)` with the same
+ValueError when neither a name nor a number is given.  Differences (documented in DESIGN.md):
+  * works on whole batches (uint8 NHWC) resident in HBM instead of one PIL image at a time;
+  * randomness is counter based (seed, global sample index, element) -- see noise/rng.py -- or
+    injected through `draws` for bit-exact parity with the reference's np.random draws.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from . import rng as _rng
+
+CORRUPTION_NAMES = (
+    'gaussian_noise', 'shot_noise', 'impulse_noise', 'defocus_blur',
+    'glass_blur', 'motion_blur', 'zoom_blur', 'snow', 'frost', 'fog',
+    'brightness', 'contrast', 'elastic_transform', 'pixelate', 'jpeg_compression',
+    'speckle_noise', 'gaussian_blur', 'spatter', 'saturate')
+
+# per-corruption: ordered (draw key, numpy dtype) of the `injected` device arrays (include/robustart_hip.h)
+_INJECT_LAYOUT = {
+    'gaussian_noise': (('noise', np.float64),),
+    'speckle_noise': (('noise', np.float64),),
+    'shot_noise': (('counts', np.int32),),
+    'impulse_noise': (('code', np.uint8),),
+    'glass_blur': (('dxdy', np.int8),),
+    'motion_blur': (('angle', np.float64),),
+    'snow': (('layer', np.float64), ('angle', np.float64)),
+    'frost': (('texture', np.uint8),),
+    'fog': (('uniform', np.float64),),
+    'elastic_transform': (('jitter', np.float32), ('field_x', np.float64), ('field_y', np.float64)),
+    'spatter': (('layer', np.float64),),
+}
+
+_frost_textures = []
+
+
+def set_frost_textures(textures):
+    """Register the frost photographs (uint8 HxWx3 RGB arrays, each at least 225x225).  The
+    reference expects six files frost/frost{1..6}.{png,jpg} that are not in its repository
+    (corruptions.py:251-256); without textures `frost` raises FileNotFoundError here."""
+    global _frost_textures
+    _frost_textures = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
+
+
+def _as_device_batch(x):
+    """-> (uint8 cuda tensor NHWC, kind, original) ; kind in {'tensor','ndarray','image'}."""
+    torch = _lib.require_gpu()
+    if isinstance(x, torch.Tensor):
+        if x.dtype != torch.uint8 or not x.is_cuda or x.dim() != 4 or x.shape[-1] != 3:
+            raise TypeError('tensor input must be a CUDA uint8 tensor shaped (n, h, w, 3)')
+        if not x.is_contiguous():
+            raise TypeError('tensor input must be contiguous (the kernels write in place)')
+        return x, 'tensor', x
+    arr = np.asarray(x)
+    if arr.dtype != np.uint8:
+        raise TypeError('image data must be uint8, got %s' % arr.dtype)
+    if arr.ndim == 3:
+        if arr.shape[-1] != 3:
+            raise TypeError('expected an HxWx3 image')
+        return torch.from_numpy(np.ascontiguousarray(arr)[None]).cuda(), 'image', x
+    if arr.ndim == 4 and arr.shape[-1] == 3:
+        return torch.from_numpy(np.ascontiguousarray(arr)).cuda(), 'ndarray', x
+    raise TypeError('expected (h, w, 3) or (n, h, w, 3) uint8 data')
+
+
+def _host_draws(name, n, severity, seed, offset):
+    """Native-mode per-image scalar draws made on the host (counter based, stream ids >= 8)."""
+    torch = _lib.require_gpu()
+    if name == 'motion_blur':
+        ang = np.array([-45.0 + 90.0 * _rng.host_uniform(seed, offset + i, 8) for i in range(n)])
+        return {'angle': ang}
+    if name == 'frost':
+        if not _frost_textures:
+            raise FileNotFoundError(
+                "frost needs texture photographs: the reference's frost/frost{1..6} files are not part "
+                "of its repository.  Call robustart_amd.noise.imagenet_c.set_frost_textures([...]).")
+        crops = np.empty((n, 224, 224, 3), dtype=np.uint8)
+        for i in range(n):
+            # corruptions.py:250,259: randint(5) over the 6-entry list, then the crop origin
+            idx = int(_rng.host_uniform(seed, offset + i, 8) * min(5, len(_frost_textures)))
+            tex = _frost_textures[idx]
+            xs = int(_rng.host_uniform(seed, offset + i, 9) * (tex.shape[0] - 224))
+            ys = int(_rng.host_uniform(seed, offset + i, 10) * (tex.shape[1] - 224))
+            crops[i] = tex[xs:xs + 224, ys:ys + 224]
+        return {'texture': crops}
+    return None
+
+
+def corrupt_batch_(batch, corruption_id, severity, seed=None, sample_offset=None, draws=None, out=None):
+    """Corruption of a CUDA uint8 NHWC tensor through the C-ABI, in place unless `out` (same shape)
+    is given.  `draws`: None, or a dict (keys as oracle/corruptions_np.draw) of per-image arrays
+    stacked on axis 0."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    n, h, w, _ = batch.shape
+    name = CORRUPTION_NAMES[corruption_id]
+    if seed is None:
+        seed = _rng.current_seed()
+    if sample_offset is None:
+        sample_offset = _rng.next_offset(n)
+    if draws is None:
+        draws = _host_draws(name, n, severity, seed, sample_offset)
+    keep = []
+    inj = None
+    n_inj = 0
+    if draws is not None and name in _INJECT_LAYOUT:
+        arrs = []
+        for key, dt in _INJECT_LAYOUT[name]:
+            if key not in draws:
+                break
+            a = np.ascontiguousarray(np.asarray(draws[key]), dtype=dt)
+            t = torch.from_numpy(a.reshape(-1).view(np.uint8) if a.dtype != np.uint8 else a.reshape(-1)).cuda()
+            keep.append(t)
+            arrs.append(t.data_ptr())
+        n_inj = len(arrs)
+        if n_inj:
+            inj = (ctypes.c_void_p * n_inj)(*arrs)
+    ws_bytes = lib.rart_corrupt_workspace_bytes(corruption_id, severity, n, h, w)
+    ws = _lib.workspace(ws_bytes, batch.device)
+    dst = batch if out is None else out
+    _lib.check(lib.rart_corrupt_u8(_lib.ptr(batch), _lib.ptr(dst), n, h, w, corruption_id, severity,
+                                   seed, sample_offset, inj, n_inj, _lib.ptr(ws), ws_bytes if ws is not None else 0,
+                                   _lib.stream_ptr()))
+    if keep:
+        torch.cuda.current_stream().synchronize()   # injected buffers must outlive the kernels
+    return dst
+
+
+def _make(name, cid):
+    def f(x, severity=1, **kw):
+        return corrupt(x, severity=severity, corruption_number=cid, **kw)
+    f.__name__ = name
+    f.__qualname__ = name
+    f.__doc__ = 'ImageNet-C %s (RobustART/noise/utils/imagenet_c/corruptions.py) on MI355X.' % name
+    return f
+
+
+corruption_tuple = tuple(_make(nm, i) for i, nm in enumerate(CORRUPTION_NAMES))
+corruption_dict = {f.__name__: f for f in corruption_tuple}
+globals().update(corruption_dict)
+
+
+def corrupt(x, severity=1, corruption_name=None, corruption_number=-1, seed=None, sample_offset=None,
+            draws=None):
+    """imagenet_c/__init__.py:13-35.  x: PIL image / HxWx3 uint8 array (returns a new HxWx3 array, like
+    the reference), an (n,h,w,3) uint8 ndarray or CUDA uint8 tensor (corrupted IN PLACE and returned,
+    like add_noise_utils.py:27-31)."""
+    if corruption_name:
+        cid = CORRUPTION_NAMES.index(corruption_name) if corruption_name in CORRUPTION_NAMES else None
+        if cid is None:
+            raise KeyError(corruption_name)
+    elif corruption_number != -1:
+        cid = range(len(CORRUPTION_NAMES))[corruption_number]   # IndexError like tuple indexing
+    else:
+        raise ValueError("Either corruption_name or corruption_number must be passed")
+    dev, kind, orig = _as_device_batch(x)
+    if dev.shape[0] == 0:
+        return orig
+    corrupt_batch_(dev, cid, severity, seed, sample_offset, draws)
+    if kind == 'tensor':
+        return orig
+    host = dev.cpu().numpy()
+    if kind == 'image':
+        return host[0]
+    np.copyto(orig, host)      # in place, same object returned (add_noise_utils.py:27-31)
+    return orig

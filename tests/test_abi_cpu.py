@@ -1,0 +1,110 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol the header
+declares, and the Python drop-in reproduces the reference's API behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'robustart_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(rart_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from robustart_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), 'header declares %s but the library does not export it' % s
+    # and the ctypes table covers the header exactly (no drift in either direction)
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.load().rart_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    """Validation happens before any HIP call, so these are safe on a GPU-less box."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    assert lib.rart_corruption_name(0) == b'gaussian_noise'
+    assert lib.rart_corruption_name(18) == b'saturate'
+    assert lib.rart_corruption_name(19) is None
+    st = lib.rart_corrupt_u8(None, None, 1, 224, 224, 99, 3, 0, 0, None, 0, None, 0, None)
+    assert st == 1 and b'unknown corruption' in lib.rart_last_error_string()
+    st = lib.rart_corrupt_u8(None, None, 1, 224, 224, 0, 6, 0, 0, None, 0, None, 0, None)
+    assert st == 1 and b'severity' in lib.rart_last_error_string()
+    # empty batch: the reference's loop body never runs -> OK, nothing touched
+    assert lib.rart_corrupt_u8(None, None, 0, 224, 224, 0, 3, 0, 0, None, 0, None, 0, None) == 0
+    assert lib.rart_corrupt_workspace_bytes(11, 3, 4, 224, 224) > 0     # contrast needs channel sums
+    assert lib.rart_attack_workspace_bytes(256) >= 256 * 32 * 4
+
+
+def test_addnoise_api_matches_reference_behaviour():
+    from robustart_amd.noise import AddNoise
+    from robustart_amd.noise.registry import noise_list, default_config, function_dict
+    from robustart_amd.noise.adv import attack_list
+    from robustart_amd.noise import imagenet_c
+    assert noise_list == ['imagenet-s', 'imagenet-c', 'pgd_linf', 'pgd_l2', 'fgsm', 'autoattack_linf',
+                          'mim_linf', 'pgd_l1']
+    assert set(function_dict) == set(noise_list) and set(attack_list) == set(noise_list[2:])
+    assert default_config['pgd_linf'] == {'f_model': None, 'eps': 8 / 255, 'rel_stepsize': 3 / 40, 'steps': 20}
+    assert default_config['mim_linf']['step_size'] == 0.002 and 'model' in default_config['mim_linf']
+    assert [f.__name__ for f in imagenet_c.corruption_tuple][:4] == ['gaussian_noise', 'shot_noise',
+                                                                      'impulse_noise', 'defocus_blur']
+    assert len(imagenet_c.corruption_tuple) == 19 and imagenet_c.corruption_tuple[15].__name__ == 'speckle_noise'
+    with pytest.raises(KeyError):          # add_noise.py:13 raises KeyError before its assert
+        AddNoise('nope')
+    a = AddNoise('imagenet-c')
+    with pytest.raises(AssertionError):    # add_noise.py:21-22
+        a.set_config(bogus=1)
+    a.set_config(corruption_name='gaussian_noise', severity=3)
+    assert a.config == {'severity': 3, 'corruption_name': 'gaussian_noise', 'corruption_number': -1}
+    # documented deviation: instances do not share config (the reference aliases the module dict)
+    assert AddNoise('imagenet-c').config['severity'] == 1
+    with pytest.raises(AssertionError):    # path input only for imagenet-c / -s
+        AddNoise('pgd_linf').add_noise('some/file.png')
+    with pytest.raises(ValueError):        # imagenet_c/__init__.py:32-33, raised before any device work
+        imagenet_c.corrupt(np.zeros((1, 8, 8, 3), np.uint8), severity=1)
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from robustart_amd.noise import AddNoise
+    a = AddNoise('imagenet-c')
+    a.config.update(corruption_name='gaussian_noise', severity=3)
+    with pytest.raises(RuntimeError, match='no GPU'):
+        a.add_noise(np.zeros((1, 224, 224, 3), np.uint8))
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import robustart_amd.noise, robustart_amd.noise.registry; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
+    subprocess.check_call([sys.executable, '-c', code])
+    for dp, _, fs in os.walk(os.path.join(ROOT, 'robustart_amd')):
+        for f in fs:
+            if f.endswith('.py'):
+                assert not re.search(r'^\s*(from|import)\s+oracle', open(os.path.join(dp, f)).read(), re.M), f
+
+
+def test_threefry_known_answers():
+    """Random123 kat_vectors for threefry2x32 (13 and 20 rounds) pin the host mirror; the GPU test
+    then pins the device generator against this mirror."""
+    from robustart_amd.noise.rng import threefry2x32
+    kat = [(13, (0, 0), (0, 0), (0x9d1c5ec6, 0x8bd50731)),
+           (13, (0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0xfd36d048, 0x2d17272c)),
+           (13, (0x243f6a88, 0x85a308d3), (0x13198a2e, 0x03707344), (0xba3e4725, 0xf27d669e)),
+           (20, (0, 0), (0, 0), (0x6b200159, 0x99ba4efe)),
+           (20, (0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0x1cb996fc, 0xbb002be7)),
+           (20, (0x243f6a88, 0x85a308d3), (0x13198a2e, 0x03707344), (0xc4923a9c, 0x483df7a0))]
+    for rounds, ctr, key, want in kat:
+        assert threefry2x32(key[0], key[1], ctr[0], ctr[1], rounds) == want

@@ -1,0 +1,171 @@
+"""GPU parity tests: HIP attack step kernels and attack drivers vs the CPU oracle
+(oracle/attacks_ref.py, itself pinned against unmodified reference APGD / MIM)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _tinynet import make_tinynet
+from oracle import attacks_ref as A
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _rand(shape, seed, lo=0.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+@pytest.mark.parametrize('shape', [(4, 3, 32, 32), (3, 3, 7, 5), (2, 3, 224, 224)])
+def test_pgd_linf_step_bit_exact(shape):
+    from robustart_amd.noise import adv
+    x0 = _rand(shape, 1)
+    x = torch.clamp(x0 + _rand(shape, 2, -0.03, 0.03), 0, 1)
+    g = _rand(shape, 3, -1, 1)
+    g.view(-1)[::17] = 0.0                      # sign(0) = 0
+    eps, alpha = 8 / 255, 8 / 255 * 3 / 40
+    want = A.pgd_linf_step(x, g, x0, eps, alpha)
+    got = adv.pgd_step_linf_(x.cuda().contiguous(), g.cuda(), x0.cuda(), eps, alpha).cpu()
+    assert torch.equal(got, want)
+    assert (got - x0).abs().max() <= eps + 1e-7 and got.min() >= 0 and got.max() <= 1
+    # idempotent projection: a zero-gradient step leaves a feasible point unchanged
+    again = adv.pgd_step_linf_(got.cuda().contiguous(), torch.zeros_like(g).cuda(), x0.cuda(), eps, alpha).cpu()
+    assert torch.allclose(again, got, atol=1e-7)
+
+
+def test_pgd_l2_and_mim_steps():
+    from robustart_amd.noise import adv
+    shape = (3, 3, 32, 32)
+    x0 = _rand(shape, 1)
+    x = torch.clamp(x0 + _rand(shape, 2, -0.01, 0.01), 0, 1)
+    g = _rand(shape, 3, -1, 1)
+    want = A.pgd_l2_step(x, g, x0, 0.5, 0.05)
+    got = adv.pgd_step_l2_(x.cuda().contiguous(), g.cuda(), x0.cuda(), 0.5, 0.05).cpu()
+    torch.testing.assert_close(got, want, atol=1e-6, rtol=0)
+    assert ((got - x0).flatten(1).norm(dim=1) <= 0.5 + 1e-5).all()
+    m = _rand(shape, 4, -1, 1)
+    wx, wm = A.mim_step(x, g, m, x0, 8 / 255, 0.002, 1.0)
+    mg = m.cuda().contiguous()
+    gx = adv.mim_step_(x.cuda().contiguous(), mg, g.cuda(), x0.cuda(), 8 / 255, 0.002, 1.0).cpu()
+    torch.testing.assert_close(gx, wx, atol=1e-6, rtol=0)
+    torch.testing.assert_close(mg.cpu(), wm, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('norm,eps', [('Linf', 8 / 255), ('L2', 0.5)])
+def test_apgd_step_and_init(norm, eps):
+    from robustart_amd.noise import adv
+    shape = (4, 3, 32, 32)
+    x0 = _rand(shape, 1)
+    t = _rand(shape, 5, -1, 1)
+    want = (x0 + eps * torch.ones_like(x0) * A._apgd_normalize(t, norm)).clamp(0, 1)
+    got = adv.apgd_init(x0.cuda(), norm, eps, injected_t=t.cuda().contiguous()).cpu()
+    torch.testing.assert_close(got, want, atol=1e-7, rtol=0)
+    xa = want.clone()
+    xold = torch.clamp(xa + _rand(shape, 6, -0.01, 0.01), 0, 1)
+    grad = _rand(shape, 7, -1, 1)
+    step = torch.tensor([2 * eps, eps, eps / 2, 2 * eps])
+    for a in (1.0, 0.75):
+        fn = A.apgd_step_linf if norm == 'Linf' else A.apgd_step_l2
+        w = fn(xa, xold, grad, x0, eps, step.view(-1, 1, 1, 1), a)
+        xa_g, xo_g = xa.cuda().contiguous(), xold.cuda().contiguous()
+        adv.apgd_step_(xa_g, xo_g, grad.cuda(), x0.cuda(), step.cuda(), norm, eps, a)
+        torch.testing.assert_close(xa_g.cpu(), w, atol=(0 if norm == 'Linf' else 2e-6), rtol=0)
+        assert torch.equal(xo_g.cpu(), xa)
+    # native random start stays inside the eps-ball and the box, and touches the ball's surface
+    nat = adv.apgd_init(x0.cuda(), norm, eps, seed=3).cpu()
+    d = (nat - x0)
+    if norm == 'Linf':
+        assert d.abs().max() <= eps + 1e-7
+    else:
+        assert (d.flatten(1).norm(dim=1) <= eps + 1e-5).all()
+
+
+def test_select_rows_and_logit_losses():
+    from robustart_amd.noise import adv
+    src, dst = _rand((5, 3, 8, 8), 1), _rand((5, 3, 8, 8), 2)
+    mask = torch.tensor([1, 0, 1, 0, 0], dtype=torch.bool)
+    got = adv.select_rows_(dst.cuda().contiguous(), src.cuda(), mask.cuda()).cpu()
+    want = dst.clone()
+    want[mask] = src[mask]
+    assert torch.equal(got, want)
+    for C in (10, 1000):
+        z = (_rand((16, C), 3, -4, 4)).requires_grad_(True)
+        y = torch.randint(0, C, (16,), generator=torch.Generator().manual_seed(1))
+        y[:4] = z[:4].argmax(1)                     # mix of correct / incorrect rows
+        yt = (y + 1 + torch.randint(0, C - 1, (16,), generator=torch.Generator().manual_seed(2))) % C
+        for kind, fn in ((0, lambda: A.ce_indiv(z, y)), (1, lambda: A.dlr_loss(z, y)),
+                         (2, lambda: A.dlr_loss_targeted(z, y, yt))):
+            li = fn()
+            gw, = torch.autograd.grad(li.sum() * 0.5, z)
+            loss, dl, pred = adv.logit_loss(z.detach().cuda(), y.cuda(), kind, yt.cuda(), 0.5)
+            torch.testing.assert_close(loss.cpu(), li.detach(), atol=2e-5, rtol=2e-5)
+            torch.testing.assert_close(dl.cpu(), gw, atol=2e-5, rtol=2e-4)
+            assert torch.equal(pred.cpu().long(), z.argmax(1))
+
+
+def _gold_model():
+    g = np.load(os.path.join(GOLD, 'attacks_ref.npz'))
+    net = make_tinynet({k[4:]: g[k] for k in g.files if k.startswith('net/')})
+    return g, net
+
+
+def test_full_attacks_match_oracle_and_reference_goldens():
+    """End to end on the tiny CNN: HIP step kernels + torch-autograd gradients vs (a) the oracle run on
+    CPU with the same injected starts, (b) the reference's own outputs (golden)."""
+    from robustart_amd.noise import adv
+    g, net = _gold_model()
+    netc = make_tinynet({k[4:]: g[k] for k in g.files if k.startswith('net/')}).cuda()
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    f_cpu = lambda z: net(A.normalize(z))  # noqa: E731
+    mean = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()
+    std = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1).cuda()
+    f_gpu = lambda z: netc((z - mean) / std)  # noqa: E731
+    tol = dict(atol=2e-5, rtol=0)
+
+    # PGD-Linf / FGSM / PGD-L2 (foolbox semantics, unpinned): same injected start as the oracle
+    eps = 8 / 255
+    u = _rand(x.shape, 9, -eps, eps)
+    want = A.pgd_linf(f_cpu, x, y, eps, 3 / 40, 7, init_u=u)
+    got = adv.pgd_linf(x.cuda(), y.cuda(), f_gpu, eps, 3 / 40, 7, init_u=u.cuda().contiguous()).cpu()
+    torch.testing.assert_close(got, want, **tol)
+    torch.testing.assert_close(adv.fgsm(x.cuda(), y.cuda(), f_gpu, eps).cpu(), A.fgsm(f_cpu, x, y, eps), **tol)
+    d0 = A.l2_ball_start(torch.randn(4, 3 * 32 * 32 + 2, generator=torch.Generator().manual_seed(4)), 0.5).view_as(x)
+    want = A.pgd_l2(f_cpu, x, y, 0.5, 3 / 40, 5, init_delta=d0)
+    got = adv.pgd_l2(x.cuda(), y.cuda(), f_gpu, 0.5, 3 / 40, 5, init_delta=d0.cuda()).cpu()
+    torch.testing.assert_close(got, want, **tol)
+
+    # MIM vs the reference's golden output
+    torch.manual_seed(11)
+    noise = torch.FloatTensor(*x.shape).uniform_(-8 / 255, 8 / 255)
+    got = adv.mim_linf(x.cuda(), y.cuda(), netc, 8 / 255, 5, 0.002, 1.0, init_noise=noise.cuda()).cpu()
+    torch.testing.assert_close(got, torch.from_numpy(g['mim/adv']), **tol)
+
+    # APGD (Linf / L2, ce / dlr) vs the reference's golden outputs
+    for norm, e in (('Linf', 8 / 255), ('L2', 0.5)):
+        for loss in ('ce', 'dlr'):
+            torch.random.manual_seed(0)
+            t = 2 * torch.rand(x.shape) - 1 if norm == 'Linf' else torch.randn(x.shape)
+            got = adv.apgd_perturb(f_gpu, x.cuda(), y.cuda(), norm, e, 10, loss, 1, init_ts=[t.cuda().contiguous()])
+            torch.testing.assert_close(got.cpu(), torch.from_numpy(g[f'apgd/{norm}/{loss}/adv']), **tol)
+
+
+def test_native_pgd_linf_invariants_at_imagenet_size():
+    """BASELINE-size property checks (no oracle run needed): eps-ball, box, determinism, sharding."""
+    from robustart_amd.noise import adv
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 7, stride=4), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1),
+                              torch.nn.Flatten(), torch.nn.Linear(8, 1000)).cuda().eval()
+    x = _rand((8, 3, 224, 224), 1).cuda()
+    y = torch.randint(0, 1000, (8,)).cuda()
+    eps = 2 / 255
+    a = adv.pgd_linf(x, y, net, eps, 3 / 40, 3, seed=5, sample_offset=100)
+    assert (a - x).abs().max() <= eps + 1e-7 and a.min() >= 0 and a.max() <= 1
+    b = adv.pgd_linf(x, y, net, eps, 3 / 40, 3, seed=5, sample_offset=100)
+    assert torch.equal(a, b)
+    # sharding invariance of the random start: samples 4..7 as their own "rank"
+    s = adv.attack_init_linf(x, eps, True, 5, 100)
+    s2 = adv.attack_init_linf(x[4:].contiguous(), eps, True, 5, 104)
+    assert torch.equal(s[4:], s2)
+    u = (s - x)[(x > eps) & (x < 1 - eps)] / eps
+    assert abs(u.mean().item()) < 5e-3 and abs(u.std().item() - 1 / np.sqrt(3)) < 5e-3
