@@ -60,6 +60,9 @@ def load():
         raise RuntimeError(
             'robustart_amd: %s is missing -- build it with `python robustart_amd/csrc/build.py` '
             '(or __graft_entry__.build()).  There is no CPU fallback for the product path.' % LIB_PATH)
+    # torch first: its bundled libamdhip64 must be THE HIP runtime of the process; loading ours
+    # first would pull /opt/rocm's copy in and the two runtimes do not share devices/streams.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library drift: fail loudly

@@ -385,9 +385,11 @@ __global__ __launch_bounds__(kBlock) void k_frost_blend(const uint8_t* __restric
 // host launchers
 // =====================================================================================
 
+// One item per thread when the launch stays below ~16k workgroups (no grid-stride tail
+// imbalance: 9408 vectors per 224x224 image = 36.75 x 256), grid-strided beyond that.
 static dim3 grid2d(uint32_t items_per_sample, int n) {
   uint32_t gx = (items_per_sample + kBlock - 1) / kBlock;
-  uint32_t cap = (uint32_t)(2048 / (n < 1 ? 1 : n));
+  uint32_t cap = (uint32_t)(16384 / (n < 1 ? 1 : n));
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;

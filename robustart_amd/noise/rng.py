@@ -1,4 +1,4 @@
-"""Host-side mirror of the library's counter-based generator (Threefry-2x32-20) for the few
+"""Host-side mirror of the library's counter-based generator (Threefry-2x32-13) for the few
 per-image SCALAR draws the host makes (motion-blur angle, frost crop origin, ...), plus the
 process-wide seed / sample counter that replaces the reference's global np.random state
 (RobustART/noise/utils/imagenet_c/corruptions.py draws from np.random)."""
@@ -7,7 +7,10 @@ _M = 0xFFFFFFFF
 _R = (13, 15, 26, 6, 17, 29, 16, 24)
 
 
-def threefry2x32(k0, k1, c0, c1, rounds=20):
+ROUNDS = 13   # must match RART_THREEFRY_ROUNDS in csrc/rart_common.h
+
+
+def threefry2x32(k0, k1, c0, c1, rounds=ROUNDS):
     ks = (k0 & _M, k1 & _M, (0x1BD11BDA ^ k0 ^ k1) & _M)
     x0 = (c0 + ks[0]) & _M
     x1 = (c1 + ks[1]) & _M

@@ -173,7 +173,7 @@ def test_native_shot_noise_distribution(sev):
         lam = lv / 255.0 * c
         y = got[i].ravel().astype(np.float64)
         unclipped = y < 255
-        kmax = int(np.floor(c))             # counts above c clip to 255
+        kmax = int(np.ceil(c)) - 1          # counts k >= c give y == 255
         # reconstruct counts for unclipped outputs: y = trunc(k/c*255)
         k = np.ceil(y[unclipped] * c / 255.0 - 1e-9).astype(int)
         frac_clip = 1.0 - unclipped.mean()
