@@ -37,6 +37,18 @@ static Family family_of(int id) {
   }
 }
 
+// Corruptions whose kernels gather from neighbouring pixels cannot run in place; when the caller
+// aliases in == out (the reference mutates its input array) the input is first staged into the
+// head of the workspace.
+static bool needs_staging(int id) {
+  switch (id) {
+    case RART_ZOOM_BLUR: case RART_DEFOCUS_BLUR: case RART_MOTION_BLUR:
+      return true;   // every other gathering corruption already goes through its own intermediate buffer
+    default:
+      return false;
+  }
+}
+
 extern "C" {
 
 int rart_version(void) { return RART_VERSION; }
@@ -47,12 +59,13 @@ const char* rart_corruption_name(int id) {
 
 size_t rart_corrupt_workspace_bytes(int id, int severity, int n, int h, int w) {
   if (id < 0 || id >= RART_NUM_CORRUPTIONS || n <= 0 || h <= 0 || w <= 0) return 0;
+  const size_t stage = needs_staging(id) ? rart_align_up((size_t)n * h * w * 3, 256) : 0;
   switch (family_of(id)) {
-    case F_POINT: return rart_ws_pointwise(id, severity, n, h, w);
-    case F_RESAMPLE: return rart_ws_resample(id, severity, n, h, w);
-    case F_JPEG: return rart_ws_jpeg(severity, n, h, w);
-    case F_STENCIL: return rart_ws_stencil(id, severity, n, h, w);
-    case F_COMPOSITE: return rart_ws_composite(id, severity, n, h, w);
+    case F_POINT: return stage + rart_ws_pointwise(id, severity, n, h, w);
+    case F_RESAMPLE: return stage + rart_ws_resample(id, severity, n, h, w);
+    case F_JPEG: return stage + rart_ws_jpeg(severity, n, h, w);
+    case F_STENCIL: return stage + rart_ws_stencil(id, severity, n, h, w);
+    case F_COMPOSITE: return stage + rart_ws_composite(id, severity, n, h, w);
   }
   return 0;
 }
@@ -75,6 +88,18 @@ int rart_corrupt_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int co
   }
   RartCorruptArgs a{in, out, n, h, w, severity, seed, sample_offset, n_injected ? injected : nullptr,
                     n_injected, workspace, workspace_bytes, (hipStream_t)stream};
+  if (needs_staging(corruption_id)) {
+    const size_t stage = rart_align_up((size_t)n * h * w * 3, 256);
+    if (in == out) {
+      if (hipMemcpyAsync(workspace, in, (size_t)n * h * w * 3, hipMemcpyDeviceToDevice, a.stream) != hipSuccess) {
+        rart_set_error("%s: staging copy failed", kNames[corruption_id]);
+        return RART_ERR_HIP;
+      }
+      a.in = (const uint8_t*)workspace;
+    }
+    a.workspace = (uint8_t*)workspace + stage;
+    a.workspace_bytes = workspace_bytes - stage;
+  }
   switch (family_of(corruption_id)) {
     case F_POINT: return rart_launch_pointwise(corruption_id, a);
     case F_RESAMPLE: return rart_launch_resample(corruption_id, a);

@@ -1,0 +1,619 @@
+// Composite corruptions for gfx950: fog (diamond-square plasma), snow, elastic_transform, spatter (mud).
+// Reference: RobustART/noise/utils/imagenet_c/corruptions.py:55-114,235-241,265-342,395-424.
+// Third-party semantics restated: scipy.ndimage.zoom / gaussian_filter /
+// map_coordinates, cv2.getAffineTransform / warpAffine (1/32-pixel fixed point) / cvtColor, and the
+// ImageMagick motion blur shared with corrupt_stencil.hip.
+#include "rart_common.h"
+#include <math.h>
+#include <vector>
+
+int rart_motion_blur_gray(const uint8_t* in, uint8_t* out, int n, int h, int w, double radius, double sigma,
+                          const double* angles_dev, double lo, double hi, uint64_t seed, uint64_t sample_offset,
+                          void* tab_ws, hipStream_t s);
+size_t rart_motion_tab_bytes(int n);
+
+#pragma clang fp contract(off)
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int HW = 224;
+
+__device__ __forceinline__ double u53(uint2 w) {
+  return ((double)(w.x >> 5) * 67108864.0 + (double)(w.y >> 6)) / 9007199254740992.0;
+}
+
+// =====================================================================================
+// fog: plasma_fractal (corruptions.py:55-101), one workgroup per image, map in HBM/L2 (fp64 256x256)
+// =====================================================================================
+constexpr int MAPN = 256;
+constexpr int PLASMA_DRAWS = 65535;
+
+__global__ __launch_bounds__(kBlock) void k_plasma(double* __restrict__ maps, double* __restrict__ minmax,
+                                                   const double* __restrict__ inj, double wibbledecay, uint32_t k0,
+                                                   uint32_t k1, uint32_t sample_base) {
+  __shared__ double red[kBlock];
+  double* M = maps + (size_t)blockIdx.x * MAPN * MAPN;
+  const double* dr = inj ? inj + (size_t)blockIdx.x * PLASMA_DRAWS : nullptr;
+  const uint32_t sample = sample_base + blockIdx.x;
+  if (threadIdx.x == 0) M[0] = 0.0;
+  __syncthreads();
+  double wibble = 100.0;
+  uint32_t base = 0;
+  auto draw = [&](uint32_t idx) -> double {
+    if (dr) return dr[idx];
+    const uint2 wv = threefry2x32(k0, k1, rart_ctr0(idx, 5), sample);
+    return -wibble + (wibble - (-wibble)) * u53(wv);  // np.random.uniform(-wibble, wibble)
+  };
+  for (int step = MAPN; step >= 2; step >>= 1) {
+    const int m = MAPN / step, half = step / 2;
+    // fillsquares
+    for (int e = threadIdx.x; e < m * m; e += kBlock) {
+      const int i = e / m, j = e % m, i1 = (i + 1) % m, j1 = (j + 1) % m;
+      const double a = M[(i * step) * MAPN + j * step] + M[(i1 * step) * MAPN + j * step];
+      const double b = M[(i * step) * MAPN + j1 * step] + M[(i1 * step) * MAPN + j1 * step];
+      const double sq = a + b;
+      const double nz = wibble * draw(base + e);
+      M[(half + i * step) * MAPN + half + j * step] = sq / 4.0 + nz;
+    }
+    __syncthreads();
+    // filldiamonds (two independent sets)
+    for (int e = threadIdx.x; e < m * m; e += kBlock) {
+      const int i = e / m, j = e % m, i1 = (i + 1) % m, j1 = (j + 1) % m, im = (i + m - 1) % m, jm = (j + m - 1) % m;
+      const double dr_ij = M[(half + i * step) * MAPN + half + j * step];
+      const double ul_ij = M[(i * step) * MAPN + j * step];
+      const double ldr = dr_ij + M[(half + im * step) * MAPN + half + j * step];
+      const double lul = ul_ij + M[(i * step) * MAPN + j1 * step];
+      const double lt = ldr + lul;
+      const double tdr = dr_ij + M[(half + i * step) * MAPN + half + jm * step];
+      const double tul = ul_ij + M[(i1 * step) * MAPN + j * step];
+      const double tt = tdr + tul;
+      const double n2 = wibble * draw(base + m * m + e);
+      const double n3 = wibble * draw(base + 2 * m * m + e);
+      M[(i * step) * MAPN + half + j * step] = lt / 4.0 + n2;
+      M[(half + i * step) * MAPN + j * step] = tt / 4.0 + n3;
+    }
+    __syncthreads();
+    base += 3 * m * m;
+    wibble /= wibbledecay;
+  }
+  // min, then max of (M - min)
+  double mn = INFINITY;
+  for (int e = threadIdx.x; e < MAPN * MAPN; e += kBlock) mn = fmin(mn, M[e]);
+  red[threadIdx.x] = mn;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  mn = red[0];
+  __syncthreads();
+  double mx = -INFINITY;
+  for (int e = threadIdx.x; e < MAPN * MAPN; e += kBlock) mx = fmax(mx, M[e] - mn);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    minmax[blockIdx.x * 2] = mn;
+    minmax[blockIdx.x * 2 + 1] = red[0];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_image_max(const uint8_t* __restrict__ in, uint32_t* __restrict__ mx,
+                                                      uint32_t elems) {
+  const uint8_t* src = in + (size_t)blockIdx.y * elems;
+  uint32_t m = 0;
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < elems; e += gridDim.x * kBlock) m = max(m, (uint32_t)src[e]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(&mx[blockIdx.y], m);
+}
+
+__global__ __launch_bounds__(kBlock) void k_fog_blend(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                      const double* __restrict__ maps,
+                                                      const double* __restrict__ minmax,
+                                                      const uint32_t* __restrict__ imax, double c0) {
+  const int img = blockIdx.y;
+  const double mn = minmax[img * 2], mxm = minmax[img * 2 + 1];
+  const double max_val = (double)imax[img] / 255.0;
+  const double* M = maps + (size_t)img * MAPN * MAPN;
+  const size_t base = (size_t)img * HW * HW * 3;
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < HW * HW; p += gridDim.x * kBlock) {
+    const int y = p / HW, x = p % HW;
+    const double sh = M[y * MAPN + x] - mn;
+    const double pl = sh / mxm;
+    const double add = c0 * pl;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v = (double)in[base + p * 3 + c] / 255.0 + add;
+      const double num = v * max_val;
+      double r = num / (max_val + c0);
+      r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
+      out[base + p * 3 + c] = (uint8_t)(uint32_t)(r * 255.0);
+    }
+  }
+}
+
+// =====================================================================================
+// generic single-channel field helpers
+// =====================================================================================
+
+// field[n][HW][HW] = loc + scale * N(0,1) (native) -- injected fields are used directly
+__global__ __launch_bounds__(kBlock) void k_normal_field(double* __restrict__ f, double loc, double scale, uint32_t k0,
+                                                         uint32_t k1, uint32_t sample_base, int stream_id) {
+  const uint32_t sample = blockIdx.y;
+  for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < HW * HW / 4; q += gridDim.x * kBlock) {
+    const float4 z = rart_normal4(k0, k1, q, stream_id, sample_base + sample);
+    double* d = f + (size_t)sample * HW * HW + q * 4;
+    d[0] = loc + scale * (double)z.x;
+    d[1] = loc + scale * (double)z.y;
+    d[2] = loc + scale * (double)z.z;
+    d[3] = loc + scale * (double)z.w;
+  }
+}
+
+// field = U(-1, 1) (native elastic displacement seeds)
+__global__ __launch_bounds__(kBlock) void k_uniform_field(double* __restrict__ f, uint32_t k0, uint32_t k1,
+                                                          uint32_t sample_base, int stream_id) {
+  const uint32_t sample = blockIdx.y;
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < HW * HW; e += gridDim.x * kBlock) {
+    const uint2 wv = threefry2x32(k0, k1, rart_ctr0(e, stream_id), sample_base + sample);
+    f[(size_t)sample * HW * HW + e] = -1.0 + 2.0 * u53(wv);
+  }
+}
+
+// scipy gaussian_filter1d along AXIS of [n][h][w] fields; REFLECT: mode='reflect' (half-sample symmetric)
+// else 'nearest'.  TIN/TOUT in {double, float}; scipy computes each line in double and casts on store.
+template <int AXIS, bool REFLECT, typename TIN, typename TOUT>
+__global__ __launch_bounds__(kBlock) void k_field_gauss(const TIN* __restrict__ src, TOUT* __restrict__ dst, int n,
+                                                        int h, int w, const double* __restrict__ wts, int radius,
+                                                        double post_scale) {
+  const size_t total = (size_t)n * h * w;
+  const int len = AXIS == 0 ? h : w;
+  const size_t stride = AXIS == 0 ? (size_t)w : 1;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int xo = (int)(i % w), yo = (int)((i / w) % h);
+    const int l = AXIS == 0 ? yo : xo;
+    const size_t base = i - (size_t)l * stride;
+    auto at = [&](int p) -> double {
+      if (REFLECT) {
+        const int period = 2 * len;
+        p %= period;
+        if (p < 0) p += period;
+        if (p >= len) p = period - 1 - p;
+      } else {
+        p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+      }
+      return (double)src[base + (size_t)p * stride];
+    };
+    double tmp = at(l) * wts[radius];
+    for (int jj = -radius; jj < 0; ++jj) {
+      const double pair = at(l + jj) + at(l - jj);
+      tmp += pair * wts[jj + radius];
+    }
+    if (post_scale != 1.0) tmp = tmp * post_scale;
+    dst[i] = (TOUT)tmp;
+  }
+}
+
+// =====================================================================================
+// snow (corruptions.py:265-290)
+// =====================================================================================
+struct SnowZoom {
+  int ch, top, out_n, trim;
+};
+
+// clipped_zoom of the fp64 layer (order-1, grid_mode False) -> threshold -> uint8 'L' image
+__global__ __launch_bounds__(kBlock) void k_snow_layer_u8(const double* __restrict__ layer, uint8_t* __restrict__ out,
+                                                          SnowZoom z, double thresh) {
+  const double* L = layer + (size_t)blockIdx.y * HW * HW;
+  uint8_t* o = out + (size_t)blockIdx.y * HW * HW;
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < HW * HW; p += gridDim.x * kBlock) {
+    const int yo = p / HW, xo = p % HW;
+    const double sy = z.out_n > 1 ? (double)((long long)(yo + z.trim) * (z.ch - 1)) / (double)(z.out_n - 1) : 0.0;
+    const double sx = z.out_n > 1 ? (double)((long long)(xo + z.trim) * (z.ch - 1)) / (double)(z.out_n - 1) : 0.0;
+    int y0 = (int)floor(sy), x0 = (int)floor(sx);
+    y0 = y0 < 0 ? 0 : (y0 > z.ch - 1 ? z.ch - 1 : y0);
+    x0 = x0 < 0 ? 0 : (x0 > z.ch - 1 ? z.ch - 1 : x0);
+    const int y1 = y0 + 1 < z.ch ? y0 + 1 : z.ch - 1, x1 = x0 + 1 < z.ch ? x0 + 1 : z.ch - 1;
+    const double ty = sy - (double)y0, tx = sx - (double)x0;
+    const double* r0 = L + (size_t)(z.top + y0) * HW + z.top;
+    const double* r1 = L + (size_t)(z.top + y1) * HW + z.top;
+    const double omty = 1.0 - ty, omtx = 1.0 - tx;
+    const double l0 = r0[x0] * omty, l1 = r1[x0] * ty;
+    const double left = l0 + l1;
+    const double g0 = r0[x1] * omty, g1 = r1[x1] * ty;
+    const double right = g0 + g1;
+    const double v0 = left * omtx, v1 = right * tx;
+    double v = v0 + v1;
+    if (v < thresh) v = 0.0;
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    o[p] = (uint8_t)(uint32_t)(v * 255.0);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_snow_blend(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                       const uint8_t* __restrict__ layer_u8, float c6, float omc6) {
+  const int img = blockIdx.y;
+  const size_t base = (size_t)img * HW * HW * 3;
+  const uint8_t* L = layer_u8 + (size_t)img * HW * HW;
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < HW * HW; p += gridDim.x * kBlock) {
+    const int y = p / HW, x = p % HW;
+    const float r = (float)in[base + p * 3] / 255.0f, g = (float)in[base + p * 3 + 1] / 255.0f,
+                b = (float)in[base + p * 3 + 2] / 255.0f;
+    const float g0 = 0.299f * r, g1 = 0.587f * g, g2 = 0.114f * b;
+    const float gray = (g0 + g1) + g2;
+    const float gg = gray * 1.5f;
+    const float lift = gg + 0.5f;
+    const double s1 = (double)L[p] / 255.0;
+    const double s2 = (double)L[(HW - 1 - y) * HW + (HW - 1 - x)] / 255.0;  // np.rot90(k=2)
+    const float px[3] = {r, g, b};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float mxv = fmaxf(px[c], lift);
+      const float a = c6 * px[c];
+      const float bb = omc6 * mxv;
+      const float xn = a + bb;
+      const double t = (double)xn + s1;
+      double v = t + s2;
+      v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+      out[base + p * 3 + c] = (uint8_t)(uint32_t)(v * 255.0);
+    }
+  }
+}
+
+// =====================================================================================
+// elastic_transform (corruptions.py:395-424)
+// =====================================================================================
+__device__ __forceinline__ int reflect101(int i, int n) {
+  const int period = 2 * (n - 1);
+  i %= period;
+  if (i < 0) i += period;
+  return i >= n ? period - i : i;
+}
+
+// per image: jitter -> cv2.getAffineTransform(pts1, pts2) -> inverse map coefficients (warpAffine inverts M)
+__global__ void k_elastic_affine(double* __restrict__ inv, const float* __restrict__ jitter_inj, float c2, uint32_t k0,
+                                 uint32_t k1, uint32_t sample_base) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= (int)gridDim.x * (int)blockDim.x) return;
+  // pts1 for a 224x224 image: centre 112, square 74 (corruptions.py:407-411)
+  const float p1[3][2] = {{186.f, 186.f}, {186.f, 38.f}, {38.f, 38.f}};
+  float p2[3][2];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 2; ++j) {
+      float jt;
+      if (jitter_inj) {
+        jt = jitter_inj[img * 6 + i * 2 + j];
+      } else {
+        const uint2 wv = threefry2x32(k0, k1, rart_ctr0(i * 2 + j, 6), sample_base + img);
+        const double lo = -(double)c2;
+        jt = (float)(lo + ((double)c2 - lo) * u53(wv));   // np.random.uniform(-c2, c2).astype(float32)
+      }
+      p2[i][j] = p1[i][j] + jt;
+    }
+  // solve M * [x y 1]^T = [x' y']^T for the three correspondences (Cramer, double)
+  const double x0 = p1[0][0], y0 = p1[0][1], x1 = p1[1][0], y1 = p1[1][1], x2 = p1[2][0], y2 = p1[2][1];
+  const double det = x0 * (y1 - y2) - y0 * (x1 - x2) + (x1 * y2 - x2 * y1);
+  double M[2][3];
+  for (int r = 0; r < 2; ++r) {
+    const double u0 = p2[0][r], u1 = p2[1][r], u2 = p2[2][r];
+    M[r][0] = (u0 * (y1 - y2) - y0 * (u1 - u2) + (u1 * y2 - u2 * y1)) / det;
+    M[r][1] = (x0 * (u1 - u2) - u0 * (x1 - x2) + (x1 * u2 - x2 * u1)) / det;
+    M[r][2] = (x0 * (y1 * u2 - y2 * u1) - y0 * (x1 * u2 - x2 * u1) + u0 * (x1 * y2 - x2 * y1)) / det;
+  }
+  double D = M[0][0] * M[1][1] - M[0][1] * M[1][0];
+  D = D != 0.0 ? 1.0 / D : 0.0;
+  const double A11 = M[1][1] * D, A22 = M[0][0] * D, A12 = -M[0][1] * D, A21 = -M[1][0] * D;
+  const double b1 = -A11 * M[0][2] - A12 * M[1][2];
+  const double b2 = -A21 * M[0][2] - A22 * M[1][2];
+  double* o = inv + (size_t)img * 6;
+  o[0] = A11; o[1] = A12; o[2] = b1; o[3] = A21; o[4] = A22; o[5] = b2;
+}
+
+// cv2.warpAffine INTER_LINEAR BORDER_REFLECT_101 on float32 (x/255): 1/32-pixel fixed-point coordinates
+__global__ __launch_bounds__(kBlock) void k_warp_affine(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                        const double* __restrict__ inv) {
+  const int img = blockIdx.y;
+  const double* A = inv + (size_t)img * 6;
+  const uint8_t* src = in + (size_t)img * HW * HW * 3;
+  float* dst = out + (size_t)img * HW * HW * 3;
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < HW * HW; p += gridDim.x * kBlock) {
+    const int y = p / HW, x = p % HW;
+    const long long adelta = llrint(A[0] * (double)x * 1024.0), bdelta = llrint(A[3] * (double)x * 1024.0);
+    const long long X0 = llrint((A[1] * (double)y + A[2]) * 1024.0) + 16;
+    const long long Y0 = llrint((A[4] * (double)y + A[5]) * 1024.0) + 16;
+    const long long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const int sx = (int)(X >> 5), sy = (int)(Y >> 5);
+    const float fx = (float)(X & 31) / 32.0f, fy = (float)(Y & 31) / 32.0f;
+    const int xa = reflect101(sx, HW), xb = reflect101(sx + 1, HW), ya = reflect101(sy, HW), yb = reflect101(sy + 1, HW);
+    const float w00 = (1.0f - fy) * (1.0f - fx), w01 = (1.0f - fy) * fx, w10 = fy * (1.0f - fx), w11 = fy * fx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v00 = (float)src[(ya * HW + xa) * 3 + c] / 255.0f, v01 = (float)src[(ya * HW + xb) * 3 + c] / 255.0f;
+      const float v10 = (float)src[(yb * HW + xa) * 3 + c] / 255.0f, v11 = (float)src[(yb * HW + xb) * 3 + c] / 255.0f;
+      const float t0 = v00 * w00, t1 = v01 * w01, t2 = v10 * w10, t3 = v11 * w11;
+      dst[p * 3 + c] = ((t0 + t1) + t2) + t3;
+    }
+  }
+}
+
+// scipy map_coordinates(order=1, mode='reflect') of the warped fp32 image at (y+dy, x+dx, c)
+__device__ __forceinline__ double reflect_coord(double c, int n) {
+  c = c + 0.5;
+  const double p = 2.0 * n;
+  c = c - p * floor(c / p);
+  if (c > (double)n) c = p - c;
+  return c - 0.5;
+}
+
+__global__ __launch_bounds__(kBlock) void k_elastic_gather(const float* __restrict__ img_all,
+                                                           const float* __restrict__ dx_all,
+                                                           const float* __restrict__ dy_all, uint8_t* __restrict__ out) {
+  const int img = blockIdx.y;
+  const float* I = img_all + (size_t)img * HW * HW * 3;
+  const float* DX = dx_all + (size_t)img * HW * HW;
+  const float* DY = dy_all + (size_t)img * HW * HW;
+  uint8_t* o = out + (size_t)img * HW * HW * 3;
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < HW * HW; p += gridDim.x * kBlock) {
+    const int y = p / HW, x = p % HW;
+    const double cy = reflect_coord((double)y + (double)DY[p], HW);
+    const double cx = reflect_coord((double)x + (double)DX[p], HW);
+    const double fy0 = floor(cy), fx0 = floor(cx);
+    const double ty = cy - fy0, tx = cx - fx0;
+    int y0 = (int)fy0, x0 = (int)fx0;
+    int y1 = y0 + 1, x1 = x0 + 1;
+    y0 = y0 < 0 ? 0 : (y0 > HW - 1 ? HW - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > HW - 1 ? HW - 1 : y1);
+    x0 = x0 < 0 ? 0 : (x0 > HW - 1 ? HW - 1 : x0);
+    x1 = x1 < 0 ? 0 : (x1 > HW - 1 ? HW - 1 : x1);
+    const double wy0 = 1.0 - ty, wx0 = 1.0 - tx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double t = 0.0;
+      t += ((double)I[(y0 * HW + x0) * 3 + c] * wy0) * wx0;
+      t += ((double)I[(y0 * HW + x1) * 3 + c] * wy0) * tx;
+      t += ((double)I[(y1 * HW + x0) * 3 + c] * ty) * wx0;
+      t += ((double)I[(y1 * HW + x1) * 3 + c] * ty) * tx;
+      float v = (float)t;
+      v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+      o[p * 3 + c] = (uint8_t)(uint32_t)(v * 255.0f);
+    }
+  }
+}
+
+// =====================================================================================
+// spatter, mud branch (corruptions.py:329-342)
+// =====================================================================================
+__global__ __launch_bounds__(kBlock) void k_spatter_mask(const double* __restrict__ liquid, float* __restrict__ m,
+                                                         double thresh, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    double v = liquid[i];
+    if (v < thresh) v = 0.0;
+    m[i] = v > thresh ? 1.0f : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_spatter_mud(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        const float* __restrict__ m_all) {
+  const int img = blockIdx.y;
+  const size_t base = (size_t)img * HW * HW * 3;
+  const float* Mk = m_all + (size_t)img * HW * HW;
+  const float col[3] = {(float)(63 / 255.), (float)(42 / 255.), (float)(20 / 255.)};
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < HW * HW; p += gridDim.x * kBlock) {
+    float m = Mk[p];
+    if (m < 0.8f) m = 0.f;
+    const float om = 1.0f - m;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = (float)in[base + p * 3 + c] / 255.0f;
+      const float cm = col[c] * m;
+      const float xm = x * om;
+      float v = xm + cm;
+      v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+      out[base + p * 3 + c] = (uint8_t)(uint32_t)(v * 255.0f);
+    }
+  }
+}
+
+// ---- host tables --------------------------------------------------------------------------------
+std::vector<double> gauss_weights(double sigma, double truncate, int* radius) {
+  const int r = (int)(truncate * sigma + 0.5);
+  std::vector<double> w(2 * r + 1);
+  double sum = 0.0;
+  for (int i = -r; i <= r; ++i) {
+    w[i + r] = exp(-0.5 / (sigma * sigma) * (double)i * (double)i);
+    sum += w[i + r];
+  }
+  for (auto& v : w) v /= sum;
+  *radius = r;
+  return w;
+}
+
+const double kFog[5][2] = {{1.5, 2}, {2., 2}, {2.5, 1.7}, {2.5, 1.5}, {3., 1.4}};
+const double kSnow[5][7] = {{0.1, 0.3, 3, 0.5, 10, 4, 0.8}, {0.2, 0.3, 2, 0.5, 12, 4, 0.7}, {0.55, 0.3, 4, 0.9, 12, 8, 0.7},
+                            {0.55, 0.3, 4.5, 0.85, 12, 8, 0.65}, {0.55, 0.3, 2.5, 0.85, 12, 12, 0.55}};
+const double kElastic[5][3] = {{244 * 2, 244 * 0.7, 244 * 0.1}, {244 * 2, 244 * 0.08, 244 * 0.2},
+                               {244 * 0.05, 244 * 0.01, 244 * 0.02}, {244 * 0.07, 244 * 0.01, 244 * 0.02},
+                               {244 * 0.12, 244 * 0.01, 244 * 0.02}};
+const double kSpatter[5][6] = {{0.65, 0.3, 4, 0.69, 0.6, 0}, {0.65, 0.3, 3, 0.68, 0.6, 0}, {0.65, 0.3, 2, 0.68, 0.5, 0},
+                               {0.65, 0.3, 1, 0.65, 1.5, 1}, {0.67, 0.4, 1, 0.65, 1.5, 1}};
+
+dim3 img_grid(int n) { return dim3((HW * HW + kBlock - 1) / kBlock, n); }
+size_t A256(size_t v) { return rart_align_up(v, 256); }
+
+// process-lifetime weight tables (async uploads read them after the call returns)
+const std::vector<double>& cached_weights(int slot, double sigma, double truncate, int* radius) {
+  static std::vector<double> tabs[16];
+  static int radii[16];
+  if (tabs[slot].empty()) tabs[slot] = gauss_weights(sigma, truncate, &radii[slot]);
+  *radius = radii[slot];
+  return tabs[slot];
+}
+}  // namespace
+#pragma clang fp contract(fast)
+
+size_t rart_ws_composite(int id, int /*severity*/, int n, int h, int w) {
+  if (h != HW || w != HW) return 0;
+  const size_t field = A256((size_t)n * HW * HW * sizeof(double));
+  switch (id) {
+    case RART_FOG: return A256((size_t)n * MAPN * MAPN * sizeof(double)) + A256((size_t)n * 2 * sizeof(double)) +
+                          A256((size_t)n * sizeof(uint32_t));
+    case RART_SNOW: return field + 2 * A256((size_t)n * HW * HW) + rart_motion_tab_bytes(n);
+    case RART_ELASTIC_TRANSFORM:
+      return A256((size_t)n * 6 * sizeof(double)) + A256((size_t)n * HW * HW * 3 * sizeof(float)) + 2 * field +
+             2 * A256((size_t)n * HW * HW * sizeof(float)) + A256(1025 * sizeof(double));
+    case RART_SPATTER: return 2 * field + 2 * A256((size_t)n * HW * HW * sizeof(float)) + 2 * A256(64 * sizeof(double));
+  }
+  return 0;
+}
+
+int rart_launch_composite(int id, const RartCorruptArgs& a) {
+  RART_CHECK_ARG(a.h == HW && a.w == HW, "%s: reference hard-codes 224x224", rart_corruption_name(id));
+  const int s = a.severity - 1;
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32), sb = (uint32_t)a.sample_offset;
+  auto inj = [&](int i) -> const void* { return (a.injected && a.n_injected > i) ? a.injected[i] : nullptr; };
+  uint8_t* ws = (uint8_t*)a.workspace;
+  const size_t field = A256((size_t)a.n * HW * HW * sizeof(double));
+  hipStream_t st = a.stream;
+  switch (id) {
+    case RART_FOG: {
+      double* maps = (double*)ws;
+      ws += A256((size_t)a.n * MAPN * MAPN * sizeof(double));
+      double* minmax = (double*)ws;
+      ws += A256((size_t)a.n * 2 * sizeof(double));
+      uint32_t* imax = (uint32_t*)ws;
+      if (hipMemsetAsync(imax, 0, (size_t)a.n * sizeof(uint32_t), st) != hipSuccess) {
+        rart_set_error("fog: memset failed");
+        return RART_ERR_HIP;
+      }
+      hipLaunchKernelGGL(k_plasma, dim3(a.n), dim3(kBlock), 0, st, maps, minmax, (const double*)inj(0), kFog[s][1], k0,
+                         k1, sb);
+      hipLaunchKernelGGL(k_image_max, dim3(8, a.n), dim3(kBlock), 0, st, a.in, imax, (uint32_t)(HW * HW * 3));
+      hipLaunchKernelGGL(k_fog_blend, img_grid(a.n), dim3(kBlock), 0, st, a.in, a.out, maps, minmax, imax, kFog[s][0]);
+      break;
+    }
+    case RART_SNOW: {
+      const double* c = kSnow[s];
+      double* layer = (double*)ws;
+      ws += field;
+      uint8_t* l8a = ws;
+      ws += A256((size_t)a.n * HW * HW);
+      uint8_t* l8b = ws;
+      ws += A256((size_t)a.n * HW * HW);
+      void* tab = ws;
+      const double* layer_src = (const double*)inj(0);
+      if (!layer_src) {
+        hipLaunchKernelGGL(k_normal_field, dim3(HW * HW / 4 / kBlock, a.n), dim3(kBlock), 0, st, layer, c[0], c[1], k0,
+                           k1, sb, 7);
+        layer_src = layer;
+      }
+      SnowZoom z;
+      z.ch = (int)ceil((double)HW / c[2]);
+      z.top = (HW - z.ch) / 2;
+      z.out_n = (int)nearbyint((double)z.ch * c[2]);
+      z.trim = (z.out_n - HW) / 2;
+      hipLaunchKernelGGL(k_snow_layer_u8, img_grid(a.n), dim3(kBlock), 0, st, layer_src, l8a, z, c[3]);
+      rart_motion_blur_gray(l8a, l8b, a.n, HW, HW, c[4], c[5], (const double*)inj(1), -135.0, -45.0, a.seed,
+                            a.sample_offset, tab, st);
+      const float c6 = (float)c[6], omc6 = (float)(1.0 - c[6]);
+      hipLaunchKernelGGL(k_snow_blend, img_grid(a.n), dim3(kBlock), 0, st, a.in, a.out, l8b, c6, omc6);
+      break;
+    }
+    case RART_ELASTIC_TRANSFORM: {
+      const double* c = kElastic[s];
+      double* inv = (double*)ws;
+      ws += A256((size_t)a.n * 6 * sizeof(double));
+      float* warped = (float*)ws;
+      ws += A256((size_t)a.n * HW * HW * 3 * sizeof(float));
+      double* f0 = (double*)ws;
+      ws += field;
+      double* f1 = (double*)ws;
+      ws += field;
+      float* dx = (float*)ws;
+      ws += A256((size_t)a.n * HW * HW * sizeof(float));
+      float* dy = (float*)ws;
+      ws += A256((size_t)a.n * HW * HW * sizeof(float));
+      double* wdev = (double*)ws;
+      int radius;
+      const std::vector<double>& wt = cached_weights(s, c[1], 3.0, &radius);
+      RART_CHECK_ARG(radius <= 512, "elastic_transform: gaussian radius too large");
+      if (hipMemcpyAsync(wdev, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+        rart_set_error("elastic_transform: weight upload failed");
+        return RART_ERR_HIP;
+      }
+      hipLaunchKernelGGL(k_elastic_affine, dim3(a.n), dim3(1), 0, st, inv, (const float*)inj(0), (float)c[2], k0, k1, sb);
+      hipLaunchKernelGGL(k_warp_affine, img_grid(a.n), dim3(kBlock), 0, st, a.in, warped, inv);
+      const int g = rart_grid_for((size_t)a.n * HW * HW, kBlock, 256 * 16);
+      for (int which = 0; which < 2; ++which) {
+        const double* fsrc = (const double*)inj(1 + which);
+        if (!fsrc) {
+          hipLaunchKernelGGL(k_uniform_field, img_grid(a.n), dim3(kBlock), 0, st, f0, k0, k1, sb, 11 + which);
+          fsrc = f0;
+        }
+        hipLaunchKernelGGL((k_field_gauss<0, true, double, double>), dim3(g), dim3(kBlock), 0, st, fsrc, f1, a.n, HW, HW,
+                           (const double*)wdev, radius, 1.0);
+        hipLaunchKernelGGL((k_field_gauss<1, true, double, float>), dim3(g), dim3(kBlock), 0, st, (const double*)f1,
+                           which == 0 ? dx : dy, a.n, HW, HW, (const double*)wdev, radius, c[0]);
+      }
+      hipLaunchKernelGGL(k_elastic_gather, img_grid(a.n), dim3(kBlock), 0, st, (const float*)warped, (const float*)dx,
+                         (const float*)dy, a.out);
+      break;
+    }
+    case RART_SPATTER: {
+      const double* c = kSpatter[s];
+      if (c[5] == 0) {
+        rart_set_error("spatter severity %d (water branch: cv2.Canny / distanceTransform / equalizeHist) is not "
+                       "implemented; severities 4-5 (mud) are", a.severity);
+        return RART_ERR_UNSUPPORTED;
+      }
+      double* layer = (double*)ws;
+      ws += field;
+      double* tmpd = (double*)ws;
+      ws += field;
+      float* m0 = (float*)ws;
+      ws += A256((size_t)a.n * HW * HW * sizeof(float));
+      float* m1 = (float*)ws;
+      ws += A256((size_t)a.n * HW * HW * sizeof(float));
+      double* w1dev = (double*)ws;
+      ws += A256(64 * sizeof(double));
+      double* w2dev = (double*)ws;
+      int r1, r2;
+      const std::vector<double>& wt1 = cached_weights(8 + (s - 3) * 2, c[2], 4.0, &r1);
+      const std::vector<double>& wt2 = cached_weights(9 + (s - 3) * 2, c[4], 4.0, &r2);
+      if (hipMemcpyAsync(w1dev, wt1.data(), wt1.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(w2dev, wt2.data(), wt2.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+        rart_set_error("spatter: weight upload failed");
+        return RART_ERR_HIP;
+      }
+      const double* lsrc = (const double*)inj(0);
+      if (!lsrc) {
+        hipLaunchKernelGGL(k_normal_field, dim3(HW * HW / 4 / kBlock, a.n), dim3(kBlock), 0, st, layer, c[0], c[1], k0,
+                           k1, sb, 13);
+        lsrc = layer;
+      }
+      const int g = rart_grid_for((size_t)a.n * HW * HW, kBlock, 256 * 16);
+      // gaussian(liquid_layer, sigma=c2): fp64, mode nearest, truncate 4
+      hipLaunchKernelGGL((k_field_gauss<0, false, double, double>), dim3(g), dim3(kBlock), 0, st, lsrc, tmpd, a.n, HW, HW,
+                         (const double*)w1dev, r1, 1.0);
+      hipLaunchKernelGGL((k_field_gauss<1, false, double, double>), dim3(g), dim3(kBlock), 0, st, (const double*)tmpd,
+                         layer, a.n, HW, HW, (const double*)w1dev, r1, 1.0);
+      hipLaunchKernelGGL(k_spatter_mask, dim3(g), dim3(kBlock), 0, st, (const double*)layer, m0, c[3],
+                         (size_t)a.n * HW * HW);
+      // gaussian(m.astype(float32), sigma=c4): float32 in/out, the axis-0 result is stored as float32
+      hipLaunchKernelGGL((k_field_gauss<0, false, float, float>), dim3(g), dim3(kBlock), 0, st, (const float*)m0, m1, a.n,
+                         HW, HW, (const double*)w2dev, r2, 1.0);
+      hipLaunchKernelGGL((k_field_gauss<1, false, float, float>), dim3(g), dim3(kBlock), 0, st, (const float*)m1, m0, a.n,
+                         HW, HW, (const double*)w2dev, r2, 1.0);
+      hipLaunchKernelGGL(k_spatter_mud, img_grid(a.n), dim3(kBlock), 0, st, a.in, a.out, (const float*)m0);
+      break;
+    }
+    default:
+      rart_set_error("rart_launch_composite: bad id %d", id);
+      return RART_ERR_INVALID;
+  }
+  RART_CHECK_LAUNCH("composite corruption launch");
+  return RART_OK;
+}

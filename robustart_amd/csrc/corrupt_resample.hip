@@ -1,0 +1,202 @@
+// Resampling corruptions for gfx950: pixelate (Pillow BOX resize, integer, bit-exact) and
+// zoom_blur (scipy.ndimage.zoom order-1 accumulation).
+// Reference: RobustART/noise/utils/imagenet_c/corruptions.py:104-114,219-232,385-391.
+// Restatements: SURVEY.md Appendix A.1 (Pillow Resample.c fixed point) and A.3 (scipy zoom).
+#include "rart_common.h"
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int KMAX = 4;  // BOX taps per output for every size pair pixelate uses (<= 3)
+
+struct BoxEntry {
+  int xmin, n;
+  int k[KMAX];
+};
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc for the BOX filter (support 0.5), one thread per
+// output index; double arithmetic in the same order as Resample.c.
+__global__ void k_box_table(BoxEntry* __restrict__ tab, int in_size, int out_size) {
+  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xx >= out_size) return;
+  const double scale = (double)in_size / (double)out_size;
+  const double fs = scale < 1.0 ? 1.0 : scale;
+  const double support = 0.5 * fs;
+  const double center = ((double)xx + 0.5) * scale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  double w[KMAX] = {0, 0, 0, 0};
+  double ww = 0.0;
+  const int n = xmax > KMAX ? KMAX : xmax;
+  for (int x = 0; x < n; ++x) {
+    const double t = ((double)(x + xmin) - center + 0.5) / fs;
+    const double v = (t > -0.5 && t <= 0.5) ? 1.0 : 0.0;
+    w[x] = v;
+    ww += v;
+  }
+  BoxEntry e;
+  e.xmin = xmin;
+  e.n = n;
+  for (int x = 0; x < KMAX; ++x) {
+    double v = w[x];
+    if (ww != 0.0) v = v / ww;
+    e.k[x] = (int)(0.5 + v * 4194304.0);  // 1 << 22; weights are >= 0
+  }
+  tab[xx] = e;
+}
+
+// One separable pass.  AXIS 1: along width (in [n][h][win][3] -> out [n][h][wout][3]);
+// AXIS 0: along height (in [n][hin][w][3] -> out [n][hout][w][3]).
+template <int AXIS>
+__global__ __launch_bounds__(kBlock) void k_box_pass(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                     const BoxEntry* __restrict__ tab, int n, int hin, int win,
+                                                     int hout, int wout) {
+  const size_t total = (size_t)n * hout * wout * 3;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int c = (int)(i % 3);
+    const size_t p = i / 3;
+    const int xo = (int)(p % wout);
+    const size_t q = p / wout;
+    const int yo = (int)(q % hout);
+    const int img = (int)(q / hout);
+    const BoxEntry e = tab[AXIS == 1 ? xo : yo];
+    int acc = 1 << 21;
+    for (int j = 0; j < e.n; ++j) {
+      const size_t src = AXIS == 1 ? (((size_t)img * hin + yo) * win + (e.xmin + j)) * 3 + c
+                                   : (((size_t)img * hin + (e.xmin + j)) * win + xo) * 3 + c;
+      acc += (int)in[src] * e.k[j];
+    }
+    acc >>= 22;
+    out[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+  }
+}
+
+// ---- zoom_blur --------------------------------------------------------------------------
+struct ZoomParams {
+  int count;
+  int ch[16], top[16], out_n[16], trim[16];
+};
+
+__global__ __launch_bounds__(kBlock) void k_zoom_blur(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                      int n, int h, int w, ZoomParams zp) {
+  __shared__ float lut[256];  // (np.array(x) / 255.).astype(np.float32)
+  lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);
+  __syncthreads();
+  const size_t pixels = (size_t)n * h * w;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < pixels; p += (size_t)gridDim.x * kBlock) {
+    const int xo = (int)(p % w);
+    const size_t q = p / w;
+    const int yo = (int)(q % h);
+    const uint8_t* img = in + (q / h) * (size_t)h * w * 3;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int z = 0; z < zp.count; ++z) {
+      const int ch = zp.ch[z], top = zp.top[z], on = zp.out_n[z], trim = zp.trim[z];
+      // source coordinate inside the crop: (o + trim) * (ch - 1) / (out_n - 1)  (grid_mode=False)
+      const double sy = on > 1 ? (double)((long long)(yo + trim) * (ch - 1)) / (double)(on - 1) : 0.0;
+      const double sx = on > 1 ? (double)((long long)(xo + trim) * (ch - 1)) / (double)(on - 1) : 0.0;
+      int y0 = (int)floor(sy), x0 = (int)floor(sx);
+      y0 = y0 < 0 ? 0 : (y0 > ch - 1 ? ch - 1 : y0);
+      x0 = x0 < 0 ? 0 : (x0 > ch - 1 ? ch - 1 : x0);
+      const int y1 = y0 + 1 < ch ? y0 + 1 : ch - 1, x1 = x0 + 1 < ch ? x0 + 1 : ch - 1;
+      const double ty = sy - (double)y0, tx = sx - (double)x0;
+      const uint8_t* r0 = img + ((size_t)(top + y0) * w + top) * 3;
+      const uint8_t* r1 = img + ((size_t)(top + y1) * w + top) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double a00 = (double)lut[r0[x0 * 3 + c]], a01 = (double)lut[r0[x1 * 3 + c]];
+        const double a10 = (double)lut[r1[x0 * 3 + c]], a11 = (double)lut[r1[x1 * 3 + c]];
+        const double omty = 1.0 - ty, omtx = 1.0 - tx;
+        const double l0 = a00 * omty, l1 = a10 * ty;
+        const double left = l0 + l1;
+        const double g0 = a01 * omty, g1 = a11 * ty;
+        const double right = g0 + g1;
+        const double v0 = left * omtx, v1 = right * tx;
+        const double v = v0 + v1;
+        acc[c] += (float)v;  // out += clipped_zoom(x, z): fp32 accumulate of the fp32-cast zoom
+      }
+    }
+    const float denom = (float)(zp.count + 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = (lut[in[p * 3 + c]] + acc[c]) / denom;
+      v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+      out[p * 3 + c] = (uint8_t)(uint32_t)(v * 255.0f);  // float32 * 255 -> np.uint8
+    }
+  }
+}
+
+}  // namespace
+#pragma clang fp contract(fast)
+
+static const double kPixelate[5] = {0.6, 0.5, 0.4, 0.3, 0.25};
+
+static int zoom_factors(int severity, double* f) {
+  // np.arange(start, stop, step): n = ceil((stop - start)/step), value_i = start + i*step
+  static const double stop[5] = {1.11, 1.16, 1.21, 1.26, 1.31}, step[5] = {0.01, 0.01, 0.02, 0.02, 0.03};
+  const int n = (int)ceil((stop[severity - 1] - 1.0) / step[severity - 1]);
+  for (int i = 0; i < n; ++i) f[i] = 1.0 + i * step[severity - 1];
+  return n;
+}
+
+size_t rart_ws_resample(int id, int severity, int n, int h, int w) {
+  if (id != RART_PIXELATE || severity < 1 || severity > 5) return 0;
+  const int s = (int)(224 * kPixelate[severity - 1]);
+  // tables (2 x 256 entries) + three intermediates: [h][s], [s][s], [s][w]
+  return rart_align_up(2 * 256 * sizeof(BoxEntry), 256) + rart_align_up((size_t)n * h * s * 3, 256) +
+         rart_align_up((size_t)n * s * s * 3, 256) + rart_align_up((size_t)n * s * w * 3, 256);
+}
+
+int rart_launch_resample(int id, const RartCorruptArgs& a) {
+  if (id == RART_PIXELATE) {
+    RART_CHECK_ARG(a.h == 224 && a.w == 224, "pixelate: reference hard-codes 224x224 (corruptions.py:388-389)");
+    const int s = (int)(224 * kPixelate[a.severity - 1]);
+    uint8_t* ws = (uint8_t*)a.workspace;
+    BoxEntry* t_down = (BoxEntry*)ws;
+    BoxEntry* t_up = t_down + 256;
+    ws += rart_align_up(2 * 256 * sizeof(BoxEntry), 256);
+    uint8_t* b1 = ws;  // [n][224][s]
+    ws += rart_align_up((size_t)a.n * a.h * s * 3, 256);
+    uint8_t* b2 = ws;  // [n][s][s]
+    ws += rart_align_up((size_t)a.n * s * s * 3, 256);
+    uint8_t* b3 = ws;  // [n][s][224]
+    hipLaunchKernelGGL(k_box_table, dim3(1), dim3(256), 0, a.stream, t_down, 224, s);
+    hipLaunchKernelGGL(k_box_table, dim3(1), dim3(256), 0, a.stream, t_up, s, 224);
+    // Pillow: horizontal pass first (uint8 intermediate), then vertical -- twice
+    hipLaunchKernelGGL(k_box_pass<1>, dim3(rart_grid_for((size_t)a.n * 224 * s * 3)), dim3(kBlock), 0, a.stream,
+                       a.in, b1, t_down, a.n, 224, 224, 224, s);
+    hipLaunchKernelGGL(k_box_pass<0>, dim3(rart_grid_for((size_t)a.n * s * s * 3)), dim3(kBlock), 0, a.stream, b1,
+                       b2, t_down, a.n, 224, s, s, s);
+    hipLaunchKernelGGL(k_box_pass<1>, dim3(rart_grid_for((size_t)a.n * s * 224 * 3)), dim3(kBlock), 0, a.stream, b2,
+                       b3, t_up, a.n, s, s, s, 224);
+    hipLaunchKernelGGL(k_box_pass<0>, dim3(rart_grid_for((size_t)a.n * 224 * 224 * 3)), dim3(kBlock), 0, a.stream,
+                       b3, a.out, t_up, a.n, s, 224, 224, 224);
+    RART_CHECK_LAUNCH("pixelate");
+    return RART_OK;
+  }
+  if (id == RART_ZOOM_BLUR) {
+    RART_CHECK_ARG(a.h == a.w, "zoom_blur: square images only (clipped_zoom crops h x h, corruptions.py:105-110)");
+    RART_CHECK_ARG(a.in != a.out, "zoom_blur cannot run in place through this entry (gather reads neighbours); "
+                                  "the Python layer stages a copy");
+    double f[16];
+    ZoomParams zp;
+    zp.count = zoom_factors(a.severity, f);
+    for (int i = 0; i < zp.count; ++i) {
+      const int ch = (int)ceil((double)a.h / f[i]);
+      zp.ch[i] = ch;
+      zp.top[i] = (a.h - ch) / 2;
+      zp.out_n[i] = (int)nearbyint((double)ch * f[i]);  // Python round(): half to even
+      zp.trim[i] = (zp.out_n[i] - a.h) / 2;
+    }
+    hipLaunchKernelGGL(k_zoom_blur, dim3(rart_grid_for((size_t)a.n * a.h * a.w, kBlock, 256 * 16)), dim3(kBlock), 0,
+                       a.stream, a.in, a.out, a.n, a.h, a.w, zp);
+    RART_CHECK_LAUNCH("zoom_blur");
+    return RART_OK;
+  }
+  rart_set_error("rart_launch_resample: bad id %d", id);
+  return RART_ERR_INVALID;
+}

@@ -1,0 +1,420 @@
+// Stencil corruptions for gfx950: gaussian_blur, glass_blur, defocus_blur, motion_blur.
+// Reference: RobustART/noise/utils/imagenet_c/corruptions.py:26-51,162-216.
+// Third-party semantics restated: skimage.filters.gaussian ==
+// scipy.ndimage.gaussian_filter (separable, edge-replicate, truncate 4, fp64, symmetric-pair
+// summation order of scipy's correlate1d); cv2.filter2D (correlation, BORDER_REFLECT_101, fp64);
+// cv2.GaussianBlur on the aliased disk (fp32); ImageMagick MotionBlurImage (one-sided gaussian
+// taps along the angle, edge virtual pixels, 8-bit requantisation).
+#include "rart_common.h"
+#include <math.h>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int MAXR = 24;  // gaussian_blur sigma 6 -> radius int(4*6+0.5)
+
+struct GaussW {
+  int radius;
+  double w[2 * MAXR + 1];
+};
+
+// scipy _gaussian_kernel1d
+GaussW make_gauss(double sigma, double truncate) {
+  GaussW g;
+  g.radius = (int)(truncate * sigma + 0.5);
+  double sum = 0.0;
+  for (int i = -g.radius; i <= g.radius; ++i) {
+    const double v = exp(-0.5 / (sigma * sigma) * (double)(i * i));
+    g.w[i + g.radius] = v;
+    sum += v;
+  }
+  for (int i = 0; i <= 2 * g.radius; ++i) g.w[i] /= sum;
+  return g;
+}
+
+// Pass 1 (axis 0 = image rows / H): u8 -> fp64 intermediate.  Pass 2 (axis 1 = W): fp64 -> u8.
+// scipy correlate1d symmetric path: tmp = in[l]*w[r]; for jj=-r..-1: tmp += (in[l+jj] + in[l-jj]) * w[jj+r].
+// MODE_IN 0: source is uint8 (value/255.0); 1: source is fp64.
+// FINISH 0: store fp64; 1: np.uint8(v*255) (glass_blur first blur, no clip); 2: np.uint8(clip(v,0,1)*255).
+template <int AXIS, int MODE_IN, int FINISH>
+__global__ __launch_bounds__(kBlock) void k_gauss_pass(const void* __restrict__ src, void* __restrict__ dst, int n,
+                                                       int h, int w, GaussW g) {
+  const size_t total = (size_t)n * h * w * 3;
+  const int len = AXIS == 0 ? h : w;
+  const size_t stride = AXIS == 0 ? (size_t)w * 3 : 3;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const size_t pix = i / 3;
+    const int xo = (int)(pix % w);
+    const int yo = (int)((pix / w) % h);
+    const int l = AXIS == 0 ? yo : xo;
+    const size_t base = i - (size_t)l * stride;  // element at position 0 along the axis
+    auto at = [&](int p) -> double {
+      p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);  // mode='nearest'
+      const size_t idx = base + (size_t)p * stride;
+      if (MODE_IN == 0) return (double)((const uint8_t*)src)[idx] / 255.0;
+      return ((const double*)src)[idx];
+    };
+    double tmp = at(l) * g.w[g.radius];
+    for (int jj = -g.radius; jj < 0; ++jj) {
+      const double pair = at(l + jj) + at(l - jj);
+      tmp += pair * g.w[jj + g.radius];
+    }
+    if (FINISH == 0) {
+      ((double*)dst)[i] = tmp;
+    } else if (FINISH == 1) {
+      ((uint8_t*)dst)[i] = (uint8_t)(uint32_t)(tmp * 255.0);
+    } else {
+      const double c = tmp < 0.0 ? 0.0 : (tmp > 1.0 ? 1.0 : tmp);
+      ((uint8_t*)dst)[i] = (uint8_t)(uint32_t)(c * 255.0);
+    }
+  }
+}
+
+// ---- glass_blur local shuffle -------------------------------------------------------------
+// corruptions.py:176-182: for h in 224-d..d+1 (desc), w likewise: swap (h,w) <-> (h+dy, w+dx).
+// Sequential per image, but swap (h,w) can only touch pixels within d of (h,w), so two swaps
+// conflict only if both coordinates differ by <= 2d.  Rows are therefore pipelined with a skew of
+// S = 2d+1 columns: at time t row index a (h = 224-d-a) handles column index b = t - a*S.  Swaps
+// issued in the same time step are >= S columns apart (no conflict) and every earlier-in-scan
+// conflicting swap has a strictly smaller time.  One workgroup per image, image resident in LDS.
+constexpr int kGlassThreads = 128;
+
+__global__ __launch_bounds__(kGlassThreads) void k_glass_shuffle(uint8_t* __restrict__ img_all, int delta, int iters,
+                                                                 const int8_t* __restrict__ inj, uint32_t k0,
+                                                                 uint32_t k1, uint32_t sample_base) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // 224*224*3
+  constexpr int HW = 224;
+  uint8_t* g = img_all + (size_t)blockIdx.x * HW * HW * 3;
+  const uint4* g4 = reinterpret_cast<const uint4*>(g);
+  uint4* l4 = reinterpret_cast<uint4*>(lds);
+  for (int i = threadIdx.x; i < HW * HW * 3 / 16; i += kGlassThreads) l4[i] = g4[i];
+  __syncthreads();
+  const int N = HW - 2 * delta;  // loop trip count per axis
+  const int S = 2 * delta + 1;
+  const int8_t* dr = inj ? inj + (size_t)blockIdx.x * iters * N * N * 2 : nullptr;
+  const uint32_t sample = sample_base + blockIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    const int T = (N - 1) * S + N;
+    for (int t = 0; t < T; ++t) {
+      for (int a = threadIdx.x; a < N; a += kGlassThreads) {
+        const int b = t - a * S;
+        if (b >= 0 && b < N) {
+          int dx, dy;
+          const size_t di = ((size_t)it * N + a) * N + b;
+          if (dr) {
+            dx = dr[di * 2];
+            dy = dr[di * 2 + 1];
+          } else {
+            const uint2 wv = threefry2x32(k0, k1, rart_ctr0((uint32_t)di, 4), sample);
+            dx = (int)__umulhi(wv.x, (uint32_t)(2 * delta)) - delta;  // randint(-d, d): upper bound exclusive
+            dy = (int)__umulhi(wv.y, (uint32_t)(2 * delta)) - delta;
+          }
+          const int hh = HW - delta - a, ww = HW - delta - b;
+          uint8_t* p = lds + ((size_t)hh * HW + ww) * 3;
+          uint8_t* q = lds + ((size_t)(hh + dy) * HW + (ww + dx)) * 3;
+          const uint8_t p0 = p[0], p1 = p[1], p2 = p[2];
+          const uint8_t q0 = q[0], q1 = q[1], q2 = q[2];
+          p[0] = q0; p[1] = q1; p[2] = q2;
+          q[0] = p0; q[1] = p1; q[2] = p2;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  uint4* o4 = reinterpret_cast<uint4*>(g);
+  for (int i = threadIdx.x; i < HW * HW * 3 / 16; i += kGlassThreads) o4[i] = l4[i];
+}
+
+// ---- defocus_blur ---------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  const int period = 2 * (n - 1);
+  i %= period;
+  if (i < 0) i += period;
+  return i >= n ? period - i : i;
+}
+
+// cv2.filter2D(plane fp64, -1, kernel): row-major tap order, fp64 multiply-add (not contracted)
+__global__ __launch_bounds__(kBlock) void k_filter2d(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int n,
+                                                     int h, int w, const double* __restrict__ kern, int ksz) {
+  __shared__ double lut[256];
+  lut[threadIdx.x] = (double)threadIdx.x / 255.0;
+  __syncthreads();
+  const int r = ksz / 2;
+  const size_t pixels = (size_t)n * h * w;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < pixels; p += (size_t)gridDim.x * kBlock) {
+    const int xo = (int)(p % w);
+    const int yo = (int)((p / w) % h);
+    const uint8_t* img = in + (p / ((size_t)h * w)) * (size_t)h * w * 3;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int a = 0; a < ksz; ++a) {
+      const int yy = reflect101(yo + a - r, h);
+      const uint8_t* row = img + (size_t)yy * w * 3;
+      for (int b = 0; b < ksz; ++b) {
+        const int xx = reflect101(xo + b - r, w);
+        const double kv = kern[a * ksz + b];
+        const double t0 = lut[row[xx * 3]] * kv, t1 = lut[row[xx * 3 + 1]] * kv, t2 = lut[row[xx * 3 + 2]] * kv;
+        a0 += t0;
+        a1 += t1;
+        a2 += t2;
+      }
+    }
+    const double v[3] = {a0, a1, a2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double cl = v[c] < 0.0 ? 0.0 : (v[c] > 1.0 ? 1.0 : v[c]);
+      out[p * 3 + c] = (uint8_t)(uint32_t)(cl * 255.0);
+    }
+  }
+}
+
+// ---- motion_blur (ImageMagick) -----------------------------------------------------------------
+struct MotionTab {
+  int offx[41], offy[41];
+};
+
+// one block per image: offsets from the angle (injected or drawn from host-mirrored stream 8)
+__global__ void k_motion_offsets(MotionTab* __restrict__ tab, const double* __restrict__ angles, int width,
+                                 double lo, double hi, uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  const int img = blockIdx.x;
+  double ang;
+  if (angles) {
+    ang = angles[img];
+  } else {
+    const uint2 wv = threefry2x32(k0, k1, rart_ctr0(0, 8), sample_base + img);
+    const double u = ((double)(wv.x >> 5) * 67108864.0 + (double)(wv.y >> 6)) / 9007199254740992.0;
+    ang = lo + (hi - lo) * u;
+  }
+  const int i = threadIdx.x;
+  if (i < width) {
+    const double a = ang * (M_PI / 180.0);
+    const double px = (double)width * sin(a), py = (double)width * cos(a);
+    const double hyp = hypot(px, py);
+    tab[img].offx[i] = (int)ceil((double)i * py / hyp - 0.5);
+    tab[img].offy[i] = (int)ceil((double)i * px / hyp - 0.5);
+  }
+}
+
+struct MotionK {
+  int width;
+  double k[41];
+};
+
+// CH = 3 (RGB image) or 1 (snow layer); out = floor(sum_i k[i] * in(x+offx[i], y+offy[i]) + 0.5), edge clamp
+template <int CH>
+__global__ __launch_bounds__(kBlock) void k_motion_blur(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        int n, int h, int w, const MotionTab* __restrict__ tab,
+                                                        MotionK mk) {
+  __shared__ MotionTab st;
+  const size_t per_img = (size_t)h * w;
+  // grid: (chunks, n)
+  const int img = blockIdx.y;
+  if (threadIdx.x < 41) {
+    st.offx[threadIdx.x] = tab[img].offx[threadIdx.x];
+    st.offy[threadIdx.x] = tab[img].offy[threadIdx.x];
+  }
+  __syncthreads();
+  const uint8_t* src = in + (size_t)img * per_img * CH;
+  uint8_t* dst = out + (size_t)img * per_img * CH;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < per_img; p += (size_t)gridDim.x * kBlock) {
+    const int xo = (int)(p % w), yo = (int)(p / w);
+    double acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+    for (int t = 0; t < mk.width; ++t) {
+      int yy = yo + st.offy[t], xx = xo + st.offx[t];
+      yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+      const uint8_t* s = src + ((size_t)yy * w + xx) * CH;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const double term = mk.k[t] * (double)s[c];
+        acc[c] += term;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      double v = floor(acc[c] + 0.5);
+      v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+      dst[p * CH + c] = (uint8_t)(uint32_t)v;
+    }
+  }
+}
+
+MotionK make_motion_kernel(double radius, double sigma) {
+  MotionK mk;
+  mk.width = (int)(2.0 * ceil(radius) + 1.0);
+  double norm = 0.0;
+  for (int i = 0; i < mk.width; ++i) {
+    mk.k[i] = exp(-((double)i * (double)i) / (2.0 * sigma * sigma)) / (sqrt(2.0 * M_PI) * sigma);
+    norm += mk.k[i];
+  }
+  for (int i = 0; i < mk.width; ++i) mk.k[i] /= norm;
+  return mk;
+}
+
+// ---- host: the anti-aliased disk of defocus_blur (corruptions.py:26-38) ------------------------
+// float32 arithmetic mirrors numpy: aliased /= sum (float32), then cv2.GaussianBlur ksize 3 or 5 as two
+// float32 passes with BORDER_REFLECT_101.
+int host_reflect101(int i, int n) {
+  const int period = 2 * (n - 1);
+  i %= period;
+  if (i < 0) i += period;
+  return i >= n ? period - i : i;
+}
+
+std::vector<double> make_disk(int radius, double alias, int* ksz_out) {
+  int half, ks;
+  if (radius <= 8) { half = 8; ks = 3; } else { half = radius; ks = 5; }
+  const int n = 2 * half + 1;
+  std::vector<float> d((size_t)n * n);
+  float sum = 0.f;
+  // np.sum(float32 array) uses pairwise summation; every term is 0 or 1 so any order is exact here
+  for (int y = -half; y <= half; ++y)
+    for (int x = -half; x <= half; ++x) {
+      const float v = (x * x + y * y) <= radius * radius ? 1.f : 0.f;
+      d[(size_t)(y + half) * n + (x + half)] = v;
+      sum += v;
+    }
+  for (auto& v : d) v = v / sum;
+  // cv2.getGaussianKernel(ks, alias, CV_32F)
+  std::vector<float> k(ks);
+  {
+    std::vector<double> kd(ks);
+    double s = 0.0;
+    for (int i = 0; i < ks; ++i) {
+      const double x = (double)i - (ks - 1) * 0.5;
+      kd[i] = exp(-(x * x) / (2.0 * alias * alias));
+      s += kd[i];
+    }
+    for (int i = 0; i < ks; ++i) k[i] = (float)(kd[i] / s);
+  }
+  const int r = ks / 2;
+  std::vector<float> tmp((size_t)n * n, 0.f), out((size_t)n * n, 0.f);
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      volatile float acc = 0.f;
+      for (int t = 0; t < ks; ++t) {
+        volatile float prod = d[(size_t)y * n + host_reflect101(x + t - r, n)] * k[t];
+        acc = acc + prod;
+      }
+      tmp[(size_t)y * n + x] = acc;
+    }
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      volatile float acc = 0.f;
+      for (int t = 0; t < ks; ++t) {
+        volatile float prod = tmp[(size_t)host_reflect101(y + t - r, n) * n + x] * k[t];
+        acc = acc + prod;
+      }
+      out[(size_t)y * n + x] = acc;
+    }
+  *ksz_out = n;
+  return std::vector<double>(out.begin(), out.end());
+}
+
+const double kGaussBlurSigma[5] = {1, 2, 3, 4, 6};
+const double kGlass[5][3] = {{0.7, 1, 2}, {0.9, 2, 1}, {1, 2, 3}, {1.1, 3, 2}, {1.5, 4, 2}};
+const double kDefocus[5][2] = {{3, 0.1}, {4, 0.5}, {6, 0.5}, {8, 0.5}, {10, 0.5}};
+const double kMotion[5][2] = {{10, 3}, {15, 5}, {15, 8}, {15, 12}, {20, 15}};
+
+template <int FINISH>
+void gauss_u8_to_u8(const uint8_t* in, uint8_t* out, double* tmp, int n, int h, int w, const GaussW& g,
+                    hipStream_t s) {
+  const int grid = rart_grid_for((size_t)n * h * w * 3, kBlock, 256 * 16);
+  hipLaunchKernelGGL((k_gauss_pass<0, 0, 0>), dim3(grid), dim3(kBlock), 0, s, (const void*)in, (void*)tmp, n, h, w, g);
+  hipLaunchKernelGGL((k_gauss_pass<1, 1, FINISH>), dim3(grid), dim3(kBlock), 0, s, (const void*)tmp, (void*)out, n,
+                     h, w, g);
+}
+}  // namespace
+#pragma clang fp contract(fast)
+
+// Shared with corrupt_composite.hip (snow uses the same ImageMagick motion blur on its 1-channel layer)
+int rart_motion_blur_gray(const uint8_t* in, uint8_t* out, int n, int h, int w, double radius, double sigma,
+                          const double* angles_dev, double lo, double hi, uint64_t seed, uint64_t sample_offset,
+                          void* tab_ws, hipStream_t s) {
+  const MotionK mk = make_motion_kernel(radius, sigma);
+  MotionTab* tab = (MotionTab*)tab_ws;
+  hipLaunchKernelGGL(k_motion_offsets, dim3(n), dim3(64), 0, s, tab, angles_dev, mk.width, lo, hi, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), (uint32_t)sample_offset);
+  uint32_t gx = (uint32_t)(((size_t)h * w + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_motion_blur<1>, dim3(gx, n), dim3(kBlock), 0, s, in, out, n, h, w, tab, mk);
+  return RART_OK;
+}
+size_t rart_motion_tab_bytes(int n) { return rart_align_up((size_t)n * sizeof(MotionTab), 256); }
+
+size_t rart_ws_stencil(int id, int /*severity*/, int n, int h, int w) {
+  const size_t tmp = rart_align_up((size_t)n * h * w * 3 * sizeof(double), 256);
+  switch (id) {
+    case RART_GAUSSIAN_BLUR: return tmp;
+    case RART_GLASS_BLUR: return tmp + rart_align_up((size_t)n * h * w * 3, 256);
+    case RART_DEFOCUS_BLUR: return rart_align_up(21 * 21 * sizeof(double), 256);
+    case RART_MOTION_BLUR: return rart_motion_tab_bytes(n);
+  }
+  return 0;
+}
+
+int rart_launch_stencil(int id, const RartCorruptArgs& a) {
+  const int s = a.severity - 1;
+  const void* inj0 = (a.injected && a.n_injected > 0) ? a.injected[0] : nullptr;
+  switch (id) {
+    case RART_GAUSSIAN_BLUR: {
+      const GaussW g = make_gauss(kGaussBlurSigma[s], 4.0);
+      gauss_u8_to_u8<2>(a.in, a.out, (double*)a.workspace, a.n, a.h, a.w, g, a.stream);
+      break;
+    }
+    case RART_GLASS_BLUR: {
+      RART_CHECK_ARG(a.h == 224 && a.w == 224, "glass_blur: reference hard-codes 224x224 (corruptions.py:177-178)");
+      const GaussW g = make_gauss(kGlass[s][0], 4.0);
+      double* tmp = (double*)a.workspace;
+      uint8_t* mid = (uint8_t*)a.workspace + rart_align_up((size_t)a.n * a.h * a.w * 3 * sizeof(double), 256);
+      gauss_u8_to_u8<1>(a.in, mid, tmp, a.n, a.h, a.w, g, a.stream);
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_glass_shuffle, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                224 * 224 * 3) != hipSuccess) {
+          rart_set_error("glass_blur: cannot raise the dynamic LDS limit");
+          return RART_ERR_HIP;
+        }
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_glass_shuffle, dim3(a.n), dim3(kGlassThreads), 224 * 224 * 3, a.stream, mid,
+                         (int)kGlass[s][1], (int)kGlass[s][2], (const int8_t*)inj0, (uint32_t)a.seed,
+                         (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
+      gauss_u8_to_u8<2>(mid, a.out, tmp, a.n, a.h, a.w, g, a.stream);
+      break;
+    }
+    case RART_DEFOCUS_BLUR: {
+      // disk tables are tiny and fixed per severity: built once, kept for the process lifetime so the
+      // async upload below never reads freed host memory
+      static std::vector<double> disks[5];
+      static int ksz[5];
+      if (disks[s].empty()) disks[s] = make_disk((int)kDefocus[s][0], kDefocus[s][1], &ksz[s]);
+      if (hipMemcpyAsync(a.workspace, disks[s].data(), disks[s].size() * sizeof(double), hipMemcpyHostToDevice,
+                         a.stream) != hipSuccess) {
+        rart_set_error("defocus_blur: kernel upload failed");
+        return RART_ERR_HIP;
+      }
+      hipLaunchKernelGGL(k_filter2d, dim3(rart_grid_for((size_t)a.n * a.h * a.w, kBlock, 256 * 16)), dim3(kBlock), 0,
+                         a.stream, a.in, a.out, a.n, a.h, a.w, (const double*)a.workspace, ksz[s]);
+      break;
+    }
+    case RART_MOTION_BLUR: {
+      const MotionK mk = make_motion_kernel(kMotion[s][0], kMotion[s][1]);
+      MotionTab* tab = (MotionTab*)a.workspace;
+      hipLaunchKernelGGL(k_motion_offsets, dim3(a.n), dim3(64), 0, a.stream, tab, (const double*)inj0, mk.width,
+                         -45.0, 45.0, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
+      uint32_t gx = (uint32_t)(((size_t)a.h * a.w + kBlock - 1) / kBlock);
+      hipLaunchKernelGGL(k_motion_blur<3>, dim3(gx, a.n), dim3(kBlock), 0, a.stream, a.in, a.out, a.n, a.h, a.w, tab,
+                         mk);
+      break;
+    }
+    default:
+      rart_set_error("rart_launch_stencil: bad id %d", id);
+      return RART_ERR_INVALID;
+  }
+  RART_CHECK_LAUNCH("stencil corruption launch");
+  return RART_OK;
+}

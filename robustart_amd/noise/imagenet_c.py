@@ -70,9 +70,6 @@ def _as_device_batch(x):
 def _host_draws(name, n, severity, seed, offset):
     """Native-mode per-image scalar draws made on the host (counter based, stream ids >= 8)."""
     torch = _lib.require_gpu()
-    if name == 'motion_blur':
-        ang = np.array([-45.0 + 90.0 * _rng.host_uniform(seed, offset + i, 8) for i in range(n)])
-        return {'angle': ang}
     if name == 'frost':
         if not _frost_textures:
             raise FileNotFoundError(
@@ -112,7 +109,11 @@ def corrupt_batch_(batch, corruption_id, severity, seed=None, sample_offset=None
         for key, dt in _INJECT_LAYOUT[name]:
             if key not in draws:
                 break
-            a = np.ascontiguousarray(np.asarray(draws[key]), dtype=dt)
+            v = draws[key]
+            if isinstance(v, (list, tuple)) and len(v) and isinstance(v[0], (list, tuple)):
+                # per-image list of arrays (fog: the successive np.random.uniform results) -> [n][flat]
+                v = np.stack([np.concatenate([np.asarray(q).ravel() for q in per]) for per in v])
+            a = np.ascontiguousarray(np.asarray(v), dtype=dt)
             t = torch.from_numpy(a.reshape(-1).view(np.uint8) if a.dtype != np.uint8 else a.reshape(-1)).cuda()
             keep.append(t)
             arrs.append(t.data_ptr())

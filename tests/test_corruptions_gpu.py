@@ -34,14 +34,23 @@ def _oracle_batch(name, batch, sev, seed):
     rs = np.random.RandomState(seed)
     per = [O.draw(name, batch[i], sev, rs) for i in range(batch.shape[0])]
     want = np.stack([O.corrupt(name, batch[i], sev, per[i]) for i in range(batch.shape[0])])
-    stacked = {k: np.stack([np.asarray(p[k]) for p in per]) for k in per[0]} if per[0] else None
+    stacked = None
+    if per[0]:
+        stacked = {k: ([p[k] for p in per] if isinstance(per[0][k], list) else np.stack([np.asarray(p[k]) for p in per]))
+                   for k in per[0]}
     return want, stacked
 
 
 # ---- injected (bit-exact) ---------------------------------------------------------------
 
 BITEXACT_INJECTED = ['gaussian_noise', 'speckle_noise', 'shot_noise', 'impulse_noise', 'contrast',
-                     'brightness', 'saturate']
+                     'brightness', 'saturate', 'pixelate', 'jpeg_compression', 'zoom_blur', 'fog']
+
+# fp corruptions whose third-party arithmetic (exp/sin/cos of the device libm, summation inside
+# OpenCV/ImageMagick) is restated rather than shared: (max LSB difference, max fraction of elements)
+TOLERANT_INJECTED = {'gaussian_blur': (1, 1e-5), 'defocus_blur': (1, 1e-5), 'motion_blur': (1, 1e-5),
+                     'glass_blur': (1, 1e-5), 'snow': (1, 1e-5), 'elastic_transform': (1, 1e-4),
+                     'spatter': (1, 1e-5)}
 
 
 @pytest.mark.parametrize('name', BITEXACT_INJECTED)
@@ -51,6 +60,57 @@ def test_injected_bit_exact(name, sev):
     want, draws = _oracle_batch(name, batch, sev, case_seed(name, sev))
     got = _run(name, batch, sev, draws)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('name', sorted(TOLERANT_INJECTED))
+@pytest.mark.parametrize('sev', [1, 3, 5])
+def test_injected_within_stated_tolerance(name, sev):
+    if name == 'spatter' and sev < 4:
+        from robustart_amd._lib import RartError
+        with pytest.raises(RartError, match='water branch'):       # documented gap: fails loudly
+            _run(name, make_batch_u8(1), sev)
+        return
+    nimg = 1 if name == 'glass_blur' else 2
+    batch = make_batch_u8(nimg, seed=40 + sev)
+    want, draws = _oracle_batch(name, batch, sev, case_seed(name, sev))
+    got = _run(name, batch, sev, draws)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    max_lsb, max_frac = TOLERANT_INJECTED[name]
+    print('%s sev %d: max diff %d, mismatching fraction %.3g' % (name, sev, diff.max(), (diff != 0).mean()))
+    assert diff.max() <= max_lsb and (diff != 0).mean() <= max_frac
+
+
+def test_hip_matches_reference_golden_crops():
+    """Direct pin against the reference's own outputs (tests/golden/corruptions_ref.npz)."""
+    import os
+    from _inputs import RUNNABLE
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'corruptions_ref.npz'))
+    for name in RUNNABLE:
+        for sev in (1, 2, 3, 4, 5):
+            x = make_image(sev)
+            d = O.draw(name, x, sev, np.random.RandomState(case_seed(name, sev)))
+            draws = {k: ([v] if isinstance(v, list) else np.asarray(v)[None]) for k, v in d.items()} if d else None
+            got = _run(name, x[None], sev, draws)[0]
+            np.testing.assert_array_equal(got[80:144, 80:144], gold[f'{name}/{sev}/crop'], err_msg=f'{name}/{sev}')
+
+
+@pytest.mark.parametrize('name', [n for n in NAMES if n != 'frost'])
+def test_native_mode_deterministic_and_shard_invariant(name):
+    sev = 4
+    batch = make_batch_u8(3, seed=60)
+    a = _run(name, batch, sev, None, 17, 500)
+    b = _run(name, batch, sev, None, 17, 500)
+    np.testing.assert_array_equal(a, b)
+    c = np.concatenate([_run(name, batch[:2], sev, None, 17, 500), _run(name, batch[2:], sev, None, 17, 502)])
+    np.testing.assert_array_equal(a, c)
+    assert (a != batch).mean() > 0.05
+    # in place == out of place
+    from robustart_amd.noise import imagenet_c as C
+    src = torch.from_numpy(batch.copy()).cuda()
+    dst = torch.empty_like(src)
+    C.corrupt_batch_(src, _cid(name), sev, seed=17, sample_offset=500, out=dst)
+    np.testing.assert_array_equal(dst.cpu().numpy(), a)
+    np.testing.assert_array_equal(src.cpu().numpy(), batch)
 
 
 def test_frost_blend_bit_exact():
