@@ -164,6 +164,64 @@ int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* y_targ
                     int kind, float scale, float* loss_out, float* dlogits_out, int32_t* pred_out,
                     rart_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Eval-mode model engine (ResNet-50 forward / backward-to-input, the `f_model(x)` + autograd step
+ * every attack iteration performs: adv/attack.py:21-22, autopgd_base.py:271-289,367-384,
+ * imfgsm_attack.py:82-84; model definition: RobustART/model/__init__.py:1 -> absent submodule,
+ * public ResNet-50 v1.5).  BatchNorm is folded into the conv weights/bias on the host (eval mode),
+ * activations are bf16 NHWC, accumulation fp32.
+ *
+ * rart_conv_igemm_bf16: C[m][n] = sum_k A[m][k] * W[n][k] with A gathered from `src`:
+ *   row m      <-> (image, oy, ox) over batch x grid_h x grid_w
+ *   k          =  tap * k_per_tap + c,  tap t reads source pixel (oy*sy + tap_dy[t], ox*sx + tap_dx[t])
+ *                 of the (src_h x src_w) image at element offset tap_src_off[t] + pixel*src_pix_stride + c
+ *                 (zeros outside the image)
+ *   W          :  bf16 [round_up(n_cols, 128 if n_cols > 64 else 64)][n_taps * k_per_tap], K contiguous
+ *   destination:  element ((image*dst_h + oy*dst_sy + dst_oy)*dst_w + ox*dst_sx + dst_ox)*dst_pix_stride + n
+ *   epilogue   :  v = acc + bias[n]; v += res[dst index]; if (mask) v = mask[dst index] > 0 ? v : 0;
+ *                 if (flags & 1) v = max(v, 0); store bf16 (or fp32 if flags & 2).  `res` may alias `dst`.
+ * Covers forward convs, backward-to-input of stride-1 convs, each input-parity class of a stride-2
+ * conv's backward, the 7x7 stem on the padded 4-channel hi/lo image, and fully connected layers.
+ * ------------------------------------------------------------------------------------- */
+typedef struct rart_conv_desc {
+  const void* src;
+  const void* wgt;
+  const float* bias;      /* fp32 [n_cols] or NULL */
+  const void* res;        /* bf16, indexed like dst, or NULL */
+  const void* mask;       /* bf16, indexed like dst, or NULL */
+  void* dst;
+  int32_t batch, grid_h, grid_w;
+  int32_t src_h, src_w, src_pix_stride;
+  int32_t k_per_tap, n_taps;
+  int32_t sy, sx;
+  int32_t tap_dy[16], tap_dx[16];
+  int64_t tap_src_off[16];
+  int32_t n_cols;
+  int32_t dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
+  int32_t flags;          /* 1 = ReLU, 2 = fp32 output */
+} rart_conv_desc;
+
+int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
+
+/* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
+ * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:
+ * the stem convolution's operand (normalisation of imfgsm_attack.py:14-23 / autoattack.py:17-20 fused). */
+int rart_engine_prep_input(const void* src, int src_is_u8, void* hi, void* lo, int n, int h, int w,
+                           const float* mean_host, const float* std_host, rart_stream_t stream);
+/* 3x3 stride-2 pad-1 max pool on bf16 NHWC, and its backward fused with the ReLU mask of its input y. */
+int rart_engine_maxpool(const void* in, void* out, int n, int h, int w, int c, rart_stream_t stream);
+int rart_engine_maxpool_bwd(const void* y, const void* dpool, void* dz, int n, int h, int w, int c,
+                            rart_stream_t stream);
+/* global average pool [n][hw][c] -> [n][c], and dz = (y > 0) ? dpool / hw : 0. */
+int rart_engine_avgpool(const void* in, void* out, int n, int hw, int c, rart_stream_t stream);
+int rart_engine_avgpool_bwd(const void* y, const void* dpool, void* dz, int n, int hw, int c, rart_stream_t stream);
+/* stem backward: bf16 patches [n][h/2][w/2][patch_cols] (column (r*7+s)*3+c) -> fp32 NCHW gradient w.r.t.
+ * the [0,1] image (the 1/std of the normalisation applied). */
+int rart_engine_stem_col2im(const void* patches, float* grad, int n, int h, int w, int patch_cols,
+                            const float* std_host, rart_stream_t stream);
+/* fp32 [rows][cols] -> bf16 [rows][dst_cols] (zero padded): dlogits -> GEMM operand. */
+int rart_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int dst_cols, rart_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,31 @@ SIGNATURES = {
     'rart_select_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_logit_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    'rart_conv_igemm_bf16': (c_int, [c_void_p, c_void_p]),
+    'rart_engine_prep_input': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p]),
+    'rart_engine_maxpool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_maxpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_avgpool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_stem_col2im': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'rart_f32_to_bf16_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
+
+
+class ConvDesc(ctypes.Structure):
+    """rart_conv_desc (include/robustart_hip.h)."""
+    _fields_ = [('src', c_void_p), ('wgt', c_void_p), ('bias', c_void_p), ('res', c_void_p), ('mask', c_void_p),
+                ('dst', c_void_p),
+                ('batch', ctypes.c_int32), ('grid_h', ctypes.c_int32), ('grid_w', ctypes.c_int32),
+                ('src_h', ctypes.c_int32), ('src_w', ctypes.c_int32), ('src_pix_stride', ctypes.c_int32),
+                ('k_per_tap', ctypes.c_int32), ('n_taps', ctypes.c_int32), ('sy', ctypes.c_int32), ('sx', ctypes.c_int32),
+                ('tap_dy', ctypes.c_int32 * 16), ('tap_dx', ctypes.c_int32 * 16), ('tap_src_off', ctypes.c_int64 * 16),
+                ('n_cols', ctypes.c_int32),
+                ('dst_h', ctypes.c_int32), ('dst_w', ctypes.c_int32), ('dst_sy', ctypes.c_int32), ('dst_sx', ctypes.c_int32),
+                ('dst_oy', ctypes.c_int32), ('dst_ox', ctypes.c_int32), ('dst_pix_stride', ctypes.c_int32),
+                ('flags', ctypes.c_int32)]
+
 
 _lib = None
 

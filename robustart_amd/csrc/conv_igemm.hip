@@ -1,0 +1,294 @@
+// bf16 implicit-GEMM convolution for gfx950 (CDNA4): the one dense-contraction kernel of the
+// eval-mode ResNet-50 forward / backward-to-input engine (K22 in SURVEY.md 2.1).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]        A gathered on the fly from an NHWC bf16 tensor
+//
+// m enumerates (image, oy, ox) over a row grid; k = tap * k_per_tap + c; for tap t the source
+// pixel is (oy*sy + dy[t], ox*sx + dx[t]) (zeros outside the image).  The same kernel therefore
+// runs: forward convs (taps = filter taps), backward-to-input of stride-1 convs (taps flipped,
+// weights re-laid on the host), each input-parity class of a stride-2 conv's backward (sub-grid +
+// strided destination), the 7x7 stem on a pre-padded 4-channel image (a "tap" = one filter row of
+// 8 pixels x 4 channels, hi/lo bf16 split of the fp32 pixels as extra taps), and plain GEMMs (fc).
+//
+// Design for MI355X: 128 x {128,64} x 32 block tile, 4 wave64s each owning a 64 x {64,32} sub-tile
+// of v_mfma_f32_32x32x16_bf16 fragments (fp32 accumulate); A/B staged global -> VGPR -> LDS as 16-byte
+// vectors, double-buffered, one barrier per K step; LDS rows padded to 80 B so ds_read_b128 fragment
+// reads are bank-conflict free; epilogue transposes through LDS (fp32) so bias / residual / ReLU-mask /
+// ReLU are applied on 16-byte rows and stores are coalesced 16 B per lane; block ids are remapped so
+// the column tiles of one row tile run on the same XCD (shared L2 for the re-read A tile).
+// Most ResNet-50 layers are HBM-bound at bf16 (K = 64..512), so the kernel is built around wide
+// coalesced traffic first and MFMA issue second.
+#include "rart_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct RartConvDescDev {
+  const uint16_t* src;
+  const uint16_t* wgt;
+  const float* bias;
+  const uint16_t* res;
+  const uint16_t* mask;
+  void* dst;
+  int batch, grid_h, grid_w;
+  int src_h, src_w, src_pix_stride;
+  int k_per_tap, n_taps;
+  int sy, sx;
+  int tap_dy[16], tap_dx[16];
+  long long tap_src_off[16];
+  int n_cols;
+  int dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
+  int flags;
+};
+
+namespace {
+constexpr int BM = 128, BK = 32, LDK = BK + 8;  // LDS row = 40 bf16 = 80 B
+constexpr int kThreads = 256;
+enum { F_RELU = 1, F_OUT_F32 = 2 };
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite)
+  return (uint16_t)(u >> 16);
+}
+
+template <int BN>
+__global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDescDev d) {
+  constexpr int WN = BN / 2;        // wave sub-tile columns
+  constexpr int TN = WN / 32;       // 32-wide MFMA tiles per wave along n
+  constexpr int B_CHUNKS = BN * 4 / kThreads;  // 16-byte chunks of the W tile per thread (2 or 1)
+  constexpr int LDC = BN + 4;       // fp32 epilogue staging row (floats)
+  constexpr int kLdsBytes = 2 * (BM + BN) * LDK * 2;
+  static_assert(64 * LDC * 4 <= kLdsBytes, "epilogue staging must fit the tile buffers");
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[kLdsBytes + BM * 8];
+  uint16_t* sA = reinterpret_cast<uint16_t*>(lds_raw);               // [2][BM][LDK]
+  uint16_t* sB = sA + 2 * BM * LDK;                                   // [2][BN][LDK]
+  long long* row_dst = reinterpret_cast<long long*>(lds_raw + kLdsBytes);  // [BM] dst element offset or -1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile mapping: all column tiles of a row tile on one XCD ----
+  const int n_tiles = (d.n_cols + BN - 1) / BN;
+  const long long M = (long long)d.batch * d.grid_h * d.grid_w;
+  const int m_tiles = (int)((M + BM - 1) / BM);
+  int m_tile, n_tile;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    m_tile = (slot / n_tiles) * 8 + xcd;
+    n_tile = slot % n_tiles;
+    if (m_tile >= m_tiles) return;
+  }
+  const long long m0 = (long long)m_tile * BM;
+  const int n0 = n_tile * BN;
+
+  // ---- per-thread gather rows (2 rows of the A tile) ----
+  const int chunk = tid & 3;  // which 16 B of the 64 B K-slice
+  int a_by[2], a_bx[2];
+  long long a_img[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long long m = m0 + (tid >> 2) + 64 * i;
+    a_ok[i] = m < M;
+    const long long mm = a_ok[i] ? m : 0;
+    const int ox = (int)(mm % d.grid_w);
+    const long long t = mm / d.grid_w;
+    const int oy = (int)(t % d.grid_h);
+    const int n = (int)(t / d.grid_h);
+    a_by[i] = oy * d.sy;
+    a_bx[i] = ox * d.sx;
+    a_img[i] = (long long)n * d.src_h * d.src_w;
+  }
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < M) {
+      const int ox = (int)(m % d.grid_w);
+      const long long t = m / d.grid_w;
+      const int oy = (int)(t % d.grid_h);
+      const int n = (int)(t / d.grid_h);
+      off = (((long long)n * d.dst_h + (oy * d.dst_sy + d.dst_oy)) * d.dst_w + (ox * d.dst_sx + d.dst_ox)) *
+            d.dst_pix_stride;
+    }
+    row_dst[tid] = off;
+  }
+
+  const int K = d.k_per_tap * d.n_taps;
+  const int KT = K / BK;
+  const int tiles_per_tap = d.k_per_tap / BK;
+
+  uint4 ra[2], rb[B_CHUNKS];
+  auto load_tile = [&](int kt) {
+    const int tap = kt / tiles_per_tap;
+    const int kc = (kt - tap * tiles_per_tap) * BK + chunk * 8;
+    const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];
+    const uint16_t* sbase = d.src + d.tap_src_off[tap];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
+      const bool ok = a_ok[i] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *reinterpret_cast<const uint4*>(sbase + (a_img[i] + (long long)iy * d.src_w + ix) * d.src_pix_stride + kc);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) {
+      const int row = (tid >> 2) + 64 * i;  // weight rows are padded to a multiple of BN on the host
+      rb[i] = *reinterpret_cast<const uint4*>(d.wgt + (long long)(n0 + row) * K + (long long)kt * BK + chunk * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<uint4*>(sA + ((buf * BM + (tid >> 2) + 64 * i) * LDK + chunk * 8)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i)
+      *reinterpret_cast<uint4*>(sB + ((buf * BN + (tid >> 2) + 64 * i) * LDK + chunk * 8)) = rb[i];
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const uint16_t* A = sA + buf * BM * LDK + (wm * 64 + frag_row) * LDK + frag_k;
+    const uint16_t* B = sB + buf * BN * LDK + (wn * WN + frag_row) * LDK + frag_k;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[2], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * LDK + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * LDK + ks * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: two 64-row halves through LDS (fp32), then 16-byte rows out ----
+  float* sC = reinterpret_cast<float*>(lds_raw);
+  constexpr int C8 = BN / 8;              // 8-column chunks per row
+  constexpr int ROWS_PER_PASS = kThreads / C8;
+  const int c8 = tid % C8, r0 = tid / C8;
+  const int col = n0 + c8 * 8;
+  const bool col_ok = col < d.n_cols;
+  float bias8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias8[j] = (d.bias && col_ok) ? d.bias[col + j] : 0.f;
+  const bool relu = d.flags & F_RELU, out_f32 = d.flags & F_OUT_F32;
+
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            sC[row * LDC + wn * WN + j * 32 + (lane & 31)] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    for (int r = r0; r < 64; r += ROWS_PER_PASS) {
+      const long long off = row_dst[h * 64 + r];
+      if (off < 0 || !col_ok) continue;
+      const float4 v0 = *reinterpret_cast<const float4*>(sC + r * LDC + c8 * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(sC + r * LDC + c8 * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+      if (d.res) {
+        const uint4 rv = *reinterpret_cast<const uint4*>(d.res + off + col);
+        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] += bf2f((uint16_t)(rw[j] & 0xFFFF));
+          v[2 * j + 1] += bf2f((uint16_t)(rw[j] >> 16));
+        }
+      }
+      if (d.mask) {
+        const uint4 mv = *reinterpret_cast<const uint4*>(d.mask + off + col);
+        const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!(bf2f((uint16_t)(mw[j] & 0xFFFF)) > 0.f)) v[2 * j] = 0.f;
+          if (!(bf2f((uint16_t)(mw[j] >> 16)) > 0.f)) v[2 * j + 1] = 0.f;
+        }
+      }
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (out_f32) {
+        float* o = reinterpret_cast<float*>(d.dst) + off + col;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        uint4 o;
+        o.x = f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.z = f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        o.w = f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + off + col) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t stream) {
+  RART_CHECK_ARG(h != nullptr, "rart_conv_igemm_bf16: null descriptor");
+  RART_CHECK_ARG(h->src && h->wgt && h->dst, "rart_conv_igemm_bf16: null tensor pointer");
+  RART_CHECK_ARG(h->batch > 0 && h->grid_h > 0 && h->grid_w > 0, "rart_conv_igemm_bf16: empty row grid");
+  RART_CHECK_ARG(h->n_taps >= 1 && h->n_taps <= 16, "rart_conv_igemm_bf16: n_taps must be 1..16");
+  RART_CHECK_ARG(h->k_per_tap > 0 && h->k_per_tap % 32 == 0, "rart_conv_igemm_bf16: k_per_tap must be a multiple of 32");
+  RART_CHECK_ARG(h->n_cols > 0 && h->n_cols % 8 == 0, "rart_conv_igemm_bf16: n_cols must be a multiple of 8");
+  RART_CHECK_ARG(h->src_pix_stride % 8 == 0 || h->src_pix_stride == 4,
+                 "rart_conv_igemm_bf16: source pixels must keep 16-byte alignment of the K chunks");
+  RART_CHECK_ARG(h->dst_pix_stride % 8 == 0, "rart_conv_igemm_bf16: dst_pix_stride must be a multiple of 8");
+  RartConvDescDev d;
+  d.src = (const uint16_t*)h->src; d.wgt = (const uint16_t*)h->wgt; d.bias = h->bias;
+  d.res = (const uint16_t*)h->res; d.mask = (const uint16_t*)h->mask; d.dst = h->dst;
+  d.batch = h->batch; d.grid_h = h->grid_h; d.grid_w = h->grid_w;
+  d.src_h = h->src_h; d.src_w = h->src_w; d.src_pix_stride = h->src_pix_stride;
+  d.k_per_tap = h->k_per_tap; d.n_taps = h->n_taps; d.sy = h->sy; d.sx = h->sx;
+  for (int i = 0; i < 16; ++i) { d.tap_dy[i] = h->tap_dy[i]; d.tap_dx[i] = h->tap_dx[i]; d.tap_src_off[i] = h->tap_src_off[i]; }
+  d.n_cols = h->n_cols; d.dst_h = h->dst_h; d.dst_w = h->dst_w; d.dst_sy = h->dst_sy; d.dst_sx = h->dst_sx;
+  d.dst_oy = h->dst_oy; d.dst_ox = h->dst_ox; d.dst_pix_stride = h->dst_pix_stride; d.flags = h->flags;
+  const long long M = (long long)d.batch * d.grid_h * d.grid_w;
+  const int m_tiles = (int)((M + BM - 1) / BM);
+  const bool wide = d.n_cols > 64;
+  const int bn = wide ? 128 : 64;
+  const int n_tiles = (d.n_cols + bn - 1) / bn;
+  const int m_tiles8 = (m_tiles + 7) / 8 * 8;  // the XCD remap enumerates row tiles in groups of 8
+  const long long blocks = (long long)m_tiles8 * n_tiles;
+  RART_CHECK_ARG(blocks < (1ll << 31), "rart_conv_igemm_bf16: grid too large");
+  if (wide)
+    hipLaunchKernelGGL(k_conv_igemm_bf16<128>, dim3((uint32_t)blocks), dim3(kThreads), 0, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(k_conv_igemm_bf16<64>, dim3((uint32_t)blocks), dim3(kThreads), 0, (hipStream_t)stream, d);
+  RART_CHECK_LAUNCH("rart_conv_igemm_bf16");
+  return RART_OK;
+}

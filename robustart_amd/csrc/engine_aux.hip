@@ -1,0 +1,324 @@
+// Non-GEMM kernels of the eval-mode ResNet-50 engine (gfx950): input preparation (normalise +
+// bf16 hi/lo split + spatial/channel padding for the 7x7 stem), 3x3/2 max-pool forward and
+// backward (+ReLU mask), global average pool forward/backward, the stem's col2im (backward to the
+// fp32 image) and an fp32 -> padded bf16 row converter.  All HBM-bound elementwise/gather work on
+// NHWC bf16 tensors, 16-byte (8-channel) vectors per lane.
+#include "rart_common.h"
+
+namespace {
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = bf2f((uint16_t)(w[j] & 0xFFFF));
+    f[2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 o;
+  o.x = f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+  o.y = f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+  o.z = f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+  o.w = f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  return o;
+}
+
+struct Norm3 {
+  float mean[3], istd[3];
+};
+
+// src: fp32 NCHW in [0,1] (SRC_U8 = false) or uint8 NHWC (SRC_U8 = true).
+// dst hi/lo: bf16 [n][h+8][w+8][4], image at offset (3,3), zero elsewhere; v = (x - mean)/std,
+// hi = bf16(v), lo = bf16(v - hi): hi + lo carries ~16 mantissa bits so eps-sized PGD steps survive.
+template <bool SRC_U8>
+__global__ __launch_bounds__(kBlock) void k_prep_input(const void* __restrict__ src, uint2* __restrict__ hi,
+                                                       uint2* __restrict__ lo, int n, int h, int w, Norm3 nm) {
+  const int ph = h + 8, pw = w + 8;
+  const size_t total = (size_t)n * ph * pw;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < total; p += (size_t)gridDim.x * kBlock) {
+    const int px = (int)(p % pw), py = (int)((p / pw) % ph);
+    const int img = (int)(p / ((size_t)pw * ph));
+    const int x = px - 3, y = py - 3;
+    uint16_t hv[4] = {0, 0, 0, 0}, lv[4] = {0, 0, 0, 0};
+    if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v01;
+        if (SRC_U8)
+          v01 = (float)((const uint8_t*)src)[(((size_t)img * h + y) * w + x) * 3 + c] * (1.0f / 255.0f);
+        else
+          v01 = ((const float*)src)[(((size_t)img * 3 + c) * h + y) * w + x];
+        const float v = (v01 - nm.mean[c]) * nm.istd[c];
+        hv[c] = f2bf(v);
+        lv[c] = f2bf(v - bf2f(hv[c]));
+      }
+    }
+    hi[p] = make_uint2(hv[0] | ((uint32_t)hv[1] << 16), hv[2] | ((uint32_t)hv[3] << 16));
+    lo[p] = make_uint2(lv[0] | ((uint32_t)lv[1] << 16), lv[2] | ((uint32_t)lv[3] << 16));
+  }
+}
+
+// 3x3 stride-2 pad-1 max pool, NHWC bf16, one thread per (output pixel, 8 channels)
+__global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict__ in, uint4* __restrict__ out, int n,
+                                                        int h, int w, int c8) {
+  const int oh = h / 2, ow = w / 2;
+  const size_t total = (size_t)n * oh * ow * c8;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int c = (int)(i % c8);
+    size_t t = i / c8;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int img = (int)(t / oh);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int y = oy * 2 - 1 + ky;
+      if ((unsigned)y >= (unsigned)h) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int x = ox * 2 - 1 + kx;
+        if ((unsigned)x >= (unsigned)w) continue;
+        float f[8];
+        unpack8(in[(((size_t)img * h + y) * w + x) * c8 + c], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
+      }
+    }
+    out[i] = pack8(m);
+  }
+}
+
+// backward of the pool fused with the ReLU mask of its input y (= relu(stem conv)):
+// dz[h,w,c] = (y > 0) * sum over the <= 4 windows containing (h,w) in which (h,w) is the FIRST
+// maximum in (ky,kx) scan order (PyTorch's argmax rule) of dpool[window].
+__global__ __launch_bounds__(kBlock) void k_maxpool_bwd(const uint4* __restrict__ y, const uint4* __restrict__ dpool,
+                                                        uint4* __restrict__ dz, int n, int h, int w, int c8) {
+  const int oh = h / 2, ow = w / 2;
+  const size_t total = (size_t)n * h * w * c8;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int c = (int)(i % c8);
+    size_t t = i / c8;
+    const int x = (int)(t % w);
+    t /= w;
+    const int yy = (int)(t % h);
+    const int img = (int)(t / h);
+    float self[8], g[8];
+    unpack8(y[i], self);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) any |= self[j] > 0.f;
+    if (any) {
+      // the (at most 2 x 2) windows containing (yy, x): window o covers [2o-1, 2o+1]
+      int oys[2], nys = 0, oxs[2], nxs = 0;
+      for (int oy = (yy > 0 ? (yy - 1) / 2 : 0); oy <= (yy + 1) / 2 && oy < oh; ++oy)
+        if (2 * oy - 1 <= yy && yy <= 2 * oy + 1) oys[nys++] = oy;
+      for (int ox = (x > 0 ? (x - 1) / 2 : 0); ox <= (x + 1) / 2 && ox < ow; ++ox)
+        if (2 * ox - 1 <= x && x <= 2 * ox + 1) oxs[nxs++] = ox;
+      for (int a = 0; a < nys; ++a)
+        for (int b = 0; b < nxs; ++b) {
+          const int oy = oys[a], ox = oxs[b];
+          // is (yy,x) the first maximum of this window, per channel?
+          bool first[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) first[j] = true;
+          for (int ky = 0; ky < 3; ++ky) {
+            const int y2 = oy * 2 - 1 + ky;
+            if ((unsigned)y2 >= (unsigned)h) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+              const int x2 = ox * 2 - 1 + kx;
+              if ((unsigned)x2 >= (unsigned)w) continue;
+              if (y2 == yy && x2 == x) continue;
+              float f[8];
+              unpack8(y[(((size_t)img * h + y2) * w + x2) * c8 + c], f);
+              const bool before = (y2 < yy) || (y2 == yy && x2 < x);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                if (before ? (f[j] >= self[j]) : (f[j] > self[j])) first[j] = false;
+              }
+            }
+          }
+          float dp[8];
+          unpack8(dpool[(((size_t)img * oh + oy) * ow + ox) * c8 + c], dp);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (first[j]) g[j] += dp[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!(self[j] > 0.f)) g[j] = 0.f;
+    dz[i] = pack8(g);
+  }
+}
+
+// global average pool [n][hw][c] -> [n][c] (bf16), fp32 accumulation
+__global__ __launch_bounds__(kBlock) void k_avgpool_fwd(const uint4* __restrict__ in, uint4* __restrict__ out, int n,
+                                                        int hw, int c8) {
+  const size_t total = (size_t)n * c8;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int c = (int)(i % c8), img = (int)(i / c8);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (int p = 0; p < hw; ++p) {
+      float f[8];
+      unpack8(in[((size_t)img * hw + p) * c8 + c], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+    const float inv = 1.0f / (float)hw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] *= inv;
+    out[i] = pack8(s);
+  }
+}
+
+// dz[n][p][c] = (y > 0) ? dpool[n][c] / hw : 0
+__global__ __launch_bounds__(kBlock) void k_avgpool_bwd(const uint4* __restrict__ y, const uint4* __restrict__ dpool,
+                                                        uint4* __restrict__ dz, int n, int hw, int c8) {
+  const size_t total = (size_t)n * hw * c8;
+  const float inv = 1.0f / (float)hw;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int c = (int)(i % c8), img = (int)(i / ((size_t)hw * c8));
+    float f[8], d[8];
+    unpack8(y[i], f);
+    unpack8(dpool[(size_t)img * c8 + c], d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = f[j] > 0.f ? d[j] * inv : 0.f;
+    dz[i] = pack8(d);
+  }
+}
+
+// Stem backward: patches[n][oh][ow][pc] (bf16, column (r*7+s)*3+c, pc >= 147) -> grad fp32 NCHW
+// dx[n][c][h][w] = istd[c] * sum_{r,s: (h+3-r), (w+3-s) even, p,q in range} patches[n][p][q][(r*7+s)*3+c]
+__global__ __launch_bounds__(kBlock) void k_stem_col2im(const uint16_t* __restrict__ patches, float* __restrict__ grad,
+                                                        int n, int h, int w, int pc, Norm3 nm) {
+  const int oh = h / 2, ow = w / 2;
+  const size_t total = (size_t)n * h * w;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < total; p += (size_t)gridDim.x * kBlock) {
+    const int x = (int)(p % w), y = (int)((p / w) % h);
+    const int img = (int)(p / ((size_t)w * h));
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int r = (y + 3) & 1; r < 7; r += 2) {
+      const int pp = (y + 3 - r) / 2;
+      if ((unsigned)pp >= (unsigned)oh || (y + 3 - r) < 0) continue;
+      for (int s = (x + 3) & 1; s < 7; s += 2) {
+        const int qq = (x + 3 - s) / 2;
+        if ((unsigned)qq >= (unsigned)ow || (x + 3 - s) < 0) continue;
+        const uint16_t* pt = patches + (((size_t)img * oh + pp) * ow + qq) * pc + (r * 7 + s) * 3;
+        g0 += bf2f(pt[0]);
+        g1 += bf2f(pt[1]);
+        g2 += bf2f(pt[2]);
+      }
+    }
+    const size_t plane = (size_t)h * w;
+    float* o = grad + (size_t)img * 3 * plane + (size_t)y * w + x;
+    o[0] = g0 * nm.istd[0];
+    o[plane] = g1 * nm.istd[1];
+    o[2 * plane] = g2 * nm.istd[2];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_f32_to_bf16_rows(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                             int rows, int cols, int dst_cols) {
+  const size_t total = (size_t)rows * dst_cols;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int c = (int)(i % dst_cols);
+    const size_t r = i / dst_cols;
+    dst[i] = c < cols ? f2bf(src[r * cols + c]) : (uint16_t)0;
+  }
+}
+
+Norm3 make_norm(const float* mean, const float* std) {
+  Norm3 nm;
+  for (int c = 0; c < 3; ++c) {
+    nm.mean[c] = mean ? mean[c] : 0.f;
+    nm.istd[c] = std ? 1.0f / std[c] : 1.f;
+  }
+  return nm;
+}
+int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
+}  // namespace
+
+extern "C" {
+
+int rart_engine_prep_input(const void* src, int src_is_u8, void* hi, void* lo, int n, int h, int w,
+                           const float* mean_host, const float* std_host, rart_stream_t stream) {
+  RART_CHECK_ARG(src && hi && lo && n > 0 && h > 0 && w > 0, "rart_engine_prep_input: bad arguments");
+  const Norm3 nm = make_norm(mean_host, std_host);
+  const size_t total = (size_t)n * (h + 8) * (w + 8);
+  if (src_is_u8)
+    hipLaunchKernelGGL(k_prep_input<true>, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, src, (uint2*)hi,
+                       (uint2*)lo, n, h, w, nm);
+  else
+    hipLaunchKernelGGL(k_prep_input<false>, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, src,
+                       (uint2*)hi, (uint2*)lo, n, h, w, nm);
+  RART_CHECK_LAUNCH("rart_engine_prep_input");
+  return RART_OK;
+}
+
+int rart_engine_maxpool(const void* in, void* out, int n, int h, int w, int c, rart_stream_t stream) {
+  RART_CHECK_ARG(in && out && n > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0, "rart_engine_maxpool: bad arguments");
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for((size_t)n * (h / 2) * (w / 2) * (c / 8))), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const uint4*)in, (uint4*)out, n, h, w, c / 8);
+  RART_CHECK_LAUNCH("rart_engine_maxpool");
+  return RART_OK;
+}
+
+int rart_engine_maxpool_bwd(const void* y, const void* dpool, void* dz, int n, int h, int w, int c,
+                            rart_stream_t stream) {
+  RART_CHECK_ARG(y && dpool && dz && n > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0,
+                 "rart_engine_maxpool_bwd: bad arguments");
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint4*)y, (const uint4*)dpool, (uint4*)dz, n, h, w, c / 8);
+  RART_CHECK_LAUNCH("rart_engine_maxpool_bwd");
+  return RART_OK;
+}
+
+int rart_engine_avgpool(const void* in, void* out, int n, int hw, int c, rart_stream_t stream) {
+  RART_CHECK_ARG(in && out && n > 0 && hw > 0 && c % 8 == 0, "rart_engine_avgpool: bad arguments");
+  hipLaunchKernelGGL(k_avgpool_fwd, dim3(grid_for((size_t)n * (c / 8))), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint4*)in, (uint4*)out, n, hw, c / 8);
+  RART_CHECK_LAUNCH("rart_engine_avgpool");
+  return RART_OK;
+}
+
+int rart_engine_avgpool_bwd(const void* y, const void* dpool, void* dz, int n, int hw, int c, rart_stream_t stream) {
+  RART_CHECK_ARG(y && dpool && dz && n > 0 && hw > 0 && c % 8 == 0, "rart_engine_avgpool_bwd: bad arguments");
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_for((size_t)n * hw * (c / 8))), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint4*)y, (const uint4*)dpool, (uint4*)dz, n, hw, c / 8);
+  RART_CHECK_LAUNCH("rart_engine_avgpool_bwd");
+  return RART_OK;
+}
+
+int rart_engine_stem_col2im(const void* patches, float* grad, int n, int h, int w, int patch_cols,
+                            const float* std_host, rart_stream_t stream) {
+  RART_CHECK_ARG(patches && grad && n > 0 && h % 2 == 0 && w % 2 == 0 && patch_cols >= 147,
+                 "rart_engine_stem_col2im: bad arguments");
+  const Norm3 nm = make_norm(nullptr, std_host);
+  hipLaunchKernelGGL(k_stem_col2im, dim3(grid_for((size_t)n * h * w)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint16_t*)patches, grad, n, h, w, patch_cols, nm);
+  RART_CHECK_LAUNCH("rart_engine_stem_col2im");
+  return RART_OK;
+}
+
+int rart_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int dst_cols, rart_stream_t stream) {
+  RART_CHECK_ARG(src && dst && rows > 0 && cols > 0 && dst_cols >= cols, "rart_f32_to_bf16_rows: bad arguments");
+  hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3(grid_for((size_t)rows * dst_cols)), dim3(kBlock), 0, (hipStream_t)stream,
+                     src, (uint16_t*)dst, rows, cols, dst_cols);
+  RART_CHECK_LAUNCH("rart_f32_to_bf16_rows");
+  return RART_OK;
+}
+
+}  // extern "C"

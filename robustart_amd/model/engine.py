@@ -1,0 +1,313 @@
+"""Eval-mode ResNet-50 on the hand-written HIP kernels: forward and backward-to-input.
+
+This is the `f_model(x)` + autograd step that every iteration of the reference's attacks
+performs (RobustART/noise/utils/adv/attack.py:21-22; Attacks/autoattack/autopgd_base.py:271-289,
+367-384; Attacks/imfgsm_attack.py:82-84) and the clean / corrupted evaluation forward
+(SURVEY.md 3.5).  Model definition: RobustART/model/__init__.py:1 -> absent submodule; the public
+ResNet-50 v1.5 (robustart_amd/model/resnet_torch.py is the plain-PyTorch statement of it).
+
+Host side (this file, PyTorch as plumbing only): fold BatchNorm (eval mode) into conv weight/bias,
+lay the weights out for the implicit-GEMM kernel (forward: [Cout][tap][Cin]; backward-to-input:
+[Cin][tap][Cout], one table per input-parity class for stride-2 convs), own the activation / gradient
+buffers, and sequence the C-ABI calls.  Device side: rart_conv_igemm_bf16 (every conv, fc, and their
+backward), rart_engine_* (stem input prep, pools, col2im), rart_logit_loss.  bf16 storage, fp32
+accumulation; the fp32 pixels enter the stem as a hi+lo bf16 pair so eps-sized perturbations are kept.
+"""
+import ctypes
+
+from .. import _lib
+
+F_RELU, F_OUT_F32 = 1, 2
+
+
+def _bf16(t):
+    import torch
+    return t.to(torch.bfloat16).contiguous()
+
+
+def _pad_rows(w2d, mult):
+    import torch
+    rows = w2d.shape[0]
+    pr = (rows + mult - 1) // mult * mult
+    if pr == rows:
+        return w2d
+    return torch.cat([w2d, torch.zeros(pr - rows, w2d.shape[1], dtype=w2d.dtype, device=w2d.device)], 0)
+
+
+def _rows_mult(n_cols):
+    return 128 if n_cols > 64 else 64
+
+
+class _Conv:
+    """One folded conv layer: forward table + backward-to-input tables."""
+
+    def __init__(self, conv, bn, device):
+        import torch
+        w = conv.weight.detach().float()
+        if bn is not None:
+            inv = (bn.running_var.detach().float() + bn.eps).rsqrt() * bn.weight.detach().float()
+            w = w * inv.view(-1, 1, 1, 1)
+            b = bn.bias.detach().float() - bn.running_mean.detach().float() * inv
+        else:
+            b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0])
+        self.cout, self.cin, self.r, self.s = w.shape
+        self.stride = conv.stride[0]
+        self.pad = conv.padding[0]
+        self.w_folded = w                    # fp32, for the reference emulation in tests
+        self.b_folded = b
+        wb = w.to(torch.bfloat16).float()    # the values the kernels see
+        # forward: rows = cout, k = (r*S + s)*Cin + c
+        self.w_fwd = _bf16(_pad_rows(wb.permute(0, 2, 3, 1).reshape(self.cout, -1), _rows_mult(self.cout))).to(device)
+        self.bias = b.contiguous().to(device)
+        self.fwd_taps = [(r - self.pad, s - self.pad) for r in range(self.r) for s in range(self.s)]
+        # backward to input: rows = cin, k = tap*Cout + cout
+        self.bwd = []    # list of (parity (ph,pw) or None, taps [(dy,dx)], weight)
+        if self.stride == 1:
+            taps, cols = [], []
+            for r in range(self.r):
+                for s in range(self.s):
+                    taps.append((self.pad - r, self.pad - s))
+                    cols.append(wb[:, :, r, s].t())                     # [cin][cout]
+            wd = torch.cat(cols, 1)
+            self.bwd.append((None, taps, _bf16(_pad_rows(wd, _rows_mult(self.cin))).to(device)))
+        else:
+            assert self.stride == 2
+            for ph in range(2):
+                for pw in range(2):
+                    taps, cols = [], []
+                    for r in range(self.r):
+                        if (ph + self.pad - r) % 2:
+                            continue
+                        for s in range(self.s):
+                            if (pw + self.pad - s) % 2:
+                                continue
+                            taps.append(((ph + self.pad - r) // 2, (pw + self.pad - s) // 2))
+                            cols.append(wb[:, :, r, s].t())
+                    if not taps:
+                        self.bwd.append(((ph, pw), [], None))
+                        continue
+                    wd = torch.cat(cols, 1)
+                    self.bwd.append(((ph, pw), taps, _bf16(_pad_rows(wd, _rows_mult(self.cin))).to(device)))
+
+
+class ResNet50Engine:
+    """Hand-written HIP eval engine for robustart_amd.model.resnet_torch.ResNet."""
+
+    def __init__(self, model, device='cuda'):
+        torch = _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        m = model
+        assert not m.training, 'the attack / eval engine folds BatchNorm: call model.eval() first'
+        dev = self.device
+        # ---- stem: 7x7/2 conv on the padded 4-channel hi/lo image; a "tap" = one filter row, 8 px x 4 ch
+        st = _Conv(m.conv1, m.bn1, dev)
+        self.stem = st
+        wb = st.w_folded.to(torch.bfloat16).float()                       # [64][3][7][7]
+        wrow = torch.zeros(64, 7, 8, 4)
+        wrow[:, :, :7, :3] = wb.permute(0, 2, 3, 1)                      # [cout][r][s][c]
+        wrow = wrow.reshape(64, 7 * 32)
+        self.stem_w = _bf16(torch.cat([wrow, wrow], 1)).to(dev)          # hi taps then lo taps
+        # stem backward: patches[(r*7+s)*3+c] = sum_k dz[k] * W[k][c][r][s]; 147 rows zero-padded to the tile
+        wp = wb.permute(2, 3, 1, 0).reshape(147, 64)
+        self.stem_patch_cols = 152                                        # 147 rounded up to 8
+        self.stem_wd = _bf16(_pad_rows(wp, _rows_mult(self.stem_patch_cols))).to(dev)
+        self.blocks = []
+        for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
+            for blk in layer:
+                ds = _Conv(blk.downsample[0], blk.downsample[1], dev) if blk.downsample is not None else None
+                self.blocks.append((_Conv(blk.conv1, blk.bn1, dev), _Conv(blk.conv2, blk.bn2, dev),
+                                    _Conv(blk.conv3, blk.bn3, dev), ds))
+        # ---- classifier
+        wfc = m.fc.weight.detach().float()
+        self.n_classes, self.fc_in = wfc.shape
+        wfb = wfc.to(torch.bfloat16).float()
+        self.fc_w = _bf16(_pad_rows(wfb, 128)).to(dev)                    # [1024][2048]
+        self.fc_b = m.fc.bias.detach().float().contiguous().to(dev)
+        self.fc_kpad = (self.n_classes + 31) // 32 * 32                   # 1024
+        wt = torch.zeros(self.fc_in, self.fc_kpad)
+        wt[:, :self.n_classes] = wfb.t()
+        self.fc_wd = _bf16(wt).to(dev)                                    # [2048][1024]
+        self._buf = {}
+
+    # ------------------------------------------------------------------ buffers / launches
+    def _get(self, name, shape, dtype=None):
+        torch = _lib.require_gpu()
+        dtype = dtype or torch.bfloat16
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def _gemm(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix,
+              bias=None, res=None, mask=None, flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0),
+              tap_src_off=None):
+        d = _lib.ConvDesc()
+        d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.res = res.data_ptr() if res is not None else None
+        d.mask = mask.data_ptr() if mask is not None else None
+        d.batch, d.grid_h, d.grid_w = batch, grid[0], grid[1]
+        d.src_h, d.src_w, d.src_pix_stride = src_hw[0], src_hw[1], src_pix
+        d.k_per_tap, d.n_taps = k_per_tap, len(taps)
+        d.sy, d.sx = stride
+        for i, (dy, dx) in enumerate(taps):
+            d.tap_dy[i], d.tap_dx[i] = dy, dx
+            d.tap_src_off[i] = tap_src_off[i] if tap_src_off is not None else 0
+        d.n_cols = n_cols
+        d.dst_h, d.dst_w = dst_hw
+        d.dst_sy, d.dst_sx = dst_stride
+        d.dst_oy, d.dst_ox = dst_off
+        d.dst_pix_stride = dst_pix
+        d.flags = flags
+        _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _conv_fwd(self, c, x, xhw, out, relu, res=None):
+        B = x.shape[0]
+        oh, ow = xhw[0] // c.stride, xhw[1] // c.stride
+        self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
+                   bias=c.bias, res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride))
+
+    def _conv_bwd(self, c, dz, dz_hw, dx, dx_hw, res=None, mask=None):
+        """dx = backward-to-input of conv c applied to dz (then + res, masked)."""
+        B = dz.shape[0]
+        for parity, taps, w in c.bwd:
+            if parity is None:
+                self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res, mask=mask)
+            else:
+                ph, pw = parity
+                if not taps:
+                    continue        # this input-parity class receives no gradient from a 1x1/2 conv
+                self._gemm(dz, w, dx, B, (dx_hw[0] // 2, dx_hw[1] // 2), dz_hw, c.cout, c.cout, taps, c.cin, dx_hw,
+                           c.cin, res=res, mask=mask, dst_stride=(2, 2), dst_off=(ph, pw))
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, src, src_is_u8, mean, std, keep):
+        torch = _lib.require_gpu()
+        lib = self.lib
+        if src_is_u8:
+            B, H, W = src.shape[0], src.shape[1], src.shape[2]
+        else:
+            B, H, W = src.shape[0], src.shape[2], src.shape[3]
+        assert H % 32 == 0 and W % 32 == 0, 'input height/width must be multiples of 32'
+        sp = _lib.stream_ptr()
+        hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
+        meanf = (ctypes.c_float * 3)(*mean)
+        stdf = (ctypes.c_float * 3)(*std)
+        _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]),
+                                              B, H, W, meanf, stdf, sp))
+        acts = {}
+        h1, w1 = H // 2, W // 2
+        y1 = self._get('y1', (B, h1, w1, 64))
+        lo_off = hi[1].data_ptr() - hi[0].data_ptr()
+        assert lo_off % 2 == 0
+        taps = [(r, 0) for r in range(7)] * 2
+        offs = [0] * 7 + [lo_off // 2] * 7
+        self._gemm(hi[0], self.stem_w, y1, B, (h1, w1), (H + 8, W + 8), 4, 32, taps, 64, (h1, w1), 64,
+                   bias=self.stem.bias, flags=F_RELU, stride=(2, 2), tap_src_off=offs)
+        h2, w2 = h1 // 2, w1 // 2
+        p1 = self._get('p1', (B, h2, w2, 64))
+        _lib.check(lib.rart_engine_maxpool(_lib.ptr(y1), _lib.ptr(p1), B, h1, w1, 64, sp))
+        acts['y1'], acts['p1'] = y1, p1
+        x, xhw = p1, (h2, w2)
+        for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
+            ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
+            ya = self._get('b%d_a' % bi, (B, xhw[0], xhw[1], ca.cout))
+            yb = self._get('b%d_b' % bi, (B, ohw[0], ohw[1], cb.cout))
+            yc = self._get('b%d_c' % bi, (B, ohw[0], ohw[1], cc.cout))
+            self._conv_fwd(ca, x, xhw, ya, True)
+            self._conv_fwd(cb, ya, xhw, yb, True)
+            if ds is not None:
+                sk = self._get('b%d_ds' % bi, (B, ohw[0], ohw[1], cc.cout))
+                self._conv_fwd(ds, x, xhw, sk, False)
+            else:
+                sk = x
+            self._conv_fwd(cc, yb, ohw, yc, True, res=sk)
+            acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
+            x, xhw = yc, ohw
+        pooled = self._get('pooled', (B, self.fc_in))
+        _lib.check(lib.rart_engine_avgpool(_lib.ptr(x), _lib.ptr(pooled), B, xhw[0] * xhw[1], self.fc_in, sp))
+        logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
+        self._gemm(pooled, self.fc_w, logits, B, (1, 1), (1, 1), self.fc_in, self.fc_in, [(0, 0)], self.n_classes,
+                   (1, 1), self.n_classes, bias=self.fc_b, flags=F_OUT_F32)
+        acts['last'] = (x, xhw)
+        acts['in_shape'] = (B, H, W)
+        return logits, acts
+
+    def logits(self, x01, mean, std):
+        """x01: fp32 NCHW in [0,1]; mean/std: 3-tuples applied inside the stem's input kernel."""
+        return self._forward(x01.detach().float().contiguous(), False, mean, std, keep=False)[0]
+
+    def logits_from_u8(self, batch_u8, mean, std):
+        """batch_u8: uint8 NHWC (the corruption kernels' output) -> logits, normalisation fused."""
+        return self._forward(batch_u8, True, mean, std, keep=False)[0]
+
+    # ------------------------------------------------------------------ forward + backward to the input
+    def forward_backward(self, x01, mean, std, y, kind, y_target=None, scale=1.0):
+        """-> (logits fp32, loss_indiv, d(sum_i scale*loss_i)/dx01 fp32 NCHW, pred int32)."""
+        from ..noise.adv import logit_loss
+        torch = _lib.require_gpu()
+        lib = self.lib
+        sp = _lib.stream_ptr()
+        x01 = x01.detach().float().contiguous()
+        logits, acts = self._forward(x01, False, mean, std, keep=True)
+        loss, dl, pred = logit_loss(logits, y, kind, y_target, scale)
+        B, H, W = acts['in_shape']
+        # fc backward: dpool[B][2048] = dlogits[B][1024 padded] . Wfc
+        dlb = self._get('dl_bf16', (B, self.fc_kpad))
+        _lib.check(lib.rart_f32_to_bf16_rows(_lib.ptr(dl), _lib.ptr(dlb), B, self.n_classes, self.fc_kpad, sp))
+        dpool = self._get('dpool', (B, self.fc_in))
+        self._gemm(dlb, self.fc_wd, dpool, B, (1, 1), (1, 1), self.fc_kpad, self.fc_kpad, [(0, 0)], self.fc_in, (1, 1),
+                   self.fc_in)
+        xl, xlhw = acts['last']
+        dz = self._get('g_out_%d' % (len(self.blocks) - 1), tuple(xl.shape))
+        _lib.check(lib.rart_engine_avgpool_bwd(_lib.ptr(xl), _lib.ptr(dpool), _lib.ptr(dz), B, xlhw[0] * xlhw[1],
+                                               self.fc_in, sp))
+        # blocks in reverse; dz = masked gradient at the block output (pre-ReLU)
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            ca, cb, cc, ds = self.blocks[bi]
+            x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
+            dzb = self._get('g_b', tuple(yb.shape))
+            self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=yb)
+            dza = self._get('g_a', tuple(ya.shape))
+            self._conv_bwd(cb, dzb, ohw, dza, xhw, mask=ya)
+            dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
+            if ds is None:
+                self._conv_bwd(ca, dza, xhw, dx, xhw, res=dz, mask=x)            # identity skip
+            else:
+                self._conv_bwd(ca, dza, xhw, dx, xhw, mask=x)
+                self._conv_bwd(ds, dz, ohw, dx, xhw, res=dx, mask=x)             # accumulate the projection skip
+            dz = dx
+        # stem: max-pool backward (+ReLU mask of y1), patches GEMM, col2im to the fp32 image
+        y1 = acts['y1']
+        h1, w1 = H // 2, W // 2
+        dz1 = self._get('g_y1', tuple(y1.shape))
+        _lib.check(lib.rart_engine_maxpool_bwd(_lib.ptr(y1), _lib.ptr(dz), _lib.ptr(dz1), B, h1, w1, 64, sp))
+        pc = self.stem_patch_cols
+        patches = self._get('patches', (B, h1, w1, pc))
+        self._gemm(dz1, self.stem_wd, patches, B, (h1, w1), (h1, w1), 64, 64, [(0, 0)], pc, (h1, w1), pc)
+        grad = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
+        stdf = (ctypes.c_float * 3)(*std)
+        _lib.check(lib.rart_engine_stem_col2im(_lib.ptr(patches), _lib.ptr(grad), B, H, W, pc, stdf, sp))
+        return logits, loss, grad, pred
+
+
+class EngineModel:
+    """Callable wrapper that carries a ResNet50Engine through the reference's `model` / `f_model` keys.
+
+    takes_normalized=True  -> drop-in for the reference's `model` (input already normalised; used by
+                               mim_linf / autoattack_linf, which apply ImageNet mean/std themselves);
+    takes_normalized=False -> drop-in for a foolbox PyTorchModel(model, bounds=(0,1), preprocessing=
+                               dict(mean, std, axis=-3)) -- the `f_model` of pgd_linf / pgd_l2 / fgsm."""
+
+    def __init__(self, torch_model, takes_normalized, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                 engine=None, device='cuda'):
+        self.rart_engine = engine or ResNet50Engine(torch_model, device)
+        self.takes_normalized = takes_normalized
+        self.rart_mean_std = (tuple(mean), tuple(std))
+
+    def __call__(self, x):
+        if self.takes_normalized:
+            return self.rart_engine.logits(x, (0., 0., 0.), (1., 1., 1.))
+        return self.rart_engine.logits(x, *self.rart_mean_std)
