@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='images in the bounded CPU baseline sample')
+    ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
+                    help="'hip' = hand-written engine (product); 'scaffold' = PyTorch-ROCm/MIOpen, for comparison only")
     return ap.parse_args()
 
 
@@ -59,6 +61,20 @@ def build_workload(B, device, rank):
     return images, labels, model
 
 
+class HipEngine:
+    """The product path: hand-written bf16 MFMA implicit-GEMM engine (robustart_amd/model/engine.py)."""
+    name = 'hip-igemm-bf16'
+    MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def __init__(self, model, device):
+        from robustart_amd.model.engine import ResNet50Engine, EngineModel
+        self.eng = ResNet50Engine(model, device)
+        self.f_model = EngineModel(None, takes_normalized=False, mean=self.MEAN, std=self.STD, engine=self.eng)
+
+    def logits_from_u8(self, u8, norm_buf):
+        return self.eng.logits_from_u8(u8, self.MEAN, self.STD)
+
+
 class Scaffold:
     """Model path used until the hand-written HIP engine covers ResNet-50: bf16 channels_last
     ResNet-50 on PyTorch-ROCm (MIOpen/hipBLASLt).  Reported as such in `config.model_path`."""
@@ -69,10 +85,12 @@ class Scaffold:
         self.mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
         self.std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
 
-    def logits_from_normalized_bf16_nhwc(self, xn):
-        # xn: (B,H,W,3) bf16 normalised (channels_last storage of an NCHW view)
-        with torch.no_grad():
-            return self.m(xn.permute(0, 3, 1, 2)).float()
+    def logits_from_u8(self, u8, norm_buf):
+        from robustart_amd import _lib
+        B = u8.shape[0]
+        _lib.check(_lib.load().rart_u8_to_normalized(_lib.ptr(u8), _lib.ptr(norm_buf), B, H, W, 1, 1, _lib.stream_ptr()))
+        with torch.no_grad():     # (B,H,W,3) bf16 = channels_last storage of an NCHW view
+            return self.m(norm_buf.permute(0, 3, 1, 2)).float()
 
     def f_model(self, x01):
         xn = ((x01 - self.mean) / self.std).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -87,9 +105,7 @@ def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
     base = (step_idx * 1_000_003 + rank * B)          # global sample index of this rank's first image
     for sev in range(1, 6):
         C.corrupt_batch_(images, 0, sev, seed=0, sample_offset=base, out=scratch_u8)
-        _lib.check(lib.rart_u8_to_normalized(_lib.ptr(scratch_u8), _lib.ptr(norm_buf), B, H, W, 1, 1,
-                                             _lib.stream_ptr()))
-        logits = path.logits_from_normalized_bf16_nhwc(norm_buf)
+        logits = path.logits_from_u8(scratch_u8, norm_buf)
         _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
         correct = correct + (pred.long() == labels).sum()
     x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
@@ -122,6 +138,26 @@ def measure_gaussian_roofline(B, device, launches=40):
     ms = sorted(a.elapsed_time(b) for a, b in ev)
     avg = sum(ms) / len(ms)
     return avg * 1e-3, ms[len(ms) // 2] * 1e-3
+
+
+def measure_igemm_roofline(path, images, labels):
+    """Dominant kernel of the step: k_conv_igemm_bf16 (every conv / fc of ResNet-50, forward and
+    backward-to-input).  One PGD gradient evaluation (forward + backward) at B = 256 is timed launch by
+    launch with events on the launch stream; achieved = algorithmic GEMM FLOPs / kernel time."""
+    eng = path.eng
+    x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
+    eng.forward_backward(x01, path.MEAN, path.STD, labels, 0)          # warm
+    eng.profile = []
+    eng.forward_backward(x01, path.MEAN, path.STD, labels, 0)
+    torch.cuda.synchronize()
+    prof, eng.profile = eng.profile, None
+    secs = sum(a.elapsed_time(b) for _, a, b in prof) * 1e-3
+    flops = sum(f for f, _, _ in prof)
+    return {'kernel': 'k_conv_igemm_bf16 (ResNet-50 forward + backward-to-input, B=256, %d launches)' % len(prof),
+            'bound': 'mfma', 'achieved': flops / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+            'frac': flops / secs / MFMA_BF16_PEAK, 'traffic': None,
+            'avg_launch_us': secs / len(prof) * 1e6, 'launches': len(prof),
+            'algorithmic_flops_per_launch': flops / len(prof), 'kernel_seconds_per_fwd_bwd': secs}
 
 
 def cpu_baseline(sample, model_fp32):
@@ -167,7 +203,7 @@ def main():
     images, labels, model = build_workload(B, device, rank)
     import copy
     model_cpu = copy.deepcopy(model) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    path = Scaffold(model, device)
+    path = HipEngine(model, device) if args.model_path == 'hip' else Scaffold(model, device)
     scratch = torch.empty_like(images)
     norm_buf = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=device)
 
@@ -214,11 +250,12 @@ def main():
                                'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': None,
                                'avg_launch_us': avg * 1e6, 'median_launch_us': med * 1e6,
                                'algorithmic_bytes_per_launch': algo}
+            out['hbm_roofline_gaussian_noise'] = out.pop('roofline')
             step_flops = (5 + 15) * B * FLOP_FWD
-            out['model_roofline'] = {'bound': 'mfma', 'achieved': step_flops * args.steps / dt / 1e12,
-                                     'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                                     'frac': step_flops * args.steps / dt / MFMA_BF16_PEAK,
-                                     'note': 'whole-step algorithmic FLOPs / step time (20 forward-equivalents per image batch)'}
+            out['step_mfma'] = {'achieved': step_flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
+                                'note': 'whole-step algorithmic FLOPs (20 forward-equivalents) / step time'}
+            if isinstance(path, HipEngine):
+                out['roofline'] = measure_igemm_roofline(path, images, labels)
             if model_cpu is not None:
                 v, secs = cpu_baseline(args.cpu_sample, model_cpu)
                 out['cpu_baseline'] = {'value': v, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',

@@ -129,6 +129,7 @@ class ResNet50Engine:
         wt[:, :self.n_classes] = wfb.t()
         self.fc_wd = _bf16(wt).to(dev)                                    # [2048][1024]
         self._buf = {}
+        self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
 
     # ------------------------------------------------------------------ buffers / launches
     def _get(self, name, shape, dtype=None):
@@ -161,6 +162,15 @@ class ResNet50Engine:
         d.dst_oy, d.dst_ox = dst_off
         d.dst_pix_stride = dst_pix
         d.flags = flags
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()          # torch's current stream == the stream the kernel is enqueued on (stream_ptr())
+            _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            e1.record()
+            flops = 2.0 * batch * grid[0] * grid[1] * k_per_tap * len(taps) * n_cols
+            self.profile.append((flops, e0, e1))
+            return
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
     def _conv_fwd(self, c, x, xhw, out, relu, res=None):
@@ -252,7 +262,9 @@ class ResNet50Engine:
         sp = _lib.stream_ptr()
         x01 = x01.detach().float().contiguous()
         logits, acts = self._forward(x01, False, mean, std, keep=True)
+        self.last_acts = acts            # exposed for the parity tests (ReLU masks of this forward)
         loss, dl, pred = logit_loss(logits, y, kind, y_target, scale)
+        self.last_dlogits = dl
         B, H, W = acts['in_shape']
         # fc backward: dpool[B][2048] = dlogits[B][1024 padded] . Wfc
         dlb = self._get('dl_bf16', (B, self.fc_kpad))
