@@ -208,10 +208,13 @@ int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
  * the stem convolution's operand (normalisation of imfgsm_attack.py:14-23 / autoattack.py:17-20 fused). */
 int rart_engine_prep_input(const void* src, int src_is_u8, void* hi, void* lo, int n, int h, int w,
                            const float* mean_host, const float* std_host, rart_stream_t stream);
-/* 3x3 stride-2 pad-1 max pool on bf16 NHWC, and its backward fused with the ReLU mask of its input y. */
-int rart_engine_maxpool(const void* in, void* out, int n, int h, int w, int c, rart_stream_t stream);
-int rart_engine_maxpool_bwd(const void* y, const void* dpool, void* dz, int n, int h, int w, int c,
-                            rart_stream_t stream);
+/* 3x3 stride-2 pad-1 max pool on bf16 NHWC; argmax_out (nullable): uint8 [n][h/2][w/2][c], the window
+ * position ky*3+kx of the first maximum (PyTorch's rule).  Backward, fused with the ReLU mask of the pool's
+ * input y: dz = (y > 0) * sum of dpool over the windows whose argmax is this pixel. */
+int rart_engine_maxpool(const void* in, void* out, void* argmax_out, int n, int h, int w, int c,
+                        rart_stream_t stream);
+int rart_engine_maxpool_bwd(const void* y, const void* argmax, const void* dpool, void* dz, int n, int h, int w,
+                            int c, rart_stream_t stream);
 /* global average pool [n][hw][c] -> [n][c], and dz = (y > 0) ? dpool / hw : 0. */
 int rart_engine_avgpool(const void* in, void* out, int n, int hw, int c, rart_stream_t stream);
 int rart_engine_avgpool_bwd(const void* y, const void* dpool, void* dz, int n, int hw, int c, rart_stream_t stream);

@@ -19,6 +19,7 @@
 // Most ResNet-50 layers are HBM-bound at bf16 (K = 64..512), so the kernel is built around wide
 // coalesced traffic first and MFMA issue second.
 #include "rart_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -54,17 +55,17 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 
 template <int BN>
-__global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDescDev d) {
+__global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvDescDev d) {
   constexpr int WN = BN / 2;        // wave sub-tile columns
   constexpr int TN = WN / 32;       // 32-wide MFMA tiles per wave along n
   constexpr int B_CHUNKS = BN * 4 / kThreads;  // 16-byte chunks of the W tile per thread (2 or 1)
   constexpr int LDC = BN + 4;       // fp32 epilogue staging row (floats)
   constexpr int kLdsBytes = 2 * (BM + BN) * LDK * 2;
   static_assert(64 * LDC * 4 <= kLdsBytes, "epilogue staging must fit the tile buffers");
-  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[kLdsBytes + BM * 8];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[kLdsBytes + BM * 4];
   uint16_t* sA = reinterpret_cast<uint16_t*>(lds_raw);               // [2][BM][LDK]
   uint16_t* sB = sA + 2 * BM * LDK;                                   // [2][BN][LDK]
-  long long* row_dst = reinterpret_cast<long long*>(lds_raw + kLdsBytes);  // [BM] dst element offset or -1
+  uint32_t* row_dst = reinterpret_cast<uint32_t*>(lds_raw + kLdsBytes);  // [BM] dst element offset or ~0u
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDesc
   // ---- per-thread gather rows (2 rows of the A tile) ----
   const int chunk = tid & 3;  // which 16 B of the 64 B K-slice
   int a_by[2], a_bx[2];
-  long long a_img[2];
+  int a_img[2];   // pixel index of the image origin (host guarantees every tensor is < 2^31 elements)
   bool a_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -100,18 +101,18 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDesc
     const int n = (int)(t / d.grid_h);
     a_by[i] = oy * d.sy;
     a_bx[i] = ox * d.sx;
-    a_img[i] = (long long)n * d.src_h * d.src_w;
+    a_img[i] = n * d.src_h * d.src_w;
   }
   if (tid < BM) {
     const long long m = m0 + tid;
-    long long off = -1;
+    uint32_t off = 0xFFFFFFFFu;
     if (m < M) {
       const int ox = (int)(m % d.grid_w);
       const long long t = m / d.grid_w;
       const int oy = (int)(t % d.grid_h);
       const int n = (int)(t / d.grid_h);
-      off = (((long long)n * d.dst_h + (oy * d.dst_sy + d.dst_oy)) * d.dst_w + (ox * d.dst_sx + d.dst_ox)) *
-            d.dst_pix_stride;
+      off = (uint32_t)(((n * d.dst_h + (oy * d.dst_sy + d.dst_oy)) * d.dst_w + (ox * d.dst_sx + d.dst_ox)) *
+                       d.dst_pix_stride);
     }
     row_dst[tid] = off;
   }
@@ -120,34 +121,45 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDesc
   const int KT = K / BK;
   const int tiles_per_tap = d.k_per_tap / BK;
 
-  uint4 ra[2], rb[B_CHUNKS];
-  auto load_tile = [&](int kt) {
-    const int tap = kt / tiles_per_tap;
-    const int kc = (kt - tap * tiles_per_tap) * BK + chunk * 8;
-    const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];
-    const uint16_t* sbase = d.src + d.tap_src_off[tap];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
-      const bool ok = a_ok[i] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(sbase + (a_img[i] + (long long)iy * d.src_w + ix) * d.src_pix_stride + kc);
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) {
-      const int row = (tid >> 2) + 64 * i;  // weight rows are padded to a multiple of BN on the host
-      rb[i] = *reinterpret_cast<const uint4*>(d.wgt + (long long)(n0 + row) * K + (long long)kt * BK + chunk * 8);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<uint4*>(sA + ((buf * BM + (tid >> 2) + 64 * i) * LDK + chunk * 8)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i)
-      *reinterpret_cast<uint4*>(sB + ((buf * BN + (tid >> 2) + 64 * i) * LDK + chunk * 8)) = rb[i];
-  };
+  // Two register sets: global loads run TWO K steps ahead of the MFMAs (the K step of a 1x1 layer is far
+  // shorter than an HBM round trip, so one step of cover leaves the kernel latency-bound at 3 blocks/CU).
+  // Written as macros over named register arrays so every index is static (no scratch).
+  uint4 ra0_0, ra0_1, ra1_0, ra1_1, rb0_0, rb0_1, rb1_0, rb1_1;   // set{0,1} x chunk{0,1}; explicit scalars
+  rb0_1 = rb1_1 = make_uint4(0, 0, 0, 0);
+#define RART_LOAD_A(I, DST)                                                                                     \
+  {                                                                                                             \
+    const int iy = a_by[I] + dy, ix = a_bx[I] + dx;                                                             \
+    const bool ok = a_ok[I] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w;            \
+    const uint32_t eoff = (uint32_t)((a_img[I] + iy * d.src_w + ix) * d.src_pix_stride + kc);                   \
+    uint4 v = make_uint4(0, 0, 0, 0);                                                                           \
+    if (ok) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase) + (size_t)(eoff * 2u));    \
+    DST = v;                                                                                                    \
+  }
+#define RART_LOAD_B(I, DST)                                                                                     \
+  {                                                                                                             \
+    const uint32_t woff = (uint32_t)((n0 + (tid >> 2) + 64 * (I)) * K + kt_ * BK + chunk * 8);                  \
+    DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.wgt) + (size_t)(woff * 2u));         \
+  }
+#define RART_LOAD_TILE(KT_, SET)                                                                                \
+  {                                                                                                             \
+    const int kt_ = (KT_);                                                                                      \
+    const int tap = kt_ / tiles_per_tap;                                                                        \
+    const int kc = (kt_ - tap * tiles_per_tap) * BK + chunk * 8;                                                \
+    const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];                                                           \
+    const uint16_t* sbase = d.src + d.tap_src_off[tap];                                                         \
+    RART_LOAD_A(0, ra##SET##_0)                                                                                 \
+    RART_LOAD_A(1, ra##SET##_1)                                                                                 \
+    RART_LOAD_B(0, rb##SET##_0)                                                                                 \
+    if constexpr (B_CHUNKS > 1) RART_LOAD_B(1, rb##SET##_1)                                                     \
+  }
+#define RART_STORE_TILE(BUF, SET)                                                                               \
+  {                                                                                                             \
+    *reinterpret_cast<uint4*>(sA + (((BUF)*BM + (tid >> 2)) * LDK + chunk * 8)) = ra##SET##_0;                  \
+    *reinterpret_cast<uint4*>(sA + (((BUF)*BM + (tid >> 2) + 64) * LDK + chunk * 8)) = ra##SET##_1;             \
+    *reinterpret_cast<uint4*>(sB + (((BUF)*BN + (tid >> 2)) * LDK + chunk * 8)) = rb##SET##_0;                  \
+    if constexpr (B_CHUNKS > 1)                                                                                 \
+      *reinterpret_cast<uint4*>(sB + (((BUF)*BN + (tid >> 2) + 64) * LDK + chunk * 8)) = rb##SET##_1;           \
+  }
 
   f32x16 acc[2][TN];
 #pragma unroll
@@ -157,32 +169,45 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDesc
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
-    const uint16_t* A = sA + buf * BM * LDK + (wm * 64 + frag_row) * LDK + frag_k;
-    const uint16_t* B = sB + buf * BN * LDK + (wn * WN + frag_row) * LDK + frag_k;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[2], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * LDK + ks * 16);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * LDK + ks * 16);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
-    __syncthreads();
+#define RART_COMPUTE(BUF)                                                                                       \
+  {                                                                                                             \
+    const uint16_t* A = sA + (BUF)*BM * LDK + (wm * 64 + frag_row) * LDK + frag_k;                              \
+    const uint16_t* B = sB + (BUF)*BN * LDK + (wn * WN + frag_row) * LDK + frag_k;                              \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                    \
+      bf16x8 af[2], bfr[TN];                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * LDK + ks * 16); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * LDK + ks * 16); \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);               \
+    }                                                                                                           \
   }
+
+  ra1_0 = ra1_1 = rb1_0 = make_uint4(0, 0, 0, 0);
+  RART_LOAD_TILE(0, 0);
+  if (KT > 1) RART_LOAD_TILE(1, 1);
+  RART_STORE_TILE(0, 0);
+  __syncthreads();
+  // step kt on LDS buffer kt&1: prefetch tile kt+2 into the register set whose tile (kt) is already in LDS,
+  // multiply, publish tile kt+1 from the other set
+  for (int kt = 0; kt < KT; kt += 2) {
+    if (kt + 2 < KT) RART_LOAD_TILE(kt + 2, 0);
+    RART_COMPUTE(0);
+    if (kt + 1 < KT) RART_STORE_TILE(1, 1);
+    __syncthreads();
+    if (kt + 1 < KT) {
+      if (kt + 3 < KT) RART_LOAD_TILE(kt + 3, 1);
+      RART_COMPUTE(1);
+      if (kt + 2 < KT) RART_STORE_TILE(0, 0);
+      __syncthreads();
+    }
+  }
+#undef RART_LOAD_TILE
+#undef RART_LOAD_A
+#undef RART_LOAD_B
+#undef RART_STORE_TILE
+#undef RART_COMPUTE
 
   // ---- epilogue: two 64-row halves through LDS (fp32), then 16-byte rows out ----
   float* sC = reinterpret_cast<float*>(lds_raw);
@@ -196,8 +221,25 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDesc
   for (int j = 0; j < 8; ++j) bias8[j] = (d.bias && col_ok) ? d.bias[col + j] : 0.f;
   const bool relu = d.flags & F_RELU, out_f32 = d.flags & F_OUT_F32;
 
+  constexpr int RP = 64 / ROWS_PER_PASS;  // rows per thread per half
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
+    // issue the residual / mask reads of this half first: their HBM latency then overlaps the LDS
+    // transposition and its barrier instead of sitting exposed in front of every store
+    uint32_t offs[RP];
+    uint4 rv[RP], mv[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const uint32_t off = col_ok ? row_dst[h * 64 + r0 + ROWS_PER_PASS * i] : 0xFFFFFFFFu;
+      offs[i] = off;
+      rv[i] = make_uint4(0, 0, 0, 0);
+      mv[i] = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 pairs: mask passes
+      if (off != 0xFFFFFFFFu) {
+        const size_t bo = (size_t)((off + (uint32_t)col) * 2u);
+        if (d.res) rv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.res) + bo);
+        if (d.mask) mv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.mask) + bo);
+      }
+    }
     if (wm == h) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -210,28 +252,23 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDesc
           }
     }
     __syncthreads();
-    for (int r = r0; r < 64; r += ROWS_PER_PASS) {
-      const long long off = row_dst[h * 64 + r];
-      if (off < 0 || !col_ok) continue;
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const uint32_t off = offs[i];
+      if (off != 0xFFFFFFFFu) {
+      const int r = r0 + ROWS_PER_PASS * i;
       const float4 v0 = *reinterpret_cast<const float4*>(sC + r * LDC + c8 * 8);
       const float4 v1 = *reinterpret_cast<const float4*>(sC + r * LDC + c8 * 8 + 4);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-      if (d.res) {
-        const uint4 rv = *reinterpret_cast<const uint4*>(d.res + off + col);
-        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+      {
+        const uint32_t rw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+        const uint32_t mw[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[2 * j] += bf2f((uint16_t)(rw[j] & 0xFFFF));
           v[2 * j + 1] += bf2f((uint16_t)(rw[j] >> 16));
-        }
-      }
-      if (d.mask) {
-        const uint4 mv = *reinterpret_cast<const uint4*>(d.mask + off + col);
-        const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
           if (!(bf2f((uint16_t)(mw[j] & 0xFFFF)) > 0.f)) v[2 * j] = 0.f;
           if (!(bf2f((uint16_t)(mw[j] >> 16)) > 0.f)) v[2 * j + 1] = 0.f;
         }
@@ -251,6 +288,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_bf16(const RartConvDesc
         o.z = f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
         o.w = f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + off + col) = o;
+      }
       }
     }
     __syncthreads();
@@ -278,6 +316,11 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   d.n_cols = h->n_cols; d.dst_h = h->dst_h; d.dst_w = h->dst_w; d.dst_sy = h->dst_sy; d.dst_sx = h->dst_sx;
   d.dst_oy = h->dst_oy; d.dst_ox = h->dst_ox; d.dst_pix_stride = h->dst_pix_stride; d.flags = h->flags;
   const long long M = (long long)d.batch * d.grid_h * d.grid_w;
+  // the kernel addresses with 32-bit element offsets from uniform bases (saves ~20 VGPRs of 64-bit math)
+  const long long src_elems = (long long)d.batch * d.src_h * d.src_w * d.src_pix_stride;
+  const long long dst_elems = (long long)d.batch * d.dst_h * d.dst_w * d.dst_pix_stride;
+  RART_CHECK_ARG(src_elems < (1ll << 31) && dst_elems < (1ll << 31),
+                 "rart_conv_igemm_bf16: tensors must stay below 2^31 elements (split the batch)");
   const int m_tiles = (int)((M + BM - 1) / BM);
   const bool wide = d.n_cols > 64;
   const int bn = wide ? 128 : 64;

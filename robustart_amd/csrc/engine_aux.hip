@@ -66,9 +66,11 @@ __global__ __launch_bounds__(kBlock) void k_prep_input(const void* __restrict__ 
   }
 }
 
-// 3x3 stride-2 pad-1 max pool, NHWC bf16, one thread per (output pixel, 8 channels)
-__global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict__ in, uint4* __restrict__ out, int n,
-                                                        int h, int w, int c8) {
+// 3x3 stride-2 pad-1 max pool, NHWC bf16, one thread per (output pixel, 8 channels).  Also records, per
+// channel, WHICH of the 9 window positions (ky*3+kx) holds the first maximum in scan order (PyTorch's
+// argmax rule) as one byte, so the backward is a <= 4-window gather instead of a 36-tap search.
+__global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                        uint2* __restrict__ arg, int n, int h, int w, int c8) {
   const int oh = h / 2, ow = w / 2;
   const size_t total = (size_t)n * oh * ow * c8;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
@@ -79,8 +81,9 @@ __global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict_
     const int oy = (int)(t % oh);
     const int img = (int)(t / oh);
     float m[8];
+    uint32_t code[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; code[j] = 0; }
     for (int ky = 0; ky < 3; ++ky) {
       const int y = oy * 2 - 1 + ky;
       if ((unsigned)y >= (unsigned)h) continue;
@@ -90,18 +93,22 @@ __global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict_
         float f[8];
         unpack8(in[(((size_t)img * h + y) * w + x) * c8 + c], f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
+        for (int j = 0; j < 8; ++j)
+          if (f[j] > m[j]) { m[j] = f[j]; code[j] = (uint32_t)(ky * 3 + kx); }
       }
     }
     out[i] = pack8(m);
+    if (arg)
+      arg[i] = make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
+                          code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24));
   }
 }
 
 // backward of the pool fused with the ReLU mask of its input y (= relu(stem conv)):
-// dz[h,w,c] = (y > 0) * sum over the <= 4 windows containing (h,w) in which (h,w) is the FIRST
-// maximum in (ky,kx) scan order (PyTorch's argmax rule) of dpool[window].
-__global__ __launch_bounds__(kBlock) void k_maxpool_bwd(const uint4* __restrict__ y, const uint4* __restrict__ dpool,
-                                                        uint4* __restrict__ dz, int n, int h, int w, int c8) {
+// dz[h,w,c] = (y > 0) * sum over the <= 4 windows containing (h,w) whose recorded argmax is (h,w).
+__global__ __launch_bounds__(kBlock) void k_maxpool_bwd(const uint4* __restrict__ y, const uint2* __restrict__ arg,
+                                                        const uint4* __restrict__ dpool, uint4* __restrict__ dz, int n,
+                                                        int h, int w, int c8) {
   const int oh = h / 2, ow = w / 2;
   const size_t total = (size_t)n * h * w * c8;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
@@ -115,45 +122,27 @@ __global__ __launch_bounds__(kBlock) void k_maxpool_bwd(const uint4* __restrict_
     unpack8(y[i], self);
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = 0.f;
-    bool any = false;
+    // windows o with 2o-1 <= pos <= 2o+1: o = pos/2 (always) and o = (pos+1)/2 when pos is odd
+    const int oy0 = yy >> 1, ox0 = x >> 1;
+    const int nys = (yy & 1) ? 2 : 1, nxs = (x & 1) ? 2 : 1;
+    for (int a = 0; a < nys; ++a) {
+      const int oy = oy0 + a;
+      if (oy >= oh) continue;
+      const uint32_t ky = (uint32_t)(yy - (2 * oy - 1));
+      for (int b = 0; b < nxs; ++b) {
+        const int ox = ox0 + b;
+        if (ox >= ow) continue;
+        const uint32_t mine = ky * 3 + (uint32_t)(x - (2 * ox - 1));
+        const size_t wi = (((size_t)img * oh + oy) * ow + ox) * c8 + c;
+        const uint2 cd = arg[wi];
+        float dp[8];
+        unpack8(dpool[wi], dp);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) any |= self[j] > 0.f;
-    if (any) {
-      // the (at most 2 x 2) windows containing (yy, x): window o covers [2o-1, 2o+1]
-      int oys[2], nys = 0, oxs[2], nxs = 0;
-      for (int oy = (yy > 0 ? (yy - 1) / 2 : 0); oy <= (yy + 1) / 2 && oy < oh; ++oy)
-        if (2 * oy - 1 <= yy && yy <= 2 * oy + 1) oys[nys++] = oy;
-      for (int ox = (x > 0 ? (x - 1) / 2 : 0); ox <= (x + 1) / 2 && ox < ow; ++ox)
-        if (2 * ox - 1 <= x && x <= 2 * ox + 1) oxs[nxs++] = ox;
-      for (int a = 0; a < nys; ++a)
-        for (int b = 0; b < nxs; ++b) {
-          const int oy = oys[a], ox = oxs[b];
-          // is (yy,x) the first maximum of this window, per channel?
-          bool first[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) first[j] = true;
-          for (int ky = 0; ky < 3; ++ky) {
-            const int y2 = oy * 2 - 1 + ky;
-            if ((unsigned)y2 >= (unsigned)h) continue;
-            for (int kx = 0; kx < 3; ++kx) {
-              const int x2 = ox * 2 - 1 + kx;
-              if ((unsigned)x2 >= (unsigned)w) continue;
-              if (y2 == yy && x2 == x) continue;
-              float f[8];
-              unpack8(y[(((size_t)img * h + y2) * w + x2) * c8 + c], f);
-              const bool before = (y2 < yy) || (y2 == yy && x2 < x);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                if (before ? (f[j] >= self[j]) : (f[j] > self[j])) first[j] = false;
-              }
-            }
-          }
-          float dp[8];
-          unpack8(dpool[(((size_t)img * oh + oy) * ow + ox) * c8 + c], dp);
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (first[j]) g[j] += dp[j];
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t cj = ((j < 4 ? cd.x : cd.y) >> (8 * (j & 3))) & 0xFFu;
+          if (cj == mine) g[j] += dp[j];
         }
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -268,20 +257,21 @@ int rart_engine_prep_input(const void* src, int src_is_u8, void* hi, void* lo, i
   return RART_OK;
 }
 
-int rart_engine_maxpool(const void* in, void* out, int n, int h, int w, int c, rart_stream_t stream) {
+int rart_engine_maxpool(const void* in, void* out, void* argmax_out, int n, int h, int w, int c,
+                        rart_stream_t stream) {
   RART_CHECK_ARG(in && out && n > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0, "rart_engine_maxpool: bad arguments");
   hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for((size_t)n * (h / 2) * (w / 2) * (c / 8))), dim3(kBlock), 0,
-                     (hipStream_t)stream, (const uint4*)in, (uint4*)out, n, h, w, c / 8);
+                     (hipStream_t)stream, (const uint4*)in, (uint4*)out, (uint2*)argmax_out, n, h, w, c / 8);
   RART_CHECK_LAUNCH("rart_engine_maxpool");
   return RART_OK;
 }
 
-int rart_engine_maxpool_bwd(const void* y, const void* dpool, void* dz, int n, int h, int w, int c,
+int rart_engine_maxpool_bwd(const void* y, const void* argmax, const void* dpool, void* dz, int n, int h, int w, int c,
                             rart_stream_t stream) {
-  RART_CHECK_ARG(y && dpool && dz && n > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0,
+  RART_CHECK_ARG(y && argmax && dpool && dz && n > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0,
                  "rart_engine_maxpool_bwd: bad arguments");
   hipLaunchKernelGGL(k_maxpool_bwd, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(kBlock), 0, (hipStream_t)stream,
-                     (const uint4*)y, (const uint4*)dpool, (uint4*)dz, n, h, w, c / 8);
+                     (const uint4*)y, (const uint2*)argmax, (const uint4*)dpool, (uint4*)dz, n, h, w, c / 8);
   RART_CHECK_LAUNCH("rart_engine_maxpool_bwd");
   return RART_OK;
 }

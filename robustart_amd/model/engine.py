@@ -218,8 +218,9 @@ class ResNet50Engine:
                    bias=self.stem.bias, flags=F_RELU, stride=(2, 2), tap_src_off=offs)
         h2, w2 = h1 // 2, w1 // 2
         p1 = self._get('p1', (B, h2, w2, 64))
-        _lib.check(lib.rart_engine_maxpool(_lib.ptr(y1), _lib.ptr(p1), B, h1, w1, 64, sp))
-        acts['y1'], acts['p1'] = y1, p1
+        parg = self._get('p1_argmax', (B, h2, w2, 64), torch.uint8) if keep else None
+        _lib.check(lib.rart_engine_maxpool(_lib.ptr(y1), _lib.ptr(p1), _lib.ptr(parg), B, h1, w1, 64, sp))
+        acts['y1'], acts['p1'], acts['p1_argmax'] = y1, p1, parg
         x, xhw = p1, (h2, w2)
         for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
             ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
@@ -295,7 +296,8 @@ class ResNet50Engine:
         y1 = acts['y1']
         h1, w1 = H // 2, W // 2
         dz1 = self._get('g_y1', tuple(y1.shape))
-        _lib.check(lib.rart_engine_maxpool_bwd(_lib.ptr(y1), _lib.ptr(dz), _lib.ptr(dz1), B, h1, w1, 64, sp))
+        _lib.check(lib.rart_engine_maxpool_bwd(_lib.ptr(y1), _lib.ptr(acts['p1_argmax']), _lib.ptr(dz), _lib.ptr(dz1),
+                                               B, h1, w1, 64, sp))
         pc = self.stem_patch_cols
         patches = self._get('patches', (B, h1, w1, pc))
         self._gemm(dz1, self.stem_wd, patches, B, (h1, w1), (h1, w1), 64, 64, [(0, 0)], pc, (h1, w1), pc)

@@ -1,0 +1,275 @@
+"""cls_solver-shaped train / eval entry for the hot path.
+
+Reference: RobustART/train/__init__.py:1 re-exports `prototype.prototype.solver.cls_solver`, whose source is
+absent; behaviour is taken from the YAML schema (exprs/nips_benchmark/pgd_adv_train/resnet50/config.yaml:1-61),
+the launchers (`python -m ...solver.X --config cfg [--evaluate] [--attack NAME --eps E]`,
+exprs/nips_benchmark/batch_eval_adv/eval.sh:43) and the only readable instance of the loop,
+cifar10/code/train.py:96-127.
+
+    python -m robustart_amd.train.cls_solver --config cfg.yaml --evaluate [--attack pgd_linf --eps 2/255]
+    python -m torch.distributed.run --nproc-per-node 8 -m robustart_amd.train.cls_solver --config cfg.yaml
+
+One process per GPU.  Evaluation: samples shard over ranks (distributed, non-repeating sampler), noise comes from
+AddNoise (HIP kernels), the forward from the HIP engine, and the ONLY collective is one all-reduce of the
+(top-1, top-5, count) counters.  Adversarial training (PGD-k inner loop, BN in eval mode during the attack,
+cifar10/code/train.py:105-111): the attack runs on the HIP engine with the current weights re-folded; the
+train-mode forward/backward and the optimizer still run on PyTorch-ROCm (the HIP wgrad kernels are not written
+yet -- DESIGN.md section 7); the gradient exchange is DDP's bucketed all-reduce over RCCL/xGMI, overlapped with
+backward (`dist.sync: False` semantics).
+"""
+import argparse
+import json
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def parse_eps(s):
+    """'8/255' or '0.031' -> float (the launchers pass fractions, batch_eval_adv/eval.sh:9-10)."""
+    if isinstance(s, (int, float)):
+        return float(s)
+    if '/' in s:
+        a, b = s.split('/')
+        return float(a) / float(b)
+    return float(s)
+
+
+def load_config(path):
+    import yaml
+    with open(path) as f:
+        return yaml.safe_load(f)
+
+
+class FakeImageNet(torch.utils.data.Dataset):
+    """`data.read_from: fake` (pgd_adv_train/resnet50/config.yaml:37): synthetic uint8 NHWC images whose content
+    is a pure function of the global index, so every world size sees the same dataset."""
+
+    def __init__(self, n, size=224, classes=1000):
+        self.n, self.size, self.classes = n, size, classes
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(1234 + i)
+        img = torch.randint(0, 256, (self.size, self.size, 3), generator=g, dtype=torch.uint8)
+        return img, int(torch.randint(0, self.classes, (1,), generator=g)), i
+
+
+def shard_indices(n, rank, world):
+    """`sampler.type: distributed` (non-repeating): contiguous ranges, the last ranks may get one fewer."""
+    per = (n + world - 1) // world
+    return list(range(min(rank * per, n), min((rank + 1) * per, n)))
+
+
+def cosine_lr(step, total, base_lr, warmup_lr, warmup_steps, min_lr=0.0):
+    """lr_scheduler.type CosineEpoch with linear warm-up (config.yaml:21-29)."""
+    if step < warmup_steps:
+        return base_lr + (warmup_lr - base_lr) * step / max(warmup_steps, 1)
+    t = (step - warmup_steps) / max(total - warmup_steps, 1)
+    return min_lr + 0.5 * (warmup_lr - min_lr) * (1 + math.cos(math.pi * t))
+
+
+def topk_correct(logits, labels, ks=(1, 5)):
+    _, pred = logits.topk(max(ks), dim=1)
+    hit = pred.eq(labels.view(-1, 1))
+    return [int(hit[:, :k].any(1).sum()) for k in ks]
+
+
+def init_dist():
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl' if use_cuda else 'gloo')       # "nccl" == RCCL on ROCm
+    return rank, world, torch.device('cuda', local) if use_cuda else torch.device('cpu')
+
+
+def all_reduce_counters(values, device):
+    """The eval path's only collective: sum of a few int64 counters."""
+    t = torch.tensor(values, dtype=torch.int64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t)
+    return [int(v) for v in t.tolist()]
+
+
+def build_model(cfg):
+    from ..model import get_model
+    return get_model(cfg['model'])
+
+
+def evaluate(cfg, args, rank, world, device, model=None):
+    """Clean / corrupted / attacked evaluation over the sharded dataset; returns the reduced metrics dict."""
+    dcfg = cfg.get('data', {})
+    n = int(dcfg.get('fake_size', dcfg.get('limit_samples', 256)))
+    bs = int(dcfg.get('batch_size', 64))
+    size = int(dcfg.get('input_size', 224))
+    ds = FakeImageNet(n, size)
+    idx = shard_indices(n, rank, world)
+    model = model or build_model(cfg)
+    model = model.to(device).eval()
+    use_hip = device.type == 'cuda' and args.engine == 'hip'
+    noise = None
+    if use_hip:
+        from ..model.engine import EngineModel
+        f_model = EngineModel(model, takes_normalized=False)
+        n_model = EngineModel(None, takes_normalized=True, engine=f_model.rart_engine)
+    if args.corruption:
+        from ..noise import AddNoise
+        noise = AddNoise('imagenet-c')
+        noise.config.update(corruption_name=args.corruption, severity=args.severity)
+    attack = None
+    if args.attack and args.attack != 'none':
+        from ..noise import AddNoise
+        attack = AddNoise(args.attack)
+        key = 'f_model' if 'f_model' in attack.config else 'model'
+        if not use_hip:
+            raise RuntimeError('attacks need the GPU path (no CPU fallback)')
+        attack.config[key] = f_model if key == 'f_model' else n_model
+        attack.config['eps'] = parse_eps(args.eps)
+        if 'steps' in attack.config and args.steps:
+            attack.config['steps'] = args.steps
+    mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
+    c1 = c5 = cnt = 0
+    t0 = time.time()
+    for s in range(0, len(idx), bs):
+        items = [ds[i] for i in idx[s:s + bs]]
+        imgs = torch.stack([it[0] for it in items]).to(device)
+        labels = torch.tensor([it[1] for it in items], device=device)
+        first = items[0][2]                                    # global index of the batch's first sample
+        if noise is not None:
+            from ..noise import imagenet_c as C
+            C.corrupt_batch_(imgs, C.CORRUPTION_NAMES.index(args.corruption), args.severity, seed=args.seed,
+                             sample_offset=first)
+        if attack is not None:
+            from ..noise import rng
+            rng.manual_seed(args.seed, first)
+            x01 = imgs.permute(0, 3, 1, 2).float().div(255.0).contiguous()
+            kw = {k: v for k, v in attack.config.items()}
+            from ..noise.registry import function_dict
+            adv_x = function_dict[attack.noise_type](x01, labels, **kw)
+            logits = f_model(adv_x)
+        elif use_hip:
+            logits = f_model.rart_engine.logits_from_u8(imgs, IMAGENET_MEAN, IMAGENET_STD)
+        else:
+            with torch.no_grad():
+                logits = model((imgs.permute(0, 3, 1, 2).float() / 255.0 - mean) / std)
+        a, b = topk_correct(logits.float(), labels)
+        c1, c5, cnt = c1 + a, c5 + b, cnt + len(items)
+    c1, c5, cnt = all_reduce_counters([c1, c5, cnt], device)
+    res = {'top1': c1 / max(cnt, 1), 'top5': c5 / max(cnt, 1), 'count': cnt, 'world_size': world,
+           'noise': args.corruption or args.attack or 'none', 'seconds': time.time() - t0}
+    if rank == 0:
+        print(json.dumps(res))
+    return res
+
+
+def train(cfg, args, rank, world, device):
+    """(Adversarial) training loop; returns the last loss (float) for tests."""
+    dcfg = cfg.get('data', {})
+    n = int(dcfg.get('fake_size', 512))
+    bs = int(dcfg.get('batch_size', 32))
+    size = int(dcfg.get('input_size', 224))
+    max_iter = int(cfg.get('max_iter', args.max_iter))
+    ds = FakeImageNet(n, size)
+    model = build_model(cfg).to(device)
+    ocfg = cfg.get('optimizer', {'type': 'SGD', 'kwargs': {'nesterov': True, 'momentum': 0.9, 'weight_decay': 1e-4}})
+    okw = dict(ocfg.get('kwargs', {}))
+    lcfg = cfg.get('lr_scheduler', {}).get('kwargs', {})
+    base_lr, warmup_lr = float(lcfg.get('base_lr', 0.1)), float(lcfg.get('warmup_lr', 0.4))
+    if ocfg.get('type', 'SGD') == 'AdamW':
+        opt = torch.optim.AdamW(model.parameters(), lr=base_lr, **okw)
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=base_lr, **okw)
+    ddp = model
+    if world > 1:
+        ddp = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[device.index] if device.type == 'cuda' else None, bucket_cap_mb=64,
+            gradient_as_bucket_view=True)
+    ema = None
+    if cfg.get('ema', {}).get('enable', False):
+        decay = float(cfg['ema'].get('kwargs', {}).get('decay', 0.9999))
+        ema = {k: v.detach().clone() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    ls = float(cfg.get('label_smooth', 0.0))
+    adv = cfg.get('adv_train', None)                        # {'eps': '4/255', 'steps': 3, 'rel_stepsize': 0.4}
+    mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
+    use_amp = device.type == 'cuda' and cfg.get('bf16', True)
+    idx = shard_indices(n, rank, world)
+    loss_v = float('nan')
+    for it in range(max_iter):
+        lr = cosine_lr(it, max_iter, base_lr, warmup_lr, int(lcfg.get('warmup_steps', max(max_iter // 20, 1))))
+        for gp in opt.param_groups:
+            gp['lr'] = lr
+        sel = [idx[(it * bs + j) % len(idx)] for j in range(bs)]
+        items = [ds[i] for i in sel]
+        imgs = torch.stack([x[0] for x in items]).to(device)
+        labels = torch.tensor([x[1] for x in items], device=device)
+        x01 = imgs.permute(0, 3, 1, 2).float().div(255.0)
+        if adv and device.type == 'cuda':
+            # inner maximisation on the HIP engine with the CURRENT weights, BN in inference mode
+            from ..model.engine import EngineModel
+            from ..noise import adv as A
+            model.eval()
+            f_model = EngineModel(model, takes_normalized=False)
+            x01 = A.pgd_linf(x01.contiguous(), labels, f_model, parse_eps(adv['eps']),
+                             float(adv.get('rel_stepsize', 3 / 40)), int(adv.get('steps', 3)), seed=it,
+                             sample_offset=sel[0])
+        model.train()
+        xin = ((x01 - mean) / std).contiguous(memory_format=torch.channels_last)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=use_amp):
+            out = ddp(xin)
+            loss = F.cross_entropy(out.float(), labels, label_smoothing=ls)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()                                     # DDP: bucketed all-reduce overlapped with backward
+        opt.step()
+        if ema is not None:
+            with torch.no_grad():
+                for k, v in model.state_dict().items():
+                    if k in ema:
+                        ema[k].mul_(decay).add_(v.detach(), alpha=1 - decay)
+        loss_v = float(loss.detach())
+        if rank == 0 and (it % int(cfg.get('saver', {}).get('print_freq', 10)) == 0 or it == max_iter - 1):
+            print(json.dumps({'iter': it, 'loss': loss_v, 'lr': lr}))
+    return loss_v, model
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', required=True)
+    ap.add_argument('--evaluate', action='store_true')
+    ap.add_argument('--attack', default=None)
+    ap.add_argument('--eps', default='8/255')
+    ap.add_argument('--steps', type=int, default=0)
+    ap.add_argument('--corruption', default=None)
+    ap.add_argument('--severity', type=int, default=3)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--engine', choices=['hip', 'torch'], default='hip')
+    ap.add_argument('--max-iter', type=int, default=20)
+    args = ap.parse_args(argv)
+    cfg = load_config(args.config)
+    rank, world, device = init_dist()
+    try:
+        if args.evaluate:
+            return evaluate(cfg, args, rank, world, device)
+        return train(cfg, args, rank, world, device)[0]
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
