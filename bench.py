@@ -245,7 +245,7 @@ def main():
         if world == 1:
             avg, med = measure_gaussian_roofline(B, device)
             algo = BYTES_PER_IMAGE * B
-            out['roofline'] = {'kernel': 'k_normal_noise_native<0> (gaussian_noise, B=256, u8 NHWC in/out)',
+            out['roofline'] = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, B=256, u8 NHWC in/out)',
                                'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
                                'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': None,
                                'avg_launch_us': avg * 1e6, 'median_launch_us': med * 1e6,

@@ -103,6 +103,14 @@ int rart_rng_uniform_u32(uint32_t* out, int n_samples, size_t elems_per_sample,
                          uint64_t seed, uint64_t sample_offset, int stream_id, rart_stream_t stream);
 int rart_rng_normal_f32(float* out, int n_samples, size_t elems_per_sample,
                         uint64_t seed, uint64_t sample_offset, int stream_id, rart_stream_t stream);
+/* Normal generator of gaussian_noise / speckle_noise: 1 (default) = matrix-core CLT generator (int8 MFMA
+ * against a Hadamard matrix, one random byte per normal, cubic kurtosis correction) whenever a sample is a
+ * whole number of 1 KiB chunks; 0 = Threefry + Box-Muller everywhere.  rart_rng_noise_field_f32 replays the
+ * N(0,1) field those two corruptions use under the current setting. */
+int rart_set_normal_generator(int kind);
+int rart_get_normal_generator(void);
+int rart_rng_noise_field_f32(float* out, int n_samples, size_t elems_per_sample, uint64_t seed,
+                             uint64_t sample_offset, rart_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Adversarial step kernels (x, x0, g: fp32, batch-major, n_per_sample elements per sample,

@@ -23,6 +23,9 @@ SIGNATURES = {
     'rart_u8_to_normalized': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_rng_uniform_u32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),
     'rart_rng_normal_f32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),
+    'rart_set_normal_generator': (c_int, [c_int]),
+    'rart_get_normal_generator': (c_int, []),
+    'rart_rng_noise_field_f32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_void_p]),
     'rart_attack_workspace_bytes': (c_size_t, [c_int]),
     'rart_attack_init_linf': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, c_float, c_float,
                                       c_u64, c_u64, c_void_p, c_void_p]),

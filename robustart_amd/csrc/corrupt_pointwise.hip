@@ -80,6 +80,128 @@ __global__ __launch_bounds__(kBlock) void k_normal_noise_native_scalar(
   }
 }
 
+// ---- matrix-core normal generator -----------------------------------------------------------------
+// The Box-Muller kernels above are bound by integer VALU throughput (~4 cycles per wave64 instruction on
+// gfx950): random BITS alone cost 12 instructions per 16-bit pair with Threefry-13.  This path spends ONE
+// random byte per normal and moves the bits->gaussian transform onto the otherwise idle matrix cores:
+//   S = A x H,  A = 32x32 iid uniform int8 (Threefry bytes), H = 32x32 Hadamard (+-1, orthogonal)
+// one v_mfma_i32_32x32x32_i8 per wave yields 1024 sums of 32 uniform bytes: by orthogonality the 32 sums of
+// a row are uncorrelated, each is a 32-term CLT sum (excess kurtosis -1.2/32), and a cubic Cornish-Fisher
+// term z = y + (0.0375/24)(y^3 - 3y) removes that kurtosis (residual: 6th cumulant, < 1e-4 in density).
+// Known limitation: the 32 outputs that share a matrix row are uncorrelated but not
+// independent (their sum of squares equals that of the 32 input bytes).
+// The field is a pure function of (seed, sample, 1 KiB chunk index): one wave = one aligned chunk.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+
+struct HadamardTable {
+  uint32_t w[64][4];
+};
+constexpr HadamardTable make_hadamard() {
+  HadamardTable t{};
+  for (int lane = 0; lane < 64; ++lane)
+    for (int q = 0; q < 4; ++q) {
+      uint32_t word = 0;
+      for (int b = 0; b < 4; ++b) {
+        const int k = 16 * (lane >> 5) + q * 4 + b, j = lane & 31;
+        int x = k & j, par = 0;
+        while (x) { par ^= x & 1; x >>= 1; }
+        word |= (uint32_t)(par ? 0xFFu : 0x01u) << (8 * b);   // int8 -1 / +1
+      }
+      t.w[lane][q] = word;
+    }
+  return t;
+}
+__device__ const HadamardTable g_hadamard = make_hadamard();
+
+// A bytes get their LSB forced to 1: uniform over the 128 odd values -127..127, i.e. exactly zero mean
+// (plain int8 has mean -1/2, which the all-ones Hadamard column would turn into a -16 offset).
+constexpr float kCltSigma = 418.0334915f;        // sqrt(32 * (128^2 - 1) / 3)
+constexpr float kCltA = 0.9953120f / kCltSigma;  // z = s * (A + B s^2): Cornish-Fisher inverse, kappa4 = -1.20015/32
+constexpr float kCltB = 0.0015627f / (kCltSigma * kCltSigma * kCltSigma);
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 16 raw CLT sums for this lane's 16 elements of chunk `chunk` (all 64 lanes of the wave must call this)
+__device__ __forceinline__ i32x4 clt_hadamard_operand(int lane) {
+  i32x4 b = {(int)g_hadamard.w[lane][0], (int)g_hadamard.w[lane][1], (int)g_hadamard.w[lane][2],
+             (int)g_hadamard.w[lane][3]};
+  return b;
+}
+
+__device__ __forceinline__ void clt_sums16(uint32_t k0, uint32_t k1, uint32_t chunk, uint32_t sample, int lane,
+                                           const i32x4 b, float* s) {
+  const uint2 w0 = threefry2x32(k0, k1, rart_ctr0(chunk * 128u + lane * 2u, 14), sample);
+  const uint2 w1 = threefry2x32(k0, k1, rart_ctr0(chunk * 128u + lane * 2u + 1u, 14), sample);
+  const i32x4 a = {(int)(w0.x | 0x01010101u), (int)(w0.y | 0x01010101u), (int)(w1.x | 0x01010101u),
+                   (int)(w1.y | 0x01010101u)};
+  // (the builtin, not inline asm: hipcc drains every outstanding load with s_waitcnt vmcnt(0) in front of an
+  //  asm statement, which would serialise the prefetched next chunk behind this chunk's arithmetic)
+  i32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[e] = (float)acc[e];
+}
+
+__device__ __forceinline__ uint32_t pack4_floor_sat(float a, float b, float c, float d) {
+  // v_cvt_pk_u8_f32 saturates to [0,255] and rounds to nearest even; floor first = np.uint8 truncation of the
+  // clipped value (negative values saturate to 0 either way)
+  uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(a), 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(b), 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c), 2, w);
+  return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(d), 3, w);
+}
+
+// One wave = one aligned 1 KiB chunk (chunk ids run across samples, so any batch packs exactly).
+// Measured alternatives: 4 chunks per wave with the loads issued up front loses to grid-tail
+// quantisation (9408 waves on 8192 slots); a persistent wave loop with the next chunk prefetched is defeated
+// by hipcc's conservative s_waitcnt vmcnt(0) at the loop header (stores and loads share the counter).
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_normal_noise_mfma(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                              uint32_t chunks_per_sample, uint32_t total_chunks,
+                                                              float c, uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (g >= total_chunks) return;                                // wave-uniform
+  const uint4 cur = in[(size_t)g * 64 + lane];
+  const i32x4 hb = clt_hadamard_operand(lane);
+  const float gsc = KIND == 0 ? 255.0f * c : c;
+  const float ga = gsc * kCltA, gb = gsc * kCltB;
+  const f32x2 ga2 = {ga, ga}, gb2 = {gb, gb};
+  const uint32_t sample = g / chunks_per_sample, chunk = g - sample * chunks_per_sample;
+  float s[16];
+  clt_sums16(k0, k1, chunk, sample_base + sample, lane, hb, s);
+  const uint32_t wi[4] = {cur.x, cur.y, cur.z, cur.w};
+  uint32_t wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // two elements per v_pk_* instruction (the packed fp32 pipe is the only 2-results-per-issue VALU path)
+    f32x2 y[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x2 x = {(float)((wi[j] >> (16 * hh)) & 0xFFu), (float)((wi[j] >> (16 * hh + 8)) & 0xFFu)};
+      const f32x2 sv = {s[j * 4 + 2 * hh], s[j * 4 + 2 * hh + 1]};
+      f32x2 t = __builtin_elementwise_fma(gb2, sv * sv, ga2);   // g * (A + B s^2)
+      if (KIND == 1) t = t * x;                                  // speckle: x + x*c*z
+      y[hh] = __builtin_elementwise_fma(t, sv, x);
+    }
+    wo[j] = pack4_floor_sat(y[0].x, y[0].y, y[1].x, y[1].y);
+  }
+  out[(size_t)g * 64 + lane] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+}
+
+// replay of the field for the parity tests: z[sample][element] exactly as the kernel above forms it
+__global__ __launch_bounds__(kBlock) void k_clt_field(float* __restrict__ out, uint32_t vec_per_sample, uint32_t k0,
+                                                      uint32_t k1, uint32_t sample_base) {
+  const uint32_t sample = blockIdx.y;
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= vec_per_sample) return;
+  float s[16];
+  clt_sums16(k0, k1, v >> 6, sample_base + sample, threadIdx.x & 63, clt_hadamard_operand(threadIdx.x & 63), s);
+  float* o = out + ((size_t)sample * vec_per_sample + v) * 16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e] = s[e] * fmaf(kCltB, s[e] * s[e], kCltA);
+}
+
 // impulse_noise (corruptions.py:136-140 -> skimage random_noise 's&p'): each element flips with
 // probability `amount` (24-bit threshold compare on the raw word), salt/pepper by one more bit.
 // One Threefry call (2 words) serves 2 elements: word>>8 = flip uniform, bit 0 = salt.
@@ -387,6 +509,19 @@ __global__ __launch_bounds__(kBlock) void k_frost_blend(const uint8_t* __restric
 
 // One item per thread when the launch stays below ~16k workgroups (no grid-stride tail
 // imbalance: 9408 vectors per 224x224 image = 36.75 x 256), grid-strided beyond that.
+// 1 = matrix-core CLT generator for gaussian/speckle noise when a sample is a whole number of 1 KiB chunks
+// (default), 0 = Threefry + Box-Muller everywhere.  The generator is part of the (seed -> field) definition.
+static int g_normal_generator = 1;
+extern "C" int rart_set_normal_generator(int kind) {
+  if (kind != 0 && kind != 1) {
+    rart_set_error("rart_set_normal_generator: kind must be 0 (Box-Muller) or 1 (matrix-core CLT)");
+    return RART_ERR_INVALID;
+  }
+  g_normal_generator = kind;
+  return RART_OK;
+}
+extern "C" int rart_get_normal_generator(void) { return g_normal_generator; }
+
 static dim3 grid2d(uint32_t items_per_sample, int n) {
   uint32_t gx = (items_per_sample + kBlock - 1) / kBlock;
   uint32_t cap = (uint32_t)(16384 / (n < 1 ? 1 : n));
@@ -425,6 +560,15 @@ int rart_launch_pointwise(int id, const RartCorruptArgs& a) {
         else
           hipLaunchKernelGGL(k_normal_noise_injected<1>, dim3(g), dim3(kBlock), 0, a.stream, a.in, a.out,
                              (const double*)inj0, total);
+      } else if (vec_ok && g_normal_generator == 1 && eps % 1024 == 0) {
+        const uint32_t cps = (uint32_t)(eps / 1024), total = cps * (uint32_t)a.n;
+        const dim3 g((total + kBlock / 64 - 1) / (kBlock / 64));
+        if (id == RART_GAUSSIAN_NOISE)
+          hipLaunchKernelGGL(k_normal_noise_mfma<0>, g, dim3(kBlock), 0, a.stream, (const uint4*)a.in, (uint4*)a.out,
+                             cps, total, (float)c, k0, k1, sbase);
+        else
+          hipLaunchKernelGGL(k_normal_noise_mfma<1>, g, dim3(kBlock), 0, a.stream, (const uint4*)a.in, (uint4*)a.out,
+                             cps, total, (float)c, k0, k1, sbase);
       } else if (vec_ok) {
         const uint32_t vps = (uint32_t)(eps / 16);
         const dim3 g = grid2d(vps, a.n);
@@ -513,4 +657,19 @@ int rart_launch_pointwise(int id, const RartCorruptArgs& a) {
   }
   RART_CHECK_LAUNCH("pointwise corruption launch");
   return RART_OK;
+}
+
+// The standard-normal field gaussian_noise / speckle_noise draw for `elems` elements per sample, replayed
+// for the parity tests (same generator selection as the corruption kernels).
+extern "C" int rart_rng_noise_field_f32(float* out, int n_samples, size_t elems, uint64_t seed, uint64_t sample_offset,
+                                        rart_stream_t stream) {
+  RART_CHECK_ARG(out && n_samples > 0 && elems > 0 && elems < (1ull << 30), "rart_rng_noise_field_f32: bad arguments");
+  if (g_normal_generator == 1 && elems % 1024 == 0) {
+    const uint32_t vps = (uint32_t)(elems / 16);
+    hipLaunchKernelGGL(k_clt_field, dim3((vps + kBlock - 1) / kBlock, n_samples), dim3(kBlock), 0,
+                       (hipStream_t)stream, out, vps, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset);
+    RART_CHECK_LAUNCH("rart_rng_noise_field_f32");
+    return RART_OK;
+  }
+  return rart_rng_normal_f32(out, n_samples, elems, seed, sample_offset, 0, stream);
 }

@@ -144,11 +144,21 @@ def test_odd_sizes_and_single_pixel_rows():
 # ---- native RNG ---------------------------------------------------------------------------
 
 def _native_normals(n, elems, seed, offset):
+    """The N(0,1) field gaussian_noise / speckle_noise use under the current generator setting."""
     from robustart_amd import _lib
     z = torch.empty(n, elems, dtype=torch.float32, device='cuda')
-    _lib.check(_lib.load().rart_rng_normal_f32(_lib.ptr(z), n, elems, seed, offset, 0, _lib.stream_ptr()))
+    _lib.check(_lib.load().rart_rng_noise_field_f32(_lib.ptr(z), n, elems, seed, offset, _lib.stream_ptr()))
     torch.cuda.synchronize()
     return z.cpu().numpy()
+
+
+@pytest.fixture(params=[1, 0], ids=['mfma-clt', 'box-muller'])
+def generator(request):
+    from robustart_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.rart_set_normal_generator(request.param))
+    yield request.param
+    _lib.check(lib.rart_set_normal_generator(1))
 
 
 def test_device_threefry_matches_host_mirror():
@@ -165,7 +175,7 @@ def test_device_threefry_matches_host_mirror():
 
 
 @pytest.mark.parametrize('name', ['gaussian_noise', 'speckle_noise'])
-def test_native_noise_matches_oracle_on_replayed_draws(name):
+def test_native_noise_matches_oracle_on_replayed_draws(name, generator):
     sev, seed, off = 3, 1234, 1000
     batch = make_batch_u8(4, seed=3)
     got = _run(name, batch, sev, None, seed, off)
@@ -182,15 +192,25 @@ def test_native_noise_matches_oracle_on_replayed_draws(name):
     np.testing.assert_array_equal(np.concatenate([a, b]), got)
 
 
-def test_native_normal_distribution():
+def test_native_normal_distribution(generator):
     from scipy import stats
-    z = _native_normals(2, 224 * 224 * 3, 99, 0).ravel().astype(np.float64)
-    assert abs(z.mean()) < 5 / np.sqrt(z.size)
-    assert abs(z.std() - 1) < 5e-3
-    assert stats.kstest(z[:200000], 'norm').pvalue > 1e-3
-    assert abs(stats.kurtosis(z)) < 0.03
-    # neighbouring elements / samples are uncorrelated
-    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 5e-3
+    z = _native_normals(8, 224 * 224 * 3, 99, 0).astype(np.float64)
+    flat = z.ravel()
+    print('generator %d: mean %.2e std %.5f skew %.4f exkurt %.4f |z|max %.2f' % (
+        generator, flat.mean(), flat.std(), stats.skew(flat), stats.kurtosis(flat), np.abs(flat).max()))
+    assert abs(flat.mean()) < 5 / np.sqrt(flat.size)
+    assert abs(flat.std() - 1) < 3e-3
+    assert abs(stats.skew(flat)) < 0.01 and abs(stats.kurtosis(flat)) < 0.015
+    assert stats.kstest(flat[:400000], 'norm').pvalue > 1e-3
+    assert stats.kstest(z[3, 1000:201000], 'norm').pvalue > 1e-3
+    # tail mass: P(|z| > 3) = 2.6998e-3
+    assert abs((np.abs(flat) > 3).mean() - 2.6998e-3) < 2.5e-4
+    # neighbouring elements, the 16 elements of one lane, elements 16 bytes apart (same matrix row in the
+    # MFMA generator) and the same element of neighbouring samples are all uncorrelated
+    assert abs(np.corrcoef(flat[:-1], flat[1:])[0, 1]) < 3e-3
+    assert abs(np.corrcoef(flat[:-16], flat[16:])[0, 1]) < 3e-3
+    assert abs(np.corrcoef(z[0], z[1])[0, 1]) < 6e-3
+    assert abs(np.corrcoef(flat[:-1] ** 2, flat[1:] ** 2)[0, 1]) < 3e-3
 
 
 def test_native_gaussian_noise_statistics():
