@@ -140,6 +140,22 @@ def measure_gaussian_roofline(B, device, launches=40):
     return avg * 1e-3, ms[len(ms) // 2] * 1e-3
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_traffic.json, produced by profiles/summarize_pmc.py); None if absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+            d = json.load(f)
+        if key == 'igemm':
+            return d['k_conv_igemm_bf16_all']['hbm_bytes']
+        for k, v in d['kernels'].items():
+            if key in k:
+                return v['hbm_bytes']
+    except Exception:
+        pass
+    return None
+
+
 def measure_igemm_roofline(path, images, labels):
     """Dominant kernel of the step: k_conv_igemm_bf16 (every conv / fc of ResNet-50, forward and
     backward-to-input).  One PGD gradient evaluation (forward + backward) at B = 256 is timed launch by
@@ -155,7 +171,8 @@ def measure_igemm_roofline(path, images, labels):
     flops = sum(f for f, _, _ in prof)
     return {'kernel': 'k_conv_igemm_bf16 (ResNet-50 forward + backward-to-input, B=256, %d launches)' % len(prof),
             'bound': 'mfma', 'achieved': flops / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-            'frac': flops / secs / MFMA_BF16_PEAK, 'traffic': None,
+            'frac': flops / secs / MFMA_BF16_PEAK, 'traffic': pmc_traffic('igemm'),
+            'traffic_note': 'HBM bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB units',
             'avg_launch_us': secs / len(prof) * 1e6, 'launches': len(prof),
             'algorithmic_flops_per_launch': flops / len(prof), 'kernel_seconds_per_fwd_bwd': secs}
 
@@ -247,7 +264,7 @@ def main():
             algo = BYTES_PER_IMAGE * B
             out['roofline'] = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, B=256, u8 NHWC in/out)',
                                'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
-                               'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': None,
+                               'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': pmc_traffic('k_normal_noise_mfma'),
                                'avg_launch_us': avg * 1e6, 'median_launch_us': med * 1e6,
                                'algorithmic_bytes_per_launch': algo}
             out['hbm_roofline_gaussian_noise'] = out.pop('roofline')
