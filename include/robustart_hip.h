@@ -159,13 +159,23 @@ int rart_apgd_step(float* x_adv, float* x_adv_old, const float* grad, const floa
                    const float* step_size, int batch, size_t n_per_sample, int norm, float eps, float a,
                    void* workspace, size_t workspace_bytes, rart_stream_t stream);
 
+/* Square attack, Linf (Attacks/autoattack/square.py:228-258).  Start: x_best = clamp(x0 + eps*sign, 0, 1) with one
+ * random sign per (image, channel, column); injected_sign: NULL or fp32 [batch][c][w] of +-1.
+ * Proposal: x_new = clamp(min(max(x_best + delta, x0-eps), x0+eps), 0, 1), delta = 2*eps*sign_host[ch] inside the
+ * s x s window at (vh, vw), shared by the whole batch like the reference. */
+int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int h, int w, float eps, uint64_t seed,
+                          uint64_t sample_offset, const float* injected_sign, rart_stream_t stream);
+int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0, int batch, int c, int h, int w,
+                             float eps, int vh, int vw, int s, const float* sign_host, rart_stream_t stream);
+
 /* Per-sample select: dst[i] = src[i] where mask[i] != 0 (rows of n_per_sample floats).
  * The x_best / x_best_adv / grad_best bookkeeping of autopgd_base.py:389-406,426-427. */
 int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batch, size_t n_per_sample,
                      rart_stream_t stream);
 
 /* Row-wise losses on logits [batch][classes] fp32 (autopgd_base.py:198-204,599-604; CE of
- * foolbox / imfgsm_attack.py:83).  kind: 0 = CE, 1 = DLR, 2 = targeted DLR (y_target required).
+ * foolbox / imfgsm_attack.py:83).  kind: 0 = CE, 1 = DLR, 2 = targeted DLR (y_target required),
+ * 3 = margin z_y - max_{j != y} z_j (Attacks/autoattack/square.py:68-86).
  * loss_out[batch] (nullable), dlogits_out[batch][classes] = d(sum_i loss_i * scale)/dlogits (nullable),
  * pred_out[batch] int32 argmax (nullable). */
 int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* y_target, int batch, int classes,
@@ -187,7 +197,8 @@ int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* y_targ
  *   W          :  bf16 [round_up(n_cols, 128 if n_cols > 64 else 64)][n_taps * k_per_tap], K contiguous
  *   destination:  element ((image*dst_h + oy*dst_sy + dst_oy)*dst_w + ox*dst_sx + dst_ox)*dst_pix_stride + n
  *   epilogue   :  v = acc + bias[n]; v += res[dst index]; if (mask) v = mask[dst index] > 0 ? v : 0;
- *                 if (flags & 1) v = max(v, 0); store bf16 (or fp32 if flags & 2).  `res` may alias `dst`.
+ *                 if (flags & 1) v = max(v, 0); if (flags & 4) v = gelu(v); store bf16 (or fp32 if flags & 2).
+ *                 `res` may alias `dst`.
  * Covers forward convs, backward-to-input of stride-1 convs, each input-parity class of a stride-2
  * conv's backward, the 7x7 stem on the padded 4-channel hi/lo image, and fully connected layers.
  * ------------------------------------------------------------------------------------- */
@@ -206,7 +217,13 @@ typedef struct rart_conv_desc {
   int64_t tap_src_off[16];
   int32_t n_cols;
   int32_t dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
-  int32_t flags;          /* 1 = ReLU, 2 = fp32 output */
+  int32_t flags;          /* 1 = ReLU, 2 = fp32 output, 4 = exact GELU */
+  /* batched problems (attention: one GEMM per (image, head)): problem z in [0, n_batched) splits into
+   * zo = z / z_inner, zi = z % z_inner; zo*_z_outer + zi*_z_inner elements are added to src / wgt / dst (res and
+   * mask follow dst).  n_batched <= 1 = a single problem.  wgt_row_stride: elements between consecutive weight
+   * rows (0 = n_taps * k_per_tap), so K / V can be read in place from the fused qkv activation. */
+  int32_t n_batched, z_inner, wgt_row_stride, reserved_;
+  int64_t src_z_outer, src_z_inner, wgt_z_outer, wgt_z_inner, dst_z_outer, dst_z_inner;
 } rart_conv_desc;
 
 int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
@@ -232,6 +249,23 @@ int rart_engine_stem_col2im(const void* patches, float* grad, int n, int h, int 
                             const float* std_host, rart_stream_t stream);
 /* fp32 [rows][cols] -> bf16 [rows][dst_cols] (zero padded): dlogits -> GEMM operand. */
 int rart_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int dst_cols, rart_stream_t stream);
+
+/* ---- ViT-B/16 forward (model `vit_base`; every matmul incl. attention runs on rart_conv_igemm_bf16) ---- */
+/* image -> normalised patches [n][(h/p)*(w/p)][3*p*p] (k = c*p*p + r*p + s, the Conv2d(3, D, p, p) weight order),
+ * bf16 hi/lo planes. */
+int rart_vit_patchify(const void* src, int src_is_u8, void* hi, void* lo, int n, int h, int w, int patch,
+                      const float* mean_host, const float* std_host, rart_stream_t stream);
+/* x[b][0] = cls_pos0 (class token + its position embedding); x[b][t] += pos[t] for t >= 1.  x bf16 [n][tokens][dim]. */
+int rart_vit_add_pos_cls(void* x, const float* cls_pos0, const float* pos, int n, int tokens, int dim,
+                         rart_stream_t stream);
+int rart_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int rows, int dim,
+                        int64_t in_row_stride, int64_t out_row_stride, float eps, rart_stream_t stream);
+/* probs[r][0..n_valid) = softmax(scale * scores[r][0..n_valid)), zeros up to ld_out (the K padding of P.V). */
+int rart_softmax_rows_bf16(const void* scores, void* probs, int64_t rows, int n_valid, int ld_in, int ld_out,
+                           float scale, rart_stream_t stream);
+/* vt[n][heads][head_dim][t_pad] <- V slice of the fused qkv activation [n][tokens][qkv_ld] (zero padded). */
+int rart_vit_transpose_v(const void* qkv, void* vt, int n, int tokens, int heads, int head_dim, int qkv_ld, int v_off,
+                         int t_pad, rart_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -304,3 +304,87 @@ def apgd_targeted_perturb(model_fn, x, y, norm, eps, n_iter, init_ts, n_target_c
             acc[ind_to_fool[ind_curr]] = False
             adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
     return adv
+
+
+# ---------------------------------------------------------------------------------------
+# Square attack, Linf (Attacks/autoattack/square.py:68-86,192-294,532-600) -- pinned
+# ---------------------------------------------------------------------------------------
+
+def square_p_selection(it, p_init, n_queries, rescale):
+    """square.py:192-219."""
+    if rescale:
+        it = int(it / n_queries * 10000)
+    if 10 < it <= 50:
+        return p_init / 2
+    if 50 < it <= 200:
+        return p_init / 4
+    if 200 < it <= 500:
+        return p_init / 8
+    if 500 < it <= 1000:
+        return p_init / 16
+    if 1000 < it <= 2000:
+        return p_init / 32
+    if 2000 < it <= 4000:
+        return p_init / 64
+    if 4000 < it <= 6000:
+        return p_init / 128
+    if 6000 < it <= 8000:
+        return p_init / 256
+    if 8000 < it:
+        return p_init / 512
+    return p_init
+
+
+def margin_loss(logits, y):
+    """square.py:68-86 (untargeted, loss='margin'): y_corr - max over the other classes."""
+    logits = logits.clone()
+    u = torch.arange(logits.shape[0])
+    y_corr = logits[u, y].clone()
+    logits[u, y] = -float('inf')
+    return y_corr - logits.max(dim=-1)[0]
+
+
+def square_linf_single_run(model_fn, x, y, eps, n_queries, p_init, rescale, init_sign, draws):
+    """square.py:221-294.  init_sign: [B,c,1,w] of +-1 (random_choice); draws[i] = (vh, vw, sign[c]) of query i
+    (random_int x2 + random_choice([c,1,1])).  The reference re-attacks only margin_min > 0; masks do the same."""
+    with torch.no_grad():
+        c, h, w = x.shape[1:]
+        n_features = c * h * w
+        x_best = torch.clamp(x + eps * init_sign, 0., 1.)
+        margin_min = margin_loss(model_fn(x_best), y)
+        loss_min = margin_min.clone()
+        for i_iter in range(n_queries):
+            todo = margin_min > 0.0
+            if not todo.any():
+                break
+            p = square_p_selection(i_iter, p_init, n_queries, rescale)
+            s = max(int(round(math.sqrt(p * n_features / c))), 1)
+            vh, vw, sg = draws[i_iter]
+            new_deltas = torch.zeros([c, h, w])
+            new_deltas[:, vh:vh + s, vw:vw + s] = 2. * eps * sg.view(c, 1, 1)
+            x_new = x_best + new_deltas
+            x_new = torch.min(torch.max(x_new, x - eps), x + eps)
+            x_new = torch.clamp(x_new, 0., 1.)
+            margin = margin_loss(model_fn(x_new), y)
+            loss = margin
+            improved = (loss < loss_min) & todo
+            loss_min = torch.where(improved, loss, loss_min)
+            accept = (improved | (margin <= 0.)) & todo
+            margin_min = torch.where(accept, margin, margin_min)
+            x_best = torch.where(accept.view(-1, 1, 1, 1), x_new, x_best)
+        return x_best
+
+
+def square_linf_perturb(model_fn, x, y, eps, n_queries, p_init, rescale, init_sign_fn, draws):
+    """square.py:532-600 (n_restarts = 1).  init_sign_fn(n_to_fool) supplies the start signs for the
+    still-robust subset."""
+    x = x.detach().clone()
+    adv = x.clone()
+    acc = model_fn(x).max(1)[1] == y
+    ind = acc.nonzero().flatten()
+    if ind.numel() != 0:
+        adv_curr = square_linf_single_run(model_fn, x[ind], y[ind], eps, n_queries, p_init, rescale,
+                                          init_sign_fn(ind.numel()), draws)
+        fooled = (model_fn(adv_curr).max(1)[1] != y[ind]).nonzero().flatten()
+        adv[ind[fooled]] = adv_curr[fooled]
+    return adv

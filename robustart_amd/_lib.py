@@ -38,6 +38,10 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     'rart_apgd_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int,
                                c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    'rart_square_init_linf': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p,
+                                      c_void_p]),
+    'rart_square_propose_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
+                                         c_int, c_void_p, c_void_p]),
     'rart_select_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_logit_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
@@ -50,6 +54,13 @@ SIGNATURES = {
     'rart_engine_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_engine_stem_col2im': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_f32_to_bf16_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rart_vit_patchify': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+    'rart_vit_add_pos_cls': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rart_layernorm_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_int64,
+                                    c_float, c_void_p]),
+    'rart_softmax_rows_bf16': (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'rart_vit_transpose_v': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 
@@ -64,7 +75,11 @@ class ConvDesc(ctypes.Structure):
                 ('n_cols', ctypes.c_int32),
                 ('dst_h', ctypes.c_int32), ('dst_w', ctypes.c_int32), ('dst_sy', ctypes.c_int32), ('dst_sx', ctypes.c_int32),
                 ('dst_oy', ctypes.c_int32), ('dst_ox', ctypes.c_int32), ('dst_pix_stride', ctypes.c_int32),
-                ('flags', ctypes.c_int32)]
+                ('flags', ctypes.c_int32),
+                ('n_batched', ctypes.c_int32), ('z_inner', ctypes.c_int32), ('wgt_row_stride', ctypes.c_int32),
+                ('reserved_', ctypes.c_int32),
+                ('src_z_outer', ctypes.c_int64), ('src_z_inner', ctypes.c_int64), ('wgt_z_outer', ctypes.c_int64),
+                ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64)]
 
 
 _lib = None

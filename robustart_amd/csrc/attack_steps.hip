@@ -313,6 +313,45 @@ __global__ __launch_bounds__(kBlock) void k_select_rows(float* __restrict__ dst,
     dst[base + e] = src[base + e];
 }
 
+// ---- Square attack, Linf (Attacks/autoattack/square.py:228-258) ---------------------------------
+// start: x_best = clamp(x + eps * sign_stripes[b][c][w], 0, 1) (one sign per image column and channel)
+__global__ __launch_bounds__(kBlock) void k_square_init(float* __restrict__ xb, const float* __restrict__ x0, int C,
+                                                        int H, int W, float eps, uint32_t k0, uint32_t k1,
+                                                        uint32_t sbase, const float* __restrict__ inj) {
+  const uint32_t b = blockIdx.y;
+  const size_t nps = (size_t)C * H * W;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const int w = (int)(e % W), c = (int)(e / ((size_t)H * W));
+    float sg;
+    if (inj) {
+      sg = inj[((size_t)b * C + c) * W + w];
+    } else {
+      const uint2 wv = threefry2x32(k0, k1, rart_ctr0((uint32_t)(c * W + w), 3), sbase + b);
+      sg = (wv.x & 1u) ? 1.f : -1.f;
+    }
+    xb[b * nps + e] = clampf(x0[b * nps + e] + eps * sg, 0.f, 1.f);
+  }
+}
+// proposal: x_new = clamp(min(max(x_best + delta, x - eps), x + eps), 0, 1), delta = 2*eps*sign[c] inside the
+// s x s window at (vh, vw) -- the window and signs are shared by the whole batch (square.py:248-252)
+struct SquareSigns {
+  float s[8];
+};
+__global__ __launch_bounds__(kBlock) void k_square_propose(float* __restrict__ xn, const float* __restrict__ xb,
+                                                           const float* __restrict__ x0, size_t total, int C, int H,
+                                                           int W, float eps, int vh, int vw, int s, SquareSigns sg) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)((i / ((size_t)W * H)) % C);
+    const bool in = h >= vh && h < vh + s && w >= vw && w < vw + s;
+    const float two_eps = 2.f * eps;
+    const float d = in ? two_eps * sg.s[c] : 0.f;
+    float v = xb[i] + d;
+    const float x = x0[i];
+    v = fminf(fmaxf(v, x - eps), x + eps);
+    xn[i] = clampf(v, 0.f, 1.f);
+  }
+}
+
 // ---- row-wise logit losses: one wave per row ------------------------------------------------
 struct Top {
   float v;
@@ -358,6 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_logit_loss(const float* __restrict__
     top[r] = best;
     excl[r] = best.i;
     if (kind == 0) break;               // CE only needs the max
+    if (kind == 3 && r == 1) break;     // margin needs top-2
     if (kind == 1 && r == 2) break;     // DLR needs top-3
   }
   if (pred_out && lane == 0) pred_out[row] = top[0].i;
@@ -375,6 +415,16 @@ __global__ __launch_bounds__(kBlock) void k_logit_loss(const float* __restrict__
         dl[(size_t)row * classes + c] = scale * (p - (c == yy ? 1.f : 0.f));
       }
     }
+    return;
+  }
+  if (kind == 3) {
+    // margin (Attacks/autoattack/square.py:68-86): z_y - max over the other classes; d/dz = e_y - e_other
+    const bool ismax = top[0].i == yy;
+    const int other = ismax ? top[1].i : top[0].i;
+    if (loss_out && lane == 0) loss_out[row] = zy - (ismax ? top[1].v : top[0].v);
+    if (dl)
+      for (int c = lane; c < classes; c += 64)
+        dl[(size_t)row * classes + c] = scale * ((c == yy ? 1.f : 0.f) - (c == other ? 1.f : 0.f));
     return;
   }
   float N, D, loss;
@@ -529,6 +579,29 @@ int rart_apgd_step(float* xa, float* xold, const float* grad, const float* x0, c
   return RART_OK;
 }
 
+int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int h, int w, float eps, uint64_t seed,
+                          uint64_t sample_offset, const float* injected_sign, rart_stream_t stream) {
+  RART_CHECK_ARG(x_best && x0 && batch > 0 && c > 0 && h > 0 && w > 0, "rart_square_init_linf: bad arguments");
+  hipLaunchKernelGGL(k_square_init, grid_rows((size_t)c * h * w, batch), dim3(kBlock), 0, (hipStream_t)stream, x_best,
+                     x0, c, h, w, eps, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset, injected_sign);
+  RART_CHECK_LAUNCH("rart_square_init_linf");
+  return RART_OK;
+}
+
+int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0, int batch, int c, int h, int w,
+                             float eps, int vh, int vw, int s, const float* sign_host, rart_stream_t stream) {
+  RART_CHECK_ARG(x_new && x_best && x0 && sign_host && batch > 0 && c > 0 && c <= 8 && h > 0 && w > 0 && s > 0,
+                 "rart_square_propose_linf: bad arguments");
+  RART_CHECK_ARG(vh >= 0 && vw >= 0 && vh + s <= h && vw + s <= w, "rart_square_propose_linf: window outside the image");
+  SquareSigns sg;
+  for (int i = 0; i < 8; ++i) sg.s[i] = i < c ? sign_host[i] : 0.f;
+  const size_t total = (size_t)batch * c * h * w;
+  hipLaunchKernelGGL(k_square_propose, dim3(rart_grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x_new, x_best,
+                     x0, total, c, h, w, eps, vh, vw, s, sg);
+  RART_CHECK_LAUNCH("rart_square_propose_linf");
+  return RART_OK;
+}
+
 int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batch, size_t nps, rart_stream_t stream) {
   RART_CHECK_ARG(dst && src && mask && batch > 0 && nps > 0, "rart_select_rows: bad arguments");
   hipLaunchKernelGGL(k_select_rows, grid_rows(nps, batch), dim3(kBlock), 0, (hipStream_t)stream, dst, src, mask, nps);
@@ -539,9 +612,9 @@ int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batc
 int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* yt, int batch, int classes, int kind,
                     float scale, float* loss_out, float* dl, int32_t* pred_out, rart_stream_t stream) {
   RART_CHECK_ARG(logits && y && batch > 0 && classes > 0, "rart_logit_loss: bad arguments");
-  RART_CHECK_ARG(kind >= 0 && kind <= 2, "rart_logit_loss: kind must be 0 (CE), 1 (DLR), 2 (targeted DLR)");
+  RART_CHECK_ARG(kind >= 0 && kind <= 3, "rart_logit_loss: kind must be 0 (CE), 1 (DLR), 2 (targeted DLR), 3 (margin)");
   RART_CHECK_ARG(kind != 2 || yt != nullptr, "rart_logit_loss: targeted DLR needs y_target");
-  RART_CHECK_ARG(kind == 0 || classes >= (kind == 1 ? 3 : 4), "rart_logit_loss: too few classes for DLR");
+  RART_CHECK_ARG(kind == 0 || classes >= (kind == 3 ? 2 : (kind == 1 ? 3 : 4)), "rart_logit_loss: too few classes");
   const int rows_per_block = kBlock / 64;
   hipLaunchKernelGGL(k_logit_loss, dim3((batch + rows_per_block - 1) / rows_per_block), dim3(kBlock), 0,
                      (hipStream_t)stream, logits, y, yt, batch, classes, kind, scale, loss_out, dl, pred_out);

@@ -40,12 +40,16 @@ struct RartConvDescDev {
   int n_cols;
   int dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
   int flags;
+  // batched problems (blockIdx.y = z): z -> (zo = z / z_inner, zi = z % z_inner); element offsets added to
+  // src / wgt / dst(+res, mask); wgt_row_stride = elements between consecutive weight rows (0 = K)
+  int z_inner, wgt_row_stride;
+  long long src_zo, src_zi, wgt_zo, wgt_zi, dst_zo, dst_zi;
 };
 
 namespace {
 constexpr int BM = 128, BK = 32, LDK = BK + 8;  // LDS row = 40 bf16 = 80 B
 constexpr int kThreads = 256;
-enum { F_RELU = 1, F_OUT_F32 = 2 };
+enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -56,6 +60,21 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 
 template <int BN>
 __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvDescDev d) {
+  // batched problems: block-uniform base shifts, kept in scalars (copying the descriptor would move its tap
+  // tables from the kernarg segment into scratch)
+  const uint16_t* p_src = d.src;
+  const uint16_t* p_wgt = d.wgt;
+  const uint16_t* p_res = d.res;
+  const uint16_t* p_mask = d.mask;
+  long long p_dst_off = 0;
+  if (gridDim.y > 1) {
+    const int z = blockIdx.y, zo = z / d.z_inner, zi = z - zo * d.z_inner;
+    p_src += zo * d.src_zo + zi * d.src_zi;
+    p_wgt += zo * d.wgt_zo + zi * d.wgt_zi;
+    p_dst_off = zo * d.dst_zo + zi * d.dst_zi;
+    if (p_res) p_res += p_dst_off;
+    if (p_mask) p_mask += p_dst_off;
+  }
   constexpr int WN = BN / 2;        // wave sub-tile columns
   constexpr int TN = WN / 32;       // 32-wide MFMA tiles per wave along n
   constexpr int B_CHUNKS = BN * 4 / kThreads;  // 16-byte chunks of the W tile per thread (2 or 1)
@@ -118,6 +137,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
   }
 
   const int K = d.k_per_tap * d.n_taps;
+  const int WRS = d.wgt_row_stride > 0 ? d.wgt_row_stride : K;   // weight row stride in elements
   const int KT = K / BK;
   const int tiles_per_tap = d.k_per_tap / BK;
 
@@ -137,8 +157,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
   }
 #define RART_LOAD_B(I, DST)                                                                                     \
   {                                                                                                             \
-    const uint32_t woff = (uint32_t)((n0 + (tid >> 2) + 64 * (I)) * K + kt_ * BK + chunk * 8);                  \
-    DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.wgt) + (size_t)(woff * 2u));         \
+    const uint32_t woff = (uint32_t)((n0 + (tid >> 2) + 64 * (I)) * WRS + kt_ * BK + chunk * 8);                  \
+    DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_wgt) + (size_t)(woff * 2u));         \
   }
 #define RART_LOAD_TILE(KT_, SET)                                                                                \
   {                                                                                                             \
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
     const int tap = kt_ / tiles_per_tap;                                                                        \
     const int kc = (kt_ - tap * tiles_per_tap) * BK + chunk * 8;                                                \
     const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];                                                           \
-    const uint16_t* sbase = d.src + d.tap_src_off[tap];                                                         \
+    const uint16_t* sbase = p_src + d.tap_src_off[tap];                                                         \
     RART_LOAD_A(0, ra##SET##_0)                                                                                 \
     RART_LOAD_A(1, ra##SET##_1)                                                                                 \
     RART_LOAD_B(0, rb##SET##_0)                                                                                 \
@@ -236,8 +256,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
       mv[i] = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 pairs: mask passes
       if (off != 0xFFFFFFFFu) {
         const size_t bo = (size_t)((off + (uint32_t)col) * 2u);
-        if (d.res) rv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.res) + bo);
-        if (d.mask) mv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.mask) + bo);
+        if (p_res) rv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_res) + bo);
+        if (p_mask) mv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_mask) + bo);
       }
     }
     if (wm == h) {
@@ -277,8 +297,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
+      if (d.flags & F_GELU) {   // exact (erf) GELU, timm's nn.GELU default
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
+      }
       if (out_f32) {
-        float* o = reinterpret_cast<float*>(d.dst) + off + col;
+        float* o = reinterpret_cast<float*>(d.dst) + p_dst_off + off + col;
         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
       } else {
@@ -287,7 +311,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
         o.y = f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
         o.z = f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
         o.w = f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + off + col) = o;
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) = o;
       }
       }
     }
@@ -315,6 +339,13 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   for (int i = 0; i < 16; ++i) { d.tap_dy[i] = h->tap_dy[i]; d.tap_dx[i] = h->tap_dx[i]; d.tap_src_off[i] = h->tap_src_off[i]; }
   d.n_cols = h->n_cols; d.dst_h = h->dst_h; d.dst_w = h->dst_w; d.dst_sy = h->dst_sy; d.dst_sx = h->dst_sx;
   d.dst_oy = h->dst_oy; d.dst_ox = h->dst_ox; d.dst_pix_stride = h->dst_pix_stride; d.flags = h->flags;
+  const int nz = h->n_batched > 1 ? h->n_batched : 1;
+  d.z_inner = h->z_inner > 0 ? h->z_inner : 1;
+  d.wgt_row_stride = h->wgt_row_stride;
+  d.src_zo = h->src_z_outer; d.src_zi = h->src_z_inner; d.wgt_zo = h->wgt_z_outer; d.wgt_zi = h->wgt_z_inner;
+  d.dst_zo = h->dst_z_outer; d.dst_zi = h->dst_z_inner;
+  RART_CHECK_ARG(nz <= 65535, "rart_conv_igemm_bf16: n_batched must be <= 65535");
+  RART_CHECK_ARG(d.wgt_row_stride == 0 || d.wgt_row_stride % 8 == 0, "rart_conv_igemm_bf16: wgt_row_stride must keep 16-byte alignment");
   const long long M = (long long)d.batch * d.grid_h * d.grid_w;
   // the kernel addresses with 32-bit element offsets from uniform bases (saves ~20 VGPRs of 64-bit math)
   const long long src_elems = (long long)d.batch * d.src_h * d.src_w * d.src_pix_stride;
@@ -329,9 +360,9 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   const long long blocks = (long long)m_tiles8 * n_tiles;
   RART_CHECK_ARG(blocks < (1ll << 31), "rart_conv_igemm_bf16: grid too large");
   if (wide)
-    hipLaunchKernelGGL(k_conv_igemm_bf16<128>, dim3((uint32_t)blocks), dim3(kThreads), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(k_conv_igemm_bf16<128>, dim3((uint32_t)blocks, nz), dim3(kThreads), 0, (hipStream_t)stream, d);
   else
-    hipLaunchKernelGGL(k_conv_igemm_bf16<64>, dim3((uint32_t)blocks), dim3(kThreads), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(k_conv_igemm_bf16<64>, dim3((uint32_t)blocks, nz), dim3(kThreads), 0, (hipStream_t)stream, d);
   RART_CHECK_LAUNCH("rart_conv_igemm_bf16");
   return RART_OK;
 }

@@ -1,10 +1,13 @@
 """Model zoo entry point -- mirrors RobustART/model/__init__.py:1 (`get_model`).
 
 Only the two architectures BASELINE.json names are in scope:
-`resnet50_official` (and its aliases) now, `vit_base` / `vit_b16_224` as a later row."""
+`resnet50_official` (forward + backward-to-input HIP engine: engine.py) and `vit_base` / `vit_b16_224`
+(forward HIP engine: vit_engine.py)."""
 from .resnet_torch import resnet50
+from .vit_torch import vit_base
 
-_REGISTRY = {'resnet50_official': resnet50, 'resnet50': resnet50}
+_REGISTRY = {'resnet50_official': resnet50, 'resnet50': resnet50, 'vit_base': vit_base, 'vit_b16_224': vit_base,
+             'vit_base_patch16_224': vit_base}
 
 
 def get_model(config):

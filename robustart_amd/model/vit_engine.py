@@ -1,0 +1,162 @@
+"""ViT-B/16 forward on the hand-written HIP kernels (evaluation of clean / corrupted images, BASELINE config 3).
+
+Every matmul -- patch embedding, qkv, Q.K^T and P.V per (image, head) as batched problems, proj, MLP, head -- runs on
+rart_conv_igemm_bf16; LayerNorm, soft-max rows, the V transpose, patch extraction and the class-token / position add
+are the small kernels of csrc/vit_aux.hip.  bf16 activations, fp32 accumulation and statistics; the image enters as
+a hi+lo bf16 pair like the ResNet stem.  Reference module: robustart_amd/model/vit_torch.py."""
+import ctypes
+
+from .. import _lib
+
+F_RELU, F_OUT_F32, F_GELU = 1, 2, 4
+
+
+def _pad_rows(w, mult):
+    import torch
+    r = (w.shape[0] + mult - 1) // mult * mult
+    if r == w.shape[0]:
+        return w
+    return torch.cat([w, torch.zeros(r - w.shape[0], w.shape[1], dtype=w.dtype)], 0)
+
+
+class ViTEngine:
+    def __init__(self, model, device='cuda'):
+        torch = _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        m = model
+        self.D, self.H, self.ps = m.embed_dim, m.num_heads, m.patch_size
+        self.hd = self.D // self.H
+        dev = self.device
+
+        def wt(linear_w, n_cols):
+            w = linear_w.detach().float().cpu().to(torch.bfloat16).float()
+            return _pad_rows(w, 128 if n_cols > 64 else 64).to(torch.bfloat16).contiguous().to(dev)
+
+        def f32(t):
+            return t.detach().float().contiguous().to(dev)
+        pe = m.patch_embed.weight.detach().float().cpu().reshape(self.D, -1)       # [D][c*ps*ps + r*ps + s]
+        peb = pe.to(torch.bfloat16).float()
+        self.pe_w = _pad_rows(torch.cat([peb, peb], 1), 128).to(torch.bfloat16).contiguous().to(dev)   # hi | lo taps
+        self.pe_b = f32(m.patch_embed.bias)
+        pos = m.pos_embed.detach().float()[0]
+        self.pos = pos.contiguous().to(dev)
+        self.cls_pos0 = (m.cls_token.detach().float()[0, 0] + pos[0]).contiguous().to(dev)
+        self.tokens = pos.shape[0]
+        self.layers = []
+        for blk in m.blocks:
+            self.layers.append(dict(
+                n1g=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias), n2g=f32(blk.norm2.weight), n2b=f32(blk.norm2.bias),
+                qkv_w=wt(blk.attn.qkv.weight, 3 * self.D), qkv_b=f32(blk.attn.qkv.bias),
+                proj_w=wt(blk.attn.proj.weight, self.D), proj_b=f32(blk.attn.proj.bias),
+                fc1_w=wt(blk.fc1.weight, blk.fc1.out_features), fc1_b=f32(blk.fc1.bias),
+                fc2_w=wt(blk.fc2.weight, self.D), fc2_b=f32(blk.fc2.bias), hidden=blk.fc1.out_features))
+        self.ng, self.nb = f32(m.norm.weight), f32(m.norm.bias)
+        self.n_classes = m.head.out_features
+        self.head_w = wt(m.head.weight, self.n_classes)
+        self.head_b = f32(m.head.bias)
+        self._buf = {}
+
+    def _get(self, name, shape, dtype=None, zero=False):
+        torch = _lib.require_gpu()
+        dtype = dtype or torch.bfloat16
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def _gemm(self, src, wgt, dst, rows, k, n_cols, src_ld, dst_ld, bias=None, res=None, flags=0, n_taps=1,
+              tap_src_off=None, rows_per_image=None, dst_rows_per_image=None, dst_row_off=0, batched=None):
+        """rows x k (x n_taps) times wgt^T -> dst.  rows_per_image/dst_rows_per_image/dst_row_off place the output
+        rows of image b at b*dst_rows_per_image + dst_row_off (class-token slot).  batched = dict(n, inner,
+        src=(outer, inner), wgt=(outer, inner), dst=(outer, inner), wgt_row_stride)."""
+        d = _lib.ConvDesc()
+        d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.res = res.data_ptr() if res is not None else None
+        d.mask = None
+        rpi = rows_per_image or rows
+        d.batch, d.grid_h, d.grid_w = rows // rpi, rpi, 1
+        d.src_h, d.src_w, d.src_pix_stride = rpi, 1, src_ld
+        d.k_per_tap, d.n_taps = k, n_taps
+        d.sy, d.sx = 1, 1
+        for i in range(n_taps):
+            d.tap_dy[i], d.tap_dx[i] = 0, 0
+            d.tap_src_off[i] = tap_src_off[i] if tap_src_off else 0
+        d.n_cols = n_cols
+        d.dst_h, d.dst_w = (dst_rows_per_image or rpi), 1
+        d.dst_sy, d.dst_sx, d.dst_oy, d.dst_ox = 1, 1, dst_row_off, 0
+        d.dst_pix_stride = dst_ld
+        d.flags = flags
+        if batched:
+            d.n_batched, d.z_inner = batched['n'], batched['inner']
+            d.src_z_outer, d.src_z_inner = batched['src']
+            d.wgt_z_outer, d.wgt_z_inner = batched['wgt']
+            d.dst_z_outer, d.dst_z_inner = batched['dst']
+            d.wgt_row_stride = batched.get('wgt_row_stride', 0)
+        _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _forward(self, src, src_is_u8, mean, std):
+        torch = _lib.require_gpu()
+        lib, sp = self.lib, _lib.stream_ptr()
+        if src_is_u8:
+            B, Himg, Wimg = src.shape[0], src.shape[1], src.shape[2]
+        else:
+            B, Himg, Wimg = src.shape[0], src.shape[2], src.shape[3]
+        D, H, hd, ps = self.D, self.H, self.hd, self.ps
+        P = (Himg // ps) * (Wimg // ps)
+        T = P + 1
+        assert T == self.tokens, 'image size does not match the position embedding'
+        kk = 3 * ps * ps
+        patches = self._get('patches', (2, B, P, kk))
+        meanf, stdf = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+        _lib.check(lib.rart_vit_patchify(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(patches[0]), _lib.ptr(patches[1]),
+                                         B, Himg, Wimg, ps, meanf, stdf, sp))
+        x = self._get('x', (B, T, D))
+        lo_off = (patches[1].data_ptr() - patches[0].data_ptr()) // 2
+        self._gemm(patches[0], self.pe_w, x, B * P, kk, D, kk, D, bias=self.pe_b, n_taps=2, tap_src_off=[0, lo_off],
+                   rows_per_image=P, dst_rows_per_image=T, dst_row_off=1)
+        _lib.check(lib.rart_vit_add_pos_cls(_lib.ptr(x), _lib.ptr(self.cls_pos0), _lib.ptr(self.pos), B, T, D, sp))
+        rows = B * T
+        ln = self._get('ln', (B, T, D))
+        qkv = self._get('qkv', (B * T + 256, 3 * D), zero=True)      # slack rows: K is read in 128-row tiles in place
+        t_pad = (T + 31) // 32 * 32                                   # 224: K extent of P.V
+        s_ld = (T + 7) // 8 * 8                                       # 200
+        scores = self._get('scores', (B * H, T, s_ld))
+        probs = self._get('probs', (B * H, T, t_pad))
+        vt = self._get('vt', (B * H * hd + 128, t_pad), zero=True)
+        att = self._get('att', (B, T, D))
+        for L in self.layers:
+            _lib.check(lib.rart_layernorm_bf16(_lib.ptr(x), _lib.ptr(L['n1g']), _lib.ptr(L['n1b']), _lib.ptr(ln), rows, D,
+                                               D, D, 1e-6, sp))
+            self._gemm(ln, L['qkv_w'], qkv, rows, D, 3 * D, D, 3 * D, bias=L['qkv_b'])
+            # S[b,h] = Q[b,h] . K[b,h]^T : K rows are read in place from qkv (row stride 3D)
+            self._gemm(qkv, qkv[:, D:], scores, T, hd, s_ld, 3 * D, s_ld, rows_per_image=T,
+                       batched=dict(n=B * H, inner=H, src=(T * 3 * D, hd), wgt=(T * 3 * D, hd), dst=(H * T * s_ld, T * s_ld),
+                                    wgt_row_stride=3 * D))
+            _lib.check(lib.rart_softmax_rows_bf16(_lib.ptr(scores), _lib.ptr(probs), B * H * T, T, s_ld, t_pad,
+                                                  float(hd) ** -0.5, sp))
+            _lib.check(lib.rart_vit_transpose_v(_lib.ptr(qkv), _lib.ptr(vt), B, T, H, hd, 3 * D, 2 * D, t_pad, sp))
+            # O[b, :, h*hd:(h+1)*hd] = P[b,h] . V[b,h]
+            self._gemm(probs, vt, att, T, t_pad, hd, t_pad, D, rows_per_image=T,
+                       batched=dict(n=B * H, inner=H, src=(H * T * t_pad, T * t_pad), wgt=(H * hd * t_pad, hd * t_pad),
+                                    dst=(T * D, hd)))
+            self._gemm(att, L['proj_w'], x, rows, D, D, D, D, bias=L['proj_b'], res=x)
+            _lib.check(lib.rart_layernorm_bf16(_lib.ptr(x), _lib.ptr(L['n2g']), _lib.ptr(L['n2b']), _lib.ptr(ln), rows, D,
+                                               D, D, 1e-6, sp))
+            hid = self._get('hid', (B, T, L['hidden']))
+            self._gemm(ln, L['fc1_w'], hid, rows, D, L['hidden'], D, L['hidden'], bias=L['fc1_b'], flags=F_GELU)
+            self._gemm(hid, L['fc2_w'], x, rows, L['hidden'], D, L['hidden'], D, bias=L['fc2_b'], res=x)
+        cls = self._get('cls', (B, D))
+        _lib.check(lib.rart_layernorm_bf16(_lib.ptr(x), _lib.ptr(self.ng), _lib.ptr(self.nb), _lib.ptr(cls), B, D, T * D, D,
+                                           1e-6, sp))
+        logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
+        self._gemm(cls, self.head_w, logits, B, D, self.n_classes, D, self.n_classes, bias=self.head_b, flags=F_OUT_F32)
+        return logits
+
+    def logits(self, x01, mean, std):
+        return self._forward(x01.detach().float().contiguous(), False, mean, std)
+
+    def logits_from_u8(self, batch_u8, mean, std):
+        return self._forward(batch_u8, True, mean, std)

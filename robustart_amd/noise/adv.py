@@ -22,7 +22,7 @@ from . import rng as _rng
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
-LOSS_CE, LOSS_DLR, LOSS_DLR_TARGETED = 0, 1, 2
+LOSS_CE, LOSS_DLR, LOSS_DLR_TARGETED, LOSS_MARGIN = 0, 1, 2, 3
 
 
 # ---------------------------------------------------------------------------------------
@@ -336,11 +336,78 @@ def apgd_targeted_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, 
     return adv
 
 
+def _square_p_selection(it, p_init, n_queries, rescale):
+    """square.py:192-219."""
+    if rescale:
+        it = int(it / n_queries * 10000)
+    for lo, hi, div in ((10, 50, 2), (50, 200, 4), (200, 500, 8), (500, 1000, 16), (1000, 2000, 32), (2000, 4000, 64),
+                        (4000, 6000, 128), (6000, 8000, 256)):
+        if lo < it <= hi:
+            return p_init / div
+    return p_init / 512 if it > 8000 else p_init
+
+
+def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, rescale=False, seed=None, sample_offset=0,
+                   init_sign=None, draws=None, check_every=50, _prov=None):
+    """SquareAttack.perturb, Linf, loss 'margin', n_restarts 1 (Attacks/autoattack/square.py:221-294,532-600).
+    Forward-only random search: per query one proposal kernel, one model forward, one margin kernel and a
+    masked row select.  The reference gathers the still-unfooled subset each query (a host sync); here the
+    full batch runs with masks and the all-fooled early exit is polled every `check_every` queries.
+    draws[i] = (vh, vw, sign[c]) overrides the counter-based window/sign draws (parity tests)."""
+    import ctypes
+    import math
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    prov = _prov or _Provider(model_fn, normalize_inside=False)
+    x, y = _check_inputs(x, y)
+    adv = x.clone()
+    acc = prov.logits(x).max(1)[1] == y
+    ind = acc.nonzero().flatten()
+    if ind.numel() == 0:
+        return adv
+    x0, yy = x[ind].contiguous(), y[ind].contiguous()
+    B, C, H, W = x0.shape
+    sd = _seed(seed)
+    x_best = torch.empty_like(x0)
+    sg0 = init_sign.contiguous() if init_sign is not None else None
+    _lib.check(lib.rart_square_init_linf(_lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), sd, sample_offset,
+                                         _lib.ptr(sg0), _lib.stream_ptr()))
+    margin_min, _, _ = logit_loss(prov.logits(x_best), yy, LOSS_MARGIN, want_grad=False)
+    loss_min = margin_min.clone()
+    x_new = torch.empty_like(x0)
+    n_features = C * H * W
+    for it in range(int(n_queries)):
+        if it % check_every == 0 and not bool((margin_min > 0).any()):      # square.py:293-294
+            break
+        p = _square_p_selection(it, p_init, n_queries, rescale)
+        s = max(int(round(math.sqrt(p * n_features / C))), 1)
+        if draws is not None:
+            vh, vw, sg = draws[it]
+            sg = [float(v) for v in sg]
+        else:
+            vh = int(_rng.host_uniform(sd, it, 9, 0) * (H - s))
+            vw = int(_rng.host_uniform(sd, it, 9, 1) * (W - s))
+            sg = [1.0 if _rng.host_uniform(sd, it, 9, 2 + c) >= 0.5 else -1.0 for c in range(C)]
+        sgc = (ctypes.c_float * C)(*sg)
+        _lib.check(lib.rart_square_propose_linf(_lib.ptr(x_new), _lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps),
+                                                int(vh), int(vw), s, sgc, _lib.stream_ptr()))
+        margin, _, _ = logit_loss(prov.logits(x_new), yy, LOSS_MARGIN, want_grad=False)
+        todo = margin_min > 0
+        improved = (margin < loss_min) & todo
+        loss_min = torch.where(improved, margin, loss_min)
+        accept = (improved | (margin <= 0)) & todo
+        margin_min = torch.where(accept, margin, margin_min)
+        select_rows_(x_best, x_new, accept)
+    fooled = (prov.logits(x_best).max(1)[1] != yy).nonzero().flatten()
+    adv[ind[fooled]] = x_best[fooled]
+    return adv
+
+
 def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None):
     """attack.py:35-38 -> AutoAttack(model, norm, eps, version).run_standard_evaluation(x, y, bs=len(x))
     (autoattack.py:90-211).  `model` takes normalised input (NormalizeModel, autoattack.py:12-23).
-    standard = [apgd-ce, apgd-t, fab-t, square]; apgd-ce and apgd-t run here, fab-t and square are the
-    SURVEY.md 8f rank-2 "next" row and are reported as skipped (the result is then an upper bound
+    standard = [apgd-ce, apgd-t, fab-t, square]; apgd-ce, apgd-t and square run here, fab-t is the
+    SURVEY.md 8f rank-2 "next" row and is reported as skipped (the result is then an upper bound
     on robust accuracy, never silently presented as the full ensemble)."""
     torch = _lib.require_gpu()
     assert norm in ['Linf', 'L2', 'L1']
@@ -357,7 +424,7 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
     if version == 'rand':
         raise NotImplementedError("AutoAttack version 'rand' (EOT over 20 forward passes) is not implemented")
     n_restarts = 5 if version == 'plus' else 1
-    skipped = [a for a in plan if a in ('fab', 'fab-t', 'square')]
+    skipped = [a for a in plan if a in ('fab', 'fab-t')]
     if skipped:
         warnings.warn('autoattack_linf: %s not implemented on this build yet -- running %s only; robust accuracy '
                       'is an upper bound of the full ensemble' % (skipped, [a for a in plan if a not in skipped]),
@@ -381,6 +448,10 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
                                         _prov=prov)
             elif attack == 'apgd-t':
                 adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, 100, 9, base_seed + 1000 * ai, 0, _prov=prov)
+            elif attack == 'square':
+                if norm != 'Linf':
+                    raise NotImplementedError('Square L2 (square.py:296-530) is not implemented')
+                adv_curr = square_perturb(None, x, y, eps, 5000, 0.8, False, base_seed + 1000 * ai, 0, _prov=prov)
             else:
                 raise ValueError('Attack not supported')
             false_batch = ~y.eq(prov.logits(adv_curr).max(1)[1])                 # :179-184

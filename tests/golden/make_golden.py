@@ -25,6 +25,7 @@ from PIL import Image  # noqa: E402
 from RobustART.noise.utils.imagenet_c import corrupt as ref_corrupt  # noqa: E402
 from RobustART.noise.utils.adv.Attacks.autoattack.autopgd_base import APGDAttack, APGDAttack_targeted  # noqa: E402
 from RobustART.noise.utils.adv.Attacks.imfgsm_attack import _mim_whitebox  # noqa: E402
+from RobustART.noise.utils.adv.Attacks.autoattack.square import SquareAttack  # noqa: E402
 
 from _inputs import RUNNABLE, make_image, case_seed  # noqa: E402
 from _tinynet import make_tinynet, make_batch  # noqa: E402
@@ -91,6 +92,9 @@ def gen_attacks():
     adv = _mim_whitebox(net, x.clone(), y.clone(), epsilon=8 / 255, num_steps=5, step_size=0.002,
                         decay_factor=1.0)
     out['mim/adv'] = adv.detach().numpy()
+    sq = SquareAttack(model_fn, p_init=.8, n_queries=40, eps=8 / 255, norm='Linf', n_restarts=1, seed=0,
+                      resc_schedule=False, device='cpu')
+    out['square/Linf/adv'] = sq.perturb(x.clone(), y.clone()).detach().numpy()
     np.savez_compressed(os.path.join(HERE, 'attacks_ref.npz'), **out)
     print('attacks_ref.npz', len(out), 'entries')
 

@@ -96,7 +96,7 @@ def test_select_rows_and_logit_losses():
         y[:4] = z[:4].argmax(1)                     # mix of correct / incorrect rows
         yt = (y + 1 + torch.randint(0, C - 1, (16,), generator=torch.Generator().manual_seed(2))) % C
         for kind, fn in ((0, lambda: A.ce_indiv(z, y)), (1, lambda: A.dlr_loss(z, y)),
-                         (2, lambda: A.dlr_loss_targeted(z, y, yt))):
+                         (2, lambda: A.dlr_loss_targeted(z, y, yt)), (3, lambda: A.margin_loss(z, y))):
             li = fn()
             gw, = torch.autograd.grad(li.sum() * 0.5, z)
             loss, dl, pred = adv.logit_loss(z.detach().cuda(), y.cuda(), kind, yt.cuda(), 0.5)
@@ -149,6 +149,35 @@ def test_full_attacks_match_oracle_and_reference_goldens():
             t = 2 * torch.rand(x.shape) - 1 if norm == 'Linf' else torch.randn(x.shape)
             got = adv.apgd_perturb(f_gpu, x.cuda(), y.cuda(), norm, e, 10, loss, 1, init_ts=[t.cuda().contiguous()])
             torch.testing.assert_close(got.cpu(), torch.from_numpy(g[f'apgd/{norm}/{loss}/adv']), **tol)
+
+
+def test_square_attack_matches_reference_golden():
+    """Square (Linf): HIP proposal / margin / select kernels, injected window + sign draws replaying the
+    reference's torch stream -> the reference's own output (golden) within fp32 noise."""
+    from robustart_amd.noise import adv
+    g, net = _gold_model()
+    netc = make_tinynet({k[4:]: g[k] for k in g.files if k.startswith('net/')}).cuda()
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    mean = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()
+    std = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1).cuda()
+    f_gpu = lambda z: netc((z - mean) / std)  # noqa: E731
+    torch.random.manual_seed(0)
+    c, h, w = 3, 32, 32
+    init = torch.sign(2 * torch.rand([4, c, 1, w]) - 1)
+    draws = []
+    for i in range(40):
+        p = A.square_p_selection(i, 0.8, 40, False)
+        s = max(int(round((p * h * w) ** 0.5)), 1)
+        vh = int((0 + (h - s) * torch.rand([1])).long())
+        vw = int((0 + (w - s) * torch.rand([1])).long())
+        draws.append((vh, vw, torch.sign(2 * torch.rand([c, 1, 1]) - 1).view(c)))
+    got = adv.square_perturb(f_gpu, x.cuda(), y.cuda(), 8 / 255, 40, 0.8, False, init_sign=init.view(4, c, w).cuda(),
+                             draws=draws, check_every=1)
+    torch.testing.assert_close(got.cpu(), torch.from_numpy(g['square/Linf/adv']), atol=2e-6, rtol=0)
+    # native draws: stays in the eps-ball / box, deterministic
+    a = adv.square_perturb(f_gpu, x.cuda(), y.cuda(), 8 / 255, 30, 0.8, False, seed=4)
+    b = adv.square_perturb(f_gpu, x.cuda(), y.cuda(), 8 / 255, 30, 0.8, False, seed=4)
+    assert torch.equal(a, b) and (a - x.cuda()).abs().max() <= 8 / 255 + 1e-6 and a.min() >= 0 and a.max() <= 1
 
 
 def test_native_pgd_linf_invariants_at_imagenet_size():

@@ -128,6 +128,24 @@ def _apgdt_with_stream(model_fn, x, y, eps, n_iter, n_target):
     return adv
 
 
+def test_square_matches_reference(gold_a):
+    net, model_fn = _model(gold_a)
+    x, y = torch.from_numpy(gold_a['x']), torch.from_numpy(gold_a['y'])
+    torch.random.manual_seed(0)
+    c, h, w = 3, 32, 32
+
+    class Draws:          # replays random_int x2 + random_choice([c,1,1]) per query, in the reference's order
+        def __getitem__(self, i):
+            p = A.square_p_selection(i, 0.8, 40, False)
+            s = max(int(round((p * h * w) ** 0.5)), 1)
+            vh = int((0 + (h - s) * torch.rand([1])).long())
+            vw = int((0 + (w - s) * torch.rand([1])).long())
+            return vh, vw, torch.sign(2 * torch.rand([c, 1, 1]) - 1).view(c)
+    adv = A.square_linf_perturb(model_fn, x, y, 8 / 255, 40, 0.8, False,
+                                lambda n: torch.sign(2 * torch.rand([n, c, 1, w]) - 1), Draws())
+    np.testing.assert_array_equal(adv.numpy(), gold_a['square/Linf/adv'])
+
+
 def test_mim_matches_reference(gold_a):
     net, _ = _model(gold_a)
     x, y = torch.from_numpy(gold_a['x']), torch.from_numpy(gold_a['y'])
