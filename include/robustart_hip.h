@@ -227,6 +227,9 @@ typedef struct rart_conv_desc {
 } rart_conv_desc;
 
 int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
+/* Tuning knob: problems with n_taps*k_per_tap >= k (and k_per_tap % 64 == 0) use the 128x{128,64}x64 pipeline
+ * (default 256); others the x32 pipeline with loads two K steps ahead. */
+int rart_igemm_set_bk64_min_k(long long k);
 
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
  * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:
@@ -263,6 +266,10 @@ int rart_layernorm_bf16(const void* x, const float* gamma, const float* beta, vo
 /* probs[r][0..n_valid) = softmax(scale * scores[r][0..n_valid)), zeros up to ld_out (the K padding of P.V). */
 int rart_softmax_rows_bf16(const void* scores, void* probs, int64_t rows, int n_valid, int ld_in, int ld_out,
                            float scale, rart_stream_t stream);
+/* Fused multi-head attention on the fused qkv activation [n][tokens][3*heads*head_dim] (q | k | v, heads contiguous,
+ * timm layout): out[n][tokens][heads*head_dim] = softmax(q k^T / sqrt(head_dim)) v, bf16 in/out, fp32 statistics.
+ * head_dim == 64, tokens <= 224.  (timm Attention.forward; model `vit_base`.) */
+int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads, int head_dim, rart_stream_t stream);
 /* vt[n][heads][head_dim][t_pad] <- V slice of the fused qkv activation [n][tokens][qkv_ld] (zero padded). */
 int rart_vit_transpose_v(const void* qkv, void* vt, int n, int tokens, int heads, int head_dim, int qkv_ld, int v_off,
                          int t_pad, rart_stream_t stream);

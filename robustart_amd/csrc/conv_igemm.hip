@@ -47,7 +47,7 @@ struct RartConvDescDev {
 };
 
 namespace {
-constexpr int BM = 128, BK = 32, LDK = BK + 8;  // LDS row = 40 bf16 = 80 B
+constexpr int BM = 128;
 constexpr int kThreads = 256;
 enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4 };
 
@@ -58,8 +58,12 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
-template <int BN>
-__global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvDescDev d) {
+// BK = 32: two register sets, loads two K steps ahead (memory-latency-bound 1x1 layers, 3 blocks/CU).
+// BK = 64: one register set, loads one (twice as long) K step ahead, half the barriers per FLOP
+//          (compute-bound 3x3 layers and transformer GEMMs; 73 KB of LDS -> 2 blocks/CU).
+template <int BN, int BK>
+__global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(const RartConvDescDev d) {
+  constexpr int LDK = BK + 8;  // LDS row: 80 B (BK 32) / 144 B (BK 64): ds_read_b128 fragment reads are conflict free
   // batched problems: block-uniform base shifts, kept in scalars (copying the descriptor would move its tap
   // tables from the kernarg segment into scratch)
   const uint16_t* p_src = d.src;
@@ -141,11 +145,36 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
   const int KT = K / BK;
   const int tiles_per_tap = d.k_per_tap / BK;
 
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+#define RART_COMPUTE(BUF)                                                                                       \
+  {                                                                                                             \
+    const uint16_t* A = sA + (BUF)*BM * LDK + (wm * 64 + frag_row) * LDK + frag_k;                              \
+    const uint16_t* B = sB + (BUF)*BN * LDK + (wn * WN + frag_row) * LDK + frag_k;                              \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                    \
+      bf16x8 af[2], bfr[TN];                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * LDK + ks * 16); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * LDK + ks * 16); \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);               \
+    }                                                                                                           \
+  }
+
+  if constexpr (BK == 32) {
   // Two register sets: global loads run TWO K steps ahead of the MFMAs (the K step of a 1x1 layer is far
   // shorter than an HBM round trip, so one step of cover leaves the kernel latency-bound at 3 blocks/CU).
   // Written as macros over named register arrays so every index is static (no scratch).
   uint4 ra0_0, ra0_1, ra1_0, ra1_1, rb0_0, rb0_1, rb1_0, rb1_1;   // set{0,1} x chunk{0,1}; explicit scalars
   rb0_1 = rb1_1 = make_uint4(0, 0, 0, 0);
+  ra1_0 = ra1_1 = rb1_0 = make_uint4(0, 0, 0, 0);
 #define RART_LOAD_A(I, DST)                                                                                     \
   {                                                                                                             \
     const int iy = a_by[I] + dy, ix = a_bx[I] + dx;                                                             \
@@ -181,30 +210,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
       *reinterpret_cast<uint4*>(sB + (((BUF)*BN + (tid >> 2) + 64) * LDK + chunk * 8)) = rb##SET##_1;           \
   }
 
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
-#define RART_COMPUTE(BUF)                                                                                       \
-  {                                                                                                             \
-    const uint16_t* A = sA + (BUF)*BM * LDK + (wm * 64 + frag_row) * LDK + frag_k;                              \
-    const uint16_t* B = sB + (BUF)*BN * LDK + (wn * WN + frag_row) * LDK + frag_k;                              \
-    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                    \
-      bf16x8 af[2], bfr[TN];                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * LDK + ks * 16); \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * LDK + ks * 16); \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);               \
-    }                                                                                                           \
-  }
-
-  ra1_0 = ra1_1 = rb1_0 = make_uint4(0, 0, 0, 0);
   RART_LOAD_TILE(0, 0);
   if (KT > 1) RART_LOAD_TILE(1, 1);
   RART_STORE_TILE(0, 0);
@@ -222,6 +227,77 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
       if (kt + 2 < KT) RART_STORE_TILE(0, 0);
       __syncthreads();
     }
+  }
+
+  } else {
+    // ---- BK = 64 pipeline: 8 chunks per row, 32 rows per pass ----
+    constexpr int NA = BM / 32, NB = BN / 32;
+    const int chunk8 = tid & 7, prow = tid >> 3;
+    int b_by[NA], b_bx[NA], b_img[NA];
+    bool b_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const long long m = m0 + prow + 32 * i;
+      b_ok[i] = m < M;
+      const long long mm = b_ok[i] ? m : 0;
+      const int ox = (int)(mm % d.grid_w);
+      const long long t = mm / d.grid_w;
+      const int oy = (int)(t % d.grid_h);
+      const int n = (int)(t / d.grid_h);
+      b_by[i] = oy * d.sy;
+      b_bx[i] = ox * d.sx;
+      b_img[i] = n * d.src_h * d.src_w;
+    }
+    uint4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;   // explicit scalars: uint4 arrays of 4 end up in scratch here
+    qb2 = qb3 = make_uint4(0, 0, 0, 0);
+#define RART_LD64_A(I, DST)                                                                                     \
+  {                                                                                                             \
+    const int iy = b_by[I] + dy, ix = b_bx[I] + dx;                                                             \
+    const bool ok = b_ok[I] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w;            \
+    const uint32_t eoff = (uint32_t)((b_img[I] + iy * d.src_w + ix) * d.src_pix_stride + kc);                   \
+    uint4 v = make_uint4(0, 0, 0, 0);                                                                           \
+    if (ok) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase) + (size_t)(eoff * 2u));    \
+    DST = v;                                                                                                    \
+  }
+#define RART_LD64_B(I, DST)                                                                                     \
+  {                                                                                                             \
+    const uint32_t woff = (uint32_t)((n0 + prow + 32 * (I)) * WRS + kt_ * BK + chunk8 * 8);                     \
+    DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_wgt) + (size_t)(woff * 2u));         \
+  }
+#define RART_LOAD64(KT_)                                                                                        \
+  {                                                                                                             \
+    const int kt_ = (KT_);                                                                                      \
+    const int tap = kt_ / tiles_per_tap;                                                                        \
+    const int kc = (kt_ - tap * tiles_per_tap) * BK + chunk8 * 8;                                               \
+    const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];                                                           \
+    const uint16_t* sbase = p_src + d.tap_src_off[tap];                                                         \
+    RART_LD64_A(0, qa0) RART_LD64_A(1, qa1) RART_LD64_A(2, qa2) RART_LD64_A(3, qa3)                             \
+    RART_LD64_B(0, qb0) RART_LD64_B(1, qb1)                                                                     \
+    if constexpr (NB > 2) { RART_LD64_B(2, qb2) RART_LD64_B(3, qb3) }                                           \
+  }
+#define RART_ST64(PTR, ROWS, I, SRC) *reinterpret_cast<uint4*>(PTR + (((BUF_)*ROWS + prow + 32 * (I)) * LDK + chunk8 * 8)) = SRC;
+#define RART_STORE64(BUF)                                                                                       \
+  {                                                                                                             \
+    const int BUF_ = (BUF);                                                                                     \
+    RART_ST64(sA, BM, 0, qa0) RART_ST64(sA, BM, 1, qa1) RART_ST64(sA, BM, 2, qa2) RART_ST64(sA, BM, 3, qa3)     \
+    RART_ST64(sB, BN, 0, qb0) RART_ST64(sB, BN, 1, qb1)                                                         \
+    if constexpr (NB > 2) { RART_ST64(sB, BN, 2, qb2) RART_ST64(sB, BN, 3, qb3) }                               \
+  }
+    RART_LOAD64(0);
+    RART_STORE64(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < KT) RART_LOAD64(kt + 1);
+      RART_COMPUTE(buf);
+      if (kt + 1 < KT) RART_STORE64(buf ^ 1);
+      __syncthreads();
+    }
+#undef RART_LOAD64
+#undef RART_STORE64
+#undef RART_LD64_A
+#undef RART_LD64_B
+#undef RART_ST64
   }
 #undef RART_LOAD_TILE
 #undef RART_LOAD_A
@@ -320,6 +396,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_conv_igemm_bf16(const RartConvD
 }
 }  // namespace
 
+// tuning knob (tests / profiling): smallest K that takes the BK = 64 pipeline; a huge value disables it
+static long long g_bk64_min_k = 256;
+extern "C" int rart_igemm_set_bk64_min_k(long long k) {
+  g_bk64_min_k = k;
+  return RART_OK;
+}
+
 extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t stream) {
   RART_CHECK_ARG(h != nullptr, "rart_conv_igemm_bf16: null descriptor");
   RART_CHECK_ARG(h->src && h->wgt && h->dst, "rart_conv_igemm_bf16: null tensor pointer");
@@ -359,10 +442,15 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   const int m_tiles8 = (m_tiles + 7) / 8 * 8;  // the XCD remap enumerates row tiles in groups of 8
   const long long blocks = (long long)m_tiles8 * n_tiles;
   RART_CHECK_ARG(blocks < (1ll << 31), "rart_conv_igemm_bf16: grid too large");
-  if (wide)
-    hipLaunchKernelGGL(k_conv_igemm_bf16<128>, dim3((uint32_t)blocks, nz), dim3(kThreads), 0, (hipStream_t)stream, d);
-  else
-    hipLaunchKernelGGL(k_conv_igemm_bf16<64>, dim3((uint32_t)blocks, nz), dim3(kThreads), 0, (hipStream_t)stream, d);
+  // K-deep problems take the BK = 64 pipeline (half the barriers per FLOP); shallow ones (K <= 128: the
+  // memory-latency-bound 1x1 layers with 2-4 K steps) keep BK = 32 with loads two steps ahead
+  const bool deep = (d.k_per_tap % 64 == 0) && ((long long)d.k_per_tap * d.n_taps >= g_bk64_min_k);
+  const dim3 grid((uint32_t)blocks, nz);
+  hipStream_t st = (hipStream_t)stream;
+  if (wide && deep) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 64>), grid, dim3(kThreads), 0, st, d);
+  else if (wide) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 32>), grid, dim3(kThreads), 0, st, d);
+  else if (deep) hipLaunchKernelGGL((k_conv_igemm_bf16<64, 64>), grid, dim3(kThreads), 0, st, d);
+  else hipLaunchKernelGGL((k_conv_igemm_bf16<64, 32>), grid, dim3(kThreads), 0, st, d);
   RART_CHECK_LAUNCH("rart_conv_igemm_bf16");
   return RART_OK;
 }

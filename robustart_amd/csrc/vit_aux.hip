@@ -102,6 +102,121 @@ __global__ __launch_bounds__(kBlock) void k_transpose_v(const uint16_t* __restri
   }
 }
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
+
+// ---- fused multi-head attention (head_dim 64, tokens <= NKT*32), one workgroup per (image, head) -------------
+// S^T = K . Q^T on v_mfma_f32_32x32x16_bf16: in the accumulator layout lane (l & 31) is the QUERY and the 16
+// registers x 2 lane halves are its keys, so the soft-max statistics of a query live in one lane pair
+// (one shuffle with lane ^ 32) and the whole row block stays in registers (NKT*16 fp32 per lane; no online
+// rescaling).  The normalised probabilities are packed to bf16 and fed straight back as the A operand of
+// O = P . V: the MFMA's k index is only a summation label, so instead of re-laying P through LDS the V operand
+// is read from LDS (stored transposed) in the key order the accumulator registers already have.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int ATT_HD = 64, ATT_LDK = ATT_HD + 8;
+
+template <int NKT>
+__global__ __launch_bounds__(kBlock, 1) void k_vit_attention(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ att,
+                                                             int T, int H, int ld, int D, float scale_log2e) {
+  constexpr int TP = NKT * 32, LDV = TP + 4;     // 228-element rows: conflict-free 8-byte reads across 32 lanes
+  __shared__ __attribute__((aligned(16))) uint16_t sK[TP * ATT_LDK];
+  __shared__ __attribute__((aligned(16))) uint16_t sVt[ATT_HD * LDV];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+  const uint16_t* base = qkv + (size_t)b * T * ld + h * ATT_HD;
+  for (int i = tid; i < TP * 8; i += kBlock) {
+    const int t = i >> 3, c = i & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (t < T) {
+      kv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + c * 8);
+      vv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + 2 * D + c * 8);
+    }
+    *reinterpret_cast<uint4*>(sK + t * ATT_LDK + c * 8) = kv;
+    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sVt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(w[j] & 0xFFFF);
+      sVt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(w[j] >> 16);
+    }
+  }
+  __syncthreads();
+  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
+    const int q = qt * 32 + l31;
+    bf16x8 bq[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < T) v = *reinterpret_cast<const uint4*>(base + (size_t)q * ld + kb * 16 + hh * 8);
+      bq[kb] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + (kt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kb], sacc[kt], 0, 0, 0);
+      }
+    }
+    // sacc[kt][r] = q . k for key kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float v = key < T ? sacc[kt][r] * scale_log2e : -INFINITY;
+        sacc[kt][r] = v;
+        m = fmaxf(m, v);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - m);
+        sacc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    f32x16 o[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        uint32_t pw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pw[j] = (uint32_t)f2bf(sacc[kt][8 * kb2 + 2 * j] * inv) | ((uint32_t)f2bf(sacc[kt][8 * kb2 + 2 * j + 1] * inv) << 16);
+        uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+        const bf16x8 pa = *reinterpret_cast<bf16x8*>(&pv);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const uint16_t* vr = sVt + (nt * 32 + l31) * LDV + kt * 32 + 16 * kb2 + 4 * hh;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 8);
+          uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, *reinterpret_cast<bf16x8*>(&bv), o[nt], 0, 0, 0);
+        }
+      }
+    // o[nt][r] = O[query qt*32 + (r&3) + 8*(r>>2) + 4*hh][d = nt*32 + l31]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (qq < T) {
+        uint16_t* orow = att + ((size_t)b * T + qq) * D + h * ATT_HD;
+        orow[l31] = f2bf(o[0][r]);
+        orow[32 + l31] = f2bf(o[1][r]);
+      }
+    }
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -152,6 +267,18 @@ int rart_softmax_rows_bf16(const void* scores, void* probs, int64_t rows, int n_
                      (hipStream_t)stream, (const uint16_t*)scores, (uint16_t*)probs, (long long)rows, n_valid, ld_in,
                      ld_out, scale);
   RART_CHECK_LAUNCH("rart_softmax_rows_bf16");
+  return RART_OK;
+}
+
+int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads, int head_dim, rart_stream_t stream) {
+  RART_CHECK_ARG(qkv && out && n > 0 && tokens > 0 && heads > 0, "rart_vit_attention: bad arguments");
+  RART_CHECK_ARG(head_dim == 64, "rart_vit_attention: head_dim must be 64 (ViT-B/16)");
+  RART_CHECK_ARG(tokens <= 224, "rart_vit_attention: at most 224 tokens (197 for 224x224 / patch 16)");
+  const int D = heads * head_dim;
+  const float scale_log2e = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(k_vit_attention<7>, dim3((uint32_t)(n * heads)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint16_t*)qkv, (uint16_t*)out, tokens, heads, 3 * D, D, scale_log2e);
+  RART_CHECK_LAUNCH("rart_vit_attention");
   return RART_OK;
 }
 

@@ -307,6 +307,19 @@ class ResNet50Engine:
         return logits, loss, grad, pred
 
 
+def make_engine(torch_model, device='cuda'):
+    """HIP engine for a model from robustart_amd.model.get_model: ResNet-50 (forward + backward-to-input) or
+    ViT-B/16 (forward only: attacks on it fall back to torch autograd in robustart_amd.noise.adv)."""
+    from .resnet_torch import ResNet
+    from .vit_torch import VisionTransformer
+    if isinstance(torch_model, ResNet):
+        return ResNet50Engine(torch_model, device)
+    if isinstance(torch_model, VisionTransformer):
+        from .vit_engine import ViTEngine
+        return ViTEngine(torch_model, device)
+    raise NotImplementedError('no HIP engine for %s (ResNet-50 / ViT-B/16 only)' % type(torch_model).__name__)
+
+
 class EngineModel:
     """Callable wrapper that carries a ResNet50Engine through the reference's `model` / `f_model` keys.
 
@@ -317,7 +330,7 @@ class EngineModel:
 
     def __init__(self, torch_model, takes_normalized, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
                  engine=None, device='cuda'):
-        self.rart_engine = engine or ResNet50Engine(torch_model, device)
+        self.rart_engine = engine or make_engine(torch_model, device)
         self.takes_normalized = takes_normalized
         self.rart_mean_std = (tuple(mean), tuple(std))
 

@@ -56,6 +56,7 @@ class ViTEngine:
         self.head_w = wt(m.head.weight, self.n_classes)
         self.head_b = f32(m.head.bias)
         self._buf = {}
+        self.fused_attention = True
 
     def _get(self, name, shape, dtype=None, zero=False):
         torch = _lib.require_gpu()
@@ -131,17 +132,10 @@ class ViTEngine:
             _lib.check(lib.rart_layernorm_bf16(_lib.ptr(x), _lib.ptr(L['n1g']), _lib.ptr(L['n1b']), _lib.ptr(ln), rows, D,
                                                D, D, 1e-6, sp))
             self._gemm(ln, L['qkv_w'], qkv, rows, D, 3 * D, D, 3 * D, bias=L['qkv_b'])
-            # S[b,h] = Q[b,h] . K[b,h]^T : K rows are read in place from qkv (row stride 3D)
-            self._gemm(qkv, qkv[:, D:], scores, T, hd, s_ld, 3 * D, s_ld, rows_per_image=T,
-                       batched=dict(n=B * H, inner=H, src=(T * 3 * D, hd), wgt=(T * 3 * D, hd), dst=(H * T * s_ld, T * s_ld),
-                                    wgt_row_stride=3 * D))
-            _lib.check(lib.rart_softmax_rows_bf16(_lib.ptr(scores), _lib.ptr(probs), B * H * T, T, s_ld, t_pad,
-                                                  float(hd) ** -0.5, sp))
-            _lib.check(lib.rart_vit_transpose_v(_lib.ptr(qkv), _lib.ptr(vt), B, T, H, hd, 3 * D, 2 * D, t_pad, sp))
-            # O[b, :, h*hd:(h+1)*hd] = P[b,h] . V[b,h]
-            self._gemm(probs, vt, att, T, t_pad, hd, t_pad, D, rows_per_image=T,
-                       batched=dict(n=B * H, inner=H, src=(H * T * t_pad, T * t_pad), wgt=(H * hd * t_pad, hd * t_pad),
-                                    dst=(T * D, hd)))
+            if self.fused_attention:
+                _lib.check(lib.rart_vit_attention(_lib.ptr(qkv), _lib.ptr(att), B, T, H, hd, sp))
+            else:
+                self._attention_unfused(qkv, scores, probs, vt, att, B, T, s_ld, t_pad)
             self._gemm(att, L['proj_w'], x, rows, D, D, D, D, bias=L['proj_b'], res=x)
             _lib.check(lib.rart_layernorm_bf16(_lib.ptr(x), _lib.ptr(L['n2g']), _lib.ptr(L['n2b']), _lib.ptr(ln), rows, D,
                                                D, D, 1e-6, sp))
@@ -154,6 +148,21 @@ class ViTEngine:
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
         self._gemm(cls, self.head_w, logits, B, D, self.n_classes, D, self.n_classes, bias=self.head_b, flags=F_OUT_F32)
         return logits
+
+    def _attention_unfused(self, qkv, scores, probs, vt, att, B, T, s_ld, t_pad):
+        """Reference decomposition (batched igemm Q.K^T -> soft-max rows -> V transpose -> batched igemm P.V); kept to
+        cross-check the fused kernel and to exercise the batched-GEMM path of rart_conv_igemm_bf16."""
+        lib, sp = self.lib, _lib.stream_ptr()
+        D, H, hd = self.D, self.H, self.hd
+        self._gemm(qkv, qkv[:, D:], scores, T, hd, s_ld, 3 * D, s_ld, rows_per_image=T,
+                   batched=dict(n=B * H, inner=H, src=(T * 3 * D, hd), wgt=(T * 3 * D, hd), dst=(H * T * s_ld, T * s_ld),
+                                wgt_row_stride=3 * D))
+        _lib.check(lib.rart_softmax_rows_bf16(_lib.ptr(scores), _lib.ptr(probs), B * H * T, T, s_ld, t_pad,
+                                              float(hd) ** -0.5, sp))
+        _lib.check(lib.rart_vit_transpose_v(_lib.ptr(qkv), _lib.ptr(vt), B, T, H, hd, 3 * D, 2 * D, t_pad, sp))
+        self._gemm(probs, vt, att, T, t_pad, hd, t_pad, D, rows_per_image=T,
+                   batched=dict(n=B * H, inner=H, src=(H * T * t_pad, T * t_pad), wgt=(H * hd * t_pad, hd * t_pad),
+                                dst=(T * D, hd)))
 
     def logits(self, x01, mean, std):
         return self._forward(x01.detach().float().contiguous(), False, mean, std)

@@ -61,3 +61,29 @@ def test_vit_forward_logits(setup, B):
     a = eng.logits_from_u8(u8, MEAN, STD)
     b = eng.logits(u8.permute(0, 3, 1, 2).float() / 255, MEAN, STD)
     torch.testing.assert_close(a, b, atol=0.02 * scale, rtol=0)
+
+
+def test_fused_attention_matches_torch_and_unfused_path(setup):
+    """rart_vit_attention vs torch softmax attention on the same bf16 qkv, and vs the batched-igemm decomposition."""
+    from robustart_amd import _lib
+    m, eng = setup
+    lib = _lib.load()
+    B, T, H, hd = 3, 197, 12, 64
+    D = H * hd
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * T + 256, 3 * D, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    qkv[B * T:] = 0
+    out = torch.empty(B, T, D, dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.rart_vit_attention(_lib.ptr(qkv), _lib.ptr(out), B, T, H, hd, _lib.stream_ptr()))
+    q3 = qkv[:B * T].float().view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q3[0] @ q3[1].transpose(-2, -1) * hd ** -0.5, -1) @ q3[2]).transpose(1, 2).reshape(B, T, D)
+    err = (out.float() - ref).abs().max().item()
+    print('fused attention max err %.4g (ref scale %.3f)' % (err, ref.abs().max().item()))
+    assert err < 0.02 * ref.abs().max().item() + 2e-2
+    s_ld, t_pad = 200, 224
+    scores = torch.empty(B * H, T, s_ld, dtype=torch.bfloat16, device='cuda')
+    probs = torch.empty(B * H, T, t_pad, dtype=torch.bfloat16, device='cuda')
+    vt = torch.zeros(B * H * hd + 128, t_pad, dtype=torch.bfloat16, device='cuda')
+    out2 = torch.empty_like(out)
+    eng._attention_unfused(qkv, scores, probs, vt, out2, B, T, s_ld, t_pad)
+    assert (out2.float() - ref).abs().max().item() < 0.03 * ref.abs().max().item() + 2e-2
