@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='images in the bounded CPU baseline sample')
+    ap.add_argument('--workload', choices=['headline', 'vit_inc'], default='headline',
+                    help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 3: ViT-B/16 evaluated "
+                         "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost skipped: no textures)")
     ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
                     help="'hip' = hand-written engine (product); 'scaffold' = PyTorch-ROCm/MIOpen, for comparison only")
     return ap.parse_args()
@@ -202,6 +205,58 @@ def cpu_baseline(sample, model_fp32):
     return 6 * sample / dt, dt
 
 
+def run_vit_inc(args, device, rank, world, dist):
+    """BASELINE config 3 (secondary mode, not the headline line): per step, one resident batch of 256 uint8 images is
+    corrupted by each of the 15 benchmark corruptions at 5 severities (frost needs textures the reference does not
+    ship -> 14 x 5 = 70 corrupted batches) and each is evaluated by ViT-B/16 on the HIP engine."""
+    from robustart_amd.model import get_model
+    from robustart_amd.model.vit_engine import ViTEngine
+    from robustart_amd.noise import imagenet_c as C, adv
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(device)
+    labels = torch.randint(0, 1000, (B,), generator=g).to(device)
+    torch.manual_seed(0)
+    eng = ViTEngine(get_model({'type': 'vit_base'}).eval(), device)
+    scratch = torch.empty_like(images)
+    ids = [i for i in range(15) if C.CORRUPTION_NAMES[i] != 'frost']
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def step(k):
+        tot = 0
+        for cid in ids:
+            for sev in range(1, 6):
+                C.corrupt_batch_(images, cid, sev, seed=0, sample_offset=k * 1_000_003 + rank * B, out=scratch)
+                logits = eng.logits_from_u8(scratch, mean, std)
+                _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
+                tot = tot + (pred.long() == labels).sum()
+        return tot
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_img = len(ids) * 5 * B * world
+    if rank == 0:
+        print(json.dumps({'metric': 'corrupted images/sec/node (ViT-B/16, ImageNet-C 14 corruptions x 5 severities, on-GPU noise)',
+                          'value': n_img * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                          'config': {'workload': 'BASELINE config 3 (secondary): 70 corrupted batches of 256 per step -> ViT-B/16 eval',
+                                     'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -216,6 +271,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)       # "nccl" == RCCL on ROCm
+    if args.workload == 'vit_inc':
+        run_vit_inc(args, device, rank, world, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     B = args.batch
     images, labels, model = build_workload(B, device, rank)
     import copy

@@ -228,7 +228,7 @@ typedef struct rart_conv_desc {
 
 int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
 /* Tuning knob: problems with n_taps*k_per_tap >= k (and k_per_tap % 64 == 0) use the 128x{128,64}x64 pipeline
- * (default 256); others the x32 pipeline with loads two K steps ahead. */
+ * (default 1024); others the x32 pipeline with loads two K steps ahead. */
 int rart_igemm_set_bk64_min_k(long long k);
 
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
