@@ -168,6 +168,22 @@ int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int 
 int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0, int batch, int c, int h, int w,
                              float eps, int vh, int vw, int s, const float* sign_host, rart_stream_t stream);
 
+/* FAB, Linf (Attacks/autoattack/fab_projections.py:7-59, fab_base.py:168-245).
+ * rart_fab_project_linf: per row r, the box-constrained Linf projection step d of points[r] onto {x: w[r].x = b[r]};
+ *   rowmax_out[r] = max|d[r]| (nullable).  One workgroup per row, bisection on the monotone piecewise-linear
+ *   constraint instead of the reference's argsort (same solution up to fp32 summation order).
+ * rart_row_dot / rart_row_absmax_diff: per-row <a,b> and max|a-b|.
+ * rart_fab_update: x1 = clamp((x1 + eta*d1)*(1-alpha[r]) + (x0 + eta*d2)*alpha[r], 0, 1).
+ * rart_fab_backoff: rows with mask != 0: x1 = x0 + (x1 - x0)*beta. */
+int rart_fab_project_linf(const float* points, const float* w, const float* b, float* d_out, float* rowmax_out, int rows,
+                          size_t n, rart_stream_t stream);
+int rart_row_dot(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream);
+int rart_row_absmax_diff(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream);
+int rart_fab_update(float* x1, const float* x0, const float* d1, const float* d2, const float* alpha, int batch,
+                    size_t n_per_sample, float eta, rart_stream_t stream);
+int rart_fab_backoff(float* x1, const float* x0, const uint8_t* mask, int batch, size_t n_per_sample, float beta,
+                     rart_stream_t stream);
+
 /* Per-sample select: dst[i] = src[i] where mask[i] != 0 (rows of n_per_sample floats).
  * The x_best / x_best_adv / grad_best bookkeeping of autopgd_base.py:389-406,426-427. */
 int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batch, size_t n_per_sample,
@@ -175,7 +191,8 @@ int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batc
 
 /* Row-wise losses on logits [batch][classes] fp32 (autopgd_base.py:198-204,599-604; CE of
  * foolbox / imfgsm_attack.py:83).  kind: 0 = CE, 1 = DLR, 2 = targeted DLR (y_target required),
- * 3 = margin z_y - max_{j != y} z_j (Attacks/autoattack/square.py:68-86).
+ * 3 = margin z_y - max_{j != y} z_j (Attacks/autoattack/square.py:68-86),
+ * 4 = FAB targeted difference -(z_y - z_t) (Attacks/autoattack/fab_pt.py:102-117).
  * loss_out[batch] (nullable), dlogits_out[batch][classes] = d(sum_i loss_i * scale)/dlogits (nullable),
  * pred_out[batch] int32 argmax (nullable). */
 int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* y_target, int batch, int classes,

@@ -388,3 +388,120 @@ def square_linf_perturb(model_fn, x, y, eps, n_queries, p_init, rescale, init_si
         fooled = (model_fn(adv_curr).max(1)[1] != y[ind]).nonzero().flatten()
         adv[ind[fooled]] = adv_curr[fooled]
     return adv
+
+
+# ---------------------------------------------------------------------------------------
+# FAB, targeted, Linf (Attacks/autoattack/fab_base.py:84-336, fab_pt.py:102-117,
+# fab_projections.py:7-59) -- pinned
+# ---------------------------------------------------------------------------------------
+
+def fab_projection_linf(t, w, b):
+    """fab_projections.py:7-59: box-constrained Linf projection of the rows of t onto {x: w.x = b}.
+    Restated with the same sort / cumsum / binary-search structure.  Returns the step d."""
+    w, b = w.clone(), b.clone()
+    sign = 2 * ((w * t).sum(1) - b >= 0).to(t.dtype) - 1
+    w = w * sign.unsqueeze(1)
+    b = b * sign
+    a = (w < 0).to(t.dtype)
+    nz = (w != 0).to(t.dtype)
+    d = (a - t) * nz
+    p = a - t * (2 * a - 1)
+    indp = torch.argsort(p, dim=1)
+    b = b - (w * t).sum(1)
+    b0 = (w * d).sum(1)
+    indp2 = indp.flip((1,))
+    ws = w.gather(1, indp2)
+    bs2 = -ws * d.gather(1, indp2)
+    s = torch.cumsum(ws.abs(), dim=1)
+    sb = torch.cumsum(bs2, dim=1) + b0.unsqueeze(1)
+    n = w.shape[1]
+    b2 = sb[:, -1] - s[:, -1] * p.gather(1, indp[:, 0:1]).squeeze(1)
+    c_l = b - b2 > 0
+    c2 = (b - b0 > 0) & (~c_l)
+    lb = torch.zeros(int(c2.sum()))
+    ub = torch.full_like(lb, n - 1)
+    indp_, sb_, s_, p_, b_ = indp[c2], sb[c2], s[c2], p[c2], b[c2]
+    for _ in range(math.ceil(math.log2(n))):
+        mid = torch.floor((lb + ub) / 2)
+        m2 = mid.long().unsqueeze(1)
+        indcurr = indp_.gather(1, n - 1 - m2)
+        bb = (sb_.gather(1, m2) - s_.gather(1, m2) * p_.gather(1, indcurr)).squeeze(1)
+        c = b_ - bb > 0
+        lb = torch.where(c, mid, lb)
+        ub = torch.where(c, ub, mid)
+    lb = lb.long()
+    if c_l.any():
+        lam = torch.clamp_min((b[c_l] - sb[c_l, -1]) / (-s[c_l, -1]), 0).unsqueeze(-1)
+        d[c_l] = (2 * a[c_l] - 1) * lam
+    u = torch.arange(int(c2.sum()))
+    lam = torch.clamp_min((b[c2] - sb[c2][u, lb]) / (-s[c2][u, lb]), 0).unsqueeze(-1)
+    d[c2] = torch.min(lam, d[c2]) * a[c2] + torch.max(-lam, d[c2]) * (1 - a[c2])
+    return d * nz
+
+
+def fab_targeted_single_run(model_fn, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9):
+    """fab_base.py:84-270 with is_targeted=True, use_rand_start=False, norm Linf."""
+    x = x.detach().clone().float()
+    y_pred = model_fn(x).max(1)[1]
+    pred = y_pred == y
+    if pred.sum() == 0:
+        return x
+    pred = pred.nonzero().flatten()
+    la_target2 = model_fn(x).sort(dim=-1)[1][:, -target_class][pred].clone()
+    im2, la2 = x[pred].clone(), y[pred].clone()
+    bs = im2.shape[0]
+    u1 = torch.arange(bs)
+    adv = im2.clone()
+    adv_c = x.clone()
+    res2 = 1e10 * torch.ones([bs])
+    x1 = im2.clone()
+    x0 = im2.clone().reshape([bs, -1])
+    for _ in range(n_iter):
+        im = x1.clone().requires_grad_()
+        with torch.enable_grad():
+            yy = model_fn(im)
+            diffy = -(yy[u1, la2] - yy[u1, la_target2])
+            g, = torch.autograd.grad(diffy.sum(), im)
+        with torch.no_grad():
+            df = diffy.detach()
+            w = g.reshape([bs, -1])
+            b = -df + (g * x1).reshape(bs, -1).sum(dim=-1)
+            d3 = fab_projection_linf(torch.cat((x1.reshape([bs, -1]), x0), 0), torch.cat((w, w), 0), torch.cat((b, b), 0))
+            d1, d2 = d3[:bs].reshape(x1.shape), d3[-bs:].reshape(x1.shape)
+            a0 = d3.abs().max(dim=1, keepdim=True)[0].view(-1, 1, 1, 1)
+            a0 = torch.max(a0, 1e-8 * torch.ones_like(a0))
+            a1, a2 = a0[:bs], a0[-bs:]
+            alpha = torch.min(torch.max(a1 / (a1 + a2), torch.zeros_like(a1)), alpha_max * torch.ones_like(a1))
+            x1 = ((x1 + eta * d1) * (1 - alpha) + (im2 + d2 * eta) * alpha).clamp(0.0, 1.0)
+            is_adv = model_fn(x1).max(1)[1] != la2
+            if is_adv.sum() > 0:
+                ia = is_adv.nonzero().flatten()
+                t = (x1[ia] - im2[ia]).reshape([ia.shape[0], -1]).abs().max(dim=1)[0]
+                better = (t < res2[ia]).float().view(-1, 1, 1, 1)
+                adv[ia] = x1[ia] * better + adv[ia] * (1 - better)
+                res2[ia] = t * (t < res2[ia]).float() + res2[ia] * (t >= res2[ia]).float()
+                x1[ia] = im2[ia] + (x1[ia] - im2[ia]) * beta
+    ind_succ = (res2 < 1e10).nonzero().flatten()
+    adv_c[pred[ind_succ]] = adv[ind_succ].clone()
+    return adv_c
+
+
+def fab_targeted_perturb(model_fn, x, y, eps, n_iter, n_target_classes=9):
+    """fab_base.py:272-336, targeted branch, n_restarts 1."""
+    adv = x.clone()
+    with torch.no_grad():
+        acc = model_fn(x).max(1)[1] == y
+    for target_class in range(2, n_target_classes + 2):
+        ind = acc.nonzero().flatten()
+        if ind.numel() == 0:
+            continue
+        xs, ys = x[ind].clone(), y[ind].clone()
+        adv_curr = fab_targeted_single_run(model_fn, xs, ys, target_class, eps, n_iter)
+        with torch.no_grad():
+            acc_curr = model_fn(adv_curr).max(1)[1] == ys
+        res = (xs - adv_curr).abs().reshape(xs.shape[0], -1).max(1)[0]
+        acc_curr = torch.max(acc_curr, res > eps)
+        fooled = (acc_curr == 0).nonzero().flatten()
+        acc[ind[fooled]] = False
+        adv[ind[fooled]] = adv_curr[fooled].clone()
+    return adv

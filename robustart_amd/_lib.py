@@ -42,6 +42,11 @@ SIGNATURES = {
                                       c_void_p]),
     'rart_square_propose_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
                                          c_int, c_void_p, c_void_p]),
+    'rart_fab_project_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'rart_row_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'rart_row_absmax_diff': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'rart_fab_update': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_void_p]),
+    'rart_fab_backoff': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_void_p]),
     'rart_select_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_logit_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),

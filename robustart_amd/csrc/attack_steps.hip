@@ -352,6 +352,152 @@ __global__ __launch_bounds__(kBlock) void k_square_propose(float* __restrict__ x
   }
 }
 
+// ---- FAB (Linf) ---------------------------------------------------------------------------------
+// Box-constrained Linf projection of a point t onto the hyperplane {x : w.x = b}
+// (Attacks/autoattack/fab_projections.py:7-59).  With sign chosen so that w.t - b >= 0, a_i = [w_i < 0],
+// p_i = room of coordinate i towards its helpful bound (1 - t_i or t_i), the step is
+//     d_i = (2 a_i - 1) * min(lambda, p_i) * [w_i != 0]
+// where lambda solves F(lambda) = sum_i |w_i| min(lambda, p_i) = |w.t - b| (F is monotone, piecewise linear).
+// The reference finds the segment by argsort(p) + cumsum + binary search over 150 528 keys per row; here one
+// workgroup per row brackets lambda by bisection on F (each evaluation is a row reduction; the 1.2 MB row stays
+// in L2) and then solves the active segment exactly -- no sort.  Also returns max_i |d_i| (fab_base.py:196).
+constexpr int kFabThreads = 512;
+__device__ __forceinline__ double fab_block_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < kFabThreads / 64; ++i) t += sh[i];
+  return t;   // valid on every thread
+}
+__device__ __forceinline__ float fab_block_min(float v, double* sh, bool want_max) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off, 64);
+    v = want_max ? fmaxf(v, o) : fminf(v, o);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (double)v;
+  __syncthreads();
+  float t = (float)sh[0];
+  for (int i = 1; i < kFabThreads / 64; ++i) t = want_max ? fmaxf(t, (float)sh[i]) : fminf(t, (float)sh[i]);
+  return t;
+}
+
+__global__ __launch_bounds__(kFabThreads) void k_fab_project_linf(const float* __restrict__ pts,
+                                                                  const float* __restrict__ wv,
+                                                                  const float* __restrict__ bv, float* __restrict__ dout,
+                                                                  float* __restrict__ rowmax, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  const float* t = pts + row * n;
+  const float* w = wv + row * n;
+  float* d = dout + row * n;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) acc += (double)(w[i] * t[i]);
+  const double wt = fab_block_sum(acc, sh);
+  const float sgn = (wt - (double)bv[row] >= 0.0) ? 1.f : -1.f;
+  const double target = fabs(wt - (double)bv[row]);
+  double wsum = 0.0, ftot = 0.0;
+  float pmin = INFINITY;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float wi = sgn * w[i];
+    const float p = wi < 0.f ? 1.f - t[i] : t[i];
+    pmin = fminf(pmin, p);
+    wsum += (double)fabsf(wi);
+    ftot += (double)(fabsf(wi) * p);
+  }
+  wsum = fab_block_sum(wsum, sh);
+  ftot = fab_block_sum(ftot, sh);
+  pmin = fab_block_min(pmin, sh, false);
+  float lam;
+  if (wsum * (double)pmin > target) {          // c_l: no coordinate saturates
+    lam = (float)fmax(target / wsum, 0.0);
+  } else if (ftot > target) {                   // c2: some coordinates saturate at their bound
+    float lo = 0.f, hi = 1.f;
+    for (int it = 0; it < 26; ++it) {
+      const float mid = 0.5f * (lo + hi);
+      double f = 0.0;
+      for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+        const float wi = sgn * w[i];
+        const float p = wi < 0.f ? 1.f - t[i] : t[i];
+        f += (double)(fabsf(wi) * fminf(mid, p));
+      }
+      f = fab_block_sum(f, sh);
+      if (f > target) hi = mid; else lo = mid;
+    }
+    double sat = 0.0, act = 0.0;                // exact solve of the segment: saturated p <= lo, active p > lo
+    for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+      const float wi = sgn * w[i];
+      const float p = wi < 0.f ? 1.f - t[i] : t[i];
+      if (p <= lo) sat += (double)(fabsf(wi) * p); else act += (double)fabsf(wi);
+    }
+    sat = fab_block_sum(sat, sh);
+    act = fab_block_sum(act, sh);
+    lam = act > 0.0 ? (float)fmax((target - sat) / act, 0.0) : hi;
+  } else {
+    lam = INFINITY;                             // hyperplane out of reach inside the box: go to the bounds
+  }
+  float mx = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float wi = sgn * w[i];
+    const float p = wi < 0.f ? 1.f - t[i] : t[i];
+    const float dv = wi == 0.f ? 0.f : (wi < 0.f ? fminf(lam, p) : -fminf(lam, p));
+    d[i] = dv;
+    mx = fmaxf(mx, fabsf(dv));
+  }
+  mx = fab_block_min(mx, sh, true);
+  if (threadIdx.x == 0 && rowmax) rowmax[row] = mx;
+}
+
+// out[r] = sum_i a[r][i]*b[r][i]  (b of the hyperplane: -df + <grad, x1>, fab_base.py:170-171)
+__global__ __launch_bounds__(kFabThreads) void k_row_dot(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) acc += (double)(a[row * n + i] * b[row * n + i]);
+  acc = fab_block_sum(acc, sh);
+  if (threadIdx.x == 0) out[row] = (float)acc;
+}
+// out[r] = max_i |a[r][i] - b[r][i]|
+__global__ __launch_bounds__(kFabThreads) void k_row_absmax_diff(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 float* __restrict__ out, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) m = fmaxf(m, fabsf(a[row * n + i] - b[row * n + i]));
+  m = fab_block_min(m, sh, true);
+  if (threadIdx.x == 0) out[row] = m;
+}
+// x1 = clamp((x1 + eta*d1)*(1 - alpha) + (x0 + eta*d2)*alpha, 0, 1)   (fab_base.py:218-219)
+__global__ __launch_bounds__(kBlock) void k_fab_update(float* __restrict__ x1, const float* __restrict__ x0,
+                                                       const float* __restrict__ d1, const float* __restrict__ d2,
+                                                       const float* __restrict__ alpha, size_t nps, float eta) {
+  const uint32_t b = blockIdx.y;
+  const float al = alpha[b], om = 1.0f - al;
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const size_t i = base + e;
+    const float u = (x1[i] + eta * d1[i]) * om;
+    const float v = (x0[i] + d2[i] * eta) * al;
+    x1[i] = clampf(u + v, 0.f, 1.f);
+  }
+}
+// rows with mask: x1 = x0 + (x1 - x0)*beta   (backward step after a success, fab_base.py:244-245)
+__global__ __launch_bounds__(kBlock) void k_fab_backoff(float* __restrict__ x1, const float* __restrict__ x0,
+                                                        const uint8_t* __restrict__ mask, size_t nps, float beta) {
+  const uint32_t b = blockIdx.y;
+  if (!mask[b]) return;
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    const size_t i = base + e;
+    x1[i] = x0[i] + (x1[i] - x0[i]) * beta;
+  }
+}
+
 // ---- row-wise logit losses: one wave per row ------------------------------------------------
 struct Top {
   float v;
@@ -396,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void k_logit_loss(const float* __restrict__
     best = wave_argmax(best);
     top[r] = best;
     excl[r] = best.i;
-    if (kind == 0) break;               // CE only needs the max
+    if (kind == 0 || kind == 4) break;  // CE / targeted difference only need the max (for pred)
     if (kind == 3 && r == 1) break;     // margin needs top-2
     if (kind == 1 && r == 2) break;     // DLR needs top-3
   }
@@ -415,6 +561,15 @@ __global__ __launch_bounds__(kBlock) void k_logit_loss(const float* __restrict__
         dl[(size_t)row * classes + c] = scale * (p - (c == yy ? 1.f : 0.f));
       }
     }
+    return;
+  }
+  if (kind == 4) {
+    // FAB targeted difference (fab_pt.py:102-117): -(z_y - z_t); d/dz = -e_y + e_t
+    const int tt = (int)yt[row];
+    if (loss_out && lane == 0) loss_out[row] = -(zy - z[tt]);
+    if (dl)
+      for (int c = lane; c < classes; c += 64)
+        dl[(size_t)row * classes + c] = scale * ((c == tt ? 1.f : 0.f) - (c == yy ? 1.f : 0.f));
     return;
   }
   if (kind == 3) {
@@ -602,6 +757,42 @@ int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0,
   return RART_OK;
 }
 
+int rart_fab_project_linf(const float* points, const float* w, const float* b, float* d_out, float* rowmax_out, int rows,
+                          size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(points && w && b && d_out && rows > 0 && n > 0, "rart_fab_project_linf: bad arguments");
+  hipLaunchKernelGGL(k_fab_project_linf, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, points, w, b, d_out,
+                     rowmax_out, n);
+  RART_CHECK_LAUNCH("rart_fab_project_linf");
+  return RART_OK;
+}
+int rart_row_dot(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(a && b && out && rows > 0 && n > 0, "rart_row_dot: bad arguments");
+  hipLaunchKernelGGL(k_row_dot, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, a, b, out, n);
+  RART_CHECK_LAUNCH("rart_row_dot");
+  return RART_OK;
+}
+int rart_row_absmax_diff(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(a && b && out && rows > 0 && n > 0, "rart_row_absmax_diff: bad arguments");
+  hipLaunchKernelGGL(k_row_absmax_diff, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, a, b, out, n);
+  RART_CHECK_LAUNCH("rart_row_absmax_diff");
+  return RART_OK;
+}
+int rart_fab_update(float* x1, const float* x0, const float* d1, const float* d2, const float* alpha, int batch,
+                    size_t nps, float eta, rart_stream_t stream) {
+  RART_CHECK_ARG(x1 && x0 && d1 && d2 && alpha && batch > 0 && nps > 0, "rart_fab_update: bad arguments");
+  hipLaunchKernelGGL(k_fab_update, grid_rows(nps, batch), dim3(kBlock), 0, (hipStream_t)stream, x1, x0, d1, d2, alpha, nps,
+                     eta);
+  RART_CHECK_LAUNCH("rart_fab_update");
+  return RART_OK;
+}
+int rart_fab_backoff(float* x1, const float* x0, const uint8_t* mask, int batch, size_t nps, float beta,
+                     rart_stream_t stream) {
+  RART_CHECK_ARG(x1 && x0 && mask && batch > 0 && nps > 0, "rart_fab_backoff: bad arguments");
+  hipLaunchKernelGGL(k_fab_backoff, grid_rows(nps, batch), dim3(kBlock), 0, (hipStream_t)stream, x1, x0, mask, nps, beta);
+  RART_CHECK_LAUNCH("rart_fab_backoff");
+  return RART_OK;
+}
+
 int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batch, size_t nps, rart_stream_t stream) {
   RART_CHECK_ARG(dst && src && mask && batch > 0 && nps > 0, "rart_select_rows: bad arguments");
   hipLaunchKernelGGL(k_select_rows, grid_rows(nps, batch), dim3(kBlock), 0, (hipStream_t)stream, dst, src, mask, nps);
@@ -612,9 +803,9 @@ int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batc
 int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* yt, int batch, int classes, int kind,
                     float scale, float* loss_out, float* dl, int32_t* pred_out, rart_stream_t stream) {
   RART_CHECK_ARG(logits && y && batch > 0 && classes > 0, "rart_logit_loss: bad arguments");
-  RART_CHECK_ARG(kind >= 0 && kind <= 3, "rart_logit_loss: kind must be 0 (CE), 1 (DLR), 2 (targeted DLR), 3 (margin)");
-  RART_CHECK_ARG(kind != 2 || yt != nullptr, "rart_logit_loss: targeted DLR needs y_target");
-  RART_CHECK_ARG(kind == 0 || classes >= (kind == 3 ? 2 : (kind == 1 ? 3 : 4)), "rart_logit_loss: too few classes");
+  RART_CHECK_ARG(kind >= 0 && kind <= 4, "rart_logit_loss: kind must be 0 (CE), 1 (DLR), 2 (targeted DLR), 3 (margin), 4 (targeted diff)");
+  RART_CHECK_ARG((kind != 2 && kind != 4) || yt != nullptr, "rart_logit_loss: targeted losses need y_target");
+  RART_CHECK_ARG(kind == 0 || classes >= ((kind == 3 || kind == 4) ? 2 : (kind == 1 ? 3 : 4)), "rart_logit_loss: too few classes");
   const int rows_per_block = kBlock / 64;
   hipLaunchKernelGGL(k_logit_loss, dim3((batch + rows_per_block - 1) / rows_per_block), dim3(kBlock), 0,
                      (hipStream_t)stream, logits, y, yt, batch, classes, kind, scale, loss_out, dl, pred_out);

@@ -22,7 +22,7 @@ from . import rng as _rng
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
-LOSS_CE, LOSS_DLR, LOSS_DLR_TARGETED, LOSS_MARGIN = 0, 1, 2, 3
+LOSS_CE, LOSS_DLR, LOSS_DLR_TARGETED, LOSS_MARGIN, LOSS_TARGETED_DIFF = 0, 1, 2, 3, 4
 
 
 # ---------------------------------------------------------------------------------------
@@ -403,11 +403,88 @@ def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, resc
     return adv
 
 
+def fab_project_linf(points, w, b):
+    """-> (d, rowmax): rart_fab_project_linf on [R, ...] fp32 tensors."""
+    torch = _lib.require_gpu()
+    R = points.shape[0]
+    n = points[0].numel()
+    d = torch.empty_like(points)
+    rm = torch.empty(R, dtype=torch.float32, device=points.device)
+    _lib.check(_lib.load().rart_fab_project_linf(_lib.ptr(points), _lib.ptr(w), _lib.ptr(b), _lib.ptr(d), _lib.ptr(rm), R, n,
+                                                 _lib.stream_ptr()))
+    return d, rm
+
+
+def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9):
+    """FABAttack.attack_single_run, is_targeted, no random start, Linf (fab_base.py:84-270)."""
+    torch = _lib.require_gpu()
+    lib, sp = _lib.load(), _lib.stream_ptr
+    logits0 = prov.logits(x)
+    pred = logits0.max(1)[1] == y
+    adv_c = x.clone()
+    idx = pred.nonzero().flatten()
+    if idx.numel() == 0:
+        return adv_c
+    la_t = logits0.sort(dim=-1)[1][:, -target_class][idx].contiguous()
+    im2, la2 = x[idx].contiguous(), y[idx].contiguous()
+    bs = im2.shape[0]
+    nps = im2[0].numel()
+    adv = im2.clone()
+    res2 = torch.full((bs,), 1e10, dtype=torch.float32, device=x.device)
+    x1 = im2.clone()
+    dotb = torch.empty(bs, dtype=torch.float32, device=x.device)
+    tbuf = torch.empty(bs, dtype=torch.float32, device=x.device)
+    for _ in range(int(n_iter)):
+        logits, df, g, _ = prov.logits_and_grad(x1, la2, LOSS_TARGETED_DIFF, la_t)       # fab_pt.py:102-117
+        _lib.check(lib.rart_row_dot(_lib.ptr(g), _lib.ptr(x1), _lib.ptr(dotb), bs, nps, sp()))
+        b = (dotb - df).contiguous()                                                       # fab_base.py:170-171
+        d1, a1 = fab_project_linf(x1, g, b)                                                # fab_base.py:174-178
+        d2, a2 = fab_project_linf(im2, g, b)
+        a1, a2 = torch.clamp(a1, min=1e-8), torch.clamp(a2, min=1e-8)
+        alpha = torch.clamp(a1 / (a1 + a2), 0.0, alpha_max).contiguous()
+        _lib.check(lib.rart_fab_update(_lib.ptr(x1), _lib.ptr(im2), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(alpha), bs, nps,
+                                       float(eta), sp()))
+        is_adv = prov.logits(x1).max(1)[1] != la2                                          # fab_base.py:221
+        _lib.check(lib.rart_row_absmax_diff(_lib.ptr(x1), _lib.ptr(im2), _lib.ptr(tbuf), bs, nps, sp()))
+        better = is_adv & (tbuf < res2)
+        select_rows_(adv, x1, better)
+        res2 = torch.where(better, tbuf, res2)
+        m = is_adv.to(torch.uint8).contiguous()
+        _lib.check(lib.rart_fab_backoff(_lib.ptr(x1), _lib.ptr(im2), _lib.ptr(m), bs, nps, float(beta), sp()))
+    succ = (res2 < 1e10).nonzero().flatten()
+    adv_c[idx[succ]] = adv[succ]
+    return adv_c
+
+
+def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_classes=9, _prov=None):
+    """FABAttack.perturb, targeted, Linf, n_restarts 1 (fab_base.py:272-336).  FAB is deterministic without
+    random restarts, so there are no draws to inject."""
+    torch = _lib.require_gpu()
+    prov = _prov or _Provider(model_fn, normalize_inside=False)
+    x, y = _check_inputs(x, y)
+    adv = x.clone()
+    acc = prov.logits(x).max(1)[1] == y
+    for target_class in range(2, n_target_classes + 2):
+        ind = acc.nonzero().flatten()
+        if ind.numel() == 0:
+            break
+        xs, ys = x[ind].contiguous(), y[ind].contiguous()
+        adv_curr = _fab_targeted_single_run(prov, xs, ys, target_class, eps, n_iter)
+        acc_curr = prov.logits(adv_curr).max(1)[1] == ys
+        res = (xs - adv_curr).abs().flatten(1).max(1)[0]
+        acc_curr = acc_curr | (res > eps)
+        fooled = (~acc_curr).nonzero().flatten()
+        acc[ind[fooled]] = False
+        adv[ind[fooled]] = adv_curr[fooled]
+    return adv
+
+
 def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None):
     """attack.py:35-38 -> AutoAttack(model, norm, eps, version).run_standard_evaluation(x, y, bs=len(x))
     (autoattack.py:90-211).  `model` takes normalised input (NormalizeModel, autoattack.py:12-23).
-    standard = [apgd-ce, apgd-t, fab-t, square]; apgd-ce, apgd-t and square run here, fab-t is the
-    SURVEY.md 8f rank-2 "next" row and is reported as skipped (the result is then an upper bound
+    standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); the
+    untargeted `fab` of version 'plus' (a 1000-class Jacobian per step, unusable on ImageNet in the reference too)
+    and the L2 variants of fab-t / square are reported as skipped (the result is then an upper bound
     on robust accuracy, never silently presented as the full ensemble)."""
     torch = _lib.require_gpu()
     assert norm in ['Linf', 'L2', 'L1']
@@ -424,7 +501,7 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
     if version == 'rand':
         raise NotImplementedError("AutoAttack version 'rand' (EOT over 20 forward passes) is not implemented")
     n_restarts = 5 if version == 'plus' else 1
-    skipped = [a for a in plan if a in ('fab', 'fab-t')]
+    skipped = [a for a in plan if a in ('fab',)] + ([a for a in plan if a == 'fab-t'] if norm != 'Linf' else [])
     if skipped:
         warnings.warn('autoattack_linf: %s not implemented on this build yet -- running %s only; robust accuracy '
                       'is an upper bound of the full ensemble' % (skipped, [a for a in plan if a not in skipped]),
@@ -448,6 +525,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
                                         _prov=prov)
             elif attack == 'apgd-t':
                 adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, 100, 9, base_seed + 1000 * ai, 0, _prov=prov)
+            elif attack == 'fab-t':
+                adv_curr = fab_targeted_perturb(None, x, y, eps, 100, 9, _prov=prov)
             elif attack == 'square':
                 if norm != 'Linf':
                     raise NotImplementedError('Square L2 (square.py:296-530) is not implemented')

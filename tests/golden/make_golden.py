@@ -26,6 +26,8 @@ from RobustART.noise.utils.imagenet_c import corrupt as ref_corrupt  # noqa: E40
 from RobustART.noise.utils.adv.Attacks.autoattack.autopgd_base import APGDAttack, APGDAttack_targeted  # noqa: E402
 from RobustART.noise.utils.adv.Attacks.imfgsm_attack import _mim_whitebox  # noqa: E402
 from RobustART.noise.utils.adv.Attacks.autoattack.square import SquareAttack  # noqa: E402
+from RobustART.noise.utils.adv.Attacks.autoattack.fab_pt import FABAttack_PT  # noqa: E402
+from RobustART.noise.utils.adv.Attacks.autoattack.fab_projections import projection_linf  # noqa: E402
 
 from _inputs import RUNNABLE, make_image, case_seed  # noqa: E402
 from _tinynet import make_tinynet, make_batch  # noqa: E402
@@ -95,6 +97,15 @@ def gen_attacks():
     sq = SquareAttack(model_fn, p_init=.8, n_queries=40, eps=8 / 255, norm='Linf', n_restarts=1, seed=0,
                       resc_schedule=False, device='cpu')
     out['square/Linf/adv'] = sq.perturb(x.clone(), y.clone()).detach().numpy()
+    fab = FABAttack_PT(model_fn, n_restarts=1, n_iter=6, eps=8 / 255, seed=0, norm='Linf', verbose=False, device='cpu',
+                       targeted=True, n_target_classes=3)
+    out['fabt/Linf/adv'] = fab.perturb(x.clone(), y.clone()).detach().numpy()
+    gp = torch.Generator().manual_seed(3)
+    pt, pw = torch.rand(6, 500, generator=gp), torch.randn(6, 500, generator=gp)
+    pw[:, ::7] = 0
+    pb = torch.tensor([0.1, 5.0, -3.0, 40.0, -60.0, 0.0]) + (pw * pt).sum(1) * torch.tensor([1, 1, 1, 0, 0, 1.])
+    out['fabproj/t'], out['fabproj/w'], out['fabproj/b'] = pt.numpy(), pw.numpy(), pb.numpy()
+    out['fabproj/d'] = projection_linf(pt, pw, pb).numpy()
     np.savez_compressed(os.path.join(HERE, 'attacks_ref.npz'), **out)
     print('attacks_ref.npz', len(out), 'entries')
 

@@ -146,6 +146,16 @@ def test_square_matches_reference(gold_a):
     np.testing.assert_array_equal(adv.numpy(), gold_a['square/Linf/adv'])
 
 
+def test_fab_projection_and_fab_t_match_reference(gold_a):
+    d = A.fab_projection_linf(torch.from_numpy(gold_a['fabproj/t']), torch.from_numpy(gold_a['fabproj/w']),
+                              torch.from_numpy(gold_a['fabproj/b']))
+    np.testing.assert_array_equal(d.numpy(), gold_a['fabproj/d'])
+    net, model_fn = _model(gold_a)
+    x, y = torch.from_numpy(gold_a['x']), torch.from_numpy(gold_a['y'])
+    adv = A.fab_targeted_perturb(model_fn, x, y, 8 / 255, 6, 3)
+    np.testing.assert_allclose(adv.numpy(), gold_a['fabt/Linf/adv'], atol=2e-6)
+
+
 def test_mim_matches_reference(gold_a):
     net, _ = _model(gold_a)
     x, y = torch.from_numpy(gold_a['x']), torch.from_numpy(gold_a['y'])
