@@ -89,6 +89,16 @@ int rart_corrupt_u8(const uint8_t* in, uint8_t* out, int n, int h, int w,
                     const void* const* injected_host_array, int n_injected,
                     void* workspace, size_t workspace_bytes, rart_stream_t stream);
 
+/* ImageNet-S resize operators (imagenet_s_gen.py:19-34,127-166): Pillow's Image.resize((resize_w, resize_h), filter) on
+ * uint8 NHWC images followed by a crop, bit-exact with Pillow (Resample.c 22-bit fixed point; Geometry.c for
+ * NEAREST).  filter = PIL.Image constant: 0 nearest, 1 bilinear, 2 bicubic, 3 box, 4 hamming, 5 lanczos.
+ * out: uint8 [n][crop_h][crop_w][3] = resized[crop_y : crop_y+crop_h, crop_x : crop_x+crop_w]. */
+size_t rart_pil_resize_workspace_bytes(int n, int h, int w, int resize_h, int resize_w, int filter, int crop_y, int crop_x,
+                                       int crop_h, int crop_w);
+int rart_pil_resize_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int resize_h, int resize_w, int filter,
+                       int crop_y, int crop_x, int crop_h, int crop_w, void* workspace, size_t workspace_bytes,
+                       rart_stream_t stream);
+
 /* uint8 NHWC -> ImageNet-normalised tensor for the model ((x/255 - mean)/std), i.e. the ToTensor +
  * Normalize step that follows AddNoise in the reference's eval pipeline
  * (exprs/exp/imagenet_c_loop_mini/config_vit_base.yaml:85-99).

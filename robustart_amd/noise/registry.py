@@ -32,11 +32,10 @@ def add_noise_for_imagenet_c(image, severity=1, corruption_name=None, corruption
 
 
 def add_noise_for_imagenet_s(image, decoder_type='pil', resize_type='pil-bilinear', transform_type='val'):
-    """add_noise_utils.py:34-38.  SURVEY.md 8f rank 1 ("next" row): the decoder x resize-operator
-    generator is not built yet; fail loudly rather than approximate."""
+    """add_noise_utils.py:34-38 -> ImageTransfer(file_path=image, ..., return_online=True).getimage()."""
     assert isinstance(image, str), "Input of imagenet-S can only be file path"
-    raise NotImplementedError('imagenet-s (ImageTransfer decoder/resize noise) is a "next" row of the '
-                              'hot-path scope table and is not implemented in this build')
+    from .imagenet_s import image_transfer
+    return image_transfer(image, decoder_type=decoder_type, resize_type=resize_type, transform_type=transform_type)
 
 
 function_dict = {

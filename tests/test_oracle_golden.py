@@ -78,6 +78,19 @@ def test_sk_gaussian_restatement_matches_scipy():
         np.testing.assert_allclose(t, O.sk_gaussian(x, sigma, multichannel=True), atol=1e-13)
 
 
+def test_resize_oracle_matches_pillow_bit_exact():
+    """ImageNet-S resize operators: the oracle's restatement of Pillow's resampler vs the Pillow wheel here."""
+    from PIL import Image
+    from oracle import resize_np as R
+    M = {'nearest': Image.NEAREST, 'bilinear': Image.BILINEAR, 'bicubic': Image.BICUBIC, 'box': Image.BOX,
+         'hamming': Image.HAMMING, 'lanczos': Image.LANCZOS}
+    for (h, w, oh, ow) in [(333, 500, 256, 256), (100, 80, 256, 256), (500, 333, 117, 301)]:
+        x = make_image(3, h, w)
+        for name in R.FILTERS:
+            ref = np.asarray(Image.fromarray(x).resize((ow, oh), M[name]))
+            np.testing.assert_array_equal(R.pil_resize_u8(x, oh, ow, name), ref, err_msg='%s %s' % (name, (h, w, oh, ow)))
+
+
 def _model(gold_a):
     net = make_tinynet({k[4:]: gold_a[k] for k in gold_a.files if k.startswith('net/')})
     return net, (lambda x: net(A.normalize(x)))
