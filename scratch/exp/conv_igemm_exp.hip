@@ -44,36 +44,23 @@ struct RartConvDescDev {
   // src / wgt / dst(+res, mask); wgt_row_stride = elements between consecutive weight rows (0 = K)
   int z_inner, wgt_row_stride;
   long long src_zo, src_zi, wgt_zo, wgt_zi, dst_zo, dst_zi;
-  // exact division by multiply-shift for dividends < 2^31 (row index -> (image, oy, ox); K step -> tap):
-  // q = (n * magic) >> shift.  A hardware 64-bit division costs ~300 instructions and every workgroup needed six.
-  uint32_t gw_magic, gw_shift, gh_magic, gh_shift, tpt_magic, tpt_shift;
 };
 
+#ifndef EXP_NOSTORE
+#define EXP_NOSTORE 0
+#endif
+#ifndef EXP_NOLOAD
+#define EXP_NOLOAD 0
+#endif
+#ifndef EXP_NOREAD
+#define EXP_NOREAD 0
+#endif
+#define EXP_OFF (d.flags & 0x4000)
 namespace {
 constexpr int BM = 128;
 constexpr int kThreads = 256;
 enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4 };
 
-__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
-  return (uint32_t)(((uint64_t)n * magic) >> shift);
-}
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) short i16x2_t;
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // round to nearest even
-  f32x2_t f = {lo, hi};
-  bf16x2_t b = __builtin_convertvector(f, bf16x2_t);
-  return __builtin_bit_cast(uint32_t, b);
-}
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {           // sign bit set -> 0 (also -0.0)
-  const i16x2_t z = {0, 0};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
-}
-__device__ __forceinline__ uint32_t positive_lanes_i16(uint32_t w) {    // 0xFFFF per half whose int16 is > 0
-  const i16x2_t z = {0, 0}, one = {1, 1}, full = {-1, -1};
-  const i16x2_t t = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z), one);
-  return __builtin_bit_cast(uint32_t, (i16x2_t)(t * full));
-}
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);
@@ -105,7 +92,9 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   constexpr int WN = BN / 2;        // wave sub-tile columns
   constexpr int TN = WN / 32;       // 32-wide MFMA tiles per wave along n
   constexpr int B_CHUNKS = BN * 4 / kThreads;  // 16-byte chunks of the W tile per thread (2 or 1)
+  constexpr int LDC = BN + 4;       // fp32 epilogue staging row (floats)
   constexpr int kLdsBytes = 2 * (BM + BN) * LDK * 2;
+  static_assert(64 * LDC * 4 <= kLdsBytes, "epilogue staging must fit the tile buffers");
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[kLdsBytes + BM * 4];
   uint16_t* sA = reinterpret_cast<uint16_t*>(lds_raw);               // [2][BM][LDK]
   uint16_t* sB = sA + 2 * BM * LDK;                                   // [2][BN][LDK]
@@ -116,7 +105,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 
   // ---- XCD-aware tile mapping: all column tiles of a row tile on one XCD ----
   const int n_tiles = (d.n_cols + BN - 1) / BN;
-  const uint32_t M = (uint32_t)(d.batch * d.grid_h * d.grid_w);   // host guarantees < 2^31
+  const long long M = (long long)d.batch * d.grid_h * d.grid_w;
   const int m_tiles = (int)((M + BM - 1) / BM);
   int m_tile, n_tile;
   {
@@ -126,7 +115,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     n_tile = slot % n_tiles;
     if (m_tile >= m_tiles) return;
   }
-  const uint32_t m0 = (uint32_t)m_tile * BM;
+  const long long m0 = (long long)m_tile * BM;
   const int n0 = n_tile * BN;
 
   // ---- per-thread gather rows (2 rows of the A tile) ----
@@ -136,25 +125,25 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   bool a_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const uint32_t m = m0 + (tid >> 2) + 64 * i;
+    const long long m = m0 + (tid >> 2) + 64 * i;
     a_ok[i] = m < M;
-    const uint32_t mm = a_ok[i] ? m : 0u;
-    const uint32_t t = fastdiv(mm, d.gw_magic, d.gw_shift);
-    const int ox = (int)(mm - t * (uint32_t)d.grid_w);
-    const int n = (int)fastdiv(t, d.gh_magic, d.gh_shift);
-    const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
+    const long long mm = a_ok[i] ? m : 0;
+    const int ox = (int)(mm % d.grid_w);
+    const long long t = mm / d.grid_w;
+    const int oy = (int)(t % d.grid_h);
+    const int n = (int)(t / d.grid_h);
     a_by[i] = oy * d.sy;
     a_bx[i] = ox * d.sx;
     a_img[i] = n * d.src_h * d.src_w;
   }
   if (tid < BM) {
-    const uint32_t m = m0 + tid;
+    const long long m = m0 + tid;
     uint32_t off = 0xFFFFFFFFu;
     if (m < M) {
-      const uint32_t t = fastdiv(m, d.gw_magic, d.gw_shift);
-      const int ox = (int)(m - t * (uint32_t)d.grid_w);
-      const int n = (int)fastdiv(t, d.gh_magic, d.gh_shift);
-      const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
+      const int ox = (int)(m % d.grid_w);
+      const long long t = m / d.grid_w;
+      const int oy = (int)(t % d.grid_h);
+      const int n = (int)(t / d.grid_h);
       off = (uint32_t)(((n * d.dst_h + (oy * d.dst_sy + d.dst_oy)) * d.dst_w + (ox * d.dst_sx + d.dst_ox)) *
                        d.dst_pix_stride);
     }
@@ -166,28 +155,26 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   const int KT = K / BK;
   const int tiles_per_tap = d.k_per_tap / BK;
 
-  // accumulators start at the bias of their column (lane & 31 is the column of a 32x32 MFMA tile): the
-  // epilogue then has no bias pass
   f32x16 acc[2][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int bc = n0 + wn * WN + j * 32 + (lane & 31);
-    const float bv = (d.bias && bc < d.n_cols) ? d.bias[bc] : 0.f;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
-  }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+  bf16x8 cfrag; for (int q = 0; q < 8; ++q) cfrag[q] = (__bf16)(float)(lane + q);
 #define RART_COMPUTE(BUF)                                                                                       \
   {                                                                                                             \
     const uint16_t* A = sA + (BUF)*BM * LDK + (wm * 64 + frag_row) * LDK + frag_k;                              \
     const uint16_t* B = sB + (BUF)*BN * LDK + (wn * WN + frag_row) * LDK + frag_k;                              \
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                    \
       bf16x8 af[2], bfr[TN];                                                                                    \
+      if (!EXP_NOREAD || EXP_OFF) {                                                                           \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * LDK + ks * 16); \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * LDK + ks * 16); \
+      } else { _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = cfrag; _Pragma("unroll") for (int j = 0; j < TN; ++j) bfr[j] = cfrag; } \
       _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);               \
@@ -216,9 +203,9 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_wgt) + (size_t)(woff * 2u));         \
   }
 #define RART_LOAD_TILE(KT_, SET)                                                                                \
-  {                                                                                                             \
+  if (!EXP_NOLOAD || EXP_OFF) {                                                                                                             \
     const int kt_ = (KT_);                                                                                      \
-    const int tap = (int)fastdiv((uint32_t)kt_, d.tpt_magic, d.tpt_shift);                                                                        \
+    const int tap = kt_ / tiles_per_tap;                                                                        \
     const int kc = (kt_ - tap * tiles_per_tap) * BK + chunk * 8;                                                \
     const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];                                                           \
     const uint16_t* sbase = p_src + d.tap_src_off[tap];                                                         \
@@ -228,7 +215,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     if constexpr (B_CHUNKS > 1) RART_LOAD_B(1, rb##SET##_1)                                                     \
   }
 #define RART_STORE_TILE(BUF, SET)                                                                               \
-  {                                                                                                             \
+  if (!EXP_NOSTORE || EXP_OFF) {                                                                                                             \
     *reinterpret_cast<uint4*>(sA + (((BUF)*BM + (tid >> 2)) * LDK + chunk * 8)) = ra##SET##_0;                  \
     *reinterpret_cast<uint4*>(sA + (((BUF)*BM + (tid >> 2) + 64) * LDK + chunk * 8)) = ra##SET##_1;             \
     *reinterpret_cast<uint4*>(sB + (((BUF)*BN + (tid >> 2)) * LDK + chunk * 8)) = rb##SET##_0;                  \
@@ -263,13 +250,13 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     bool b_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const uint32_t m = m0 + prow + 32 * i;
+      const long long m = m0 + prow + 32 * i;
       b_ok[i] = m < M;
-      const uint32_t mm = b_ok[i] ? m : 0u;
-      const uint32_t t = fastdiv(mm, d.gw_magic, d.gw_shift);
-      const int ox = (int)(mm - t * (uint32_t)d.grid_w);
-      const int n = (int)fastdiv(t, d.gh_magic, d.gh_shift);
-      const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
+      const long long mm = b_ok[i] ? m : 0;
+      const int ox = (int)(mm % d.grid_w);
+      const long long t = mm / d.grid_w;
+      const int oy = (int)(t % d.grid_h);
+      const int n = (int)(t / d.grid_h);
       b_by[i] = oy * d.sy;
       b_bx[i] = ox * d.sx;
       b_img[i] = n * d.src_h * d.src_w;
@@ -291,9 +278,9 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_wgt) + (size_t)(woff * 2u));         \
   }
 #define RART_LOAD64(KT_)                                                                                        \
-  {                                                                                                             \
+  if (!EXP_NOLOAD || EXP_OFF) {                                                                                                             \
     const int kt_ = (KT_);                                                                                      \
-    const int tap = (int)fastdiv((uint32_t)kt_, d.tpt_magic, d.tpt_shift);                                                                        \
+    const int tap = kt_ / tiles_per_tap;                                                                        \
     const int kc = (kt_ - tap * tiles_per_tap) * BK + chunk8 * 8;                                               \
     const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];                                                           \
     const uint16_t* sbase = p_src + d.tap_src_off[tap];                                                         \
@@ -303,7 +290,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   }
 #define RART_ST64(PTR, ROWS, I, SRC) *reinterpret_cast<uint4*>(PTR + (((BUF_)*ROWS + prow + 32 * (I)) * LDK + chunk8 * 8)) = SRC;
 #define RART_STORE64(BUF)                                                                                       \
-  {                                                                                                             \
+  if (!EXP_NOSTORE || EXP_OFF) {                                                                                                             \
     const int BUF_ = (BUF);                                                                                     \
     RART_ST64(sA, BM, 0, qa0) RART_ST64(sA, BM, 1, qa1) RART_ST64(sA, BM, 2, qa2) RART_ST64(sA, BM, 3, qa3)     \
     RART_ST64(sB, BN, 0, qb0) RART_ST64(sB, BN, 1, qb1)                                                         \
@@ -331,100 +318,93 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 #undef RART_STORE_TILE
 #undef RART_COMPUTE
 
-  // ---- epilogue: each wave transposes its own 64 x WN sub-tile through a private LDS region, 32 rows at a
-  //      time, so the four waves drain concurrently and no block barrier sits between MFMAs and stores (the K
-  //      loop's last barrier already fenced the tile buffers).  fp32 staging -> bias / residual / ReLU mask /
-  //      activation on 16-byte rows -> coalesced 16 B stores (128 B or 64 B per row per instruction).
-  constexpr int LDW = WN + 4;                    // staging row (floats)
-  constexpr int CW = WN / 8;                     // 8-column chunks per sub-tile row (8 / 4)
-  constexpr int RPI = 64 / CW;                   // rows covered by one wave-wide access (8 / 16)
-  constexpr int NQ = 32 / RPI;                   // accesses per 32-row pass (4 / 2)
-  static_assert(4 * 32 * LDW * 4 <= kLdsBytes, "epilogue staging must fit the tile buffers");
-  float* sW = reinterpret_cast<float*>(lds_raw) + wave * 32 * LDW;
-  const int cw = lane % CW, rw0 = lane / CW;
-  const int col = n0 + wn * WN + cw * 8;
+  // ---- epilogue: two 64-row halves through LDS (fp32), then 16-byte rows out ----
+  float* sC = reinterpret_cast<float*>(lds_raw);
+  constexpr int C8 = BN / 8;              // 8-column chunks per row
+  constexpr int ROWS_PER_PASS = kThreads / C8;
+  const int c8 = tid % C8, r0 = tid / C8;
+  const int col = n0 + c8 * 8;
   const bool col_ok = col < d.n_cols;
+  float bias8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias8[j] = (d.bias && col_ok) ? d.bias[col + j] : 0.f;
   const bool relu = d.flags & F_RELU, out_f32 = d.flags & F_OUT_F32;
+
+  constexpr int RP = 64 / ROWS_PER_PASS;  // rows per thread per half
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    // issue the residual / mask reads of this pass first: their HBM latency overlaps the LDS transposition
-    uint32_t offs[NQ];
-    uint4 rv[NQ], mv[NQ];
+  for (int h = 0; h < 2; ++h) {
+    // issue the residual / mask reads of this half first: their HBM latency then overlaps the LDS
+    // transposition and its barrier instead of sitting exposed in front of every store
+    uint32_t offs[RP];
+    uint4 rv[RP], mv[RP];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const uint32_t off = col_ok ? row_dst[wm * 64 + i * 32 + q * RPI + rw0] : 0xFFFFFFFFu;
-      offs[q] = off;
-      rv[q] = make_uint4(0, 0, 0, 0);
-      mv[q] = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 pairs: mask passes
+    for (int i = 0; i < RP; ++i) {
+      const uint32_t off = col_ok ? row_dst[h * 64 + r0 + ROWS_PER_PASS * i] : 0xFFFFFFFFu;
+      offs[i] = off;
+      rv[i] = make_uint4(0, 0, 0, 0);
+      mv[i] = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 pairs: mask passes
       if (off != 0xFFFFFFFFu) {
         const size_t bo = (size_t)((off + (uint32_t)col) * 2u);
-        if (p_res) rv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_res) + bo);
-        if (p_mask) mv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_mask) + bo);
+        if (p_res) rv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_res) + bo);
+        if (p_mask) mv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_mask) + bo);
       }
     }
+    if (wm == h) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        sW[row * LDW + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const uint32_t off = offs[q];
-      const int r = q * RPI + rw0;
-      const float4 v0 = *reinterpret_cast<const float4*>(sW + r * LDW + cw * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(sW + r * LDW + cw * 8 + 4);
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            sC[row * LDC + wn * WN + j * 32 + (lane & 31)] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const uint32_t off = offs[i];
       if (off != 0xFFFFFFFFu) {
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        const uint32_t rw[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
-        const uint32_t mw[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
-        if (p_res) {
+      const int r = r0 + ROWS_PER_PASS * i;
+      const float4 v0 = *reinterpret_cast<const float4*>(sC + r * LDC + c8 * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(sC + r * LDC + c8 * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[2 * j] += __uint_as_float(rw[j] << 16);
-            v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
-          }
-        }
-        if (d.flags & F_GELU) {   // exact (erf) GELU, timm's nn.GELU default
+      for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+      {
+        const uint32_t rw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+        const uint32_t mw[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
-        }
-        if (out_f32) {
-          if (p_mask) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (!((short)(mw[j] & 0xFFFF) > 0)) v[2 * j] = 0.f;
-              if (!((short)(mw[j] >> 16) > 0)) v[2 * j + 1] = 0.f;
-            }
-          }
-          if (relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-          float* o = reinterpret_cast<float*>(d.dst) + p_dst_off + off + col;
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          // bf16 output: hardware RNE pack (v_cvt_pk_bf16_f32), then mask and ReLU on the packed pairs with
-          // 16-bit integer ops (a bf16 is > 0 exactly when its bits, read as int16, are > 0)
-          uint32_t o[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-            if (p_mask) o[j] &= positive_lanes_i16(mw[j]);
-            if (relu) o[j] = relu_bf16x2(o[j]);
-          }
-          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) =
-              make_uint4(o[0], o[1], o[2], o[3]);
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] += bf2f((uint16_t)(rw[j] & 0xFFFF));
+          v[2 * j + 1] += bf2f((uint16_t)(rw[j] >> 16));
+          if (!(bf2f((uint16_t)(mw[j] & 0xFFFF)) > 0.f)) v[2 * j] = 0.f;
+          if (!(bf2f((uint16_t)(mw[j] >> 16)) > 0.f)) v[2 * j + 1] = 0.f;
         }
       }
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (d.flags & F_GELU) {   // exact (erf) GELU, timm's nn.GELU default
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
+      }
+      if (out_f32) {
+        float* o = reinterpret_cast<float*>(d.dst) + p_dst_off + off + col;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        uint4 o;
+        o.x = f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.z = f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        o.w = f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) = o;
+      }
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 }
 }  // namespace
@@ -460,25 +440,12 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   d.wgt_row_stride = h->wgt_row_stride;
   d.src_zo = h->src_z_outer; d.src_zi = h->src_z_inner; d.wgt_zo = h->wgt_z_outer; d.wgt_zi = h->wgt_z_inner;
   d.dst_zo = h->dst_z_outer; d.dst_zi = h->dst_z_inner;
-  {
-    auto magic = [](uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividends < 2^31
-      uint32_t l = 0;
-      while ((1ull << l) < dv) ++l;
-      sh = 31 + l;
-      mg = (uint32_t)(((1ull << sh) + dv - 1) / dv);
-    };
-    magic((uint32_t)d.grid_w, d.gw_magic, d.gw_shift);
-    magic((uint32_t)d.grid_h, d.gh_magic, d.gh_shift);
-    magic((uint32_t)(d.k_per_tap / ((d.k_per_tap % 64 == 0 && (long long)d.k_per_tap * d.n_taps >= g_bk64_min_k) ? 64 : 32)),
-          d.tpt_magic, d.tpt_shift);
-  }
   RART_CHECK_ARG(nz <= 65535, "rart_conv_igemm_bf16: n_batched must be <= 65535");
   RART_CHECK_ARG(d.wgt_row_stride == 0 || d.wgt_row_stride % 8 == 0, "rart_conv_igemm_bf16: wgt_row_stride must keep 16-byte alignment");
   const long long M = (long long)d.batch * d.grid_h * d.grid_w;
   // the kernel addresses with 32-bit element offsets from uniform bases (saves ~20 VGPRs of 64-bit math)
   const long long src_elems = (long long)d.batch * d.src_h * d.src_w * d.src_pix_stride;
   const long long dst_elems = (long long)d.batch * d.dst_h * d.dst_w * d.dst_pix_stride;
-  RART_CHECK_ARG(M < (1ll << 31), "rart_conv_igemm_bf16: row grid must stay below 2^31 rows");
   RART_CHECK_ARG(src_elems < (1ll << 31) && dst_elems < (1ll << 31),
                  "rart_conv_igemm_bf16: tensors must stay below 2^31 elements (split the batch)");
   const int m_tiles = (int)((M + BM - 1) / BM);
