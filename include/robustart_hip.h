@@ -301,6 +301,31 @@ int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads,
 int rart_vit_transpose_v(const void* qkv, void* vt, int n, int tokens, int heads, int head_dim, int qkv_ld, int v_off,
                          int t_pad, rart_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training-side step kernels.  The solver the reference launches
+ * (RobustART/train/__init__.py:1 -> absent submodule) is configured by
+ * exprs/nips_benchmark/pgd_adv_train/resnet50/config.yaml:11-33 (SGD nesterov 0.9, wd 1e-4, label_smooth 0.1,
+ * EMA 0.9999) and exprs/nips_benchmark/new_adv_train/vit_base/config.yaml:11-38 (AdamW); the arithmetic is
+ * torch.optim.SGD / torch.optim.AdamW / F.cross_entropy(label_smoothing).  All buffers are flat fp32 arenas,
+ * 16-byte aligned, updated in place.
+ *   g' = grad*grad_scale (+ weight_decay*param for SGD); grad_scale folds the 1/world_size of the gradient mean.
+ *   ema (nullable): ema = ema_decay*ema + (1-ema_decay)*param_new.   zero_grad != 0: grad is reset to 0.
+ * Hyper-parameters are doubles (Python floats in the reference's configs); the kernels compute in fp32 and form
+ * 1-beta, 1-lr*wd, 1-decay in double rounded once, as torch does with its scalar arguments.
+ * ------------------------------------------------------------------------------------- */
+int rart_sgd_step_f32(float* param, float* grad, float* momentum_buf, float* ema, size_t n, double lr, double momentum,
+                      double weight_decay, int nesterov, double grad_scale, double ema_decay, int zero_grad,
+                      rart_stream_t stream);
+/* step counts from 1 (bias corrections 1-beta^step); decoupled weight decay (param *= 1 - lr*wd). */
+int rart_adamw_step_f32(float* param, float* grad, float* exp_avg, float* exp_avg_sq, float* ema, size_t n, double lr,
+                        double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
+                        double ema_decay, int zero_grad, rart_stream_t stream);
+int rart_ema_update_f32(float* ema, const float* param, size_t n, double decay, rart_stream_t stream);
+/* loss_out[batch] (nullable) = (1-s)*(-log p_y) + s*mean_c(-log p_c);
+ * dlogits_out[batch][classes] (nullable) = scale * (softmax - (1-s)*onehot - s/classes). */
+int rart_label_smooth_ce_f32(const float* logits, const int64_t* labels, int batch, int classes, double smoothing,
+                             double scale, float* loss_out, float* dlogits_out, rart_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

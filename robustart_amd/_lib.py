@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'librobustart_hip.so')
 
 c_void_p, c_int, c_size_t, c_u64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
                                               ctypes.c_uint64, ctypes.c_float)
+c_double = ctypes.c_double
 
 # name -> (restype, argtypes); every symbol include/robustart_hip.h declares
 SIGNATURES = {
@@ -70,6 +71,13 @@ SIGNATURES = {
     'rart_softmax_rows_bf16': (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'rart_vit_attention': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_vit_transpose_v': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_sgd_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double, c_double, c_int,
+                                  c_double, c_double, c_int, c_void_p]),
+    'rart_adamw_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double,
+                                    c_double, c_double, c_double, c_int, c_double, c_double, c_int, c_void_p]),
+    'rart_ema_update_f32': (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_void_p]),
+    'rart_label_smooth_ce_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p,
+                                         c_void_p]),
 }
 
 

@@ -13,9 +13,10 @@ One process per GPU.  Evaluation: samples shard over ranks (distributed, non-rep
 AddNoise (HIP kernels), the forward from the HIP engine, and the ONLY collective is one all-reduce of the
 (top-1, top-5, count) counters.  Adversarial training (PGD-k inner loop, BN in eval mode during the attack,
 cifar10/code/train.py:105-111): the attack runs on the HIP engine with the current weights re-folded; the
-train-mode forward/backward and the optimizer still run on PyTorch-ROCm (the HIP wgrad kernels are not written
-yet -- DESIGN.md section 7); the gradient exchange is DDP's bucketed all-reduce over RCCL/xGMI, overlapped with
-backward (`dist.sync: False` semantics).
+train-mode forward/backward still runs on PyTorch-ROCm (the HIP wgrad / train-mode BN kernels are not written
+yet -- DESIGN.md section 8); the loss + its gradient (label-smoothed CE), the optimizer (SGD-Nesterov / AdamW), the
+EMA and the gradient reset are HIP kernels over flat parameter arenas (train/arena.py), and the gradient exchange is
+a few large all-reduces on arena slices over RCCL/xGMI, overlapped with backward unless `dist.sync: True`.
 """
 import argparse
 import json
@@ -200,19 +201,44 @@ def train(cfg, args, rank, world, device):
     okw = dict(ocfg.get('kwargs', {}))
     lcfg = cfg.get('lr_scheduler', {}).get('kwargs', {})
     base_lr, warmup_lr = float(lcfg.get('base_lr', 0.1)), float(lcfg.get('warmup_lr', 0.4))
-    if ocfg.get('type', 'SGD') == 'AdamW':
-        opt = torch.optim.AdamW(model.parameters(), lr=base_lr, **okw)
-    else:
-        opt = torch.optim.SGD(model.parameters(), lr=base_lr, **okw)
-    ddp = model
-    if world > 1:
-        ddp = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[device.index] if device.type == 'cuda' else None, bucket_cap_mb=64,
-            gradient_as_bucket_view=True)
+    min_lr = float(lcfg.get('min_lr', 0.0))
+    kind = ocfg.get('type', 'SGD')
+    # flat arenas: parameters / gradients are views; the exchange is a few large all-reduces on arena slices,
+    # overlapped with backward unless the config asks for `dist.sync: True`
+    from .arena import HipOptimizer, ParamArena, label_smooth_ce
+    no_wd = ocfg.get('no_wd', {}) or {}
+    norm_names, fc_bias_names = set(), set()
+    for mn, mod in model.named_modules():
+        if isinstance(mod, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.LayerNorm, torch.nn.GroupNorm)):
+            norm_names.update(mn + '.' + pn for pn, _ in mod.named_parameters(recurse=False))
+        if isinstance(mod, torch.nn.Linear) and mod.bias is not None:
+            fc_bias_names.add(mn + '.bias')
+
+    def no_decay(name, p):
+        return (bool(no_wd.get('norm', False)) and name in norm_names) or \
+               (bool(no_wd.get('fc', False)) and name in fc_bias_names)
+
+    arena = ParamArena(model, bucket_bytes=int(cfg.get('dist', {}).get('bucket_mb', 48)) << 20, no_decay=no_decay,
+                       overlap=not bool(cfg.get('dist', {}).get('sync', False)))
+    ema_on = bool(cfg.get('ema', {}).get('enable', False))
+    decay = float(cfg.get('ema', {}).get('kwargs', {}).get('decay', 0.9999))
+    use_hip_opt = device.type == 'cuda' and args.engine == 'hip'
     ema = None
-    if cfg.get('ema', {}).get('enable', False):
-        decay = float(cfg['ema'].get('kwargs', {}).get('decay', 0.9999))
-        ema = {k: v.detach().clone() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    if use_hip_opt:
+        # SGD-Nesterov / AdamW + EMA + gradient reset: one HIP launch over the arena (rart_sgd_step_f32 / rart_adamw_step_f32)
+        opt = HipOptimizer(arena, kind=kind, lr=base_lr, momentum=float(okw.get('momentum', 0.9)),
+                           nesterov=bool(okw.get('nesterov', False)), weight_decay=float(okw.get('weight_decay', 0.0)),
+                           betas=tuple(okw.get('betas', (0.9, 0.999))), eps=float(okw.get('eps', 1e-8)),
+                           ema_decay=decay if ema_on else None)
+    else:
+        # CPU scaffold for the multi-process tests (gloo): torch's optimizer on the same arena views
+        groups = [{'params': [p for n, p in zip(arena.names, arena.params) if not no_decay(n, p)]},
+                  {'params': [p for n, p in zip(arena.names, arena.params) if no_decay(n, p)], 'weight_decay': 0.0}]
+        groups = [g for g in groups if g['params']]
+        opt = torch.optim.AdamW(groups, lr=base_lr, **okw) if kind == 'AdamW' else torch.optim.SGD(groups, lr=base_lr, **okw)
+        if ema_on:
+            ema = arena.flat_p.clone()
+    ema_buffers = {k: v.detach().clone() for k, v in model.named_buffers() if v.dtype.is_floating_point} if ema_on else {}
     ls = float(cfg.get('label_smooth', 0.0))
     adv = cfg.get('adv_train', None)                        # {'eps': '4/255', 'steps': 3, 'rel_stepsize': 0.4}
     mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
@@ -221,9 +247,7 @@ def train(cfg, args, rank, world, device):
     idx = shard_indices(n, rank, world)
     loss_v = float('nan')
     for it in range(max_iter):
-        lr = cosine_lr(it, max_iter, base_lr, warmup_lr, int(lcfg.get('warmup_steps', max(max_iter // 20, 1))))
-        for gp in opt.param_groups:
-            gp['lr'] = lr
+        lr = cosine_lr(it, max_iter, base_lr, warmup_lr, int(lcfg.get('warmup_steps', max(max_iter // 20, 1))), min_lr)
         sel = [idx[(it * bs + j) % len(idx)] for j in range(bs)]
         items = [ds[i] for i in sel]
         imgs = torch.stack([x[0] for x in items]).to(device)
@@ -241,16 +265,33 @@ def train(cfg, args, rank, world, device):
         model.train()
         xin = ((x01 - mean) / std).contiguous(memory_format=torch.channels_last)
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=use_amp):
-            out = ddp(xin)
+            out = model(xin)
+        if use_hip_opt:
+            # label-smoothed CE and its gradient in one HIP kernel; autograd continues from dlogits
+            loss_rows, dlogits = label_smooth_ce(out, labels, ls, 1.0 / len(items))
+            out.backward(dlogits.to(out.dtype))             # bucket all-reduces start from the grad hooks
+            loss = loss_rows.mean()
+        else:
             loss = F.cross_entropy(out.float(), labels, label_smoothing=ls)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()                                     # DDP: bucketed all-reduce overlapped with backward
-        opt.step()
-        if ema is not None:
+            loss.backward()
+        scale = arena.finish_grad_exchange()                # waits for the buckets; returns 1 / world_size
+        if use_hip_opt:
+            opt.lr = lr
+            opt.step(grad_scale=scale)                      # update + EMA + grad reset, one launch per decay range
+        else:
+            for gp in opt.param_groups:
+                gp['lr'] = lr
+            if scale != 1.0:
+                arena.flat_g.mul_(scale)
+            opt.step()
+            arena.flat_g.zero_()
+            if ema is not None:
+                ema.mul_(decay).add_(arena.flat_p, alpha=1 - decay)
+        if ema_buffers:
             with torch.no_grad():
-                for k, v in model.state_dict().items():
-                    if k in ema:
-                        ema[k].mul_(decay).add_(v.detach(), alpha=1 - decay)
+                for k, v in model.named_buffers():
+                    if k in ema_buffers:
+                        ema_buffers[k].mul_(decay).add_(v.detach(), alpha=1 - decay)
         loss_v = float(loss.detach())
         if rank == 0 and (it % int(cfg.get('saver', {}).get('print_freq', 10)) == 0 or it == max_iter - 1):
             print(json.dumps({'iter': it, 'loss': loss_v, 'lr': lr}))

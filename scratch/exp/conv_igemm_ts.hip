@@ -60,6 +60,23 @@ enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4 };
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // round to nearest even
+  f32x2_t f = {lo, hi};
+  bf16x2_t b = __builtin_convertvector(f, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {           // sign bit set -> 0 (also -0.0)
+  const i16x2_t z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
+}
+__device__ __forceinline__ uint32_t positive_lanes_i16(uint32_t w) {    // 0xFFFF per half whose int16 is > 0
+  const i16x2_t z = {0, 0}, one = {1, 1}, full = {-1, -1};
+  const i16x2_t t = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z), one);
+  return __builtin_bit_cast(uint32_t, (i16x2_t)(t * full));
+}
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);
@@ -153,13 +170,18 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   const int KT = K / BK;
   const int tiles_per_tap = d.k_per_tap / BK;
 
+  // accumulators start at the bias of their column (lane & 31 is the column of a 32x32 MFMA tile): the
+  // epilogue then has no bias pass
   f32x16 acc[2][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int bc = n0 + wn * WN + j * 32 + (lane & 31);
+    const float bv = (d.bias && bc < d.n_cols) ? d.bias[bc] : 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+  }
 
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
 #define RART_COMPUTE(BUF)                                                                                       \
@@ -331,9 +353,6 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   const int cw = lane % CW, rw0 = lane / CW;
   const int col = n0 + wn * WN + cw * 8;
   const bool col_ok = col < d.n_cols;
-  float bias8[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bias8[j] = (d.bias && col_ok) ? d.bias[col + j] : 0.f;
   const bool relu = d.flags & F_RELU, out_f32 = d.flags & F_OUT_F32;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -371,38 +390,46 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
       const float4 v1 = *reinterpret_cast<const float4*>(sW + r * LDW + cw * 8 + 4);
       if (off != 0xFFFFFFFFu) {
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-        {
-          const uint32_t rw[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
-          const uint32_t mw[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
+        const uint32_t rw[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
+        const uint32_t mw[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
+        if (p_res) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            v[2 * j] += bf2f((uint16_t)(rw[j] & 0xFFFF));
-            v[2 * j + 1] += bf2f((uint16_t)(rw[j] >> 16));
-            if (!(bf2f((uint16_t)(mw[j] & 0xFFFF)) > 0.f)) v[2 * j] = 0.f;
-            if (!(bf2f((uint16_t)(mw[j] >> 16)) > 0.f)) v[2 * j + 1] = 0.f;
+            v[2 * j] += __uint_as_float(rw[j] << 16);
+            v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
           }
-        }
-        if (relu) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         if (d.flags & F_GELU) {   // exact (erf) GELU, timm's nn.GELU default
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
         }
         if (out_f32) {
+          if (p_mask) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (!((short)(mw[j] & 0xFFFF) > 0)) v[2 * j] = 0.f;
+              if (!((short)(mw[j] >> 16) > 0)) v[2 * j + 1] = 0.f;
+            }
+          }
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
           float* o = reinterpret_cast<float*>(d.dst) + p_dst_off + off + col;
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
-          uint4 o;
-          o.x = f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          o.y = f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          o.z = f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-          o.w = f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) = o;
+          // bf16 output: hardware RNE pack (v_cvt_pk_bf16_f32), then mask and ReLU on the packed pairs with
+          // 16-bit integer ops (a bf16 is > 0 exactly when its bits, read as int16, are > 0)
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+            if (p_mask) o[j] &= positive_lanes_i16(mw[j]);
+            if (relu) o[j] = relu_bf16x2(o[j]);
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) =
+              make_uint4(o[0], o[1], o[2], o[3]);
         }
       }
     }
@@ -413,7 +440,6 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   TS(4)
   __builtin_amdgcn_s_waitcnt(0);
   TS(5)
-  if (tid == 0 && blockIdx.x < 8192) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); g_dbg[blockIdx.x * 16 + 15] = ((unsigned long long)xcc << 32) | hwid; }
 }
 }  // namespace
 

@@ -1,5 +1,5 @@
-"""N > 1 logic on CPU (gloo, world size 2): dataset sharding, the eval metric all-reduce, the DDP gradient
-all-reduce of the training loop, and rank-invariant global sample indexing.  No GPU work."""
+"""N > 1 logic on CPU (gloo, world size 2): dataset sharding, the eval metric all-reduce, the bucketed gradient
+all-reduce of the training loop (flat arenas, train/arena.py), and rank-invariant global sample indexing.  No GPU work."""
 import json
 import os
 import socket
@@ -21,7 +21,8 @@ args = Args(); args.engine='torch'; args.corruption=None; args.attack=None; args
 args.severity=3; args.seed=0; args.max_iter=3
 cfg = {'model': {'type': 'tiny_test'}, 'data': {'fake_size': 22, 'batch_size': 4, 'input_size': 32},
        'label_smooth': 0.1, 'ema': {'enable': True, 'kwargs': {'decay': 0.9}}, 'max_iter': 3, 'bf16': False,
-       'lr_scheduler': {'kwargs': {'base_lr': 0.01, 'warmup_lr': 0.02}}}
+       'lr_scheduler': {'kwargs': {'base_lr': 0.01, 'warmup_lr': 0.02}},
+       'dist': {'bucket_mb': 0, 'sync': bool(int(os.environ.get('RART_TEST_SYNC', '0')))}}   # bucket_mb 0: one bucket per parameter
 # a tiny model registered under the solver's get_model for the test
 import robustart_amd.model as M
 def tiny(**kw):
@@ -93,3 +94,39 @@ def test_shard_indices_cover_ragged_and_empty():
     assert abs(parse_eps('8/255') - 8 / 255) < 1e-12 and parse_eps('0.5') == 0.5
     assert cosine_lr(0, 100, 0.1, 0.4, 10) == 0.1 and abs(cosine_lr(10, 100, 0.1, 0.4, 10) - 0.4) < 1e-12
     assert cosine_lr(100, 100, 0.1, 0.4, 10) < 1e-9
+
+
+def test_param_arena_views_buckets_and_decay_ranges():
+    from robustart_amd.train.arena import ParamArena
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Flatten(),
+                                torch.nn.Linear(5, 7))
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    arena = ParamArena(model, bucket_bytes=64, no_decay=lambda n, p: n.startswith('1.'))
+    # parameters are views into the arena, values preserved, 16-byte aligned starts
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n])
+        off = (p.data_ptr() - arena.flat_p.data_ptr()) // 4
+        assert 0 <= off < arena.numel and off % 4 == 0
+        assert p.grad.data_ptr() == arena.flat_g.data_ptr() + 4 * off
+    # the no-decay range is the tail of the arena and holds exactly the BatchNorm parameters
+    tail = [n for n, o in zip(arena.names, arena.offsets) if o >= arena.decay_end]
+    assert sorted(tail) == ['1.bias', '1.weight']
+    # buckets tile the arena exactly once
+    cover = sorted((lo, hi) for lo, hi, _ in arena.buckets)
+    assert cover[0][0] == 0 and cover[-1][1] == arena.numel
+    assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert sum(c for _, _, c in arena.buckets) == len(arena.params)
+    # gradients accumulate into the arena
+    model(torch.randn(2, 3, 3, 3)).sum().backward()
+    assert arena.flat_g.abs().sum() > 0
+    assert arena.finish_grad_exchange() == 1.0
+
+
+def test_world2_sync_mode_also_keeps_replicas_identical():
+    os.environ['RART_TEST_SYNC'] = '1'
+    try:
+        r2 = _run(2)
+    finally:
+        os.environ.pop('RART_TEST_SYNC', None)
+    assert all(r['params_identical_across_ranks'] for r in r2)
