@@ -154,6 +154,27 @@ def evaluate(cfg, args, rank, world, device, model=None):
             attack.config['steps'] = args.steps
     mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
+    # transfer harness: adversarial examples crafted on cfg.model, scored on the target model
+    tgt_model = None
+    if getattr(args, 'tgt_type', None):
+        from ..model import get_model
+        tgt = get_model({'type': args.tgt_type}).to(device).eval()
+        if use_hip:
+            from ..model.engine import EngineModel
+            try:
+                tgt_model = EngineModel(tgt, takes_normalized=False)
+            except Exception:                                   # no HIP engine for this architecture: torch module
+                tgt_model = lambda z, _t=tgt: _t((z - mean) / std)   # noqa: E731
+        else:
+            tgt_model = lambda z, _t=tgt: _t((z - mean) / std)       # noqa: E731
+    writer = None
+    if getattr(args, 'save_dir', None):
+        from ..metrics import ResultWriter, result_dir
+        noise_name = args.corruption or (args.attack if args.attack and args.attack != 'none' else 'none')
+        eps_name = ('%d' % args.severity) if args.corruption else (
+            ('%.3f' % parse_eps(args.eps)) if noise_name != 'none' else '0')
+        writer = ResultWriter(result_dir(args.save_dir, getattr(args, 'src_name', None) or cfg['model']['type'],
+                                         noise_name, eps_name, tgt_name=getattr(args, 'tgt_name', None)), rank, world)
     c1 = c5 = cnt = 0
     t0 = time.time()
     for s in range(0, len(idx), bs):
@@ -172,7 +193,8 @@ def evaluate(cfg, args, rank, world, device, model=None):
             kw = {k: v for k, v in attack.config.items()}
             from ..noise.registry import function_dict
             adv_x = function_dict[attack.noise_type](x01, labels, **kw)
-            logits = f_model(adv_x)
+            with torch.no_grad():
+                logits = (tgt_model or f_model)(adv_x)
         elif use_hip:
             logits = f_model.rart_engine.logits_from_u8(imgs, IMAGENET_MEAN, IMAGENET_STD)
         else:
@@ -180,6 +202,10 @@ def evaluate(cfg, args, rank, world, device, model=None):
                 logits = model((imgs.permute(0, 3, 1, 2).float() / 255.0 - mean) / std)
         a, b = topk_correct(logits.float(), labels)
         c1, c5, cnt = c1 + a, c5 + b, cnt + len(items)
+        if writer is not None:
+            writer.write_batch(logits, labels, idx[s:s + bs])
+    if writer is not None:
+        writer.close(barrier=dist.barrier if dist.is_available() and dist.is_initialized() else None)
     c1, c5, cnt = all_reduce_counters([c1, c5, cnt], device)
     res = {'top1': c1 / max(cnt, 1), 'top5': c5 / max(cnt, 1), 'count': cnt, 'world_size': world,
            'noise': args.corruption or args.attack or 'none', 'seconds': time.time() - t0}
@@ -310,6 +336,11 @@ def main(argv=None):
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--engine', choices=['hip', 'torch'], default='hip')
     ap.add_argument('--max-iter', type=int, default=20)
+    ap.add_argument('--save-dir', default=None, help='root of <model>/<noise>_<eps>/results.txt.all (robustart_amd.metrics)')
+    ap.add_argument('--src_name', default=None, help='name of the attacked (source) model in the result path')
+    ap.add_argument('--tgt_name', default=None, help='transfer: name of the target model (new_transfer/eval.sh:42-44)')
+    ap.add_argument('--tgt-type', default=None, help='transfer: model.type of the target model; adversarial examples '
+                    'are crafted on cfg.model and scored on this one')
     args = ap.parse_args(argv)
     cfg = load_config(args.config)
     rank, world, device = init_dist()

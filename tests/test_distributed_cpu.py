@@ -19,6 +19,7 @@ from robustart_amd.train import cls_solver as S
 class Args: pass
 args = Args(); args.engine='torch'; args.corruption=None; args.attack=None; args.eps='8/255'; args.steps=0
 args.severity=3; args.seed=0; args.max_iter=3
+args.save_dir=os.path.join(os.environ['RART_TEST_SAVE'], 'w' + os.environ['WORLD_SIZE']); args.src_name='tiny'; args.tgt_name=None; args.tgt_type=None
 cfg = {'model': {'type': 'tiny_test'}, 'data': {'fake_size': 22, 'batch_size': 4, 'input_size': 32},
        'label_smooth': 0.1, 'ema': {'enable': True, 'kwargs': {'decay': 0.9}}, 'max_iter': 3, 'bf16': False,
        'lr_scheduler': {'kwargs': {'base_lr': 0.01, 'warmup_lr': 0.02}},
@@ -32,6 +33,7 @@ def tiny(**kw):
 M._REGISTRY['tiny_test'] = tiny
 rank, world, device = S.init_dist()
 res = S.evaluate(cfg, args, rank, world, device)
+merged = [json.loads(l) for l in open(os.path.join(args.save_dir, 'tiny', 'none_0', 'results.txt.all'))] if rank == 0 else []
 loss, model = S.train(cfg, args, rank, world, device)
 flat = torch.cat([p.detach().flatten() for p in model.parameters()])
 gathered = [torch.zeros_like(flat) for _ in range(world)] if world > 1 else [flat]
@@ -40,7 +42,7 @@ if world > 1:
 same = all(torch.equal(gathered[0], g) for g in gathered)
 idx = S.shard_indices(22, rank, world)
 out = {'rank': rank, 'world': world, 'res': res, 'params_identical_across_ranks': same, 'n_local': len(idx),
-       'first': idx[0], 'loss': loss}
+       'first': idx[0], 'loss': loss, 'merged': [(r['index'], r['prediction'], r['label']) for r in merged]}
 print('RESULT ' + json.dumps(out))
 if dist.is_initialized(): dist.destroy_process_group()
 '''
@@ -55,6 +57,8 @@ def _free_port():
 
 
 def _run(world):
+    import tempfile
+    os.environ.setdefault('RART_TEST_SAVE', tempfile.mkdtemp())
     port = _free_port()
     procs = []
     for r in range(world):
@@ -80,7 +84,10 @@ def test_world2_matches_world1_and_syncs_gradients():
     for o in two:
         assert o['res']['count'] == 22 == one['res']['count']
         assert o['res']['top1'] == one['res']['top1'] and o['res']['top5'] == one['res']['top5']
-    # the training exchange: after 3 DDP steps all ranks hold identical parameters
+    # the result writer: rank 0's merged results.txt.all is identical for both world sizes, ordered by global index
+    m2 = [o for o in two if o['rank'] == 0][0]['merged']
+    assert m2 == one['merged'] and [r[0] for r in m2] == list(range(22))
+    # the training exchange: after 3 steps all ranks hold identical parameters
     assert all(o['params_identical_across_ranks'] for o in two)
     assert all(o['loss'] == o['loss'] for o in two)          # finite
 
