@@ -326,6 +326,42 @@ int rart_ema_update_f32(float* ema, const float* param, size_t n, double decay, 
 int rart_label_smooth_ce_f32(const float* logits, const int64_t* labels, int batch, int classes, double smoothing,
                              double scale, float* loss_out, float* dlogits_out, rart_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Train-mode conv + BatchNorm support (cls_solver training step): the contractions run on
+ * rart_conv_igemm_bf16; these are the HBM-bound kernels around it.  Activations are bf16 [rows][channels]
+ * (NHWC, rows = batch*h*w), statistics fp32.  channels: a power of two in [8, 2048].
+ * Reference arithmetic: torch.nn.BatchNorm2d (training mode) and conv2d's autograd.
+ * ------------------------------------------------------------------------------------- */
+size_t rart_bn_workspace_bytes(size_t rows, int channels);
+/* batch statistics of z, y = [relu](z*scale + shift [+ res]); running stats updated in place when non-NULL
+ * (running_var with the unbiased variance); mean_out / invstd_out [channels] are kept for the backward;
+ * scale_shift [2][channels] receives gamma*invstd and beta - mean*gamma*invstd. */
+int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, size_t rows, int channels, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, double momentum, double eps,
+                               int relu, float* mean_out, float* invstd_out, float* scale_shift, void* workspace,
+                               size_t workspace_bytes, rart_stream_t stream);
+/* g = dy * [ymask > 0] (ymask NULL: g = dy); dgamma = sum g*xhat, dbeta = sum g (written, or added when
+ * accumulate != 0); dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); g_out (nullable) receives g.
+ * coef: [3][channels] fp32 scratch. */
+int rart_bn_train_backward_bf16(const void* dy, const void* ymask, const void* z, void* dz, void* g_out, size_t rows,
+                                int channels, const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                                float* dbeta, int accumulate, float* coef, void* workspace, size_t workspace_bytes,
+                                rart_stream_t stream);
+/* dst[(t*channels + c)][m] = src[img(m), oy*sy + tap_dy[t], ox*sx + tap_dx[t], c] for m < batch*grid_h*grid_w, zero
+ * outside the image and for the padding rows up to rows_padded (multiple of 64): the K(=pixel)-contiguous operand
+ * layout of the weight-gradient GEMM.  channels: 4 (stem's padded plane) or a multiple of 8. */
+int rart_transpose_gather_bf16(const void* src, void* dst, int batch, int src_h, int src_w, int channels, int grid_h,
+                               int grid_w, int sy, int sx, int n_taps, const int* tap_dy, const int* tap_dx,
+                               long long rows_padded, rart_stream_t stream);
+/* grad[n][c][t] (torch conv weight layout, t = r*S + s) (+)= sum_z partial[z][t*channels_padded + c][n];
+ * partial: fp32 [splits][taps*channels_padded][ld_n], the split-K output of rart_conv_igemm_bf16. */
+int rart_wgrad_reduce_f32(const float* partial, int splits, int taps, int channels, int channels_padded, int n_out,
+                          int ld_n, float* grad, int accumulate, rart_stream_t stream);
+/* fp32 master weight [n_out][channels][r][s] -> bf16 igemm table over the listed taps:
+ * transpose 0: out[n][ti*channels + c] (forward), 1: out[c][ti*n_out + n] (backward to input); rows zero-padded. */
+int rart_pack_conv_weight_bf16(const float* weight, void* out, int n_out, int channels, int r, int s, int n_taps,
+                               const int* tap_r, const int* tap_s, int transpose, int rows_padded, rart_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

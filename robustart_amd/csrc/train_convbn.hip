@@ -1,0 +1,454 @@
+// Train-mode conv + BatchNorm support kernels for gfx950 (ResNet-50 training step of cls_solver; SURVEY.md 8a M2,
+// BASELINE config 5).  The dense contractions stay on rart_conv_igemm_bf16; this file holds the HBM-bound
+// pieces around it:
+//   * batch statistics of a conv output z[M][C] (bf16 NHWC): two-level deterministic column sums, finalised
+//     into mean / invstd / fused scale+shift and the running-statistics update (nn.BatchNorm2d, momentum 0.1,
+//     unbiased running variance);
+//   * y = relu(z*scale + shift + residual);
+//   * BatchNorm backward: g = dy * [y > 0]; reductions sum(g), sum(g*xhat); dz = gamma*invstd*(g - mean(g) -
+//     xhat*mean(g*xhat)); dgamma = sum(g*xhat), dbeta = sum(g) written straight into the gradient arena;
+//   * weight gradient as a split-K GEMM on the igemm kernel: both operands are needed K(=pixel)-contiguous, so
+//     dz and the (implicit) im2col matrix are transposed by `rart_transpose_gather_bf16`
+//     (out[(tap, c)][m] = x[pixel(m) + tap][c]), the igemm writes fp32 partials per K split, and
+//     `rart_wgrad_reduce_f32` sums the splits in fixed order into the torch weight layout [N][C][R][S];
+//   * packing of the fp32 master weights into the bf16 forward / backward-to-input tables of the igemm.
+// Reference arithmetic: torch.nn.BatchNorm2d / conv2d autograd (the reference trains with PyTorch:
+// cifar10/code/train.py:96-127; model RobustART/model/__init__.py:1 -> public ResNet-50).
+#include "rart_common.h"
+
+namespace {
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float bf2f(uint32_t v16) { return __uint_as_float(v16 << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = __uint_as_float(w[j] << 16);
+    f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 o;
+  o.x = f2bf(f[0]) | (f2bf(f[1]) << 16);
+  o.y = f2bf(f[2]) | (f2bf(f[3]) << 16);
+  o.z = f2bf(f[4]) | (f2bf(f[5]) << 16);
+  o.w = f2bf(f[6]) | (f2bf(f[7]) << 16);
+  return o;
+}
+// 8 per-channel "keep" flags from a post-ReLU activation vector: bits > 0 as int16
+__device__ __forceinline__ void keep8(const uint4& v, bool* k) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    k[2 * j] = (short)(w[j] & 0xFFFFu) > 0;
+    k[2 * j + 1] = (short)(w[j] >> 16) > 0;
+  }
+}
+
+// ---- two-level column reductions over rows of a [M][C] bf16 matrix ------------------------------------------
+// MODE 0: a = sum z, b = sum z^2.   MODE 1: g = dy*[ymask>0]; a = sum g, b = sum g*xhat  (xhat from z, mean, invstd)
+// Block = 256 threads = (C/8 channel groups) x (2048/C row lanes); partial[chunk][0/1][C] fp32.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_colsum2(const uint4* __restrict__ z, const uint4* __restrict__ dy,
+                                                     const uint4* __restrict__ ymask, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, size_t M, int C,
+                                                     size_t rows_per_chunk, float* __restrict__ partial) {
+  __shared__ float sh[2][2048];
+  const int c8n = C / 8;
+  const int rows_par = kBlock / c8n;
+  const int tid = threadIdx.x, cg = tid % c8n, rl = tid / c8n;
+  const size_t r0 = (size_t)blockIdx.x * rows_per_chunk;
+  const size_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+  float a[8], b[8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = b[j] = 0.f;
+    mu[j] = MODE == 1 ? mean[cg * 8 + j] : 0.f;
+    is[j] = MODE == 1 ? invstd[cg * 8 + j] : 0.f;
+  }
+  for (size_t r = r0 + rl; r < r1; r += rows_par) {
+    const size_t idx = r * c8n + cg;
+    float zf[8];
+    unpack8(z[idx], zf);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[j] += zf[j];
+        b[j] = fmaf(zf[j], zf[j], b[j]);
+      }
+    } else {
+      float gf[8];
+      unpack8(dy[idx], gf);
+      bool kp[8];
+      if (ymask) keep8(ymask[idx], kp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = (!ymask || kp[j]) ? gf[j] : 0.f;
+        a[j] += g;
+        b[j] = fmaf(g, (zf[j] - mu[j]) * is[j], b[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sh[0][rl * C + cg * 8 + j] = a[j];
+    sh[1][rl * C + cg * 8 + j] = b[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kBlock) {
+    float sa = 0.f, sb = 0.f;
+    for (int r = 0; r < rows_par; ++r) {
+      sa += sh[0][r * C + c];
+      sb += sh[1][r * C + c];
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = sa;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sb;
+  }
+}
+
+// forward finalise: one thread per channel
+__global__ void k_bn_finalize_fwd(const float* __restrict__ partial, int chunks, int C, double inv_m, double unbias,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                  float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                  float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                  float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s += (double)partial[((size_t)k * 2 + 0) * C + c];
+    q += (double)partial[((size_t)k * 2 + 1) * C + c];
+  }
+  const double mu = s * inv_m;
+  double var = q * inv_m - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * is;
+  mean_out[c] = (float)mu;
+  invstd_out[c] = is;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - (float)mu * sc;
+  if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+}
+
+// backward finalise: dgamma / dbeta into the gradient arena, k1 = mean(g), k2 = mean(g*xhat), sg = gamma*invstd
+__global__ void k_bn_finalize_bwd(const float* __restrict__ partial, int chunks, int C, double inv_m,
+                                  const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                  float* __restrict__ coef /* [3][C]: k1, k2, gamma*invstd */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s += (double)partial[((size_t)k * 2 + 0) * C + c];
+    q += (double)partial[((size_t)k * 2 + 1) * C + c];
+  }
+  if (accumulate) {
+    dbeta[c] += (float)s;
+    dgamma[c] += (float)q;
+  } else {
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+  }
+  coef[c] = (float)(s * inv_m);
+  coef[C + c] = (float)(q * inv_m);
+  coef[2 * C + c] = gamma[c] * invstd[c];
+}
+
+__global__ __launch_bounds__(kBlock) void k_bn_apply(const uint4* __restrict__ z, const uint4* __restrict__ res,
+                                                     uint4* __restrict__ y, size_t n8, int c8n,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     int relu) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (size_t)gridDim.x * kBlock) {
+    const int cg = (int)(i % c8n);
+    float zf[8], rf[8];
+    unpack8(z[i], zf);
+    if (res) unpack8(res[i], rf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = fmaf(zf[j], scale[cg * 8 + j], shift[cg * 8 + j]);
+      if (res) v += rf[j];
+      if (relu) v = fmaxf(v, 0.f);
+      zf[j] = v;
+    }
+    y[i] = pack8(zf);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(const uint4* __restrict__ dy, const uint4* __restrict__ ymask,
+                                                         const uint4* __restrict__ z, uint4* __restrict__ dz,
+                                                         uint4* __restrict__ g_out, size_t n8, int c8n, int C,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ coef) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (size_t)gridDim.x * kBlock) {
+    const int cg = (int)(i % c8n);
+    float gf[8], zf[8];
+    unpack8(dy[i], gf);
+    unpack8(z[i], zf);
+    bool kp[8];
+    if (ymask) keep8(ymask[i], kp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      const float g = (!ymask || kp[j]) ? gf[j] : 0.f;
+      gf[j] = g;
+      const float xh = (zf[j] - mean[c]) * invstd[c];
+      zf[j] = coef[2 * C + c] * (g - coef[c] - xh * coef[C + c]);
+    }
+    dz[i] = pack8(zf);
+    if (g_out) g_out[i] = pack8(gf);
+  }
+}
+
+// ---- transposed (im2col) copy: out[(t*C + c)][m] = x[img(m), oy*sy + dy_t, ox*sx + dx_t, c]; zeros outside the
+//      image and for m >= M.  64 pixels x 64 channels per workgroup through LDS.
+struct GatherArgs {
+  int batch, src_h, src_w, C, grid_h, grid_w, sy, sx, n_taps;
+  int tap_dy[49], tap_dx[49];
+  long long M, M_pad;
+};
+__global__ __launch_bounds__(kBlock) void k_transpose_gather(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                                             const GatherArgs a) {
+  __shared__ uint16_t tile[64][72];
+  const int tid = threadIdx.x;
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64, t = blockIdx.z;
+  const int dy = a.tap_dy[t], dx = a.tap_dx[t];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = tid / 8 + 32 * i, ch = tid % 8;
+    const long long m = m0 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < a.M && c0 + ch * 8 < a.C) {
+      const int ox = (int)(m % a.grid_w);
+      const long long q = m / a.grid_w;
+      const int oy = (int)(q % a.grid_h), img = (int)(q / a.grid_h);
+      const int iy = oy * a.sy + dy, ix = ox * a.sx + dx;
+      if ((unsigned)iy < (unsigned)a.src_h && (unsigned)ix < (unsigned)a.src_w)
+        v = *reinterpret_cast<const uint4*>(x + (((size_t)img * a.src_h + iy) * a.src_w + ix) * a.C + c0 + ch * 8);
+    }
+    *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid / 8 + 32 * i, mch = tid % 8;
+    if (c0 + c >= a.C) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      w[j] = (uint32_t)tile[mch * 8 + 2 * j][c] | ((uint32_t)tile[mch * 8 + 2 * j + 1][c] << 16);
+    *reinterpret_cast<uint4*>(out + ((size_t)t * a.C + c0 + c) * a.M_pad + m0 + mch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+// C == 4 (the stem's padded hi plane): one thread per (tap, pixel), four output rows
+__global__ __launch_bounds__(kBlock) void k_transpose_gather_c4(const uint2* __restrict__ x, uint16_t* __restrict__ out,
+                                                                const GatherArgs a) {
+  const long long m = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const int t = blockIdx.y;
+  if (m >= a.M_pad) return;
+  uint2 v = make_uint2(0, 0);
+  if (m < a.M) {
+    const int ox = (int)(m % a.grid_w);
+    const long long q = m / a.grid_w;
+    const int oy = (int)(q % a.grid_h), img = (int)(q / a.grid_h);
+    const int iy = oy * a.sy + a.tap_dy[t], ix = ox * a.sx + a.tap_dx[t];
+    if ((unsigned)iy < (unsigned)a.src_h && (unsigned)ix < (unsigned)a.src_w)
+      v = x[((size_t)img * a.src_h + iy) * a.src_w + ix];
+  }
+  uint16_t* o = out + (size_t)t * 4 * a.M_pad + m;
+  o[0] = (uint16_t)(v.x & 0xFFFF);
+  o[a.M_pad] = (uint16_t)(v.x >> 16);
+  o[2 * a.M_pad] = (uint16_t)(v.y & 0xFFFF);
+  o[3 * a.M_pad] = (uint16_t)(v.y >> 16);
+}
+
+// ---- split-K reduce: grad[n][c][t] (torch [N][C][R][S], t = r*S + s) (+)= sum_z partial[z][(t*Cp + c)][n]
+__global__ __launch_bounds__(kBlock) void k_wgrad_reduce(const float* __restrict__ partial, int splits, int taps, int C,
+                                                         int Cp, int N, int ldn, float* __restrict__ grad, int accumulate) {
+  const size_t total = (size_t)N * C * taps;
+  const size_t zstride = (size_t)taps * Cp * ldn;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    // consecutive threads walk n fastest so the partial reads are coalesced
+    const int n = (int)(i % N);
+    const size_t q = i / N;
+    const int c = (int)(q % C), t = (int)(q / C);
+    const float* p = partial + ((size_t)t * Cp + c) * ldn + n;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += p[(size_t)z * zstride];
+    float* g = grad + ((size_t)n * C + c) * taps + t;
+    *g = accumulate ? *g + s : s;
+  }
+}
+
+// ---- fp32 master weights [N][C][R][S] -> bf16 igemm tables
+//   transpose == 0: out[n][k], k = ti*C + c          (forward; rows padded to rows_pad with zeros)
+//   transpose == 1: out[c][k], k = ti*N + n          (backward to input)
+// tap list: (r, s) pairs, ti enumerates them.
+struct PackArgs {
+  int N, C, R, S, n_taps, transpose, rows_pad;
+  int tap_r[49], tap_s[49];
+};
+__global__ __launch_bounds__(kBlock) void k_pack_weight(const float* __restrict__ w, uint16_t* __restrict__ out,
+                                                        const PackArgs a) {
+  const int inner = a.transpose ? a.N : a.C;
+  const size_t K = (size_t)a.n_taps * inner;
+  const size_t total = (size_t)a.rows_pad * K;
+  const int rows = a.transpose ? a.C : a.N;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int row = (int)(i / K);
+    const size_t k = i % K;
+    const int ti = (int)(k / inner), in = (int)(k % inner);
+    float v = 0.f;
+    if (row < rows) {
+      const int n = a.transpose ? in : row, c = a.transpose ? row : in;
+      v = w[(((size_t)n * a.C + c) * a.R + a.tap_r[ti]) * a.S + a.tap_s[ti]];
+    }
+    out[i] = (uint16_t)f2bf(v);
+  }
+}
+
+inline unsigned grid_for(size_t n) {
+  size_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > 256u * 32u) b = 256u * 32u;
+  return (unsigned)b;
+}
+inline int chunks_for(size_t M, int C, size_t* rows_per_chunk) {
+  // ~2048 workgroups, each at least one pass of its row lanes
+  const size_t rows_par = (size_t)(kBlock / (C / 8));
+  size_t chunks = 2048;
+  size_t rpc = (M + chunks - 1) / chunks;
+  if (rpc < rows_par * 4) rpc = rows_par * 4;
+  chunks = (M + rpc - 1) / rpc;
+  *rows_per_chunk = rpc;
+  return (int)chunks;
+}
+}  // namespace
+
+extern "C" size_t rart_bn_workspace_bytes(size_t rows, int channels) {
+  if (channels < 8 || channels % 8 != 0 || channels > 2048) return 0;
+  size_t rpc;
+  const int chunks = chunks_for(rows, channels, &rpc);
+  return (size_t)chunks * 2 * channels * sizeof(float);
+}
+
+extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, size_t rows, int channels,
+                                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                          double momentum, double eps, int relu, float* mean_out, float* invstd_out,
+                                          float* scale_shift /* [2][channels] */, void* workspace, size_t workspace_bytes,
+                                          rart_stream_t stream) {
+  RART_CHECK_ARG(z && y && gamma && beta && mean_out && invstd_out && scale_shift && rows > 1,
+                 "rart_bn_train_forward_bf16: null pointer or fewer than 2 rows");
+  RART_CHECK_ARG(channels >= 8 && channels % 8 == 0 && channels <= 2048 && 2048 % channels == 0,
+                 "rart_bn_train_forward_bf16: channels must be a power of two in [8, 2048]");
+  const size_t need = rart_bn_workspace_bytes(rows, channels);
+  if (!workspace || workspace_bytes < need) {
+    rart_set_error("rart_bn_train_forward_bf16: workspace of %zu bytes required", need);
+    return RART_ERR_WORKSPACE;
+  }
+  size_t rpc;
+  const int chunks = chunks_for(rows, channels, &rpc);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_colsum2<0>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
+                     rows, channels, rpc, (float*)workspace);
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + 63) / 64), dim3(64), 0, st, (const float*)workspace, chunks,
+                     channels, 1.0 / (double)rows, (double)rows / (double)(rows - 1), gamma, beta, (float)eps,
+                     (float)momentum, running_mean, running_var, mean_out, invstd_out, scale_shift,
+                     scale_shift + channels);
+  const size_t n8 = rows * (size_t)(channels / 8);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n8)), dim3(kBlock), 0, st, (const uint4*)z, (const uint4*)res, (uint4*)y,
+                     n8, channels / 8, scale_shift, scale_shift + channels, relu);
+  RART_CHECK_LAUNCH("rart_bn_train_forward_bf16");
+  return RART_OK;
+}
+
+extern "C" int rart_bn_train_backward_bf16(const void* dy, const void* ymask, const void* z, void* dz, void* g_out,
+                                           size_t rows, int channels, const float* gamma, const float* mean,
+                                           const float* invstd, float* dgamma, float* dbeta, int accumulate,
+                                           float* coef /* [3][channels] scratch */, void* workspace,
+                                           size_t workspace_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(dy && z && dz && gamma && mean && invstd && dgamma && dbeta && coef && rows > 0,
+                 "rart_bn_train_backward_bf16: null pointer");
+  RART_CHECK_ARG(channels >= 8 && channels % 8 == 0 && channels <= 2048 && 2048 % channels == 0,
+                 "rart_bn_train_backward_bf16: channels must be a power of two in [8, 2048]");
+  const size_t need = rart_bn_workspace_bytes(rows, channels);
+  if (!workspace || workspace_bytes < need) {
+    rart_set_error("rart_bn_train_backward_bf16: workspace of %zu bytes required", need);
+    return RART_ERR_WORKSPACE;
+  }
+  size_t rpc;
+  const int chunks = chunks_for(rows, channels, &rpc);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_colsum2<1>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, (const uint4*)dy,
+                     (const uint4*)ymask, mean, invstd, rows, channels, rpc, (float*)workspace);
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((channels + 63) / 64), dim3(64), 0, st, (const float*)workspace, chunks,
+                     channels, 1.0 / (double)rows, gamma, invstd, dgamma, dbeta, accumulate, coef);
+  const size_t n8 = rows * (size_t)(channels / 8);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n8)), dim3(kBlock), 0, st, (const uint4*)dy, (const uint4*)ymask,
+                     (const uint4*)z, (uint4*)dz, (uint4*)g_out, n8, channels / 8, channels, mean, invstd, coef);
+  RART_CHECK_LAUNCH("rart_bn_train_backward_bf16");
+  return RART_OK;
+}
+
+extern "C" int rart_transpose_gather_bf16(const void* src, void* dst, int batch, int src_h, int src_w, int channels,
+                                          int grid_h, int grid_w, int sy, int sx, int n_taps, const int* tap_dy,
+                                          const int* tap_dx, long long rows_padded, rart_stream_t stream) {
+  RART_CHECK_ARG(src && dst && batch > 0 && grid_h > 0 && grid_w > 0 && tap_dy && tap_dx,
+                 "rart_transpose_gather_bf16: bad arguments");
+  RART_CHECK_ARG(n_taps >= 1 && n_taps <= 49, "rart_transpose_gather_bf16: 1..49 taps");
+  RART_CHECK_ARG(channels == 4 || channels % 8 == 0, "rart_transpose_gather_bf16: channels must be 4 or a multiple of 8");
+  GatherArgs a;
+  a.batch = batch; a.src_h = src_h; a.src_w = src_w; a.C = channels; a.grid_h = grid_h; a.grid_w = grid_w;
+  a.sy = sy; a.sx = sx; a.n_taps = n_taps;
+  for (int i = 0; i < n_taps; ++i) { a.tap_dy[i] = tap_dy[i]; a.tap_dx[i] = tap_dx[i]; }
+  a.M = (long long)batch * grid_h * grid_w;
+  a.M_pad = rows_padded;
+  RART_CHECK_ARG(a.M_pad >= a.M && a.M_pad % 64 == 0, "rart_transpose_gather_bf16: rows_padded must be >= rows and a multiple of 64");
+  hipStream_t st = (hipStream_t)stream;
+  if (channels == 4)
+    hipLaunchKernelGGL(k_transpose_gather_c4, dim3((unsigned)((a.M_pad + kBlock - 1) / kBlock), n_taps), dim3(kBlock), 0, st,
+                       (const uint2*)src, (uint16_t*)dst, a);
+  else
+    hipLaunchKernelGGL(k_transpose_gather, dim3((unsigned)(a.M_pad / 64), (channels + 63) / 64, n_taps), dim3(kBlock), 0, st,
+                       (const uint16_t*)src, (uint16_t*)dst, a);
+  RART_CHECK_LAUNCH("rart_transpose_gather_bf16");
+  return RART_OK;
+}
+
+extern "C" int rart_wgrad_reduce_f32(const float* partial, int splits, int taps, int channels, int channels_padded,
+                                     int n_out, int ld_n, float* grad, int accumulate, rart_stream_t stream) {
+  RART_CHECK_ARG(partial && grad && splits >= 1 && taps >= 1 && channels >= 1 && channels_padded >= channels &&
+                     n_out >= 1 && ld_n >= n_out, "rart_wgrad_reduce_f32: bad arguments");
+  const size_t total = (size_t)n_out * channels * taps;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, partial, splits, taps,
+                     channels, channels_padded, n_out, ld_n, grad, accumulate);
+  RART_CHECK_LAUNCH("rart_wgrad_reduce_f32");
+  return RART_OK;
+}
+
+extern "C" int rart_pack_conv_weight_bf16(const float* weight, void* out, int n_out, int channels, int r, int s, int n_taps,
+                                          const int* tap_r, const int* tap_s, int transpose, int rows_padded,
+                                          rart_stream_t stream) {
+  RART_CHECK_ARG(weight && out && n_out > 0 && channels > 0 && r > 0 && s > 0 && tap_r && tap_s,
+                 "rart_pack_conv_weight_bf16: bad arguments");
+  RART_CHECK_ARG(n_taps >= 1 && n_taps <= 49, "rart_pack_conv_weight_bf16: 1..49 taps");
+  RART_CHECK_ARG(rows_padded >= (transpose ? channels : n_out), "rart_pack_conv_weight_bf16: rows_padded too small");
+  PackArgs a;
+  a.N = n_out; a.C = channels; a.R = r; a.S = s; a.n_taps = n_taps; a.transpose = transpose; a.rows_pad = rows_padded;
+  for (int i = 0; i < n_taps; ++i) {
+    RART_CHECK_ARG(tap_r[i] >= 0 && tap_r[i] < r && tap_s[i] >= 0 && tap_s[i] < s, "rart_pack_conv_weight_bf16: tap outside the filter");
+    a.tap_r[i] = tap_r[i]; a.tap_s[i] = tap_s[i];
+  }
+  const size_t total = (size_t)rows_padded * n_taps * (transpose ? n_out : channels);
+  hipLaunchKernelGGL(k_pack_weight, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, weight, (uint16_t*)out, a);
+  RART_CHECK_LAUNCH("rart_pack_conv_weight_bf16");
+  return RART_OK;
+}

@@ -1,0 +1,378 @@
+"""Train-mode ResNet-50 on the HIP kernels: forward with batch statistics, backward to every parameter.
+
+The training step of the reference's solver (RobustART/train/__init__.py:1 -> absent `prototype` cls_solver;
+loop shape: cifar10/code/train.py:96-127; config exprs/nips_benchmark/pgd_adv_train/resnet50/config.yaml) for
+`resnet50_official`: conv -> BatchNorm(batch statistics) -> ReLU bottlenecks, label-smoothed CE, gradients of all
+25.6 M parameters.  PyTorch here is plumbing only (buffers, parameter storage); every FLOP and every pass over
+an activation is a HIP kernel:
+
+  contraction (forward conv, backward-to-input, weight gradient, fc)   rart_conv_igemm_bf16
+  batch statistics / normalise+ReLU+residual / BatchNorm backward        rart_bn_train_forward_bf16 / _backward_bf16
+  K-contiguous operands of the weight-gradient GEMM                      rart_transpose_gather_bf16
+  split-K partial sums -> torch weight layout                            rart_wgrad_reduce_f32
+  fp32 master weights -> bf16 igemm tables (after every optimizer step)  rart_pack_conv_weight_bf16
+
+Gradients are written straight into the parameters' `.grad` tensors (views of the flat gradient arena,
+train/arena.py); `on_grad_ready(param)` lets the arena launch a bucket's all-reduce as soon as its last gradient
+exists, so the exchange overlaps the rest of the backward pass.
+"""
+import ctypes
+
+from .. import _lib
+from .engine import F_OUT_F32, _rows_mult
+
+
+def _ints(vals):
+    return (ctypes.c_int * max(len(vals), 1))(*vals)
+
+
+class _TConv:
+    """One conv (+ its BatchNorm) in training mode: packed tables, saved activations, geometry."""
+
+    def __init__(self, conv, bn, device, torch):
+        self.conv, self.bn = conv, bn
+        self.cout, self.cin, self.r, self.s = conv.weight.shape
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.fwd_taps = [(r - self.pad, s - self.pad) for r in range(self.r) for s in range(self.s)]
+        self.all_rs = [(r, s) for r in range(self.r) for s in range(self.s)]
+        bf = torch.bfloat16
+        self.w_fwd = torch.zeros((self.cout + _rows_mult(self.cout) - 1) // _rows_mult(self.cout) * _rows_mult(self.cout),
+                                 self.r * self.s * self.cin, dtype=bf, device=device)
+        rm = _rows_mult(self.cin)
+        rows_b = (self.cin + rm - 1) // rm * rm
+        self.bwd = []        # (parity or None, taps [(dy,dx)], rs list, table)
+        if self.stride == 1:
+            taps = [(self.pad - r, self.pad - s) for r, s in self.all_rs]
+            self.bwd.append((None, taps, self.all_rs, torch.zeros(rows_b, len(taps) * self.cout, dtype=bf, device=device)))
+        else:
+            for ph in range(2):
+                for pw in range(2):
+                    rs = [(r, s) for r, s in self.all_rs if (ph + self.pad - r) % 2 == 0 and (pw + self.pad - s) % 2 == 0]
+                    taps = [((ph + self.pad - r) // 2, (pw + self.pad - s) // 2) for r, s in rs]
+                    tab = torch.zeros(rows_b, len(taps) * self.cout, dtype=bf, device=device) if rs else None
+                    self.bwd.append(((ph, pw), taps, rs, tab))
+        if bn is not None:
+            self.mean = torch.empty(self.cout, dtype=torch.float32, device=device)
+            self.invstd = torch.empty(self.cout, dtype=torch.float32, device=device)
+            self.scale_shift = torch.empty(2, self.cout, dtype=torch.float32, device=device)
+
+    def repack(self, lib, sp):
+        w = self.conv.weight
+        assert w.dtype.is_floating_point and w.is_contiguous()
+        wf = w.detach().float() if str(w.dtype) != 'torch.float32' else w.detach()
+        rs = self.all_rs
+        _lib.check(lib.rart_pack_conv_weight_bf16(wf.data_ptr(), self.w_fwd.data_ptr(), self.cout, self.cin, self.r, self.s,
+                                                  len(rs), _ints([a for a, _ in rs]), _ints([b for _, b in rs]), 0,
+                                                  self.w_fwd.shape[0], sp))
+        for parity, taps, prs, tab in self.bwd:
+            if tab is None:
+                continue
+            _lib.check(lib.rart_pack_conv_weight_bf16(wf.data_ptr(), tab.data_ptr(), self.cout, self.cin, self.r, self.s,
+                                                      len(prs), _ints([a for a, _ in prs]), _ints([b for _, b in prs]), 1,
+                                                      tab.shape[0], sp))
+
+
+class ResNet50TrainEngine:
+    def __init__(self, model, device='cuda', on_grad_ready=None, bn_momentum=None):
+        torch = _lib.require_gpu()
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.model = model
+        self.on_grad_ready = on_grad_ready or (lambda p: None)
+        m, dev = model, self.device
+        self.stem = _TConv(m.conv1, m.bn1, dev, torch)
+        self.stem_w = torch.zeros(64, 2 * 7 * 32, dtype=torch.bfloat16, device=dev)
+        self.blocks = []
+        for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
+            for blk in layer:
+                ds = _TConv(blk.downsample[0], blk.downsample[1], dev, torch) if blk.downsample is not None else None
+                self.blocks.append((_TConv(blk.conv1, blk.bn1, dev, torch), _TConv(blk.conv2, blk.bn2, dev, torch),
+                                    _TConv(blk.conv3, blk.bn3, dev, torch), ds))
+        self.n_classes, self.fc_in = m.fc.weight.shape
+        self.fc_kpad = (self.n_classes + 127) // 128 * 128
+        self.fc_w = torch.zeros(self.fc_kpad, self.fc_in, dtype=torch.bfloat16, device=dev)      # [1024][2048]
+        self.fc_wd = torch.zeros(self.fc_in, self.fc_kpad, dtype=torch.bfloat16, device=dev)     # [2048][1024]
+        self._buf = {}
+        self.repack()
+
+    # ------------------------------------------------------------------ tables
+    def repack(self):
+        """fp32 master weights -> bf16 igemm tables; call after every optimizer step."""
+        torch, sp = self.torch, _lib.stream_ptr()
+        for c in [self.stem] + [c for blk in self.blocks for c in blk if c is not None]:
+            if c is not self.stem:
+                c.repack(self.lib, sp)
+        # stem forward table: a "tap" = one filter row of 8 px x 4 ch on the padded hi/lo planes (engine.py)
+        wb = self.model.conv1.weight.detach().float()
+        wrow = torch.zeros(64, 7, 8, 4, device=self.device)
+        wrow[:, :, :7, :3] = wb.permute(0, 2, 3, 1)
+        wrow = wrow.reshape(64, 224).to(torch.bfloat16)
+        self.stem_w[:, :224] = wrow
+        self.stem_w[:, 224:] = wrow
+        one = _ints([0])
+        w = self.model.fc.weight.detach()
+        _lib.check(self.lib.rart_pack_conv_weight_bf16(w.data_ptr(), self.fc_w.data_ptr(), self.n_classes, self.fc_in, 1, 1,
+                                                       1, one, one, 0, self.fc_kpad, sp))
+        # backward-to-input of the classifier: rows = features, K = classes padded to fc_kpad (row stride fc_kpad)
+        self.fc_wd[:, :self.n_classes] = w.t().to(torch.bfloat16)
+
+    # ------------------------------------------------------------------ helpers
+    def _get(self, name, shape, dtype=None, zero=False):
+        torch = self.torch
+        dtype = dtype or torch.bfloat16
+        key = (name, tuple(shape), dtype)      # gradient buffers are reused across stages with different shapes
+        t = self._buf.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._buf[key] = t
+        return t
+
+    def _scratch(self, name, nbytes):
+        t = self._buf.get(name)
+        if t is None or t.numel() < nbytes:
+            t = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def _gemm(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, res=None,
+              flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0), tap_src_off=None, bias=None, batched=None):
+        d = _lib.ConvDesc()
+        d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.res = res.data_ptr() if res is not None else None
+        d.mask = None
+        d.batch, d.grid_h, d.grid_w = batch, grid[0], grid[1]
+        d.src_h, d.src_w, d.src_pix_stride = src_hw[0], src_hw[1], src_pix
+        d.k_per_tap, d.n_taps = k_per_tap, len(taps)
+        d.sy, d.sx = stride
+        for i, (dy, dx) in enumerate(taps):
+            d.tap_dy[i], d.tap_dx[i] = dy, dx
+            d.tap_src_off[i] = tap_src_off[i] if tap_src_off is not None else 0
+        d.n_cols = n_cols
+        d.dst_h, d.dst_w = dst_hw
+        d.dst_sy, d.dst_sx = dst_stride
+        d.dst_oy, d.dst_ox = dst_off
+        d.dst_pix_stride = dst_pix
+        d.flags = flags
+        if batched is not None:
+            d.n_batched, d.z_inner = batched['n'], batched['n']
+            d.src_z_outer, d.src_z_inner = 0, batched['src']
+            d.wgt_z_outer, d.wgt_z_inner = 0, batched['wgt']
+            d.dst_z_outer, d.dst_z_inner = 0, batched['dst']
+            d.wgt_row_stride = batched['wgt_row_stride']
+        _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _conv_fwd(self, c, x, xhw, out):
+        B = x.shape[0]
+        oh, ow = xhw[0] // c.stride, xhw[1] // c.stride
+        self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
+                   stride=(c.stride, c.stride))
+
+    def _conv_dgrad(self, c, dz, dz_hw, dx, dx_hw, res=None):
+        B = dz.shape[0]
+        first = True
+        for parity, taps, rs, w in c.bwd:
+            if parity is None:
+                self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res)
+            else:
+                ph, pw = parity
+                if not taps:
+                    continue
+                self._gemm(dz, w, dx, B, (dx_hw[0] // 2, dx_hw[1] // 2), dz_hw, c.cout, c.cout, taps, c.cin, dx_hw,
+                           c.cin, res=res, dst_stride=(2, 2), dst_off=(ph, pw))
+            first = False
+        return first
+
+    def _bn_fwd(self, c, z, y, rows, relu, res=None):
+        lib, bn = self.lib, c.bn
+        need = lib.rart_bn_workspace_bytes(rows, c.cout)
+        ws = self._scratch('bn_ws', need)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        _lib.check(lib.rart_bn_train_forward_bf16(
+            z.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(), rows, c.cout, bn.weight.data_ptr(),
+            bn.bias.data_ptr(), bn.running_mean.data_ptr() if bn.track_running_stats else None,
+            bn.running_var.data_ptr() if bn.track_running_stats else None, mom, bn.eps, 1 if relu else 0,
+            c.mean.data_ptr(), c.invstd.data_ptr(), c.scale_shift.data_ptr(), ws.data_ptr(), need, _lib.stream_ptr()))
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+
+    def _bn_bwd(self, c, dy, ymask, z, dz, rows, g_out=None):
+        lib, bn = self.lib, c.bn
+        need = lib.rart_bn_workspace_bytes(rows, c.cout)
+        ws = self._scratch('bn_ws', need)
+        coef = self._get('bn_coef', (3, 2048), self.torch.float32)
+        _lib.check(lib.rart_bn_train_backward_bf16(
+            dy.data_ptr(), ymask.data_ptr() if ymask is not None else None, z.data_ptr(), dz.data_ptr(),
+            g_out.data_ptr() if g_out is not None else None, rows, c.cout, bn.weight.data_ptr(), c.mean.data_ptr(),
+            c.invstd.data_ptr(), bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), 0, coef.data_ptr(), ws.data_ptr(),
+            need, _lib.stream_ptr()))
+        self.on_grad_ready(bn.weight)
+        self.on_grad_ready(bn.bias)
+
+    def _wgrad(self, dz, n_out, n_pad_cols, x, x_hw, x_c, grid_hw, taps, stride, grad, r_s_count, c_valid=None):
+        """grad[n_out][c][taps] = sum_m dz[m][n] * x[pixel(m) + tap][c] as a split-K GEMM on the igemm kernel.
+        dz: bf16 [B, gh, gw, n_pad_cols] (columns >= n_out are zero); x: bf16 [B, ih, iw, x_c]."""
+        torch, lib, sp = self.torch, self.lib, _lib.stream_ptr()
+        B = dz.shape[0]
+        gh, gw = grid_hw
+        M = B * gh * gw
+        kp = len(taps) * x_c                                   # rows of the transposed im2col matrix
+        bn_tile = 128 if n_pad_cols > 64 else 64
+        tiles = ((kp + 127) // 128) * ((n_pad_cols + bn_tile - 1) // bn_tile)
+        splits = max(1, min(1024 // max(tiles, 1), M // 512 if M >= 1024 else 1, 256))
+        chunk = ((M + splits - 1) // splits + 63) // 64 * 64
+        m_pad = chunk * splits
+        n_rows = (n_pad_cols + bn_tile - 1) // bn_tile * bn_tile
+        dzt = self._scratch('wg_dzT', n_rows * m_pad * 2)
+        colt = self._scratch('wg_colT', kp * m_pad * 2)
+        zero = _ints([0])
+        # rows of dzT beyond n_pad_cols belong to the igemm's tile padding: keep them zero
+        if n_rows > n_pad_cols:
+            dzt[n_pad_cols * m_pad * 2:n_rows * m_pad * 2].zero_()
+        _lib.check(lib.rart_transpose_gather_bf16(dz.data_ptr(), dzt.data_ptr(), B, gh, gw, n_pad_cols, gh, gw, 1, 1, 1,
+                                                  zero, zero, m_pad, sp))
+        _lib.check(lib.rart_transpose_gather_bf16(x.data_ptr(), colt.data_ptr(), B, x_hw[0], x_hw[1], x_c, gh, gw,
+                                                  stride, stride, len(taps), _ints([t[0] for t in taps]),
+                                                  _ints([t[1] for t in taps]), m_pad, sp))
+        ld_n = (n_pad_cols + 7) // 8 * 8
+        part = self._scratch('wg_part', splits * kp * ld_n * 4)
+        self._gemm(colt, dzt, part, 1, (1, kp), (1, kp), m_pad, chunk, [(0, 0)], ld_n, (1, kp), ld_n, flags=F_OUT_F32,
+                   batched={'n': splits, 'src': chunk, 'wgt': chunk, 'dst': kp * ld_n, 'wgrad': True,
+                            'wgt_row_stride': m_pad})
+        cv = c_valid if c_valid is not None else x_c
+        _lib.check(lib.rart_wgrad_reduce_f32(part.data_ptr(), splits, len(taps), cv, x_c, n_out, ld_n, grad.data_ptr(), 0,
+                                             sp))
+
+    def _conv_wgrad(self, c, dz, dz_hw, x, x_hw):
+        self._wgrad(dz, c.cout, c.cout, x, x_hw, c.cin, dz_hw, c.fwd_taps, c.stride, c.conv.weight.grad, c.r * c.s)
+        self.on_grad_ready(c.conv.weight)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, src, src_is_u8, mean, std):
+        torch, lib, sp = self.torch, self.lib, _lib.stream_ptr()
+        if src_is_u8:
+            B, H, W = src.shape[0], src.shape[1], src.shape[2]
+        else:
+            src = src.detach().float().contiguous()
+            B, H, W = src.shape[0], src.shape[2], src.shape[3]
+        assert H % 32 == 0 and W % 32 == 0
+        hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
+        _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]), B, H, W,
+                                              (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), sp))
+        h1, w1 = H // 2, W // 2
+        z1 = self._get('z1', (B, h1, w1, 64))
+        y1 = self._get('y1', (B, h1, w1, 64))
+        lo_off = (hi[1].data_ptr() - hi[0].data_ptr()) // 2
+        self._gemm(hi[0], self.stem_w, z1, B, (h1, w1), (H + 8, W + 8), 4, 32, [(r, 0) for r in range(7)] * 2, 64, (h1, w1),
+                   64, stride=(2, 2), tap_src_off=[0] * 7 + [lo_off] * 7)
+        self._bn_fwd(self.stem, z1, y1, B * h1 * w1, True)
+        h2, w2 = h1 // 2, w1 // 2
+        p1 = self._get('p1', (B, h2, w2, 64))
+        parg = self._get('p1_argmax', (B, h2, w2, 64), torch.uint8)
+        _lib.check(lib.rart_engine_maxpool(_lib.ptr(y1), _lib.ptr(p1), _lib.ptr(parg), B, h1, w1, 64, sp))
+        acts = {'hi': hi, 'z1': z1, 'y1': y1, 'p1': p1, 'parg': parg, 'in_shape': (B, H, W)}
+        x, xhw = p1, (h2, w2)
+        for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
+            ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
+            za = self._get('b%d_za' % bi, (B, xhw[0], xhw[1], ca.cout))
+            ya = self._get('b%d_ya' % bi, (B, xhw[0], xhw[1], ca.cout))
+            zb = self._get('b%d_zb' % bi, (B, ohw[0], ohw[1], cb.cout))
+            yb = self._get('b%d_yb' % bi, (B, ohw[0], ohw[1], cb.cout))
+            zc = self._get('b%d_zc' % bi, (B, ohw[0], ohw[1], cc.cout))
+            out = self._get('b%d_out' % bi, (B, ohw[0], ohw[1], cc.cout))
+            self._conv_fwd(ca, x, xhw, za)
+            self._bn_fwd(ca, za, ya, B * xhw[0] * xhw[1], True)
+            self._conv_fwd(cb, ya, xhw, zb)
+            rows_o = B * ohw[0] * ohw[1]
+            self._bn_fwd(cb, zb, yb, rows_o, True)
+            self._conv_fwd(cc, yb, ohw, zc)
+            zd = None
+            if ds is not None:
+                zd = self._get('b%d_zd' % bi, (B, ohw[0], ohw[1], cc.cout))
+                sk = self._get('b%d_sk' % bi, (B, ohw[0], ohw[1], cc.cout))
+                self._conv_fwd(ds, x, xhw, zd)
+                self._bn_fwd(ds, zd, sk, rows_o, False)
+            else:
+                sk = x
+            self._bn_fwd(cc, zc, out, rows_o, True, res=sk)
+            acts['b%d' % bi] = (x, xhw, za, ya, zb, yb, zc, zd, out, ohw)
+            x, xhw = out, ohw
+        pooled = self._get('pooled', (B, self.fc_in))
+        _lib.check(lib.rart_engine_avgpool(_lib.ptr(x), _lib.ptr(pooled), B, xhw[0] * xhw[1], self.fc_in, sp))
+        logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
+        self._gemm(pooled, self.fc_w, logits, B, (1, 1), (1, 1), self.fc_in, self.fc_in, [(0, 0)], self.n_classes, (1, 1),
+                   self.n_classes, bias=self.model.fc.bias.detach(), flags=F_OUT_F32)
+        acts['last'], acts['pooled'] = (x, xhw), pooled
+        self.acts = acts
+        return logits
+
+    # ------------------------------------------------------------------ backward to every parameter
+    def backward(self, dlogits):
+        """dlogits: fp32 [B][classes] = d(loss)/dlogits.  Fills .grad of every parameter (overwrites)."""
+        torch, lib, sp, acts = self.torch, self.lib, _lib.stream_ptr(), self.acts
+        B, H, W = acts['in_shape']
+        fc = self.model.fc
+        dl = dlogits.detach().float().contiguous()
+        fc.bias.grad.copy_(dl.sum(0))
+        self.on_grad_ready(fc.bias)
+        dlb = self._get('dl_bf16', (B, self.fc_kpad))
+        _lib.check(lib.rart_f32_to_bf16_rows(_lib.ptr(dl), _lib.ptr(dlb), B, self.n_classes, self.fc_kpad, sp))
+        pooled = acts['pooled']
+        # classifier weight gradient: [classes][features] = dl^T . pooled  (1x1 "conv" over B pixels)
+        self._wgrad(dlb.view(B, 1, 1, self.fc_kpad), self.n_classes, self.fc_kpad, pooled.view(B, 1, 1, self.fc_in), (1, 1),
+                    self.fc_in, (1, 1), [(0, 0)], 1, fc.weight.grad, 1)
+        self.on_grad_ready(fc.weight)
+        dpool = self._get('dpool', (B, self.fc_in))
+        self._gemm(dlb, self.fc_wd, dpool, B, (1, 1), (1, 1), self.fc_kpad, self.fc_kpad, [(0, 0)], self.fc_in, (1, 1),
+                   self.fc_in)
+        xl, xlhw = acts['last']
+        d_out = self._get('g_out_a', tuple(xl.shape))
+        _lib.check(lib.rart_engine_avgpool_bwd(_lib.ptr(xl), _lib.ptr(dpool), _lib.ptr(d_out), B, xlhw[0] * xlhw[1],
+                                               self.fc_in, sp))
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            ca, cb, cc, ds = self.blocks[bi]
+            x, xhw, za, ya, zb, yb, zc, zd, out, ohw = acts['b%d' % bi]
+            rows_o, rows_i = B * ohw[0] * ohw[1], B * xhw[0] * xhw[1]
+            dzc = self._get('g_zc', tuple(zc.shape))
+            g = self._get('g_skip', tuple(zc.shape))
+            self._bn_bwd(cc, d_out, out, zc, dzc, rows_o, g_out=g)
+            self._conv_wgrad(cc, dzc, ohw, yb, ohw)
+            dyb = self._get('g_yb', tuple(yb.shape))
+            self._conv_dgrad(cc, dzc, ohw, dyb, ohw)
+            dzb = self._get('g_zb', tuple(zb.shape))
+            self._bn_bwd(cb, dyb, yb, zb, dzb, rows_o)
+            self._conv_wgrad(cb, dzb, ohw, ya, xhw)
+            dya = self._get('g_ya', tuple(ya.shape))
+            if cb.stride == 2:
+                dya.zero_()                      # parity classes without taps receive no gradient
+            self._conv_dgrad(cb, dzb, ohw, dya, xhw)
+            dza = self._get('g_za', tuple(za.shape))
+            self._bn_bwd(ca, dya, ya, za, dza, rows_i)
+            self._conv_wgrad(ca, dza, xhw, x, xhw)
+            dx = self._get('g_x_%d' % (bi % 2), tuple(x.shape))
+            if ds is None:
+                self._conv_dgrad(ca, dza, xhw, dx, xhw, res=g)
+            else:
+                self._conv_dgrad(ca, dza, xhw, dx, xhw)
+                dzd = self._get('g_zd', tuple(zd.shape))
+                self._bn_bwd(ds, g, None, zd, dzd, rows_o)
+                self._conv_wgrad(ds, dzd, ohw, x, xhw)
+                if ds.stride == 2:
+                    # a 1x1 stride-2 conv reaches only the even/even pixels: add its gradient there
+                    self._conv_dgrad(ds, dzd, ohw, dx, xhw, res=dx)
+                else:
+                    self._conv_dgrad(ds, dzd, ohw, dx, xhw, res=dx)
+            d_out = dx
+        # stem: max-pool backward (applies y1's ReLU mask), BatchNorm backward, weight gradient on the padded hi plane
+        y1, z1 = acts['y1'], acts['z1']
+        h1, w1 = H // 2, W // 2
+        dy1 = self._get('g_y1', tuple(y1.shape))
+        _lib.check(lib.rart_engine_maxpool_bwd(_lib.ptr(y1), _lib.ptr(acts['parg']), _lib.ptr(d_out), _lib.ptr(dy1), B, h1, w1,
+                                               64, sp))
+        dz1 = self._get('g_z1', tuple(z1.shape))
+        self._bn_bwd(self.stem, dy1, y1, z1, dz1, B * h1 * w1)
+        taps = [(r, s) for r in range(7) for s in range(7)]    # hi plane holds the image at offset (3, 3)
+        self._wgrad(dz1, 64, 64, acts['hi'][0], (H + 8, W + 8), 4, (h1, w1), taps, 2, self.model.conv1.weight.grad, 49,
+                    c_valid=3)
+        self.on_grad_ready(self.model.conv1.weight)

@@ -69,6 +69,9 @@ class ParamArena:
         self._handles = []
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._hooks = []
+        self.overlap = overlap
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self.autograd_hooks = True
         if self.world > 1 and overlap:      # dist.sync: True -> every bucket is reduced after backward instead
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -82,6 +85,13 @@ class ParamArena:
                 lo, hi, _ = self.buckets[b]
                 self._handles.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         return hook
+
+    def grad_ready(self, param):
+        """Same bookkeeping as the autograd hook, for gradients produced outside autograd (the HIP train engine)."""
+        if self.world > 1 and self.overlap:
+            i = self._index.get(id(param))
+            if i is not None:
+                self._make_hook(i)(param)
 
     def finish_grad_exchange(self):
         """Wait for the bucket all-reduces launched during backward; buckets whose parameters produced no gradient
