@@ -347,15 +347,19 @@ int rart_bn_train_backward_bf16(const void* dy, const void* ymask, const void* z
                                 int channels, const float* gamma, const float* mean, const float* invstd, float* dgamma,
                                 float* dbeta, int accumulate, float* coef, void* workspace, size_t workspace_bytes,
                                 rart_stream_t stream);
-/* dst[(t*channels + c)][m] = src[img(m), oy*sy + tap_dy[t], ox*sx + tap_dx[t], c] for m < batch*grid_h*grid_w, zero
- * outside the image and for the padding rows up to rows_padded (multiple of 64): the K(=pixel)-contiguous operand
- * layout of the weight-gradient GEMM.  channels: 4 (stem's padded plane) or a multiple of 8. */
+/* T[(t*channels + c)][m] = src[img(m), oy*sy + tap_dy[t], ox*sx + tap_dx[t], c] for m < batch*grid_h*grid_w, zero
+ * outside the image and for the padding up to rows_padded (multiple of 64): the K(=pixel)-contiguous operand of the
+ * weight-gradient GEMM.  Stored as one compact slab per K split, dst[m / chunk][row][m % chunk] with rows_total rows
+ * per slab (chunk 0 = a single slab; rows_total 0 = taps*channels): a split then touches a few MB instead of one
+ * 128-byte piece from each of hundreds of multi-MB rows (TLB / DRAM-page locality).
+ * channels: 4 (stem's padded plane) or a multiple of 8. */
 int rart_transpose_gather_bf16(const void* src, void* dst, int batch, int src_h, int src_w, int channels, int grid_h,
                                int grid_w, int sy, int sx, int n_taps, const int* tap_dy, const int* tap_dx,
-                               long long rows_padded, rart_stream_t stream);
+                               long long rows_padded, int chunk, int rows_total, rart_stream_t stream);
 /* grad[n][c][t] (torch conv weight layout, t = r*S + s) (+)= sum_z partial[z][t*channels_padded + c][n];
- * partial: fp32 [splits][taps*channels_padded][ld_n], the split-K output of rart_conv_igemm_bf16. */
-int rart_wgrad_reduce_f32(const float* partial, int splits, int taps, int channels, int channels_padded, int n_out,
+ * partial: fp32 [splits][taps*channels_padded][ld_n], the split-K output of rart_conv_igemm_bf16; it is scratch:
+ * more than 16 splits are first folded 16:1 in place. */
+int rart_wgrad_reduce_f32(float* partial, int splits, int taps, int channels, int channels_padded, int n_out,
                           int ld_n, float* grad, int accumulate, rart_stream_t stream);
 /* fp32 master weight [n_out][channels][r][s] -> bf16 igemm table over the listed taps:
  * transpose 0: out[n][ti*channels + c] (forward), 1: out[c][ti*n_out + n] (backward to input); rows zero-padded. */

@@ -119,12 +119,17 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   const uint32_t M = (uint32_t)(d.batch * d.grid_h * d.grid_w);   // host guarantees < 2^31
   const int m_tiles = (int)((M + BM - 1) / BM);
   int m_tile, n_tile;
-  {
+  if (m_tiles >= 16) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     m_tile = (slot / n_tiles) * 8 + xcd;
     n_tile = slot % n_tiles;
     if (m_tile >= m_tiles) return;
+  } else {
+    // few row tiles (split-K weight gradients, per-head attention products): the XCD remap would leave most XCDs
+    // idle (row tile i lives on XCD i & 7); plain order spreads the column tiles and the z batches over all of them
+    m_tile = blockIdx.x / n_tiles;
+    n_tile = blockIdx.x - m_tile * n_tiles;
   }
   const uint32_t m0 = (uint32_t)m_tile * BM;
   const int n0 = n_tile * BN;
@@ -485,7 +490,7 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   const bool wide = d.n_cols > 64;
   const int bn = wide ? 128 : 64;
   const int n_tiles = (d.n_cols + bn - 1) / bn;
-  const int m_tiles8 = (m_tiles + 7) / 8 * 8;  // the XCD remap enumerates row tiles in groups of 8
+  const int m_tiles8 = m_tiles >= 16 ? (m_tiles + 7) / 8 * 8 : m_tiles;  // the XCD remap enumerates row tiles in groups of 8
   const long long blocks = (long long)m_tiles8 * n_tiles;
   RART_CHECK_ARG(blocks < (1ll << 31), "rart_conv_igemm_bf16: grid too large");
   // K-deep problems take the BK = 64 pipeline (half the barriers per FLOP); shallow ones (K <= 128: the

@@ -112,19 +112,42 @@ __global__ __launch_bounds__(kBlock) void k_colsum2(const uint4* __restrict__ z,
   }
 }
 
-// forward finalise: one thread per channel
-__global__ void k_bn_finalize_fwd(const float* __restrict__ partial, int chunks, int C, double inv_m, double unbias,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                  float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                  float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                  float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s += (double)partial[((size_t)k * 2 + 0) * C + c];
-    q += (double)partial[((size_t)k * 2 + 1) * C + c];
+// Finalisers: 16 channels x 16 chunk lanes per 256-thread block (a single thread walking 2048 partials is a
+// 2048-deep chain of dependent-latency loads, ~0.5 ms per layer); fixed summation order -> deterministic.
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int chunks, int C, int c, int lane16,
+                                                double (*sh)[16][16], double& s, double& q) {
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int k = lane16; k < chunks; k += 16) {
+      a += (double)partial[((size_t)k * 2 + 0) * C + c];
+      b += (double)partial[((size_t)k * 2 + 1) * C + c];
+    }
   }
+  const int cl = threadIdx.x & 15;
+  sh[0][lane16][cl] = a;
+  sh[1][lane16][cl] = b;
+  __syncthreads();
+  s = q = 0.0;
+  if (lane16 == 0) {
+    for (int k = 0; k < 16; ++k) {
+      s += sh[0][k][cl];
+      q += sh[1][k][cl];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ partial, int chunks, int C, double inv_m,
+                                                         double unbias, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float momentum,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                         float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  __shared__ double sh[2][16][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  double s, q;
+  reduce_partials(partial, chunks, C, c, lane16, sh, s, q);
+  if (lane16 != 0 || c >= C) return;
   const double mu = s * inv_m;
   double var = q * inv_m - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -139,17 +162,15 @@ __global__ void k_bn_finalize_fwd(const float* __restrict__ partial, int chunks,
 }
 
 // backward finalise: dgamma / dbeta into the gradient arena, k1 = mean(g), k2 = mean(g*xhat), sg = gamma*invstd
-__global__ void k_bn_finalize_bwd(const float* __restrict__ partial, int chunks, int C, double inv_m,
-                                  const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                  float* __restrict__ coef /* [3][C]: k1, k2, gamma*invstd */) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s += (double)partial[((size_t)k * 2 + 0) * C + c];
-    q += (double)partial[((size_t)k * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ partial, int chunks, int C, double inv_m,
+                                                         const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                         float* __restrict__ coef /* [3][C]: k1, k2, gamma*invstd */) {
+  __shared__ double sh[2][16][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  double s, q;
+  reduce_partials(partial, chunks, C, c, lane16, sh, s, q);
+  if (lane16 != 0 || c >= C) return;
   if (accumulate) {
     dbeta[c] += (float)s;
     dgamma[c] += (float)q;
@@ -162,18 +183,27 @@ __global__ void k_bn_finalize_bwd(const float* __restrict__ partial, int chunks,
   coef[2 * C + c] = gamma[c] * invstd[c];
 }
 
+// The grid stride (gridDim.x * 256 vectors) is a multiple of the channel-group count (a power of two <= 256), so a
+// thread meets the same 8 channels in every iteration: its per-channel constants are loaded once, outside the loop.
 __global__ __launch_bounds__(kBlock) void k_bn_apply(const uint4* __restrict__ z, const uint4* __restrict__ res,
                                                      uint4* __restrict__ y, size_t n8, int c8n,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      int relu) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (size_t)gridDim.x * kBlock) {
-    const int cg = (int)(i % c8n);
+  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const int cg = (int)(i0 & (size_t)(c8n - 1));
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[cg * 8 + j];
+    sh[j] = shift[cg * 8 + j];
+  }
+  for (size_t i = i0; i < n8; i += (size_t)gridDim.x * kBlock) {
     float zf[8], rf[8];
     unpack8(z[i], zf);
     if (res) unpack8(res[i], rf);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = fmaf(zf[j], scale[cg * 8 + j], shift[cg * 8 + j]);
+      float v = fmaf(zf[j], sc[j], sh[j]);
       if (res) v += rf[j];
       if (relu) v = fmaxf(v, 0.f);
       zf[j] = v;
@@ -187,8 +217,19 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(const uint4* __restrict
                                                          uint4* __restrict__ g_out, size_t n8, int c8n, int C,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ coef) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (size_t)gridDim.x * kBlock) {
-    const int cg = (int)(i % c8n);
+  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const int cg = (int)(i0 & (size_t)(c8n - 1));
+  float mu[8], is[8], k1[8], k2[8], sg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c];
+    is[j] = invstd[c];
+    k1[j] = coef[c];
+    k2[j] = coef[C + c];
+    sg[j] = coef[2 * C + c];
+  }
+  for (size_t i = i0; i < n8; i += (size_t)gridDim.x * kBlock) {
     float gf[8], zf[8];
     unpack8(dy[i], gf);
     unpack8(z[i], zf);
@@ -196,11 +237,10 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(const uint4* __restrict
     if (ymask) keep8(ymask[i], kp);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = cg * 8 + j;
       const float g = (!ymask || kp[j]) ? gf[j] : 0.f;
       gf[j] = g;
-      const float xh = (zf[j] - mean[c]) * invstd[c];
-      zf[j] = coef[2 * C + c] * (g - coef[c] - xh * coef[C + c]);
+      const float xh = (zf[j] - mu[j]) * is[j];
+      zf[j] = sg[j] * (g - k1[j] - xh * k2[j]);
     }
     dz[i] = pack8(zf);
     if (g_out) g_out[i] = pack8(gf);
@@ -213,6 +253,7 @@ struct GatherArgs {
   int batch, src_h, src_w, C, grid_h, grid_w, sy, sx, n_taps;
   int tap_dy[49], tap_dx[49];
   long long M, M_pad;
+  int chunk, rows_total;   // output layout [M_pad / chunk][rows_total][chunk]: one compact slab per K split
 };
 __global__ __launch_bounds__(kBlock) void k_transpose_gather(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
                                                              const GatherArgs a) {
@@ -245,7 +286,9 @@ __global__ __launch_bounds__(kBlock) void k_transpose_gather(const uint16_t* __r
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       w[j] = (uint32_t)tile[mch * 8 + 2 * j][c] | ((uint32_t)tile[mch * 8 + 2 * j + 1][c] << 16);
-    *reinterpret_cast<uint4*>(out + ((size_t)t * a.C + c0 + c) * a.M_pad + m0 + mch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    const long long slab = m0 / a.chunk, mk = m0 - slab * a.chunk;        // 64-pixel tiles never straddle a chunk
+    *reinterpret_cast<uint4*>(out + ((size_t)slab * a.rows_total + (size_t)t * a.C + c0 + c) * a.chunk + mk + mch * 8) =
+        make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 // C == 4 (the stem's padded hi plane): one thread per (tap, pixel), four output rows
@@ -263,28 +306,58 @@ __global__ __launch_bounds__(kBlock) void k_transpose_gather_c4(const uint2* __r
     if ((unsigned)iy < (unsigned)a.src_h && (unsigned)ix < (unsigned)a.src_w)
       v = x[((size_t)img * a.src_h + iy) * a.src_w + ix];
   }
-  uint16_t* o = out + (size_t)t * 4 * a.M_pad + m;
+  const long long slab = m / a.chunk, mk = m - slab * a.chunk;
+  uint16_t* o = out + ((size_t)slab * a.rows_total + (size_t)t * 4) * a.chunk + mk;
   o[0] = (uint16_t)(v.x & 0xFFFF);
-  o[a.M_pad] = (uint16_t)(v.x >> 16);
-  o[2 * a.M_pad] = (uint16_t)(v.y & 0xFFFF);
-  o[3 * a.M_pad] = (uint16_t)(v.y >> 16);
+  o[a.chunk] = (uint16_t)(v.x >> 16);
+  o[2 * (size_t)a.chunk] = (uint16_t)(v.y & 0xFFFF);
+  o[3 * (size_t)a.chunk] = (uint16_t)(v.y >> 16);
 }
 
 // ---- split-K reduce: grad[n][c][t] (torch [N][C][R][S], t = r*S + s) (+)= sum_z partial[z][(t*Cp + c)][n]
-__global__ __launch_bounds__(kBlock) void k_wgrad_reduce(const float* __restrict__ partial, int splits, int taps, int C,
-                                                         int Cp, int N, int ldn, float* __restrict__ grad, int accumulate) {
-  const size_t total = (size_t)N * C * taps;
-  const size_t zstride = (size_t)taps * Cp * ldn;
+// One workgroup = 32 output channels n x (up to 32 input channels c) x all taps: partial rows are read 128 B at a
+// time along n (coalesced), the sums are transposed through LDS, and each n writes its contiguous (c, t) run.
+// Layers with a tiny weight tensor run up to 256 K splits (the GEMM needs the parallelism); those are first folded
+// 16:1 by a fully parallel streaming kernel (in place, into the first slot of each group), fixed order.
+constexpr int kWgNT = 32, kWgRow = 296, kFold = 16;
+__global__ __launch_bounds__(kBlock) void k_wgrad_fold(float* __restrict__ partial, int splits, size_t zstride) {
+  const int groups = (splits + kFold - 1) / kFold;
+  const size_t total = (size_t)groups * zstride;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    // consecutive threads walk n fastest so the partial reads are coalesced
-    const int n = (int)(i % N);
-    const size_t q = i / N;
-    const int c = (int)(q % C), t = (int)(q / C);
-    const float* p = partial + ((size_t)t * Cp + c) * ldn + n;
+    const int gidx = (int)(i / zstride);
+    const size_t e = i - (size_t)gidx * zstride;
+    float* p = partial + (size_t)gidx * kFold * zstride + e;
+    const int cnt = splits - gidx * kFold < kFold ? splits - gidx * kFold : kFold;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += p[(size_t)z * zstride];
-    float* g = grad + ((size_t)n * C + c) * taps + t;
-    *g = accumulate ? *g + s : s;
+#pragma unroll 4
+    for (int j = 0; j < cnt; ++j) s += p[(size_t)j * zstride];
+    p[0] = s;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_wgrad_reduce(const float* __restrict__ partial, int splits, int zstep, int taps,
+                                                         int C, int Cp, int N, int ldn, int ct, float* __restrict__ grad,
+                                                         int accumulate) {
+  __shared__ float tile[kWgNT][kWgRow + 1];
+  const int tid = threadIdx.x, nl = tid & 31, cl = tid >> 5;          // 32 n lanes x 8 c lanes
+  const int n0 = blockIdx.x * kWgNT, c0 = blockIdx.y * ct;
+  const int cn = C - c0 < ct ? C - c0 : ct;                            // channels in this tile
+  const size_t zstride = (size_t)taps * Cp * ldn * zstep;
+  const int n = n0 + nl;
+  for (int j = cl; j < cn * taps; j += 8) {       // j = c * taps + t: the position inside n's contiguous run
+    const int c = j / taps, t = j - c * taps;
+    float s = 0.f;
+    if (n < N) {
+      const float* p = partial + ((size_t)t * Cp + c0 + c) * ldn + n;
+      for (int z = 0; z < splits; ++z) s += p[(size_t)z * zstride];
+    }
+    tile[nl][j] = s;
+  }
+  __syncthreads();
+  const int run = cn * taps;                                           // contiguous floats per n
+  for (int r = 0; r < kWgNT; ++r) {
+    if (n0 + r >= N) break;
+    float* g = grad + ((size_t)(n0 + r) * C + c0) * taps;
+    for (int i = tid; i < run; i += kBlock) g[i] = accumulate ? g[i] + tile[r][i] : tile[r][i];
   }
 }
 
@@ -322,7 +395,7 @@ inline unsigned grid_for(size_t n) {
   return (unsigned)b;
 }
 inline int chunks_for(size_t M, int C, size_t* rows_per_chunk) {
-  // ~2048 workgroups, each at least one pass of its row lanes
+  // ~2048 workgroups (8 per CU), each at least four passes of its row lanes
   const size_t rows_par = (size_t)(kBlock / (C / 8));
   size_t chunks = 2048;
   size_t rpc = (M + chunks - 1) / chunks;
@@ -359,7 +432,7 @@ extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_colsum2<0>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
                      rows, channels, rpc, (float*)workspace);
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + 63) / 64), dim3(64), 0, st, (const float*)workspace, chunks,
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + 15) / 16), dim3(256), 0, st, (const float*)workspace, chunks,
                      channels, 1.0 / (double)rows, (double)rows / (double)(rows - 1), gamma, beta, (float)eps,
                      (float)momentum, running_mean, running_var, mean_out, invstd_out, scale_shift,
                      scale_shift + channels);
@@ -389,7 +462,7 @@ extern "C" int rart_bn_train_backward_bf16(const void* dy, const void* ymask, co
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_colsum2<1>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, (const uint4*)dy,
                      (const uint4*)ymask, mean, invstd, rows, channels, rpc, (float*)workspace);
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((channels + 63) / 64), dim3(64), 0, st, (const float*)workspace, chunks,
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((channels + 15) / 16), dim3(256), 0, st, (const float*)workspace, chunks,
                      channels, 1.0 / (double)rows, gamma, invstd, dgamma, dbeta, accumulate, coef);
   const size_t n8 = rows * (size_t)(channels / 8);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n8)), dim3(kBlock), 0, st, (const uint4*)dy, (const uint4*)ymask,
@@ -400,7 +473,8 @@ extern "C" int rart_bn_train_backward_bf16(const void* dy, const void* ymask, co
 
 extern "C" int rart_transpose_gather_bf16(const void* src, void* dst, int batch, int src_h, int src_w, int channels,
                                           int grid_h, int grid_w, int sy, int sx, int n_taps, const int* tap_dy,
-                                          const int* tap_dx, long long rows_padded, rart_stream_t stream) {
+                                          const int* tap_dx, long long rows_padded, int chunk, int rows_total,
+                                          rart_stream_t stream) {
   RART_CHECK_ARG(src && dst && batch > 0 && grid_h > 0 && grid_w > 0 && tap_dy && tap_dx,
                  "rart_transpose_gather_bf16: bad arguments");
   RART_CHECK_ARG(n_taps >= 1 && n_taps <= 49, "rart_transpose_gather_bf16: 1..49 taps");
@@ -412,6 +486,10 @@ extern "C" int rart_transpose_gather_bf16(const void* src, void* dst, int batch,
   a.M = (long long)batch * grid_h * grid_w;
   a.M_pad = rows_padded;
   RART_CHECK_ARG(a.M_pad >= a.M && a.M_pad % 64 == 0, "rart_transpose_gather_bf16: rows_padded must be >= rows and a multiple of 64");
+  a.chunk = chunk > 0 ? chunk : (int)a.M_pad;
+  a.rows_total = rows_total > 0 ? rows_total : n_taps * channels;
+  RART_CHECK_ARG(a.chunk % 64 == 0 && a.M_pad % a.chunk == 0 && a.rows_total >= n_taps * channels,
+                 "rart_transpose_gather_bf16: chunk must be a multiple of 64 dividing rows_padded; rows_total >= taps*channels");
   hipStream_t st = (hipStream_t)stream;
   if (channels == 4)
     hipLaunchKernelGGL(k_transpose_gather_c4, dim3((unsigned)((a.M_pad + kBlock - 1) / kBlock), n_taps), dim3(kBlock), 0, st,
@@ -423,13 +501,30 @@ extern "C" int rart_transpose_gather_bf16(const void* src, void* dst, int batch,
   return RART_OK;
 }
 
-extern "C" int rart_wgrad_reduce_f32(const float* partial, int splits, int taps, int channels, int channels_padded,
+extern "C" int rart_wgrad_reduce_f32(float* partial, int splits, int taps, int channels, int channels_padded,
                                      int n_out, int ld_n, float* grad, int accumulate, rart_stream_t stream) {
   RART_CHECK_ARG(partial && grad && splits >= 1 && taps >= 1 && channels >= 1 && channels_padded >= channels &&
                      n_out >= 1 && ld_n >= n_out, "rart_wgrad_reduce_f32: bad arguments");
-  const size_t total = (size_t)n_out * channels * taps;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, partial, splits, taps,
-                     channels, channels_padded, n_out, ld_n, grad, accumulate);
+  RART_CHECK_ARG(taps <= kWgRow, "rart_wgrad_reduce_f32: too many taps");
+  // channel-tile width: as wide as the LDS row allows for big tensors, narrower for small ones so that at least
+  // ~512 workgroups share the (latency-bound) partial reads
+  int ct = kWgRow / taps;
+  if (ct > 32) ct = 32;
+  const long long want = (long long)channels * ((n_out + kWgNT - 1) / kWgNT) / 512;
+  if (ct > want) ct = (int)(want < 1 ? 1 : want);
+  if (ct > channels) ct = channels;
+  int zstep = 1;
+  if (splits > kFold) {   // in place: the caller's partial buffer is scratch
+    const size_t zs = (size_t)taps * channels_padded * ld_n;
+    const int groups = (splits + kFold - 1) / kFold;
+    hipLaunchKernelGGL(k_wgrad_fold, dim3(grid_for((size_t)groups * zs)), dim3(kBlock), 0, (hipStream_t)stream,
+                       partial, splits, zs);
+    splits = groups;
+    zstep = kFold;
+  }
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_out + kWgNT - 1) / kWgNT, (channels + ct - 1) / ct), dim3(kBlock), 0,
+                     (hipStream_t)stream, partial, splits, zstep, taps, channels, channels_padded, n_out, ld_n, ct, grad,
+                     accumulate);
   RART_CHECK_LAUNCH("rart_wgrad_reduce_f32");
   return RART_OK;
 }

@@ -224,22 +224,22 @@ class ResNet50TrainEngine:
         chunk = ((M + splits - 1) // splits + 63) // 64 * 64
         m_pad = chunk * splits
         n_rows = (n_pad_cols + bn_tile - 1) // bn_tile * bn_tile
+        # both operands are stored as one compact slab per K split: [splits][rows][chunk]
         dzt = self._scratch('wg_dzT', n_rows * m_pad * 2)
         colt = self._scratch('wg_colT', kp * m_pad * 2)
         zero = _ints([0])
-        # rows of dzT beyond n_pad_cols belong to the igemm's tile padding: keep them zero
         if n_rows > n_pad_cols:
-            dzt[n_pad_cols * m_pad * 2:n_rows * m_pad * 2].zero_()
+            dzt[:n_rows * m_pad * 2].zero_()                     # tile-padding rows of every slab stay zero
         _lib.check(lib.rart_transpose_gather_bf16(dz.data_ptr(), dzt.data_ptr(), B, gh, gw, n_pad_cols, gh, gw, 1, 1, 1,
-                                                  zero, zero, m_pad, sp))
+                                                  zero, zero, m_pad, chunk, n_rows, sp))
         _lib.check(lib.rart_transpose_gather_bf16(x.data_ptr(), colt.data_ptr(), B, x_hw[0], x_hw[1], x_c, gh, gw,
                                                   stride, stride, len(taps), _ints([t[0] for t in taps]),
-                                                  _ints([t[1] for t in taps]), m_pad, sp))
+                                                  _ints([t[1] for t in taps]), m_pad, chunk, kp, sp))
         ld_n = (n_pad_cols + 7) // 8 * 8
         part = self._scratch('wg_part', splits * kp * ld_n * 4)
-        self._gemm(colt, dzt, part, 1, (1, kp), (1, kp), m_pad, chunk, [(0, 0)], ld_n, (1, kp), ld_n, flags=F_OUT_F32,
-                   batched={'n': splits, 'src': chunk, 'wgt': chunk, 'dst': kp * ld_n, 'wgrad': True,
-                            'wgt_row_stride': m_pad})
+        self._gemm(colt, dzt, part, 1, (1, kp), (1, kp), chunk, chunk, [(0, 0)], ld_n, (1, kp), ld_n, flags=F_OUT_F32,
+                   batched={'n': splits, 'src': kp * chunk, 'wgt': n_rows * chunk, 'dst': kp * ld_n,
+                            'wgt_row_stride': chunk})
         cv = c_valid if c_valid is not None else x_c
         _lib.check(lib.rart_wgrad_reduce_f32(part.data_ptr(), splits, len(taps), cv, x_c, n_out, ld_n, grad.data_ptr(), 0,
                                              sp))

@@ -13,10 +13,11 @@ One process per GPU.  Evaluation: samples shard over ranks (distributed, non-rep
 AddNoise (HIP kernels), the forward from the HIP engine, and the ONLY collective is one all-reduce of the
 (top-1, top-5, count) counters.  Adversarial training (PGD-k inner loop, BN in eval mode during the attack,
 cifar10/code/train.py:105-111): the attack runs on the HIP engine with the current weights re-folded; the
-train-mode forward/backward still runs on PyTorch-ROCm (the HIP wgrad / train-mode BN kernels are not written
-yet -- DESIGN.md section 8); the loss + its gradient (label-smoothed CE), the optimizer (SGD-Nesterov / AdamW), the
-EMA and the gradient reset are HIP kernels over flat parameter arenas (train/arena.py), and the gradient exchange is
-a few large all-reduces on arena slices over RCCL/xGMI, overlapped with backward unless `dist.sync: True`.
+train-mode forward/backward of ResNet-50 runs on the HIP train engine (model/train_engine.py: igemm contractions,
+batch-statistics BatchNorm kernels, split-K weight gradients; other architectures use torch autograd as scaffold); the
+loss + its gradient (label-smoothed CE), the optimizer (SGD-Nesterov / AdamW), the EMA and the gradient reset are HIP
+kernels over flat parameter arenas (train/arena.py), and the gradient exchange is a few large all-reduces on arena
+slices over RCCL/xGMI, overlapped with backward unless `dist.sync: True`.
 """
 import argparse
 import json
@@ -265,6 +266,13 @@ def train(cfg, args, rank, world, device):
         if ema_on:
             ema = arena.flat_p.clone()
     ema_buffers = {k: v.detach().clone() for k, v in model.named_buffers() if v.dtype.is_floating_point} if ema_on else {}
+    train_engine = None
+    if use_hip_opt and getattr(args, 'train_engine', 'hip') == 'hip':
+        from ..model.resnet_torch import ResNet
+        if isinstance(model, ResNet) and size % 32 == 0:
+            from ..model.train_engine import ResNet50TrainEngine
+            model.train()
+            train_engine = ResNet50TrainEngine(model, device, on_grad_ready=arena.grad_ready)
     ls = float(cfg.get('label_smooth', 0.0))
     adv = cfg.get('adv_train', None)                        # {'eps': '4/255', 'steps': 3, 'rel_stepsize': 0.4}
     mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
@@ -289,21 +297,30 @@ def train(cfg, args, rank, world, device):
                              float(adv.get('rel_stepsize', 3 / 40)), int(adv.get('steps', 3)), seed=it,
                              sample_offset=sel[0])
         model.train()
-        xin = ((x01 - mean) / std).contiguous(memory_format=torch.channels_last)
-        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=use_amp):
-            out = model(xin)
-        if use_hip_opt:
-            # label-smoothed CE and its gradient in one HIP kernel; autograd continues from dlogits
-            loss_rows, dlogits = label_smooth_ce(out, labels, ls, 1.0 / len(items))
-            out.backward(dlogits.to(out.dtype))             # bucket all-reduces start from the grad hooks
+        if train_engine is not None:
+            # train-mode forward (batch statistics), label-smoothed CE, backward to every parameter: all HIP
+            logits = train_engine.forward(x01.contiguous(), False, IMAGENET_MEAN, IMAGENET_STD)
+            loss_rows, dlogits = label_smooth_ce(logits, labels, ls, 1.0 / len(items))
+            train_engine.backward(dlogits)                  # gradients land in the arena; buckets reduce as they fill
             loss = loss_rows.mean()
         else:
-            loss = F.cross_entropy(out.float(), labels, label_smoothing=ls)
-            loss.backward()
+            xin = ((x01 - mean) / std).contiguous(memory_format=torch.channels_last)
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=use_amp):
+                out = model(xin)
+            if use_hip_opt:
+                # label-smoothed CE and its gradient in one HIP kernel; autograd continues from dlogits
+                loss_rows, dlogits = label_smooth_ce(out, labels, ls, 1.0 / len(items))
+                out.backward(dlogits.to(out.dtype))         # bucket all-reduces start from the grad hooks
+                loss = loss_rows.mean()
+            else:
+                loss = F.cross_entropy(out.float(), labels, label_smoothing=ls)
+                loss.backward()
         scale = arena.finish_grad_exchange()                # waits for the buckets; returns 1 / world_size
         if use_hip_opt:
             opt.lr = lr
             opt.step(grad_scale=scale)                      # update + EMA + grad reset, one launch per decay range
+            if train_engine is not None:
+                train_engine.repack()                       # fp32 master weights -> bf16 igemm tables
         else:
             for gp in opt.param_groups:
                 gp['lr'] = lr
@@ -336,6 +353,8 @@ def main(argv=None):
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--engine', choices=['hip', 'torch'], default='hip')
     ap.add_argument('--max-iter', type=int, default=20)
+    ap.add_argument('--train-engine', choices=['hip', 'torch'], default='hip', dest='train_engine',
+                    help='train-mode forward/backward: hip = ResNet50TrainEngine, torch = autograd scaffold')
     ap.add_argument('--save-dir', default=None, help='root of <model>/<noise>_<eps>/results.txt.all (robustart_amd.metrics)')
     ap.add_argument('--src_name', default=None, help='name of the attacked (source) model in the result path')
     ap.add_argument('--tgt_name', default=None, help='transfer: name of the target model (new_transfer/eval.sh:42-44)')

@@ -87,11 +87,19 @@ def test_transpose_gather_matches_unfold(B, H, C, r, stride):
     m_pad = (M + 63) // 64 * 64 + 64
     out = torch.full((len(taps) * C, m_pad), 7.0, device='cuda', dtype=torch.bfloat16)
     L.check(lib.rart_transpose_gather_bf16(x.data_ptr(), out.data_ptr(), B, H, H, C, oh, oh, stride, stride, len(taps),
-                                           _ints([t[0] for t in taps]), _ints([t[1] for t in taps]), m_pad, L.stream_ptr()))
+                                           _ints([t[0] for t in taps]), _ints([t[1] for t in taps]), m_pad, 0, 0, L.stream_ptr()))
     cols = F.unfold(x.float().permute(0, 3, 1, 2), r, padding=pad, stride=stride)     # [B][C*r*r][oh*ow], (c, tap) order
     cols = cols.view(B, C, r * r, oh * oh).permute(2, 1, 0, 3).reshape(r * r * C, M)  # -> (tap, c) rows, m = (b, pix)
     assert torch.equal(out[:, :M].float(), cols)
     assert torch.count_nonzero(out[:, M:]).item() == 0
+    # slab layout: [m_pad / chunk][rows_total][chunk] with extra (untouched) padding rows per slab
+    chunk, rows_total = 64, len(taps) * C + 8
+    slabs = torch.full((m_pad // chunk, rows_total, chunk), 7.0, device='cuda', dtype=torch.bfloat16)
+    L.check(lib.rart_transpose_gather_bf16(x.data_ptr(), slabs.data_ptr(), B, H, H, C, oh, oh, stride, stride, len(taps),
+                                           _ints([t[0] for t in taps]), _ints([t[1] for t in taps]), m_pad, chunk,
+                                           rows_total, L.stream_ptr()))
+    assert torch.equal(slabs[:, :len(taps) * C, :].permute(1, 0, 2).reshape(len(taps) * C, m_pad), out)
+    assert bool((slabs[:, len(taps) * C:, :] == 7.0).all())
 
 
 def test_transpose_gather_c4_and_pack_weight():
@@ -105,7 +113,7 @@ def test_transpose_gather_c4_and_pack_weight():
     m_pad = (M + 63) // 64 * 64
     out = torch.empty(49 * 4, m_pad, device='cuda', dtype=torch.bfloat16)
     L.check(lib.rart_transpose_gather_bf16(x.data_ptr(), out.data_ptr(), B, H + 8, H + 8, 4, oh, oh, 2, 2, 49,
-                                           _ints([t[0] for t in taps]), _ints([t[1] for t in taps]), m_pad, L.stream_ptr()))
+                                           _ints([t[0] for t in taps]), _ints([t[1] for t in taps]), m_pad, 0, 0, L.stream_ptr()))
     ref = torch.empty(49, 4, B, oh, oh, device='cuda')
     for ti, (a, b) in enumerate(taps):
         ref[ti] = x.float()[:, a:a + 2 * oh:2, b:b + 2 * oh:2, :].permute(3, 0, 1, 2)
