@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='images in the bounded CPU baseline sample')
-    ap.add_argument('--workload', choices=['headline', 'vit_inc'], default='headline',
+    ap.add_argument('--workload', choices=['headline', 'vit_inc', 'adv_train'], default='headline',
                     help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 3: ViT-B/16 evaluated "
                          "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost skipped: no textures)")
     ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
@@ -257,6 +257,69 @@ def run_vit_inc(args, device, rank, world, dist):
                                      'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
 
 
+def run_adv_train(args, device, rank, world, dist):
+    """BASELINE config 5 (secondary mode): ResNet-50 adversarial training, PGD-3 inner loop on the HIP eval engine
+    (re-folded from the live weights every step), train-mode forward/backward on the HIP train engine, label-smoothed
+    CE / SGD-Nesterov + EMA kernels over flat arenas, bucketed gradient all-reduce over RCCL overlapped with backward."""
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.model.train_engine import ResNet50TrainEngine
+    from robustart_amd.noise import adv as A
+    from robustart_amd.train.arena import HipOptimizer, ParamArena, label_smooth_ce
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    x01 = (torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).float() / 255.0).to(device)
+    labels = torch.randint(0, 1000, (B,), generator=g).to(device)
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = get_model({'type': 'resnet50_official'}).to(device)
+    arena = ParamArena(model, bucket_bytes=48 << 20)
+    opt = HipOptimizer(arena, 'SGD', lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, ema_decay=0.9999)
+    model.eval()
+    attack = EngineModel(model, takes_normalized=False)
+    model.train()
+    eng = ResNet50TrainEngine(model, device, on_grad_ready=arena.grad_ready)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def step(k):
+        attack.rart_engine.refold(model)
+        xa = A.pgd_linf(x01, labels, attack, 4 / 255, 0.4, 3, seed=k, sample_offset=rank * B)
+        logits = eng.forward(xa, False, mean, std)
+        loss_rows, dl = label_smooth_ce(logits, labels, 0.1, 1.0 / B)
+        eng.backward(dl)
+        opt.lr = 0.1
+        opt.step(grad_scale=arena.finish_grad_exchange())
+        eng.repack()
+        return loss_rows
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss_rows = step(args.warmup + i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        flops = (3 * 2 + 3) * FLOP_FWD * B * world          # PGD-3: 3 x (fwd + bwd-to-input); train step: fwd + 2 x bwd
+        print(json.dumps({'metric': 'adversarially trained images/sec/node (ResNet-50, cls_solver step, PGD-3 inner loop)',
+                          'value': B * world * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                          'final_loss': float(loss_rows.mean()),
+                          'step_mfma': {'achieved': flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
+                                        'note': '9 forward-equivalents per image (SURVEY.md 8d)'},
+                          'config': {'workload': 'BASELINE config 5 (secondary): PGD-Linf-3 eps 4/255 on the eval engine + '
+                                                 'train-mode fwd/bwd + SGD-Nesterov/EMA, batch 256 per GPU',
+                                     'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -271,8 +334,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)       # "nccl" == RCCL on ROCm
-    if args.workload == 'vit_inc':
-        run_vit_inc(args, device, rank, world, dist)
+    if args.workload in ('vit_inc', 'adv_train'):
+        (run_vit_inc if args.workload == 'vit_inc' else run_adv_train)(args, device, rank, world, dist)
         if dist is not None:
             dist.destroy_process_group()
         return

@@ -362,9 +362,12 @@ int rart_transpose_gather_bf16(const void* src, void* dst, int batch, int src_h,
 int rart_wgrad_reduce_f32(float* partial, int splits, int taps, int channels, int channels_padded, int n_out,
                           int ld_n, float* grad, int accumulate, rart_stream_t stream);
 /* fp32 master weight [n_out][channels][r][s] -> bf16 igemm table over the listed taps:
- * transpose 0: out[n][ti*channels + c] (forward), 1: out[c][ti*n_out + n] (backward to input); rows zero-padded. */
-int rart_pack_conv_weight_bf16(const float* weight, void* out, int n_out, int channels, int r, int s, int n_taps,
-                               const int* tap_r, const int* tap_s, int transpose, int rows_padded, rart_stream_t stream);
+ * transpose 0: out[n][ti*channels + c] (forward), 1: out[c][ti*n_out + n] (backward to input); rows zero-padded.
+ * out_channel_scale (nullable, [n_out]): weight[n] is multiplied by it first -- the eval-mode BatchNorm fold
+ * gamma*rsqrt(running_var + eps), so the attack engine can be re-folded from the live parameters every iteration. */
+int rart_pack_conv_weight_bf16(const float* weight, const float* out_channel_scale, void* out, int n_out, int channels,
+                               int r, int s, int n_taps, const int* tap_r, const int* tap_s, int transpose,
+                               int rows_padded, rart_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -89,8 +89,8 @@ SIGNATURES = {
                                            c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.c_longlong,
                                            c_int, c_int, c_void_p]),
     'rart_wgrad_reduce_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
-    'rart_pack_conv_weight_bf16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
-                                           ctypes.POINTER(c_int), c_int, c_int, c_void_p]),
+    'rart_pack_conv_weight_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_void_p]),
 }
 
 

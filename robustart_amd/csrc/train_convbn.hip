@@ -369,8 +369,8 @@ struct PackArgs {
   int N, C, R, S, n_taps, transpose, rows_pad;
   int tap_r[49], tap_s[49];
 };
-__global__ __launch_bounds__(kBlock) void k_pack_weight(const float* __restrict__ w, uint16_t* __restrict__ out,
-                                                        const PackArgs a) {
+__global__ __launch_bounds__(kBlock) void k_pack_weight(const float* __restrict__ w, const float* __restrict__ row_scale,
+                                                        uint16_t* __restrict__ out, const PackArgs a) {
   const int inner = a.transpose ? a.N : a.C;
   const size_t K = (size_t)a.n_taps * inner;
   const size_t total = (size_t)a.rows_pad * K;
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_weight(const float* __restrict_
     if (row < rows) {
       const int n = a.transpose ? in : row, c = a.transpose ? row : in;
       v = w[(((size_t)n * a.C + c) * a.R + a.tap_r[ti]) * a.S + a.tap_s[ti]];
+      if (row_scale) v *= row_scale[n];      // eval-mode BatchNorm folded into the conv: gamma * rsqrt(var + eps)
     }
     out[i] = (uint16_t)f2bf(v);
   }
@@ -529,9 +530,9 @@ extern "C" int rart_wgrad_reduce_f32(float* partial, int splits, int taps, int c
   return RART_OK;
 }
 
-extern "C" int rart_pack_conv_weight_bf16(const float* weight, void* out, int n_out, int channels, int r, int s, int n_taps,
-                                          const int* tap_r, const int* tap_s, int transpose, int rows_padded,
-                                          rart_stream_t stream) {
+extern "C" int rart_pack_conv_weight_bf16(const float* weight, const float* out_channel_scale, void* out, int n_out,
+                                          int channels, int r, int s, int n_taps, const int* tap_r, const int* tap_s,
+                                          int transpose, int rows_padded, rart_stream_t stream) {
   RART_CHECK_ARG(weight && out && n_out > 0 && channels > 0 && r > 0 && s > 0 && tap_r && tap_s,
                  "rart_pack_conv_weight_bf16: bad arguments");
   RART_CHECK_ARG(n_taps >= 1 && n_taps <= 49, "rart_pack_conv_weight_bf16: 1..49 taps");
@@ -543,7 +544,8 @@ extern "C" int rart_pack_conv_weight_bf16(const float* weight, void* out, int n_
     a.tap_r[i] = tap_r[i]; a.tap_s[i] = tap_s[i];
   }
   const size_t total = (size_t)rows_padded * n_taps * (transpose ? n_out : channels);
-  hipLaunchKernelGGL(k_pack_weight, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, weight, (uint16_t*)out, a);
+  hipLaunchKernelGGL(k_pack_weight, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, weight, out_channel_scale,
+                     (uint16_t*)out, a);
   RART_CHECK_LAUNCH("rart_pack_conv_weight_bf16");
   return RART_OK;
 }

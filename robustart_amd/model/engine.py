@@ -90,6 +90,10 @@ class _Conv:
                     self.bwd.append(((ph, pw), taps, _bf16(_pad_rows(wd, _rows_mult(self.cin))).to(device)))
 
 
+def _cints(vals):
+    return (ctypes.c_int * max(len(vals), 1))(*vals)
+
+
 class ResNet50Engine:
     """Hand-written HIP eval engine for robustart_amd.model.resnet_torch.ResNet."""
 
@@ -130,6 +134,61 @@ class ResNet50Engine:
         self.fc_wd = _bf16(wt).to(dev)                                    # [2048][1024]
         self._buf = {}
         self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
+
+    # ------------------------------------------------------------------ re-fold from the live parameters
+    def refold(self, model):
+        """Re-derive every table from `model`'s CURRENT parameters and running statistics, on the GPU
+        (rart_pack_conv_weight_bf16 with the BatchNorm scale folded in): the adversarial-training loop attacks the
+        model it is training (cifar10/code/train.py:105-111), so the attack engine is refreshed every iteration."""
+        torch = _lib.require_gpu()
+        lib, sp = self.lib, _lib.stream_ptr()
+        m = model
+
+        def fold(c, conv, bn):
+            w = conv.weight.detach()
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+            scale = (bn.running_var.detach() + bn.eps).rsqrt() * bn.weight.detach()
+            c.bias.copy_(bn.bias.detach() - bn.running_mean.detach() * scale)
+            rs = [(r, s) for r in range(c.r) for s in range(c.s)]
+            _lib.check(lib.rart_pack_conv_weight_bf16(w.data_ptr(), scale.data_ptr(), c.w_fwd.data_ptr(), c.cout, c.cin, c.r,
+                                                      c.s, len(rs), _cints([a for a, _ in rs]), _cints([b for _, b in rs]), 0,
+                                                      c.w_fwd.shape[0], sp))
+            for parity, taps, tab in c.bwd:
+                if tab is None:
+                    continue
+                if parity is None:
+                    prs = rs
+                else:
+                    ph, pw = parity
+                    prs = [(r, s_) for r, s_ in rs if (ph + c.pad - r) % 2 == 0 and (pw + c.pad - s_) % 2 == 0]
+                _lib.check(lib.rart_pack_conv_weight_bf16(w.data_ptr(), scale.data_ptr(), tab.data_ptr(), c.cout, c.cin, c.r,
+                                                          c.s, len(prs), _cints([a for a, _ in prs]),
+                                                          _cints([b for _, b in prs]), 1, tab.shape[0], sp))
+            return scale
+
+        sc = fold(self.stem, m.conv1, m.bn1)
+        wb = (m.conv1.weight.detach() * sc.view(-1, 1, 1, 1)).to(torch.bfloat16)          # [64][3][7][7]
+        wrow = torch.zeros(64, 7, 8, 4, dtype=torch.bfloat16, device=self.device)
+        wrow[:, :, :7, :3] = wb.permute(0, 2, 3, 1)
+        wrow = wrow.reshape(64, 224)
+        self.stem_w[:, :224] = wrow
+        self.stem_w[:, 224:] = wrow
+        self.stem_wd.zero_()
+        self.stem_wd[:147] = wb.permute(2, 3, 1, 0).reshape(147, 64)
+        bi = 0
+        for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
+            for blk in layer:
+                ca, cb, cc, ds = self.blocks[bi]
+                fold(ca, blk.conv1, blk.bn1)
+                fold(cb, blk.conv2, blk.bn2)
+                fold(cc, blk.conv3, blk.bn3)
+                if ds is not None:
+                    fold(ds, blk.downsample[0], blk.downsample[1])
+                bi += 1
+        wfb = m.fc.weight.detach().to(torch.bfloat16)
+        self.fc_w[:self.n_classes] = wfb
+        self.fc_wd[:, :self.n_classes] = wfb.t()
+        self.fc_b.copy_(m.fc.bias.detach())
 
     # ------------------------------------------------------------------ buffers / launches
     def _get(self, name, shape, dtype=None):

@@ -61,13 +61,13 @@ class _TConv:
         assert w.dtype.is_floating_point and w.is_contiguous()
         wf = w.detach().float() if str(w.dtype) != 'torch.float32' else w.detach()
         rs = self.all_rs
-        _lib.check(lib.rart_pack_conv_weight_bf16(wf.data_ptr(), self.w_fwd.data_ptr(), self.cout, self.cin, self.r, self.s,
+        _lib.check(lib.rart_pack_conv_weight_bf16(wf.data_ptr(), None, self.w_fwd.data_ptr(), self.cout, self.cin, self.r, self.s,
                                                   len(rs), _ints([a for a, _ in rs]), _ints([b for _, b in rs]), 0,
                                                   self.w_fwd.shape[0], sp))
         for parity, taps, prs, tab in self.bwd:
             if tab is None:
                 continue
-            _lib.check(lib.rart_pack_conv_weight_bf16(wf.data_ptr(), tab.data_ptr(), self.cout, self.cin, self.r, self.s,
+            _lib.check(lib.rart_pack_conv_weight_bf16(wf.data_ptr(), None, tab.data_ptr(), self.cout, self.cin, self.r, self.s,
                                                       len(prs), _ints([a for a, _ in prs]), _ints([b for _, b in prs]), 1,
                                                       tab.shape[0], sp))
 
@@ -112,7 +112,7 @@ class ResNet50TrainEngine:
         self.stem_w[:, 224:] = wrow
         one = _ints([0])
         w = self.model.fc.weight.detach()
-        _lib.check(self.lib.rart_pack_conv_weight_bf16(w.data_ptr(), self.fc_w.data_ptr(), self.n_classes, self.fc_in, 1, 1,
+        _lib.check(self.lib.rart_pack_conv_weight_bf16(w.data_ptr(), None, self.fc_w.data_ptr(), self.n_classes, self.fc_in, 1, 1,
                                                        1, one, one, 0, self.fc_kpad, sp))
         # backward-to-input of the classifier: rows = features, K = classes padded to fc_kpad (row stride fc_kpad)
         self.fc_wd[:, :self.n_classes] = w.t().to(torch.bfloat16)

@@ -60,9 +60,20 @@ class FakeImageNet(torch.utils.data.Dataset):
         return self.n
 
     def __getitem__(self, i):
-        g = torch.Generator().manual_seed(1234 + i)
-        img = torch.randint(0, 256, (self.size, self.size, 3), generator=g, dtype=torch.uint8)
-        return img, int(torch.randint(0, self.classes, (1,), generator=g)), i
+        img, lab = self.batch([i], 'cpu')
+        return img[0], int(lab[0]), i
+
+    def batch(self, indices, device):
+        """(uint8 [b, size, size, 3], int64 [b]) generated ON `device` from the global indices alone: an integer
+        hash of (index, element), identical on CPU and GPU and for every world size (no host loop, no H2D copy)."""
+        idx = torch.as_tensor(list(indices), dtype=torch.int64, device=device).view(-1, 1)
+        e = torch.arange(self.size * self.size * 3, dtype=torch.int64, device=device).view(1, -1)
+        h = (idx * 1000003 + e) * 2654435761 % 4294967296
+        h = (h ^ (h >> 15)) * 2246822519 % 4294967296
+        h = h ^ (h >> 13)
+        img = (h & 255).to(torch.uint8).view(-1, self.size, self.size, 3)
+        lab = ((idx.view(-1) * 2654435761 % 4294967296) >> 7) % self.classes
+        return img, lab
 
 
 def shard_indices(n, rank, world):
@@ -179,10 +190,9 @@ def evaluate(cfg, args, rank, world, device, model=None):
     c1 = c5 = cnt = 0
     t0 = time.time()
     for s in range(0, len(idx), bs):
-        items = [ds[i] for i in idx[s:s + bs]]
-        imgs = torch.stack([it[0] for it in items]).to(device)
-        labels = torch.tensor([it[1] for it in items], device=device)
-        first = items[0][2]                                    # global index of the batch's first sample
+        items = idx[s:s + bs]
+        imgs, labels = ds.batch(items, device)
+        first = items[0]                                       # global index of the batch's first sample
         if noise is not None:
             from ..noise import imagenet_c as C
             C.corrupt_batch_(imgs, C.CORRUPTION_NAMES.index(args.corruption), args.severity, seed=args.seed,
@@ -280,20 +290,24 @@ def train(cfg, args, rank, world, device):
     use_amp = device.type == 'cuda' and cfg.get('bf16', True)
     idx = shard_indices(n, rank, world)
     loss_v = float('nan')
+    attack_model = None
     for it in range(max_iter):
         lr = cosine_lr(it, max_iter, base_lr, warmup_lr, int(lcfg.get('warmup_steps', max(max_iter // 20, 1))), min_lr)
         sel = [idx[(it * bs + j) % len(idx)] for j in range(bs)]
-        items = [ds[i] for i in sel]
-        imgs = torch.stack([x[0] for x in items]).to(device)
-        labels = torch.tensor([x[1] for x in items], device=device)
+        items = sel
+        imgs, labels = ds.batch(sel, device)
         x01 = imgs.permute(0, 3, 1, 2).float().div(255.0)
         if adv and device.type == 'cuda':
-            # inner maximisation on the HIP engine with the CURRENT weights, BN in inference mode
+            # inner maximisation on the HIP eval engine with the CURRENT weights, BN in inference mode: the engine is
+            # built once and re-folded on the GPU from the live parameters / running statistics every iteration
             from ..model.engine import EngineModel
             from ..noise import adv as A
-            model.eval()
-            f_model = EngineModel(model, takes_normalized=False)
-            x01 = A.pgd_linf(x01.contiguous(), labels, f_model, parse_eps(adv['eps']),
+            if attack_model is None:
+                model.eval()
+                attack_model = EngineModel(model, takes_normalized=False)
+            else:
+                attack_model.rart_engine.refold(model)
+            x01 = A.pgd_linf(x01.contiguous(), labels, attack_model, parse_eps(adv['eps']),
                              float(adv.get('rel_stepsize', 3 / 40)), int(adv.get('steps', 3)), seed=it,
                              sample_offset=sel[0])
         model.train()

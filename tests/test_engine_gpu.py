@@ -264,3 +264,40 @@ def test_pgd_through_engine_matches_autograd_path(setup):
     assert agree > 0.6
     la, lb = eng.logits(a, MEAN, STD), eng.logits(b, MEAN, STD)
     assert (la - lb).abs().max() <= 0.05 * lb.abs().max()
+
+
+@pytest.mark.gpu
+def test_refold_reproduces_constructor_tables_and_tracks_new_weights():
+    """ResNet50Engine.refold (GPU-side BatchNorm fold + packing) == the constructor's host-side fold, bit for bit; after
+    the parameters change, the refolded engine matches a freshly constructed one."""
+    import copy
+    import torch
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import ResNet50Engine
+    torch.manual_seed(3)
+    model = get_model({'type': 'resnet50_official'}).cuda().eval()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+    eng = ResNet50Engine(model)
+
+    def tables(e):
+        out = [e.stem_w, e.stem_wd, e.fc_w, e.fc_wd, e.fc_b, e.stem.bias]
+        for blk in e.blocks:
+            for c in blk:
+                if c is not None:
+                    out += [c.w_fwd, c.bias] + [w for _, _, w in c.bwd if w is not None]
+        return [t.clone() for t in out]
+
+    before = tables(eng)
+    eng.refold(model)
+    for a, b in zip(before, tables(eng)):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.0 + 0.05 * torch.randn_like(p))
+    eng.refold(model)
+    fresh = tables(ResNet50Engine(model))
+    for a, b in zip(fresh, tables(eng)):
+        assert torch.equal(a, b)
