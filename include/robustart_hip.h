@@ -146,6 +146,16 @@ int rart_pgd_step_linf(float* x, const float* g, const float* x0, size_t n_elems
  * clip [0,1].  workspace: rart_attack_workspace_bytes(batch). */
 int rart_pgd_step_l2(float* x, const float* g, const float* x0, int batch, size_t n_per_sample,
                      float eps, float alpha, void* workspace, size_t workspace_bytes, rart_stream_t stream);
+/* PGD-L1 step of ART's ProjectedGradientDescentPyTorch(norm=1) (adv/attack.py:44-49; ART is unpinned in the
+ * reference's requirements.txt:25, this is the 1.x algorithm): x = clip(x + eps_step*g/(sum|g| + 1e-7), 0, 1);
+ * x = x0 + (x - x0)*min(1, eps/(sum|x - x0| + 1e-7)).  workspace: rart_attack_workspace_bytes(batch). */
+int rart_pgd_step_l1(float* x, const float* g, const float* x0, int batch, size_t n_per_sample, float eps, float eps_step,
+                     void* workspace, size_t workspace_bytes, rart_stream_t stream);
+/* ART random_sphere(norm=1) start: x = clip(x0 + r * s_i e_i / sum e, 0, 1), e ~ Exp(1), s = +-1, r = sqrt(U(0, eps^2)).
+ * injected_signed_exp [batch][n] (s_i*e_i) and injected_radius [batch] replace the native draws (both or neither). */
+int rart_random_start_l1(float* x, const float* x0, int batch, size_t n_per_sample, float eps, uint64_t seed,
+                         uint64_t sample_offset, const float* injected_signed_exp, const float* injected_radius,
+                         void* workspace, size_t workspace_bytes, rart_stream_t stream);
 
 /* MIM step (Attacks/imfgsm_attack.py:85-90): g/=mean|g| per sample; m = decay*m + g;
  * x = clip(x0 + clip(x + step*sign(m) - x0, +-eps), 0, 1).  workspace: rart_attack_workspace_bytes(batch). */

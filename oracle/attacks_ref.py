@@ -505,3 +505,34 @@ def fab_targeted_perturb(model_fn, x, y, eps, n_iter, n_target_classes=9):
         acc[ind[fooled]] = False
         adv[ind[fooled]] = adv_curr[fooled].clone()
     return adv
+
+
+def pgd_l1_art(loss_grad, x, y, eps, eps_step, max_iter, init_signed_exp, init_radius):
+    """ART ProjectedGradientDescentPyTorch(norm=1, num_random_init=1), the attack behind the reference's `pgd_l1`
+    (RobustART/noise/utils/adv/attack.py:44-49).  PARITY UNPINNED: ART is an unvendored, version-unpinned dependency
+    (requirements.txt:25) absent from this container; this restates the published ART 1.x algorithm
+    (attacks/evasion/projected_gradient_descent/projected_gradient_descent_pytorch.py: _compute_perturbation_pytorch,
+    _apply_perturbation_pytorch, _projection; utils.random_sphere).  fp32 op by op.
+
+    loss_grad(x, y) -> d CE / dx (any positive per-sample scale: the step normalises by the L1 norm);
+    init_signed_exp [B, n]: sign_i * e_i with e ~ Exp(1) (normalised spacings = ART's sorted-uniform spacings in
+    distribution); init_radius [B]: sqrt(U(0, eps^2))."""
+    import numpy as np
+    f32 = np.float32
+    tol = f32(10e-8)
+    B = x.shape[0]
+    x0 = x.astype(f32)
+    se = init_signed_exp.astype(f32).reshape(B, -1)
+    ssum = np.zeros(B, f32)
+    for b in range(B):
+        ssum[b] = np.abs(se[b]).astype(np.float64).sum()            # the kernel sums in a fixed 2-level order (fp32)
+    xa = np.clip(x0 + (se * (init_radius.astype(f32) / ssum)[:, None]).reshape(x0.shape), f32(0), f32(1)).astype(f32)
+    for _ in range(max_iter):
+        g = loss_grad(xa, y).astype(f32).reshape(B, -1)
+        gn = np.abs(g).astype(np.float64).sum(1).astype(f32) + tol
+        step = (f32(eps_step) * (g / gn[:, None])).reshape(x0.shape)
+        xa = np.clip(xa + step, f32(0), f32(1)).astype(f32)
+        d = (xa - x0).reshape(B, -1)
+        fac = np.minimum(f32(1.0), f32(eps) / (np.abs(d).astype(np.float64).sum(1).astype(f32) + tol))
+        xa = (d * fac[:, None]).reshape(x0.shape) + x0
+    return xa.astype(f32)

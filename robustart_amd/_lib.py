@@ -35,6 +35,10 @@ SIGNATURES = {
     'rart_pgd_step_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
     'rart_pgd_step_l2': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
                                  c_void_p, c_size_t, c_void_p]),
+    'rart_pgd_step_l1': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
+                                 c_void_p, c_size_t, c_void_p]),
+    'rart_random_start_l1': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, c_u64, c_u64, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
     'rart_mim_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
                               c_float, c_void_p, c_size_t, c_void_p]),
     'rart_apgd_init': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_int, c_float, c_u64, c_u64,

@@ -211,6 +211,83 @@ __global__ __launch_bounds__(kBlock) void k_pgd_l2_project(float* __restrict__ x
   }
 }
 
+// ---- PGD-L1 (ART ProjectedGradientDescentPyTorch, norm = 1; adv/attack.py:44-49) ---------------------------
+// ART (unpinned in requirements.txt:25; algorithm of the 1.x series): perturbation = g / (sum|g| + tol),
+// x <- clip(x + eps_step * perturbation, 0, 1), then delta <- delta * min(1, eps / (sum|delta| + tol)), tol = 10e-8.
+constexpr float kArtTol = 10e-8f;
+__global__ __launch_bounds__(kBlock) void k_pgd_l1_move(float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ x0,
+                                                        const float* __restrict__ gpart, float* __restrict__ dpart,
+                                                        size_t nps, float eps_step) {
+  __shared__ float sh[kBlock / 64];
+  const uint32_t b = blockIdx.y;
+  const float gn = sum_partials(gpart + (size_t)b * RCH) + kArtTol;
+  const Chunk c = chunk_of(nps);
+  float acc = 0.f;
+  for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
+    const size_t i = (size_t)b * nps + e;
+    const float x1 = clampf(x[i] + eps_step * (g[i] / gn), 0.f, 1.f);
+    x[i] = x1;
+    acc += fabsf(x1 - x0[i]);
+  }
+  const float r = block_sum(acc, sh);
+  if (threadIdx.x == 0) dpart[(size_t)b * RCH + blockIdx.x] = r;
+}
+__global__ __launch_bounds__(kBlock) void k_pgd_l1_project(float* __restrict__ x, const float* __restrict__ x0,
+                                                           const float* __restrict__ dpart, size_t nps, float eps) {
+  const uint32_t b = blockIdx.y;
+  const float factor = fminf(1.0f, eps / (sum_partials(dpart + (size_t)b * RCH) + kArtTol));
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock)
+    x[base + e] = (x[base + e] - x0[base + e]) * factor + x0[base + e];
+}
+// ART random_sphere(norm=1): a uniform point of the L1 sphere of radius r = sqrt(U(0, eps^2)): spacings of
+// sorted uniforms x random signs.  Spacings of n-1 sorted uniforms are Dirichlet(1,..,1) = normalised Exp(1)
+// draws, which is how they are formed here (no 150 527-key sort per sample).  injected: [batch][nps] signed
+// exponentials (sign * e_i) and injected_r[batch] radii for the parity tests.
+__global__ __launch_bounds__(kBlock) void k_l1_start_reduce(float* __restrict__ part, size_t nps, uint32_t k0, uint32_t k1,
+                                                            uint32_t sbase, const float* __restrict__ inj) {
+  __shared__ float sh[kBlock / 64];
+  const uint32_t b = blockIdx.y;
+  const Chunk c = chunk_of(nps);
+  float acc = 0.f;
+  for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
+    float v;
+    if (inj) v = fabsf(inj[(size_t)b * nps + e]);
+    else {
+      const uint2 w = threefry2x32(k0, k1, rart_ctr0((uint32_t)e, 5), sbase + b);
+      v = -logf(u01(w.x));
+    }
+    acc += v;
+  }
+  const float r = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(size_t)b * RCH + blockIdx.x] = r;
+}
+__global__ __launch_bounds__(kBlock) void k_l1_start_apply(float* __restrict__ x, const float* __restrict__ x0,
+                                                           const float* __restrict__ part, size_t nps, float eps,
+                                                           uint32_t k0, uint32_t k1, uint32_t sbase,
+                                                           const float* __restrict__ inj, const float* __restrict__ inj_r) {
+  const uint32_t b = blockIdx.y;
+  float r;
+  if (inj_r) r = inj_r[b];
+  else {
+    const uint2 w = threefry2x32(k0, k1, rart_ctr0(0xFFFFFFFu, 5), sbase + b);
+    r = sqrtf(u01(w.y) * eps * eps);
+  }
+  const float scale = r / sum_partials(part + (size_t)b * RCH);
+  const size_t base = (size_t)b * nps;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
+    float v;
+    if (inj) v = inj[base + e];
+    else {
+      const uint2 w = threefry2x32(k0, k1, rart_ctr0((uint32_t)e, 5), sbase + b);
+      v = -logf(u01(w.x));
+      if (w.y & 1u) v = -v;
+    }
+    x[base + e] = clampf(x0[base + e] + v * scale, 0.f, 1.f);
+  }
+}
+
 // ---- MIM -------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_mim_apply(float* __restrict__ x, float* __restrict__ m,
                                                       const float* __restrict__ g, const float* __restrict__ x0,
@@ -679,6 +756,36 @@ int rart_pgd_step_l2(float* x, const float* g, const float* x0, int batch, size_
   hipLaunchKernelGGL(k_pgd_l2_move, dim3(RCH, batch), dim3(kBlock), 0, s, x, g, x0, gpart, dpart, nps, alpha);
   hipLaunchKernelGGL(k_pgd_l2_project, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, dpart, nps, eps);
   RART_CHECK_LAUNCH("rart_pgd_step_l2");
+  return RART_OK;
+}
+
+int rart_pgd_step_l1(float* x, const float* g, const float* x0, int batch, size_t nps, float eps, float eps_step,
+                     void* ws, size_t ws_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(x && g && x0 && batch > 0 && nps > 0, "rart_pgd_step_l1: bad arguments");
+  if (int e = need_ws("rart_pgd_step_l1", ws, ws_bytes, (size_t)batch * RCH * 2)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  float* gpart = (float*)ws;
+  float* dpart = gpart + (size_t)batch * RCH;
+  hipLaunchKernelGGL(k_reduce_rows<1>, dim3(RCH, batch), dim3(kBlock), 0, s, g, gpart, nps);
+  hipLaunchKernelGGL(k_pgd_l1_move, dim3(RCH, batch), dim3(kBlock), 0, s, x, g, x0, gpart, dpart, nps, eps_step);
+  hipLaunchKernelGGL(k_pgd_l1_project, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, dpart, nps, eps);
+  RART_CHECK_LAUNCH("rart_pgd_step_l1");
+  return RART_OK;
+}
+
+int rart_random_start_l1(float* x, const float* x0, int batch, size_t nps, float eps, uint64_t seed, uint64_t sample_offset,
+                         const float* injected_signed_exp, const float* injected_radius, void* ws, size_t ws_bytes,
+                         rart_stream_t stream) {
+  RART_CHECK_ARG(x && x0 && batch > 0 && nps > 0 && nps < (1ull << 28) - 1, "rart_random_start_l1: bad arguments");
+  RART_CHECK_ARG((injected_signed_exp == nullptr) == (injected_radius == nullptr),
+                 "rart_random_start_l1: inject both the signed exponentials and the radii, or neither");
+  if (int e = need_ws("rart_random_start_l1", ws, ws_bytes, (size_t)batch * RCH)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), sb = (uint32_t)sample_offset;
+  hipLaunchKernelGGL(k_l1_start_reduce, dim3(RCH, batch), dim3(kBlock), 0, s, (float*)ws, nps, k0, k1, sb, injected_signed_exp);
+  hipLaunchKernelGGL(k_l1_start_apply, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, (const float*)ws, nps, eps, k0, k1,
+                     sb, injected_signed_exp, injected_radius);
+  RART_CHECK_LAUNCH("rart_random_start_l1");
   return RART_OK;
 }
 

@@ -230,3 +230,46 @@ def test_native_pgd_linf_invariants_at_imagenet_size():
     assert torch.equal(s[4:], s2)
     u = (s - x)[(x > eps) & (x < 1 - eps)] / eps
     assert abs(u.mean().item()) < 5e-3 and abs(u.std().item() - 1 / np.sqrt(3)) < 5e-3
+
+
+def test_pgd_l1_art_matches_oracle_and_stays_in_the_l1_ball():
+    """pgd_l1 (ART PGD norm=1; parity unpinned -- ART is absent, the oracle restates its published algorithm): HIP kernels +
+    autograd gradients on the tiny CNN vs the oracle with the same injected start; AddNoise('pgd_l1') dispatch; L1-ball
+    and box invariants at ImageNet size with the native RNG."""
+    from robustart_amd.noise import AddNoise, adv
+    g, net = _gold_model()
+    netc = make_tinynet({k[4:]: g[k] for k in g.files if k.startswith('net/')}).cuda()
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    B, n = x.shape[0], x[0].numel()
+    rs = np.random.RandomState(5)
+    se = (rs.exponential(size=(B, n)) * rs.choice([-1.0, 1.0], size=(B, n))).astype(np.float32)
+    eps, eps_step, iters = 12.0, 1.5, 6
+    rad = np.sqrt(rs.uniform(0, eps ** 2, B)).astype(np.float32)
+
+    def loss_grad(xa, yy):
+        z = torch.from_numpy(xa).requires_grad_(True)
+        torch.nn.functional.cross_entropy(net(A.normalize(z)), torch.from_numpy(np.asarray(yy))).backward()
+        return z.grad.numpy()
+    want = A.pgd_l1_art(loss_grad, x.numpy(), y.numpy(), eps, eps_step, iters, se, rad)
+    got = adv.pgd_l1(x.cuda(), y.cuda(), netc, eps, 32, eps_step, iters, 16, init_signed_exp=torch.from_numpy(se),
+                     init_radius=torch.from_numpy(rad)).cpu()
+    torch.testing.assert_close(got, torch.from_numpy(want), atol=2e-5, rtol=0)
+    d = (got - x).flatten(1).abs().sum(1)
+    assert (d <= eps * (1 + 1e-5)).all() and got.min() >= 0 and got.max() <= 1
+    assert (d > 0.5 * eps).all()                                  # the steps (1.5 each) do fill the ball
+    # the plugin entry: same registry name / config keys as the reference (add_noise_utils.py:7-18)
+    an = AddNoise('pgd_l1')
+    an.set_config(model=netc, eps=eps, input_size=32, eps_step=eps_step, max_iter=3, batch_size=16)
+    out = an.add_noise(x.cuda(), y.cuda())
+    assert out.shape == x.shape and out.is_cuda
+    assert ((out.cpu() - x).flatten(1).abs().sum(1) <= eps * (1 + 1e-5)).all()
+    # native start at ImageNet size: radius <= eps, clipped to the box, different per sample, reproducible
+    x224 = _rand((3, 3, 224, 224), 1).cuda()
+    s1 = adv.random_start_l1(x224, 1600.0, seed=3)
+    s2 = adv.random_start_l1(x224, 1600.0, seed=3)
+    assert torch.equal(s1, s2)
+    dn = (s1 - x224).flatten(1).abs().sum(1)
+    assert (dn <= 1600.0 * (1 + 1e-5)).all() and (dn > 0).all() and s1.min() >= 0 and s1.max() <= 1
+    assert dn[0] != dn[1]
+    signs = torch.sign(s1 - x224).flatten(1)
+    assert abs(float(signs.mean())) < 0.02                        # random signs
