@@ -98,6 +98,15 @@ size_t rart_pil_resize_workspace_bytes(int n, int h, int w, int resize_h, int re
 int rart_pil_resize_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int resize_h, int resize_w, int filter,
                        int crop_y, int crop_x, int crop_h, int crop_w, void* workspace, size_t workspace_bytes,
                        rart_stream_t stream);
+/* The 'opencv-*' ImageNet-S resize operators (imagenet_s_gen.py:27-33,138-146): cv2.resize(img, (resize_w, resize_h),
+ * interpolation) on uint8 NHWC images followed by a crop.  interpolation = cv2 constant: 0 INTER_NEAREST, 1 INTER_LINEAR,
+ * 2 INTER_CUBIC, 3 INTER_AREA, 4 INTER_LANCZOS4.  Restates opencv/modules/imgproc/src/resize.cpp (4.x) -- OpenCV is an
+ * unpinned dependency absent from the build container: parity unpinned.  out: uint8 [n][crop_h][crop_w][3]. */
+size_t rart_cv_resize_workspace_bytes(int n, int h, int w, int resize_h, int resize_w, int interpolation, int crop_y,
+                                      int crop_x, int crop_h, int crop_w);
+int rart_cv_resize_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int resize_h, int resize_w, int interpolation,
+                      int crop_y, int crop_x, int crop_h, int crop_w, void* workspace, size_t workspace_bytes,
+                      rart_stream_t stream);
 
 /* uint8 NHWC -> ImageNet-normalised tensor for the model ((x/255 - mean)/std), i.e. the ToTensor +
  * Normalize step that follows AddNoise in the reference's eval pipeline

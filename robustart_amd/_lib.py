@@ -23,6 +23,8 @@ SIGNATURES = {
                                 ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
     'rart_pil_resize_workspace_bytes': (c_size_t, [c_int] * 10),
     'rart_pil_resize_u8': (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
+    'rart_cv_resize_workspace_bytes': (c_size_t, [c_int] * 10),
+    'rart_cv_resize_u8': (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     'rart_u8_to_normalized': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_rng_uniform_u32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),
     'rart_rng_normal_f32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),

@@ -3,9 +3,9 @@ ImageTransfer(return_online=True) (RobustART/noise/utils/add_noise_utils.py:34-3
 
 Decoding a file is host I/O (PIL, as the reference's 'pil' decoder); the resize operator -- the part that differs
 between the ImageNet-S variants and the part that is arithmetic -- runs on the GPU, bit-exact with Pillow, through
-rart_pil_resize_u8.  Not available in this build (raise NotImplementedError, loudly): the 'opencv' and 'ffmpeg'
-decoders and the five 'opencv-*' resize operators (OpenCV is not installed, nothing to pin them against), and the
-reference's memcached reader.  Unlike the reference (which passes float sizes to Image.resize and only works on
+rart_pil_resize_u8; the five 'opencv-*' operators run through rart_cv_resize_u8, a restatement of OpenCV's resize.cpp
+(OpenCV is not installed here, so those five are parity-unpinned -- see oracle/resize_cv_np.py).  Not available in this
+build (raise NotImplementedError, loudly): the 'opencv' and 'ffmpeg' decoders and the reference's memcached reader.  Unlike the reference (which passes float sizes to Image.resize and only works on
 Python <= 3.9, imagenet_s_gen.py:129,167) sizes are converted with int()."""
 import random
 
@@ -14,7 +14,8 @@ import numpy as np
 from .. import _lib
 
 PIL_FILTERS = {'pil-nearest': 0, 'pil-bilinear': 1, 'pil-cubic': 2, 'pil-box': 3, 'pil-hamming': 4, 'pil-lanczos': 5}
-CV_MODES = ('opencv-nearest', 'opencv-bilinear', 'opencv-area', 'opencv-cubic', 'opencv-lanczos')
+# imagenet_s_gen.py:27-33 -> cv2.INTER_* constants
+CV_MODES = {'opencv-nearest': 0, 'opencv-bilinear': 1, 'opencv-cubic': 2, 'opencv-area': 3, 'opencv-lanczos': 4}
 
 
 def pil_resize(batch_u8, resize_hw, filter_id, crop=None):
@@ -30,6 +31,21 @@ def pil_resize(batch_u8, resize_hw, filter_id, crop=None):
     ws = _lib.workspace(nb, batch_u8.device)
     _lib.check(lib.rart_pil_resize_u8(_lib.ptr(batch_u8), _lib.ptr(out), n, h, w, rh, rw, filter_id, cy, cx, ch, cw,
                                       _lib.ptr(ws), nb, _lib.stream_ptr()))
+    return out
+
+
+def cv_resize(batch_u8, resize_hw, interpolation, crop=None):
+    """batch_u8: CUDA uint8 (n,h,w,3) -> cv2.resize(img, (rw, rh), interpolation) then crop (cy, cx, ch, cw)."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    n, h, w, _ = batch_u8.shape
+    rh, rw = int(resize_hw[0]), int(resize_hw[1])
+    cy, cx, ch, cw = crop if crop is not None else (0, 0, rh, rw)
+    out = torch.empty(n, ch, cw, 3, dtype=torch.uint8, device=batch_u8.device)
+    nb = lib.rart_cv_resize_workspace_bytes(n, h, w, rh, rw, interpolation, cy, cx, ch, cw)
+    ws = _lib.workspace(nb, batch_u8.device)
+    _lib.check(lib.rart_cv_resize_u8(_lib.ptr(batch_u8), _lib.ptr(out), n, h, w, rh, rw, interpolation, cy, cx, ch, cw,
+                                     _lib.ptr(ws), nb, _lib.stream_ptr()))
     return out
 
 
@@ -73,22 +89,21 @@ def image_transfer(image, decoder_type='pil', resize_type='pil-bilinear', transf
     """ImageTransfer(file_path=image, ..., return_online=True).getimage(): (224,224,3) uint8 ndarray.  `image`: a file
     path / encoded bytes, or an already decoded HxWx3 uint8 array."""
     torch = _lib.require_gpu()
-    if resize_type in CV_MODES:
-        raise NotImplementedError('%s needs OpenCV semantics that cannot be pinned here (cv2 absent); the six pil-* '
-                                  'operators are available' % resize_type)
-    if resize_type not in PIL_FILTERS:
+    if resize_type not in PIL_FILTERS and resize_type not in CV_MODES:
         raise NotImplementedError(resize_type)
     arr = image if isinstance(image, np.ndarray) else decode(image, decoder_type)
     size = (resize, resize) if not isinstance(resize, tuple) else resize
-    f = PIL_FILTERS[resize_type]
+    is_cv = resize_type in CV_MODES
+    op = cv_resize if is_cv else pil_resize
+    f = CV_MODES[resize_type] if is_cv else PIL_FILTERS[resize_type]
     if transform_type == 'val':
-        first = tuple(int(s * 8 / 7) for s in size)                    # imagenet_s_gen.py:129
+        first = tuple(int(s * 8 / 7) for s in size)                    # imagenet_s_gen.py:129,139
         th, tw = size
         i, j = int(round((first[0] - th) / 2.)), int(round((first[1] - tw) / 2.))
         dev = torch.from_numpy(np.ascontiguousarray(arr)[None]).cuda()
-        return pil_resize(dev, first, f, crop=(i, j, th, tw))[0].cpu().numpy()
+        return op(dev, first, f, crop=(i, j, th, tw))[0].cpu().numpy()
     if transform_type == 'train':
         y, x, h, w = _train_params(arr.shape[:2], random.Random(seed))
         dev = torch.from_numpy(np.ascontiguousarray(arr[y:y + h, x:x + w])[None]).cuda()
-        return pil_resize(dev, size, f)[0].cpu().numpy()
+        return op(dev, size, f)[0].cpu().numpy()
     raise NotImplementedError(transform_type)

@@ -199,3 +199,22 @@ def test_foolbox_style_pgd_identities():
     assert (delta.flatten(1).norm(dim=1) <= 0.5 + 1e-6).all()
     adv = A.pgd_l2(model_fn, x, y, 0.5, 3 / 40, 5, init_delta=delta)
     assert ((adv - x).flatten(1).norm(dim=1) <= 0.5 + 1e-5).all() and adv.min() >= 0 and adv.max() <= 1
+
+
+def test_opencv_resize_oracle_invariants():
+    """oracle/resize_cv_np.py is parity-unpinned (cv2 absent): only its algebraic invariants can be checked here --
+    constants are fixed points, same-size resize is the identity, exact 2x2 decimation is the rounded 4-pixel mean for
+    both LINEAR and AREA, NEAREST picks floor(dx * scale)."""
+    from oracle import resize_cv_np as CV
+    flat = np.full((50, 70, 3), 201, np.uint8)
+    rs = np.random.RandomState(0)
+    x = rs.randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    for interp in range(5):
+        r = CV.resize(flat, (256, 256), interp)
+        assert r.shape == (256, 256, 3) and r.min() == 201 == r.max()
+        assert np.array_equal(CV.resize(x, (64, 48), interp), x)
+    ref = ((x.astype(np.int64).reshape(24, 2, 32, 2, 3).sum((1, 3)) + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(CV.resize(x, (32, 24), CV.LINEAR), ref) and np.array_equal(CV.resize(x, (32, 24), CV.AREA), ref)
+    nn = CV.resize(x, (100, 30), CV.NEAREST)
+    assert np.array_equal(nn[7, 13], x[int(np.floor(7 * 48 / 30)), int(np.floor(13 * 64 / 100))])
+    assert CV.imagenet_s_val(rs.randint(0, 256, (300, 400, 3)).astype(np.uint8), CV.CUBIC).shape == (224, 224, 3)
