@@ -320,6 +320,21 @@ int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads,
 int rart_vit_transpose_v(const void* qkv, void* vt, int n, int tokens, int heads, int head_dim, int qkv_ld, int v_off,
                          int t_pad, rart_stream_t stream);
 
+/* ViT-B/16 backward-to-input pieces (autograd through timm's VisionTransformer for the attack gradient); the
+ * contractions run on rart_conv_igemm_bf16 (batched for the per-head products).  bf16 storage, fp32 math. */
+int rart_gelu_bf16(const void* u, void* out, size_t n, rart_stream_t stream);            /* exact (erf) GELU */
+int rart_gelu_bwd_bf16(const void* dh, const void* u, void* du, size_t n, rart_stream_t stream);   /* du = dh*gelu'(u) */
+/* dx = LayerNorm backward to the input (statistics recomputed from x) [+ res]; strides in elements per row. */
+int rart_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const void* res, void* dx, int rows, int dim,
+                            int64_t dy_row_stride, int64_t x_row_stride, int64_t res_row_stride, int64_t dx_row_stride,
+                            float eps, rart_stream_t stream);
+/* dS = scale * P * (dP - rowsum(P*dP)) on [0, n_valid), zeros up to ld_out (soft-max backward, scale = 1/sqrt(head_dim)). */
+int rart_softmax_bwd_rows_bf16(const void* probs, const void* dprobs, void* dscores, int64_t rows, int n_valid, int ld_p,
+                               int ld_dp, int ld_out, float scale, rart_stream_t stream);
+/* grad[b][c][y][x] (fp32, w.r.t. the [0,1] image) from the patch-embedding input gradient [b*patches][ld >= 3*p*p]. */
+int rart_vit_unpatchify_f32(const void* dpatches, float* grad, int n, int h, int w, int patch, int64_t ld,
+                            const float* std_host, rart_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Training-side step kernels.  The solver the reference launches
  * (RobustART/train/__init__.py:1 -> absent submodule) is configured by

@@ -77,6 +77,14 @@ SIGNATURES = {
     'rart_softmax_rows_bf16': (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'rart_vit_attention': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_vit_transpose_v': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_gelu_bf16': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rart_gelu_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rart_layernorm_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_float, c_void_p]),
+    'rart_softmax_bwd_rows_bf16': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_float,
+                                           c_void_p]),
+    'rart_vit_unpatchify_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64,
+                                        ctypes.POINTER(c_float), c_void_p]),
     'rart_sgd_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double, c_double, c_int,
                                   c_double, c_double, c_int, c_void_p]),
     'rart_adamw_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double,

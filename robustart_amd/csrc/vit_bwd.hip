@@ -1,0 +1,176 @@
+// ViT-B/16 backward-to-input support kernels for gfx950: the pieces of `autograd(loss, x)` through timm's
+// VisionTransformer (model `vit_base`; reference use: the gradient step of every attack, adv/attack.py:21-22,
+// autopgd_base.py:271-289) that are not contractions.  The contractions -- all dgrad GEMMs and the five per-head
+// products of the attention backward (dP = dO V^T, dQ = dS K, dK = dS^T Q, dV = P^T dO, and the recomputed
+// S = Q K^T) -- run on rart_conv_igemm_bf16 as batched problems; transposed operands come from
+// rart_transpose_gather_bf16 / rart_vit_transpose_v.  HBM-bound row / elementwise kernels, bf16 storage, fp32 math.
+#include "rart_common.h"
+
+namespace {
+constexpr int kBlock = 256;
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  // d/dv [v * Phi(v)] = Phi(v) + v * phi(v)
+  return 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
+
+template <int BWD>
+__global__ __launch_bounds__(kBlock) void k_gelu(const uint4* __restrict__ a, const uint4* __restrict__ u,
+                                                 uint4* __restrict__ out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (size_t)gridDim.x * kBlock) {
+    const uint4 uv = u[i];
+    const uint32_t uw[4] = {uv.x, uv.y, uv.z, uv.w};
+    uint32_t aw[4] = {0, 0, 0, 0};
+    if (BWD) {
+      const uint4 av = a[i];
+      aw[0] = av.x; aw[1] = av.y; aw[2] = av.z; aw[3] = av.w;
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u0 = bf2f((uint16_t)(uw[j] & 0xFFFF)), u1 = bf2f((uint16_t)(uw[j] >> 16));
+      float r0, r1;
+      if (BWD) {
+        r0 = bf2f((uint16_t)(aw[j] & 0xFFFF)) * gelu_grad_f(u0);
+        r1 = bf2f((uint16_t)(aw[j] >> 16)) * gelu_grad_f(u1);
+      } else {
+        r0 = gelu_f(u0);
+        r1 = gelu_f(u1);
+      }
+      o[j] = f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// LayerNorm backward to the input, one wave per row (statistics recomputed from x in fp32):
+//   xhat = (x - mean) * rstd;  g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ res]
+__global__ __launch_bounds__(kBlock) void k_layernorm_bwd(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                          const float* __restrict__ gamma, const uint16_t* __restrict__ res,
+                                                          uint16_t* __restrict__ dx, int rows, int d, long long dy_stride,
+                                                          long long x_stride, long long res_stride, long long dx_stride,
+                                                          float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint16_t* xr = x + (size_t)row * x_stride;
+  const uint16_t* gr = dy + (size_t)row * dy_stride;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += bf2f(xr[c]);
+  const float mean = rart_wave_sum(s) / (float)d;
+  float v = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float t = bf2f(xr[c]) - mean;
+    v += t * t;
+  }
+  const float rstd = rsqrtf(rart_wave_sum(v) / (float)d + eps);
+  float sg = 0.f, sgx = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float g = bf2f(gr[c]) * gamma[c];
+    sg += g;
+    sgx += g * (bf2f(xr[c]) - mean) * rstd;
+  }
+  const float mg = rart_wave_sum(sg) / (float)d, mgx = rart_wave_sum(sgx) / (float)d;
+  uint16_t* o = dx + (size_t)row * dx_stride;
+  const uint16_t* rr = res ? res + (size_t)row * res_stride : nullptr;
+  for (int c = lane; c < d; c += 64) {
+    const float xh = (bf2f(xr[c]) - mean) * rstd;
+    float r = rstd * (bf2f(gr[c]) * gamma[c] - mg - xh * mgx);
+    if (rr) r += bf2f(rr[c]);
+    o[c] = f2bf(r);
+  }
+}
+
+// dS[row][c] = scale * P[row][c] * (dP[row][c] - sum_k P[row][k] dP[row][k]), c < n_valid; zeros up to ld_out
+__global__ __launch_bounds__(kBlock) void k_softmax_bwd_rows(const uint16_t* __restrict__ p, const uint16_t* __restrict__ dp,
+                                                             uint16_t* __restrict__ ds, long long rows, int n_valid, int ld_p,
+                                                             int ld_dp, int ld_out, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint16_t* pr = p + row * ld_p;
+  const uint16_t* dr = dp + row * ld_dp;
+  float dot = 0.f;
+  for (int c = lane; c < n_valid; c += 64) dot += bf2f(pr[c]) * bf2f(dr[c]);
+  dot = rart_wave_sum(dot);
+  uint16_t* o = ds + row * ld_out;
+  for (int c = lane; c < ld_out; c += 64)
+    o[c] = c < n_valid ? f2bf(scale * bf2f(pr[c]) * (bf2f(dr[c]) - dot)) : (uint16_t)0;
+}
+
+// grad[b][c][y][x] = dpatch[b][patch(y, x)][c*ps*ps + (y % ps)*ps + (x % ps)] * istd[c]   (fp32 NCHW, pixels in [0,1])
+struct Istd3 { float v[3]; };
+__global__ __launch_bounds__(kBlock) void k_unpatchify(const uint16_t* __restrict__ dp, float* __restrict__ grad, int n, int h,
+                                                       int w, int ps, long long ld, Istd3 is) {
+  const int gw = w / ps, gh = h / ps;
+  const size_t total = (size_t)n * 3 * h * w;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), c = (int)((i / ((size_t)w * h)) % 3);
+    const int img = (int)(i / ((size_t)3 * w * h));
+    const int px = x / ps, py = y / ps;
+    const size_t prow = (size_t)img * gh * gw + (size_t)py * gw + px;
+    grad[i] = bf2f(dp[prow * ld + (size_t)c * ps * ps + (y % ps) * ps + (x % ps)]) * is.v[c];
+  }
+}
+int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
+}  // namespace
+
+extern "C" {
+
+int rart_gelu_bf16(const void* u, void* out, size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(u && out && n > 0 && n % 8 == 0, "rart_gelu_bf16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(k_gelu<0>, dim3(grid_for(n / 8)), dim3(kBlock), 0, (hipStream_t)stream, nullptr, (const uint4*)u,
+                     (uint4*)out, n / 8);
+  RART_CHECK_LAUNCH("rart_gelu_bf16");
+  return RART_OK;
+}
+
+int rart_gelu_bwd_bf16(const void* dh, const void* u, void* du, size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(dh && u && du && n > 0 && n % 8 == 0, "rart_gelu_bwd_bf16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(k_gelu<1>, dim3(grid_for(n / 8)), dim3(kBlock), 0, (hipStream_t)stream, (const uint4*)dh,
+                     (const uint4*)u, (uint4*)du, n / 8);
+  RART_CHECK_LAUNCH("rart_gelu_bwd_bf16");
+  return RART_OK;
+}
+
+int rart_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const void* res, void* dx, int rows, int dim,
+                            int64_t dy_row_stride, int64_t x_row_stride, int64_t res_row_stride, int64_t dx_row_stride,
+                            float eps, rart_stream_t stream) {
+  RART_CHECK_ARG(dy && x && gamma && dx && rows > 0 && dim > 0, "rart_layernorm_bwd_bf16: bad arguments");
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3((rows + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint16_t*)dy, (const uint16_t*)x, gamma, (const uint16_t*)res, (uint16_t*)dx, rows, dim,
+                     (long long)dy_row_stride, (long long)x_row_stride, (long long)res_row_stride, (long long)dx_row_stride, eps);
+  RART_CHECK_LAUNCH("rart_layernorm_bwd_bf16");
+  return RART_OK;
+}
+
+int rart_softmax_bwd_rows_bf16(const void* probs, const void* dprobs, void* dscores, int64_t rows, int n_valid, int ld_p,
+                               int ld_dp, int ld_out, float scale, rart_stream_t stream) {
+  RART_CHECK_ARG(probs && dprobs && dscores && rows > 0 && n_valid > 0 && ld_p >= n_valid && ld_dp >= n_valid &&
+                     ld_out >= n_valid, "rart_softmax_bwd_rows_bf16: bad arguments");
+  hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((uint32_t)((rows + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const uint16_t*)probs, (const uint16_t*)dprobs, (uint16_t*)dscores,
+                     (long long)rows, n_valid, ld_p, ld_dp, ld_out, scale);
+  RART_CHECK_LAUNCH("rart_softmax_bwd_rows_bf16");
+  return RART_OK;
+}
+
+int rart_vit_unpatchify_f32(const void* dpatches, float* grad, int n, int h, int w, int patch, int64_t ld,
+                            const float* std_host, rart_stream_t stream) {
+  RART_CHECK_ARG(dpatches && grad && std_host && n > 0 && patch > 0 && h % patch == 0 && w % patch == 0 &&
+                     ld >= 3 * patch * patch, "rart_vit_unpatchify_f32: bad arguments");
+  Istd3 is;
+  for (int c = 0; c < 3; ++c) is.v[c] = 1.0f / std_host[c];
+  hipLaunchKernelGGL(k_unpatchify, dim3(grid_for((size_t)n * 3 * h * w)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint16_t*)dpatches, grad, n, h, w, patch, (long long)ld, is);
+  RART_CHECK_LAUNCH("rart_vit_unpatchify_f32");
+  return RART_OK;
+}
+
+}  // extern "C"

@@ -367,8 +367,8 @@ class ResNet50Engine:
 
 
 def make_engine(torch_model, device='cuda'):
-    """HIP engine for a model from robustart_amd.model.get_model: ResNet-50 (forward + backward-to-input) or
-    ViT-B/16 (forward only: attacks on it fall back to torch autograd in robustart_amd.noise.adv)."""
+    """HIP engine for a model from robustart_amd.model.get_model: ResNet-50 or ViT-B/16, each with forward and
+    backward-to-input (`forward_backward`) on the hand-written kernels."""
     from .resnet_torch import ResNet
     from .vit_torch import VisionTransformer
     if isinstance(torch_model, ResNet):

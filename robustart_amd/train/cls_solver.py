@@ -136,13 +136,9 @@ def evaluate(cfg, args, rank, world, device, model=None):
     use_hip = device.type == 'cuda' and args.engine == 'hip'
     noise = None
     if use_hip:
-        from ..model.engine import EngineModel, ResNet50Engine
+        from ..model.engine import EngineModel
         f_model = EngineModel(model, takes_normalized=False)
         n_model = EngineModel(None, takes_normalized=True, engine=f_model.rart_engine)
-        if not isinstance(f_model.rart_engine, ResNet50Engine):
-            # forward-only engine (ViT-B/16): clean / corrupted evaluation runs on HIP, gradient attacks would need
-            # the backward pass and go through torch autograd on the plain module instead
-            grad_model = model
     if args.corruption:
         from ..noise import AddNoise
         noise = AddNoise('imagenet-c')
@@ -154,13 +150,7 @@ def evaluate(cfg, args, rank, world, device, model=None):
         key = 'f_model' if 'f_model' in attack.config else 'model'
         if not use_hip:
             raise RuntimeError('attacks need the GPU path (no CPU fallback)')
-        from ..model.engine import ResNet50Engine as _R50
-        if isinstance(f_model.rart_engine, _R50):
-            attack.config[key] = f_model if key == 'f_model' else n_model
-        else:
-            mean_t = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
-            std_t = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
-            attack.config[key] = (lambda z: grad_model((z - mean_t) / std_t)) if key == 'f_model' else grad_model
+        attack.config[key] = f_model if key == 'f_model' else n_model      # ResNet-50 and ViT-B/16: HIP forward + backward
         attack.config['eps'] = parse_eps(args.eps)
         if 'steps' in attack.config and args.steps:
             attack.config['steps'] = args.steps

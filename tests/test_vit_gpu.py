@@ -87,3 +87,106 @@ def test_fused_attention_matches_torch_and_unfused_path(setup):
     out2 = torch.empty_like(out)
     eng._attention_unfused(qkv, scores, probs, vt, out2, B, T, s_ld, t_pad)
     assert (out2.float() - ref).abs().max().item() < 0.03 * ref.abs().max().item() + 2e-2
+
+
+def test_vit_backward_kernels():
+    """GELU, GELU', LayerNorm backward, soft-max backward rows, un-patchify vs torch."""
+    from robustart_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(2)
+    u = (torch.randn(64, 3072, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    dh = torch.randn(64, 3072, generator=g).to(torch.bfloat16).cuda()
+    out, du = torch.empty_like(u), torch.empty_like(u)
+    _lib.check(lib.rart_gelu_bf16(_lib.ptr(u), _lib.ptr(out), u.numel(), _lib.stream_ptr()))
+    _lib.check(lib.rart_gelu_bwd_bf16(_lib.ptr(dh), _lib.ptr(u), _lib.ptr(du), u.numel(), _lib.stream_ptr()))
+    ut = u.float().requires_grad_(True)
+    yt = torch.nn.functional.gelu(ut)
+    yt.backward(dh.float())
+    torch.testing.assert_close(out.float(), yt.detach(), atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(du.float(), ut.grad, atol=2e-2, rtol=1e-2)
+    # LayerNorm backward with residual
+    x = (torch.randn(37, 768, generator=g) * 2 + 0.3).to(torch.bfloat16).cuda()
+    dy = torch.randn(37, 768, generator=g).to(torch.bfloat16).cuda()
+    res = torch.randn(37, 768, generator=g).to(torch.bfloat16).cuda()
+    gam = (1 + 0.1 * torch.randn(768, generator=g)).cuda()
+    dx = torch.empty_like(x)
+    _lib.check(lib.rart_layernorm_bwd_bf16(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(gam), _lib.ptr(res), _lib.ptr(dx), 37, 768, 768,
+                                           768, 768, 768, 1e-6, _lib.stream_ptr()))
+    xt = x.float().requires_grad_(True)
+    torch.nn.functional.layer_norm(xt, (768,), gam, torch.zeros(768, device='cuda'), 1e-6).backward(dy.float())
+    torch.testing.assert_close(dx.float(), xt.grad + res.float(), atol=3e-2, rtol=2e-2)
+    # soft-max backward rows
+    s = (torch.randn(50, 197, generator=g) * 3).cuda()
+    p = torch.softmax(s * 0.125, 1)
+    pb = torch.zeros(50, 224, dtype=torch.bfloat16, device='cuda')
+    pb[:, :197] = p.to(torch.bfloat16)
+    dp = torch.zeros(50, 200, dtype=torch.bfloat16, device='cuda')
+    dp[:, :197] = torch.randn(50, 197, generator=g).to(torch.bfloat16).cuda()
+    ds = torch.full((50, 224), 9.0, dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.rart_softmax_bwd_rows_bf16(_lib.ptr(pb), _lib.ptr(dp), _lib.ptr(ds), 50, 197, 224, 200, 224, 0.125,
+                                              _lib.stream_ptr()))
+    pf, df = pb[:, :197].float(), dp[:, :197].float()
+    ref = 0.125 * pf * (df - (pf * df).sum(1, keepdim=True))
+    torch.testing.assert_close(ds[:, :197].float(), ref, atol=2e-3, rtol=2e-2)
+    assert torch.count_nonzero(ds[:, 197:]).item() == 0
+    # un-patchify: inverse layout of rart_vit_patchify, scaled by 1/std
+    B, ps, H = 2, 16, 64
+    P, kk = (H // ps) ** 2, 3 * ps * ps
+    dpat = torch.randn(B * P, kk, generator=g).to(torch.bfloat16).cuda()
+    grad = torch.empty(B, 3, H, H, device='cuda')
+    _lib.check(lib.rart_vit_unpatchify_f32(_lib.ptr(dpat), _lib.ptr(grad), B, H, H, ps, kk, (ctypes.c_float * 3)(*STD),
+                                           _lib.stream_ptr()))
+    ref = dpat.float().view(B, H // ps, H // ps, 3, ps, ps).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, H, H)
+    ref = ref / torch.tensor(STD, device='cuda').view(1, 3, 1, 1)
+    torch.testing.assert_close(grad, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('kind', [0, 1])
+def test_vit_backward_to_input_matches_torch_autograd(setup, kind):
+    """forward_backward (every GEMM and attention product on the igemm kernel) vs torch autograd through the fp32 module."""
+    from robustart_amd.noise.adv import logit_loss
+    m, eng = setup
+    torch.manual_seed(5)
+    B = 4
+    x01 = torch.rand(B, 3, 224, 224, device='cuda')
+    y = torch.randint(0, 1000, (B,), device='cuda')
+    logits, loss, grad, pred = eng.forward_backward(x01, MEAN, STD, y, kind)
+    mean = torch.tensor(MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(STD, device='cuda').view(1, 3, 1, 1)
+    xr = x01.clone().requires_grad_(True)
+    out = m((xr - mean) / std)
+    # same upstream gradient on both sides: the DLR loss picks the top-3 logits, and on random-init weights the
+    # engine's bf16 logits (within 2 % of the scale) order near-ties differently from fp32
+    g_ref, = torch.autograd.grad(out, xr, grad_outputs=eng.last_dlogits)
+    if kind == 0:
+        l_ref, _, _ = logit_loss(out, y, kind, None, 1.0)
+        torch.testing.assert_close(loss, l_ref, rtol=2e-2, atol=2e-2)
+    scale = out.detach().abs().max()
+    assert (logits - out.detach()).abs().max() < 0.02 * scale
+    assert pred.tolist() == out.argmax(1).tolist()
+    a, b = grad.double().flatten(), g_ref.double().flatten()
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    rel = float((a - b).norm() / b.norm())
+    print('ViT grad cos %.5f rel %.4f' % (cos, rel))
+    assert cos > 0.995 and rel < 0.1
+    for i in range(B):                                      # per-sample directions too
+        ai, bi = grad[i].double().flatten(), g_ref[i].double().flatten()
+        assert float((ai @ bi) / (ai.norm() * bi.norm())) > 0.99
+
+
+def test_pgd_on_vit_runs_on_the_hip_engine(setup):
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.noise import AddNoise
+    m, eng = setup
+    torch.manual_seed(6)
+    x01 = torch.rand(3, 3, 224, 224, device='cuda')
+    y = torch.randint(0, 1000, (3,), device='cuda')
+    f_model = EngineModel(None, takes_normalized=False, engine=eng)
+    an = AddNoise('pgd_linf')
+    an.set_config(f_model=f_model, eps=4 / 255, steps=3)
+    adv_x = an.add_noise(x01, y)
+    assert (adv_x - x01).abs().max() <= 4 / 255 + 1e-6 and adv_x.min() >= 0 and adv_x.max() <= 1
+    clean = torch.nn.functional.cross_entropy(eng.logits(x01, MEAN, STD), y)
+    attacked = torch.nn.functional.cross_entropy(eng.logits(adv_x, MEAN, STD), y)
+    assert attacked > clean                                  # the gradient points uphill
