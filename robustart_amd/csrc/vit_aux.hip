@@ -51,7 +51,32 @@ __global__ __launch_bounds__(kBlock) void k_add_pos_cls(uint16_t* __restrict__ x
   }
 }
 
-// LayerNorm over the last dim, one wave per row, fp32 two-pass statistics
+// ---- row kernels: one wave per row, the row lives in registers as 16-byte vectors (lane l holds vectors l and l + 64),
+//      so every tensor is read exactly once with coalesced 16-byte loads.  Rows of up to 1024 elements, multiple of 8.
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = __uint_as_float(w[j] << 16);
+    f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                    f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+}
+// loads the row's vectors v (< nv) into r[2][8] (zeros elsewhere)
+__device__ __forceinline__ void load_row(const uint16_t* row, int nv, int lane, float r[2][8]) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = lane + 64 * k;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (v < nv) q = *reinterpret_cast<const uint4*>(row + (size_t)v * 8);
+    unpack8(q, r[k]);
+  }
+}
+
+// LayerNorm over the last dim, fp32 two-pass statistics
 __global__ __launch_bounds__(kBlock) void k_layernorm(const uint16_t* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, uint16_t* __restrict__ out,
                                                       int rows, int d, long long in_stride, long long out_stride,
@@ -59,46 +84,101 @@ __global__ __launch_bounds__(kBlock) void k_layernorm(const uint16_t* __restrict
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const uint16_t* xr = x + (size_t)row * in_stride;
+  const int nv = d / 8;
+  float xr[2][8];
+  load_row(x + (size_t)row * in_stride, nv, lane, xr);
   float s = 0.f;
-  for (int c = lane; c < d; c += 64) s += bf2f(xr[c]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += xr[k][j];                   // padding vectors are zero
   const float mean = rart_wave_sum(s) / (float)d;
   float v = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const float t = bf2f(xr[c]) - mean;
-    v += t * t;
-  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (lane + 64 * k < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = xr[k][j] - mean;
+        v += t * t;
+      }
+    }
   const float rstd = rsqrtf(rart_wave_sum(v) / (float)d + eps);
   uint16_t* o = out + (size_t)row * out_stride;
-  for (int c = lane; c < d; c += 64) o[c] = f2bf((bf2f(xr[c]) - mean) * rstd * g[c] + b[c]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int vi = lane + 64 * k;
+    if (vi < nv) {
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (xr[k][j] - mean) * rstd * g[vi * 8 + j] + b[vi * 8 + j];
+      *reinterpret_cast<uint4*>(o + (size_t)vi * 8) = pack8(r);
+    }
+  }
 }
 
-// P[row][0..n_valid) = softmax(scale * S[row][0..n_valid)), P[row][n_valid..ld_out) = 0; one wave per row
+// P[row][0..n_valid) = softmax(scale * S[row][0..n_valid)), P[row][n_valid..ld_out) = 0
 __global__ __launch_bounds__(kBlock) void k_softmax_rows(const uint16_t* __restrict__ sm, uint16_t* __restrict__ pm,
                                                          long long rows, int n_valid, int ld_in, int ld_out,
                                                          float scale) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const uint16_t* sr = sm + row * ld_in;
-  uint16_t* pr = pm + row * ld_out;
+  float sr[2][8];
+  load_row(sm + row * ld_in, ld_in / 8, lane, sr);
   float mx = -INFINITY;
-  for (int c = lane; c < n_valid; c += 64) mx = fmaxf(mx, bf2f(sr[c]) * scale);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if ((lane + 64 * k) * 8 + j < n_valid) mx = fmaxf(mx, sr[k][j] * scale);
   mx = rart_wave_max(mx);
   float sum = 0.f;
-  for (int c = lane; c < n_valid; c += 64) sum += __expf(bf2f(sr[c]) * scale - mx);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = (lane + 64 * k) * 8 + j < n_valid;
+      sr[k][j] = ok ? __expf(sr[k][j] * scale - mx) : 0.f;
+      sum += sr[k][j];
+    }
   const float inv = 1.0f / rart_wave_sum(sum);
-  for (int c = lane; c < ld_out; c += 64) pr[c] = c < n_valid ? f2bf(__expf(bf2f(sr[c]) * scale - mx) * inv) : (uint16_t)0;
+  uint16_t* pr = pm + row * ld_out;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int vi = lane + 64 * k;
+    if (vi < ld_out / 8) {
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = sr[k][j] * inv;
+      *reinterpret_cast<uint4*>(pr + (size_t)vi * 8) = pack8(r);
+    }
+  }
 }
 
-// vt[b][h][dd][t] = qkv[b][t][v_off + h*hd + dd] (t < T), 0 for T <= t < t_pad
+// vt[b][h][dd][t] = qkv[b][t][v_off + h*hd + dd] (t < T), 0 for T <= t < t_pad: 64 tokens x 64 dims per workgroup
+// through LDS (head_dim == 64); reads are 128-byte rows, writes 128-byte runs of tokens.
 __global__ __launch_bounds__(kBlock) void k_transpose_v(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ vt,
                                                         int n, int t, int heads, int hd, int ld, int v_off, int t_pad) {
-  const size_t total = (size_t)n * heads * hd * t_pad;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const int tok = (int)(i % t_pad), dd = (int)((i / t_pad) % hd), hh = (int)((i / ((size_t)t_pad * hd)) % heads);
-    const int img = (int)(i / ((size_t)t_pad * hd * heads));
-    vt[i] = tok < t ? qkv[((size_t)img * t + tok) * ld + v_off + hh * hd + dd] : (uint16_t)0;
+  __shared__ uint16_t tile[64][72];
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * 64, bh = blockIdx.y, img = bh / heads, hh = bh - img * heads;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = tid / 8 + 32 * i, ch = tid % 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t0 + r < t) v = *reinterpret_cast<const uint4*>(qkv + ((size_t)img * t + t0 + r) * ld + v_off + hh * hd + ch * 8);
+    *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int dd = tid / 8 + 32 * i, tc = tid % 8;
+    if (t0 + tc * 8 >= t_pad) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[tc * 8 + 2 * j][dd] | ((uint32_t)tile[tc * 8 + 2 * j + 1][dd] << 16);
+    *reinterpret_cast<uint4*>(vt + ((size_t)bh * hd + dd) * t_pad + t0 + tc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
@@ -252,6 +332,8 @@ int rart_vit_add_pos_cls(void* x, const float* cls_pos0, const float* pos, int n
 int rart_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int rows, int dim,
                         int64_t in_row_stride, int64_t out_row_stride, float eps, rart_stream_t stream) {
   RART_CHECK_ARG(x && gamma && beta && out && rows > 0 && dim > 0, "rart_layernorm_bf16: bad arguments");
+  RART_CHECK_ARG(dim % 8 == 0 && dim <= 1024 && in_row_stride % 8 == 0 && out_row_stride % 8 == 0,
+                 "rart_layernorm_bf16: dim must be a multiple of 8, at most 1024; row strides multiples of 8");
   hipLaunchKernelGGL(k_layernorm, dim3((rows + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, (hipStream_t)stream,
                      (const uint16_t*)x, gamma, beta, (uint16_t*)out, rows, dim, (long long)in_row_stride,
                      (long long)out_row_stride, eps);
@@ -263,6 +345,8 @@ int rart_softmax_rows_bf16(const void* scores, void* probs, int64_t rows, int n_
                            float scale, rart_stream_t stream) {
   RART_CHECK_ARG(scores && probs && rows > 0 && n_valid > 0 && ld_in >= n_valid && ld_out >= n_valid,
                  "rart_softmax_rows_bf16: bad arguments");
+  RART_CHECK_ARG(ld_in % 8 == 0 && ld_out % 8 == 0 && ld_in <= 1024 && ld_out <= 1024,
+                 "rart_softmax_rows_bf16: leading dimensions must be multiples of 8, at most 1024");
   hipLaunchKernelGGL(k_softmax_rows, dim3((uint32_t)((rows + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
                      (hipStream_t)stream, (const uint16_t*)scores, (uint16_t*)probs, (long long)rows, n_valid, ld_in,
                      ld_out, scale);
@@ -285,9 +369,10 @@ int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads,
 int rart_vit_transpose_v(const void* qkv, void* vt, int n, int tokens, int heads, int head_dim, int qkv_ld, int v_off,
                          int t_pad, rart_stream_t stream) {
   RART_CHECK_ARG(qkv && vt && n > 0 && tokens > 0 && t_pad >= tokens, "rart_vit_transpose_v: bad arguments");
-  hipLaunchKernelGGL(k_transpose_v, dim3(grid_for((size_t)n * heads * head_dim * t_pad)), dim3(kBlock), 0,
-                     (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)vt, n, tokens, heads, head_dim, qkv_ld, v_off,
-                     t_pad);
+  RART_CHECK_ARG(head_dim == 64 && t_pad % 8 == 0 && qkv_ld % 8 == 0 && v_off % 8 == 0,
+                 "rart_vit_transpose_v: head_dim must be 64; t_pad, qkv_ld and v_off multiples of 8");
+  hipLaunchKernelGGL(k_transpose_v, dim3((t_pad + 63) / 64, n * heads), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint16_t*)qkv, (uint16_t*)vt, n, tokens, heads, head_dim, qkv_ld, v_off, t_pad);
   RART_CHECK_LAUNCH("rart_vit_transpose_v");
   return RART_OK;
 }

@@ -49,7 +49,30 @@ __global__ __launch_bounds__(kBlock) void k_gelu(const uint4* __restrict__ a, co
   }
 }
 
-// LayerNorm backward to the input, one wave per row (statistics recomputed from x in fp32):
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = __uint_as_float(w[j] << 16);
+    f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                    f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+}
+__device__ __forceinline__ void load_row(const uint16_t* row, int nv, int lane, float r[2][8]) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = lane + 64 * k;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (v < nv) q = *reinterpret_cast<const uint4*>(row + (size_t)v * 8);
+    unpack8(q, r[k]);
+  }
+}
+
+// LayerNorm backward to the input, one wave per row, rows held in registers as 16-byte vectors (every tensor is read
+// once); statistics recomputed from x in fp32:
 //   xhat = (x - mean) * rstd;  g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ res]
 __global__ __launch_bounds__(kBlock) void k_layernorm_bwd(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                           const float* __restrict__ gamma, const uint16_t* __restrict__ res,
@@ -59,31 +82,56 @@ __global__ __launch_bounds__(kBlock) void k_layernorm_bwd(const uint16_t* __rest
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const uint16_t* xr = x + (size_t)row * x_stride;
-  const uint16_t* gr = dy + (size_t)row * dy_stride;
+  const int nv = d / 8;
+  float xr[2][8], gr[2][8];
+  load_row(x + (size_t)row * x_stride, nv, lane, xr);
+  load_row(dy + (size_t)row * dy_stride, nv, lane, gr);
   float s = 0.f;
-  for (int c = lane; c < d; c += 64) s += bf2f(xr[c]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += xr[k][j];
   const float mean = rart_wave_sum(s) / (float)d;
   float v = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const float t = bf2f(xr[c]) - mean;
-    v += t * t;
-  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (lane + 64 * k < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = xr[k][j] - mean;
+        v += t * t;
+      }
+    }
   const float rstd = rsqrtf(rart_wave_sum(v) / (float)d + eps);
   float sg = 0.f, sgx = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const float g = bf2f(gr[c]) * gamma[c];
-    sg += g;
-    sgx += g * (bf2f(xr[c]) - mean) * rstd;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int vi = lane + 64 * k;
+    if (vi < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gr[k][j] *= gamma[vi * 8 + j];
+        xr[k][j] = (xr[k][j] - mean) * rstd;                     // xhat
+        sg += gr[k][j];
+        sgx += gr[k][j] * xr[k][j];
+      }
+    }
   }
   const float mg = rart_wave_sum(sg) / (float)d, mgx = rart_wave_sum(sgx) / (float)d;
   uint16_t* o = dx + (size_t)row * dx_stride;
-  const uint16_t* rr = res ? res + (size_t)row * res_stride : nullptr;
-  for (int c = lane; c < d; c += 64) {
-    const float xh = (bf2f(xr[c]) - mean) * rstd;
-    float r = rstd * (bf2f(gr[c]) * gamma[c] - mg - xh * mgx);
-    if (rr) r += bf2f(rr[c]);
-    o[c] = f2bf(r);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int vi = lane + 64 * k;
+    if (vi < nv) {
+      float r[8], rs[8];
+      if (res) unpack8(*reinterpret_cast<const uint4*>(res + (size_t)row * res_stride + (size_t)vi * 8), rs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        r[j] = rstd * (gr[k][j] - mg - xr[k][j] * mgx);
+        if (res) r[j] += rs[j];
+      }
+      *reinterpret_cast<uint4*>(o + (size_t)vi * 8) = pack8(r);
+    }
   }
 }
 
@@ -94,14 +142,27 @@ __global__ __launch_bounds__(kBlock) void k_softmax_bwd_rows(const uint16_t* __r
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const uint16_t* pr = p + row * ld_p;
-  const uint16_t* dr = dp + row * ld_dp;
+  float pr[2][8], dr[2][8];
+  load_row(p + row * ld_p, ld_p / 8, lane, pr);
+  load_row(dp + row * ld_dp, ld_dp / 8, lane, dr);
   float dot = 0.f;
-  for (int c = lane; c < n_valid; c += 64) dot += bf2f(pr[c]) * bf2f(dr[c]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if ((lane + 64 * k) * 8 + j < n_valid) dot += pr[k][j] * dr[k][j];
   dot = rart_wave_sum(dot);
   uint16_t* o = ds + row * ld_out;
-  for (int c = lane; c < ld_out; c += 64)
-    o[c] = c < n_valid ? f2bf(scale * bf2f(pr[c]) * (bf2f(dr[c]) - dot)) : (uint16_t)0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int vi = lane + 64 * k;
+    if (vi < ld_out / 8) {
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (vi * 8 + j < n_valid) ? scale * pr[k][j] * (dr[k][j] - dot) : 0.f;
+      *reinterpret_cast<uint4*>(o + (size_t)vi * 8) = pack8(r);
+    }
+  }
 }
 
 // grad[b][c][y][x] = dpatch[b][patch(y, x)][c*ps*ps + (y % ps)*ps + (x % ps)] * istd[c]   (fp32 NCHW, pixels in [0,1])
@@ -143,6 +204,8 @@ int rart_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, c
                             int64_t dy_row_stride, int64_t x_row_stride, int64_t res_row_stride, int64_t dx_row_stride,
                             float eps, rart_stream_t stream) {
   RART_CHECK_ARG(dy && x && gamma && dx && rows > 0 && dim > 0, "rart_layernorm_bwd_bf16: bad arguments");
+  RART_CHECK_ARG(dim % 8 == 0 && dim <= 1024 && dy_row_stride % 8 == 0 && x_row_stride % 8 == 0 && res_row_stride % 8 == 0 &&
+                     dx_row_stride % 8 == 0, "rart_layernorm_bwd_bf16: dim a multiple of 8, at most 1024; strides multiples of 8");
   hipLaunchKernelGGL(k_layernorm_bwd, dim3((rows + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, (hipStream_t)stream,
                      (const uint16_t*)dy, (const uint16_t*)x, gamma, (const uint16_t*)res, (uint16_t*)dx, rows, dim,
                      (long long)dy_row_stride, (long long)x_row_stride, (long long)res_row_stride, (long long)dx_row_stride, eps);
@@ -154,6 +217,8 @@ int rart_softmax_bwd_rows_bf16(const void* probs, const void* dprobs, void* dsco
                                int ld_dp, int ld_out, float scale, rart_stream_t stream) {
   RART_CHECK_ARG(probs && dprobs && dscores && rows > 0 && n_valid > 0 && ld_p >= n_valid && ld_dp >= n_valid &&
                      ld_out >= n_valid, "rart_softmax_bwd_rows_bf16: bad arguments");
+  RART_CHECK_ARG(ld_p % 8 == 0 && ld_dp % 8 == 0 && ld_out % 8 == 0 && ld_p <= 1024 && ld_dp <= 1024 && ld_out <= 1024,
+                 "rart_softmax_bwd_rows_bf16: leading dimensions must be multiples of 8, at most 1024");
   hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((uint32_t)((rows + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
                      (hipStream_t)stream, (const uint16_t*)probs, (const uint16_t*)dprobs, (uint16_t*)dscores,
                      (long long)rows, n_valid, ld_p, ld_dp, ld_out, scale);
