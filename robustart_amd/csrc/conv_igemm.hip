@@ -1,5 +1,6 @@
-// bf16 implicit-GEMM convolution for gfx950 (CDNA4): the one dense-contraction kernel of the
-// eval-mode ResNet-50 forward / backward-to-input engine (K22 in SURVEY.md 2.1).
+// bf16 implicit-GEMM convolution for gfx950 (CDNA4): the one dense-contraction kernel of the engines -- ResNet-50
+// eval forward / backward-to-input, its train-mode forward / backward / weight gradients, and every GEMM of ViT-B/16
+// forward and backward-to-input (K22 in SURVEY.md 2.1).
 //
 //   C[m][n] = sum_k A[m][k] * W[n][k]        A gathered on the fly from an NHWC bf16 tensor
 //
@@ -10,14 +11,19 @@
 // strided destination), the 7x7 stem on a pre-padded 4-channel image (a "tap" = one filter row of
 // 8 pixels x 4 channels, hi/lo bf16 split of the fp32 pixels as extra taps), and plain GEMMs (fc).
 //
-// Design for MI355X: 128 x {128,64} x 32 block tile, 4 wave64s each owning a 64 x {64,32} sub-tile
-// of v_mfma_f32_32x32x16_bf16 fragments (fp32 accumulate); A/B staged global -> VGPR -> LDS as 16-byte
-// vectors, double-buffered, one barrier per K step; LDS rows padded to 80 B so ds_read_b128 fragment
-// reads are bank-conflict free; epilogue transposes through LDS (fp32) so bias / residual / ReLU-mask /
-// ReLU are applied on 16-byte rows and stores are coalesced 16 B per lane; block ids are remapped so
-// the column tiles of one row tile run on the same XCD (shared L2 for the re-read A tile).
-// Most ResNet-50 layers are HBM-bound at bf16 (K = 64..512), so the kernel is built around wide
-// coalesced traffic first and MFMA issue second.
+// Design for MI355X: 128 x {128,64} x {32,64} block tile, 4 wave64s each owning a 64 x {64,32} sub-tile of
+// v_mfma_f32_32x32x16_bf16 fragments (fp32 accumulate, started at the column's bias); A/B staged
+// global -> VGPR -> LDS as 16-byte vectors, double-buffered, one barrier per K step (BK 32: two register sets, loads two
+// K steps ahead; BK 64 for K >= 1024: one set, half the barriers per FLOP); LDS rows padded to 80 / 144 B so
+// ds_read_b128 fragment reads are bank-conflict free; in the epilogue each wave transposes its own sub-tile through a
+// private LDS region (no block barrier after the last MFMA), adds the residual, packs with v_cvt_pk_bf16_f32, applies
+// ReLU / the ReLU mask on packed pairs (v_pk_max_i16) and stores coalesced 16-byte rows; the pixel index is decoded with
+// host-computed multiply-shift constants; block ids are remapped so the column tiles of one row tile run on the same XCD
+// (shared L2 for the re-read A tile) unless there are fewer than 16 row tiles (short-M GEMMs: split-K weight gradients,
+// per-head attention products), which keep plain order so all XCDs work.  Batched problems (blockIdx.y) shift the
+// operand bases per z: attention products and split-K partial sums run as one launch.
+// Most ResNet-50 layers are HBM-bound at bf16 (K = 64..512), so the kernel is built around wide coalesced traffic first
+// and MFMA issue second (DESIGN.md 4.3 has the measured breakdown).
 #include "rart_common.h"
 #include <type_traits>
 
