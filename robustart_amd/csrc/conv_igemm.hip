@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 }  // namespace
 
 // tuning knob (tests / profiling): smallest K that takes the BK = 64 pipeline; a huge value disables it
-static long long g_bk64_min_k = 1024;   // A/B on MI355X: ResNet-50 fwd+bwd 14.4 (never) / 13.8 (256) / 13.3 ms (1024)
+static long long g_bk64_min_k = 256;    // A/B on MI355X (scratch/ab_bk64.py): ResNet-50 fwd+bwd 13.2 (never) / 12.0 (1024) / 11.9 ms (256)
 extern "C" int rart_igemm_set_bk64_min_k(long long k) {
   g_bk64_min_k = k;
   return RART_OK;

@@ -15,14 +15,6 @@ from .. import _lib
 F_RELU, F_OUT_F32, F_GELU = 1, 2, 4
 
 
-def _pad_rows(w, mult):
-    import torch
-    r = (w.shape[0] + mult - 1) // mult * mult
-    if r == w.shape[0]:
-        return w
-    return torch.cat([w, torch.zeros(r - w.shape[0], w.shape[1], dtype=w.dtype)], 0)
-
-
 class ViTEngine:
     def __init__(self, model, device='cuda'):
         torch = _lib.require_gpu()
@@ -31,21 +23,45 @@ class ViTEngine:
         m = model
         self.D, self.H, self.ps = m.embed_dim, m.num_heads, m.patch_size
         self.hd = self.D // self.H
-        dev = self.device
+        self.refold(model)
+        self._buf = {}
+        self.fused_attention = True
+
+    def refold(self, model):
+        """(Re)build every weight table from `model`'s current parameters.  Parameters already on the GPU are packed
+        there (a dozen small torch ops per layer), so the adversarial-training loop can refresh the attack engine every
+        iteration, like ResNet50Engine.refold."""
+        torch = _lib.require_gpu()
+        m, dev = model, self.device
+
+        def bf(w2d):                                         # fp32 [rows][k] (any device) -> bf16 on the engine's device
+            return w2d.detach().to(dev, torch.float32).to(torch.bfloat16)
+
+        def pad_rows(w, mult):
+            r = (w.shape[0] + mult - 1) // mult * mult
+            if r == w.shape[0]:
+                return w.contiguous()
+            return torch.cat([w, torch.zeros(r - w.shape[0], w.shape[1], dtype=w.dtype, device=w.device)], 0).contiguous()
 
         def wt(linear_w, n_cols):
-            w = linear_w.detach().float().cpu().to(torch.bfloat16).float()
-            return _pad_rows(w, 128 if n_cols > 64 else 64).to(torch.bfloat16).contiguous().to(dev)
+            return pad_rows(bf(linear_w), 128 if n_cols > 64 else 64)
+
+        def wd(linear_w, k_pad=None):
+            """backward-to-input table: dx[rows][in] = dy[rows][out] . W  ->  rows = in features, K = out features"""
+            w = bf(linear_w).t()
+            if k_pad is not None and k_pad > w.shape[1]:
+                w = torch.cat([w, torch.zeros(w.shape[0], k_pad - w.shape[1], dtype=w.dtype, device=dev)], 1)
+            return pad_rows(w, 128 if w.shape[0] > 64 else 64)
 
         def f32(t):
-            return t.detach().float().contiguous().to(dev)
-        pe = m.patch_embed.weight.detach().float().cpu().reshape(self.D, -1)       # [D][c*ps*ps + r*ps + s]
-        peb = pe.to(torch.bfloat16).float()
-        self.pe_w = _pad_rows(torch.cat([peb, peb], 1), 128).to(torch.bfloat16).contiguous().to(dev)   # hi | lo taps
+            return t.detach().to(dev, torch.float32).contiguous()
+        pe = m.patch_embed.weight.detach().reshape(self.D, -1)                         # [D][c*ps*ps + r*ps + s]
+        peb = bf(pe)
+        self.pe_w = pad_rows(torch.cat([peb, peb], 1), 128)                            # hi | lo taps
         self.pe_b = f32(m.patch_embed.bias)
-        pos = m.pos_embed.detach().float()[0]
-        self.pos = pos.contiguous().to(dev)
-        self.cls_pos0 = (m.cls_token.detach().float()[0, 0] + pos[0]).contiguous().to(dev)
+        pos = f32(m.pos_embed)[0]
+        self.pos = pos.contiguous()
+        self.cls_pos0 = (f32(m.cls_token)[0, 0] + pos[0]).contiguous()
         self.tokens = pos.shape[0]
         self.layers = []
         for blk in m.blocks:
@@ -54,26 +70,16 @@ class ViTEngine:
                 qkv_w=wt(blk.attn.qkv.weight, 3 * self.D), qkv_b=f32(blk.attn.qkv.bias),
                 proj_w=wt(blk.attn.proj.weight, self.D), proj_b=f32(blk.attn.proj.bias),
                 fc1_w=wt(blk.fc1.weight, blk.fc1.out_features), fc1_b=f32(blk.fc1.bias),
-                fc2_w=wt(blk.fc2.weight, self.D), fc2_b=f32(blk.fc2.bias), hidden=blk.fc1.out_features))
+                fc2_w=wt(blk.fc2.weight, self.D), fc2_b=f32(blk.fc2.bias), hidden=blk.fc1.out_features,
+                qkv_wd=wd(blk.attn.qkv.weight), proj_wd=wd(blk.attn.proj.weight),
+                fc1_wd=wd(blk.fc1.weight), fc2_wd=wd(blk.fc2.weight)))
         self.ng, self.nb = f32(m.norm.weight), f32(m.norm.bias)
         self.n_classes = m.head.out_features
         self.head_w = wt(m.head.weight, self.n_classes)
         self.head_b = f32(m.head.bias)
-        # backward-to-input tables: dx[rows][in] = dy[rows][out] . W  ->  rows = in features, K = out features
-
-        def wd(linear_w, k_pad=None):
-            w = linear_w.detach().float().cpu().to(torch.bfloat16).float().t().contiguous()      # [in][out]
-            if k_pad is not None and k_pad > w.shape[1]:
-                w = torch.cat([w, torch.zeros(w.shape[0], k_pad - w.shape[1])], 1)
-            return _pad_rows(w, 128 if w.shape[0] > 64 else 64).to(torch.bfloat16).contiguous().to(dev)
-        for L, blk in zip(self.layers, m.blocks):
-            L['qkv_wd'], L['proj_wd'] = wd(blk.attn.qkv.weight), wd(blk.attn.proj.weight)
-            L['fc1_wd'], L['fc2_wd'] = wd(blk.fc1.weight), wd(blk.fc2.weight)
         self.head_kpad = (self.n_classes + 31) // 32 * 32
         self.head_wd = wd(m.head.weight, self.head_kpad)
-        self.pe_wd = wd(m.patch_embed.weight.detach().reshape(self.D, -1))
-        self._buf = {}
-        self.fused_attention = True
+        self.pe_wd = wd(pe)
 
     def _get(self, name, shape, dtype=None, zero=False):
         torch = _lib.require_gpu()

@@ -190,3 +190,23 @@ def test_pgd_on_vit_runs_on_the_hip_engine(setup):
     clean = torch.nn.functional.cross_entropy(eng.logits(x01, MEAN, STD), y)
     attacked = torch.nn.functional.cross_entropy(eng.logits(adv_x, MEAN, STD), y)
     assert attacked > clean                                  # the gradient points uphill
+
+
+def test_vit_refold_tracks_new_weights(setup):
+    """ViTEngine.refold (GPU-side packing from live parameters) == a freshly constructed engine, bit for bit."""
+    import copy
+    from robustart_amd.model.vit_engine import ViTEngine
+    m, _ = setup
+    m2 = copy.deepcopy(m)
+    eng = ViTEngine(m2, 'cuda')
+    torch.manual_seed(9)
+    x = torch.rand(2, 3, 224, 224, device='cuda')
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.mul_(1.0 + 0.05 * torch.randn_like(p))
+    eng.refold(m2)
+    fresh = ViTEngine(m2, 'cuda')
+    assert torch.equal(eng.logits(x, MEAN, STD), fresh.logits(x, MEAN, STD))
+    for a, b in zip(eng.layers, fresh.layers):
+        for k in a:
+            assert (a[k] == b[k]) if isinstance(a[k], int) else torch.equal(a[k], b[k])
