@@ -316,6 +316,11 @@ int rart_softmax_rows_bf16(const void* scores, void* probs, int64_t rows, int n_
  * timm layout): out[n][tokens][heads*head_dim] = softmax(q k^T / sqrt(head_dim)) v, bf16 in/out, fp32 statistics.
  * head_dim == 64, tokens <= 224.  (timm Attention.forward; model `vit_base`.) */
 int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads, int head_dim, rart_stream_t stream);
+/* Backward of the same attention: dqkv[n][tokens][3*heads*head_dim] (dQ | dK | dV, qkv's layout) from qkv, the forward's
+ * output out[n][tokens][heads*head_dim] and its gradient dout; one fused kernel per (image, head), nothing score-sized
+ * leaves the chip. */
+int rart_vit_attention_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, int n, int tokens, int heads,
+                           int head_dim, rart_stream_t stream);
 /* vt[n][heads][head_dim][t_pad] <- V slice of the fused qkv activation [n][tokens][qkv_ld] (zero padded). */
 int rart_vit_transpose_v(const void* qkv, void* vt, int n, int tokens, int heads, int head_dim, int qkv_ld, int v_off,
                          int t_pad, rart_stream_t stream);

@@ -76,6 +76,7 @@ SIGNATURES = {
                                     c_float, c_void_p]),
     'rart_softmax_rows_bf16': (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'rart_vit_attention': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_vit_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_vit_transpose_v': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_gelu_bf16': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'rart_gelu_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

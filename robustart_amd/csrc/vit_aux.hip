@@ -297,6 +297,269 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention(const uint16_t* __r
     }
   }
 }
+// ---- fused attention backward (head_dim 64, tokens <= NKT*32), one workgroup per (image, head) ----------------------
+// dQ, dK, dV of softmax(Q K^T / sqrt(d)) V from Q, K, V, O (the forward's output) and dO; everything stays in LDS / registers (the unfused path
+// writes ~2 GB of score-sized temporaries per layer at B = 256).  Two phases over the same LDS-resident operands:
+//   B (a wave owns 32 QUERIES): S^T = K Q^T and dP^T = V dO^T land with lane = query, so the row statistics
+//     (max, 1/sum; delta = rowsum(dO * O)) need one shuffle; dS feeds straight back as the A operand of dQ = dS K (K read
+//     transposed from LDS in the accumulator's key order, the forward kernel's P.V trick); stats go to LDS.
+//   A (a wave owns 32 KEYS): S = Q K^T and dP = dO V^T are recomputed with lane = key (statistics broadcast from LDS),
+//     so P^T and dS^T are directly the A operands of dV = P^T dO and dK = dS^T Q (dO, Q read transposed from LDS);
+//     dK / dV accumulate in registers over the query tiles.  7 small products instead of 5, no cross-wave reduction.
+template <int NKT>
+__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ oout,
+                                                                 const uint16_t* __restrict__ dout, uint16_t* __restrict__ dqkv, int T, int H, int ld, int D,
+                                                                 float scale, float scale_log2e) {
+  constexpr int TP = NKT * 32, LDV = TP + 4;
+  __shared__ __attribute__((aligned(16))) uint16_t sQ[TP * ATT_LDK];
+  __shared__ __attribute__((aligned(16))) uint16_t sK[TP * ATT_LDK];     // phase A: Q^T  [64][LDV]
+  __shared__ __attribute__((aligned(16))) uint16_t sV[TP * ATT_LDK];     // phase A: dO^T [64][LDV]
+  __shared__ __attribute__((aligned(16))) uint16_t sdO[TP * ATT_LDK];
+  __shared__ __attribute__((aligned(16))) uint16_t sKt[ATT_HD * LDV];
+  __shared__ float sStat[TP * 3];
+  static_assert(ATT_HD * LDV <= TP * ATT_LDK, "transposed operands reuse the K / V arrays");
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+  const uint16_t* base = qkv + (size_t)b * T * ld + h * ATT_HD;
+  const uint16_t* dbase = dout + (size_t)b * T * D + h * ATT_HD;
+  for (int i = tid; i < TP * 8; i += kBlock) {
+    const int t = i >> 3, c = i & 7;
+    uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv, dv = qv;
+    if (t < T) {
+      qv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + c * 8);
+      kv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + c * 8);
+      vv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + 2 * D + c * 8);
+      dv = *reinterpret_cast<const uint4*>(dbase + (size_t)t * D + c * 8);
+    }
+    *reinterpret_cast<uint4*>(sQ + t * ATT_LDK + c * 8) = qv;
+    *reinterpret_cast<uint4*>(sK + t * ATT_LDK + c * 8) = kv;
+    *reinterpret_cast<uint4*>(sV + t * ATT_LDK + c * 8) = vv;
+    *reinterpret_cast<uint4*>(sdO + t * ATT_LDK + c * 8) = dv;
+    const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sKt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(w[j] & 0xFFFF);
+      sKt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(w[j] >> 16);
+    }
+  }
+  __syncthreads();
+  uint16_t* gq = dqkv + (size_t)b * T * ld + h * ATT_HD;      // dQ | dK (+D) | dV (+2D), same layout as qkv
+
+  // ---------------- phase B: queries ----------------
+  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
+    const int q = qt * 32 + l31;
+    bf16x8 bq[4], bdo[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      bq[kb] = *reinterpret_cast<const bf16x8*>(sQ + q * ATT_LDK + kb * 16 + hh * 8);
+      bdo[kb] = *reinterpret_cast<const bf16x8*>(sdO + q * ATT_LDK + kb * 16 + hh * 8);
+    }
+    // delta_q = sum_k P dP = sum_d dO[q][d] O[q][d] (O = the forward's output row): known before any dP tile exists, so
+    // the dP^T tiles can be consumed one at a time instead of holding all 7 (112 more registers) next to S^T
+    float delta = 0.f;
+    if (q < T) {
+      const uint16_t* orow = oout + ((size_t)b * T + q) * D + h * ATT_HD + hh * 32;
+      const uint16_t* drow = sdO + q * ATT_LDK + hh * 32;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 ov = *reinterpret_cast<const uint4*>(orow + c * 8), dv = *reinterpret_cast<const uint4*>(drow + c * 8);
+        const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          delta += bf2f((uint16_t)(ow[j] & 0xFFFF)) * bf2f((uint16_t)(dw[j] & 0xFFFF));
+          delta += bf2f((uint16_t)(ow[j] >> 16)) * bf2f((uint16_t)(dw[j] >> 16));
+        }
+      }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 ak = *reinterpret_cast<const bf16x8*>(sK + (kt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, bq[kb], sacc[kt], 0, 0, 0);
+      }
+    }
+    // lane = query qt*32 + l31; register r of tile kt = key kt*32 + (r&3) + 8*(r>>2) + 4*hh
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float v = key < T ? sacc[kt][r] * scale_log2e : -INFINITY;
+        sacc[kt][r] = v;
+        m = fmaxf(m, v);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - m);
+        sacc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (hh == 0) {
+      sStat[q * 3 + 0] = m;
+      sStat[q * 3 + 1] = inv;
+      sStat[q * 3 + 2] = delta;
+    }
+    f32x16 dq[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[nt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(sV + (kt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bdo[kb], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        uint32_t pw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r0 = 8 * kb2 + 2 * j;
+          const float d0 = scale * inv * sacc[kt][r0] * (dp[r0] - delta);
+          const float d1 = scale * inv * sacc[kt][r0 + 1] * (dp[r0 + 1] - delta);
+          pw[j] = (uint32_t)f2bf(d0) | ((uint32_t)f2bf(d1) << 16);
+        }
+        uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+        const bf16x8 da = *reinterpret_cast<bf16x8*>(&pv);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const uint16_t* kr = sKt + (nt * 32 + l31) * LDV + kt * 32 + 16 * kb2 + 4 * hh;
+          const uint2 lo = *reinterpret_cast<const uint2*>(kr), hi = *reinterpret_cast<const uint2*>(kr + 8);
+          uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          dq[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, *reinterpret_cast<bf16x8*>(&bv), dq[nt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one key tile at a time: interleaving the unrolled tiles multiplies the live dP tiles
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (qq < T) {
+        uint16_t* orow = gq + (size_t)qq * ld;
+        orow[l31] = f2bf(dq[0][r]);
+        orow[32 + l31] = f2bf(dq[1][r]);
+      }
+    }
+  }
+
+  // ---------------- phase A: keys ----------------
+  // K / V fragments of the (up to two) key tiles this wave owns move to registers, then K's and V's LDS arrays are
+  // overwritten by Q^T and dO^T
+  bf16x8 bk[2][4], bvv[2][4];
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki) {
+    const int kt = wave + ki * (kBlock / 64);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      uint4 z = make_uint4(0, 0, 0, 0);
+      bk[ki][kb] = *reinterpret_cast<bf16x8*>(&z);
+      bvv[ki][kb] = *reinterpret_cast<bf16x8*>(&z);
+      if (kt < NKT) {
+        bk[ki][kb] = *reinterpret_cast<const bf16x8*>(sK + (kt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
+        bvv[ki][kb] = *reinterpret_cast<const bf16x8*>(sV + (kt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
+      }
+    }
+  }
+  __syncthreads();
+  uint16_t* sQt = sK;
+  uint16_t* sdOt = sV;
+  for (int i = tid; i < TP * 8; i += kBlock) {
+    const int t = i >> 3, c = i & 7;
+    const uint4 qv = *reinterpret_cast<const uint4*>(sQ + t * ATT_LDK + c * 8);
+    const uint4 dv = *reinterpret_cast<const uint4*>(sdO + t * ATT_LDK + c * 8);
+    const uint32_t wq[4] = {qv.x, qv.y, qv.z, qv.w}, wd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sQt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(wq[j] & 0xFFFF);
+      sQt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(wq[j] >> 16);
+      sdOt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(wd[j] & 0xFFFF);
+      sdOt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(wd[j] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki) {
+    const int kt = wave + ki * (kBlock / 64);
+    if (kt >= NKT) break;
+    const bool key_ok = kt * 32 + l31 < T;
+    f32x16 dvv[2], dkk[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dvv[nt][r] = dkk[nt][r] = 0.f;
+#pragma unroll 1
+    for (int qt = 0; qt < NKT; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 aq = *reinterpret_cast<const bf16x8*>(sQ + (qt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
+        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sdO + (qt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bk[ki][kb], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bvv[ki][kb], dp, 0, 0, 0);
+      }
+      // lane = key kt*32 + l31; register r = query qt*32 + (r&3) + 8*(r>>2) + 4*hh
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float p = key_ok ? __builtin_amdgcn_exp2f(s[r] * scale_log2e - sStat[q * 3]) * sStat[q * 3 + 1] : 0.f;
+        s[r] = p;
+        dp[r] = scale * p * (dp[r] - sStat[q * 3 + 2]);
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        uint32_t pw[4], dw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r0 = 8 * kb2 + 2 * j;
+          pw[j] = (uint32_t)f2bf(s[r0]) | ((uint32_t)f2bf(s[r0 + 1]) << 16);
+          dw[j] = (uint32_t)f2bf(dp[r0]) | ((uint32_t)f2bf(dp[r0 + 1]) << 16);
+        }
+        uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]), dv = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+        const bf16x8 pa = *reinterpret_cast<bf16x8*>(&pv), da = *reinterpret_cast<bf16x8*>(&dv);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const uint16_t* orow = sdOt + (nt * 32 + l31) * LDV + qt * 32 + 16 * kb2 + 4 * hh;
+          const uint16_t* qrow = sQt + (nt * 32 + l31) * LDV + qt * 32 + 16 * kb2 + 4 * hh;
+          const uint2 olo = *reinterpret_cast<const uint2*>(orow), ohi = *reinterpret_cast<const uint2*>(orow + 8);
+          const uint2 qlo = *reinterpret_cast<const uint2*>(qrow), qhi = *reinterpret_cast<const uint2*>(qrow + 8);
+          uint4 bo = make_uint4(olo.x, olo.y, ohi.x, ohi.y), bqv = make_uint4(qlo.x, qlo.y, qhi.x, qhi.y);
+          dvv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, *reinterpret_cast<bf16x8*>(&bo), dvv[nt], 0, 0, 0);
+          dkk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, *reinterpret_cast<bf16x8*>(&bqv), dkk[nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (kk < T) {
+        uint16_t* orow = gq + (size_t)kk * ld;
+        orow[D + l31] = f2bf(dkk[0][r]);
+        orow[D + 32 + l31] = f2bf(dkk[1][r]);
+        orow[2 * D + l31] = f2bf(dvv[0][r]);
+        orow[2 * D + 32 + l31] = f2bf(dvv[1][r]);
+      }
+    }
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -363,6 +626,20 @@ int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads,
   hipLaunchKernelGGL(k_vit_attention<7>, dim3((uint32_t)(n * heads)), dim3(kBlock), 0, (hipStream_t)stream,
                      (const uint16_t*)qkv, (uint16_t*)out, tokens, heads, 3 * D, D, scale_log2e);
   RART_CHECK_LAUNCH("rart_vit_attention");
+  return RART_OK;
+}
+
+int rart_vit_attention_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, int n, int tokens, int heads,
+                           int head_dim, rart_stream_t stream) {
+  RART_CHECK_ARG(qkv && out && dout && dqkv && n > 0 && tokens > 0 && heads > 0, "rart_vit_attention_bwd: bad arguments");
+  RART_CHECK_ARG(head_dim == 64, "rart_vit_attention_bwd: head_dim must be 64 (ViT-B/16)");
+  RART_CHECK_ARG(tokens <= 224, "rart_vit_attention_bwd: at most 224 tokens (197 for 224x224 / patch 16)");
+  const int D = heads * head_dim;
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  hipLaunchKernelGGL(k_vit_attention_bwd<7>, dim3((uint32_t)(n * heads)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, (uint16_t*)dqkv, tokens, heads, 3 * D, D, scale,
+                     scale * 1.4426950408889634f);
+  RART_CHECK_LAUNCH("rart_vit_attention_bwd");
   return RART_OK;
 }
 

@@ -26,6 +26,7 @@ class ViTEngine:
         self.refold(model)
         self._buf = {}
         self.fused_attention = True
+        self.fused_attention_bwd = True      # False: the decomposition into batched igemm products (cross-check)
 
     def refold(self, model):
         """(Re)build every weight table from `model`'s current parameters.  Parameters already on the GPU are packed
@@ -151,12 +152,12 @@ class ViTEngine:
             scores = self._get('scores', (B * H, T, s_ld))
             probs = self._get('probs', (B * H, T, t_pad))
             vt = self._get('vt', (B * H * hd + 128, t_pad), zero=True)
-        att = self._get('att', (B, T, D))
         saved = []
         for li, L in enumerate(self.layers):
             # keep mode stores what the backward needs: block input, post-attention stream, qkv, fc1 pre-activation
             qkv = self._get('qkv%d' % li if keep else 'qkv', (B * T + 256, 3 * D), zero=True)   # slack rows: K tiles read in place
             xm = self._get('xm%d' % li, (B, T, D)) if keep else x
+            att = self._get('att%d' % li if keep else 'att', (B, T, D))     # kept: delta = rowsum(dO * O) in the backward
             xo = self._get('x%d' % (li + 1), (B, T, D)) if keep else x
             _lib.check(lib.rart_layernorm_bf16(_lib.ptr(x), _lib.ptr(L['n1g']), _lib.ptr(L['n1b']), _lib.ptr(ln), rows, D,
                                                D, D, 1e-6, sp))
@@ -173,7 +174,7 @@ class ViTEngine:
                 u = self._get('u%d' % li, (B, T, L['hidden']))
                 self._gemm(ln, L['fc1_w'], u, rows, D, L['hidden'], D, L['hidden'], bias=L['fc1_b'])
                 _lib.check(lib.rart_gelu_bf16(_lib.ptr(u), _lib.ptr(hid), u.numel(), sp))
-                saved.append((x, xm, qkv, u))
+                saved.append((x, xm, qkv, u, att))
             else:
                 self._gemm(ln, L['fc1_w'], hid, rows, D, L['hidden'], D, L['hidden'], bias=L['fc1_b'], flags=F_GELU)
             self._gemm(hid, L['fc2_w'], xo, rows, L['hidden'], D, L['hidden'], D, bias=L['fc2_b'], res=xm)
@@ -272,7 +273,7 @@ class ViTEngine:
         dqkv = self._get('g_qkv', (rows, 3 * D))
         for li in range(len(self.layers) - 1, -1, -1):
             L = self.layers[li]
-            x_in, xm, qkv, u = saved[li]
+            x_in, xm, qkv, u, att = saved[li]
             dh = self._get('g_hid', (rows, L['hidden']))
             self._gemm(dx, L['fc2_wd'], dh, rows, D, L['hidden'], D, L['hidden'])
             _lib.check(lib.rart_gelu_bwd_bf16(_lib.ptr(dh), _lib.ptr(u), _lib.ptr(dh), dh.numel(), sp))
@@ -283,7 +284,11 @@ class ViTEngine:
                                                    rows, D, D, D, D, D, 1e-6, sp))
             datt = self._get('g_att', (rows, D))
             self._gemm(dxm, L['proj_wd'], datt, rows, D, D, D, D)
-            self._attention_bwd(qkv, datt, dqkv, B, T)
+            if self.fused_attention_bwd:
+                _lib.check(lib.rart_vit_attention_bwd(_lib.ptr(qkv), _lib.ptr(att), _lib.ptr(datt), _lib.ptr(dqkv), B, T,
+                                                      self.H, self.hd, sp))
+            else:
+                self._attention_bwd(qkv, datt, dqkv, B, T)
             self._gemm(dqkv, L['qkv_wd'], dln, rows, 3 * D, D, 3 * D, D)
             _lib.check(lib.rart_layernorm_bwd_bf16(_lib.ptr(dln), _lib.ptr(x_in), _lib.ptr(L['n1g']), _lib.ptr(dxm), _lib.ptr(dx),
                                                    rows, D, D, D, D, D, 1e-6, sp))

@@ -210,3 +210,41 @@ def test_vit_refold_tracks_new_weights(setup):
     for a, b in zip(eng.layers, fresh.layers):
         for k in a:
             assert (a[k] == b[k]) if isinstance(a[k], int) else torch.equal(a[k], b[k])
+
+
+def test_fused_attention_backward_matches_unfused_and_torch(setup):
+    """rart_vit_attention_bwd vs torch autograd of softmax(QK^T/sqrt(d))V on the same bf16 q, k, v, and vs the
+    batched-GEMM decomposition through the whole network."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(11)
+    B, T, H, hd = 3, 197, 12, 64
+    D = H * hd
+    qkv = (torch.randn(B * T + 256, 3 * D, device='cuda') * 0.7).to(torch.bfloat16)
+    dout = torch.randn(B * T, D, device='cuda').to(torch.bfloat16)
+    q, k, v = [qkv[:B * T].float().view(B, T, 3, H, hd)[:, :, i].permute(0, 2, 1, 3).requires_grad_(True) for i in range(3)]
+    p = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1)
+    o = p @ v                                                          # [B][H][T][hd]
+    o.backward(dout.float().view(B, T, H, hd).permute(0, 2, 1, 3))
+    att = o.detach().permute(0, 2, 1, 3).reshape(B * T, D).to(torch.bfloat16).contiguous()
+    dqkv = torch.zeros(B * T, 3 * D, device='cuda', dtype=torch.bfloat16)
+    _lib.check(lib.rart_vit_attention_bwd(_lib.ptr(qkv), _lib.ptr(att), _lib.ptr(dout), _lib.ptr(dqkv), B, T, H, hd,
+                                          _lib.stream_ptr()))
+    got = dqkv.float().view(B, T, 3, H, hd)
+    for i, ref in enumerate((q.grad, k.grad, v.grad)):
+        g = got[:, :, i].permute(0, 2, 1, 3)
+        a, b2 = g.double().flatten(), ref.double().flatten()
+        cos = float((a @ b2) / (a.norm() * b2.norm()))
+        rel = float((a - b2).norm() / b2.norm())
+        assert cos > 0.9995 and rel < 0.03, (i, cos, rel)
+    # whole network: fused vs unfused backward give the same input gradient (up to bf16 rounding of dS / P)
+    m, eng = setup
+    x01 = torch.rand(2, 3, 224, 224, device='cuda')
+    y = torch.randint(0, 1000, (2,), device='cuda')
+    eng.fused_attention_bwd = True
+    g1 = eng.forward_backward(x01, MEAN, STD, y, 0)[2]
+    eng.fused_attention_bwd = False
+    g2 = eng.forward_backward(x01, MEAN, STD, y, 0)[2]
+    eng.fused_attention_bwd = True
+    a, b2 = g1.double().flatten(), g2.double().flatten()
+    assert float((a @ b2) / (a.norm() * b2.norm())) > 0.9995
