@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='images in the bounded CPU baseline sample')
-    ap.add_argument('--workload', choices=['headline', 'vit_inc', 'adv_train'], default='headline',
+    ap.add_argument('--workload', choices=['headline', 'vit_inc', 'vit_pgd', 'adv_train'], default='headline',
                     help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 3: ViT-B/16 evaluated "
                          "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost skipped: no textures)")
     ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
@@ -257,6 +257,51 @@ def run_vit_inc(args, device, rank, world, dist):
                                      'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
 
 
+def run_vit_pgd(args, device, rank, world, dist):
+    """Secondary mode: PGD-Linf-7 (eps 2/255) evaluation of ViT-B/16, forward and backward-to-input on the HIP engine
+    (fused attention forward / backward kernels, every GEMM on the igemm kernel)."""
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.model.vit_engine import ViTEngine
+    from robustart_amd.noise import adv as A
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    x01 = (torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).float() / 255.0).to(device)
+    labels = torch.randint(0, 1000, (B,), generator=g).to(device)
+    torch.manual_seed(0)
+    f_model = EngineModel(None, takes_normalized=False, engine=ViTEngine(get_model({'type': 'vit_base'}).eval(), device))
+
+    def step(k):
+        xa = A.pgd_linf(x01, labels, f_model, 2 / 255, 3 / 40, 7, seed=k, sample_offset=rank * B)
+        return (f_model(xa).argmax(1) == labels).sum()
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        flops = 15 * 35.1e9 * B * world                       # (2k + 1) F, F(ViT-B/16) = 35.1 GFLOP (SURVEY.md 8d)
+        print(json.dumps({'metric': 'attacked images/sec/node (ViT-B/16, PGD-Linf-7 eval)', 'value': B * world * args.steps / dt,
+                          'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                          'step_mfma': {'achieved': flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
+                                        'note': '15 forward-equivalents per image'},
+                          'config': {'workload': 'secondary: PGD-Linf-7 eps 2/255 + final forward, ViT-B/16, batch 256 per GPU',
+                                     'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
+
+
 def run_adv_train(args, device, rank, world, dist):
     """BASELINE config 5 (secondary mode): ResNet-50 adversarial training, PGD-3 inner loop on the HIP eval engine
     (re-folded from the live weights every step), train-mode forward/backward on the HIP train engine, label-smoothed
@@ -334,8 +379,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)       # "nccl" == RCCL on ROCm
-    if args.workload in ('vit_inc', 'adv_train'):
-        (run_vit_inc if args.workload == 'vit_inc' else run_adv_train)(args, device, rank, world, dist)
+    if args.workload in ('vit_inc', 'vit_pgd', 'adv_train'):
+        {'vit_inc': run_vit_inc, 'vit_pgd': run_vit_pgd, 'adv_train': run_adv_train}[args.workload](args, device, rank, world, dist)
         if dist is not None:
             dist.destroy_process_group()
         return
