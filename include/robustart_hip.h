@@ -339,6 +339,17 @@ int rart_softmax_bwd_rows_bf16(const void* probs, const void* dprobs, void* dsco
 /* grad[b][c][y][x] (fp32, w.r.t. the [0,1] image) from the patch-embedding input gradient [b*patches][ld >= 3*p*p]. */
 int rart_vit_unpatchify_f32(const void* dpatches, float* grad, int n, int h, int w, int patch, int64_t ld,
                             const float* std_host, rart_stream_t stream);
+/* ViT training: LayerNorm backward to the input (dx nullable) plus dgamma = sum_rows dy*xhat, dbeta = sum_rows dy
+ * (written, or added when accumulate != 0); deterministic two-level reduction.  workspace: rart_layernorm_bwd_workspace_bytes. */
+size_t rart_layernorm_bwd_workspace_bytes(int dim);
+int rart_layernorm_bwd_full_bf16(const void* dy, const void* x, const float* gamma, const void* res, void* dx, int rows,
+                                 int dim, int64_t dy_row_stride, int64_t x_row_stride, int64_t res_row_stride,
+                                 int64_t dx_row_stride, float eps, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                                 size_t workspace_bytes, rart_stream_t stream);
+/* out[c] (+)= sum_r x[r][c] for a bf16 [rows][cols] matrix with row stride ld (Linear bias gradients, position embedding). */
+size_t rart_colsum_workspace_bytes(int rows, int cols);
+int rart_colsum_bf16(const void* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* workspace,
+                     size_t workspace_bytes, rart_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training-side step kernels.  The solver the reference launches

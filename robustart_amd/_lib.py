@@ -86,6 +86,12 @@ SIGNATURES = {
                                            c_void_p]),
     'rart_vit_unpatchify_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64,
                                         ctypes.POINTER(c_float), c_void_p]),
+    'rart_layernorm_bwd_workspace_bytes': (c_size_t, [c_int]),
+    'rart_layernorm_bwd_full_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_float, c_void_p, c_void_p, c_int,
+                                             c_void_p, c_size_t, c_void_p]),
+    'rart_colsum_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'rart_colsum_bf16': (c_int, [c_void_p, ctypes.c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'rart_sgd_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double, c_double, c_int,
                                   c_double, c_double, c_int, c_void_p]),
     'rart_adamw_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double,

@@ -239,3 +239,179 @@ int rart_vit_unpatchify_f32(const void* dpatches, float* grad, int n, int h, int
 }
 
 }  // extern "C"
+
+// ---- parameter-gradient reductions for ViT training (LayerNorm gamma / beta, Linear biases, position embedding) ----
+namespace {
+// LayerNorm backward to the input AND per-wave partial sums of dgamma = sum_rows dy*xhat, dbeta = sum_rows dy:
+// a wave walks rows (grid stride), so its 2 x 8 column slots accumulate in registers; partial[wave][2][d] fp32.
+__global__ __launch_bounds__(kBlock) void k_layernorm_bwd_full(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                               const float* __restrict__ gamma, const uint16_t* __restrict__ res,
+                                                               uint16_t* __restrict__ dx, int rows, int d, long long dy_stride,
+                                                               long long x_stride, long long res_stride, long long dx_stride,
+                                                               float eps, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (kBlock / 64);
+  const int nv = d / 8;
+  float ag[2][8], ab[2][8], gm[2][8];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ag[k][j] = ab[k][j] = 0.f;
+      const int vi = lane + 64 * k;
+      gm[k][j] = vi < nv ? gamma[vi * 8 + j] : 0.f;
+    }
+  for (int row = wave_g; row < rows; row += n_waves) {
+    float xr[2][8], gr[2][8];
+    load_row(x + (size_t)row * x_stride, nv, lane, xr);
+    load_row(dy + (size_t)row * dy_stride, nv, lane, gr);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xr[k][j];
+    const float mean = rart_wave_sum(s) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (lane + 64 * k < nv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = xr[k][j] - mean;
+          v += t * t;
+        }
+      }
+    const float rstd = rsqrtf(rart_wave_sum(v) / (float)d + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (lane + 64 * k < nv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xr[k][j] = (xr[k][j] - mean) * rstd;               // xhat
+          ag[k][j] += gr[k][j] * xr[k][j];
+          ab[k][j] += gr[k][j];
+          gr[k][j] *= gm[k][j];
+          sg += gr[k][j];
+          sgx += gr[k][j] * xr[k][j];
+        }
+      }
+    const float mg = rart_wave_sum(sg) / (float)d, mgx = rart_wave_sum(sgx) / (float)d;
+    if (dx) {
+      uint16_t* o = dx + (size_t)row * dx_stride;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nv) {
+          float r[8], rs[8];
+          if (res) unpack8(*reinterpret_cast<const uint4*>(res + (size_t)row * res_stride + (size_t)vi * 8), rs);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            r[j] = rstd * (gr[k][j] - mg - xr[k][j] * mgx);
+            if (res) r[j] += rs[j];
+          }
+          *reinterpret_cast<uint4*>(o + (size_t)vi * 8) = pack8(r);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int vi = lane + 64 * k;
+    if (vi < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        partial[((size_t)wave_g * 2 + 0) * d + vi * 8 + j] = ag[k][j];
+        partial[((size_t)wave_g * 2 + 1) * d + vi * 8 + j] = ab[k][j];
+      }
+    }
+  }
+}
+// out[s][c] (+)= sum_k partial[k][s][c], fixed order; s < n_sets
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(const float* __restrict__ partial, int n_part, int n_sets, int d,
+                                                            float* __restrict__ out0, float* __restrict__ out1, int accumulate) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= d) return;
+  for (int s = 0; s < n_sets; ++s) {
+    double a = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < n_part; ++k) a += (double)partial[((size_t)k * n_sets + s) * d + c];   // independent loads, fixed order
+    float* o = s == 0 ? out0 : out1;
+    if (o) o[c] = accumulate ? o[c] + (float)a : (float)a;
+  }
+}
+// column sums of a bf16 [rows][cols] matrix (row stride ld): thread = one 8-column vector, block = a chunk of rows
+__global__ __launch_bounds__(kBlock) void k_colsum_bf16(const uint16_t* __restrict__ x, long long ld, int rows, int cols,
+                                                        int rows_per_chunk, float* __restrict__ partial) {
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  if (v * 8 >= cols) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * ld + (size_t)v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += f[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) partial[(size_t)blockIdx.y * cols + v * 8 + j] = a[j];
+}
+}  // namespace
+
+extern "C" {
+
+// 512 waves walk the rows: enough to fill the GPU, few enough that the fixed-order final reduction (one thread per
+// column over all partials) stays short
+size_t rart_layernorm_bwd_workspace_bytes(int dim) { return (size_t)512 * 2 * dim * sizeof(float); }
+
+int rart_layernorm_bwd_full_bf16(const void* dy, const void* x, const float* gamma, const void* res, void* dx, int rows,
+                                 int dim, int64_t dy_row_stride, int64_t x_row_stride, int64_t res_row_stride,
+                                 int64_t dx_row_stride, float eps, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                                 size_t workspace_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(dy && x && gamma && dgamma && dbeta && rows > 0 && dim > 0, "rart_layernorm_bwd_full_bf16: bad arguments");
+  RART_CHECK_ARG(dim % 8 == 0 && dim <= 1024 && dy_row_stride % 8 == 0 && x_row_stride % 8 == 0 && res_row_stride % 8 == 0 &&
+                     dx_row_stride % 8 == 0, "rart_layernorm_bwd_full_bf16: dim a multiple of 8, at most 1024; strides multiples of 8");
+  const size_t need = rart_layernorm_bwd_workspace_bytes(dim);
+  if (!workspace || workspace_bytes < need) {
+    rart_set_error("rart_layernorm_bwd_full_bf16: workspace of %zu bytes required", need);
+    return RART_ERR_WORKSPACE;
+  }
+  int blocks = (rows + kBlock / 64 - 1) / (kBlock / 64);
+  if (blocks > 128) blocks = 128;                                  // 512 waves
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_layernorm_bwd_full, dim3(blocks), dim3(kBlock), 0, st, (const uint16_t*)dy, (const uint16_t*)x, gamma,
+                     (const uint16_t*)res, (uint16_t*)dx, rows, dim, (long long)dy_row_stride, (long long)x_row_stride,
+                     (long long)res_row_stride, (long long)dx_row_stride, eps, (float*)workspace);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((dim + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (const float*)workspace,
+                     blocks * (kBlock / 64), 2, dim, dgamma, dbeta, accumulate);
+  RART_CHECK_LAUNCH("rart_layernorm_bwd_full_bf16");
+  return RART_OK;
+}
+
+size_t rart_colsum_workspace_bytes(int rows, int cols) {
+  const int chunks = rows < 128 ? 1 : (rows / 64 > 256 ? 256 : rows / 64);   // ~64 rows per thread, at most 256 partials
+  return (size_t)chunks * cols * sizeof(float);
+}
+
+int rart_colsum_bf16(const void* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* workspace,
+                     size_t workspace_bytes, rart_stream_t stream) {
+  RART_CHECK_ARG(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "rart_colsum_bf16: bad arguments");
+  const size_t need = rart_colsum_workspace_bytes(rows, cols);
+  if (!workspace || workspace_bytes < need) {
+    rart_set_error("rart_colsum_bf16: workspace of %zu bytes required", need);
+    return RART_ERR_WORKSPACE;
+  }
+  const int chunks = (int)(need / ((size_t)cols * sizeof(float)));
+  const int rpc = (rows + chunks - 1) / chunks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_colsum_bf16, dim3((cols / 8 + kBlock - 1) / kBlock, chunks), dim3(kBlock), 0, st, (const uint16_t*)x,
+                     (long long)ld, rows, cols, rpc, (float*)workspace);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((cols + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (const float*)workspace, chunks,
+                     1, cols, out, nullptr, accumulate);
+  RART_CHECK_LAUNCH("rart_colsum_bf16");
+  return RART_OK;
+}
+
+}  // extern "C"

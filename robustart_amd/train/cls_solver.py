@@ -269,10 +269,14 @@ def train(cfg, args, rank, world, device):
     train_engine = None
     if use_hip_opt and getattr(args, 'train_engine', 'hip') == 'hip':
         from ..model.resnet_torch import ResNet
+        from ..model.vit_torch import VisionTransformer
+        model.train()
         if isinstance(model, ResNet) and size % 32 == 0:
             from ..model.train_engine import ResNet50TrainEngine
-            model.train()
             train_engine = ResNet50TrainEngine(model, device, on_grad_ready=arena.grad_ready)
+        elif isinstance(model, VisionTransformer):
+            from ..model.vit_train_engine import ViTTrainEngine
+            train_engine = ViTTrainEngine(model, device, on_grad_ready=arena.grad_ready)
     ls = float(cfg.get('label_smooth', 0.0))
     adv = cfg.get('adv_train', None)                        # {'eps': '4/255', 'steps': 3, 'rel_stepsize': 0.4}
     mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)

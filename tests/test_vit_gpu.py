@@ -248,3 +248,49 @@ def test_fused_attention_backward_matches_unfused_and_torch(setup):
     eng.fused_attention_bwd = True
     a, b2 = g1.double().flatten(), g2.double().flatten()
     assert float((a @ b2) / (a.norm() * b2.norm())) > 0.9995
+
+
+def test_vit_train_engine_parameter_gradients_match_torch_autograd():
+    """ViTTrainEngine (forward + backward to all 152 parameters on HIP) vs torch autograd through the fp32 module."""
+    import copy
+    from robustart_amd import _lib
+    from robustart_amd.model import get_model
+    from robustart_amd.model.vit_train_engine import ViTTrainEngine
+    from robustart_amd.train.arena import label_smooth_ce
+    lib = _lib.load()
+    torch.manual_seed(3)
+    model = get_model({'type': 'vit_base', 'kwargs': {'num_classes': 1000, 'drop_path_rate': 0.0}}).cuda().train()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bias'):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.05).cuda())
+            if 'norm' in n and n.endswith('weight'):
+                p.copy_((1 + torch.randn(p.shape, generator=g) * 0.1).cuda())
+    ref = copy.deepcopy(model)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    ready = []
+    eng = ViTTrainEngine(model, 'cuda', on_grad_ready=lambda p: ready.append(id(p)))
+    B = 4
+    x01 = torch.rand(B, 3, 224, 224, device='cuda')
+    y = torch.randint(0, 1000, (B,), device='cuda')
+    logits = eng.forward(x01, False, MEAN, STD)
+    loss_rows, dl = label_smooth_ce(logits, y, 0.1, 1.0 / B)
+    eng.backward(dl)
+    assert sorted(ready) == sorted(id(p) for p in model.parameters())
+    mean = torch.tensor(MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(STD, device='cuda').view(1, 3, 1, 1)
+    out = ref((x01 - mean) / std)
+    out.backward(dl)                                              # the same upstream gradient on both sides
+    assert (logits - out.detach()).abs().max() < 0.02 * out.detach().abs().max()
+    rep = []
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        a, b2 = p.grad.double().flatten(), q.grad.double().flatten()
+        rep.append((float((a @ b2) / (a.norm() * b2.norm() + 1e-30)), float(a.norm() / (b2.norm() + 1e-30)), n))
+    rep.sort()
+    print('lowest parameter-gradient cosines:', [(round(c, 4), round(r, 3), n) for c, r, n in rep[:6]])
+    import numpy as np
+    cs = np.array([c for c, _, _ in rep])
+    assert np.median(cs) > 0.999 and cs.min() > 0.98, rep[:8]
+    assert all(0.9 < r < 1.1 for _, r, _ in rep), [x for x in rep if not 0.9 < x[1] < 1.1][:8]
