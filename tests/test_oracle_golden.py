@@ -218,3 +218,16 @@ def test_opencv_resize_oracle_invariants():
     nn = CV.resize(x, (100, 30), CV.NEAREST)
     assert np.array_equal(nn[7, 13], x[int(np.floor(7 * 48 / 30)), int(np.floor(13 * 64 / 100))])
     assert CV.imagenet_s_val(rs.randint(0, 256, (300, 400, 3)).astype(np.uint8), CV.CUBIC).shape == (224, 224, 3)
+
+
+def test_imagenet_s_train_crop_box_matches_reference():
+    """robustart_amd.noise.imagenet_s._train_params == the reference's ImageTransfer.get_params for the same
+    `random` seed (golden vectors from tests/golden/make_imagenet_s_golden.py, incl. the fallback branches for
+    extreme aspect ratios)."""
+    import json
+    import random
+    from robustart_amd.noise.imagenet_s import _train_params
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'imagenet_s_params_ref.json')))
+    assert len(cases) >= 40
+    for c in cases:
+        assert list(_train_params((c['h'], c['w']), random.Random(c['seed']))) == c['box'], c
