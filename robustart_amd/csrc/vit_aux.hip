@@ -306,8 +306,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention(const uint16_t* __r
 //   A (a wave owns 32 KEYS): S = Q K^T and dP = dO V^T are recomputed with lane = key (statistics broadcast from LDS),
 //     so P^T and dS^T are directly the A operands of dV = P^T dO and dK = dS^T Q (dO, Q read transposed from LDS);
 //     dK / dV accumulate in registers over the query tiles.  7 small products instead of 5, no cross-wave reduction.
-template <int NKT>
-__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ oout,
+// NW waves per workgroup: with 8 waves each wave owns ONE query tile in phase B and ONE key tile in phase A (7 tiles),
+// so a workgroup walks each phase once instead of twice (one workgroup per CU either way: 158 KB of LDS)
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ oout,
                                                                  const uint16_t* __restrict__ dout, uint16_t* __restrict__ dqkv, int T, int H, int ld, int D,
                                                                  float scale, float scale_log2e) {
   constexpr int TP = NKT * 32, LDV = TP + 4;
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd(const uint16_t*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
   const uint16_t* base = qkv + (size_t)b * T * ld + h * ATT_HD;
   const uint16_t* dbase = dout + (size_t)b * T * D + h * ATT_HD;
-  for (int i = tid; i < TP * 8; i += kBlock) {
+  constexpr int NT = NW * 64, KI = (NKT + NW - 1) / NW;      // threads; key tiles per wave in phase A
+  for (int i = tid; i < TP * 8; i += NT) {
     const int t = i >> 3, c = i & 7;
     uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv, dv = qv;
     if (t < T) {
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd(const uint16_t*
   uint16_t* gq = dqkv + (size_t)b * T * ld + h * ATT_HD;      // dQ | dK (+D) | dV (+2D), same layout as qkv
 
   // ---------------- phase B: queries ----------------
-  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
+  for (int qt = wave; qt < NKT; qt += NW) {
     const int q = qt * 32 + l31;
     bf16x8 bq[4], bdo[4];
 #pragma unroll
@@ -462,10 +465,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd(const uint16_t*
   // ---------------- phase A: keys ----------------
   // K / V fragments of the (up to two) key tiles this wave owns move to registers, then K's and V's LDS arrays are
   // overwritten by Q^T and dO^T
-  bf16x8 bk[2][4], bvv[2][4];
+  bf16x8 bk[KI][4], bvv[KI][4];
 #pragma unroll
-  for (int ki = 0; ki < 2; ++ki) {
-    const int kt = wave + ki * (kBlock / 64);
+  for (int ki = 0; ki < KI; ++ki) {
+    const int kt = wave + ki * NW;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       uint4 z = make_uint4(0, 0, 0, 0);
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd(const uint16_t*
   __syncthreads();
   uint16_t* sQt = sK;
   uint16_t* sdOt = sV;
-  for (int i = tid; i < TP * 8; i += kBlock) {
+  for (int i = tid; i < TP * 8; i += NT) {
     const int t = i >> 3, c = i & 7;
     const uint4 qv = *reinterpret_cast<const uint4*>(sQ + t * ATT_LDK + c * 8);
     const uint4 dv = *reinterpret_cast<const uint4*>(sdO + t * ATT_LDK + c * 8);
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd(const uint16_t*
   }
   __syncthreads();
 #pragma unroll
-  for (int ki = 0; ki < 2; ++ki) {
-    const int kt = wave + ki * (kBlock / 64);
+  for (int ki = 0; ki < KI; ++ki) {
+    const int kt = wave + ki * NW;
     if (kt >= NKT) break;
     const bool key_ok = kt * 32 + l31 < T;
     f32x16 dvv[2], dkk[2];
@@ -636,7 +639,7 @@ int rart_vit_attention_bwd(const void* qkv, const void* out, const void* dout, v
   RART_CHECK_ARG(tokens <= 224, "rart_vit_attention_bwd: at most 224 tokens (197 for 224x224 / patch 16)");
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
-  hipLaunchKernelGGL(k_vit_attention_bwd<7>, dim3((uint32_t)(n * heads)), dim3(kBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((k_vit_attention_bwd<7, 8>), dim3((uint32_t)(n * heads)), dim3(512), 0, (hipStream_t)stream,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, (uint16_t*)dqkv, tokens, heads, 3 * D, D, scale,
                      scale * 1.4426950408889634f);
   RART_CHECK_LAUNCH("rart_vit_attention_bwd");
