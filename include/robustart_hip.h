@@ -244,6 +244,7 @@ int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* y_targ
  *   destination:  element ((image*dst_h + oy*dst_sy + dst_oy)*dst_w + ox*dst_sx + dst_ox)*dst_pix_stride + n
  *   epilogue   :  v = acc + bias[n]; v += res[dst index]; if (mask) v = mask[dst index] > 0 ? v : 0;
  *                 if (flags & 1) v = max(v, 0); if (flags & 4) v = gelu(v); store bf16 (or fp32 if flags & 2).
+ *                 flags & 8: `mask` holds a GELU pre-activation u instead and v = v * gelu'(u) (no sign masking).
  *                 `res` may alias `dst`.
  * Covers forward convs, backward-to-input of stride-1 convs, each input-parity class of a stride-2
  * conv's backward, the 7x7 stem on the padded 4-channel hi/lo image, and fully connected layers.

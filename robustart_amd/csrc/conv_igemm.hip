@@ -58,7 +58,7 @@ struct RartConvDescDev {
 namespace {
 constexpr int BM = 128;
 constexpr int kThreads = 256;
-enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4 };
+enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8 };
 
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
@@ -92,6 +92,18 @@ __device__ __forceinline__ float gelu_erf(float v) {
   p = fmaf(p, t, 0.254829592f);
   const float erf_abs = 1.0f - p * t * __expf(-x * x);
   return 0.5f * v * (1.0f + copysignf(erf_abs, v));
+}
+// d/du [u * Phi(u)] = Phi(u) + u * phi(u), sharing the exponential with the erf approximation above
+__device__ __forceinline__ float gelu_grad_erf(float u) {
+  const float x = fabsf(u) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-x * x);                         // exp(-u^2 / 2)
+  const float erf_abs = 1.0f - p * t * e;
+  return fmaf(u * 0.3989422804014327f, e, 0.5f * (1.0f + copysignf(erf_abs, u)));
 }
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -417,8 +429,15 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
         }
+        if (d.flags & F_GELU_BWD) {   // `mask` holds the GELU's pre-activation u: v *= gelu'(u) (ViT fc2 backward-to-input)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] *= gelu_grad_erf(__uint_as_float(mw[j] << 16));
+            v[2 * j + 1] *= gelu_grad_erf(__uint_as_float(mw[j] & 0xFFFF0000u));
+          }
+        }
         if (out_f32) {
-          if (p_mask) {
+          if (p_mask && !(d.flags & F_GELU_BWD)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               if (!((short)(mw[j] & 0xFFFF) > 0)) v[2 * j] = 0.f;
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-            if (p_mask) o[j] &= positive_lanes_i16(mw[j]);
+            if (p_mask && !(d.flags & F_GELU_BWD)) o[j] &= positive_lanes_i16(mw[j]);
             if (relu) o[j] = relu_bf16x2(o[j]);
           }
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) =

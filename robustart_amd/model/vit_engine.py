@@ -12,7 +12,7 @@ import ctypes
 
 from .. import _lib
 
-F_RELU, F_OUT_F32, F_GELU = 1, 2, 4
+F_RELU, F_OUT_F32, F_GELU, F_GELU_BWD = 1, 2, 4, 8
 
 
 class ViTEngine:
@@ -93,7 +93,7 @@ class ViTEngine:
 
     def _gemm(self, src, wgt, dst, rows, k, n_cols, src_ld, dst_ld, bias=None, res=None, flags=0, n_taps=1,
               tap_src_off=None, rows_per_image=None, dst_rows_per_image=None, dst_row_off=0, batched=None,
-              src_rows_per_image=None):
+              src_rows_per_image=None, mask=None):
         """rows x k (x n_taps) times wgt^T -> dst.  rows_per_image/dst_rows_per_image/dst_row_off place the output
         rows of image b at b*dst_rows_per_image + dst_row_off (class-token slot).  batched = dict(n, inner,
         src=(outer, inner), wgt=(outer, inner), dst=(outer, inner), wgt_row_stride)."""
@@ -101,7 +101,7 @@ class ViTEngine:
         d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
         d.bias = bias.data_ptr() if bias is not None else None
         d.res = res.data_ptr() if res is not None else None
-        d.mask = None
+        d.mask = mask.data_ptr() if mask is not None else None
         rpi = rows_per_image or rows
         d.batch, d.grid_h, d.grid_w = rows // rpi, rpi, 1
         d.src_h, d.src_w, d.src_pix_stride = (src_rows_per_image or rpi), 1, src_ld
@@ -275,8 +275,7 @@ class ViTEngine:
             L = self.layers[li]
             x_in, xm, qkv, u, att = saved[li]
             dh = self._get('g_hid', (rows, L['hidden']))
-            self._gemm(dx, L['fc2_wd'], dh, rows, D, L['hidden'], D, L['hidden'])
-            _lib.check(lib.rart_gelu_bwd_bf16(_lib.ptr(dh), _lib.ptr(u), _lib.ptr(dh), dh.numel(), sp))
+            self._gemm(dx, L['fc2_wd'], dh, rows, D, L['hidden'], D, L['hidden'], mask=u, flags=F_GELU_BWD)   # du = (dx W2) * gelu'(u)
             dln = self._get('g_ln', (rows, D))
             self._gemm(dh, L['fc1_wd'], dln, rows, L['hidden'], D, L['hidden'], D)
             dxm = self._get('g_xm', (B, T, D))

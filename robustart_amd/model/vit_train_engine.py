@@ -15,7 +15,7 @@ Gradients are written into the parameters' `.grad` tensors (views of the flat gr
 import ctypes
 
 from .. import _lib
-from .vit_engine import F_OUT_F32, ViTEngine
+from .vit_engine import F_GELU_BWD, F_OUT_F32, ViTEngine
 
 
 class ViTTrainEngine(ViTEngine):
@@ -125,8 +125,7 @@ class ViTTrainEngine(ViTEngine):
             self._colsum(dx, D, rows, D, blk.fc2.bias.grad)
             self.on_grad_ready(blk.fc2.bias)
             dh = self._get('g_hid', (rows, hidden))
-            self._gemm(dx, L['fc2_wd'], dh, rows, D, hidden, D, hidden)
-            _lib.check(lib.rart_gelu_bwd_bf16(_lib.ptr(dh), _lib.ptr(u), _lib.ptr(dh), dh.numel(), sp))
+            self._gemm(dx, L['fc2_wd'], dh, rows, D, hidden, D, hidden, mask=u, flags=F_GELU_BWD)     # du = (dx W2) * gelu'(u)
             _lib.check(lib.rart_layernorm_bf16(_lib.ptr(xm), _lib.ptr(L['n2g']), _lib.ptr(L['n2b']), _lib.ptr(ln), rows, D, D, D,
                                                1e-6, sp))
             self._linear_grads(blk.fc1, dh, hidden, ln, rows)
