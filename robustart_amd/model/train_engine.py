@@ -171,7 +171,6 @@ class ResNet50TrainEngine:
 
     def _conv_dgrad(self, c, dz, dz_hw, dx, dx_hw, res=None):
         B = dz.shape[0]
-        first = True
         for parity, taps, rs, w in c.bwd:
             if parity is None:
                 self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res)
@@ -181,8 +180,6 @@ class ResNet50TrainEngine:
                     continue
                 self._gemm(dz, w, dx, B, (dx_hw[0] // 2, dx_hw[1] // 2), dz_hw, c.cout, c.cout, taps, c.cin, dx_hw,
                            c.cin, res=res, dst_stride=(2, 2), dst_off=(ph, pw))
-            first = False
-        return first
 
     def _bn_fwd(self, c, z, y, rows, relu, res=None):
         lib, bn = self.lib, c.bn
@@ -210,7 +207,7 @@ class ResNet50TrainEngine:
         self.on_grad_ready(bn.weight)
         self.on_grad_ready(bn.bias)
 
-    def _wgrad(self, dz, n_out, n_pad_cols, x, x_hw, x_c, grid_hw, taps, stride, grad, r_s_count, c_valid=None):
+    def _wgrad(self, dz, n_out, n_pad_cols, x, x_hw, x_c, grid_hw, taps, stride, grad, c_valid=None):
         """grad[n_out][c][taps] = sum_m dz[m][n] * x[pixel(m) + tap][c] as a split-K GEMM on the igemm kernel.
         dz: bf16 [B, gh, gw, n_pad_cols] (columns >= n_out are zero); x: bf16 [B, ih, iw, x_c]."""
         torch, lib, sp = self.torch, self.lib, _lib.stream_ptr()
@@ -245,7 +242,7 @@ class ResNet50TrainEngine:
                                              sp))
 
     def _conv_wgrad(self, c, dz, dz_hw, x, x_hw):
-        self._wgrad(dz, c.cout, c.cout, x, x_hw, c.cin, dz_hw, c.fwd_taps, c.stride, c.conv.weight.grad, c.r * c.s)
+        self._wgrad(dz, c.cout, c.cout, x, x_hw, c.cin, dz_hw, c.fwd_taps, c.stride, c.conv.weight.grad)
         self.on_grad_ready(c.conv.weight)
 
     # ------------------------------------------------------------------ forward
@@ -321,7 +318,7 @@ class ResNet50TrainEngine:
         pooled = acts['pooled']
         # classifier weight gradient: [classes][features] = dl^T . pooled  (1x1 "conv" over B pixels)
         self._wgrad(dlb.view(B, 1, 1, self.fc_kpad), self.n_classes, self.fc_kpad, pooled.view(B, 1, 1, self.fc_in), (1, 1),
-                    self.fc_in, (1, 1), [(0, 0)], 1, fc.weight.grad, 1)
+                    self.fc_in, (1, 1), [(0, 0)], 1, fc.weight.grad)
         self.on_grad_ready(fc.weight)
         dpool = self._get('dpool', (B, self.fc_in))
         self._gemm(dlb, self.fc_wd, dpool, B, (1, 1), (1, 1), self.fc_kpad, self.fc_kpad, [(0, 0)], self.fc_in, (1, 1),
@@ -358,11 +355,8 @@ class ResNet50TrainEngine:
                 dzd = self._get('g_zd', tuple(zd.shape))
                 self._bn_bwd(ds, g, None, zd, dzd, rows_o)
                 self._conv_wgrad(ds, dzd, ohw, x, xhw)
-                if ds.stride == 2:
-                    # a 1x1 stride-2 conv reaches only the even/even pixels: add its gradient there
-                    self._conv_dgrad(ds, dzd, ohw, dx, xhw, res=dx)
-                else:
-                    self._conv_dgrad(ds, dzd, ohw, dx, xhw, res=dx)
+                # accumulate the projection skip (a 1x1 stride-2 conv reaches only the even/even pixels)
+                self._conv_dgrad(ds, dzd, ohw, dx, xhw, res=dx)
             d_out = dx
         # stem: max-pool backward (applies y1's ReLU mask), BatchNorm backward, weight gradient on the padded hi plane
         y1, z1 = acts['y1'], acts['z1']
@@ -373,6 +367,5 @@ class ResNet50TrainEngine:
         dz1 = self._get('g_z1', tuple(z1.shape))
         self._bn_bwd(self.stem, dy1, y1, z1, dz1, B * h1 * w1)
         taps = [(r, s) for r in range(7) for s in range(7)]    # hi plane holds the image at offset (3, 3)
-        self._wgrad(dz1, 64, 64, acts['hi'][0], (H + 8, W + 8), 4, (h1, w1), taps, 2, self.model.conv1.weight.grad, 49,
-                    c_valid=3)
+        self._wgrad(dz1, 64, 64, acts['hi'][0], (H + 8, W + 8), 4, (h1, w1), taps, 2, self.model.conv1.weight.grad, c_valid=3)
         self.on_grad_ready(self.model.conv1.weight)

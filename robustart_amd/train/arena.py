@@ -71,7 +71,6 @@ class ParamArena:
         self._hooks = []
         self.overlap = overlap
         self._index = {id(p): i for i, p in enumerate(self.params)}
-        self.autograd_hooks = True
         if self.world > 1 and overlap:      # dist.sync: True -> every bucket is reduced after backward instead
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))

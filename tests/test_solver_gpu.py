@@ -60,7 +60,8 @@ def test_vit_attacked_eval_transfer_results_and_adv_train(tmp_path):
     clean = S.evaluate(_cfg('vit_base', n=6, bs=6), a, rank, world, device)
     a.attack = 'pgd_linf'
     adv = S.evaluate(_cfg('vit_base', n=6, bs=6), a, rank, world, device)
-    assert adv['count'] == 6 and adv['noise'] == 'pgd_linf' and adv['top1'] <= clean['top1'] + 1e-9
+    # (each evaluate() builds its own randomly initialised model, so accuracies are not comparable across calls)
+    assert clean['count'] == 6 and adv['count'] == 6 and adv['noise'] == 'pgd_linf'
     p_clean = os.path.join(str(tmp_path), 'vitA', 'none_0', 'results.txt.all')
     p_adv = os.path.join(str(tmp_path), 'vitA', 'pgd_linf_%.3f' % (2 / 255), 'results.txt.all')
     assert len(open(p_clean).readlines()) == 6 == len(open(p_adv).readlines())
