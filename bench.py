@@ -45,11 +45,57 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='images in the bounded CPU baseline sample')
     ap.add_argument('--workload', choices=['headline', 'vit_inc', 'vit_pgd', 'adv_train'], default='headline',
-                    help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 3: ViT-B/16 evaluated "
+                    help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 4: ViT-B/16 evaluated "
                          "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost skipped: no textures)")
     ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
                     help="'hip' = hand-written engine (product); 'scaffold' = PyTorch-ROCm/MIOpen, for comparison only")
+    ap.add_argument('--spawn-check', action='store_true',
+                    help='launch-path self test (no GPU work): every rank joins a gloo group, rank 0 prints one JSON line '
+                         'with the world size it saw -- covers the --gpus N re-launch on a CPU-only box')
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_multi_rank(n):
+    """`python bench.py --gpus N` started as ONE plain process (no RANK in the environment): re-launch this very
+    command line as N ranks, one per GPU, under torch.distributed.run on 127.0.0.1 -- the launch shape of the reference's
+    own evaluation (exprs/exp/imagenet_c_loop_mini/eval.sh:21-23, torchrun --nproc_per_node=8) -- and hand back its exit
+    code.  Rank 0 of the child job prints the one JSON line; stdout / stderr pass straight through."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def spawn_check(args):
+    """Body of --spawn-check: the rendezvous of the multi-rank launch without any GPU work (gloo)."""
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({'spawn_check': True, 'n_gpus': world, 'requested_gpus': args.gpus,
+                          'rank_sum': seen, 'expected_rank_sum': world * (world + 1) // 2}))
 
 
 def build_workload(B, device, rank):
@@ -206,7 +252,7 @@ def cpu_baseline(sample, model_fp32):
 
 
 def run_vit_inc(args, device, rank, world, dist):
-    """BASELINE config 3 (secondary mode, not the headline line): per step, one resident batch of 256 uint8 images is
+    """BASELINE config 4 (secondary mode, not the headline line): per step, one resident batch of 256 uint8 images is
     corrupted by each of the 15 benchmark corruptions at 5 severities (frost needs textures the reference does not
     ship -> 14 x 5 = 70 corrupted batches) and each is evaluated by ViT-B/16 on the HIP engine."""
     from robustart_amd.model import get_model
@@ -253,7 +299,7 @@ def run_vit_inc(args, device, rank, world, dist):
                           'value': n_img * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-                          'config': {'workload': 'BASELINE config 3 (secondary): 70 corrupted batches of 256 per step -> ViT-B/16 eval',
+                          'config': {'workload': 'BASELINE config 4 (secondary): 70 corrupted batches of 256 per step -> ViT-B/16 eval',
                                      'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
 
 
@@ -367,11 +413,20 @@ def run_adv_train(args, device, rank, world, dist):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # started as a plain process: become N ranks (the driver's own torchrun launch sets RANK and skips this)
+        sys.exit(relaunch_multi_rank(args.gpus))
+    if args.spawn_check:
+        return spawn_check(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
+    if local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
