@@ -297,6 +297,15 @@ int rart_engine_avgpool_bwd(const void* y, const void* dpool, void* dz, int n, i
  * the [0,1] image (the 1/std of the normalisation applied). */
 int rart_engine_stem_col2im(const void* patches, float* grad, int n, int h, int w, int patch_cols,
                             const float* std_host, rart_stream_t stream);
+/* The same stem backward as ONE kernel: pooled gradient dpool [n][h/4][w/4][64] bf16 + the max pool's argmax codes
+ * (rart_engine_maxpool; code 15 = window maximum <= 0) -> fp32 NCHW gradient w.r.t. the [0,1] image.  Max-pool backward,
+ * the ReLU mask and the transposed 7x7/2 convolution are fused: an implicit GEMM over the 4x4 neighbourhood of
+ * stem-output positions (K = 16 taps x 64 channels, N = 4 input parities x 3 channels) on MFMA with the gathered
+ * operand built in LDS.  wtab: bf16 [16][1024], row (py*2+px)*3+c, column ((dp+1)*4+(dq+1))*64+k = W[k][c][py+3-2dp][px+3-2dq]
+ * (0 where the tap index leaves 0..6; rows 12..15 zero).  h, w multiples of 4.
+ * (autograd of attack.py:21-22 / autopgd_base.py:271-289 through conv1-bn1-relu-maxpool) */
+int rart_engine_stem_bwd_fused(const void* dpool, const void* argmax, const void* wtab, float* grad, int n, int h, int w,
+                               const float* std_host, rart_stream_t stream);
 /* fp32 [rows][cols] -> bf16 [rows][dst_cols] (zero padded): dlogits -> GEMM operand. */
 int rart_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int dst_cols, rart_stream_t stream);
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     'rart_engine_avgpool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_engine_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_engine_stem_col2im': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'rart_engine_stem_bwd_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_f32_to_bf16_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_vit_patchify': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),
@@ -192,11 +193,14 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device):
-    """A cached, grow-only scratch buffer per device (torch's allocator owns the memory)."""
+    """A cached, grow-only scratch buffer per (device, current stream): kernels enqueued on different streams (a loader
+    stream corrupting the next batch while an attack runs) never share scratch memory; within one stream the launches
+    are ordered, so one buffer is safe.  torch's allocator owns the memory."""
     import torch
     if nbytes <= 0:
         return None
-    key = str(device)
+    dev = torch.device(device)
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

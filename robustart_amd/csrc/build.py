@@ -19,13 +19,12 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-I', os.path.join(os.path.dirname(PKG), 'include')]
 
-# feature macros tell stubs_todo.hip which families already have a real translation unit
+
 # per-file extra flags: the matrix-core noise generator reads its MFMA sums straight from VGPRs (gfx950's unified
 # register file) instead of v_accvgpr_read copies: 16 fewer VALU instructions of ~215 in a VALU-issue-bound kernel
 EXTRA_FLAGS = {'corrupt_pointwise.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
-FEATURES = {'corrupt_resample.hip': 'RART_HAVE_RESAMPLE', 'corrupt_jpeg.hip': 'RART_HAVE_JPEG',
-            'corrupt_stencil.hip': 'RART_HAVE_STENCIL', 'corrupt_composite.hip': 'RART_HAVE_COMPOSITE'}
+FEATURES = {}
 
 
 def sources():

@@ -98,6 +98,11 @@ __global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict_
       }
     }
     out[i] = pack8(m);
+    // code 15 = the window maximum is <= 0: behind a ReLU its gradient is dead, so the fused stem backward
+    // (stem_fused.hip) needs no second look at y; it never equals a window position, k_maxpool_bwd is unaffected
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!(m[j] > 0.f)) code[j] = 15u;
     if (arg)
       arg[i] = make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
                           code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24));

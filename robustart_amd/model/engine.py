@@ -116,6 +116,8 @@ class ResNet50Engine:
         wp = wb.permute(2, 3, 1, 0).reshape(147, 64)
         self.stem_patch_cols = 152                                        # 147 rounded up to 8
         self.stem_wd = _bf16(_pad_rows(wp, _rows_mult(self.stem_patch_cols))).to(dev)
+        self.stem_wt = self._stem_bwd_table(wb).to(dev)                  # fused stem backward (stem_fused.hip)
+        self.fused_stem_bwd = True       # False: max-pool bwd -> patches GEMM -> col2im (kept as the cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -134,6 +136,26 @@ class ResNet50Engine:
         self.fc_wd = _bf16(wt).to(dev)                                    # [2048][1024]
         self._buf = {}
         self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
+
+    @staticmethod
+    def _stem_bwd_table(wb):
+        """bf16 [16][1024] table of rart_engine_stem_bwd_fused from the folded stem weights wb [64][3][7][7]:
+        row (py*2+px)*3+c, column ((dp+1)*4+(dq+1))*64+k = W[k][c][py+3-2dp][px+3-2dq] (0 outside 0..6)."""
+        import torch
+        t = torch.zeros(16, 16, 64, dtype=wb.dtype, device=wb.device)
+        for py in range(2):
+            for px in range(2):
+                for dp in range(-1, 3):
+                    r = py + 3 - 2 * dp
+                    if not 0 <= r <= 6:
+                        continue
+                    for dq in range(-1, 3):
+                        s_ = px + 3 - 2 * dq
+                        if not 0 <= s_ <= 6:
+                            continue
+                        for c in range(3):
+                            t[(py * 2 + px) * 3 + c, (dp + 1) * 4 + (dq + 1)] = wb[:, c, r, s_]
+        return t.reshape(16, 1024).to(torch.bfloat16).contiguous()
 
     # ------------------------------------------------------------------ re-fold from the live parameters
     def refold(self, model):
@@ -175,6 +197,7 @@ class ResNet50Engine:
         self.stem_w[:, 224:] = wrow
         self.stem_wd.zero_()
         self.stem_wd[:147] = wb.permute(2, 3, 1, 0).reshape(147, 64)
+        self.stem_wt.copy_(self._stem_bwd_table(wb.float()))
         bi = 0
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -351,7 +374,14 @@ class ResNet50Engine:
                 self._conv_bwd(ca, dza, xhw, dx, xhw, mask=x)
                 self._conv_bwd(ds, dz, ohw, dx, xhw, res=dx, mask=x)             # accumulate the projection skip
             dz = dx
-        # stem: max-pool backward (+ReLU mask of y1), patches GEMM, col2im to the fp32 image
+        grad = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
+        stdf = (ctypes.c_float * 3)(*std)
+        if self.fused_stem_bwd:
+            # stem: max-pool backward + ReLU mask + transposed 7x7/2 conv to the fp32 image, one kernel
+            _lib.check(lib.rart_engine_stem_bwd_fused(_lib.ptr(dz), _lib.ptr(acts['p1_argmax']), _lib.ptr(self.stem_wt),
+                                                      _lib.ptr(grad), B, H, W, stdf, sp))
+            return logits, loss, grad, pred
+        # cross-check path: max-pool backward (+ReLU mask of y1), patches GEMM, col2im to the fp32 image
         y1 = acts['y1']
         h1, w1 = H // 2, W // 2
         dz1 = self._get('g_y1', tuple(y1.shape))
@@ -360,8 +390,6 @@ class ResNet50Engine:
         pc = self.stem_patch_cols
         patches = self._get('patches', (B, h1, w1, pc))
         self._gemm(dz1, self.stem_wd, patches, B, (h1, w1), (h1, w1), 64, 64, [(0, 0)], pc, (h1, w1), pc)
-        grad = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
-        stdf = (ctypes.c_float * 3)(*std)
         _lib.check(lib.rart_engine_stem_col2im(_lib.ptr(patches), _lib.ptr(grad), B, H, W, pc, stdf, sp))
         return logits, loss, grad, pred
 

@@ -138,6 +138,14 @@ def _seed(seed):
     return _rng.current_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
+def _offset(sample_offset, n):
+    """Global index of the call's first sample.  None (the AddNoise.add_noise path) advances the process-wide sample
+    counter of noise/rng.py by n, exactly as corrupt_batch_ does: consecutive calls draw fresh random starts (the
+    reference draws from torch's global generator per call) and the draws do not depend on how a dataset is batched;
+    an explicit offset (solver / bench: the dataset index of the first image) pins them."""
+    return _rng.next_offset(n) if sample_offset is None else int(sample_offset)
+
+
 # ---------------------------------------------------------------------------------------
 # gradient providers
 # ---------------------------------------------------------------------------------------
@@ -200,12 +208,12 @@ def _check_inputs(x, y):
 # the attack_list functions (attack.py:20-52)
 # ---------------------------------------------------------------------------------------
 
-def pgd_linf(input, label, f_model, eps, rel_stepsize, steps, seed=None, sample_offset=0, init_u=None):
+def pgd_linf(input, label, f_model, eps, rel_stepsize, steps, seed=None, sample_offset=None, init_u=None):
     """attack.py:20-23 -> foolbox LinfProjectedGradientDescentAttack(rel_stepsize, steps), raw advs.
     random start U(-eps,eps) clipped to [0,1]; `steps` x { CE-sum gradient; fused sign/project/clip }."""
     x0, y = _check_inputs(input, label)
     prov = _Provider(f_model, normalize_inside=False)
-    x = attack_init_linf(x0, eps, True, seed, sample_offset, init_u)
+    x = attack_init_linf(x0, eps, True, seed, _offset(sample_offset, x0.shape[0]), init_u)
     for _ in range(int(steps)):
         _, _, g, _ = prov.logits_and_grad(x, y, LOSS_CE)
         pgd_step_linf_(x, g, x0, eps, eps * rel_stepsize)
@@ -221,7 +229,7 @@ def fgsm(input, label, f_model, eps):
     return pgd_step_linf_(x, g, x0, eps, eps)
 
 
-def pgd_l2(input, label, f_model, eps, rel_stepsize, steps, seed=None, sample_offset=0, init_delta=None):
+def pgd_l2(input, label, f_model, eps, rel_stepsize, steps, seed=None, sample_offset=None, init_delta=None):
     """attack.py:25-28 -> foolbox L2ProjectedGradientDescentAttack.  Start: uniform point of the
     eps-ball (normalised (n+2)-dim gaussian, first n coordinates)."""
     torch = _lib.require_gpu()
@@ -230,7 +238,7 @@ def pgd_l2(input, label, f_model, eps, rel_stepsize, steps, seed=None, sample_of
     if init_delta is None:
         B, n = x0.shape[0], x0[0].numel()
         t = torch.empty(B, n + 2, dtype=torch.float32, device=x0.device)
-        _lib.check(_lib.load().rart_rng_normal_f32(_lib.ptr(t), B, n + 2, _seed(seed), sample_offset, 3,
+        _lib.check(_lib.load().rart_rng_normal_f32(_lib.ptr(t), B, n + 2, _seed(seed), _offset(sample_offset, B), 3,
                                                    _lib.stream_ptr()))
         init_delta = (eps * t[:, :n] / t.norm(dim=1, keepdim=True)).view_as(x0)   # one-off start (host plumbing)
     x = torch.clamp(x0 + init_delta, 0.0, 1.0).contiguous()
@@ -240,14 +248,14 @@ def pgd_l2(input, label, f_model, eps, rel_stepsize, steps, seed=None, sample_of
     return x
 
 
-def mim_linf(input, label, model, eps, num_steps, step_size, decay_factor, seed=None, sample_offset=0,
+def mim_linf(input, label, model, eps, num_steps, step_size, decay_factor, seed=None, sample_offset=None,
              init_noise=None):
     """attack.py:40-42 -> _mim_whitebox (imfgsm_attack.py:62-93).  The reference's two throw-away
     forwards (:69, :91) and per-step SGD object are not reproduced; the iterate is identical."""
     torch = _lib.require_gpu()
     x0, y = _check_inputs(input, label)
     prov = _Provider(model, normalize_inside=True)
-    x = attack_init_linf(x0, eps, False, seed, sample_offset, init_noise)     # not clipped (:73-74)
+    x = attack_init_linf(x0, eps, False, seed, _offset(sample_offset, x0.shape[0]), init_noise)     # not clipped (:73-74)
     m = torch.zeros_like(x0)
     B = x0.shape[0]
     for _ in range(int(num_steps)):
@@ -313,12 +321,13 @@ def _apgd_single_run(prov, x, y, norm, eps, n_iter, loss_kind, y_target=None, rh
 
 
 def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce', n_restarts=1, seed=None,
-                 sample_offset=0, init_ts=None, _prov=None):
+                 sample_offset=None, init_ts=None, _prov=None):
     """APGDAttack.perturb (autopgd_base.py:450-529, best_loss=False)."""
     torch = _lib.require_gpu()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
     kind = {'ce': LOSS_CE, 'dlr': LOSS_DLR}[loss]
+    sample_offset = _offset(sample_offset, x.shape[0])
     y_pred = prov.logits(x).max(1)[1]
     adv = x.clone()
     acc = y_pred == y
@@ -336,11 +345,12 @@ def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce'
 
 
 def apgd_targeted_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, n_target_classes=9, seed=None,
-                          sample_offset=0, init_ts=None, _prov=None):
+                          sample_offset=None, init_ts=None, _prov=None):
     """APGDAttack_targeted.perturb (autopgd_base.py:610-690, n_restarts 1)."""
     torch = _lib.require_gpu()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
+    sample_offset = _offset(sample_offset, x.shape[0])
     y_pred = prov.logits(x).max(1)[1]
     adv = x.clone()
     acc = y_pred == y
@@ -370,7 +380,7 @@ def _square_p_selection(it, p_init, n_queries, rescale):
     return p_init / 512 if it > 8000 else p_init
 
 
-def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, rescale=False, seed=None, sample_offset=0,
+def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, rescale=False, seed=None, sample_offset=None,
                    init_sign=None, draws=None, check_every=50, _prov=None):
     """SquareAttack.perturb, Linf, loss 'margin', n_restarts 1 (Attacks/autoattack/square.py:221-294,532-600).
     Forward-only random search: per query one proposal kernel, one model forward, one margin kernel and a
@@ -383,6 +393,7 @@ def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, resc
     lib = _lib.load()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
+    sample_offset = _offset(sample_offset, x.shape[0])
     adv = x.clone()
     acc = prov.logits(x).max(1)[1] == y
     ind = acc.nonzero().flatten()
@@ -566,7 +577,7 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
     return x_adv
 
 
-def pgd_l1(input, label, model, eps, input_size, eps_step, max_iter, batch_size, seed=None, sample_offset=0,
+def pgd_l1(input, label, model, eps, input_size, eps_step, max_iter, batch_size, seed=None, sample_offset=None,
            init_signed_exp=None, init_radius=None):
     """attack.py:44-49 -> ART ProjectedGradientDescentPyTorch(norm=1, num_random_init=1) on a PyTorchClassifier with
     clip_values (0, 1) and ImageNet preprocessing (so `model` takes normalised input and the attack lives in [0,1]).
@@ -577,7 +588,7 @@ def pgd_l1(input, label, model, eps, input_size, eps_step, max_iter, batch_size,
     batch of 16 only chunks the work (the per-sample L1 normalisation makes the batch-mean loss scale irrelevant)."""
     x0, y = _check_inputs(input, label)
     prov = _Provider(model, normalize_inside=True)
-    x = random_start_l1(x0, eps, seed, sample_offset, init_signed_exp, init_radius)
+    x = random_start_l1(x0, eps, seed, _offset(sample_offset, x0.shape[0]), init_signed_exp, init_radius)
     for _ in range(int(max_iter)):
         _, _, g, _ = prov.logits_and_grad(x, y, LOSS_CE)
         pgd_step_l1_(x, g, x0, eps, eps_step)

@@ -1,0 +1,16 @@
+import sys; sys.path.insert(0, '/root/repo')
+import time, torch
+from robustart_amd.model import get_model
+from robustart_amd.model.engine import ResNet50Engine
+MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+torch.manual_seed(0)
+eng = ResNet50Engine(get_model({'type': 'resnet50_official'}).eval(), 'cuda')
+B = 256
+x = torch.rand(B, 3, 224, 224, device='cuda'); y = torch.randint(0, 1000, (B,), device='cuda')
+def t(fn, n=8):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+for fused in (False, True, False, True):
+    eng.fused_stem_bwd = fused
+    print('fused_stem_bwd=%s  fwd+bwd %.3f ms' % (fused, t(lambda: eng.forward_backward(x, MEAN, STD, y, 0))), flush=True)

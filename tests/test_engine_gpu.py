@@ -301,3 +301,71 @@ def test_refold_reproduces_constructor_tables_and_tracks_new_weights():
     fresh = tables(ResNet50Engine(model))
     for a, b in zip(fresh, tables(eng)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 64, 96), (3, 32, 32), (1, 224, 224)])
+def test_fused_stem_backward_kernel_vs_fp64(B, H, W):
+    """rart_engine_stem_bwd_fused alone: random pooled gradient, random argmax codes (including the dead code 15 and
+    out-of-image window positions), random bf16 weights.  Reference in fp64: scatter the pooled gradient to the recorded
+    window positions (max-pool backward), round dz1 to bf16 as the kernel stores it, transposed 7x7/2 conv, / std."""
+    import ctypes
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import ResNet50Engine
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    oh, ow = H // 2, W // 2
+    qh, qw = oh // 2, ow // 2
+    wb = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(torch.bfloat16).float()
+    dpool = torch.randn(B, qh, qw, 64, generator=g).to(torch.bfloat16)
+    code = torch.randint(0, 10, (B, qh, qw, 64), generator=g, dtype=torch.uint8)
+    code[code == 9] = 15
+    # window positions that fall outside the stem-output grid can never be an argmax: remap them to a valid one
+    ky, kx = code // 3, code % 3
+    qy = torch.arange(qh).view(1, qh, 1, 1)
+    qx = torch.arange(qw).view(1, 1, qw, 1)
+    live = code != 15
+    py = 2 * qy - 1 + ky.long()
+    px = 2 * qx - 1 + kx.long()
+    bad = live & ((py < 0) | (py >= oh) | (px < 0) | (px >= ow))
+    code[bad] = 4                                                   # the window centre is always inside
+    ky, kx = code // 3, code % 3
+    py = (2 * qy - 1 + ky.long()).clamp(0, oh - 1)
+    px = (2 * qx - 1 + kx.long()).clamp(0, ow - 1)
+    live = code != 15
+    dz1 = torch.zeros(B, oh, ow, 64, dtype=torch.float64)
+    bi = torch.arange(B).view(B, 1, 1, 1).expand_as(code)
+    ci = torch.arange(64).view(1, 1, 1, 64).expand_as(code)
+    dz1.index_put_((bi[live], py.expand_as(code)[live], px.expand_as(code)[live], ci[live]), dpool.double()[live],
+                   accumulate=True)
+    dz1 = dz1.float().to(torch.bfloat16).double()
+    ref = torch.nn.grad.conv2d_input((B, 3, H, W), wb.double(), dz1.permute(0, 3, 1, 2), stride=2, padding=3)
+    ref = ref / torch.tensor(STD, dtype=torch.float64).view(1, 3, 1, 1)
+    wt = ResNet50Engine._stem_bwd_table(wb).cuda()
+    grad = torch.full((B, 3, H, W), float('nan'), device='cuda')
+    stdf = (ctypes.c_float * 3)(*STD)
+    _lib.check(lib.rart_engine_stem_bwd_fused(_lib.ptr(dpool.cuda()), _lib.ptr(code.cuda()), _lib.ptr(wt), _lib.ptr(grad),
+                                              B, H, W, stdf, _lib.stream_ptr()))
+    got = grad.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    print('fused stem backward B=%d %dx%d: max abs err %.3e (ref max %.3f)' % (B, H, W, err, ref.abs().max().item()))
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_fused_stem_backward_matches_unfused_chain(setup):
+    m, eng = setup
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(3, 3, 96, 128, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    try:
+        eng.fused_stem_bwd = True
+        _, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        eng.fused_stem_bwd = False
+        _, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.fused_stem_bwd = True
+    a, b = ga.flatten().double(), gb.flatten().double()
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    rel = ((a - b).norm() / b.norm()).item()
+    print('fused vs unfused stem backward: cos %.6f rel-L2 %.5f' % (cos, rel))
+    assert cos > 0.9999 and rel < 0.01      # the unfused chain rounds the 147 patch columns to bf16, the fused one does not
