@@ -264,13 +264,17 @@ typedef struct rart_conv_desc {
   int64_t tap_src_off[16];
   int32_t n_cols;
   int32_t dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
-  int32_t flags;          /* 1 = ReLU, 2 = fp32 output, 4 = exact GELU */
+  int32_t flags;          /* 1 = ReLU, 2 = fp32 output, 4 = exact GELU, 8 = GELU' of `mask`, 16 = `mask` is a 1-bit tensor */
   /* batched problems (attention: one GEMM per (image, head)): problem z in [0, n_batched) splits into
    * zo = z / z_inner, zi = z % z_inner; zo*_z_outer + zi*_z_inner elements are added to src / wgt / dst (res and
    * mask follow dst).  n_batched <= 1 = a single problem.  wgt_row_stride: elements between consecutive weight
    * rows (0 = n_taps * k_per_tap), so K / V can be read in place from the fused qkv activation. */
   int32_t n_batched, z_inner, wgt_row_stride, reserved_;
   int64_t src_z_outer, src_z_inner, wgt_z_outer, wgt_z_inner, dst_z_outer, dst_z_inner;
+  /* 1-bit-per-element sign tensors, indexed like dst (byte = element / 8, bit = element % 8): the eval engine's backward
+   * needs activations only for their ReLU sign, so the forward GEMM writes (output > 0) here (nullable) and the backward
+   * GEMM reads it through `mask` with flag 16 -- 1/16 of the bytes of a bf16 mask.  bf16 output, unbatched problems. */
+  void* sign_out;
 } rart_conv_desc;
 
 int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
@@ -288,6 +292,10 @@ int rart_engine_prep_input(const void* src, int src_is_u8, void* hi, void* lo, i
  * input y: dz = (y > 0) * sum of dpool over the windows whose argmax is this pixel. */
 int rart_engine_maxpool(const void* in, void* out, void* argmax_out, int n, int h, int w, int c,
                         rart_stream_t stream);
+/* The same pool, also writing sign_out (nullable): uint8 [n][h/2][w/2][c/8], bit j of byte k = (pooled channel 8k+j > 0)
+ * -- the 1-bit ReLU mask the backward GEMMs read with rart_conv_desc flag 16.  argmax code 15 = window maximum <= 0. */
+int rart_engine_maxpool_keep(const void* in, void* out, void* argmax_out, void* sign_out, int n, int h, int w, int c,
+                             rart_stream_t stream);
 int rart_engine_maxpool_bwd(const void* y, const void* argmax, const void* dpool, void* dz, int n, int h, int w,
                             int c, rart_stream_t stream);
 /* global average pool [n][hw][c] -> [n][c], and dz = (y > 0) ? dpool / hw : 0. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     'rart_engine_prep_input': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),
     'rart_engine_maxpool': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_maxpool_keep': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_engine_maxpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_engine_avgpool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_engine_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -131,7 +132,8 @@ class ConvDesc(ctypes.Structure):
                 ('n_batched', ctypes.c_int32), ('z_inner', ctypes.c_int32), ('wgt_row_stride', ctypes.c_int32),
                 ('reserved_', ctypes.c_int32),
                 ('src_z_outer', ctypes.c_int64), ('src_z_inner', ctypes.c_int64), ('wgt_z_outer', ctypes.c_int64),
-                ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64)]
+                ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64),
+                ('sign_out', c_void_p)]
 
 
 _lib = None

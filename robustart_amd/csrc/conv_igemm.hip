@@ -53,12 +53,15 @@ struct RartConvDescDev {
   // exact division by multiply-shift for dividends < 2^31 (row index -> (image, oy, ox); K step -> tap):
   // q = (n * magic) >> shift.  A hardware 64-bit division costs ~300 instructions and every workgroup needed six.
   uint32_t gw_magic, gw_shift, gh_magic, gh_shift, tpt_magic, tpt_shift;
+  // 1-bit-per-element side tensors, indexed like dst (byte (off + col) / 8, bit col % 8): sign_out receives (output > 0)
+  // of a bf16 store (the ReLU mask the backward pass will need); with F_MASK_BITS `mask` is such a tensor instead of bf16
+  uint8_t* sign_out;
 };
 
 namespace {
 constexpr int BM = 128;
 constexpr int kThreads = 256;
-enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8 };
+enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8, F_MASK_BITS = 16 };
 
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
@@ -74,6 +77,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // round
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {           // sign bit set -> 0 (also -0.0)
   const i16x2_t z = {0, 0};
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
+}
+// two mask bits (bit 0 -> low half, bit 1 -> high half) -> 0xFFFF per selected bf16 half
+__device__ __forceinline__ uint32_t halves_from_bits(uint32_t byte, int pair) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe(byte, 2 * pair, 1);        // 0 or 0xFFFFFFFF
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe(byte, 2 * pair + 1, 1);
+  return __builtin_amdgcn_perm(hi, lo, 0x07060100u);                              // {hi.b3, hi.b2, lo.b1, lo.b0}
+}
+// packed pair of non-negative-or-zero bf16 (after ReLU) or any bf16 -> 2 bits (half > 0)
+__device__ __forceinline__ uint32_t bits_from_halves(uint32_t w) {
+  const i16x2_t z = {0, 0}, one = {1, 1};
+  const uint32_t t = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z), one));
+  return (t | (t >> 15)) & 3u;
 }
 __device__ __forceinline__ uint32_t positive_lanes_i16(uint32_t w) {    // 0xFFFF per half whose int16 is > 0
   const i16x2_t z = {0, 0}, one = {1, 1}, full = {-1, -1};
@@ -380,7 +395,8 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   const int cw = lane % CW, rw0 = lane / CW;
   const int col = n0 + wn * WN + cw * 8;
   const bool col_ok = col < d.n_cols;
-  const bool relu = d.flags & F_RELU, out_f32 = d.flags & F_OUT_F32;
+  const bool relu = d.flags & F_RELU, out_f32 = d.flags & F_OUT_F32, mask_bits = d.flags & F_MASK_BITS;
+  uint8_t* const p_sign = d.sign_out;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     // issue the residual / mask reads of this pass first: their HBM latency overlaps the LDS transposition
@@ -395,7 +411,10 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
       if (off != 0xFFFFFFFFu) {
         const size_t bo = (size_t)((off + (uint32_t)col) * 2u);
         if (p_res) rv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_res) + bo);
-        if (p_mask) mv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_mask) + bo);
+        if (p_mask) {
+          if (mask_bits) mv[q].x = reinterpret_cast<const uint8_t*>(p_mask)[(off + (uint32_t)col) >> 3];
+          else mv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_mask) + bo);
+        }
       }
     }
 #pragma unroll
@@ -458,8 +477,13 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-            if (p_mask && !(d.flags & F_GELU_BWD)) o[j] &= positive_lanes_i16(mw[j]);
+            if (p_mask && !(d.flags & F_GELU_BWD)) o[j] &= mask_bits ? halves_from_bits(mw[0], j) : positive_lanes_i16(mw[j]);
             if (relu) o[j] = relu_bf16x2(o[j]);
+          }
+          if (p_sign) {
+            const uint32_t sb = bits_from_halves(o[0]) | (bits_from_halves(o[1]) << 2) | (bits_from_halves(o[2]) << 4) |
+                                (bits_from_halves(o[3]) << 6);
+            p_sign[(off + (uint32_t)col) >> 3] = (uint8_t)sb;
           }
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) =
               make_uint4(o[0], o[1], o[2], o[3]);
@@ -503,6 +527,9 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   d.wgt_row_stride = h->wgt_row_stride;
   d.src_zo = h->src_z_outer; d.src_zi = h->src_z_inner; d.wgt_zo = h->wgt_z_outer; d.wgt_zi = h->wgt_z_inner;
   d.dst_zo = h->dst_z_outer; d.dst_zi = h->dst_z_inner;
+  d.sign_out = (uint8_t*)h->sign_out;
+  RART_CHECK_ARG(!(d.sign_out || (d.flags & F_MASK_BITS)) || (nz == 1 && !(d.flags & (F_OUT_F32 | F_GELU_BWD))),
+                 "rart_conv_igemm_bf16: sign_out / bit masks need a single bf16-output problem");
   {
     auto magic = [](uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividends < 2^31
       uint32_t l = 0;

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(kBlock) void k_prep_input(const void* __restrict__ 
 // channel, WHICH of the 9 window positions (ky*3+kx) holds the first maximum in scan order (PyTorch's
 // argmax rule) as one byte, so the backward is a <= 4-window gather instead of a 36-tap search.
 __global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict__ in, uint4* __restrict__ out,
-                                                        uint2* __restrict__ arg, int n, int h, int w, int c8) {
+                                                        uint2* __restrict__ arg, uint8_t* __restrict__ sign, int n, int h,
+                                                        int w, int c8) {
   const int oh = h / 2, ow = w / 2;
   const size_t total = (size_t)n * oh * ow * c8;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
@@ -103,6 +104,12 @@ __global__ __launch_bounds__(kBlock) void k_maxpool_fwd(const uint4* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (!(m[j] > 0.f)) code[j] = 15u;
+    if (sign) {       // 1 bit per channel: pooled value > 0 (the ReLU mask of the first block's input)
+      uint32_t sb = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sb |= (m[j] > 0.f ? 1u : 0u) << j;
+      sign[i] = (uint8_t)sb;
+    }
     if (arg)
       arg[i] = make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
                           code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24));
@@ -277,13 +284,19 @@ int rart_engine_prep_input(const void* src, int src_is_u8, void* hi, void* lo, i
   return RART_OK;
 }
 
-int rart_engine_maxpool(const void* in, void* out, void* argmax_out, int n, int h, int w, int c,
-                        rart_stream_t stream) {
+int rart_engine_maxpool_keep(const void* in, void* out, void* argmax_out, void* sign_out, int n, int h, int w, int c,
+                             rart_stream_t stream) {
   RART_CHECK_ARG(in && out && n > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0, "rart_engine_maxpool: bad arguments");
   hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for((size_t)n * (h / 2) * (w / 2) * (c / 8))), dim3(kBlock), 0,
-                     (hipStream_t)stream, (const uint4*)in, (uint4*)out, (uint2*)argmax_out, n, h, w, c / 8);
+                     (hipStream_t)stream, (const uint4*)in, (uint4*)out, (uint2*)argmax_out, (uint8_t*)sign_out, n, h, w,
+                     c / 8);
   RART_CHECK_LAUNCH("rart_engine_maxpool");
   return RART_OK;
+}
+
+int rart_engine_maxpool(const void* in, void* out, void* argmax_out, int n, int h, int w, int c,
+                        rart_stream_t stream) {
+  return rart_engine_maxpool_keep(in, out, argmax_out, nullptr, n, h, w, c, stream);
 }
 
 int rart_engine_maxpool_bwd(const void* y, const void* argmax, const void* dpool, void* dz, int n, int h, int w, int c,

@@ -17,7 +17,7 @@ import ctypes
 
 from .. import _lib
 
-F_RELU, F_OUT_F32 = 1, 2
+F_RELU, F_OUT_F32, F_MASK_BITS = 1, 2, 16
 
 
 def _bf16(t):
@@ -118,6 +118,7 @@ class ResNet50Engine:
         self.stem_wd = _bf16(_pad_rows(wp, _rows_mult(self.stem_patch_cols))).to(dev)
         self.stem_wt = self._stem_bwd_table(wb).to(dev)                  # fused stem backward (stem_fused.hip)
         self.fused_stem_bwd = True       # False: max-pool bwd -> patches GEMM -> col2im (kept as the cross-check)
+        self.sign_bit_masks = True       # False: the backward reads the bf16 activations for their ReLU sign (cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -225,12 +226,13 @@ class ResNet50Engine:
 
     def _gemm(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix,
               bias=None, res=None, mask=None, flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0),
-              tap_src_off=None):
+              tap_src_off=None, sign_out=None):
         d = _lib.ConvDesc()
         d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
         d.bias = bias.data_ptr() if bias is not None else None
         d.res = res.data_ptr() if res is not None else None
         d.mask = mask.data_ptr() if mask is not None else None
+        d.sign_out = sign_out.data_ptr() if sign_out is not None else None
         d.batch, d.grid_h, d.grid_w = batch, grid[0], grid[1]
         d.src_h, d.src_w, d.src_pix_stride = src_hw[0], src_hw[1], src_pix
         d.k_per_tap, d.n_taps = k_per_tap, len(taps)
@@ -255,24 +257,28 @@ class ResNet50Engine:
             return
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
-    def _conv_fwd(self, c, x, xhw, out, relu, res=None):
+    def _conv_fwd(self, c, x, xhw, out, relu, res=None, sign=None):
         B = x.shape[0]
         oh, ow = xhw[0] // c.stride, xhw[1] // c.stride
         self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
-                   bias=c.bias, res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride))
+                   bias=c.bias, res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride), sign_out=sign)
 
     def _conv_bwd(self, c, dz, dz_hw, dx, dx_hw, res=None, mask=None):
-        """dx = backward-to-input of conv c applied to dz (then + res, masked)."""
+        """dx = backward-to-input of conv c applied to dz (then + res, masked).  mask: the forward activation at dx's
+        place (bf16) or its 1-bit sign tensor (uint8, written by the forward GEMM's sign_out)."""
+        torch = _lib.require_gpu()
         B = dz.shape[0]
+        fl = F_MASK_BITS if (mask is not None and mask.dtype == torch.uint8) else 0
         for parity, taps, w in c.bwd:
             if parity is None:
-                self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res, mask=mask)
+                self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res, mask=mask,
+                           flags=fl)
             else:
                 ph, pw = parity
                 if not taps:
                     continue        # this input-parity class receives no gradient from a 1x1/2 conv
                 self._gemm(dz, w, dx, B, (dx_hw[0] // 2, dx_hw[1] // 2), dz_hw, c.cout, c.cout, taps, c.cin, dx_hw,
-                           c.cin, res=res, mask=mask, dst_stride=(2, 2), dst_off=(ph, pw))
+                           c.cin, res=res, mask=mask, flags=fl, dst_stride=(2, 2), dst_off=(ph, pw))
 
     # ------------------------------------------------------------------ forward
     def _forward(self, src, src_is_u8, mean, std, keep):
@@ -301,7 +307,9 @@ class ResNet50Engine:
         h2, w2 = h1 // 2, w1 // 2
         p1 = self._get('p1', (B, h2, w2, 64))
         parg = self._get('p1_argmax', (B, h2, w2, 64), torch.uint8) if keep else None
-        _lib.check(lib.rart_engine_maxpool(_lib.ptr(y1), _lib.ptr(p1), _lib.ptr(parg), B, h1, w1, 64, sp))
+        bits = keep and self.sign_bit_masks
+        xs = self._get('p1_sign', (B, h2, w2, 8), torch.uint8) if bits else None
+        _lib.check(lib.rart_engine_maxpool_keep(_lib.ptr(y1), _lib.ptr(p1), _lib.ptr(parg), _lib.ptr(xs), B, h1, w1, 64, sp))
         acts['y1'], acts['p1'], acts['p1_argmax'] = y1, p1, parg
         x, xhw = p1, (h2, w2)
         for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
@@ -309,16 +317,21 @@ class ResNet50Engine:
             ya = self._get('b%d_a' % bi, (B, xhw[0], xhw[1], ca.cout))
             yb = self._get('b%d_b' % bi, (B, ohw[0], ohw[1], cb.cout))
             yc = self._get('b%d_c' % bi, (B, ohw[0], ohw[1], cc.cout))
-            self._conv_fwd(ca, x, xhw, ya, True)
-            self._conv_fwd(cb, ya, xhw, yb, True)
+            sa = self._get('b%d_a_sign' % bi, (B, xhw[0], xhw[1], ca.cout // 8), torch.uint8) if bits else None
+            sb = self._get('b%d_b_sign' % bi, (B, ohw[0], ohw[1], cb.cout // 8), torch.uint8) if bits else None
+            sc = self._get('b%d_c_sign' % bi, (B, ohw[0], ohw[1], cc.cout // 8), torch.uint8) if bits else None
+            self._conv_fwd(ca, x, xhw, ya, True, sign=sa)
+            self._conv_fwd(cb, ya, xhw, yb, True, sign=sb)
             if ds is not None:
                 sk = self._get('b%d_ds' % bi, (B, ohw[0], ohw[1], cc.cout))
                 self._conv_fwd(ds, x, xhw, sk, False)
             else:
                 sk = x
-            self._conv_fwd(cc, yb, ohw, yc, True, res=sk)
+            self._conv_fwd(cc, yb, ohw, yc, True, res=sk, sign=sc)
+            # the backward pass needs the activations only for their ReLU sign: the 1-bit tensors when enabled
             acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
-            x, xhw = yc, ohw
+            acts['b%d_masks' % bi] = (xs, sa, sb) if bits else (x, ya, yb)
+            x, xhw, xs = yc, ohw, sc
         pooled = self._get('pooled', (B, self.fc_in))
         _lib.check(lib.rart_engine_avgpool(_lib.ptr(x), _lib.ptr(pooled), B, xhw[0] * xhw[1], self.fc_in, sp))
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
@@ -363,16 +376,17 @@ class ResNet50Engine:
         for bi in range(len(self.blocks) - 1, -1, -1):
             ca, cb, cc, ds = self.blocks[bi]
             x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
+            mx, ma, mb = acts['b%d_masks' % bi]
             dzb = self._get('g_b', tuple(yb.shape))
-            self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=yb)
+            self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb)
             dza = self._get('g_a', tuple(ya.shape))
-            self._conv_bwd(cb, dzb, ohw, dza, xhw, mask=ya)
+            self._conv_bwd(cb, dzb, ohw, dza, xhw, mask=ma)
             dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
             if ds is None:
-                self._conv_bwd(ca, dza, xhw, dx, xhw, res=dz, mask=x)            # identity skip
+                self._conv_bwd(ca, dza, xhw, dx, xhw, res=dz, mask=mx)            # identity skip
             else:
-                self._conv_bwd(ca, dza, xhw, dx, xhw, mask=x)
-                self._conv_bwd(ds, dz, ohw, dx, xhw, res=dx, mask=x)             # accumulate the projection skip
+                self._conv_bwd(ca, dza, xhw, dx, xhw, mask=mx)
+                self._conv_bwd(ds, dz, ohw, dx, xhw, res=dx, mask=mx)             # accumulate the projection skip
             dz = dx
         grad = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
         stdf = (ctypes.c_float * 3)(*std)

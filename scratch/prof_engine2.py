@@ -1,0 +1,56 @@
+"""Per-launch table of one ResNet-50 gradient evaluation (forward + backward-to-input) at B = 256: every igemm launch with
+its algorithmic FLOPs and HBM bytes, the measured time (events on the launch stream) and the roofline floor
+max(FLOPs / 2.5 PFLOP/s, bytes / 8 TB/s).  Output -> profiles/r02_igemm_per_shape.txt."""
+import sys; sys.path.insert(0, '/root/repo')
+import time, torch
+from robustart_amd.model import get_model
+from robustart_amd.model.engine import ResNet50Engine
+MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+PEAK_F, PEAK_B = 2.5e15, 8.0e12
+torch.manual_seed(0)
+eng = ResNet50Engine(get_model({'type': 'resnet50_official'}).eval(), 'cuda')
+for a in sys.argv[1:]:
+    if '=' in a:
+        k, v = a.split('='); setattr(eng, k, bool(int(v)))
+B = 256
+x = torch.rand(B, 3, 224, 224, device='cuda'); y = torch.randint(0, 1000, (B,), device='cuda')
+rows = []
+orig = eng._gemm
+def wrapped(src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, **kw):
+    M = batch * grid[0] * grid[1]; K = k_per_tap * len(taps)
+    stride = kw.get('stride', (1, 1))
+    # unique source bytes: the pixels the row grid touches once (taps re-read them from cache), capped by the tensor
+    src_bytes = min(src.numel() * src.element_size(), M * K * 2) if len(taps) > 1 else M * K * 2
+    by = src_bytes + K * n_cols * 2 + M * n_cols * (4 if kw.get('flags', 0) & 2 else 2)
+    if kw.get('res') is not None: by += M * n_cols * 2
+    mk = kw.get('mask')
+    if mk is not None: by += M * n_cols * (2 if mk.dtype != torch.uint8 else 0.125)
+    if kw.get('sign_out') is not None: by += M * n_cols * 0.125
+    fl = 2.0 * M * K * n_cols
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r = orig(src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, **kw); e1.record()
+    rows.append(((M, K, n_cols, len(taps)), fl, by, e0, e1))
+    return r
+for _ in range(2): eng.forward_backward(x, MEAN, STD, y, 0)
+eng._gemm = wrapped
+eng.forward_backward(x, MEAN, STD, y, 0)
+rows.clear()
+eng.forward_backward(x, MEAN, STD, y, 0)
+torch.cuda.synchronize()
+eng._gemm = orig
+agg = {}
+for key, fl, by, a, b in rows:
+    us = a.elapsed_time(b) * 1e3
+    e = agg.setdefault(key, [0.0, 0, 0.0, 0.0]); e[0] += us; e[1] += 1; e[2] += fl; e[3] += by
+print('%9s %6s %6s %4s %4s %9s %8s %8s %9s %6s' % ('M', 'K', 'N', 'taps', 'x', 'us', 'TF/s', 'GB/s', 'floor_us', 'frac'))
+tot = totf = 0.0
+for key, (us, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    floor = max(fl / PEAK_F, by / PEAK_B) * 1e6
+    tot += us; totf += floor
+    print('%9d %6d %6d %4d %4d %9.1f %8.1f %8.1f %9.1f %6.3f' % (*key, cnt, us, fl / us / 1e6, by / us / 1e3, floor, floor / us))
+print('igemm launches %d: measured %.1f us, roofline floor %.1f us, fraction of the per-layer floor %.3f' %
+      (len(rows), tot, totf, totf / tot))
+for name, fn in (('fwd+bwd', lambda: eng.forward_backward(x, MEAN, STD, y, 0)), ('fwd', lambda: eng.logits(x, MEAN, STD))):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(6): fn()
+    torch.cuda.synchronize(); print(name, 'ms %.3f' % ((time.perf_counter() - t0) / 6 * 1e3))

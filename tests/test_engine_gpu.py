@@ -369,3 +369,24 @@ def test_fused_stem_backward_matches_unfused_chain(setup):
     rel = ((a - b).norm() / b.norm()).item()
     print('fused vs unfused stem backward: cos %.6f rel-L2 %.5f' % (cos, rel))
     assert cos > 0.9999 and rel < 0.01      # the unfused chain rounds the 147 patch columns to bf16, the fused one does not
+
+
+def test_sign_bit_masks_match_bf16_masks_exactly(setup):
+    """The backward GEMMs read the ReLU masks as 1-bit tensors written by the forward epilogues (rart_conv_desc.sign_out,
+    flag 16) instead of re-reading the bf16 activations: the decision (stored bf16 > 0) is the same, so the gradient must
+    be BIT-identical to the bf16-mask path; also at a stride-2 / projection block boundary and odd batch."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(91)
+    x = torch.rand(3, 3, 96, 64, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    try:
+        eng.sign_bit_masks = True
+        la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        ga = ga.clone()
+        eng.sign_bit_masks = False
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.sign_bit_masks = True
+    assert torch.equal(la, lb)
+    assert torch.equal(ga, gb)
+    assert ga.abs().max() > 0
