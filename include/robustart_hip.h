@@ -282,6 +282,17 @@ int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
  * (default 1024); others the x32 pipeline with loads two K steps ahead. */
 int rart_igemm_set_bk64_min_k(long long k);
 
+/* 3x3 stride-1 "same" convolution, channels in = channels out = 64 or 128, bf16 NHWC, with the input halo tile resident
+ * in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 / layer2 conv2, forward (taps (r-1, s-1), bias + ReLU, sign_out =
+ * 1-bit mask of the output) and backward-to-input (taps (1-r, 1-s), weights [cin][tap*cout+co], mask_bits = 1-bit ReLU
+ * mask of the destination).  wgt: bf16 [channels (padded rows allowed)][9*channels], k = tap*channels + c.  Any pointer
+ * of bias / mask_bits / sign_out may be NULL.  rart_conv3x3_halo_supported: 1 when the geometry fits the LDS tile
+ * (otherwise use rart_conv_igemm_bf16, which computes the same function). */
+int rart_conv3x3_halo_supported(int channels, int h, int w);
+int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const float* bias, const void* mask_bits, void* sign_out,
+                           void* dst, int n, int h, int w, int channels, const int* tap_dy, const int* tap_dx, int relu,
+                           rart_stream_t stream);
+
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
  * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:
  * the stem convolution's operand (normalisation of imfgsm_attack.py:14-23 / autoattack.py:17-20 fused). */

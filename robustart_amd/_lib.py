@@ -60,6 +60,9 @@ SIGNATURES = {
     'rart_logit_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     'rart_conv_igemm_bf16': (c_int, [c_void_p, c_void_p]),
+    'rart_conv3x3_halo_supported': (c_int, [c_int, c_int, c_int]),
+    'rart_conv3x3_halo_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_void_p]),
     'rart_igemm_set_bk64_min_k': (c_int, [ctypes.c_longlong]),
     'rart_engine_prep_input': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),

@@ -119,6 +119,7 @@ class ResNet50Engine:
         self.stem_wt = self._stem_bwd_table(wb).to(dev)                  # fused stem backward (stem_fused.hip)
         self.fused_stem_bwd = True       # False: max-pool bwd -> patches GEMM -> col2im (kept as the cross-check)
         self.sign_bit_masks = True       # False: the backward reads the bf16 activations for their ReLU sign (cross-check)
+        self.halo_conv3x3 = True         # False: layer1 / layer2 3x3 convs on the generic implicit GEMM (cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -257,9 +258,20 @@ class ResNet50Engine:
             return
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
+    def _halo_ok(self, c, hw):
+        return (self.halo_conv3x3 and self.profile is None and c.r == 3 and c.s == 3 and c.stride == 1 and c.pad == 1
+                and c.cin == c.cout and self.lib.rart_conv3x3_halo_supported(c.cin, hw[0], hw[1]))
+
+    def _halo(self, src, w, dst, B, hw, ch, taps, bias=None, mask=None, sign=None, relu=False):
+        _lib.check(self.lib.rart_conv3x3_halo_bf16(_lib.ptr(src), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(mask), _lib.ptr(sign),
+                                                   _lib.ptr(dst), B, hw[0], hw[1], ch, _cints([t[0] for t in taps]),
+                                                   _cints([t[1] for t in taps]), 1 if relu else 0, _lib.stream_ptr()))
+
     def _conv_fwd(self, c, x, xhw, out, relu, res=None, sign=None):
         B = x.shape[0]
         oh, ow = xhw[0] // c.stride, xhw[1] // c.stride
+        if res is None and self._halo_ok(c, xhw):
+            return self._halo(x, c.w_fwd, out, B, xhw, c.cin, c.fwd_taps, bias=c.bias, sign=sign, relu=relu)
         self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
                    bias=c.bias, res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride), sign_out=sign)
 
@@ -269,6 +281,8 @@ class ResNet50Engine:
         torch = _lib.require_gpu()
         B = dz.shape[0]
         fl = F_MASK_BITS if (mask is not None and mask.dtype == torch.uint8) else 0
+        if res is None and (mask is None or fl) and self._halo_ok(c, dx_hw):
+            return self._halo(dz, c.bwd[0][2], dx, B, dx_hw, c.cin, c.bwd[0][1], mask=mask)
         for parity, taps, w in c.bwd:
             if parity is None:
                 self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res, mask=mask,

@@ -390,3 +390,69 @@ def test_sign_bit_masks_match_bf16_masks_exactly(setup):
     assert torch.equal(la, lb)
     assert torch.equal(ga, gb)
     assert ga.abs().max() > 0
+
+
+@pytest.mark.parametrize('C,B,H,W', [(64, 3, 56, 56), (64, 2, 24, 24), (64, 5, 7, 9), (128, 3, 28, 28), (128, 2, 12, 12),
+                                     (128, 1, 5, 27)])
+def test_halo_conv3x3_forward_and_backward_vs_fp64(C, B, H, W):
+    """rart_conv3x3_halo_bf16 (input halo tile resident in LDS) against an fp64 evaluation of the same bf16 operands:
+    forward (bias + ReLU + sign bits) and backward-to-input (flipped taps + 1-bit mask); image boundaries inside a
+    workgroup's run of positions, odd sizes, positions past the end."""
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import _Conv, _cints
+    lib = _lib.load()
+    assert lib.rart_conv3x3_halo_supported(C, H, W)
+    g = torch.Generator().manual_seed(C + B + H)
+    conv = torch.nn.Conv2d(C, C, 3, padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5)
+    c = _Conv(conv, None, 'cuda')
+    c.bias.copy_(torch.randn(C, generator=g) * 0.1)
+    x = _rand_bf16((B, H, W, C), 5, relu=True).cuda()
+    y = torch.empty_like(x)
+    sign = torch.zeros(B, H, W, C // 8, dtype=torch.uint8, device='cuda')
+    sp = _lib.stream_ptr()
+    _lib.check(lib.rart_conv3x3_halo_bf16(_lib.ptr(x), _lib.ptr(c.w_fwd), _lib.ptr(c.bias), None, _lib.ptr(sign), _lib.ptr(y),
+                                          B, H, W, C, _cints([t[0] for t in c.fwd_taps]), _cints([t[1] for t in c.fwd_taps]),
+                                          1, sp))
+    wq = conv.weight.detach().to(torch.bfloat16).double()
+    ref = F.relu(F.conv2d(x.cpu().double().permute(0, 3, 1, 2), wq, c.bias.cpu().double(), padding=1)).permute(0, 2, 3, 1)
+    got = y.cpu().double()
+    ulp = ref.abs().clamp_min(2.0 ** -20) * 2.0 ** -8
+    assert ((got - ref).abs() <= ulp + 1e-6).all(), (got - ref).abs().max()
+    bits = torch.from_numpy(np.unpackbits(sign.cpu().numpy(), axis=-1, bitorder='little')).bool()
+    assert torch.equal(bits, y.cpu() > 0)
+    # backward to input with a random 1-bit mask
+    dz = _rand_bf16((B, H, W, C), 6).cuda()
+    mask = torch.randint(0, 256, (B, H, W, C // 8), generator=g, dtype=torch.uint8).cuda()
+    dx = torch.empty_like(dz)
+    taps = c.bwd[0][1]
+    _lib.check(lib.rart_conv3x3_halo_bf16(_lib.ptr(dz), _lib.ptr(c.bwd[0][2]), None, _lib.ptr(mask), None, _lib.ptr(dx),
+                                          B, H, W, C, _cints([t[0] for t in taps]), _cints([t[1] for t in taps]), 0, sp))
+    refg = torch.nn.grad.conv2d_input((B, C, H, W), wq, dz.cpu().double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    mb = torch.from_numpy(np.unpackbits(mask.cpu().numpy(), axis=-1, bitorder='little')).double()
+    refg = refg * mb
+    gotg = dx.cpu().double()
+    ulp = refg.abs().clamp_min(2.0 ** -20) * 2.0 ** -8
+    assert ((gotg - refg).abs() <= ulp + 1e-6).all(), (gotg - refg).abs().max()
+
+
+def test_halo_conv3x3_engine_matches_generic_igemm(setup):
+    m, eng = setup
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(3, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    try:
+        eng.halo_conv3x3 = True
+        la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        ga = ga.clone()
+        eng.halo_conv3x3 = False
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.halo_conv3x3 = True
+    # same bf16 operands, fp32 accumulation in a different order: rare 1-ulp bf16 flips that then propagate
+    assert (la - lb).abs().max() <= 0.02 * lb.abs().max()
+    a, b = ga.flatten().double(), gb.flatten().double()
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    print('halo vs generic 3x3: logits max diff %.4f (scale %.2f), grad cos %.6f' % ((la - lb).abs().max().item(), lb.abs().max().item(), cos))
+    assert cos > 0.995
