@@ -277,8 +277,9 @@ def apgd_perturb(model_fn, x, y, norm, eps, n_iter, loss, init_ts, n_restarts=1)
     for counter in range(n_restarts):
         ind_to_fool = acc.nonzero().flatten()
         if ind_to_fool.numel() != 0:
+            t = init_ts(counter, x[ind_to_fool].shape) if callable(init_ts) else init_ts[counter]
             _, acc_curr, _, adv_curr = apgd_single_run(model_fn, x[ind_to_fool].clone(), y[ind_to_fool].clone(),
-                                                       norm, eps, n_iter, loss, init_ts[counter])
+                                                       norm, eps, n_iter, loss, t)
             ind_curr = (acc_curr == 0).nonzero().flatten()
             acc[ind_to_fool[ind_curr]] = False
             adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
@@ -298,8 +299,9 @@ def apgd_targeted_perturb(model_fn, x, y, norm, eps, n_iter, init_ts, n_target_c
             y_to_fool = y[ind_to_fool].clone()
             output = model_fn(x_to_fool)
             y_target = output.sort(dim=1)[1][:, -target_class]
+            t = init_ts(j, x_to_fool.shape) if callable(init_ts) else init_ts[j]
             _, acc_curr, _, adv_curr = apgd_single_run(model_fn, x_to_fool, y_to_fool, norm, eps, n_iter,
-                                                       'dlr-targeted', init_ts[j], y_target=y_target)
+                                                       'dlr-targeted', t, y_target=y_target)
             ind_curr = (acc_curr == 0).nonzero().flatten()
             acc[ind_to_fool[ind_curr]] = False
             adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
@@ -505,6 +507,80 @@ def fab_targeted_perturb(model_fn, x, y, eps, n_iter, n_target_classes=9):
         acc[ind[fooled]] = False
         adv[ind[fooled]] = adv_curr[fooled].clone()
     return adv
+
+
+# ---------------------------------------------------------------------------------------
+# AutoAttack orchestrator, Linf (Attacks/autoattack/autoattack.py:90-211) -- pinned
+# ---------------------------------------------------------------------------------------
+
+class TorchStreamDraws:
+    """The random draws of the reference's sub-attacks, made from torch's GLOBAL generator in the reference's order
+    (each attack's perturb() re-seeds it first: autopgd_base.py:502, :644, square.py:567, fab_base.py:281):
+      APGD / APGD-T start direction  2 * rand(x.shape) - 1           (autopgd_base.py:214)
+      Square start signs             sign(2 * rand([n, c, 1, w]) - 1) (square.py:114,246)
+      Square query i                 randint h, randint w, sign(2 * rand([c, 1, 1]) - 1)   (square.py:118,268-274)"""
+
+    def __init__(self, seed):
+        self.seed = seed
+
+    def reseed(self):
+        torch.random.manual_seed(self.seed)
+
+    def pm1(self, _index, shape):
+        return 2 * torch.rand(tuple(shape)) - 1
+
+    def square_init(self, n, c, w):
+        return torch.sign(2 * torch.rand([n, c, 1, w]) - 1)
+
+    def square_draws(self, c, h, w, n_queries, p_init=0.8, rescale=False):
+        outer = self
+
+        class _Draws:
+            def __getitem__(self, i):
+                p = square_p_selection(i, p_init, n_queries, rescale)
+                s = max(int(round(math.sqrt(p * h * w))), 1)
+                vh = int((0 + (h - s) * torch.rand([1])).long())
+                vw = int((0 + (w - s) * torch.rand([1])).long())
+                return vh, vw, torch.sign(2 * torch.rand([c, 1, 1]) - 1).view(c)
+        del outer
+        return _Draws()
+
+
+def autoattack_linf(model_fn, x_orig, y_orig, eps, draws, plan=('apgd-ce', 'apgd-t', 'fab-t', 'square'), apgd_iter=100,
+                    apgdt_iter=100, apgdt_classes=9, fab_iter=100, fab_classes=9, square_queries=5000, trace=None):
+    """AutoAttack.run_standard_evaluation (autoattack.py:90-211) with bs >= len(x), version 'standard' hyper-parameters
+    (autoattack.py:253-267) unless overridden.  model_fn takes x in [0,1] (NormalizeModel already applied).
+    draws: a TorchStreamDraws-like object; trace (list) receives (attack, robust_flags copy) after every attack."""
+    with torch.no_grad():
+        robust = y_orig.eq(model_fn(x_orig).max(1)[1])                      # :95-109
+        x_adv = x_orig.clone().detach()
+        c, h, w = x_orig.shape[1:]
+        for attack in plan:
+            if int(robust.sum()) == 0:                                       # :117-121
+                break
+            idcs = robust.nonzero().flatten()                                # :125-135
+            x, y = x_orig[idcs].clone(), y_orig[idcs].clone()
+            draws.reseed()                                                   # each perturb() re-seeds with the same seed
+            with torch.enable_grad():
+                if attack == 'apgd-ce':
+                    adv_curr = apgd_perturb(model_fn, x, y, 'Linf', eps, apgd_iter, 'ce', draws.pm1, 1)
+                elif attack == 'apgd-t':
+                    adv_curr = apgd_targeted_perturb(model_fn, x, y, 'Linf', eps, apgdt_iter, draws.pm1, apgdt_classes)
+                elif attack == 'fab-t':
+                    adv_curr = fab_targeted_perturb(model_fn, x, y, eps, fab_iter, fab_classes)
+                elif attack == 'square':
+                    adv_curr = square_linf_perturb(model_fn, x, y, eps, square_queries, 0.8, False,
+                                                   lambda n: draws.square_init(n, c, w),
+                                                   draws.square_draws(c, h, w, square_queries))
+                else:
+                    raise ValueError('Attack not supported')
+            false_batch = ~y.eq(model_fn(adv_curr).max(1)[1])                # :179-184
+            non_robust = idcs[false_batch]
+            robust[non_robust] = False
+            x_adv[non_robust] = adv_curr[false_batch].detach()
+            if trace is not None:
+                trace.append((attack, robust.clone()))
+    return x_adv
 
 
 def pgd_l1_art(loss_grad, x, y, eps, eps_step, max_iter, init_signed_exp, init_radius):

@@ -320,6 +320,15 @@ def _apgd_single_run(prov, x, y, norm, eps, n_iter, loss_kind, y_target=None, rh
     return x_best, acc, loss_best, x_best_adv
 
 
+def _injected_start(init_ts, index, x_sub):
+    """Parity hook: init_ts is None (counter-based draws), a list indexed by restart / target class, or a callable
+    (index, shape) -> tensor drawing lazily for the still-robust subset (whose size is only known at run time)."""
+    if init_ts is None:
+        return None
+    t = init_ts(index, tuple(x_sub.shape)) if callable(init_ts) else init_ts[index]
+    return t.to(x_sub.device, x_sub.dtype).contiguous()
+
+
 def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce', n_restarts=1, seed=None,
                  sample_offset=None, init_ts=None, _prov=None):
     """APGDAttack.perturb (autopgd_base.py:450-529, best_loss=False)."""
@@ -335,7 +344,7 @@ def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce'
         ind_to_fool = acc.nonzero().flatten()
         if ind_to_fool.numel() != 0:
             x_f, y_f = x[ind_to_fool].contiguous(), y[ind_to_fool].contiguous()
-            t = init_ts[counter] if init_ts is not None else None
+            t = _injected_start(init_ts, counter, x_f)
             _, acc_curr, _, adv_curr = _apgd_single_run(prov, x_f, y_f, norm, eps, n_iter, kind, None, 0.75,
                                                         _seed(seed) + counter, sample_offset, t)
             ind_curr = (~acc_curr).nonzero().flatten()
@@ -360,7 +369,7 @@ def apgd_targeted_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, 
             x_f, y_f = x[ind_to_fool].contiguous(), y[ind_to_fool].contiguous()
             output = prov.logits(x_f)
             y_target = output.sort(dim=1)[1][:, -target_class]
-            t = init_ts[j] if init_ts is not None else None
+            t = _injected_start(init_ts, j, x_f)
             _, acc_curr, _, adv_curr = _apgd_single_run(prov, x_f, y_f, norm, eps, n_iter, LOSS_DLR_TARGETED,
                                                         y_target, 0.75, _seed(seed) + 100 + j, sample_offset, t)
             ind_curr = (~acc_curr).nonzero().flatten()
@@ -403,6 +412,8 @@ def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, resc
     B, C, H, W = x0.shape
     sd = _seed(seed)
     x_best = torch.empty_like(x0)
+    if callable(init_sign):            # parity hook: start signs for the still-robust subset, [n, c, 1, w] or [n, c, w]
+        init_sign = init_sign(B).reshape(B, C, W).to(x0.device, torch.float32)
     sg0 = init_sign.contiguous() if init_sign is not None else None
     _lib.check(lib.rart_square_init_linf(_lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), sd, sample_offset,
                                          _lib.ptr(sg0), _lib.stream_ptr()))
@@ -513,20 +524,24 @@ def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_class
     return adv
 
 
-def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None):
+def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None, _overrides=None):
     """attack.py:35-38 -> AutoAttack(model, norm, eps, version).run_standard_evaluation(x, y, bs=len(x))
     (autoattack.py:90-211).  `model` takes normalised input (NormalizeModel, autoattack.py:12-23).
     standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); the
     untargeted `fab` of version 'plus' (a 1000-class Jacobian per step, unusable on ImageNet in the reference too)
     and the L2 variants of fab-t / square are reported as skipped (the result is then an upper bound
-    on robust accuracy, never silently presented as the full ensemble)."""
+    on robust accuracy, never silently presented as the full ensemble).
+    _overrides (parity tests only; the reference shrinks the same attributes, autoattack.py:253-267): dict with any of
+    plan, apgd_iter, apgdt_iter, apgdt_classes, fab_iter, fab_classes, square_queries, and `draws` -- an object like
+    oracle.attacks_ref.TorchStreamDraws replaying the reference's torch random stream instead of the counter-based RNG."""
     torch = _lib.require_gpu()
     assert norm in ['Linf', 'L2', 'L1']
     if norm == 'L1':
-        raise NotImplementedError('AutoAttack L1 (L1_projection, autopgd_base.py:19-83) is not reached by '
-                                  'autoattack_linf and is not implemented')
+        raise NotImplementedError("AutoAttack norm='L1' runs APGD with the L1 projection only (apgd_l1_perturb); the L1 "
+                                  'variants of FAB-T / Square are not implemented and autoattack_linf never selects L1')
     x_orig, y_orig = _check_inputs(input, label)
     prov = _Provider(model, normalize_inside=True)
+    ov = dict(_overrides or {})
     plan = {'standard': ['apgd-ce', 'apgd-t', 'fab-t', 'square'],
             'plus': ['apgd-ce', 'apgd-dlr', 'fab', 'square', 'apgd-t', 'fab-t'],
             'rand': ['apgd-ce', 'apgd-dlr']}.get(version)
@@ -534,7 +549,12 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
         raise ValueError('unknown AutoAttack version %r' % (version,))
     if version == 'rand':
         raise NotImplementedError("AutoAttack version 'rand' (EOT over 20 forward passes) is not implemented")
+    plan = list(ov.get('plan', plan))
     n_restarts = 5 if version == 'plus' else 1
+    apgd_iter, apgdt_iter = int(ov.get('apgd_iter', 100)), int(ov.get('apgdt_iter', 100))
+    apgdt_classes, fab_iter, fab_classes = int(ov.get('apgdt_classes', 9)), int(ov.get('fab_iter', 100)), int(ov.get('fab_classes', 9))
+    square_queries = int(ov.get('square_queries', 5000))
+    draws = ov.get('draws')
     skipped = [a for a in plan if a in ('fab',)] + ([a for a in plan if a == 'fab-t'] if norm != 'Linf' else [])
     if skipped:
         warnings.warn('autoattack_linf: %s not implemented on this build yet -- running %s only; robust accuracy '
@@ -544,6 +564,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
         robust_flags = y_orig.eq(prov.logits(x_orig).max(1)[1])                  # :95-109
         x_adv = x_orig.clone()
         base_seed = _seed(seed)
+        first = _offset(None, x_orig.shape[0])       # the call's samples keep their global indices through every sub-attack
+        C, H, W = x_orig.shape[1:]
         for ai, attack in enumerate(plan):
             if attack in skipped:
                 continue
@@ -551,20 +573,28 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None)
             if idcs.numel() == 0:
                 break
             x, y = x_orig[idcs].contiguous(), y_orig[idcs].contiguous()
+            if draws is not None:
+                draws.reseed()                       # every perturb() of the reference re-seeds torch with self.seed
+            ts = draws.pm1 if draws is not None else None
+            sd = base_seed + 1000 * ai
             if attack == 'apgd-ce':
-                adv_curr = apgd_perturb(None, x, y, norm, eps, 100, 'ce', n_restarts, base_seed + 1000 * ai, 0,
-                                        _prov=prov)
+                adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'ce', n_restarts, sd, first, init_ts=ts, _prov=prov)
             elif attack == 'apgd-dlr':
-                adv_curr = apgd_perturb(None, x, y, norm, eps, 100, 'dlr', n_restarts, base_seed + 1000 * ai, 0,
-                                        _prov=prov)
+                adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'dlr', n_restarts, sd, first, init_ts=ts, _prov=prov)
             elif attack == 'apgd-t':
-                adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, 100, 9, base_seed + 1000 * ai, 0, _prov=prov)
+                adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, apgdt_iter, apgdt_classes, sd, first, init_ts=ts,
+                                                 _prov=prov)
             elif attack == 'fab-t':
-                adv_curr = fab_targeted_perturb(None, x, y, eps, 100, 9, _prov=prov)
+                adv_curr = fab_targeted_perturb(None, x, y, eps, fab_iter, fab_classes, _prov=prov)
             elif attack == 'square':
                 if norm != 'Linf':
                     raise NotImplementedError('Square L2 (square.py:296-530) is not implemented')
-                adv_curr = square_perturb(None, x, y, eps, 5000, 0.8, False, base_seed + 1000 * ai, 0, _prov=prov)
+                if draws is not None:
+                    adv_curr = square_perturb(None, x, y, eps, square_queries, 0.8, False, sd, first,
+                                              init_sign=lambda n: draws.square_init(n, C, W),
+                                              draws=draws.square_draws(C, H, W, square_queries), check_every=1, _prov=prov)
+                else:
+                    adv_curr = square_perturb(None, x, y, eps, square_queries, 0.8, False, sd, first, _prov=prov)
             else:
                 raise ValueError('Attack not supported')
             false_batch = ~y.eq(prov.logits(adv_curr).max(1)[1])                 # :179-184

@@ -76,6 +76,67 @@ class FakeImageNet(torch.utils.data.Dataset):
         return img, lab
 
 
+class StructuredFakeImageNet(FakeImageNet):
+    """`data.read_from: structured`: a LEARNABLE synthetic set (still a pure function of the global index): class c of
+    `classes` (default 16) owns a fixed +-1 pattern on an 8 x 8 x 3 grid; an image is 128 + contrast * pattern(upsampled)
+    + the hash noise of FakeImageNet scaled to +-noise.  A network fitted to it has real decision margins, which is what
+    the bf16-engine-vs-fp32 attack-outcome test needs (random-pixel images with hash labels can only be memorised)."""
+
+    def __init__(self, n, size=224, classes=16, contrast=48.0, noise=40.0):
+        super().__init__(n, size, classes)
+        self.contrast, self.noise = float(contrast), float(noise)
+
+    def batch(self, indices, device):
+        raw, _ = super().batch(indices, device)
+        idx = torch.as_tensor(list(indices), dtype=torch.int64, device=device)
+        lab = ((idx * 2654435761 % 4294967296) >> 7) % self.classes
+        cell = torch.arange(self.size, device=device) * 8 // self.size                      # pixel -> grid cell
+        cy, cx, ch = cell.view(1, -1, 1, 1), cell.view(1, 1, -1, 1), torch.arange(3, device=device).view(1, 1, 1, 3)
+        h = (lab.view(-1, 1, 1, 1) * 7919 + cy * 131 + cx * 17 + ch) * 2654435761 % 4294967296
+        sign = (((h ^ (h >> 13)) >> 5) & 1).float() * 2.0 - 1.0
+        img = 128.0 + self.contrast * sign + (raw.float() - 127.5) * (self.noise / 127.5)
+        return img.clamp_(0, 255).to(torch.uint8), lab
+
+
+def make_dataset(dcfg, n, size):
+    if dcfg.get('read_from', 'fake') == 'structured':
+        return StructuredFakeImageNet(n, size, int(dcfg.get('structured_classes', 16)),
+                                      float(dcfg.get('structured_contrast', 48.0)), float(dcfg.get('structured_noise', 40.0)))
+    return FakeImageNet(n, size)
+
+
+def load_pretrain(model, path, prefer='model', strict=True):
+    """`saver.pretrain.path` / --recover: load a checkpoint written by this solver or by the reference's
+    (torch.save of {'model': state_dict, 'ema': {...}, ...} or a bare state_dict; DistributedDataParallel's 'module.'
+    prefix stripped).  prefer = 'ema' picks the EMA weights when the file has them."""
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    sd = ck
+    if isinstance(ck, dict):
+        for key in ((prefer, 'model', 'state_dict', 'ema') if prefer else ('model', 'state_dict')):
+            if key in ck and isinstance(ck[key], dict):
+                sd = ck[key]
+                break
+    if isinstance(sd, dict) and 'ema_state_dict' in sd:          # reference EMA wrapper
+        sd = sd['ema_state_dict']
+    sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=strict)
+    return ck if isinstance(ck, dict) else {}
+
+
+def save_checkpoint(path, model, ema_state=None, optimizer_state=None, step=0, extra=None):
+    """The reference solver's checkpoint shape: {'model', 'ema', 'optimizer', 'last_iter'} (state dicts on the CPU)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    ck = {'model': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'last_iter': int(step)}
+    if ema_state is not None:
+        ck['ema'] = {k: v.detach().cpu() for k, v in ema_state.items()}
+    if optimizer_state is not None:
+        ck['optimizer'] = optimizer_state
+    if extra:
+        ck.update(extra)
+    torch.save(ck, path)
+    return path
+
+
 def shard_indices(n, rank, world):
     """`sampler.type: distributed` (non-repeating): contiguous ranges, the last ranks may get one fewer."""
     per = (n + world - 1) // world
@@ -118,9 +179,15 @@ def all_reduce_counters(values, device):
     return [int(v) for v in t.tolist()]
 
 
-def build_model(cfg):
+def build_model(cfg, args=None):
+    """get_model + `saver.pretrain.path` (or --recover): the weights an evaluation / fine-tuning run starts from."""
     from ..model import get_model
-    return get_model(cfg['model'])
+    model = get_model(cfg['model'])
+    pre = (cfg.get('saver', {}) or {}).get('pretrain', {}) or {}
+    path = getattr(args, 'recover', None) or pre.get('path')
+    if path:
+        load_pretrain(model, path, prefer='ema' if pre.get('use_ema', False) else 'model')
+    return model
 
 
 def evaluate(cfg, args, rank, world, device, model=None):
@@ -129,9 +196,9 @@ def evaluate(cfg, args, rank, world, device, model=None):
     n = int(dcfg.get('fake_size', dcfg.get('limit_samples', 256)))
     bs = int(dcfg.get('batch_size', 64))
     size = int(dcfg.get('input_size', 224))
-    ds = FakeImageNet(n, size)
+    ds = make_dataset(dcfg, n, size)
     idx = shard_indices(n, rank, world)
-    model = model or build_model(cfg)
+    model = model or build_model(cfg, args)
     model = model.to(device).eval()
     use_hip = device.type == 'cuda' and args.engine == 'hip'
     noise = None
@@ -188,12 +255,12 @@ def evaluate(cfg, args, rank, world, device, model=None):
             C.corrupt_batch_(imgs, C.CORRUPTION_NAMES.index(args.corruption), args.severity, seed=args.seed,
                              sample_offset=first)
         if attack is not None:
+            # the attack's random starts are a function of (seed, dataset index): set the process-wide counter to the
+            # batch's first global index, which every attack reads when no explicit sample_offset is passed
             from ..noise import rng
             rng.manual_seed(args.seed, first)
             x01 = imgs.permute(0, 3, 1, 2).float().div(255.0).contiguous()
-            kw = {k: v for k, v in attack.config.items()}
-            from ..noise.registry import function_dict
-            adv_x = function_dict[attack.noise_type](x01, labels, **kw)
+            adv_x = attack.add_noise(x01, labels)
             with torch.no_grad():
                 logits = (tgt_model or f_model)(adv_x)
         elif use_hip:
@@ -222,8 +289,8 @@ def train(cfg, args, rank, world, device):
     bs = int(dcfg.get('batch_size', 32))
     size = int(dcfg.get('input_size', 224))
     max_iter = int(cfg.get('max_iter', args.max_iter))
-    ds = FakeImageNet(n, size)
-    model = build_model(cfg).to(device)
+    ds = make_dataset(dcfg, n, size)
+    model = build_model(cfg, args).to(device)
     ocfg = cfg.get('optimizer', {'type': 'SGD', 'kwargs': {'nesterov': True, 'momentum': 0.9, 'weight_decay': 1e-4}})
     okw = dict(ocfg.get('kwargs', {}))
     lcfg = cfg.get('lr_scheduler', {}).get('kwargs', {})
@@ -346,6 +413,22 @@ def train(cfg, args, rank, world, device):
         loss_v = float(loss.detach())
         if rank == 0 and (it % int(cfg.get('saver', {}).get('print_freq', 10)) == 0 or it == max_iter - 1):
             print(json.dumps({'iter': it, 'loss': loss_v, 'lr': lr}))
+    # checkpoint (rank 0): model, EMA (parameters from the optimizer's arena + the EMA'd buffers), last iteration
+    save_dir = (cfg.get('saver', {}) or {}).get('save_dir') or getattr(args, 'ckpt_dir', None)
+    ema_sd = None
+    if ema_on:
+        if use_hip_opt:
+            ema_sd = opt.ema_state_dict(model)
+        elif ema is not None:
+            ema_sd = {nm: ema[o:o + p.numel()].view_as(p).clone() for nm, p, o in zip(arena.names, arena.params, arena.offsets)}
+        if ema_sd is not None:
+            ema_sd.update(ema_buffers)
+            for k, v in model.named_buffers():                  # integer buffers (num_batches_tracked) are not averaged
+                if k not in ema_sd:
+                    ema_sd[k] = v.detach().clone()
+    train.last_ema_state = ema_sd
+    if save_dir and rank == 0:
+        save_checkpoint(os.path.join(save_dir, 'ckpt.pth.tar'), model, ema_sd, None, max_iter)
     return loss_v, model
 
 
@@ -363,6 +446,8 @@ def main(argv=None):
     ap.add_argument('--max-iter', type=int, default=20)
     ap.add_argument('--train-engine', choices=['hip', 'torch'], default='hip', dest='train_engine',
                     help='train-mode forward/backward: hip = ResNet50TrainEngine, torch = autograd scaffold')
+    ap.add_argument('--recover', default=None, help='checkpoint to start from (overrides saver.pretrain.path)')
+    ap.add_argument('--ckpt-dir', default=None, dest='ckpt_dir', help='write <dir>/ckpt.pth.tar at the end of training')
     ap.add_argument('--save-dir', default=None, help='root of <model>/<noise>_<eps>/results.txt.all (robustart_amd.metrics)')
     ap.add_argument('--src_name', default=None, help='name of the attacked (source) model in the result path')
     ap.add_argument('--tgt_name', default=None, help='transfer: name of the target model (new_transfer/eval.sh:42-44)')

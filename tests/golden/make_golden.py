@@ -110,6 +110,54 @@ def gen_attacks():
     print('attacks_ref.npz', len(out), 'entries')
 
 
+AA_CASES = {   # name -> (eps, plan or None (= the 'standard' order), apgd n_iter, apgd-t n_iter, apgd-t classes, fab n_iter, fab classes, square queries)
+    'standard': (1 / 255, None, 2, 2, 2, 10, 3, 60),
+    'reordered': (1 / 255, ['square', 'fab-t', 'apgd-t', 'apgd-ce'], 4, 4, 2, 6, 3, 40),
+}
+
+
+def aa_inputs():
+    net = make_tinynet()
+    x = make_batch(n=16, seed=21)
+    y = net(normalize(x)).max(1)[1]
+    y[3] = (y[3] + 1) % 10                 # one sample is misclassified before any attack runs
+    return net, x, y
+
+
+def gen_autoattack():
+    """AutoAttack(model, 'Linf', eps, version='standard', seed=0).run_standard_evaluation of the UNMODIFIED reference
+    (autoattack.py:90-211) on the tiny CNN, iteration counts shrunk through the attribute overrides the reference itself
+    uses in set_version (autoattack.py:253-267).  `model` takes normalised input (NormalizeModel wraps it; its .cuda()
+    calls are identity here, _ref_import.py).  Saved next to attacks_ref.npz as autoattack_ref.npz."""
+    from RobustART.noise.utils.adv.Attacks.autoattack.autoattack import AutoAttack
+    net, x, y = aa_inputs()
+    out = {'x': x.numpy(), 'y': y.numpy()}
+    for name, (eps, plan, ai, ti, tc, fi, fc, sq) in AA_CASES.items():
+        aa = AutoAttack(net, norm='Linf', eps=eps, seed=0, verbose=False, version='standard', device='cpu')
+        aa.apgd.n_iter = ai
+        aa.apgd_targeted.n_iter, aa.apgd_targeted.n_target_classes = ti, tc
+        aa.fab.n_iter, aa.fab.n_target_classes = fi, fc
+        aa.square.n_queries = sq
+        if plan is not None:
+            aa.attacks_to_run = list(plan)
+        adv = aa.run_standard_evaluation(x.clone(), y.clone(), bs=len(x))
+        out[f'{name}/adv'] = adv.detach().numpy()
+        out[f'{name}/robust'] = (net(normalize(adv)).max(1)[1] == y).numpy()
+        # the same run one attack at a time (run_standard_evaluation_individual, autoattack.py:228-249)
+        aa.attacks_to_run = list(plan) if plan is not None else ['apgd-ce', 'apgd-t', 'fab-t', 'square']
+        indiv = aa.run_standard_evaluation_individual(x.clone(), y.clone(), bs=len(x))
+        for k, v in indiv.items():
+            out[f'{name}/individual/{k}'] = v.detach().numpy()
+        print(name, 'robust after the ensemble:', int(out[f'{name}/robust'].sum()), 'of', len(x), '| changed rows',
+              ((adv - x).abs().flatten(1).max(1)[0] > 0).nonzero().flatten().tolist())
+    np.savez_compressed(os.path.join(HERE, 'autoattack_ref.npz'), **out)
+    print('autoattack_ref.npz', len(out), 'entries')
+
+
 if __name__ == '__main__':
-    gen_corruptions()
-    gen_attacks()
+    if 'autoattack' in sys.argv[1:]:
+        gen_autoattack()
+    else:
+        gen_corruptions()
+        gen_attacks()
+        gen_autoattack()

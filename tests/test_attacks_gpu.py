@@ -175,8 +175,8 @@ def test_square_attack_matches_reference_golden():
                              draws=draws, check_every=1)
     torch.testing.assert_close(got.cpu(), torch.from_numpy(g['square/Linf/adv']), atol=2e-6, rtol=0)
     # native draws: stays in the eps-ball / box, deterministic
-    a = adv.square_perturb(f_gpu, x.cuda(), y.cuda(), 8 / 255, 30, 0.8, False, seed=4)
-    b = adv.square_perturb(f_gpu, x.cuda(), y.cuda(), 8 / 255, 30, 0.8, False, seed=4)
+    a = adv.square_perturb(f_gpu, x.cuda(), y.cuda(), 8 / 255, 30, 0.8, False, seed=4, sample_offset=0)
+    b = adv.square_perturb(f_gpu, x.cuda(), y.cuda(), 8 / 255, 30, 0.8, False, seed=4, sample_offset=0)
     assert torch.equal(a, b) and (a - x.cuda()).abs().max() <= 8 / 255 + 1e-6 and a.min() >= 0 and a.max() <= 1
 
 
@@ -273,3 +273,60 @@ def test_pgd_l1_art_matches_oracle_and_stays_in_the_l1_ball():
     assert dn[0] != dn[1]
     signs = torch.sign(s1 - x224).flatten(1)
     assert abs(float(signs.mean())) < 0.02                        # random signs
+
+
+def _f_gpu_and_gold():
+    g, net = _gold_model()
+    netc = make_tinynet({k[4:]: g[k] for k in g.files if k.startswith('net/')}).cuda()
+    mean = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()
+    std = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1).cuda()
+    return g, netc, (lambda z: netc((z - mean) / std))
+
+
+def test_apgd_targeted_matches_reference_golden():
+    """APGD-T on the HIP step kernels (rart_apgd_init / rart_apgd_step / rart_logit_loss kind 2 / rart_select_rows) vs the
+    reference's own APGDAttack_targeted output (attacks_ref.npz 'apgdt/Linf/adv', autopgd_base.py:571-690): the start
+    direction of every target class is drawn lazily from the replayed torch stream for the still-robust subset, exactly
+    as tests/test_oracle_golden.py::_apgdt_with_stream does for the oracle."""
+    from robustart_amd.noise import adv
+    g, netc, f_gpu = _f_gpu_and_gold()
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    torch.random.manual_seed(0)
+    got = adv.apgd_targeted_perturb(f_gpu, x.cuda(), y.cuda(), 'Linf', 4 / 255, 8, 3,
+                                    init_ts=lambda j, shape: 2 * torch.rand(shape) - 1)
+    torch.testing.assert_close(got.cpu(), torch.from_numpy(g['apgdt/Linf/adv']), atol=2e-5, rtol=0)
+    assert (got.cpu() - x).abs().max() <= 4 / 255 + 1e-6
+
+
+AA_CASES = {'standard': (1 / 255, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 10, 3, 60),
+            'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40)}
+
+
+@pytest.mark.parametrize('case', sorted(AA_CASES))
+def test_autoattack_linf_orchestrator_matches_reference_golden(case):
+    """adv.autoattack_linf (the function AddNoise('autoattack_linf') dispatches to) vs the reference's
+    AutoAttack.run_standard_evaluation on the tiny CNN (tests/golden/autoattack_ref.npz; autoattack.py:90-211): robust-flag
+    bookkeeping, per-attack robust subset, x_adv[non_robust] update and early exit, in two attack orders, with every
+    sub-attack on the HIP kernels and the reference's torch random stream replayed through _overrides['draws']."""
+    from robustart_amd.noise import adv
+    g, netc, f_gpu = _f_gpu_and_gold()
+    ga = np.load(os.path.join(GOLD, 'autoattack_ref.npz'))
+    x, y = torch.from_numpy(ga['x']), torch.from_numpy(ga['y'])
+    eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case]
+    ov = dict(plan=plan, apgd_iter=ai, apgdt_iter=ti, apgdt_classes=tc, fab_iter=fi, fab_classes=fc, square_queries=sq,
+              draws=A.TorchStreamDraws(0))
+    got = adv.autoattack_linf(x.cuda(), y.cuda(), netc, 'Linf', eps, 'standard', False, _overrides=ov).cpu()
+    want = torch.from_numpy(ga[f'{case}/adv'])
+    torch.testing.assert_close(got, want, atol=5e-5, rtol=0)
+    robust = (netc((got.cuda() - torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()) /
+                   torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1).cuda()).argmax(1).cpu() == y)
+    assert np.array_equal(robust.numpy(), ga[f'{case}/robust'])
+    assert torch.equal(got[3], x[3])                    # misclassified from the start: never attacked, never changed
+    # native (counter-based) draws through the AddNoise plugin entry: eps-ball, box, reproducible
+    from robustart_amd.noise import AddNoise, rng
+    an = AddNoise('autoattack_linf')
+    an.set_config(model=netc, norm='Linf', eps=eps, version='standard', verbose=False)
+    rng.manual_seed(5)
+    a = adv.autoattack_linf(x.cuda(), y.cuda(), netc, 'Linf', eps, 'standard', False,
+                            _overrides=dict(apgd_iter=3, apgdt_iter=2, apgdt_classes=2, fab_iter=3, fab_classes=2, square_queries=20))
+    assert (a.cpu() - x).abs().max() <= eps + 1e-6 and a.min() >= 0 and a.max() <= 1

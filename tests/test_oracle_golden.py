@@ -231,3 +231,32 @@ def test_imagenet_s_train_crop_box_matches_reference():
     assert len(cases) >= 40
     for c in cases:
         assert list(_train_params((c['h'], c['w']), random.Random(c['seed']))) == c['box'], c
+
+
+@pytest.fixture(scope='module')
+def gold_aa():
+    return np.load(os.path.join(GOLD, 'autoattack_ref.npz'))
+
+
+AA_CASES = {'standard': (1 / 255, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 10, 3, 60),
+            'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40)}
+
+
+@pytest.mark.parametrize('case', sorted(AA_CASES))
+def test_autoattack_orchestrator_matches_reference(gold_a, gold_aa, case):
+    """oracle.attacks_ref.autoattack_linf vs AutoAttack.run_standard_evaluation of the unmodified reference
+    (tests/golden/make_golden.py gen_autoattack): robust-flag bookkeeping, per-attack robust subset, x_adv[non_robust]
+    update, early exit, in two attack orders; plus every attack run alone (run_standard_evaluation_individual)."""
+    net, model_fn = _model(gold_a)
+    x, y = torch.from_numpy(gold_aa['x']), torch.from_numpy(gold_aa['y'])
+    eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case]
+    kw = dict(apgd_iter=ai, apgdt_iter=ti, apgdt_classes=tc, fab_iter=fi, fab_classes=fc, square_queries=sq)
+    trace = []
+    adv = A.autoattack_linf(model_fn, x, y, eps, A.TorchStreamDraws(0), plan=plan, trace=trace, **kw)
+    np.testing.assert_allclose(adv.numpy(), gold_aa[f'{case}/adv'], atol=1e-6)
+    np.testing.assert_array_equal((model_fn(adv).max(1)[1] == y).numpy(), gold_aa[f'{case}/robust'])
+    assert not trace[0][1][3]                      # the initially misclassified sample is never attacked
+    assert np.array_equal(adv[3].numpy(), x[3].numpy())
+    for k in plan:
+        one = A.autoattack_linf(model_fn, x, y, eps, A.TorchStreamDraws(0), plan=(k,), **kw)
+        np.testing.assert_allclose(one.numpy(), gold_aa[f'{case}/individual/{k}'], atol=1e-6)

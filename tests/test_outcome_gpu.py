@@ -1,0 +1,167 @@
+"""Outcome-level guards of the bf16 engines:
+  * robust accuracy under PGD-7 from the bf16 HIP engine vs the fp32 PyTorch module on a ResNet-50 with REAL decision margins
+    (fitted on the structured synthetic set by the HIP train engine), per-image agreement and a logit error histogram;
+  * B = 256 launches (XCD tile remap, 32-bit addressing, M = 802 816 / 3 211 264 row grids) against the same images run
+    in small batches: bit-equal logits and gradients, and the corruption kernels chunked vs whole."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+
+
+class _Args:
+    engine = 'hip'
+    train_engine = 'hip'
+    corruption = None
+    attack = None
+    eps = '2/255'
+    steps = 7
+    severity = 3
+    seed = 0
+    max_iter = 2
+    recover = None
+    ckpt_dir = None
+
+
+@pytest.fixture(scope='module')
+def fitted(tmp_path_factory):
+    """ResNet-50 fitted for 400 SGD-Nesterov steps (HIP train engine, batch 64) on StructuredFakeImageNet, saved and
+    re-loaded through the solver's checkpoint path (saver.pretrain.path)."""
+    from robustart_amd.train import cls_solver as S
+    rank, world, device = S.init_dist()
+    d = str(tmp_path_factory.mktemp('ckpt'))
+    cfg = {'model': {'type': 'resnet50_official', 'kwargs': {'num_classes': 1000}},
+           'data': {'read_from': 'structured', 'fake_size': 4096, 'batch_size': 64, 'input_size': 224},
+           'label_smooth': 0.0, 'max_iter': 400, 'ema': {'enable': True, 'kwargs': {'decay': 0.9}},
+           'lr_scheduler': {'kwargs': {'base_lr': 0.02, 'warmup_lr': 0.08, 'warmup_steps': 10}},
+           'saver': {'save_dir': d, 'print_freq': 50}}
+    a = _Args()
+    loss, model = S.train(cfg, a, rank, world, device)
+    assert loss < 1.0, 'the structured set must be learnable (final loss %.3f)' % loss
+    path = os.path.join(d, 'ckpt.pth.tar')
+    assert os.path.exists(path)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ck) >= {'model', 'ema', 'last_iter'} and ck['last_iter'] == 400
+    assert set(ck['ema']) == set(ck['model'])                      # EMA covers parameters AND buffers
+    cfg2 = dict(cfg, saver={'pretrain': {'path': path}})
+    m2 = S.build_model(cfg2, a).cuda().eval()
+    for (k, v), (_, w) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(v.cpu(), w.cpu()), k
+    # 'module.'-prefixed bare state dict (a DDP checkpoint of the reference) loads too
+    torch.save({('module.' + k): v for k, v in ck['model'].items()}, os.path.join(d, 'bare.pth'))
+    S.load_pretrain(S.build_model(cfg, a), os.path.join(d, 'bare.pth'))
+    return S, cfg, m2
+
+
+def test_pgd7_outcome_bf16_engine_vs_fp32_module(fitted):
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.noise import adv
+    S, cfg, model = fitted
+    ds = S.make_dataset(cfg['data'], 4096, 224)
+    eng = EngineModel(model, takes_normalized=False)
+    mean = torch.tensor(MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(STD, device='cuda').view(1, 3, 1, 1)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    f32 = lambda z: model((z - mean) / std)      # noqa: E731  (fp32 PyTorch module, MIOpen)
+    eps, n_img, bs = 2 / 255, 512, 64
+    stats = {'clean_e': 0, 'clean_t': 0, 'adv_e': 0, 'adv_t': 0, 'agree_adv': 0, 'agree_clean': 0, 'cross_e_on_t': 0}
+    errs = []
+    for s in range(0, n_img, bs):
+        items = list(range(8192 + s, 8192 + s + bs))            # indices the training never saw
+        imgs, y = ds.batch(items, 'cuda')
+        x = imgs.permute(0, 3, 1, 2).float().div(255.0).contiguous()
+        with torch.no_grad():
+            le, lt = eng(x).float(), f32(x).float()
+        errs.append(((le - lt).abs().max(1)[0] / lt.abs().max(1)[0]).cpu())
+        u = ((torch.rand(x.shape, generator=torch.Generator().manual_seed(s)) * 2 - 1) * eps).cuda()
+        xa_e = adv.pgd_linf(x, y, eng, eps, 3 / 40, 7, init_u=u)
+        xa_t = adv.pgd_linf(x, y, f32, eps, 3 / 40, 7, init_u=u)
+        with torch.no_grad():
+            pe, pt = eng(xa_e).argmax(1), f32(xa_t).argmax(1)
+            cross = f32(xa_e).argmax(1)
+        stats['clean_e'] += int((le.argmax(1) == y).sum()); stats['clean_t'] += int((lt.argmax(1) == y).sum())
+        stats['agree_clean'] += int((le.argmax(1) == lt.argmax(1)).sum())
+        stats['adv_e'] += int((pe == y).sum()); stats['adv_t'] += int((pt == y).sum())
+        stats['agree_adv'] += int((pe == pt).sum())
+        stats['cross_e_on_t'] += int((cross == y).sum())   # engine-crafted examples scored by the fp32 module
+    errs = torch.cat(errs)
+    hist = np.histogram(errs.numpy(), bins=[0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1.0])[0].tolist()
+    rep = {k: v / n_img for k, v in stats.items()}
+    rep['logit_rel_err_hist_bins'] = [0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1.0]
+    rep['logit_rel_err_hist'] = hist
+    rep['logit_rel_err_median'] = float(errs.median())
+    print('PGD-7 eps 2/255 outcome, bf16 HIP engine vs fp32 module, 512 held-out images: ' + json.dumps(rep))
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(rep, open('gpurun_out/outcome_bf16_vs_fp32.json', 'w'), indent=1)
+    assert rep['clean_t'] > 0.9, 'the fitted network must classify the held-out structured images'
+    assert rep['adv_t'] < rep['clean_t'] - 0.05, 'PGD-7 must bite (otherwise the comparison is vacuous)'
+    assert abs(rep['adv_e'] - rep['adv_t']) <= 0.01           # |delta robust accuracy| <= 1 point
+    assert rep['agree_adv'] >= 0.95                             # per-image adversarial prediction agreement
+    assert abs(rep['cross_e_on_t'] - rep['adv_t']) <= 0.02      # engine-crafted examples are as strong on the fp32 model
+
+
+def test_b256_matches_small_batches_bit_for_bit():
+    """Every 32nd image of a B = 256 forward / forward_backward equals the same image run in a batch of 2 (the kernels'
+    arithmetic per output element does not depend on the batch: same K order, same tiles), and rart_corrupt_u8 on the
+    whole batch equals the batch corrupted in chunks with the matching global sample offsets."""
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import ResNet50Engine
+    from robustart_amd.noise import imagenet_c as C
+    torch.manual_seed(0)
+    eng = ResNet50Engine(get_model({'type': 'resnet50_official'}).eval(), 'cuda')
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(256, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 1000, (256,), generator=g).cuda()
+    big = eng.logits(x, MEAN, STD).clone()
+    lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    lb, gb = lb.clone(), gb.clone()
+    assert torch.equal(big, lb)
+    for i in range(0, 256, 32):
+        xs, ys = x[i:i + 2].contiguous(), y[i:i + 2].contiguous()
+        small = eng.logits(xs, MEAN, STD)
+        assert torch.equal(small[0], big[i]) and torch.equal(small[1], big[i + 1]), i
+        ls, _, gs, _ = eng.forward_backward(xs, MEAN, STD, ys, 0)
+        assert torch.equal(ls[0], lb[i]) and torch.equal(gs[0], gb[i]) and torch.equal(gs[1], gb[i + 1]), i
+    u8 = torch.randint(0, 256, (256, 224, 224, 3), generator=g, dtype=torch.uint8).cuda()
+    for name in ('gaussian_noise', 'shot_noise', 'impulse_noise', 'jpeg_compression', 'contrast', 'pixelate', 'zoom_blur',
+                 'defocus_blur', 'fog'):
+        cid = C.CORRUPTION_NAMES.index(name)
+        whole = torch.empty_like(u8)
+        C.corrupt_batch_(u8, cid, 3, seed=9, sample_offset=1000, out=whole)
+        for i in (0, 96, 224):
+            part = torch.empty(32, 224, 224, 3, dtype=torch.uint8, device='cuda')
+            C.corrupt_batch_(u8[i:i + 32].contiguous(), cid, 3, seed=9, sample_offset=1000 + i, out=part)
+            assert torch.equal(part, whole[i:i + 32]), (name, i)
+
+
+def test_consecutive_add_noise_calls_draw_fresh_starts():
+    """every AddNoise.add_noise call advances the process-wide sample counter, so two consecutive calls do
+    not share their random starts (the reference draws from torch's global generator per call), while manual_seed
+    restores reproducibility."""
+    from robustart_amd.noise import AddNoise, rng
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, stride=4), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1),
+                              torch.nn.Flatten(), torch.nn.Linear(4, 10)).cuda().eval()
+    x = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    y = torch.zeros(4, dtype=torch.int64).cuda()
+    an = AddNoise('pgd_linf')
+    an.config.update(f_model=net, eps=8 / 255, steps=1)
+    rng.manual_seed(3)
+    a = an.add_noise(x, y).clone()
+    b = an.add_noise(x, y).clone()
+    assert not torch.equal(a, b)
+    rng.manual_seed(3)
+    a2 = an.add_noise(x, y)
+    assert torch.equal(a, a2)
+    for name, kw in (('mim_linf', dict(model=net, eps=8 / 255, num_steps=1)), ('pgd_l2', dict(f_model=net, eps=0.5, steps=1))):
+        an = AddNoise(name)
+        an.config.update(**kw)
+        rng.manual_seed(3)
+        assert not torch.equal(an.add_noise(x, y), an.add_noise(x, y)), name
