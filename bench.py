@@ -43,7 +43,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=8, help='images in the bounded CPU baseline sample')
+    ap.add_argument('--cpu-sample', type=int, default=64, help='images of the bounded model leg of the CPU baseline')
+    ap.add_argument('--cpu-sweep', action='store_true', help='only run the CPU 14 corruptions x 5 severities sweep (BASELINE.md 3b)')
     ap.add_argument('--workload', choices=['headline', 'vit_inc', 'vit_pgd', 'adv_train'], default='headline',
                     help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 4: ViT-B/16 evaluated "
                          "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost skipped: no textures)")
@@ -226,29 +227,121 @@ def measure_igemm_roofline(path, images, labels):
             'algorithmic_flops_per_launch': flops / len(prof), 'kernel_seconds_per_fwd_bwd': secs}
 
 
-def cpu_baseline(sample, model_fp32):
-    """Oracle (numpy restatement, asserted equal to the reference) + torch-CPU ResNet-50 on the host
-    cores, on `sample` images of the same workload: IN-C x5 + PGD-7."""
+def _cpu_model_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _cpu_corrupt_chunk(job):
+    """Pool worker: the oracle's per-image loop (add_noise_utils.py:27-31) over one chunk of the 256-image batch."""
+    import numpy as np
+    from oracle import corruptions_np as O
+    name, sev, seed, lo, hi = job
+    rs = np.random.RandomState(seed + lo)
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randint(0, 256, (256, H, W, 3), generator=g, dtype=torch.uint8).numpy()[lo:hi]
+    t0 = time.perf_counter()
+    O.corrupt_batch(name, imgs, sev, rs)
+    return time.perf_counter() - t0
+
+
+def _cpu_corrupt_rate(pool, procs, name, sev, reps):
+    """images/s of one corruption at one severity over the 256-image batch of BASELINE.md section 3, all cores
+    (multiprocessing.Pool): median wall time of `reps` repetitions after one warm-up."""
+    n = 256
+    per = max(1, (n + procs - 1) // procs)
+    jobs = [(name, sev, 0, lo, min(lo + per, n)) for lo in range(0, n, per)]
+    walls = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        pool.map(_cpu_corrupt_chunk, jobs)
+        walls.append(time.perf_counter() - t0)
+    walls = sorted(walls[1:])
+    return n / walls[len(walls) // 2]
+
+
+def cpu_baseline(model_sample, model_fp32, reps=5):
+    """the oracle (numpy / scipy / Pillow restatement, pinned to the reference by the golden
+    fixtures) + a PyTorch-CPU fp32 ResNet-50 on the host cores, on the same workload as the GPU line:
+      * gaussian_noise at severities 1..5 on the 256-image batch (seed 1234): one process and Pool(os.cpu_count()),
+        median of `reps` repetitions after a warm-up;
+      * ResNet-50 fp32 evaluation (batch 32) and PGD-Linf-7 on a bounded sample of `model_sample` images, all cores;
+    combined into images/s of the step (5 corrupted evaluations + 1 attacked evaluation per source image)."""
+    import multiprocessing as mp
     import numpy as np
     from oracle import corruptions_np as O
     from oracle import attacks_ref as A
+    procs = os.cpu_count() or 1
+    t_all = time.time()
+    with mp.get_context('fork').Pool(procs) as pool:
+        pool_rate = {sev: _cpu_corrupt_rate(pool, procs, 'gaussian_noise', sev, reps) for sev in range(1, 6)}
+    # single process, severity 3 (the configuration the survey container timed: 297 images/s on one Xeon core)
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randint(0, 256, (256, H, W, 3), generator=g, dtype=torch.uint8).numpy()
     rs = np.random.RandomState(0)
-    imgs = rs.randint(0, 256, (sample, H, W, 3)).astype(np.uint8)
-    y = torch.from_numpy(rs.randint(0, 1000, (sample,)))
+    one = []
+    for r in range(3):
+        t0 = time.perf_counter()
+        O.corrupt_batch('gaussian_noise', imgs[:64], 3, rs)
+        one.append(64 / (time.perf_counter() - t0))
     m = model_fp32.float().eval()
     f = lambda z: m(A.normalize(z))  # noqa: E731
-    t0 = time.time()
-    for sev in range(1, 6):
-        out = O.corrupt_batch('gaussian_noise', imgs, sev, rs)
-        with torch.no_grad():
-            f(torch.from_numpy(out).permute(0, 3, 1, 2).float() / 255).argmax(1)
-    x = torch.from_numpy(imgs).permute(0, 3, 1, 2).float() / 255
-    u = (torch.rand(x.shape) * 2 - 1) * (2 / 255)
-    adv_x = A.pgd_linf(f, x, y, 2 / 255, 3 / 40, 7, init_u=u)
+    n = model_sample
+    y = torch.from_numpy(rs.randint(0, 1000, (n,)))
+    x = torch.from_numpy(imgs[:n]).permute(0, 3, 1, 2).float() / 255
     with torch.no_grad():
-        f(adv_x).argmax(1)
-    dt = time.time() - t0
-    return 6 * sample / dt, dt
+        f(x[:32]).argmax(1)                                      # warm-up (thread pool, MKL-DNN primitives)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for s in range(0, n, 32):
+            f(x[s:s + 32]).argmax(1)
+    t_eval = (time.perf_counter() - t0) / n                      # seconds per evaluated image
+    t0 = time.perf_counter()
+    for s in range(0, n, 32):
+        u = (torch.rand(x[s:s + 32].shape) * 2 - 1) * (2 / 255)
+        adv_x = A.pgd_linf(f, x[s:s + 32], y[s:s + 32], 2 / 255, 3 / 40, 7, init_u=u)
+        with torch.no_grad():
+            f(adv_x).argmax(1)
+    t_pgd = (time.perf_counter() - t0) / n                       # seconds per attacked + evaluated image
+    t_corrupt = sum(1.0 / pool_rate[sev] for sev in range(1, 6))  # seconds per source image, 5 severities, all cores
+    per_source_image = t_corrupt + 5 * t_eval + t_pgd
+    return {'value': 6.0 / per_source_image, 'unit': 'images/s', 'cores': procs, 'kind': 'port',
+            'cpu_model': _cpu_model_name(), 'torch_threads': torch.get_num_threads(),
+            'sample': 'oracle gaussian_noise sev 1..5 on 256 images (Pool(%d), median of %d reps after a warm-up) + torch-CPU '
+                      'fp32 ResNet-50 evaluation and PGD-Linf-7 on %d images at batch 32 (%.1f s in total)'
+                      % (procs, reps, n, time.time() - t_all),
+            'gaussian_noise_sev3_images_per_s': {'pool_all_cores': pool_rate[3], 'one_process': sorted(one)[1]},
+            'resnet50_fp32_eval_images_per_s': 1.0 / t_eval, 'pgd7_images_per_s': 1.0 / t_pgd,
+            'libs': {'numpy': np.__version__, 'torch': torch.__version__}}
+
+
+def cpu_sweep(reps=5):
+    """every ImageNet-C corruption the oracle restates x 5 severities on the 256-image batch,
+    all cores (frost needs the reference's absent textures and is skipped) -> profiles/r02_cpu_sweep.json.
+        python bench.py --cpu-sweep"""
+    import multiprocessing as mp
+    from oracle import corruptions_np as O
+    procs = os.cpu_count() or 1
+    names = [n for n in O.CORRUPTION_NAMES[:15] if n != 'frost']
+    res = {'cpu_model': _cpu_model_name(), 'cores': procs, 'images': 256, 'reps': reps, 'unit': 'images/s', 'rates': {}}
+    with mp.get_context('fork').Pool(procs) as pool:
+        for nm in names:
+            res['rates'][nm] = {}
+            for sev in range(1, 6):
+                r = reps if nm not in ('glass_blur', 'zoom_blur') else 1       # python pixel loops: one repetition
+                res['rates'][nm][str(sev)] = _cpu_corrupt_rate(pool, procs, nm, sev, r)
+            print(nm, res['rates'][nm], flush=True)
+    tot = sum(1.0 / v for d in res['rates'].values() for v in d.values())
+    res['all_14x5_images_per_s'] = len(names) * 5 / tot
+    out = os.path.join(ROOT, 'gpurun_out', 'cpu_sweep.json')
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(res, open(out, 'w'), indent=1)
+    print(json.dumps({'cpu_sweep': res['all_14x5_images_per_s'], 'unit': 'corrupted images/s', 'cores': procs}))
 
 
 def run_vit_inc(args, device, rank, world, dist):
@@ -418,6 +511,8 @@ def main():
         sys.exit(relaunch_multi_rank(args.gpus))
     if args.spawn_check:
         return spawn_check(args)
+    if args.cpu_sweep:
+        return cpu_sweep()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -497,10 +592,7 @@ def main():
             if isinstance(path, HipEngine):
                 out['roofline'] = measure_igemm_roofline(path, images, labels)
             if model_cpu is not None:
-                v, secs = cpu_baseline(args.cpu_sample, model_cpu)
-                out['cpu_baseline'] = {'value': v, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                                       'sample': '%d images: oracle gaussian_noise sev 1..5 + torch-CPU fp32 ResNet-50 '
-                                                 'eval + PGD-Linf-7 (%.1f s)' % (args.cpu_sample, secs)}
+                out['cpu_baseline'] = cpu_baseline(args.cpu_sample, model_cpu)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
