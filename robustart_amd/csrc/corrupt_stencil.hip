@@ -72,6 +72,73 @@ __global__ __launch_bounds__(kBlock) void k_gauss_pass(const void* __restrict__ 
   }
 }
 
+// Both passes in ONE kernel for radius <= 16 (gaussian_blur severities 1-4, both blurs of glass_blur): a workgroup owns a
+// 16 x 32 pixel tile, stages the (16 + 2r) x (32 + 2r) x 3 clamped neighbourhood as the fp64 values u8 / 255.0 in LDS,
+// writes the axis-0 pass (fp64, scipy's symmetric-pair order) to a second LDS array and runs the axis-1 pass from it.
+// Identical arithmetic to the two-pass kernels above, bit for bit, without the 8-byte-per-element fp64 intermediate in HBM
+// (pass 1 wrote 308 MB and pass 2 read it back: 515 + 357 us per 256-image batch, profiles/r02_corruption_kernels_before.csv).
+constexpr int GF_TH = 16, GF_TW = 32, GF_RMAX = 16;
+template <int FINISH>
+__global__ __launch_bounds__(kBlock) void k_gauss_fused(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int h,
+                                                        int w, GaussW g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t gf_lds[];
+  const int r = g.radius;
+  const int RW = (GF_TW + 2 * r) * 3, RH = GF_TH + 2 * r;
+  double* lut = reinterpret_cast<double*>(gf_lds);          // [256]
+  double* sIn = lut + 256;                                    // [RH][RW]
+  double* sP1 = sIn + RH * RW;                                // [GF_TH][RW]
+  double* sWt = sP1 + GF_TH * RW;                             // [2r + 1]
+  const int tid = threadIdx.x;
+  lut[tid] = (double)tid / 255.0;
+  if (tid <= 2 * r) sWt[tid] = g.w[tid];
+  __syncthreads();
+  const int x0 = blockIdx.x * GF_TW, y0 = blockIdx.y * GF_TH;
+  const uint8_t* img = src + (size_t)blockIdx.z * h * w * 3;
+  for (int i = tid; i < RH * RW; i += kBlock) {
+    const int ry = i / RW, rxe = i - ry * RW;
+    const int px = rxe / 3, c = rxe - px * 3;
+    int yy = y0 - r + ry, xx = x0 - r + px;
+    yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);              // mode='nearest'
+    xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+    sIn[i] = lut[img[((size_t)yy * w + xx) * 3 + c]];
+  }
+  __syncthreads();
+  for (int i = tid; i < GF_TH * RW; i += kBlock) {
+    const int ty = i / RW, rxe = i - ty * RW;
+    const double* col = sIn + (ty + r) * RW + rxe;
+    double tmp = col[0] * sWt[r];
+    for (int jj = -r; jj < 0; ++jj) {
+      const double pair = col[jj * RW] + col[-jj * RW];
+      tmp += pair * sWt[jj + r];
+    }
+    sP1[i] = tmp;
+  }
+  __syncthreads();
+  uint8_t* out = dst + (size_t)blockIdx.z * h * w * 3;
+  for (int i = tid; i < GF_TH * GF_TW * 3; i += kBlock) {
+    const int ty = i / (GF_TW * 3), xe = i - ty * (GF_TW * 3);
+    const int yy = y0 + ty, xx = x0 + xe / 3;
+    if (yy >= h || xx >= w) continue;
+    const double* row = sP1 + ty * RW + xe + 3 * r;
+    double tmp = row[0] * sWt[r];
+    for (int jj = -r; jj < 0; ++jj) {
+      const double pair = row[3 * jj] + row[-3 * jj];
+      tmp += pair * sWt[jj + r];
+    }
+    uint8_t o;
+    if (FINISH == 1) {
+      o = (uint8_t)(uint32_t)(tmp * 255.0);
+    } else {
+      const double c = tmp < 0.0 ? 0.0 : (tmp > 1.0 ? 1.0 : tmp);
+      o = (uint8_t)(uint32_t)(c * 255.0);
+    }
+    out[((size_t)yy * w) * 3 + (size_t)x0 * 3 + xe] = o;
+  }
+}
+size_t gauss_fused_lds(int r) {
+  return (256 + (size_t)(GF_TH + 2 * r) * (GF_TW + 2 * r) * 3 + (size_t)GF_TH * (GF_TW + 2 * r) * 3 + 2 * r + 1) * sizeof(double);
+}
+
 // ---- glass_blur local shuffle -------------------------------------------------------------
 // corruptions.py:176-182: for h in 224-d..d+1 (desc), w likewise: swap (h,w) <-> (h+dy, w+dx).
 // Sequential per image, but swap (h,w) can only touch pixels within d of (h,w), so two swaps
@@ -136,38 +203,76 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i >= n ? period - i : i;
 }
 
-// cv2.filter2D(plane fp64, -1, kernel): row-major tap order, fp64 multiply-add (not contracted)
+// cv2.filter2D(plane fp64, -1, kernel): row-major tap order, fp64 multiply then add (not contracted).
+// A workgroup owns a 16 x 64 pixel tile: the reflected (16 + 2r) x (64 + 2r) x 3 neighbourhood is staged ONCE in LDS as the
+// fp64 values u8 / 255.0 (the first version re-fetched every tap from global memory through a byte LUT: 3.9 ms per
+// 256-image batch), the disk kernel sits in LDS too (broadcast reads), and a thread accumulates 4 horizontally adjacent
+// pixels x 3 channels in registers, tap by tap in the reference order -- bit-identical results.  The kernel is bound by the
+// fp64 vector rate: 441 taps x 3 channels x (mul + add) per pixel = 34 G instructions per batch, 0.87 ms at the MI355X
+// fp64 peak; the 30 %-of-HBM target of the byte-sized corruptions does not apply to a 21 x 21 dense filter.
+constexpr int F2_TH = 16, F2_TW = 64, F2_PX = 4;
+template <int KSZ>
 __global__ __launch_bounds__(kBlock) void k_filter2d(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int n,
-                                                     int h, int w, const double* __restrict__ kern, int ksz) {
-  __shared__ double lut[256];
-  lut[threadIdx.x] = (double)threadIdx.x / 255.0;
-  __syncthreads();
+                                                     int h, int w, const double* __restrict__ kern) {
+  constexpr int ksz = KSZ;
+  extern __shared__ __attribute__((aligned(16))) uint8_t f2_lds[];
   const int r = ksz / 2;
-  const size_t pixels = (size_t)n * h * w;
-  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < pixels; p += (size_t)gridDim.x * kBlock) {
-    const int xo = (int)(p % w);
-    const int yo = (int)((p / w) % h);
-    const uint8_t* img = in + (p / ((size_t)h * w)) * (size_t)h * w * 3;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int a = 0; a < ksz; ++a) {
-      const int yy = reflect101(yo + a - r, h);
-      const uint8_t* row = img + (size_t)yy * w * 3;
-      for (int b = 0; b < ksz; ++b) {
-        const int xx = reflect101(xo + b - r, w);
-        const double kv = kern[a * ksz + b];
-        const double t0 = lut[row[xx * 3]] * kv, t1 = lut[row[xx * 3 + 1]] * kv, t2 = lut[row[xx * 3 + 2]] * kv;
-        a0 += t0;
-        a1 += t1;
-        a2 += t2;
+  const int RW = (F2_TW + 2 * r) * 3, RH = F2_TH + 2 * r;
+  double* lut = reinterpret_cast<double*>(f2_lds);     // [256]
+  double* sK = lut + 256;                                // [ksz * ksz]
+  double* sIn = sK + ksz * ksz;                          // [RH][RW]
+  const int tid = threadIdx.x;
+  lut[tid] = (double)tid / 255.0;
+  for (int i = tid; i < ksz * ksz; i += kBlock) sK[i] = kern[i];
+  __syncthreads();
+  const int x0 = blockIdx.x * F2_TW, y0 = blockIdx.y * F2_TH;
+  const uint8_t* img = in + (size_t)blockIdx.z * h * w * 3;
+  for (int i = tid; i < RH * RW; i += kBlock) {
+    const int ry = i / RW, rxe = i - ry * RW;
+    const int px = rxe / 3, c = rxe - px * 3;
+    const int yy = reflect101(y0 - r + ry, h), xx = reflect101(x0 - r + px, w);
+    sIn[i] = lut[img[((size_t)yy * w + xx) * 3 + c]];
+  }
+  __syncthreads();
+  // thread -> (row ty, 4 pixels starting at tx4): 16 rows x 16 groups
+  const int ty = tid >> 4, tx4 = (tid & 15) * F2_PX;
+  double acc[F2_PX * 3];
+#pragma unroll
+  for (int k = 0; k < F2_PX * 3; ++k) acc[k] = 0.0;
+  for (int a = 0; a < ksz; ++a) {
+    // the (KSZ + 3) x 3 values a row of taps touches are loaded once into registers; the b loop is fully unrolled so
+    // the sliding window costs no LDS re-reads (the runtime-trip-count version re-read 12 doubles per tap: LDS bound)
+    const double* row = sIn + (ty + a) * RW + tx4 * 3;
+    const double* kr = sK + a * ksz;
+    double win[(KSZ + F2_PX - 1) * 3];
+#pragma unroll
+    for (int k = 0; k < (KSZ + F2_PX - 1) * 3; ++k) win[k] = row[k];
+#pragma unroll
+    for (int b = 0; b < KSZ; ++b) {
+      const double kv = kr[b];
+#pragma unroll
+      for (int k = 0; k < F2_PX * 3; ++k) {
+        const double t = win[b * 3 + k] * kv;
+        acc[k] += t;
       }
     }
-    const double v[3] = {a0, a1, a2};
+  }
+  const int yy = y0 + ty;
+  if (yy < h) {
+    uint8_t* o = out + ((size_t)blockIdx.z * h + yy) * w * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double cl = v[c] < 0.0 ? 0.0 : (v[c] > 1.0 ? 1.0 : v[c]);
-      out[p * 3 + c] = (uint8_t)(uint32_t)(cl * 255.0);
+    for (int k = 0; k < F2_PX * 3; ++k) {
+      const int xx = x0 + tx4 + k / 3;
+      if (xx < w) {
+        const double cl = acc[k] < 0.0 ? 0.0 : (acc[k] > 1.0 ? 1.0 : acc[k]);
+        o[(size_t)xx * 3 + k % 3] = (uint8_t)(uint32_t)(cl * 255.0);
+      }
     }
   }
+}
+size_t filter2d_lds(int ksz) {
+  const int r = ksz / 2;
+  return (256 + (size_t)ksz * ksz + (size_t)(F2_TH + 2 * r) * (F2_TW + 2 * r) * 3) * sizeof(double);
 }
 
 // ---- motion_blur (ImageMagick) -----------------------------------------------------------------
@@ -323,6 +428,19 @@ const double kMotion[5][2] = {{10, 3}, {15, 5}, {15, 8}, {15, 12}, {20, 15}};
 template <int FINISH>
 void gauss_u8_to_u8(const uint8_t* in, uint8_t* out, double* tmp, int n, int h, int w, const GaussW& g,
                     hipStream_t s) {
+  if (g.radius <= GF_RMAX && n <= 65535) {
+    const size_t lds = gauss_fused_lds(g.radius);
+    static size_t lds_set[3] = {0, 0, 0};
+    if (lds > lds_set[FINISH]) {
+      if (hipFuncSetAttribute((const void*)k_gauss_fused<FINISH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+        lds_set[FINISH] = lds;
+    }
+    if (lds <= lds_set[FINISH]) {
+      hipLaunchKernelGGL((k_gauss_fused<FINISH>), dim3((w + GF_TW - 1) / GF_TW, (h + GF_TH - 1) / GF_TH, n), dim3(kBlock), lds, s,
+                         in, out, h, w, g);
+      return;
+    }
+  }
   const int grid = rart_grid_for((size_t)n * h * w * 3, kBlock, 256 * 16);
   hipLaunchKernelGGL((k_gauss_pass<0, 0, 0>), dim3(grid), dim3(kBlock), 0, s, (const void*)in, (void*)tmp, n, h, w, g);
   hipLaunchKernelGGL((k_gauss_pass<1, 1, FINISH>), dim3(grid), dim3(kBlock), 0, s, (const void*)tmp, (void*)out, n,
@@ -397,8 +515,26 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
         rart_set_error("defocus_blur: kernel upload failed");
         return RART_ERR_HIP;
       }
-      hipLaunchKernelGGL(k_filter2d, dim3(rart_grid_for((size_t)a.n * a.h * a.w, kBlock, 256 * 16)), dim3(kBlock), 0,
-                         a.stream, a.in, a.out, a.n, a.h, a.w, (const double*)a.workspace, ksz[s]);
+      RART_CHECK_ARG(a.n <= 65535, "defocus_blur: at most 65535 images per call");
+      const size_t lds = filter2d_lds(ksz[s]);
+      static size_t lds_set = 0;
+      if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)k_filter2d<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter2d_lds(21)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_filter2d<21>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter2d_lds(21)) != hipSuccess) {
+          rart_set_error("defocus_blur: cannot raise the dynamic LDS limit");
+          return RART_ERR_HIP;
+        }
+        lds_set = filter2d_lds(21);
+      }
+      const dim3 f2grid((a.w + F2_TW - 1) / F2_TW, (a.h + F2_TH - 1) / F2_TH, a.n);
+      if (ksz[s] == 17)
+        hipLaunchKernelGGL(k_filter2d<17>, f2grid, dim3(kBlock), lds, a.stream, a.in, a.out, a.n, a.h, a.w, (const double*)a.workspace);
+      else if (ksz[s] == 21)
+        hipLaunchKernelGGL(k_filter2d<21>, f2grid, dim3(kBlock), lds, a.stream, a.in, a.out, a.n, a.h, a.w, (const double*)a.workspace);
+      else {
+        rart_set_error("defocus_blur: unexpected disk size %d", ksz[s]);
+        return RART_ERR_INVALID;
+      }
       break;
     }
     case RART_MOTION_BLUR: {
