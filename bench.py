@@ -50,6 +50,7 @@ def parse():
                          "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost skipped: no textures)")
     ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
                     help="'hip' = hand-written engine (product); 'scaffold' = PyTorch-ROCm/MIOpen, for comparison only")
+    ap.add_argument('--one-stream', action='store_true', help='run the two halves of a step back to back on one stream (A/B)')
     ap.add_argument('--spawn-check', action='store_true',
                     help='launch-path self test (no GPU work): every rank joins a gloo group, rank 0 prints one JSON line '
                          'with the world size it saw -- covers the --gpus N re-launch on a CPU-only box')
@@ -112,17 +113,24 @@ def build_workload(B, device, rank):
 
 
 class HipEngine:
-    """The product path: hand-written bf16 MFMA implicit-GEMM engine (robustart_amd/model/engine.py)."""
+    """The product path: hand-written bf16 MFMA implicit-GEMM engine (robustart_amd/model/engine.py).
+    Two engine instances (own activation buffers, same folded weights) let the step run its two independent halves on two
+    HIP streams: the corrupted evaluations (HBM-bound layer1 / layer2 most of the time) overlap the PGD chain's
+    MFMA-bound deep layers and fill each other's grid tails."""
     name = 'hip-igemm-bf16'
     MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
-    def __init__(self, model, device):
+    def __init__(self, model, device, two_streams=True):
         from robustart_amd.model.engine import ResNet50Engine, EngineModel
         self.eng = ResNet50Engine(model, device)
         self.f_model = EngineModel(None, takes_normalized=False, mean=self.MEAN, std=self.STD, engine=self.eng)
+        n_side = int(os.environ.get('RART_BENCH_SIDE_STREAMS', '1')) if two_streams else 0
+        self.eval_engs = [ResNet50Engine(model, device) for _ in range(n_side)] or [self.eng]
+        self.sides = [torch.cuda.Stream(device=device) for _ in range(n_side)]
+        self.side = self.sides[0] if self.sides else None
 
-    def logits_from_u8(self, u8, norm_buf):
-        return self.eng.logits_from_u8(u8, self.MEAN, self.STD)
+    def logits_from_u8(self, u8, norm_buf, k=0):
+        return self.eval_engs[k % len(self.eval_engs)].logits_from_u8(u8, self.MEAN, self.STD)
 
 
 class Scaffold:
@@ -153,18 +161,35 @@ def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
     lib = _lib.load()
     correct = 0
     base = (step_idx * 1_000_003 + rank * B)          # global sample index of this rank's first image
+    side = getattr(path, 'side', None)
+    main = torch.cuda.current_stream()
+    sides = getattr(path, 'sides', None) or [main]
+    for sd in sides:
+        if sd is not main:
+            sd.wait_stream(main)                       # the previous step's consumers of the scratch buffers are done
+    parts = []
     for sev in range(1, 6):
-        C.corrupt_batch_(images, 0, sev, seed=0, sample_offset=base, out=scratch_u8)
-        logits = path.logits_from_u8(scratch_u8, norm_buf)
-        _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
-        correct = correct + (pred.long() == labels).sum()
+        k = (sev - 1) % len(sides)
+        with torch.cuda.stream(sides[k]):
+            buf = scratch_u8 if k == 0 else one_step.extra.setdefault(k, torch.empty_like(scratch_u8))
+            C.corrupt_batch_(images, 0, sev, seed=0, sample_offset=base, out=buf)
+            logits = path.logits_from_u8(buf, norm_buf, k) if isinstance(path, HipEngine) else path.logits_from_u8(buf, norm_buf)
+            _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
+            parts.append((pred.long() == labels).sum())
     x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
     x_adv = adv.pgd_linf(x01, labels, path.f_model, 2 / 255, 3 / 40, 7, seed=1, sample_offset=base)
     with torch.no_grad():
         logits = path.f_model(x_adv).float()
     _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
     correct_adv = (pred.long() == labels).sum()
+    for sd in sides:
+        if sd is not main:
+            main.wait_stream(sd)                       # join: the step is complete when every stream's part is
+    correct = sum(parts)
     return correct, correct_adv
+
+
+one_step.extra = {}
 
 
 def measure_gaussian_roofline(B, device, launches=40):
@@ -192,9 +217,9 @@ def measure_gaussian_roofline(B, device, launches=40):
 
 def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_traffic.json, produced by profiles/summarize_pmc.py); None if absent."""
+    (profiles/r02_pmc_traffic.json, produced by profiles/summarize_pmc.py); None if absent."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
             d = json.load(f)
         if key == 'igemm':
             return d['k_conv_igemm_bf16_all']['hbm_bytes']
@@ -237,14 +262,24 @@ def _cpu_model_name():
     return 'unknown'
 
 
+_CPU_IMGS = None      # the 256-image batch of BASELINE.md section 3, created before the pool forks (workers inherit it)
+
+
+def _cpu_batch():
+    global _CPU_IMGS
+    if _CPU_IMGS is None:
+        g = torch.Generator().manual_seed(1234)
+        _CPU_IMGS = torch.randint(0, 256, (256, H, W, 3), generator=g, dtype=torch.uint8).numpy()
+    return _CPU_IMGS
+
+
 def _cpu_corrupt_chunk(job):
     """Pool worker: the oracle's per-image loop (add_noise_utils.py:27-31) over one chunk of the 256-image batch."""
     import numpy as np
     from oracle import corruptions_np as O
     name, sev, seed, lo, hi = job
     rs = np.random.RandomState(seed + lo)
-    g = torch.Generator().manual_seed(1234)
-    imgs = torch.randint(0, 256, (256, H, W, 3), generator=g, dtype=torch.uint8).numpy()[lo:hi]
+    imgs = _cpu_batch()[lo:hi]
     t0 = time.perf_counter()
     O.corrupt_batch(name, imgs, sev, rs)
     return time.perf_counter() - t0
@@ -278,11 +313,11 @@ def cpu_baseline(model_sample, model_fp32, reps=5):
     from oracle import attacks_ref as A
     procs = os.cpu_count() or 1
     t_all = time.time()
+    imgs = _cpu_batch()
+    torch.set_num_threads(torch.get_num_threads())      # (no-op; the pool below must fork BEFORE torch spins up its workers)
     with mp.get_context('fork').Pool(procs) as pool:
         pool_rate = {sev: _cpu_corrupt_rate(pool, procs, 'gaussian_noise', sev, reps) for sev in range(1, 6)}
     # single process, severity 3 (the configuration the survey container timed: 297 images/s on one Xeon core)
-    g = torch.Generator().manual_seed(1234)
-    imgs = torch.randint(0, 256, (256, H, W, 3), generator=g, dtype=torch.uint8).numpy()
     rs = np.random.RandomState(0)
     one = []
     for r in range(3):
@@ -328,6 +363,7 @@ def cpu_sweep(reps=5):
     from oracle import corruptions_np as O
     procs = os.cpu_count() or 1
     names = [n for n in O.CORRUPTION_NAMES[:15] if n != 'frost']
+    _cpu_batch()
     res = {'cpu_model': _cpu_model_name(), 'cores': procs, 'images': 256, 'reps': reps, 'unit': 'images/s', 'rates': {}}
     with mp.get_context('fork').Pool(procs) as pool:
         for nm in names:
@@ -538,7 +574,7 @@ def main():
     images, labels, model = build_workload(B, device, rank)
     import copy
     model_cpu = copy.deepcopy(model) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    path = HipEngine(model, device) if args.model_path == 'hip' else Scaffold(model, device)
+    path = HipEngine(model, device, two_streams=not args.one_stream) if args.model_path == 'hip' else Scaffold(model, device)
     scratch = torch.empty_like(images)
     norm_buf = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=device)
 
@@ -574,7 +610,8 @@ def main():
         'config': {'workload': 'per step and GPU: gaussian_noise sev 1..5 on 256 u8 224x224 images -> normalise -> '
                                'ResNet-50 eval (1280 img) + PGD-Linf-7 eps 2/255 ResNet-50 eval (256 img)',
                    'global_batch': B * world, 'images_per_step': imgs_per_step,
-                   'model_path': path.name, 'parallelism': 'dp%d' % world},
+                   'model_path': path.name, 'parallelism': 'dp%d' % world,
+                   'streams': 1 + len(getattr(path, 'sides', None) or [])},
     }
     if rank == 0:
         if world == 1:
