@@ -213,6 +213,20 @@ int rart_fab_update(float* x1, const float* x0, const float* d1, const float* d2
 int rart_fab_backoff(float* x1, const float* x0, const uint8_t* mask, int batch, size_t n_per_sample, float beta,
                      rart_stream_t stream);
 
+/* ---- APGD with the L1 threat model (Attacks/autoattack/autopgd_base.py:19-83, 222-226, 351-364, 431-441) ----
+ * rart_l1_project: the reference's L1_projection(x2 = x, y2 = y, eps1 = eps) for `rows` rows of n fp32 elements: delta with
+ * ||y + delta||_1 <= eps and 0 <= x + y + delta <= 1.  out = delta (point_out = 0) or the projected point x + y + delta
+ * (point_out = 1; clamp01 additionally clamps it to [0,1] as attack_single_run :237 does).  out may alias y.
+ * rart_row_kth_abs: thr[r] = k[r]-th smallest (0-based, clamped to [0, n-1]) of |g[r][.]|, exact (radix select).
+ * rart_apgd_l1_move: delta_u = x_adv + step_size[r] * sign(g * [|g| >= thr[r]]) / (count_r + 1e-10) - x0 (:355-360).
+ * rart_row_count_diff: out[r] = #{i : a[r][i] != b[r][i]} as fp32 (L0_norm, other_utils.py:42-43). */
+int rart_l1_project(const float* x, const float* y, float* out, int rows, size_t n, float eps, int point_out, int clamp01,
+                    rart_stream_t stream);
+int rart_row_kth_abs(const float* g, const int64_t* k, float* thr, int rows, size_t n, rart_stream_t stream);
+int rart_apgd_l1_move(const float* x_adv, const float* grad, const float* x0, const float* thr, const float* step_size,
+                      float* delta_u, int rows, size_t n, rart_stream_t stream);
+int rart_row_count_diff(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream);
+
 /* Per-sample select: dst[i] = src[i] where mask[i] != 0 (rows of n_per_sample floats).
  * The x_best / x_best_adv / grad_best bookkeeping of autopgd_base.py:389-406,426-427. */
 int rart_select_rows(float* dst, const float* src, const uint8_t* mask, int batch, size_t n_per_sample,

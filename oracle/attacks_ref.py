@@ -267,6 +267,166 @@ def apgd_single_run(model_fn, x, y, norm, eps, n_iter, loss, init_t, y_target=No
     return x_best, acc, loss_best, x_best_adv
 
 
+# ---------------------------------------------------------------------------------------
+# APGD, L1 threat model (autopgd_base.py:19-83 L1_projection; :222-226, :300-313, :351-364, :431-441, :531-555) -- pinned
+# ---------------------------------------------------------------------------------------
+
+def l1_projection(x2, y2, eps1):
+    """autopgd_base.py:19-83: delta such that ||y2 + delta||_1 <= eps1 and 0 <= x2 + y2 + delta <= 1 (the exact projection
+    onto the intersection of the L1 ball around x2 and the box).  Per coordinate the perturbation magnitude |y| shrinks by
+    clip(alpha, -u, |y|), u = min(min(1 - x - y, x + y), 0) being what the box alone demands; alpha is the root of the
+    piecewise-linear budget equation, found on the sorted breakpoints."""
+    x = x2.clone().float().reshape(x2.shape[0], -1)
+    y = y2.clone().float().reshape(y2.shape[0], -1)
+    sigma = y.clone().sign()
+    u = torch.min(1 - x - y, x + y)
+    u = torch.min(torch.zeros_like(y), u)
+    l = -torch.clone(y).abs()
+    d = u.clone()
+    bs, indbs = torch.sort(-torch.cat((u, l), 1), dim=1)
+    bs2 = torch.cat((bs[:, 1:], torch.zeros(bs.shape[0], 1)), 1)
+    inu = 2 * (indbs < u.shape[1]).float() - 1
+    size1 = inu.cumsum(dim=1)
+    s1 = -u.sum(dim=1)
+    c = eps1 - y.clone().abs().sum(dim=1)
+    c5 = s1 + c < 0
+    c2 = c5.nonzero().squeeze(1)
+    s = s1.unsqueeze(-1) + torch.cumsum((bs2 - bs) * size1, dim=1)
+    if c2.numel() != 0:
+        lb = torch.zeros_like(c2).float()
+        ub = torch.ones_like(lb) * (bs.shape[1] - 1)
+        nitermax = torch.ceil(torch.log2(torch.tensor(bs.shape[1]).float()))
+        counter = 0
+        while counter < nitermax:
+            counter4 = torch.floor((lb + ub) / 2.)
+            counter2 = counter4.long()
+            c8 = s[c2, counter2] + c[c2] < 0
+            lb = torch.where(c8, counter4, lb)
+            ub = torch.where(c8, ub, counter4)
+            counter += 1
+        lb2 = lb.long()
+        alpha = (-s[c2, lb2] - c[c2]) / size1[c2, lb2 + 1] + bs2[c2, lb2]
+        d[c2] = -torch.min(torch.max(-u[c2], alpha.unsqueeze(-1)), -l[c2])
+    return (sigma * d).view(x2.shape)
+
+
+def _l0(x):
+    return (x != 0.).reshape(x.shape[0], -1).sum(-1)
+
+
+def apgd_l1_single_run(model_fn, x, y, eps, n_iter, loss, init_t=None, x_init=None, y_target=None, trace=None):
+    """attack_single_run with norm = 'L1' (autopgd_base.py:208-448): start x + t + L1_projection(x, t, eps) from
+    t = randn (:222-226) or a given x_init (:230-234); sparse sign steps on the top-k gradient entries (:351-364); every
+    k = max(int(0.04 n_iter), 1) iterations the sparsity / step size adaptation of :431-441.  Returns
+    (x_best, acc, loss_best, x_best_adv)."""
+    crit = {'ce': ce_indiv, 'dlr': dlr_loss}.get(loss) or (lambda lg, yy: dlr_loss_targeted(lg, yy, y_target))
+    nd = x.dim() - 1
+    B = x.shape[0]
+    n_fts = x[0].numel()
+    if x_init is None:
+        x_adv = x + init_t + l1_projection(x, init_t, eps)
+    else:
+        x_adv = x_init.clone()
+    x_adv = x_adv.clamp(0., 1.)
+    x_best = x_adv.clone()
+    x_best_adv = x_adv.clone()
+    logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y)
+    grad_best = grad.clone()
+    acc = logits.max(1)[1] == y
+    loss_best = loss_indiv.clone()
+    alpha = 1.
+    step_size = alpha * eps * torch.ones([B, *([1] * nd)])
+    k = max(int(.04 * n_iter), 1)
+    if x_init is None:
+        topk = .2 * torch.ones([B])
+        sp_old = n_fts * torch.ones_like(topk)
+    else:
+        topk = _l0(x_adv - x) / n_fts / 1.5
+        sp_old = _l0(x_adv - x)
+    adasp_redstep, adasp_minstep = 1.5, 10.
+    counter3 = 0
+    u = torch.arange(B)
+    for i in range(n_iter):
+        x_adv = x_adv.detach()
+        grad_topk = grad.abs().reshape(B, -1).sort(-1)[0]
+        topk_curr = torch.clamp((1. - topk) * n_fts, min=0, max=n_fts - 1).long()
+        grad_topk = grad_topk[u, topk_curr].view(-1, *[1] * nd)
+        sparsegrad = grad * (grad.abs() >= grad_topk).float()
+        x_adv_1 = x_adv + step_size * sparsegrad.sign() / (
+            sparsegrad.sign().abs().reshape(B, -1).sum(dim=-1).view(-1, *[1] * nd) + 1e-10)
+        delta_u = x_adv_1 - x
+        delta_p = l1_projection(x, delta_u, eps)
+        x_adv = x + delta_u + delta_p
+
+        logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y)
+        pred = logits.max(1)[1] == y
+        acc = torch.min(acc, pred)
+        x_best_adv[~pred] = x_adv[~pred] + 0.
+        y1 = loss_indiv.clone()
+        ind = y1 > loss_best
+        x_best[ind] = x_adv[ind].clone()
+        grad_best[ind] = grad[ind].clone()
+        loss_best[ind] = y1[ind] + 0
+        if trace is not None:
+            trace.append(dict(x_adv=x_adv.clone(), grad=grad.clone(), loss=y1.clone(), step_size=step_size.flatten().clone(),
+                              topk=topk.clone()))
+        counter3 += 1
+        if counter3 == k:
+            sp_curr = _l0(x_best - x)
+            fl_redtopk = (sp_curr / sp_old) < .95
+            topk = sp_curr / n_fts / 1.5
+            step_size[fl_redtopk] = alpha * eps
+            step_size[~fl_redtopk] /= adasp_redstep
+            step_size.clamp_(alpha * eps / adasp_minstep, alpha * eps)
+            sp_old = sp_curr.clone()
+            x_adv[fl_redtopk] = x_best[fl_redtopk].clone()
+            grad[fl_redtopk] = grad_best[fl_redtopk].clone()
+            counter3 = 0
+    return x_best, acc, loss_best, x_best_adv
+
+
+def apgd_l1_largereps_schedule(eps, n_iter):
+    """autopgd_base.py:490-495: (epss, iters) of the decreasing-radius schedule used when use_largereps is set."""
+    epss = [3. * eps, 2. * eps, 1. * eps]
+    iters = [math.ceil(.3 * n_iter), math.ceil(.3 * n_iter), math.ceil(.4 * n_iter)]
+    iters[-1] = n_iter - sum(iters[:-1])
+    return epss, iters
+
+
+def apgd_l1_decr_eps(model_fn, x, y, eps, n_iter, loss, init_noise, y_target=None):
+    """decr_eps_pgd (autopgd_base.py:531-555): x_init = x + randn, projected onto the 3 eps ball, then three runs with
+    radii 3 eps, 2 eps, eps, each started from the previous best point re-projected.  init_noise = the torch.randn_like(x)."""
+    epss, iters = apgd_l1_largereps_schedule(eps, n_iter)
+    x_init = x + init_noise
+    x_init = x_init + l1_projection(x, x_init, 1. * float(epss[0]))      # (sic: the reference passes x_init, not x_init - x)
+    for e, nit in zip(epss, iters):
+        x_init = x_init + l1_projection(x, x_init - x, e)
+        x_init, acc, loss_b, x_adv = apgd_l1_single_run(model_fn, x, y, e, nit, loss, x_init=x_init, y_target=y_target)
+    return x_init, acc, loss_b, x_adv
+
+
+def apgd_l1_perturb(model_fn, x, y, eps, n_iter, loss, draws, n_restarts=1, use_largereps=False):
+    """APGDAttack.perturb with norm = 'L1' (autopgd_base.py:450-529).  draws(counter, shape) supplies the torch.randn of
+    restart `counter` for the still-robust subset (randn for a plain run, randn_like for the larger-eps schedule)."""
+    x = x.detach().clone().float()
+    y_pred = model_fn(x).max(1)[1]
+    adv = x.clone()
+    acc = y_pred == y
+    for counter in range(n_restarts):
+        ind = acc.nonzero().flatten()
+        if ind.numel() != 0:
+            xs, ys = x[ind].clone(), y[ind].clone()
+            t = draws(counter, xs.shape)
+            if use_largereps:
+                _, acc_curr, _, adv_curr = apgd_l1_decr_eps(model_fn, xs, ys, eps, n_iter, loss, t)
+            else:
+                _, acc_curr, _, adv_curr = apgd_l1_single_run(model_fn, xs, ys, eps, n_iter, loss, init_t=t)
+            ind_curr = (acc_curr == 0).nonzero().flatten()
+            acc[ind[ind_curr]] = False
+            adv[ind[ind_curr]] = adv_curr[ind_curr].clone()
+    return adv
+
+
 def apgd_perturb(model_fn, x, y, norm, eps, n_iter, loss, init_ts, n_restarts=1):
     """autopgd_base.py:450-529 (best_loss=False).  init_ts[r] = start direction for restart r,
     shaped like the still-robust subset at that restart."""
@@ -528,6 +688,9 @@ class TorchStreamDraws:
 
     def pm1(self, _index, shape):
         return 2 * torch.rand(tuple(shape)) - 1
+
+    def randn(self, _index, shape):                      # APGD-L1 start (autopgd_base.py:223, :538)
+        return torch.randn(tuple(shape))
 
     def square_init(self, n, c, w):
         return torch.sign(2 * torch.rand([n, c, 1, w]) - 1)

@@ -56,6 +56,10 @@ SIGNATURES = {
     'rart_row_absmax_diff': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_fab_update': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_void_p]),
     'rart_fab_backoff': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_void_p]),
+    'rart_l1_project': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_int, c_int, c_void_p]),
+    'rart_row_kth_abs': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'rart_apgd_l1_move': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'rart_row_count_diff': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_select_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_logit_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),

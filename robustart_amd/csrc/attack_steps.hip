@@ -529,6 +529,153 @@ __global__ __launch_bounds__(kFabThreads) void k_fab_project_linf(const float* _
   if (threadIdx.x == 0 && rowmax) rowmax[row] = mx;
 }
 
+// ---- APGD, L1 threat model (autopgd_base.py:19-83, 222-226, 351-364, 431-441) -----------------------------------------
+// L1_projection: delta with ||y + delta||_1 <= eps and 0 <= x + y + delta <= 1.  Per coordinate |y_i| shrinks by
+// clip(alpha, lo_i, a_i), a_i = |y_i|, lo_i = -min(min(1 - x_i - y_i, x_i + y_i), 0) (what the box alone demands), and alpha
+// is the root of G(alpha) = sum_i clip(alpha, lo_i, a_i) = sum_i a_i - eps (only when G(0) = sum lo_i is below that
+// target).  The reference sorts the 2n breakpoints and binary-searches a cumulative sum; here one workgroup per row brackets
+// alpha by bisection on G (a row reduction per evaluation, fp64 accumulation) and then solves the active linear segment
+// exactly -- no sort, the same structure as k_fab_project_linf.  In place: out = x + y + delta (the projected point) when
+// `point_out`, else out = delta.
+__device__ __forceinline__ void l1_lo_hi(float xv, float yv, float& lo, float& a) {
+  a = fabsf(yv);
+  const float s = xv + yv;
+  lo = -fminf(fminf(1.f - s, s), 0.f);
+}
+__global__ __launch_bounds__(kFabThreads) void k_l1_project(const float* __restrict__ xs, const float* __restrict__ ys,
+                                                            float* __restrict__ out, size_t n, float eps, int point_out,
+                                                            int clamp01) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  const float* x = xs + row * n;
+  const float* y = ys + row * n;
+  float* o = out + row * n;
+  double sa = 0.0, slo = 0.0;
+  float amax = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    float lo, a;
+    l1_lo_hi(x[i], y[i], lo, a);
+    sa += (double)a;
+    slo += (double)lo;
+    amax = fmaxf(amax, a);
+  }
+  sa = fab_block_sum(sa, sh);
+  slo = fab_block_sum(slo, sh);
+  amax = fab_block_min(amax, sh, true);
+  const double target = sa - (double)eps;           // = -c of the reference
+  float alpha = 0.f;                                  // s1 + c >= 0: the box shrink alone is inside the ball (d = u)
+  if (slo < target) {
+    float blo = 0.f, bhi = amax;
+    for (int it = 0; it < 30; ++it) {
+      const float mid = 0.5f * (blo + bhi);
+      double g = 0.0;
+      for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+        float lo, a;
+        l1_lo_hi(x[i], y[i], lo, a);
+        g += (double)fminf(fmaxf(mid, lo), a);
+      }
+      g = fab_block_sum(g, sh);
+      if (g > target) bhi = mid; else blo = mid;
+    }
+    // exact solve on the segment containing blo: coordinates with lo_i < blo < a_i move with alpha, the others are fixed
+    double fixed = 0.0, act = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+      float lo, a;
+      l1_lo_hi(x[i], y[i], lo, a);
+      if (lo <= blo && blo < a) act += 1.0; else fixed += (double)fminf(fmaxf(blo, lo), a);
+    }
+    fixed = fab_block_sum(fixed, sh);
+    act = fab_block_sum(act, sh);
+    alpha = act > 0.0 ? (float)((target - fixed) / act) : bhi;
+    alpha = fminf(fmaxf(alpha, blo), bhi);
+  }
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float xv = x[i], yv = y[i];
+    float lo, a;
+    l1_lo_hi(xv, yv, lo, a);
+    const float shrink = (slo < target) ? fminf(fmaxf(alpha, lo), a) : lo;      // d = -shrink
+    const float sg = yv > 0.f ? 1.f : (yv < 0.f ? -1.f : 0.f);
+    const float delta = -sg * shrink;
+    float v = point_out ? (xv + yv) + delta : delta;
+    if (point_out && clamp01) v = clampf(v, 0.f, 1.f);
+    o[i] = v;
+  }
+}
+
+// thr[r] = the k[r]-th smallest |g[r][.]| (0-based), EXACT: radix select on the float bit patterns, 4 passes of 8 bits,
+// one workgroup per row (autopgd_base.py:352-354: grad.abs().sort()[..., topk_curr]).
+__global__ __launch_bounds__(kFabThreads) void k_row_kth_abs(const float* __restrict__ gs, const int64_t* __restrict__ ks,
+                                                             float* __restrict__ thr, size_t n) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_prefix, s_rank;
+  const size_t row = blockIdx.x;
+  const float* g = gs + row * n;
+  if (threadIdx.x == 0) {
+    long long k = ks[row];
+    k = k < 0 ? 0 : (k > (long long)n - 1 ? (long long)n - 1 : k);
+    s_prefix = 0u;
+    s_rank = (uint32_t)k;
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t prefix = s_prefix, hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+      const uint32_t b = __float_as_uint(g[i]) & 0x7FFFFFFFu;      // |g|: non-negative floats order like their bits
+      if ((b & hi_mask) == prefix) atomicAdd(&hist[(b >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t r = s_rank, d = 0;
+      for (; d < 255; ++d) {
+        if (r < hist[d]) break;
+        r -= hist[d];
+      }
+      s_rank = r;
+      s_prefix = prefix | (d << shift);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) thr[row] = __uint_as_float(s_prefix);
+}
+
+// The sparse sign step of APGD-L1 (autopgd_base.py:355-358): delta_u = x_adv + step * sign(sparse) / (count + 1e-10) - x0 with
+// sparse = g * [|g| >= thr]; count = number of non-zero signs of the row.  Writes delta_u (the projection follows).
+__global__ __launch_bounds__(kFabThreads) void k_apgd_l1_move(const float* __restrict__ xa, const float* __restrict__ gs,
+                                                              const float* __restrict__ x0, const float* __restrict__ thr,
+                                                              const float* __restrict__ step, float* __restrict__ du, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  const float t = thr[row];
+  double cnt = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float g = gs[row * n + i];
+    cnt += (fabsf(g) >= t && g != 0.f) ? 1.0 : 0.0;
+  }
+  cnt = fab_block_sum(cnt, sh);
+  const float denom = (float)cnt + 1e-10f;
+  const float ss = step[row];
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float g = gs[row * n + i];
+    const float sg = (fabsf(g) >= t) ? signf(g) : 0.f;
+    const float q = ss * sg;
+    const float x1 = xa[row * n + i] + q / denom;
+    du[row * n + i] = x1 - x0[row * n + i];
+  }
+}
+
+// out[r] = number of i with a[r][i] != b[r][i]  (L0_norm(x_best - x), other_utils.py:42-43)
+__global__ __launch_bounds__(kFabThreads) void k_row_count_diff(const float* __restrict__ a, const float* __restrict__ b,
+                                                                float* __restrict__ out, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  double c = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) c += ((a[row * n + i] - b[row * n + i]) != 0.f) ? 1.0 : 0.0;
+  c = fab_block_sum(c, sh);
+  if (threadIdx.x == 0) out[row] = (float)c;
+}
+
 // out[r] = sum_i a[r][i]*b[r][i]  (b of the hyperplane: -df + <grad, x1>, fab_base.py:170-171)
 __global__ __launch_bounds__(kFabThreads) void k_row_dot(const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, size_t n) {
@@ -917,6 +1064,38 @@ int rart_logit_loss(const float* logits, const int64_t* y, const int64_t* yt, in
   hipLaunchKernelGGL(k_logit_loss, dim3((batch + rows_per_block - 1) / rows_per_block), dim3(kBlock), 0,
                      (hipStream_t)stream, logits, y, yt, batch, classes, kind, scale, loss_out, dl, pred_out);
   RART_CHECK_LAUNCH("rart_logit_loss");
+  return RART_OK;
+}
+
+
+int rart_l1_project(const float* x, const float* y, float* out, int rows, size_t n, float eps, int point_out, int clamp01,
+                    rart_stream_t stream) {
+  RART_CHECK_ARG(x && y && out && rows > 0 && n > 0 && eps >= 0.f, "rart_l1_project: bad arguments");
+  hipLaunchKernelGGL(k_l1_project, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, x, y, out, n, eps, point_out, clamp01);
+  RART_CHECK_LAUNCH("rart_l1_project");
+  return RART_OK;
+}
+
+int rart_row_kth_abs(const float* g, const int64_t* k, float* thr, int rows, size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(g && k && thr && rows > 0 && n > 0 && n < (1ull << 32), "rart_row_kth_abs: bad arguments");
+  hipLaunchKernelGGL(k_row_kth_abs, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, g, k, thr, n);
+  RART_CHECK_LAUNCH("rart_row_kth_abs");
+  return RART_OK;
+}
+
+int rart_apgd_l1_move(const float* x_adv, const float* grad, const float* x0, const float* thr, const float* step_size,
+                      float* delta_u, int rows, size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(x_adv && grad && x0 && thr && step_size && delta_u && rows > 0 && n > 0, "rart_apgd_l1_move: bad arguments");
+  hipLaunchKernelGGL(k_apgd_l1_move, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, x_adv, grad, x0, thr, step_size,
+                     delta_u, n);
+  RART_CHECK_LAUNCH("rart_apgd_l1_move");
+  return RART_OK;
+}
+
+int rart_row_count_diff(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream) {
+  RART_CHECK_ARG(a && b && out && rows > 0 && n > 0, "rart_row_count_diff: bad arguments");
+  hipLaunchKernelGGL(k_row_count_diff, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, a, b, out, n);
+  RART_CHECK_LAUNCH("rart_row_count_diff");
   return RART_OK;
 }
 

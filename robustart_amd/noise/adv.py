@@ -378,6 +378,143 @@ def apgd_targeted_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, 
     return adv
 
 
+
+# ---------------------------------------------------------------------------------------
+# APGD with the L1 threat model (autopgd_base.py:19-83, 222-226, 300-313, 351-364, 431-441, 531-555)
+# ---------------------------------------------------------------------------------------
+
+def l1_projection(x, y, eps, point_out=False, clamp01=False, out=None):
+    """L1_projection(x2, y2, eps1) of the reference (autopgd_base.py:19-83) through rart_l1_project: delta (default) or the
+    projected point x + y + delta (point_out), optionally clamped to [0,1]."""
+    torch = _lib.require_gpu()
+    x, y = x.detach().float().contiguous(), y.detach().float().contiguous()
+    out = torch.empty_like(y) if out is None else out
+    _lib.check(_lib.load().rart_l1_project(_lib.ptr(x), _lib.ptr(y), _lib.ptr(out), x.shape[0], x[0].numel(), float(eps),
+                                           1 if point_out else 0, 1 if clamp01 else 0, _lib.stream_ptr()))
+    return out
+
+
+def _row_count_diff(a, b):
+    torch = _lib.require_gpu()
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().rart_row_count_diff(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.shape[0], a[0].numel(),
+                                               _lib.stream_ptr()))
+    return out
+
+
+def _apgd_l1_single_run(prov, x, y, eps, n_iter, loss_kind, y_target=None, init_t=None, x_init=None, seed=None,
+                        sample_offset=0):
+    """attack_single_run, norm 'L1' (autopgd_base.py:208-448).  Heavy tensors move only through HIP kernels
+    (rart_l1_project, rart_row_kth_abs, rart_apgd_l1_move, rart_row_count_diff, rart_select_rows); the [B]-sized sparsity
+    / step-size state is bookkeeping on small device tensors, without host synchronisation."""
+    torch = _lib.require_gpu()
+    lib, sp = _lib.load(), _lib.stream_ptr
+    B, n_fts = x.shape[0], x[0].numel()
+    if x_init is None:
+        if init_t is None:
+            init_t = torch.empty_like(x)
+            _lib.check(lib.rart_rng_normal_f32(_lib.ptr(init_t), B, n_fts, _seed(seed), sample_offset, 5, sp()))
+        x_adv = l1_projection(x, init_t, eps, point_out=True, clamp01=True)           # :222-226, :237
+    else:
+        x_adv = x_init.clamp(0.0, 1.0).contiguous()
+    x_best = x_adv.clone()
+    x_best_adv = x_adv.clone()
+    logits, loss_indiv, grad, pred = prov.logits_and_grad(x_adv, y, loss_kind, y_target)
+    grad_best = grad.clone()
+    acc = pred.to(torch.int64) == y
+    loss_best = loss_indiv.clone()
+    alpha = 1.0
+    step_size = torch.full((B,), alpha * eps, dtype=torch.float32, device=x.device)
+    k = max(int(.04 * n_iter), 1)
+    if x_init is None:
+        topk = torch.full((B,), 0.2, dtype=torch.float32, device=x.device)
+        sp_old = torch.full((B,), float(n_fts), dtype=torch.float32, device=x.device)
+    else:
+        sp_old = _row_count_diff(x_adv, x)
+        topk = sp_old / n_fts / 1.5
+    counter3 = 0
+    thr = torch.empty(B, dtype=torch.float32, device=x.device)
+    du = torch.empty_like(x)
+    for i in range(n_iter):
+        topk_curr = torch.clamp((1.0 - topk) * n_fts, min=0, max=n_fts - 1).long().contiguous()      # :352-353
+        _lib.check(lib.rart_row_kth_abs(_lib.ptr(grad), _lib.ptr(topk_curr), _lib.ptr(thr), B, n_fts, sp()))
+        _lib.check(lib.rart_apgd_l1_move(_lib.ptr(x_adv), _lib.ptr(grad), _lib.ptr(x), _lib.ptr(thr), _lib.ptr(step_size),
+                                         _lib.ptr(du), B, n_fts, sp()))                               # :355-360
+        x_adv = l1_projection(x, du, eps, point_out=True, clamp01=False, out=x_adv)                    # :361-362
+        logits, loss_indiv, grad, pred = prov.logits_and_grad(x_adv, y, loss_kind, y_target)
+        pred_ok = pred.to(torch.int64) == y
+        acc = acc & pred_ok
+        select_rows_(x_best_adv, x_adv, ~pred_ok)
+        ind = loss_indiv > loss_best
+        select_rows_(x_best, x_adv, ind)
+        select_rows_(grad_best, grad, ind)
+        loss_best = torch.where(ind, loss_indiv, loss_best)
+        counter3 += 1
+        if counter3 == k:                                                                              # :431-441
+            sp_curr = _row_count_diff(x_best, x)
+            fl_redtopk = (sp_curr / sp_old) < .95
+            topk = sp_curr / n_fts / 1.5
+            step_size = torch.where(fl_redtopk, torch.full_like(step_size, alpha * eps), step_size / 1.5)
+            step_size = step_size.clamp(alpha * eps / 10.0, alpha * eps).contiguous()
+            sp_old = sp_curr.clone()
+            select_rows_(x_adv, x_best, fl_redtopk)
+            select_rows_(grad, grad_best, fl_redtopk)
+            counter3 = 0
+    return x_best, acc, loss_best, x_best_adv
+
+
+def _apgd_l1_decr_eps(prov, x, y, eps, n_iter, loss_kind, y_target, noise):
+    """decr_eps_pgd (autopgd_base.py:531-555): radii 3 eps, 2 eps, eps over ceil(.3 n), ceil(.3 n), the rest."""
+    import math
+    epss = [3.0 * eps, 2.0 * eps, 1.0 * eps]
+    iters = [math.ceil(.3 * n_iter), math.ceil(.3 * n_iter), math.ceil(.4 * n_iter)]
+    iters[-1] = n_iter - sum(iters[:-1])
+    x_init = x + noise
+    x_init = x_init + l1_projection(x, x_init, float(epss[0]))      # (sic: the reference passes x_init, not x_init - x)
+    res = None
+    for e, nit in zip(epss, iters):
+        x_init = x_init + l1_projection(x, x_init - x, e)
+        res = _apgd_l1_single_run(prov, x, y, e, nit, loss_kind, y_target, x_init=x_init)
+        x_init = res[0]
+    return res
+
+
+def apgd_l1_perturb(model_fn, x, y, eps=12.0, n_iter=100, loss='ce', n_restarts=1, use_largereps=False, seed=None,
+                    sample_offset=None, draws=None, n_target_classes=0, _prov=None):
+    """APGDAttack.perturb with norm = 'L1' (autopgd_base.py:450-529) and, with n_target_classes > 0,
+    APGDAttack_targeted.perturb (:610-690).  draws(index, shape) -> the torch.randn of that restart / target class
+    (parity tests); default: counter-based normal draws."""
+    torch = _lib.require_gpu()
+    prov = _prov or _Provider(model_fn, normalize_inside=False)
+    x, y = _check_inputs(x, y)
+    sample_offset = _offset(sample_offset, x.shape[0])
+    adv = x.clone()
+    acc = prov.logits(x).max(1)[1] == y
+    targeted = n_target_classes > 0
+    rounds = range(2, n_target_classes + 2) if targeted else range(n_restarts)
+    kind = LOSS_DLR_TARGETED if targeted else {'ce': LOSS_CE, 'dlr': LOSS_DLR}[loss]
+    for j, r in enumerate(rounds):
+        ind = acc.nonzero().flatten()
+        if ind.numel() == 0:
+            continue
+        xs, ys = x[ind].contiguous(), y[ind].contiguous()
+        y_target = prov.logits(xs).sort(dim=1)[1][:, -r] if targeted else None
+        if draws is not None:
+            noise = draws(j, tuple(xs.shape)).to(xs.device, torch.float32).contiguous()
+        else:
+            noise = torch.empty_like(xs)
+            _lib.check(_lib.load().rart_rng_normal_f32(_lib.ptr(noise), xs.shape[0], xs[0].numel(), _seed(seed) + 7919 * j,
+                                                       sample_offset, 5, _lib.stream_ptr()))
+        if use_largereps:
+            _, acc_curr, _, adv_curr = _apgd_l1_decr_eps(prov, xs, ys, eps, n_iter, kind, y_target, noise)
+        else:
+            _, acc_curr, _, adv_curr = _apgd_l1_single_run(prov, xs, ys, eps, n_iter, kind, y_target, init_t=noise)
+        fooled = (~acc_curr).nonzero().flatten()
+        acc[ind[fooled]] = False
+        adv[ind[fooled]] = adv_curr[fooled]
+    return adv
+
+
 def _square_p_selection(it, p_init, n_queries, rescale):
     """square.py:192-219."""
     if rescale:
@@ -536,9 +673,6 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     oracle.attacks_ref.TorchStreamDraws replaying the reference's torch random stream instead of the counter-based RNG."""
     torch = _lib.require_gpu()
     assert norm in ['Linf', 'L2', 'L1']
-    if norm == 'L1':
-        raise NotImplementedError("AutoAttack norm='L1' runs APGD with the L1 projection only (apgd_l1_perturb); the L1 "
-                                  'variants of FAB-T / Square are not implemented and autoattack_linf never selects L1')
     x_orig, y_orig = _check_inputs(input, label)
     prov = _Provider(model, normalize_inside=True)
     ov = dict(_overrides or {})
@@ -556,6 +690,9 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     square_queries = int(ov.get('square_queries', 5000))
     draws = ov.get('draws')
     skipped = [a for a in plan if a in ('fab',)] + ([a for a in plan if a == 'fab-t'] if norm != 'Linf' else [])
+    if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes; FAB-T / Square L1: not built
+        skipped += [a for a in plan if a == 'square']
+        n_restarts, apgdt_classes = int(ov.get('apgd_restarts', 5)), int(ov.get('apgdt_classes', 5))
     if skipped:
         warnings.warn('autoattack_linf: %s not implemented on this build yet -- running %s only; robust accuracy '
                       'is an upper bound of the full ensemble' % (skipped, [a for a in plan if a not in skipped]),
@@ -577,7 +714,12 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
                 draws.reseed()                       # every perturb() of the reference re-seeds torch with self.seed
             ts = draws.pm1 if draws is not None else None
             sd = base_seed + 1000 * ai
-            if attack == 'apgd-ce':
+            if norm == 'L1' and attack in ('apgd-ce', 'apgd-dlr', 'apgd-t'):
+                adv_curr = apgd_l1_perturb(None, x, y, eps, apgdt_iter if attack == 'apgd-t' else apgd_iter,
+                                           'dlr' if attack == 'apgd-dlr' else 'ce', n_restarts, True, sd, first,
+                                           draws=(lambda j, shape: draws.randn(j, shape)) if draws is not None else None,
+                                           n_target_classes=apgdt_classes if attack == 'apgd-t' else 0, _prov=prov)
+            elif attack == 'apgd-ce':
                 adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'ce', n_restarts, sd, first, init_ts=ts, _prov=prov)
             elif attack == 'apgd-dlr':
                 adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'dlr', n_restarts, sd, first, init_ts=ts, _prov=prov)

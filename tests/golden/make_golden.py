@@ -154,10 +154,45 @@ def gen_autoattack():
     print('autoattack_ref.npz', len(out), 'entries')
 
 
+def gen_apgd_l1():
+    """L1_projection itself on random rows (some already inside the ball / box, some far outside) and APGDAttack with
+    norm='L1' (plain and with the larger-eps schedule of AutoAttack's L1 'standard' version) -> apgd_l1_ref.npz."""
+    from RobustART.noise.utils.adv.Attacks.autoattack.autopgd_base import L1_projection
+    out = {}
+    g = torch.Generator().manual_seed(8)
+    px = torch.rand(8, 3, 10, 10, generator=g)
+    py = torch.randn(8, 3, 10, 10, generator=g) * torch.tensor([0.001, 0.01, 0.05, 0.2, 0.5, 1.0, 2.0, 0.0]).view(8, 1, 1, 1)
+    py[6, :, :5] = 0
+    out['proj/x'], out['proj/y'] = px.numpy(), py.numpy()
+    for e in (0.5, 4.0, 12.0):
+        out[f'proj/delta/{e}'] = L1_projection(px, py, e).numpy()
+    net = make_tinynet()
+    model_fn = lambda z: net(normalize(z))  # noqa: E731
+    x = make_batch(n=6, seed=33)
+    y = model_fn(x).max(1)[1]
+    out['x'], out['y'] = x.numpy(), y.numpy()
+    for loss in ('ce', 'dlr'):
+        att = APGDAttack(model_fn, n_iter=25, norm='L1', n_restarts=1, eps=3.0, seed=0, loss=loss, device='cpu')
+        att.init_hyperparam(x)
+        torch.random.manual_seed(0)
+        xb, acc, lb, xba = att.attack_single_run(x.clone(), y.clone())
+        out[f'single/{loss}/x_best'], out[f'single/{loss}/acc'] = xb.detach().numpy(), acc.numpy()
+        out[f'single/{loss}/loss_best'], out[f'single/{loss}/x_best_adv'] = lb.detach().numpy(), xba.detach().numpy()
+        out[f'perturb/{loss}/adv'] = att.perturb(x.clone(), y.clone()).detach().numpy()
+    att = APGDAttack(model_fn, n_iter=20, norm='L1', n_restarts=2, eps=2.0, seed=0, loss='ce', device='cpu', use_largereps=True)
+    out['largereps/ce/adv'] = att.perturb(x.clone(), y.clone()).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, 'apgd_l1_ref.npz'), **out)
+    print('apgd_l1_ref.npz', len(out), 'entries; robust after the plain ce run:',
+          int((model_fn(torch.from_numpy(out['perturb/ce/adv'])).max(1)[1] == y).sum()), 'of', len(x))
+
+
 if __name__ == '__main__':
-    if 'autoattack' in sys.argv[1:]:
+    if 'apgd_l1' in sys.argv[1:]:
+        gen_apgd_l1()
+    elif 'autoattack' in sys.argv[1:]:
         gen_autoattack()
     else:
         gen_corruptions()
         gen_attacks()
         gen_autoattack()
+        gen_apgd_l1()

@@ -330,3 +330,79 @@ def test_autoattack_linf_orchestrator_matches_reference_golden(case):
     a = adv.autoattack_linf(x.cuda(), y.cuda(), netc, 'Linf', eps, 'standard', False,
                             _overrides=dict(apgd_iter=3, apgdt_iter=2, apgdt_classes=2, fab_iter=3, fab_classes=2, square_queries=20))
     assert (a.cpu() - x).abs().max() <= eps + 1e-6 and a.min() >= 0 and a.max() <= 1
+
+
+def test_l1_projection_and_kth_select_kernels():
+    """rart_l1_project (bisection + exact segment solve, no sort) vs the reference's sort-based L1_projection outputs
+    (tests/golden/apgd_l1_ref.npz, autopgd_base.py:19-83); at ImageNet row size against the oracle and the two
+    constraints; rart_row_kth_abs (radix select) exactly equal to sort()[k]; rart_row_count_diff."""
+    from robustart_amd import _lib
+    from robustart_amd.noise import adv
+    gl = np.load(os.path.join(GOLD, 'apgd_l1_ref.npz'))
+    x, y = torch.from_numpy(gl['proj/x']).cuda(), torch.from_numpy(gl['proj/y']).cuda()
+    for e in (0.5, 4.0, 12.0):
+        d = adv.l1_projection(x, y, e)
+        torch.testing.assert_close(d.cpu(), torch.from_numpy(gl[f'proj/delta/{e}']), atol=2e-6, rtol=1e-5)
+    g = torch.Generator().manual_seed(12)
+    n = 3 * 224 * 224
+    xb = torch.rand(3, n, generator=g)
+    yb = torch.randn(3, n, generator=g) * torch.tensor([0.002, 0.05, 0.5]).view(3, 1)
+    for e in (12.0, 60.0):
+        want = A.l1_projection(xb, yb, e)
+        got = adv.l1_projection(xb.cuda(), yb.cuda(), e).cpu()
+        # the reference's own fp32 cumsum over 300k sorted breakpoints carries ~1e-5 relative error in alpha (the kernel
+        # sums in fp64); the budget check below shows which side is exact
+        assert (got - want).abs().max() <= 1e-4, (got - want).abs().max()
+        spent = (yb.double() + got.double()).abs().sum(1)
+        active = yb.abs().sum(1) > e                      # rows that had to be projected land ON the sphere
+        assert ((spent[active] - e).abs() <= e * 2e-6).all(), spent
+        z = xb + yb + got
+        assert z.min() >= -1e-6 and z.max() <= 1 + 1e-6
+        assert ((yb + got).abs().sum(1) <= e * (1 + 1e-5) + 1e-4).all()
+    pt = adv.l1_projection(xb.cuda(), yb.cuda(), 12.0, point_out=True, clamp01=True).cpu()
+    # (x + y) + delta is rounded at ulp(x) ~ 6e-8 per element: 150k residues of coordinates projected to zero add up
+    assert pt.min() >= 0 and pt.max() <= 1 and ((pt.double() - xb.double()).abs().sum(1) <= 12.0 * (1 + 1e-3)).all()
+    # exact k-th smallest |g|
+    lib = _lib.load()
+    gr = torch.randn(5, n, generator=g)
+    gr[1, ::3] = 0.0
+    gr[2] = gr[2].round()                                         # many ties
+    ks = torch.tensor([0, n - 1, 12345, int(0.8 * n), 77], dtype=torch.int64)
+    thr = torch.empty(5, device='cuda')
+    grc, ksc = gr.cuda(), ks.cuda()
+    _lib.check(lib.rart_row_kth_abs(_lib.ptr(grc), _lib.ptr(ksc), _lib.ptr(thr), 5, n, _lib.stream_ptr()))
+    want = gr.abs().sort(-1)[0][torch.arange(5), ks]
+    assert torch.equal(thr.cpu(), want)
+    cnt = torch.empty(5, device='cuda')
+    _lib.check(lib.rart_row_count_diff(_lib.ptr(grc), _lib.ptr(torch.zeros_like(grc)), _lib.ptr(cnt), 5, n, _lib.stream_ptr()))
+    assert torch.equal(cnt.cpu(), (gr != 0).sum(1).float())
+
+
+def test_apgd_l1_matches_reference_golden():
+    """APGD with the L1 threat model on the HIP kernels vs the reference's APGDAttack(norm='L1') outputs on the tiny CNN
+    (tests/golden/apgd_l1_ref.npz): plain runs with both losses, and the larger-eps schedule with two restarts that
+    AutoAttack's L1 'standard' version uses; the reference's torch.randn stream is replayed through `draws`."""
+    from robustart_amd.noise import adv
+    g, netc, f_gpu = _f_gpu_and_gold()
+    gl = np.load(os.path.join(GOLD, 'apgd_l1_ref.npz'))
+    x, y = torch.from_numpy(gl['x']), torch.from_numpy(gl['y'])
+    for loss in ('ce', 'dlr'):
+        torch.random.manual_seed(0)
+        got = adv.apgd_l1_perturb(f_gpu, x.cuda(), y.cuda(), 3.0, 25, loss, draws=lambda j, shape: torch.randn(shape)).cpu()
+        want = torch.from_numpy(gl[f'perturb/{loss}/adv'])
+        print('apgd-l1 %s: max |diff| %.3g' % (loss, (got - want).abs().max().item()))
+        torch.testing.assert_close(got, want, atol=1e-4, rtol=0)
+        assert ((got - x).abs().flatten(1).sum(1) <= 3.0 * (1 + 1e-4)).all() and got.min() >= 0 and got.max() <= 1
+    torch.random.manual_seed(0)
+    got = adv.apgd_l1_perturb(f_gpu, x.cuda(), y.cuda(), 2.0, 20, 'ce', n_restarts=2, use_largereps=True,
+                              draws=lambda j, shape: torch.randn(shape)).cpu()
+    torch.testing.assert_close(got, torch.from_numpy(gl['largereps/ce/adv']), atol=1e-4, rtol=0)
+    # native draws at a larger size: L1 ball, box, reproducible with pinned offsets
+    xl = _rand((3, 3, 64, 64), 2).cuda()
+    yl = torch.zeros(3, dtype=torch.int64).cuda()
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 5, stride=4), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1),
+                              torch.nn.Flatten(), torch.nn.Linear(8, 10)).cuda().eval()
+    a = adv.apgd_l1_perturb(net, xl, yl, 8.0, 10, 'ce', seed=2, sample_offset=0)
+    b = adv.apgd_l1_perturb(net, xl, yl, 8.0, 10, 'ce', seed=2, sample_offset=0)
+    assert torch.equal(a, b)
+    assert ((a - xl).abs().flatten(1).sum(1) <= 8.0 * (1 + 1e-4)).all() and a.min() >= 0 and a.max() <= 1

@@ -260,3 +260,47 @@ def test_autoattack_orchestrator_matches_reference(gold_a, gold_aa, case):
     for k in plan:
         one = A.autoattack_linf(model_fn, x, y, eps, A.TorchStreamDraws(0), plan=(k,), **kw)
         np.testing.assert_allclose(one.numpy(), gold_aa[f'{case}/individual/{k}'], atol=1e-6)
+
+
+@pytest.fixture(scope='module')
+def gold_l1():
+    return np.load(os.path.join(GOLD, 'apgd_l1_ref.npz'))
+
+
+def test_l1_projection_matches_reference(gold_l1):
+    """oracle l1_projection vs the reference's L1_projection (autopgd_base.py:19-83) on rows inside / outside the ball and
+    the box; the result always satisfies both constraints."""
+    x, y = torch.from_numpy(gold_l1['proj/x']), torch.from_numpy(gold_l1['proj/y'])
+    for e in (0.5, 4.0, 12.0):
+        d = A.l1_projection(x, y, e)
+        np.testing.assert_allclose(d.numpy(), gold_l1[f'proj/delta/{e}'], atol=1e-6)
+        z = x + y + d
+        assert z.min() >= -1e-6 and z.max() <= 1 + 1e-6
+        assert ((y + d).abs().flatten(1).sum(1) <= e * (1 + 1e-5) + 1e-5).all()
+
+
+@pytest.mark.parametrize('loss', ['ce', 'dlr'])
+def test_apgd_l1_matches_reference(gold_a, gold_l1, loss):
+    net, model_fn = _model(gold_a)
+    x, y = torch.from_numpy(gold_l1['x']), torch.from_numpy(gold_l1['y'])
+    torch.random.manual_seed(0)
+    t = torch.randn(x.shape)
+    xb, acc, lb, xba = A.apgd_l1_single_run(model_fn, x, y, 3.0, 25, loss, init_t=t)
+    np.testing.assert_allclose(xb.numpy(), gold_l1[f'single/{loss}/x_best'], atol=2e-6)
+    np.testing.assert_allclose(xba.numpy(), gold_l1[f'single/{loss}/x_best_adv'], atol=2e-6)
+    np.testing.assert_allclose(lb.numpy(), gold_l1[f'single/{loss}/loss_best'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(acc.numpy(), gold_l1[f'single/{loss}/acc'])
+    torch.random.manual_seed(0)
+    adv = A.apgd_l1_perturb(model_fn, x, y, 3.0, 25, loss, lambda c, shape: torch.randn(shape))
+    np.testing.assert_allclose(adv.numpy(), gold_l1[f'perturb/{loss}/adv'], atol=2e-6)
+    assert ((adv - x).abs().flatten(1).sum(1) <= 3.0 * (1 + 1e-5)).all() and adv.min() >= 0 and adv.max() <= 1
+
+
+def test_apgd_l1_largereps_matches_reference(gold_a, gold_l1):
+    """The larger-eps schedule AutoAttack's L1 'standard' version switches on (autoattack.py:258-262; decr_eps_pgd,
+    autopgd_base.py:531-555), two restarts."""
+    net, model_fn = _model(gold_a)
+    x, y = torch.from_numpy(gold_l1['x']), torch.from_numpy(gold_l1['y'])
+    torch.random.manual_seed(0)
+    adv = A.apgd_l1_perturb(model_fn, x, y, 2.0, 20, 'ce', lambda c, shape: torch.randn(shape), n_restarts=2, use_largereps=True)
+    np.testing.assert_allclose(adv.numpy(), gold_l1['largereps/ce/adv'], atol=2e-6)
