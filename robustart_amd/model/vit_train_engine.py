@@ -151,12 +151,15 @@ class ViTTrainEngine(ViTEngine):
             self._gemm(dqkv, L['qkv_wd'], dln, rows, 3 * D, D, 3 * D, D)
             self._ln_bwd(dln, x_in, L['n1g'], dxm, dx, rows, (D, D, D, D), blk.norm1)
         # ---- embeddings: x0[b][0] = cls + pos[0]; x0[b][1+p] = patch_embed(patch p) + pos[1+p]
+        # derive every gradient that READS pos_embed.grad before the first on_grad_ready: with a small dist.bucket_mb the
+        # {cls_token, pos_embed} bucket would otherwise start its asynchronous all-reduce (in place, on the RCCL stream)
+        # while patch_embed.bias.grad is still being computed from it, and the bias would be summed across ranks twice
         pos_g = m.pos_embed.grad.view(T * D)
         self._colsum(dx, T * D, B, T * D, pos_g)
-        self.on_grad_ready(m.pos_embed)
         m.cls_token.grad.view(D).copy_(pos_g[:D])
-        self.on_grad_ready(m.cls_token)
         m.patch_embed.bias.grad.copy_(m.pos_embed.grad.view(T, D)[1:].sum(0))
+        self.on_grad_ready(m.pos_embed)
+        self.on_grad_ready(m.cls_token)
         self.on_grad_ready(m.patch_embed.bias)
         kk = 3 * self.ps * self.ps
         patches_hi = self._buf['patches'][0]

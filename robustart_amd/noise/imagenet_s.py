@@ -103,7 +103,9 @@ def image_transfer(image, decoder_type='pil', resize_type='pil-bilinear', transf
         dev = torch.from_numpy(np.ascontiguousarray(arr)[None]).cuda()
         return op(dev, first, f, crop=(i, j, th, tw))[0].cpu().numpy()
     if transform_type == 'train':
-        y, x, h, w = _train_params(arr.shape[:2], random.Random(seed))
+        # seed None: the GLOBAL random module, like the reference's get_params (imagenet_s_gen.py:222-246), so a user's
+        # random.seed(...) makes AddNoise('imagenet-s') reproducible; an explicit seed gets its own generator
+        y, x, h, w = _train_params(arr.shape[:2], random if seed is None else random.Random(seed))
         dev = torch.from_numpy(np.ascontiguousarray(arr[y:y + h, x:x + w])[None]).cuda()
         return op(dev, size, f)[0].cpu().numpy()
     raise NotImplementedError(transform_type)
