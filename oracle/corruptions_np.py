@@ -816,16 +816,149 @@ def elastic_transform(x, severity, draws):
     return np.clip(ndi.map_coordinates(image, indices, order=1, mode='reflect').reshape(shape), 0, 1) * 255
 
 
+# ---- OpenCV pieces of spatter's water branch, restated (PARITY UNPINNED: cv2 is absent from this image and the
+#      reference has no fixture for them; the restatements follow OpenCV 4.5's imgproc sources as recalled in SURVEY.md
+#      Appendix B -- canny.cpp, distransform.cpp, thresh.cpp, box_filter, histogram.cpp, filter.dispatch.cpp).  Every
+#      stage is integer / fixed-point arithmetic, so the HIP kernels reproduce this file bit for bit.
+
+def _reflect101_pad(a, r):
+    return np.pad(a, r, mode='reflect')
+
+
+def cv_canny_u8(img, low, high):
+    """cv2.Canny(img, low, high): aperture 3, L1 gradient magnitude, BORDER_REPLICATE Sobel, non-maximum suppression with
+    the TG22 fixed-point sector test, hysteresis over 8-neighbours.  Returns 0 / 255."""
+    p = np.pad(img.astype(np.int32), 1, mode='edge')
+    dx = (p[:-2, 2:] + 2 * p[1:-1, 2:] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[1:-1, :-2] + p[2:, :-2])
+    dy = (p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])
+    mag = np.abs(dx) + np.abs(dy)
+    mp = np.pad(mag, 1, mode='constant')                 # zero border rows / columns (canny.cpp mag_buf)
+    m = mag
+    left, right = mp[1:-1, :-2], mp[1:-1, 2:]
+    up, down = mp[:-2, 1:-1], mp[2:, 1:-1]
+    ax, ay = np.abs(dx).astype(np.int64), np.abs(dy).astype(np.int64) << 15
+    tg22x = ax * 13573                                   # TG22 = (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
+    tg67x = tg22x + (ax << 16)
+    horiz = ay < tg22x
+    vert = (~horiz) & (ay > tg67x)
+    diag = ~(horiz | vert)
+    s_neg = (dx < 0) != (dy < 0)                         # (xs ^ ys) < 0  ->  s = -1
+    # s = 1: compare with (i-1, j-1) and (i+1, j+1);  s = -1: with (i-1, j+1) and (i+1, j-1)
+    ul, dr = mp[:-2, :-2], mp[2:, 2:]
+    ur, dl = mp[:-2, 2:], mp[2:, :-2]
+    c_h = (m > left) & (m >= right)
+    c_v = (m > up) & (m >= down)
+    c_d = np.where(s_neg, (m > ur) & (m > dl), (m > ul) & (m > dr))
+    local_max = (horiz & c_h) | (vert & c_v) | (diag & c_d)
+    cand = (m > low) & local_max
+    strong = cand & (m > high)
+    # hysteresis: candidates 8-connected to a strong pixel
+    import scipy.ndimage as ndi
+    grown = ndi.binary_propagation(strong, structure=np.ones((3, 3), bool), mask=cand)
+    return np.where(grown, 255, 0).astype(np.uint8)
+
+
+CV_DIST_A, CV_DIST_B, CV_DIST_C = 65536, 91750, 143976      # cvRound({1, 1.4, 2.1969} * 2^16): DIST_L2, 5x5 mask
+CV_DIST_INIT = (2 ** 31 - 1) >> 2
+
+
+def cv_distance_transform_l2_5(src):
+    """cv2.distanceTransform(src, cv2.DIST_L2, 5): two-pass 5x5 chamfer distance to the nearest zero pixel in 16.16 fixed
+    point (distransform.cpp distanceTransform_5x5).  Returns the int64 fixed-point plane (float result = plane / 65536)."""
+    h, w = src.shape
+    a, b, c = CV_DIST_A, CV_DIST_B, CV_DIST_C
+    T = np.full((h + 4, w + 4), CV_DIST_INIT, dtype=np.int64)
+    jj = np.arange(w, dtype=np.int64)
+    for i in range(h):                                   # forward
+        r1, r2 = T[i + 1], T[i]                          # rows i-1, i-2 (padded by 2)
+        cand = np.minimum.reduce([r2[1:w + 1] + c, r2[3:w + 3] + c, r1[0:w] + c, r1[1:w + 1] + b, r1[2:w + 2] + a,
+                                  r1[3:w + 3] + b, r1[4:w + 4] + c])
+        cand = np.where(src[i] == 0, 0, cand)
+        cand[0] = min(cand[0], T[i + 2, 1] + a) if src[i, 0] != 0 else 0        # left border neighbour (INIT)
+        # tmp[j] = min(cand[j], tmp[j-1] + a)  ==  a*j + running min of (cand[k] - a*k)
+        T[i + 2, 2:w + 2] = a * jj + np.minimum.accumulate(cand - a * jj)
+    for i in range(h - 1, -1, -1):                       # backward
+        r1, r2 = T[i + 3], T[i + 4]                      # rows i+1, i+2
+        cur = T[i + 2, 2:w + 2]
+        cand = np.minimum.reduce([cur, r2[3:w + 3] + c, r2[1:w + 1] + c, r1[4:w + 4] + c, r1[3:w + 3] + b, r1[2:w + 2] + a,
+                                  r1[1:w + 1] + b, r1[0:w] + c])
+        rev = cand[::-1]
+        T[i + 2, 2:w + 2] = (a * jj + np.minimum.accumulate(rev - a * jj))[::-1]
+    return np.minimum(T[2:h + 2, 2:w + 2], CV_DIST_INIT)
+
+
+def cv_blur3_f32_to_u8_fixed(fixed):
+    """cv2.blur(float32 plane, (3, 3)).astype(np.uint8) on values that are multiples of 2^-16 below 21: the 9-term sums are
+    exact in float32, the result is float32(sum * (1/9)) truncated."""
+    p = _reflect101_pad(fixed.astype(np.int64), 1)
+    s9 = sum(p[dy:dy + fixed.shape[0], dx:dx + fixed.shape[1]] for dy in range(3) for dx in range(3))
+    val = ((s9.astype(np.float64) / 65536.0) * (1.0 / 9.0)).astype(np.float32)
+    return val.astype(np.uint8)
+
+
+def cv_equalize_hist_u8(img):
+    """cv2.equalizeHist (histogram.cpp): lut[i] = saturate(cvRound(cumsum_after_first_bin * 255.f / (total - hist[first])))."""
+    hist = np.bincount(img.ravel(), minlength=256)
+    i0 = int(np.nonzero(hist)[0][0])
+    total = img.size
+    if hist[i0] == total:
+        return np.full_like(img, i0)
+    scale = np.float32(255.0) / np.float32(total - hist[i0])
+    lut = np.zeros(256, dtype=np.uint8)
+    acc = 0
+    for i in range(i0 + 1, 256):
+        acc += int(hist[i])
+        lut[i] = np.uint8(min(255, max(0, int(np.rint(np.float32(acc) * scale)))))
+    return lut[img]
+
+
+def cv_filter2d_u8_int3(img, ker):
+    """cv2.filter2D(u8, cv2.CV_8U, 3x3 integer kernel): correlation, BORDER_REFLECT_101, saturated."""
+    p = _reflect101_pad(img.astype(np.int64), 1)
+    h, w = img.shape
+    acc = sum(int(ker[dy][dx]) * p[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3))
+    return np.clip(acc, 0, 255).astype(np.uint8)
+
+
+def cv_blur3_u8(img):
+    """cv2.blur(u8, (3, 3)): round(sum / 9) (9 is odd: no ties)."""
+    p = _reflect101_pad(img.astype(np.int64), 1)
+    h, w = img.shape
+    s9 = sum(p[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3))
+    return ((2 * s9 + 9) // 18).astype(np.uint8)
+
+
+def spatter_water_stages(liquid, c):
+    """The integer pipeline of corruptions.py:305-318 on the thresholded liquid layer; returns (liquid_u8, dist_u8_final)."""
+    liquid_u8 = (liquid * 255).astype(np.uint8)
+    dist = 255 - cv_canny_u8(liquid_u8, 50, 150)
+    fixed = np.minimum(cv_distance_transform_l2_5(dist), 20 * 65536)          # threshold(dist, 20, 20, THRESH_TRUNC)
+    d = cv_blur3_f32_to_u8_fixed(fixed)
+    d = cv_equalize_hist_u8(d)
+    d = cv_filter2d_u8_int3(d, [[-2, -1, 0], [-1, 1, 1], [0, 1, 2]])
+    d = cv_blur3_u8(d)
+    return liquid_u8, d
+
+
 def spatter(x, severity, draws):
-    """corruptions.py:293-342.  Only the 'mud' branch (severity 4-5, c[5]==1) is restated; the
-    'water' branch (severity 1-3) needs cv2.Canny/distanceTransform/equalizeHist and is a
-    documented gap."""
+    """corruptions.py:293-342.  Mud branch (severity 4-5): scipy / numpy only.  Water branch (severity 1-3): the OpenCV
+    stages above -- PARITY UNPINNED."""
     c = PARAMS['spatter'][severity - 1]
-    if c[5] == 0:
-        raise NotImplementedError("spatter severity 1-3 (water branch) is not restated")
     x = np.array(x, dtype=np.float32) / 255.
     liquid = sk_gaussian(draws['layer'], sigma=c[2])
     liquid[liquid < c[3]] = 0
+    if c[5] == 0:
+        liquid_u8, d = spatter_water_stages(liquid, c)
+        m = liquid_u8 * d.astype(np.float32)                                  # uint8 * float32 -> float32, exact
+        m = np.repeat(m[..., None], 4, axis=2)                                # cvtColor GRAY2BGRA (alpha of a float image: 1)
+        m[..., 3] = 1.0
+        m /= np.max(m, axis=(0, 1))
+        m *= c[4]
+        color = np.concatenate((175 / 255. * np.ones_like(m[..., :1]), 238 / 255. * np.ones_like(m[..., :1]),
+                                238 / 255. * np.ones_like(m[..., :1])), axis=2)
+        color = np.concatenate((color, np.ones_like(color[..., :1])), axis=2)  # BGR2BGRA
+        xa = np.concatenate((x, np.ones_like(x[..., :1])), axis=2)
+        return np.clip(xa + m * color, 0, 1)[..., :3] * 255                    # BGRA2BGR
     m = np.where(liquid > c[3], 1, 0)
     m = sk_gaussian(m.astype(np.float32), sigma=c[4])
     m[m < 0.8] = 0

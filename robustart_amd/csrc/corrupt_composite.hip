@@ -11,6 +11,8 @@ int rart_motion_blur_gray(const uint8_t* in, uint8_t* out, int n, int h, int w, 
                           const double* angles_dev, double lo, double hi, uint64_t seed, uint64_t sample_offset,
                           void* tab_ws, hipStream_t s);
 size_t rart_motion_tab_bytes(int n);
+int rart_launch_spatter_water(const uint8_t* in, uint8_t* out, const double* liquid, int n, double thresh, double c4,
+                              uint8_t* scratch_u8, int* scratch_i32, hipStream_t st);
 
 #pragma clang fp contract(off)
 
@@ -564,11 +566,6 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
     }
     case RART_SPATTER: {
       const double* c = kSpatter[s];
-      if (c[5] == 0) {
-        rart_set_error("spatter severity %d (water branch: cv2.Canny / distanceTransform / equalizeHist) is not "
-                       "implemented; severities 4-5 (mud) are", a.severity);
-        return RART_ERR_UNSUPPORTED;
-      }
       double* layer = (double*)ws;
       ws += field;
       double* tmpd = (double*)ws;
@@ -581,8 +578,10 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
       ws += A256(64 * sizeof(double));
       double* w2dev = (double*)ws;
       int r1, r2;
-      const std::vector<double>& wt1 = cached_weights(8 + (s - 3) * 2, c[2], 4.0, &r1);
-      const std::vector<double>& wt2 = cached_weights(9 + (s - 3) * 2, c[4], 4.0, &r2);
+      const bool water = c[5] == 0;
+      const std::vector<double>& wt1 = cached_weights(water ? 12 + s : 8 + (s - 3) * 2, c[2], 4.0, &r1);
+      const std::vector<double>& wt2 = water ? wt1 : cached_weights(9 + (s - 3) * 2, c[4], 4.0, &r2);
+      if (water) r2 = r1;
       if (hipMemcpyAsync(w1dev, wt1.data(), wt1.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
           hipMemcpyAsync(w2dev, wt2.data(), wt2.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
         rart_set_error("spatter: weight upload failed");
@@ -600,6 +599,12 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
                          (const double*)w1dev, r1, 1.0);
       hipLaunchKernelGGL((k_field_gauss<1, false, double, double>), dim3(g), dim3(kBlock), 0, st, (const double*)tmpd,
                          layer, a.n, HW, HW, (const double*)w1dev, r1, 1.0);
+      if (water) {
+        // severities 1-3: the Canny / distance-transform / equalizeHist pipeline (corrupt_spatter.hip); tmpd and m0 are free
+        const int rc = rart_launch_spatter_water(a.in, a.out, (const double*)layer, a.n, c[3], c[4], (uint8_t*)m0, (int*)tmpd, st);
+        if (rc != RART_OK) return rc;
+        break;
+      }
       hipLaunchKernelGGL(k_spatter_mask, dim3(g), dim3(kBlock), 0, st, (const double*)layer, m0, c[3],
                          (size_t)a.n * HW * HW);
       // gaussian(m.astype(float32), sigma=c4): float32 in/out, the axis-0 result is stored as float32

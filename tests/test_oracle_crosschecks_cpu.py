@@ -59,3 +59,49 @@ def test_art_l1_scaling_projection_stays_in_the_ball_but_is_not_the_exact_projec
                       np.array([0.1, 0.5, 1.0], dtype=np.float32))
     d = x1 - x0
     assert (np.abs(d).sum(1) <= 2.0 * (1 + 1e-5)).all() and x1.min() >= 0 and x1.max() <= 1
+
+
+def test_spatter_water_stages_restatements():
+    """OpenCV stages of spatter's water branch (unpinned: cv2 absent): the scan formulation of the 5x5 chamfer distance
+    equals the literal two-pass raster loops of distransform.cpp; the chamfer distance tracks scipy's exact Euclidean
+    transform within the mask's known ~2 % error; Canny of a filled square is its closed one-pixel outline; equalizeHist
+    maps the extreme populated bins to 0 / 255; the whole branch runs for severities 1-3."""
+    import scipy.ndimage as ndi
+    rs = np.random.RandomState(5)
+
+    def dt_loops(src):
+        h, w = src.shape
+        a, b, c = O.CV_DIST_A, O.CV_DIST_B, O.CV_DIST_C
+        T = np.full((h + 4, w + 4), O.CV_DIST_INIT, dtype=np.int64)
+        for i in range(h):
+            for j in range(w):
+                I, J = i + 2, j + 2
+                T[I, J] = 0 if src[i, j] == 0 else min(T[I - 2, J - 1] + c, T[I - 2, J + 1] + c, T[I - 1, J - 2] + c,
+                                                      T[I - 1, J - 1] + b, T[I - 1, J] + a, T[I - 1, J + 1] + b,
+                                                      T[I - 1, J + 2] + c, T[I, J - 1] + a)
+        for i in range(h - 1, -1, -1):
+            for j in range(w - 1, -1, -1):
+                I, J = i + 2, j + 2
+                if T[I, J] > a:
+                    T[I, J] = min(T[I, J], T[I + 2, J + 1] + c, T[I + 2, J - 1] + c, T[I + 1, J + 2] + c, T[I + 1, J + 1] + b,
+                                  T[I + 1, J] + a, T[I + 1, J - 1] + b, T[I + 1, J - 2] + c, T[I, J + 1] + a)
+        return np.minimum(T[2:h + 2, 2:w + 2], O.CV_DIST_INIT)
+    src = (rs.rand(48, 41) > 0.02).astype(np.uint8) * 255
+    fixed = O.cv_distance_transform_l2_5(src)
+    assert np.array_equal(fixed, dt_loops(src))
+    edt = ndi.distance_transform_edt(src)
+    cham = fixed / 65536.0
+    assert (np.abs(cham - edt) <= 0.03 * edt + 1e-9).all()
+    img = np.zeros((40, 40), np.uint8)
+    img[10:30, 12:28] = 200
+    e = O.cv_canny_u8(img, 50, 150)
+    ys, xs = np.nonzero(e)
+    assert e.max() == 255 and ys.min() in (9, 10) and ys.max() in (29, 30) and (e[15:25, 16:24] == 0).all()
+    assert ndi.label(e, structure=np.ones((3, 3)))[1] == 1              # one closed contour
+    q = rs.randint(3, 9, (30, 30)).astype(np.uint8)
+    eq = O.cv_equalize_hist_u8(q)
+    assert eq[q == q.min()].max() == 0 and eq[q == q.max()].min() == 255
+    x = rs.randint(0, 256, (224, 224, 3)).astype(np.uint8)
+    for sev in (1, 2, 3):
+        y = O.corrupt('spatter', x, sev, O.draw('spatter', x, sev, np.random.RandomState(sev)))
+        assert y.dtype == np.uint8 and 0.005 < (y != x).mean() < 0.5
