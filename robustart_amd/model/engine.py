@@ -254,15 +254,27 @@ class ResNet50Engine:
             _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
             e1.record()
             flops = 2.0 * batch * grid[0] * grid[1] * k_per_tap * len(taps) * n_cols
-            self.profile.append((flops, e0, e1))
+            self.profile.append((flops, e0, e1, 'igemm'))
             return
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
     def _halo_ok(self, c, hw):
-        return (self.halo_conv3x3 and self.profile is None and c.r == 3 and c.s == 3 and c.stride == 1 and c.pad == 1
+        return (self.halo_conv3x3 and c.r == 3 and c.s == 3 and c.stride == 1 and c.pad == 1
                 and c.cin == c.cout and self.lib.rart_conv3x3_halo_supported(c.cin, hw[0], hw[1]))
 
     def _halo(self, src, w, dst, B, hw, ch, taps, bias=None, mask=None, sign=None, relu=False):
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            prof, self.profile = self.profile, None
+            try:
+                self._halo(src, w, dst, B, hw, ch, taps, bias=bias, mask=mask, sign=sign, relu=relu)
+            finally:
+                self.profile = prof
+            e1.record()
+            self.profile.append((2.0 * B * hw[0] * hw[1] * 9 * ch * ch, e0, e1, 'halo3x3'))
+            return
         _lib.check(self.lib.rart_conv3x3_halo_bf16(_lib.ptr(src), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(mask), _lib.ptr(sign),
                                                    _lib.ptr(dst), B, hw[0], hw[1], ch, _cints([t[0] for t in taps]),
                                                    _cints([t[1] for t in taps]), 1 if relu else 0, _lib.stream_ptr()))

@@ -31,13 +31,23 @@ def wrapped(src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols
     e0.record(); r = orig(src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, **kw); e1.record()
     rows.append(((M, K, n_cols, len(taps)), fl, by, e0, e1))
     return r
+orig_halo = eng._halo
+def wrapped_halo(src, w, dst, B_, hw, ch, taps, **kw):
+    M = B_ * hw[0] * hw[1]
+    by = 2 * M * ch * 2 + 9 * ch * ch * 2 + (M * ch * 0.125 if (kw.get('mask') is not None or kw.get('sign') is not None) else 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r = orig_halo(src, w, dst, B_, hw, ch, taps, **kw); e1.record()
+    rows.append(((M, 9 * ch, ch, 99), 2.0 * M * 9 * ch * ch, by, e0, e1))      # taps column 99 = k_conv3x3_halo
+    return r
 for _ in range(2): eng.forward_backward(x, MEAN, STD, y, 0)
 eng._gemm = wrapped
+eng._halo = wrapped_halo
 eng.forward_backward(x, MEAN, STD, y, 0)
 rows.clear()
 eng.forward_backward(x, MEAN, STD, y, 0)
 torch.cuda.synchronize()
 eng._gemm = orig
+eng._halo = orig_halo
 agg = {}
 for key, fl, by, a, b in rows:
     us = a.elapsed_time(b) * 1e3
@@ -48,7 +58,8 @@ for key, (us, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     floor = max(fl / PEAK_F, by / PEAK_B) * 1e6
     tot += us; totf += floor
     print('%9d %6d %6d %4d %4d %9.1f %8.1f %8.1f %9.1f %6.3f' % (*key, cnt, us, fl / us / 1e6, by / us / 1e3, floor, floor / us))
-print('igemm launches %d: measured %.1f us, roofline floor %.1f us, fraction of the per-layer floor %.3f' %
+print('(taps 99 = the LDS-resident 3x3 kernel k_conv3x3_halo)')
+print('conv launches %d: measured %.1f us, roofline floor %.1f us, fraction of the per-layer floor %.3f' %
       (len(rows), tot, totf, totf / tot))
 for name, fn in (('fwd+bwd', lambda: eng.forward_backward(x, MEAN, STD, y, 0)), ('fwd', lambda: eng.logits(x, MEAN, STD))):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
