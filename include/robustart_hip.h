@@ -339,6 +339,14 @@ int rart_engine_stem_col2im(const void* patches, float* grad, int n, int h, int 
  * (autograd of attack.py:21-22 / autopgd_base.py:271-289 through conv1-bn1-relu-maxpool) */
 int rart_engine_stem_bwd_fused(const void* dpool, const void* argmax, const void* wtab, float* grad, int n, int h, int w,
                                const float* std_host, rart_stream_t stream);
+/* The stem FORWARD as one persistent kernel: normalisation + hi/lo bf16 split (rart_engine_prep_input), 7x7/2 convolution
+ * with the folded BatchNorm bias + ReLU (the K = 448 row-tap GEMM) and the 3x3/2 max pool (rart_engine_maxpool_keep) fused;
+ * the 112 x 112 x 64 stem output never reaches HBM.  wgt: bf16 [64][wgt_row_stride], row n, column r*32 + s*4 + c =
+ * W[n][c][r][s] (s = 7 and c = 3 zero) -- the hi half of the stem table; outputs as rart_engine_maxpool_keep
+ * (p1 bf16 [n][h/4][w/4][64], argmax codes and sign bits nullable).  h, w multiples of 4. */
+int rart_engine_stem_fwd_fused(const void* src, int src_is_u8, const void* wgt, int wgt_row_stride, const float* bias,
+                               void* p1, void* argmax_out, void* sign_out, int n, int h, int w, const float* mean_host,
+                               const float* std_host, rart_stream_t stream);
 /* fp32 [rows][cols] -> bf16 [rows][dst_cols] (zero padded): dlogits -> GEMM operand. */
 int rart_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int dst_cols, rart_stream_t stream);
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     'rart_engine_avgpool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_engine_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_engine_stem_col2im': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'rart_engine_stem_fwd_fused': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                           c_int, c_void_p, c_void_p, c_void_p]),
     'rart_engine_stem_bwd_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_f32_to_bf16_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_vit_patchify': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

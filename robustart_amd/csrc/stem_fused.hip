@@ -175,3 +175,196 @@ extern "C" int rart_engine_stem_bwd_fused(const void* dpool, const void* argmax,
   RART_CHECK_LAUNCH("rart_engine_stem_bwd_fused");
   return RART_OK;
 }
+
+// =====================================================================================================================
+// Fused stem FORWARD: input normalisation (hi + lo bf16 split) + 7x7/2 convolution + folded BatchNorm bias + ReLU + 3x3/2
+// max pool in ONE persistent kernel.  Replaces k_prep_input -> implicit GEMM (K = 448) -> k_maxpool_fwd, which wrote and
+// re-read the padded hi/lo image (110 MB) and the 112 x 112 x 64 stem output (411 MB) per 256-image forward; here the stem
+// output never leaves the chip (the backward needs only the pool's argmax codes, code 15 = dead ReLU, and 1-bit signs).
+//
+// A workgroup loops over 8 x 8 tiles of POOLED positions.  Per tile: the 39 x 39 input patch behind the 17 x 17 stem
+// outputs the tile's windows touch is staged in LDS as two [39][40 px][4 ch] bf16 planes (hi, lo; zeros outside the
+// image); the convolution is the same row-tap implicit GEMM as before (a tap = one filter row of 8 px x 4 ch, hi taps then
+// lo taps, same K order => same fp32 sums), with M = the 289 stem positions of the tile, read straight from the patch --
+// every fragment address is patch base + an immediate -- and the 64 x 224 weight matrix resident in LDS for the whole
+// launch; operands are swapped so a lane owns 4 consecutive channels of one position and the ReLU'd bf16 tile goes to LDS
+// with 8-byte writes; the pool reads 16-byte channel groups from it and writes p1, the argmax codes and the sign bits.
+// =====================================================================================================================
+namespace {
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int SF_PT = 8;                        // pooled tile side
+constexpr int SF_R = 2 * SF_PT + 1;             // stem-output region side (17)
+constexpr int SF_NPOS = SF_R * SF_R;            // 289
+constexpr int SF_PH = 2 * (SF_R - 1) + 7;       // patch rows (39)
+constexpr int SF_PW = 40;                       // patch row stride in pixels (39 used + 1: a K slice reads 8 px from 2*16)
+constexpr int SF_PLANE = SF_PH * SF_PW * 8;     // bytes per hi / lo plane (12 480)
+constexpr int SF_WROW = 464;                    // weight row stride in LDS (224 k x 2 B + 16 pad: conflict-free b128 reads)
+constexpr int SF_YROW = 144;                    // stem-output tile row stride (64 ch x 2 B + 16 pad)
+constexpr int SF_W_BYTES = 64 * SF_WROW;        // 29 696
+constexpr int SF_T_BYTES = SF_NPOS * SF_YROW;   // 41 616 (>= 2 * SF_PLANE: the tile aliases the patch)
+static_assert(SF_T_BYTES >= 2 * SF_PLANE, "the stem-output tile must cover the patch it aliases");
+
+struct StemNorm { float mean[3], istd[3]; };
+
+__device__ __forceinline__ uint16_t sf_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <bool SRC_U8>
+__global__ __launch_bounds__(256, 2) void k_stem_fwd_fused(const void* __restrict__ src, const uint16_t* __restrict__ wgt,
+                                                           int wgt_row_stride, const float* __restrict__ bias,
+                                                           uint4* __restrict__ p1, uint2* __restrict__ arg,
+                                                           uint8_t* __restrict__ sign, int n, int h, int w, StemNorm nm) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[SF_W_BYTES + SF_T_BYTES];
+  uint8_t* sW = lds;
+  uint8_t* sP = lds + SF_W_BYTES;               // patch (hi plane, lo plane) / stem-output tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kq = lane >> 5;
+  const int oh = h >> 1, ow = w >> 1, oh2 = oh >> 1, ow2 = ow >> 1;
+  const int tiles_x = (ow2 + SF_PT - 1) / SF_PT, tiles_y = (oh2 + SF_PT - 1) / SF_PT;
+  const int n_tiles = n * tiles_y * tiles_x;
+
+  // weights: [64][224] of the hi half (the lo taps use the same values), once per workgroup
+  for (int i = tid; i < 64 * 28; i += 256) {
+    const int row = i / 28, ch = i - row * 28;
+    *reinterpret_cast<uint4*>(sW + row * SF_WROW + ch * 16) =
+        *reinterpret_cast<const uint4*>(wgt + (size_t)row * wgt_row_stride + ch * 8);
+  }
+  // per-lane constants: the five 32-position M tiles of this wave half, bias of the lane's 16 channels
+  uint32_t a_off[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int p = wm * 160 + i * 32 + (lane & 31);
+    p = p < SF_NPOS ? p : SF_NPOS - 1;          // rows past the region recompute the last position; never stored
+    const int py = p / SF_R, px = p - py * SF_R;
+    a_off[i] = (uint32_t)(((2 * py) * SF_PW + 2 * px) * 8 + kq * 16);
+  }
+  const uint32_t w_off = (uint32_t)((wn * 32 + (lane & 31)) * SF_WROW + kq * 16);
+  float bz[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bz[r] = bias ? bias[wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq] : 0.f;
+
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int img = t / (tiles_y * tiles_x);
+    const int tr = t - img * (tiles_y * tiles_x);
+    const int q0y = (tr / tiles_x) * SF_PT, q0x = (tr % tiles_x) * SF_PT;
+    const int in_y0 = 4 * q0y - 5, in_x0 = 4 * q0x - 5;          // input pixel of patch (0, 0)
+    __syncthreads();                                               // previous tile's pool is done with the LDS tile
+    // ---- stage the patch: (x - mean) / std as hi + lo bf16, zeros outside the image and in the 4th channel
+    for (int i = tid; i < SF_PH * SF_PW; i += 256) {
+      const int pr = i / SF_PW, pc = i - pr * SF_PW;
+      const int y = in_y0 + pr, x = in_x0 + pc;
+      uint16_t hv[3] = {0, 0, 0}, lv[3] = {0, 0, 0};
+      if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w && pc < SF_PH) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float v01;
+          if (SRC_U8) v01 = (float)((const uint8_t*)src)[(((size_t)img * h + y) * w + x) * 3 + c] * (1.0f / 255.0f);
+          else v01 = ((const float*)src)[(((size_t)img * 3 + c) * h + y) * w + x];
+          const float v = (v01 - nm.mean[c]) * nm.istd[c];
+          hv[c] = sf_f2bf(v);
+          lv[c] = sf_f2bf(v - __uint_as_float((uint32_t)hv[c] << 16));
+        }
+      }
+      *reinterpret_cast<uint2*>(sP + i * 8) = make_uint2(hv[0] | ((uint32_t)hv[1] << 16), hv[2]);
+      *reinterpret_cast<uint2*>(sP + SF_PLANE + i * 8) = make_uint2(lv[0] | ((uint32_t)lv[1] << 16), lv[2]);
+    }
+    __syncthreads();
+    // ---- implicit GEMM: 2 planes x 7 row taps x 2 k-steps, D^T accumulators (register -> channel, lane -> position)
+    f32x16 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = bz[r];
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + w_off + r * 64 + ks * 32);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(sP + a_off[i] + plane * SF_PLANE + r * (SF_PW * 8) + ks * 32);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[i], 0, 0, 0);
+          }
+        }
+    __syncthreads();                                               // every wave is done reading the patch
+    // ---- ReLU, bf16, into the LDS tile [position][64 ch]
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int p = wm * 160 + i * 32 + (lane & 31);
+      if (p < SF_NPOS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t lo2 = pack2(fmaxf(acc[i][4 * q], 0.f), fmaxf(acc[i][4 * q + 1], 0.f));
+          const uint32_t hi2 = pack2(fmaxf(acc[i][4 * q + 2], 0.f), fmaxf(acc[i][4 * q + 3], 0.f));
+          *reinterpret_cast<uint2*>(sP + p * SF_YROW + (wn * 32 + 8 * q + 4 * kq) * 2) = make_uint2(lo2, hi2);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3x3/2 max pool (pad 1): first maximum in scan order, code 15 when the maximum is <= 0
+    for (int i = tid; i < SF_PT * SF_PT * 8; i += 256) {
+      const int c = i & 7, q = i >> 3;
+      const int qy = q / SF_PT, qx = q - qy * SF_PT;
+      const int gy = q0y + qy, gx = q0x + qx;
+      if (gy >= oh2 || gx >= ow2) continue;
+      float m[8];
+      uint32_t code[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; code[j] = 0; }
+      for (int ky = 0; ky < 3; ++ky) {
+        const int y1 = 2 * gy - 1 + ky;
+        if ((unsigned)y1 >= (unsigned)oh) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int x1 = 2 * gx - 1 + kx;
+          if ((unsigned)x1 >= (unsigned)ow) continue;
+          const uint4 v = *reinterpret_cast<const uint4*>(sP + ((2 * qy + ky) * SF_R + 2 * qx + kx) * SF_YROW + c * 16);
+          const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float f = (j & 1) ? __uint_as_float(wv[j >> 1] & 0xFFFF0000u) : __uint_as_float(wv[j >> 1] << 16);
+            if (f > m[j]) { m[j] = f; code[j] = (uint32_t)(ky * 3 + kx); }
+          }
+        }
+      }
+      const size_t o = (((size_t)img * oh2 + gy) * ow2 + gx) * 8 + c;
+      p1[o] = make_uint4(pack2(m[0], m[1]), pack2(m[2], m[3]), pack2(m[4], m[5]), pack2(m[6], m[7]));
+      uint32_t sb = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (m[j] > 0.f) sb |= 1u << j; else code[j] = 15u;
+      }
+      if (sign) sign[o] = (uint8_t)sb;
+      if (arg) arg[o] = make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
+                                   code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int rart_engine_stem_fwd_fused(const void* src, int src_is_u8, const void* wgt, int wgt_row_stride, const float* bias,
+                                          void* p1, void* argmax_out, void* sign_out, int n, int h, int w,
+                                          const float* mean_host, const float* std_host, rart_stream_t stream) {
+  RART_CHECK_ARG(src && wgt && p1 && n > 0 && h % 4 == 0 && w % 4 == 0 && h >= 4 && w >= 4 && wgt_row_stride >= 224 &&
+                 wgt_row_stride % 8 == 0, "rart_engine_stem_fwd_fused: bad arguments (h, w multiples of 4)");
+  StemNorm nm;
+  for (int c = 0; c < 3; ++c) {
+    nm.mean[c] = mean_host ? mean_host[c] : 0.f;
+    nm.istd[c] = std_host ? 1.0f / std_host[c] : 1.f;
+  }
+  const long long tiles = (long long)n * ((h / 4 + SF_PT - 1) / SF_PT) * ((w / 4 + SF_PT - 1) / SF_PT);
+  const int grid = (int)(tiles < 512 ? tiles : 512);              // persistent: 2 workgroups per CU
+  if (src_is_u8)
+    hipLaunchKernelGGL(k_stem_fwd_fused<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (const uint16_t*)wgt,
+                       wgt_row_stride, bias, (uint4*)p1, (uint2*)argmax_out, (uint8_t*)sign_out, n, h, w, nm);
+  else
+    hipLaunchKernelGGL(k_stem_fwd_fused<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (const uint16_t*)wgt,
+                       wgt_row_stride, bias, (uint4*)p1, (uint2*)argmax_out, (uint8_t*)sign_out, n, h, w, nm);
+  RART_CHECK_LAUNCH("rart_engine_stem_fwd_fused");
+  return RART_OK;
+}

@@ -120,6 +120,7 @@ class ResNet50Engine:
         self.fused_stem_bwd = True       # False: max-pool bwd -> patches GEMM -> col2im (kept as the cross-check)
         self.sign_bit_masks = True       # False: the backward reads the bf16 activations for their ReLU sign (cross-check)
         self.halo_conv3x3 = True         # False: layer1 / layer2 3x3 convs on the generic implicit GEMM (cross-check)
+        self.fused_stem_fwd = True       # False: prep_input -> row-tap GEMM -> max pool (cross-check; keeps acts['y1'])
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -316,26 +317,33 @@ class ResNet50Engine:
             B, H, W = src.shape[0], src.shape[2], src.shape[3]
         assert H % 32 == 0 and W % 32 == 0, 'input height/width must be multiples of 32'
         sp = _lib.stream_ptr()
-        hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
         meanf = (ctypes.c_float * 3)(*mean)
         stdf = (ctypes.c_float * 3)(*std)
-        _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]),
-                                              B, H, W, meanf, stdf, sp))
         acts = {}
         h1, w1 = H // 2, W // 2
-        y1 = self._get('y1', (B, h1, w1, 64))
-        lo_off = hi[1].data_ptr() - hi[0].data_ptr()
-        assert lo_off % 2 == 0
-        taps = [(r, 0) for r in range(7)] * 2
-        offs = [0] * 7 + [lo_off // 2] * 7
-        self._gemm(hi[0], self.stem_w, y1, B, (h1, w1), (H + 8, W + 8), 4, 32, taps, 64, (h1, w1), 64,
-                   bias=self.stem.bias, flags=F_RELU, stride=(2, 2), tap_src_off=offs)
         h2, w2 = h1 // 2, w1 // 2
         p1 = self._get('p1', (B, h2, w2, 64))
         parg = self._get('p1_argmax', (B, h2, w2, 64), torch.uint8) if keep else None
         bits = keep and self.sign_bit_masks
         xs = self._get('p1_sign', (B, h2, w2, 8), torch.uint8) if bits else None
-        _lib.check(lib.rart_engine_maxpool_keep(_lib.ptr(y1), _lib.ptr(p1), _lib.ptr(parg), _lib.ptr(xs), B, h1, w1, 64, sp))
+        if self.fused_stem_fwd:
+            # normalise + hi/lo split + 7x7/2 conv + bias + ReLU + 3x3/2 max pool in one persistent kernel
+            y1 = None
+            _lib.check(lib.rart_engine_stem_fwd_fused(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(self.stem_w),
+                                                      self.stem_w.shape[1], _lib.ptr(self.stem.bias), _lib.ptr(p1), _lib.ptr(parg),
+                                                      _lib.ptr(xs), B, H, W, meanf, stdf, sp))
+        else:
+            hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
+            _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]),
+                                                  B, H, W, meanf, stdf, sp))
+            y1 = self._get('y1', (B, h1, w1, 64))
+            lo_off = hi[1].data_ptr() - hi[0].data_ptr()
+            assert lo_off % 2 == 0
+            taps = [(r, 0) for r in range(7)] * 2
+            offs = [0] * 7 + [lo_off // 2] * 7
+            self._gemm(hi[0], self.stem_w, y1, B, (h1, w1), (H + 8, W + 8), 4, 32, taps, 64, (h1, w1), 64,
+                       bias=self.stem.bias, flags=F_RELU, stride=(2, 2), tap_src_off=offs)
+            _lib.check(lib.rart_engine_maxpool_keep(_lib.ptr(y1), _lib.ptr(p1), _lib.ptr(parg), _lib.ptr(xs), B, h1, w1, 64, sp))
         acts['y1'], acts['p1'], acts['p1_argmax'] = y1, p1, parg
         x, xhw = p1, (h2, w2)
         for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
@@ -423,6 +431,7 @@ class ResNet50Engine:
             return logits, loss, grad, pred
         # cross-check path: max-pool backward (+ReLU mask of y1), patches GEMM, col2im to the fp32 image
         y1 = acts['y1']
+        assert y1 is not None, 'the unfused stem backward needs the stem output: set fused_stem_fwd = False as well'
         h1, w1 = H // 2, W // 2
         dz1 = self._get('g_y1', tuple(y1.shape))
         _lib.check(lib.rart_engine_maxpool_bwd(_lib.ptr(y1), _lib.ptr(acts['p1_argmax']), _lib.ptr(dz), _lib.ptr(dz1),

@@ -218,6 +218,18 @@ def test_backward_to_input(setup, B, HW, kind):
     y = torch.randint(0, 1000, (B,), generator=g).cuda()
     logits, loss, grad, pred = eng.forward_backward(x, MEAN, STD, y, kind)
     assert torch.equal(pred.long(), logits.argmax(1))
+    if eng.last_acts['y1'] is None:
+        # the fused stem forward never materialises the stem output; the reference below needs it for the ReLU / max-pool
+        # decisions: take it from the unfused stem (bit-identical, test_fused_stem_forward_is_bit_identical)
+        acts, dl_keep = eng.last_acts, eng.last_dlogits
+        try:
+            eng.fused_stem_fwd = False
+            _, acts_u = eng._forward(x.detach().float().contiguous(), False, MEAN, STD, keep=True)
+            acts['y1'] = acts_u['y1'].clone()
+            assert torch.equal(acts_u['p1'], acts['p1'])
+        finally:
+            eng.fused_stem_fwd = True
+        eng.last_acts, eng.last_dlogits = acts, dl_keep
     # (1) rigorous: same masks as the engine's forward -> only fp32-accumulate / bf16-rounding noise remains
     ref = _reference_backward_with_engine_masks(eng, eng.last_acts, eng.last_dlogits, STD).cuda()
     for i in range(B):
@@ -360,10 +372,11 @@ def test_fused_stem_backward_matches_unfused_chain(setup):
     try:
         eng.fused_stem_bwd = True
         _, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
-        eng.fused_stem_bwd = False
+        ga = ga.clone()
+        eng.fused_stem_bwd = eng.fused_stem_fwd = False
         _, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
     finally:
-        eng.fused_stem_bwd = True
+        eng.fused_stem_bwd = eng.fused_stem_fwd = True
     a, b = ga.flatten().double(), gb.flatten().double()
     cos = (a @ b / (a.norm() * b.norm())).item()
     rel = ((a - b).norm() / b.norm()).item()
@@ -456,3 +469,27 @@ def test_halo_conv3x3_engine_matches_generic_igemm(setup):
     cos = (a @ b / (a.norm() * b.norm())).item()
     print('halo vs generic 3x3: logits max diff %.4f (scale %.2f), grad cos %.6f' % ((la - lb).abs().max().item(), lb.abs().max().item(), cos))
     assert cos > 0.995
+
+
+@pytest.mark.parametrize('B,H,W,u8', [(3, 224, 224, False), (2, 96, 160, True), (5, 32, 64, False)])
+def test_fused_stem_forward_is_bit_identical(setup, B, H, W, u8):
+    """rart_engine_stem_fwd_fused (normalise + hi/lo split + 7x7/2 conv + ReLU + max pool in one persistent kernel) against
+    the three-kernel chain it replaces: same K order and operands, so the pooled activation, the argmax codes and the sign
+    bits must be BIT-identical (image borders, partial pooled tiles, fp32 and uint8 entries)."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(B * 7 + H)
+    if u8:
+        src = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).cuda()
+    else:
+        src = torch.rand(B, 3, H, W, generator=g).cuda()
+    out = {}
+    try:
+        for fused in (True, False):
+            eng.fused_stem_fwd = fused
+            _, acts = eng._forward(src, u8, MEAN, STD, keep=True)
+            out[fused] = (acts['p1'].clone(), acts['p1_argmax'].clone(), eng._buf['p1_sign'].clone())
+    finally:
+        eng.fused_stem_fwd = True
+    for a, b, name in zip(out[True], out[False], ('p1', 'argmax', 'sign')):
+        assert torch.equal(a, b), name
+    assert (out[True][0] > 0).any() and (out[True][1] == 15).any()
