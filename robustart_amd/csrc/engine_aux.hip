@@ -35,6 +35,7 @@ struct Norm3 {
   float mean[3], istd[3];
 };
 
+#pragma clang fp contract(off)   // op-by-op rounding: the fused stem forward (stem_fused.hip) restates this arithmetic
 // src: fp32 NCHW in [0,1] (SRC_U8 = false) or uint8 NHWC (SRC_U8 = true).
 // dst hi/lo: bf16 [n][h+8][w+8][4], image at offset (3,3), zero elsewhere; v = (x - mean)/std,
 // hi = bf16(v), lo = bf16(v - hi): hi + lo carries ~16 mantissa bits so eps-sized PGD steps survive.
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_input(const void* __restrict__ 
   }
 }
 
+#pragma clang fp contract(fast)
 // 3x3 stride-2 pad-1 max pool, NHWC bf16, one thread per (output pixel, 8 channels).  Also records, per
 // channel, WHICH of the 9 window positions (ky*3+kx) holds the first maximum in scan order (PyTorch's
 // argmax rule) as one byte, so the backward is a <= 4-window gather instead of a 36-tap search.

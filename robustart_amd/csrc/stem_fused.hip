@@ -205,6 +205,8 @@ constexpr int SF_T_BYTES = SF_NPOS * SF_YROW;   // 41 616 (>= 2 * SF_PLANE: the 
 static_assert(SF_T_BYTES >= 2 * SF_PLANE, "the stem-output tile must cover the patch it aliases");
 
 struct StemNorm { float mean[3], istd[3]; };
+// the normalisation must round exactly like k_prep_input (engine_aux.hip): multiply, subtract, multiply -- no contraction
+#pragma clang fp contract(off)
 
 __device__ __forceinline__ uint16_t sf_f2bf(float f) {
   uint32_t u = __float_as_uint(f);
@@ -253,24 +255,44 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd_fused(const void* __restric
     const int q0y = (tr / tiles_x) * SF_PT, q0x = (tr % tiles_x) * SF_PT;
     const int in_y0 = 4 * q0y - 5, in_x0 = 4 * q0x - 5;          // input pixel of patch (0, 0)
     __syncthreads();                                               // previous tile's pool is done with the LDS tile
-    // ---- stage the patch: (x - mean) / std as hi + lo bf16, zeros outside the image and in the 4th channel
-    for (int i = tid; i < SF_PH * SF_PW; i += 256) {
-      const int pr = i / SF_PW, pc = i - pr * SF_PW;
-      const int y = in_y0 + pr, x = in_x0 + pc;
-      uint16_t hv[3] = {0, 0, 0}, lv[3] = {0, 0, 0};
-      if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w && pc < SF_PH) {
+    // ---- stage the patch: (x - mean) / std as hi + lo bf16, zeros outside the image and in the 4th channel.
+    //      All of a thread's loads (7 pixels x 3 channels) are issued before the first conversion / LDS store.
+    {
+      constexpr int U = (SF_PH * SF_PW + 255) / 256;               // 7
+      float v01[U][3];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = u * 256 + tid;
+        const int pr = i / SF_PW, pc = i - pr * SF_PW;
+        const int y = in_y0 + pr, x = in_x0 + pc;
+        ok[u] = i < SF_PH * SF_PW && (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w && pc < SF_PH;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float v01;
-          if (SRC_U8) v01 = (float)((const uint8_t*)src)[(((size_t)img * h + y) * w + x) * 3 + c] * (1.0f / 255.0f);
-          else v01 = ((const float*)src)[(((size_t)img * 3 + c) * h + y) * w + x];
-          const float v = (v01 - nm.mean[c]) * nm.istd[c];
-          hv[c] = sf_f2bf(v);
-          lv[c] = sf_f2bf(v - __uint_as_float((uint32_t)hv[c] << 16));
+          v01[u][c] = 0.f;
+          if (ok[u]) {
+            if (SRC_U8) v01[u][c] = (float)((const uint8_t*)src)[(((size_t)img * h + y) * w + x) * 3 + c];
+            else v01[u][c] = ((const float*)src)[(((size_t)img * 3 + c) * h + y) * w + x];
+          }
         }
       }
-      *reinterpret_cast<uint2*>(sP + i * 8) = make_uint2(hv[0] | ((uint32_t)hv[1] << 16), hv[2]);
-      *reinterpret_cast<uint2*>(sP + SF_PLANE + i * 8) = make_uint2(lv[0] | ((uint32_t)lv[1] << 16), lv[2]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = u * 256 + tid;
+        if (i >= SF_PH * SF_PW) continue;
+        uint16_t hv[3] = {0, 0, 0}, lv[3] = {0, 0, 0};
+        if (ok[u]) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float x01 = SRC_U8 ? v01[u][c] * (1.0f / 255.0f) : v01[u][c];
+            const float v = (x01 - nm.mean[c]) * nm.istd[c];
+            hv[c] = sf_f2bf(v);
+            lv[c] = sf_f2bf(v - __uint_as_float((uint32_t)hv[c] << 16));
+          }
+        }
+        *reinterpret_cast<uint2*>(sP + i * 8) = make_uint2(hv[0] | ((uint32_t)hv[1] << 16), hv[2]);
+        *reinterpret_cast<uint2*>(sP + SF_PLANE + i * 8) = make_uint2(lv[0] | ((uint32_t)lv[1] << 16), lv[2]);
+      }
     }
     __syncthreads();
     // ---- implicit GEMM: 2 planes x 7 row taps x 2 k-steps, D^T accumulators (register -> channel, lane -> position)
@@ -345,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd_fused(const void* __restric
     }
   }
 }
+#pragma clang fp contract(fast)
 }  // namespace
 
 extern "C" int rart_engine_stem_fwd_fused(const void* src, int src_is_u8, const void* wgt, int wgt_row_stride, const float* bias,
