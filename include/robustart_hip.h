@@ -296,8 +296,9 @@ int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
  * (default 1024); others the x32 pipeline with loads two K steps ahead. */
 int rart_igemm_set_bk64_min_k(long long k);
 
-/* 3x3 stride-1 "same" convolution, channels in = channels out = 64 or 128, bf16 NHWC, with the input halo tile resident
- * in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 / layer2 conv2, forward (taps (r-1, s-1), bias + ReLU, sign_out =
+/* 3x3 stride-1 "same" convolution, channels in = channels out = 64, 128 or 256 (256: images of at most 224 positions, one
+ * image per workgroup), bf16 NHWC, with the input halo tile resident in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 /
+ * layer2 / layer3 conv2, forward (taps (r-1, s-1), bias + ReLU, sign_out =
  * 1-bit mask of the output) and backward-to-input (taps (1-r, 1-s), weights [cin][tap*cout+co], mask_bits = 1-bit ReLU
  * mask of the destination).  wgt: bf16 [channels (padded rows allowed)][9*channels], k = tap*channels + c.  Any pointer
  * of bias / mask_bits / sign_out may be NULL.  rart_conv3x3_halo_supported: 1 when the geometry fits the LDS tile

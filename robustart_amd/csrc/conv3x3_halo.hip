@@ -256,6 +256,132 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_halo(const RartHaloDesc d) {
 #undef RART_STAMP
 }
 
+// ---- layer3-shaped variant: C = 256, images of at most 224 positions (14 x 14): ONE IMAGE PER WORKGROUP --------------------
+// The whole zero-ringed image (16 x 16 halo positions x 512 B = 131 KB, chunk-major planes) is resident in LDS, so no tap needs
+// masking and at B = 256 the grid is exactly one workgroup per CU (the implicit GEMM runs these launches as 784 tiles on 512
+// slots: a 53 %-full second round, 668 TFLOP/s).  8 waves: wave n owns ALL 7 M tiles x 32 output channels (112 accumulator
+// registers), streams its 32 x 64 weight slice per step from L2 one step ahead and never meets a barrier in the 36-step K loop.
+constexpr int IM_C = 256, IM_CP = 32, IM_MAXPOS = 256, IM_MT = 7, IM_T = 512;
+constexpr int IM_PLANE = (IM_MAXPOS + 1) * 16;
+constexpr int IM_LDS = IM_CP * IM_PLANE;
+static_assert(IM_PLANE % 256 == 16, "plane stride must be 16 mod 256");
+
+__global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc d) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[IM_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int H = d.h, W = d.w, W2 = W + 2, NP = H * W;
+  const size_t img_base = (size_t)blockIdx.x * NP;
+  const uint16_t* wp = d.wgt + (size_t)(wn * 32 + (lane & 31)) * (9 * IM_C) + (lane >> 5) * 8;
+  bf16x8 bq[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) bq[0][ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 16);
+  {
+    // the (h + 2) x (w + 2) ring-padded image, all 16 loads of a thread in flight before the first LDS store
+    constexpr int U = IM_MAXPOS * IM_CP / IM_T;          // 16
+    const int n_items = (H + 2) * W2 * IM_CP;
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = u * IM_T + tid;
+      const int chunk = idx & (IM_CP - 1), hp = idx / IM_CP;
+      const int hy = (int)fastdiv((uint32_t)hp, d.w2_magic, d.w2_shift), hx = hp - hy * W2;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (idx < n_items && hy >= 1 && hy <= H && hx >= 1 && hx <= W)
+        v[u] = *reinterpret_cast<const uint4*>(d.src + (img_base + (size_t)(hy - 1) * W + (hx - 1)) * IM_C + chunk * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = u * IM_T + tid;
+      if (idx < n_items) *reinterpret_cast<uint4*>(lds + (idx & (IM_CP - 1)) * IM_PLANE + (idx / IM_CP) * 16) = v[u];
+    }
+  }
+  const uint32_t kq = (uint32_t)(lane >> 5);
+  uint32_t abase[IM_MT];
+#pragma unroll
+  for (int i = 0; i < IM_MT; ++i) {
+    int p = i * 32 + (lane & 31);
+    p = p < NP ? p : NP - 1;                              // rows past the image recompute its last position; never stored
+    const int y = (int)fastdiv((uint32_t)p, d.w_magic, d.w_shift), x = p - y * W;
+    abase[i] = (uint32_t)(((y + 1) * W2 + x + 1) * 16) + kq * (uint32_t)IM_PLANE;
+  }
+  f32x16 acc[IM_MT];
+  {
+    const float bv = d.bias ? d.bias[wn * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+    for (int i = 0; i < IM_MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = bv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < 36; ++st) {
+    const int tap = st >> 2, kh = st & 3;
+    if (st + 1 < 36) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bq[(st + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(wp + (st + 1) * 64 + ks * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);                    // keep the prefetch ahead of this step's MFMAs (see k_conv3x3_halo)
+    const int toff = (d.tap_dy[tap] * W2 + d.tap_dx[tap]) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[IM_MT];
+#pragma unroll
+      for (int i = 0; i < IM_MT; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(lds + (int)abase[i] + toff + (kh * 8 + ks * 2) * IM_PLANE);
+#pragma unroll
+      for (int i = 0; i < IM_MT; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[st & 1][ks], acc[i], 0, 0, 0);
+    }
+  }
+  __syncthreads();        // the image is dead: its memory becomes the epilogue staging (8 waves x 32 rows x 36 floats)
+  constexpr int LDW = 32 + 4;
+  static_assert(8 * 32 * LDW * 4 <= IM_LDS, "epilogue staging must fit");
+  float* sE = reinterpret_cast<float*>(lds) + wn * 32 * LDW;
+  const int cw = lane & 3, rw0 = lane >> 2;
+  const int col = wn * 32 + cw * 8;
+#pragma unroll
+  for (int i = 0; i < IM_MT; ++i) {
+    if (i * 32 >= NP) break;                              // block-uniform
+    uint32_t mb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = i * 32 + q * 16 + rw0;
+      mb[q] = 0xFFu;
+      if (d.mask_bits && p < NP) mb[q] = d.mask_bits[((img_base + p) * IM_C + col) >> 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      sE[row * LDW + (lane & 31)] = acc[i][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = q * 16 + rw0;
+      const int p = i * 32 + r;
+      const float4 v0 = *reinterpret_cast<const float4*>(sE + r * LDW + cw * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(sE + r * LDW + cw * 8 + 4);
+      if (p < NP) {
+        uint32_t o[4] = {pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w)};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (d.mask_bits) o[t] &= halves_from_bits(mb[q], t);
+          if (d.relu) o[t] = relu_bf16x2(o[t]);
+        }
+        const size_t e = (img_base + p) * IM_C + col;
+        *reinterpret_cast<uint4*>(d.dst + e) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (d.sign_out)
+          d.sign_out[e >> 3] = (uint8_t)(bits_from_halves(o[0]) | (bits_from_halves(o[1]) << 2) | (bits_from_halves(o[2]) << 4) |
+                                         (bits_from_halves(o[3]) << 6));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 void magic_for(uint32_t dv, uint32_t& mg, uint32_t& sh) {      // exact for dividends < 2^31
   uint32_t l = 0;
   while ((1ull << l) < dv) ++l;
@@ -276,6 +402,7 @@ static int halo_rows_per_block(int channels, int w) {
 // 1 if rart_conv3x3_halo_bf16 can run this geometry (at least one image row per workgroup fits its LDS tile)
 extern "C" int rart_conv3x3_halo_supported(int channels, int h, int w) {
   if (h < 1 || w < 1) return 0;
+  if (channels == IM_C) return (h * w <= IM_MT * 32 && (h + 2) * (w + 2) <= IM_MAXPOS) ? 1 : 0;    // one image per workgroup
   return halo_rows_per_block(channels, w) > 0 ? 1 : 0;
 }
 
@@ -283,14 +410,14 @@ extern "C" int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const fl
                                       void* dst, int n, int h, int w, int channels, const int* tap_dy, const int* tap_dx,
                                       int relu, rart_stream_t stream) {
   RART_CHECK_ARG(src && wgt && dst && tap_dy && tap_dx && n > 0, "rart_conv3x3_halo_bf16: bad arguments");
-  RART_CHECK_ARG(rart_conv3x3_halo_supported(channels, h, w), "rart_conv3x3_halo_bf16: unsupported geometry (channels 64 / 128, halo must fit LDS)");
+  RART_CHECK_ARG(rart_conv3x3_halo_supported(channels, h, w), "rart_conv3x3_halo_bf16: unsupported geometry (channels 64 / 128 / 256, the halo tile must fit LDS)");
   const long long G = (long long)n * h * w;
   RART_CHECK_ARG(G * channels < (1ll << 31), "rart_conv3x3_halo_bf16: tensor must stay below 2^31 elements");
   RartHaloDesc d;
   d.src = (const uint16_t*)src; d.wgt = (const uint16_t*)wgt; d.bias = bias; d.mask_bits = (const uint8_t*)mask_bits;
   d.sign_out = (uint8_t*)sign_out; d.dst = (uint16_t*)dst;
   d.rows_total = n * h; d.h = h; d.w = w; d.relu = relu;
-  d.rows_per_block = halo_rows_per_block(channels, w);
+  d.rows_per_block = channels == IM_C ? h : halo_rows_per_block(channels, w);
   for (int t = 0; t < 9; ++t) {
     RART_CHECK_ARG(tap_dy[t] >= -1 && tap_dy[t] <= 1 && tap_dx[t] >= -1 && tap_dx[t] <= 1, "rart_conv3x3_halo_bf16: taps must lie in -1..1");
     d.tap_dy[t] = tap_dy[t]; d.tap_dx[t] = tap_dx[t];
@@ -299,7 +426,9 @@ extern "C" int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const fl
   magic_for((uint32_t)h, d.h_magic, d.h_shift);
   magic_for((uint32_t)(w + 2), d.w2_magic, d.w2_shift);
   const dim3 grid((uint32_t)((d.rows_total + d.rows_per_block - 1) / d.rows_per_block));
-  if (channels == 64) hipLaunchKernelGGL(k_conv3x3_halo<64>, grid, dim3(256), 0, (hipStream_t)stream, d);
+  if (channels == IM_C) {
+    hipLaunchKernelGGL(k_conv3x3_image256, dim3(n), dim3(IM_T), 0, (hipStream_t)stream, d);
+  } else if (channels == 64) hipLaunchKernelGGL(k_conv3x3_halo<64>, grid, dim3(256), 0, (hipStream_t)stream, d);
   else hipLaunchKernelGGL(k_conv3x3_halo<128>, grid, dim3(256), 0, (hipStream_t)stream, d);
   RART_CHECK_LAUNCH("rart_conv3x3_halo_bf16");
   return RART_OK;

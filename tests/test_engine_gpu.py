@@ -406,7 +406,7 @@ def test_sign_bit_masks_match_bf16_masks_exactly(setup):
 
 
 @pytest.mark.parametrize('C,B,H,W', [(64, 3, 56, 56), (64, 2, 24, 24), (64, 5, 7, 9), (128, 3, 28, 28), (128, 2, 12, 12),
-                                     (128, 1, 5, 27)])
+                                     (128, 1, 5, 27), (256, 3, 14, 14), (256, 2, 6, 10), (256, 1, 1, 1)])
 def test_halo_conv3x3_forward_and_backward_vs_fp64(C, B, H, W):
     """rart_conv3x3_halo_bf16 (input halo tile resident in LDS) against an fp64 evaluation of the same bf16 operands:
     forward (bias + ReLU + sign bits) and backward-to-input (flipped taps + 1-bit mask); image boundaries inside a
