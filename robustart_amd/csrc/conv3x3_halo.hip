@@ -257,8 +257,10 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_halo(const RartHaloDesc d) {
 }
 
 // ---- layer3-shaped variant: C = 256, images of at most 224 positions (14 x 14): ONE IMAGE PER WORKGROUP --------------------
-// The whole zero-ringed image (16 x 16 halo positions x 512 B = 131 KB, chunk-major planes) is resident in LDS, so no tap needs
-// masking and at B = 256 the grid is exactly one workgroup per CU (the implicit GEMM runs these launches as 784 tiles on 512
+// The whole zero-ringed image (16 x 16 halo positions x 512 B = 131 KB, chunk-major planes, row stride 16) is resident in LDS,
+// an M tile is two image rows x 16 column slots (so the 32 fragment reads of a tile are two contiguous 256-byte runs: bank
+// conflict free -- 32 consecutive raster positions of a 14-wide image were 2-way conflicted, SQ_LDS_BANK_CONFLICT 44 %), no tap
+// needs masking and at B = 256 the grid is exactly one workgroup per CU (the implicit GEMM runs these launches as 784 tiles on 512
 // slots: a 53 %-full second round, 668 TFLOP/s).  8 waves: wave n owns ALL 7 M tiles x 32 output channels (112 accumulator
 // registers), streams its 32 x 64 weight slice per step from L2 one step ahead and never meets a barrier in the 36-step K loop.
 constexpr int IM_C = 256, IM_CP = 32, IM_MAXPOS = 256, IM_MT = 7, IM_T = 512;
@@ -269,7 +271,8 @@ static_assert(IM_PLANE % 256 == 16, "plane stride must be 16 mod 256");
 __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc d) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[IM_LDS];
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-  const int H = d.h, W = d.w, W2 = W + 2, NP = H * W;
+  const int H = d.h, W = d.w, NP = H * W;
+  constexpr int W2 = 16;                                   // halo row stride (w <= 14)
   const size_t img_base = (size_t)blockIdx.x * NP;
   const uint16_t* wp = d.wgt + (size_t)(wn * 32 + (lane & 31)) * (9 * IM_C) + (lane >> 5) * 8;
   bf16x8 bq[2][4];
@@ -278,13 +281,13 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
   {
     // the (h + 2) x (w + 2) ring-padded image, all 16 loads of a thread in flight before the first LDS store
     constexpr int U = IM_MAXPOS * IM_CP / IM_T;          // 16
-    const int n_items = (H + 2) * W2 * IM_CP;
+    const int n_items = (H + 2) * W2 * IM_CP;              // halo rows 0 .. H+1, 16 slots each
     uint4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = u * IM_T + tid;
       const int chunk = idx & (IM_CP - 1), hp = idx / IM_CP;
-      const int hy = (int)fastdiv((uint32_t)hp, d.w2_magic, d.w2_shift), hx = hp - hy * W2;
+      const int hy = hp >> 4, hx = hp & 15;
       v[u] = make_uint4(0, 0, 0, 0);
       if (idx < n_items && hy >= 1 && hy <= H && hx >= 1 && hx <= W)
         v[u] = *reinterpret_cast<const uint4*>(d.src + (img_base + (size_t)(hy - 1) * W + (hx - 1)) * IM_C + chunk * 8);
@@ -299,9 +302,7 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
   uint32_t abase[IM_MT];
 #pragma unroll
   for (int i = 0; i < IM_MT; ++i) {
-    int p = i * 32 + (lane & 31);
-    p = p < NP ? p : NP - 1;                              // rows past the image recompute its last position; never stored
-    const int y = (int)fastdiv((uint32_t)p, d.w_magic, d.w_shift), x = p - y * W;
+    const int y = min(2 * i + ((lane >> 4) & 1), H - 1), x = min(lane & 15, W - 1);   // slots past the image: clamped, never stored
     abase[i] = (uint32_t)(((y + 1) * W2 + x + 1) * 16) + kq * (uint32_t)IM_PLANE;
   }
   f32x16 acc[IM_MT];
@@ -341,13 +342,13 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
   const int col = wn * 32 + cw * 8;
 #pragma unroll
   for (int i = 0; i < IM_MT; ++i) {
-    if (i * 32 >= NP) break;                              // block-uniform
+    if (2 * i >= H) break;                                // block-uniform
     uint32_t mb[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int p = i * 32 + q * 16 + rw0;
+      const int y = 2 * i + q, x = rw0;                   // staged row r = q * 16 + rw0 <-> (image row 2i + q, column rw0)
       mb[q] = 0xFFu;
-      if (d.mask_bits && p < NP) mb[q] = d.mask_bits[((img_base + p) * IM_C + col) >> 3];
+      if (d.mask_bits && y < H && x < W) mb[q] = d.mask_bits[((img_base + (size_t)y * W + x) * IM_C + col) >> 3];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -360,17 +361,17 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int r = q * 16 + rw0;
-      const int p = i * 32 + r;
+      const int y = 2 * i + q, x = rw0;
       const float4 v0 = *reinterpret_cast<const float4*>(sE + r * LDW + cw * 8);
       const float4 v1 = *reinterpret_cast<const float4*>(sE + r * LDW + cw * 8 + 4);
-      if (p < NP) {
+      if (y < H && x < W) {
         uint32_t o[4] = {pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w)};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if (d.mask_bits) o[t] &= halves_from_bits(mb[q], t);
           if (d.relu) o[t] = relu_bf16x2(o[t]);
         }
-        const size_t e = (img_base + p) * IM_C + col;
+        const size_t e = (img_base + (size_t)y * W + x) * IM_C + col;
         *reinterpret_cast<uint4*>(d.dst + e) = make_uint4(o[0], o[1], o[2], o[3]);
         if (d.sign_out)
           d.sign_out[e >> 3] = (uint8_t)(bits_from_halves(o[0]) | (bits_from_halves(o[1]) << 2) | (bits_from_halves(o[2]) << 4) |
@@ -402,7 +403,7 @@ static int halo_rows_per_block(int channels, int w) {
 // 1 if rart_conv3x3_halo_bf16 can run this geometry (at least one image row per workgroup fits its LDS tile)
 extern "C" int rart_conv3x3_halo_supported(int channels, int h, int w) {
   if (h < 1 || w < 1) return 0;
-  if (channels == IM_C) return (h * w <= IM_MT * 32 && (h + 2) * (w + 2) <= IM_MAXPOS) ? 1 : 0;    // one image per workgroup
+  if (channels == IM_C) return (h <= 2 * IM_MT && w <= 14) ? 1 : 0;    // one image per workgroup, halo row stride 16
   return halo_rows_per_block(channels, w) > 0 ? 1 : 0;
 }
 
