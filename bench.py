@@ -252,6 +252,11 @@ def measure_igemm_roofline(path, images, labels):
            'traffic_note': 'HBM bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB units',
            'avg_launch_us': secs / len(ig) * 1e6, 'launches': len(ig),
            'algorithmic_flops_per_launch': flops / len(ig), 'kernel_seconds_per_fwd_bwd': secs}
+    if out['traffic']:
+        # what is left on this kernel is mostly the K <= 256 1x1 layers of layer1 / layer2, which sit on the HBM roofline:
+        # the same launches priced by bytes (PMC traffic per launch / measured launch time)
+        out['hbm_view'] = {'achieved': out['traffic'] / (secs / len(ig)) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                           'frac': out['traffic'] / (secs / len(ig)) / HBM_PEAK}
     if halo:
         hs = sum(a.elapsed_time(b) for _, a, b, _ in halo) * 1e-3
         hf = sum(f for f, _, _, _ in halo)

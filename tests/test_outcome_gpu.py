@@ -93,12 +93,22 @@ def test_pgd7_outcome_bf16_engine_vs_fp32_module(fitted):
         stats['adv_e'] += int((pe == y).sum()); stats['adv_t'] += int((pt == y).sum())
         stats['agree_adv'] += int((pe == pt).sum())
         stats['cross_e_on_t'] += int((cross == y).sum())   # engine-crafted examples scored by the fp32 module
+    # gradient direction on the fitted network: engine backward-to-input vs fp32 autograd, same images
+    imgs, y = ds.batch(list(range(20000, 20064)), 'cuda')
+    x = imgs.permute(0, 3, 1, 2).float().div(255.0).contiguous()
+    _, _, g_e, _ = eng.rart_engine.forward_backward(x, MEAN, STD, y, 0)
+    xr = x.clone().requires_grad_(True)
+    g_t, = torch.autograd.grad(torch.nn.functional.cross_entropy(f32(xr), y, reduction='sum'), xr)
+    a, b = g_e.flatten(1).double(), g_t.flatten(1).double()
+    cos = ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).cpu()
+    sign_agree = float((torch.sign(g_e) == torch.sign(g_t)).float().mean())
     errs = torch.cat(errs)
     hist = np.histogram(errs.numpy(), bins=[0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1.0])[0].tolist()
     rep = {k: v / n_img for k, v in stats.items()}
     rep['logit_rel_err_hist_bins'] = [0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1.0]
     rep['logit_rel_err_hist'] = hist
     rep['logit_rel_err_median'] = float(errs.median())
+    rep['grad_cos_median'], rep['grad_cos_min'], rep['grad_sign_agreement'] = float(cos.median()), float(cos.min()), sign_agree
     print('PGD-7 eps 4/255 outcome, bf16 HIP engine vs fp32 module, 2048 held-out images: ' + json.dumps(rep))
     os.makedirs('gpurun_out', exist_ok=True)
     json.dump(rep, open('gpurun_out/outcome_bf16_vs_fp32.json', 'w'), indent=1)
@@ -107,6 +117,7 @@ def test_pgd7_outcome_bf16_engine_vs_fp32_module(fitted):
     assert abs(rep['adv_e'] - rep['adv_t']) <= 0.01           # |delta robust accuracy| <= 1 point
     assert rep['agree_adv'] >= 0.95                             # per-image adversarial prediction agreement
     assert abs(rep['cross_e_on_t'] - rep['adv_t']) <= 0.02      # engine-crafted examples are as strong on the fp32 model
+    assert rep['grad_cos_median'] > 0.97 and rep['grad_sign_agreement'] > 0.85    # the PGD sign step sees the same direction
 
 
 def test_b256_matches_small_batches_bit_for_bit():
@@ -133,7 +144,8 @@ def test_b256_matches_small_batches_bit_for_bit():
         assert torch.equal(ls[0], lb[i]) and torch.equal(gs[0], gb[i]) and torch.equal(gs[1], gb[i + 1]), i
     u8 = torch.randint(0, 256, (256, 224, 224, 3), generator=g, dtype=torch.uint8).cuda()
     for name in ('gaussian_noise', 'shot_noise', 'impulse_noise', 'jpeg_compression', 'contrast', 'pixelate', 'zoom_blur',
-                 'defocus_blur', 'fog'):
+                 'defocus_blur', 'fog', 'glass_blur', 'motion_blur', 'snow', 'elastic_transform', 'spatter', 'gaussian_blur',
+                 'brightness'):
         cid = C.CORRUPTION_NAMES.index(name)
         whole = torch.empty_like(u8)
         C.corrupt_batch_(u8, cid, 3, seed=9, sample_offset=1000, out=whole)
