@@ -308,6 +308,22 @@ int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const float* bias, 
                            void* dst, int n, int h, int w, int channels, const int* tap_dy, const int* tap_dx, int relu,
                            rart_stream_t stream);
 
+/* One identity Bottleneck (1x1 c_io -> c_mid, 3x3 c_mid -> c_mid, 1x1 c_mid -> c_io, + the block input) as ONE kernel with
+ * both intermediates kept on chip (csrc/bottleneck_fused.hip); supported geometry: c_io 256, c_mid 64, 56 x 56 (ResNet-50
+ * layer1 blocks 1-2).  Replaces three rart_conv_igemm_bf16 / rart_conv3x3_halo_bf16 launches and computes the same function.
+ * x, out: bf16 NHWC [n][h][w][c_io], out != x.  w1: bf16 [c_mid][c_io]; w2: the 3x3 table [c_mid][9*c_mid] (k = tap*c_mid + c)
+ * re-ordered by rart_bottleneck_pack_w2 into MFMA-fragment order (each fragment load reads 1 KiB contiguous), with its taps; w3: bf16 [c_io][c_mid]; b1..b3 fp32 or NULL.  m1 / m2 / m3: 1 bit per element of the stage-1 / stage-2 / final
+ * result (byte (pos*C + ch) >> 3, bit ch & 7).
+ *   backward = 0: out = relu(w3.relu(w2*relu(w1.x + b1) + b2) + b3 + x); m1..m3 are OUTPUTS (value > 0), each may be NULL.
+ *   backward = 1: x is the gradient at the block output (already masked by that output's ReLU), w1 / w2 / w3 the transposed
+ *                 tables of conv3 / conv2 (flipped taps) / conv1, no biases; out = m3 . (w3.(m2.(w2*(m1.(w1.x)))) + x) with
+ *                 m1 = sign of the forward's conv2 output, m2 = of its conv1 output, m3 = of the block input (or NULL). */
+int rart_bottleneck_fused_supported(int c_io, int c_mid, int h, int w);
+int rart_bottleneck_pack_w2(const void* w2_rows, void* w2_frag, int c_mid, rart_stream_t stream);
+int rart_bottleneck_fused_bf16(const void* x, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
+                               const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
+                               int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);
+
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
  * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:
  * the stem convolution's operand (normalisation of imfgsm_attack.py:14-23 / autoattack.py:17-20 fused). */

@@ -121,6 +121,7 @@ class ResNet50Engine:
         self.sign_bit_masks = True       # False: the backward reads the bf16 activations for their ReLU sign (cross-check)
         self.halo_conv3x3 = True         # False: layer1 / layer2 3x3 convs on the generic implicit GEMM (cross-check)
         self.fused_stem_fwd = True       # False: prep_input -> row-tap GEMM -> max pool (cross-check; keeps acts['y1'])
+        self.fused_bottleneck = True     # False: layer1's identity blocks as three conv launches each (cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -139,6 +140,19 @@ class ResNet50Engine:
         self.fc_wd = _bf16(wt).to(dev)                                    # [2048][1024]
         self._buf = {}
         self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
+        self._pack_frag_tables()
+
+    def _pack_frag_tables(self):
+        """MFMA-fragment-ordered copies of the 3x3 tables the fused Bottleneck kernel streams from L2 (a fragment load then
+        reads 1 KiB contiguous instead of touching 32 cache lines)."""
+        torch = _lib.require_gpu()
+        sp = _lib.stream_ptr()
+        for ca, cb, cc, ds in self.blocks:
+            if ds is None and cb.r == 3 and cb.stride == 1 and cb.cin == 64 and cb.cout == 64:
+                for name, tab in (('w_fwd_frag', cb.w_fwd), ('w_bwd_frag', cb.bwd[0][2])):
+                    if getattr(cb, name, None) is None:
+                        setattr(cb, name, torch.empty(64 * 576, dtype=torch.bfloat16, device=self.device))
+                    _lib.check(self.lib.rart_bottleneck_pack_w2(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), 64, sp))
 
     @staticmethod
     def _stem_bwd_table(wb):
@@ -215,6 +229,7 @@ class ResNet50Engine:
         self.fc_w[:self.n_classes] = wfb
         self.fc_wd[:, :self.n_classes] = wfb.t()
         self.fc_b.copy_(m.fc.bias.detach())
+        self._pack_frag_tables()
 
     # ------------------------------------------------------------------ buffers / launches
     def _get(self, name, shape, dtype=None):
@@ -279,6 +294,30 @@ class ResNet50Engine:
         _lib.check(self.lib.rart_conv3x3_halo_bf16(_lib.ptr(src), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(mask), _lib.ptr(sign),
                                                    _lib.ptr(dst), B, hw[0], hw[1], ch, _cints([t[0] for t in taps]),
                                                    _cints([t[1] for t in taps]), 1 if relu else 0, _lib.stream_ptr()))
+
+    def _bneck_ok(self, ca, cb, cc, ds, xhw):
+        return (self.fused_bottleneck and ds is None and cb.stride == 1 and cb.r == 3 and ca.r == 1 and cc.r == 1
+                and ca.cin == cc.cout and getattr(cb, 'w_fwd_frag', None) is not None
+                and self.lib.rart_bottleneck_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]))
+
+    def _bneck(self, x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward):
+        """One identity Bottleneck as a single launch (csrc/bottleneck_fused.hip), forward or backward-to-input."""
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            prof, self.profile = self.profile, None
+            try:
+                self._bneck(x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward)
+            finally:
+                self.profile = prof
+            e1.record()
+            self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * (2 * c_io + 9 * c_mid), e0, e1, 'bottleneck'))
+            return
+        _lib.check(self.lib.rart_bottleneck_fused_bf16(
+            _lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(m1),
+            _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, hw[0], hw[1], c_io, c_mid, _cints([t[0] for t in taps]),
+            _cints([t[1] for t in taps]), 1 if backward else 0, _lib.stream_ptr()))
 
     def _conv_fwd(self, c, x, xhw, out, relu, res=None, sign=None):
         B = x.shape[0]
@@ -354,6 +393,14 @@ class ResNet50Engine:
             sa = self._get('b%d_a_sign' % bi, (B, xhw[0], xhw[1], ca.cout // 8), torch.uint8) if bits else None
             sb = self._get('b%d_b_sign' % bi, (B, ohw[0], ohw[1], cb.cout // 8), torch.uint8) if bits else None
             sc = self._get('b%d_c_sign' % bi, (B, ohw[0], ohw[1], cc.cout // 8), torch.uint8) if bits else None
+            if (bits or not keep) and self._bneck_ok(ca, cb, cc, ds, xhw):
+                # the two 64-channel intermediates stay on chip; the backward pass gets their sign bits
+                self._bneck(x, ca.w_fwd, cb.w_fwd_frag, cc.w_fwd, ca.bias, cb.bias, cc.bias, sa, sb, sc, yc, B, xhw, cc.cout,
+                            ca.cout, cb.fwd_taps, False)
+                acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
+                acts['b%d_masks' % bi] = (xs, sa, sb)
+                x, xhw, xs = yc, ohw, sc
+                continue
             self._conv_fwd(ca, x, xhw, ya, True, sign=sa)
             self._conv_fwd(cb, ya, xhw, yb, True, sign=sb)
             if ds is not None:
@@ -411,6 +458,12 @@ class ResNet50Engine:
             ca, cb, cc, ds = self.blocks[bi]
             x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
             mx, ma, mb = acts['b%d_masks' % bi]
+            if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._bneck_ok(ca, cb, cc, ds, xhw)):
+                dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
+                self._bneck(dz, cc.bwd[0][2], cb.w_bwd_frag, ca.bwd[0][2], None, None, None, mb, ma, mx, dx, B, xhw, cc.cout,
+                            ca.cout, cb.bwd[0][1], True)
+                dz = dx
+                continue
             dzb = self._get('g_b', tuple(yb.shape))
             self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb)
             dza = self._get('g_a', tuple(ya.shape))

@@ -493,3 +493,114 @@ def test_fused_stem_forward_is_bit_identical(setup, B, H, W, u8):
     for a, b, name in zip(out[True], out[False], ('p1', 'argmax', 'sign')):
         assert torch.equal(a, b), name
     assert (out[True][0] > 0).any() and (out[True][1] == 15).any()
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_fused_bottleneck_forward_and_backward_vs_fp64(B):
+    """rart_bottleneck_fused_bf16 (1x1 -> 3x3 -> 1x1 + input with both 64-channel intermediates on chip) against an fp64
+    evaluation of the same bf16 operands with the intermediates rounded to bf16 where the kernel rounds them: forward
+    (biases, ReLUs, the three sign tensors) and backward-to-input (three 1-bit masks, flipped taps, residual gradient).
+    A 1-ulp flip of an intermediate (fp32 accumulation order) moves a few outputs by more than their own ulp, so the
+    bound is 1 ulp for all but 1e-3 of the elements and 1 % of the tensor scale for every element."""
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import _Conv, _cints
+    lib = _lib.load()
+    H = W = 56
+    assert lib.rart_bottleneck_fused_supported(256, 64, H, W)
+    assert not lib.rart_bottleneck_fused_supported(512, 128, 28, 28)
+    g = torch.Generator().manual_seed(40 + B)
+
+    def mk(cin, cout, k):
+        conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5)
+        c = _Conv(conv, None, 'cuda')
+        c.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        return conv, c
+
+    (c1, ca), (c2, cb), (c3, cc) = mk(256, 64, 1), mk(64, 64, 3), mk(64, 256, 1)
+    wq = [c.weight.detach().to(torch.bfloat16).double() for c in (c1, c2, c3)]
+    bq = [c.bias.cpu().double() for c in (ca, cb, cc)]
+    rb = lambda t: t.to(torch.bfloat16).double()            # where the kernel rounds
+    x = _rand_bf16((B, H, W, 256), 5, relu=True).cuda()
+    y = torch.empty_like(x)
+    s1 = torch.zeros(B, H, W, 8, dtype=torch.uint8, device='cuda')
+    s2 = torch.zeros_like(s1)
+    s3 = torch.zeros(B, H, W, 32, dtype=torch.uint8, device='cuda')
+    sp = _lib.stream_ptr()
+    dy, dx_ = _cints([t[0] for t in cb.fwd_taps]), _cints([t[1] for t in cb.fwd_taps])
+    w2f, w2b = torch.empty(64 * 576, dtype=torch.bfloat16, device='cuda'), torch.empty(64 * 576, dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.rart_bottleneck_pack_w2(_lib.ptr(cb.w_fwd), _lib.ptr(w2f), 64, sp))
+    _lib.check(lib.rart_bottleneck_pack_w2(_lib.ptr(cb.bwd[0][2]), _lib.ptr(w2b), 64, sp))
+    _lib.check(lib.rart_bottleneck_fused_bf16(_lib.ptr(x), _lib.ptr(ca.w_fwd), _lib.ptr(w2f), _lib.ptr(cc.w_fwd),
+                                              _lib.ptr(ca.bias), _lib.ptr(cb.bias), _lib.ptr(cc.bias), _lib.ptr(s1), _lib.ptr(s2),
+                                              _lib.ptr(s3), _lib.ptr(y), B, H, W, 256, 64, dy, dx_, 0, sp))
+    xd = x.cpu().double().permute(0, 3, 1, 2)
+    a1 = rb(F.relu(F.conv2d(xd, wq[0], bq[0])))
+    a2 = rb(F.relu(F.conv2d(a1, wq[1], bq[1], padding=1)))
+    ref = F.relu(F.conv2d(a2, wq[2], bq[2]) + xd).permute(0, 2, 3, 1)
+    got = y.cpu().double()
+
+    def close(got, ref, what):
+        err = (got - ref).abs()
+        ulp = ref.abs().clamp_min(2.0 ** -20) * 2.0 ** -8 + 1e-6
+        frac = (err > ulp).double().mean().item()
+        print('%s: beyond 1 ulp %.2e of the elements, max err %.4f (scale %.2f)' % (what, frac, err.max().item(), ref.abs().max().item()))
+        assert frac < 1e-3 and err.max() <= 0.01 * ref.abs().max(), what
+
+    close(got, ref, 'forward')
+    unpack = lambda t: torch.from_numpy(np.unpackbits(t.cpu().numpy(), axis=-1, bitorder='little')).bool()
+    assert torch.equal(unpack(s3), y.cpu() > 0)
+    for s, a, name in ((s1, a1, 'a1'), (s2, a2, 'a2')):
+        mism = (unpack(s) != (a.permute(0, 2, 3, 1) > 0)).double().mean().item()
+        assert mism < 1e-4, (name, mism)
+    # forward without sign outputs (the evaluation path) writes the same activations
+    y2 = torch.empty_like(x)
+    _lib.check(lib.rart_bottleneck_fused_bf16(_lib.ptr(x), _lib.ptr(ca.w_fwd), _lib.ptr(w2f), _lib.ptr(cc.w_fwd),
+                                              _lib.ptr(ca.bias), _lib.ptr(cb.bias), _lib.ptr(cc.bias), None, None, None,
+                                              _lib.ptr(y2), B, H, W, 256, 64, dy, dx_, 0, sp))
+    assert torch.equal(y, y2)
+    # backward to input with random masks
+    gz = _rand_bf16((B, H, W, 256), 6).cuda()
+    mb = torch.randint(0, 256, (B, H, W, 8), generator=g, dtype=torch.uint8).cuda()      # sign of the conv2 output
+    ma = torch.randint(0, 256, (B, H, W, 8), generator=g, dtype=torch.uint8).cuda()      # sign of the conv1 output
+    mx = torch.randint(0, 256, (B, H, W, 32), generator=g, dtype=torch.uint8).cuda()     # sign of the block input
+    dx = torch.empty_like(gz)
+    taps = cb.bwd[0][1]
+    _lib.check(lib.rart_bottleneck_fused_bf16(_lib.ptr(gz), _lib.ptr(cc.bwd[0][2]), _lib.ptr(w2b), _lib.ptr(ca.bwd[0][2]),
+                                              None, None, None, _lib.ptr(mb), _lib.ptr(ma), _lib.ptr(mx), _lib.ptr(dx), B, H, W,
+                                              256, 64, _cints([t[0] for t in taps]), _cints([t[1] for t in taps]), 1, sp))
+    bits = lambda t: unpack(t).double().permute(0, 3, 1, 2)
+    gd = gz.cpu().double().permute(0, 3, 1, 2)
+    d2 = rb(torch.nn.grad.conv2d_input((B, 64, H, W), wq[2], gd) * bits(mb))
+    d1 = rb(torch.nn.grad.conv2d_input((B, 64, H, W), wq[1], d2, padding=1) * bits(ma))
+    refg = ((torch.nn.grad.conv2d_input((B, 256, H, W), wq[0], d1) + gd) * bits(mx)).permute(0, 2, 3, 1)
+    close(dx.cpu().double(), refg, 'backward')
+
+
+def test_fused_bottleneck_engine_matches_three_launch_chain(setup):
+    m, eng = setup
+    g = torch.Generator().manual_seed(321)
+    x = torch.rand(3, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    try:
+        eng.fused_bottleneck = True
+        eng.profile = []
+        la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        kinds = [p[3] for p in eng.profile]
+        eng.profile = None
+        assert kinds.count('bottleneck') == 4, kinds          # layer1 blocks 1 and 2, forward and backward
+        ga = ga.clone()
+        ea = eng.logits(x, MEAN, STD).clone()
+        eng.fused_bottleneck = False
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        eb = eng.logits(x, MEAN, STD)
+    finally:
+        eng.fused_bottleneck = True
+        eng.profile = None
+    assert torch.equal(la, ea)                                # with and without sign outputs: same activations
+    assert (la - lb).abs().max() <= 0.02 * lb.abs().max() and (ea - eb).abs().max() <= 0.02 * eb.abs().max()
+    a, b = ga.flatten().double(), gb.flatten().double()
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    print('fused bottleneck vs chain: logits max diff %.4f (scale %.2f), grad cos %.6f' % ((la - lb).abs().max().item(), lb.abs().max().item(), cos))
+    assert cos > 0.995
