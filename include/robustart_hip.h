@@ -300,10 +300,13 @@ int rart_igemm_set_bk64_min_k(long long k);
  * image per workgroup), bf16 NHWC, with the input halo tile resident in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 /
  * layer2 / layer3 conv2, forward (taps (r-1, s-1), bias + ReLU, sign_out =
  * 1-bit mask of the output) and backward-to-input (taps (1-r, 1-s), weights [cin][tap*cout+co], mask_bits = 1-bit ReLU
- * mask of the destination).  wgt: bf16 [channels (padded rows allowed)][9*channels], k = tap*channels + c.  Any pointer
+ * mask of the destination).  wgt: the bf16 table [channels][9*channels] (k = tap*channels + c) RE-ORDERED by
+ * rart_conv3x3_pack_frag_bf16 into MFMA-fragment order (fragment (K step st of 64, column tile wn, ks) = 64 lanes x 8
+ * elements, lane l = w[wn*32 + (l & 31)][st*64 + ks*16 + (l >> 5)*8 ..]: a fragment load reads 1 KiB contiguous).  Any pointer
  * of bias / mask_bits / sign_out may be NULL.  rart_conv3x3_halo_supported: 1 when the geometry fits the LDS tile
  * (otherwise use rart_conv_igemm_bf16, which computes the same function). */
 int rart_conv3x3_halo_supported(int channels, int h, int w);
+int rart_conv3x3_pack_frag_bf16(const void* w_rows, void* w_frag, int channels, rart_stream_t stream);
 int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const float* bias, const void* mask_bits, void* sign_out,
                            void* dst, int n, int h, int w, int channels, const int* tap_dy, const int* tap_dx, int relu,
                            rart_stream_t stream);
@@ -312,14 +315,13 @@ int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const float* bias, 
  * both intermediates kept on chip (csrc/bottleneck_fused.hip); supported geometry: c_io 256, c_mid 64, 56 x 56 (ResNet-50
  * layer1 blocks 1-2).  Replaces three rart_conv_igemm_bf16 / rart_conv3x3_halo_bf16 launches and computes the same function.
  * x, out: bf16 NHWC [n][h][w][c_io], out != x.  w1: bf16 [c_mid][c_io]; w2: the 3x3 table [c_mid][9*c_mid] (k = tap*c_mid + c)
- * re-ordered by rart_bottleneck_pack_w2 into MFMA-fragment order (each fragment load reads 1 KiB contiguous), with its taps; w3: bf16 [c_io][c_mid]; b1..b3 fp32 or NULL.  m1 / m2 / m3: 1 bit per element of the stage-1 / stage-2 / final
+ * re-ordered by rart_conv3x3_pack_frag_bf16 into MFMA-fragment order, with its taps; w3: bf16 [c_io][c_mid]; b1..b3 fp32 or NULL.  m1 / m2 / m3: 1 bit per element of the stage-1 / stage-2 / final
  * result (byte (pos*C + ch) >> 3, bit ch & 7).
  *   backward = 0: out = relu(w3.relu(w2*relu(w1.x + b1) + b2) + b3 + x); m1..m3 are OUTPUTS (value > 0), each may be NULL.
  *   backward = 1: x is the gradient at the block output (already masked by that output's ReLU), w1 / w2 / w3 the transposed
  *                 tables of conv3 / conv2 (flipped taps) / conv1, no biases; out = m3 . (w3.(m2.(w2*(m1.(w1.x)))) + x) with
  *                 m1 = sign of the forward's conv2 output, m2 = of its conv1 output, m3 = of the block input (or NULL). */
 int rart_bottleneck_fused_supported(int c_io, int c_mid, int h, int w);
-int rart_bottleneck_pack_w2(const void* w2_rows, void* w2_frag, int c_mid, rart_stream_t stream);
 int rart_bottleneck_fused_bf16(const void* x, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
                                const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
                                int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);

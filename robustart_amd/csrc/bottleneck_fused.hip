@@ -37,7 +37,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // (arrays of HIP'
 struct RartBneckDesc {
   const uint16_t* x;        // [n][56][56][256] bf16: the block input (forward) / the masked gradient at the block output (backward)
   const uint16_t* w1;       // [64][256]   rows = stage-A output channel
-  const uint16_t* w2;       // fragment-major 3x3 table (rart_bottleneck_pack_w2): [tap][blk][s][lane][8]
+  const uint16_t* w2;       // fragment-major 3x3 table (rart_conv3x3_pack_frag_bf16): [tap][blk][s][lane][8]
   const uint16_t* w3;       // [256][64]   rows = stage-C output channel
   const float* b1;
   const float* b2;
@@ -424,24 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
 #endif
 #undef RART_STAMP
 }
-// w2 [64][576] (k = tap*64 + c) -> fragment-major: element e of lane l of fragment (tap, blk, s) =
-// w2[blk*32 + (l & 31)][tap*64 + s*16 + (l >> 5)*8 + e]
-__global__ void k_bneck_pack_w2(const uint16_t* __restrict__ w, uint16_t* __restrict__ o) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread: 9 * 2 * 4 * 64 = 4608
-  if (i >= 9 * 2 * 4 * 64) return;
-  const int l = i & 63, s = (i >> 6) & 3, blk = (i >> 8) & 1, tap = i >> 9;
-  *reinterpret_cast<uint4*>(o + i * 8) =
-      *reinterpret_cast<const uint4*>(w + (blk * 32 + (l & 31)) * 576 + tap * 64 + s * 16 + (l >> 5) * 8);
-}
 }  // namespace
-
-extern "C" int rart_bottleneck_pack_w2(const void* w2_rows, void* w2_frag, int c_mid, rart_stream_t stream) {
-  RART_CHECK_ARG(w2_rows && w2_frag && w2_rows != w2_frag, "rart_bottleneck_pack_w2: bad arguments");
-  RART_CHECK_ARG(c_mid == 64, "rart_bottleneck_pack_w2: c_mid must be 64");
-  hipLaunchKernelGGL(k_bneck_pack_w2, dim3(18), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w2_rows, (uint16_t*)w2_frag);
-  RART_CHECK_LAUNCH("rart_bottleneck_pack_w2");
-  return RART_OK;
-}
 
 // 1 if rart_bottleneck_fused_bf16 runs this block geometry
 extern "C" int rart_bottleneck_fused_supported(int c_io, int c_mid, int h, int w) {

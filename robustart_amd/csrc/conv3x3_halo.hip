@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct RartHaloDesc {
   const uint16_t* src;
-  const uint16_t* wgt;      // [C][9 * C] bf16, k = tap * C + c
+  const uint16_t* wgt;      // fragment-major table of the [C][9 * C] weights (rart_conv3x3_pack_frag_bf16)
   const float* bias;        // fp32 [C] or null
   const uint8_t* mask_bits; // 1 bit per output element or null
   uint8_t* sign_out;        // 1 bit per output element or null
@@ -114,10 +114,13 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_halo(const RartHaloDesc d) {
   const uint32_t n_hrows = n_rows + 2u;
 
   // ---- weight fragments of step 0 in flight first: lane -> output channel wn*32 + (lane & 31), k half (lane >> 5)
-  const uint16_t* wp = d.wgt + (size_t)(wn * 32 + (lane & 31)) * (9 * C) + (lane >> 5) * 8;
+  //      (fragment-major table, rart_conv3x3_pack_frag_bf16: the 64 lanes of a fragment load read 1 KiB contiguous; with
+  //      row-major weights every lane sat on its own cache line and the K loop was bound by the texture-address unit)
+  const uint16_t* wp = d.wgt + wn * 2048 + lane * 8;
+  constexpr int WST = Cf::WAVES_N * 2048;         // elements per K step: WAVES_N x 4 fragments x 512
   bf16x8 bq[2][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) bq[0][ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 16);
+  for (int ks = 0; ks < 4; ++ks) bq[0][ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
 
   {
     // halo tile: every load of the thread (<= 13 chunks of 16 bytes) in flight before the first LDS store
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_halo(const RartHaloDesc d) {
     const int tap = st / Cf::KSTEPS, kh = st % Cf::KSTEPS;
     if (st + 1 < Cf::STEPS) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bq[(st + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(wp + (st + 1) * 64 + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) bq[(st + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(wp + (st + 1) * WST + ks * 512);
     }
     // pin the prefetch at the top of the step: left alone, hipcc sinks these loads behind the step's MFMAs and then waits
     // vmcnt(0) at the next step's first MFMA -- an exposed L2 round trip per tap (measured: 138 cycles per MFMA)
@@ -274,10 +277,11 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
   const int H = d.h, W = d.w, NP = H * W;
   constexpr int W2 = 16;                                   // halo row stride (w <= 14)
   const size_t img_base = (size_t)blockIdx.x * NP;
-  const uint16_t* wp = d.wgt + (size_t)(wn * 32 + (lane & 31)) * (9 * IM_C) + (lane >> 5) * 8;
+  const uint16_t* wp = d.wgt + wn * 2048 + lane * 8;      // fragment-major table (see k_conv3x3_halo)
+  constexpr int WST = (IM_C / 32) * 2048;
   bf16x8 bq[2][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) bq[0][ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 16);
+  for (int ks = 0; ks < 4; ++ks) bq[0][ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
   {
     // the (h + 2) x (w + 2) ring-padded image, all 16 loads of a thread in flight before the first LDS store
     constexpr int U = IM_MAXPOS * IM_CP / IM_T;          // 16
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
     const int tap = st >> 2, kh = st & 3;
     if (st + 1 < 36) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bq[(st + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(wp + (st + 1) * 64 + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) bq[(st + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(wp + (st + 1) * WST + ks * 512);
     }
     __builtin_amdgcn_sched_barrier(0);                    // keep the prefetch ahead of this step's MFMAs (see k_conv3x3_halo)
     const int toff = (d.tap_dy[tap] * W2 + d.tap_dx[tap]) * 16;
@@ -383,6 +387,17 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
   }
 }
 
+// w [C][9C] (k = tap*C + c) -> fragment-major: element e of lane l of fragment (K step st of 64, column tile wn, ks) =
+// w[wn*32 + (l & 31)][st*64 + ks*16 + (l >> 5)*8 + e]; fragment index (st * C/32 + wn) * 4 + ks, 512 elements each
+__global__ void k_conv3x3_pack_frag(const uint16_t* __restrict__ w, uint16_t* __restrict__ o, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread
+  if (i >= 9 * C * C / 8) return;
+  const int nwn = C / 32;
+  const int l = i & 63, ks = (i >> 6) & 3, f = i >> 8, wn = f % nwn, st = f / nwn;
+  *reinterpret_cast<uint4*>(o + (size_t)i * 8) =
+      *reinterpret_cast<const uint4*>(w + (size_t)(wn * 32 + (l & 31)) * (9 * C) + st * 64 + ks * 16 + (l >> 5) * 8);
+}
+
 void magic_for(uint32_t dv, uint32_t& mg, uint32_t& sh) {      // exact for dividends < 2^31
   uint32_t l = 0;
   while ((1ull << l) < dv) ++l;
@@ -405,6 +420,16 @@ extern "C" int rart_conv3x3_halo_supported(int channels, int h, int w) {
   if (h < 1 || w < 1) return 0;
   if (channels == IM_C) return (h <= 2 * IM_MT && w <= 14) ? 1 : 0;    // one image per workgroup, halo row stride 16
   return halo_rows_per_block(channels, w) > 0 ? 1 : 0;
+}
+
+extern "C" int rart_conv3x3_pack_frag_bf16(const void* w_rows, void* w_frag, int channels, rart_stream_t stream) {
+  RART_CHECK_ARG(w_rows && w_frag && w_rows != w_frag, "rart_conv3x3_pack_frag_bf16: bad arguments");
+  RART_CHECK_ARG(channels == 64 || channels == 128 || channels == 256, "rart_conv3x3_pack_frag_bf16: channels must be 64, 128 or 256");
+  const int chunks = 9 * channels * channels / 8;
+  hipLaunchKernelGGL(k_conv3x3_pack_frag, dim3((chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w_rows,
+                     (uint16_t*)w_frag, channels);
+  RART_CHECK_LAUNCH("rart_conv3x3_pack_frag_bf16");
+  return RART_OK;
 }
 
 extern "C" int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const float* bias, const void* mask_bits, void* sign_out,

@@ -143,16 +143,16 @@ class ResNet50Engine:
         self._pack_frag_tables()
 
     def _pack_frag_tables(self):
-        """MFMA-fragment-ordered copies of the 3x3 tables the fused Bottleneck kernel streams from L2 (a fragment load then
-        reads 1 KiB contiguous instead of touching 32 cache lines)."""
+        """MFMA-fragment-ordered copies of the 3x3 tables the LDS-resident kernels (conv3x3_halo.hip, bottleneck_fused.hip)
+        stream from L2: a fragment load then reads 1 KiB contiguous instead of touching 32 cache lines."""
         torch = _lib.require_gpu()
         sp = _lib.stream_ptr()
         for ca, cb, cc, ds in self.blocks:
-            if ds is None and cb.r == 3 and cb.stride == 1 and cb.cin == 64 and cb.cout == 64:
+            if cb.r == 3 and cb.stride == 1 and cb.cin == cb.cout and cb.cin in (64, 128, 256):
                 for name, tab in (('w_fwd_frag', cb.w_fwd), ('w_bwd_frag', cb.bwd[0][2])):
                     if getattr(cb, name, None) is None:
-                        setattr(cb, name, torch.empty(64 * 576, dtype=torch.bfloat16, device=self.device))
-                    _lib.check(self.lib.rart_bottleneck_pack_w2(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), 64, sp))
+                        setattr(cb, name, torch.empty(9 * cb.cin * cb.cin, dtype=torch.bfloat16, device=self.device))
+                    _lib.check(self.lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), cb.cin, sp))
 
     @staticmethod
     def _stem_bwd_table(wb):
@@ -276,7 +276,7 @@ class ResNet50Engine:
 
     def _halo_ok(self, c, hw):
         return (self.halo_conv3x3 and c.r == 3 and c.s == 3 and c.stride == 1 and c.pad == 1
-                and c.cin == c.cout and self.lib.rart_conv3x3_halo_supported(c.cin, hw[0], hw[1]))
+                and c.cin == c.cout and getattr(c, 'w_fwd_frag', None) is not None and self.lib.rart_conv3x3_halo_supported(c.cin, hw[0], hw[1]))
 
     def _halo(self, src, w, dst, B, hw, ch, taps, bias=None, mask=None, sign=None, relu=False):
         if self.profile is not None:
@@ -323,7 +323,7 @@ class ResNet50Engine:
         B = x.shape[0]
         oh, ow = xhw[0] // c.stride, xhw[1] // c.stride
         if res is None and self._halo_ok(c, xhw):
-            return self._halo(x, c.w_fwd, out, B, xhw, c.cin, c.fwd_taps, bias=c.bias, sign=sign, relu=relu)
+            return self._halo(x, c.w_fwd_frag, out, B, xhw, c.cin, c.fwd_taps, bias=c.bias, sign=sign, relu=relu)
         self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
                    bias=c.bias, res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride), sign_out=sign)
 
@@ -334,7 +334,7 @@ class ResNet50Engine:
         B = dz.shape[0]
         fl = F_MASK_BITS if (mask is not None and mask.dtype == torch.uint8) else 0
         if res is None and (mask is None or fl) and self._halo_ok(c, dx_hw):
-            return self._halo(dz, c.bwd[0][2], dx, B, dx_hw, c.cin, c.bwd[0][1], mask=mask)
+            return self._halo(dz, c.w_bwd_frag, dx, B, dx_hw, c.cin, c.bwd[0][1], mask=mask)
         for parity, taps, w in c.bwd:
             if parity is None:
                 self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res, mask=mask,

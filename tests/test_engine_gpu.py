@@ -230,6 +230,17 @@ def test_backward_to_input(setup, B, HW, kind):
         finally:
             eng.fused_stem_fwd = True
         eng.last_acts, eng.last_dlogits = acts, dl_keep
+    if eng.fused_bottleneck:
+        # the fused Bottleneck kernel never writes the two inner activations of layer1's identity blocks; the reference below
+        # wants them for the ReLU decisions: the three-launch chain fills the same buffers (and must agree on the logits)
+        acts, dl_keep = eng.last_acts, eng.last_dlogits
+        try:
+            eng.fused_bottleneck = False
+            lg_u, _ = eng._forward(x.detach().float().contiguous(), False, MEAN, STD, keep=True)
+        finally:
+            eng.fused_bottleneck = True
+        assert torch.equal(lg_u, logits)
+        eng.last_acts, eng.last_dlogits = acts, dl_keep
     # (1) rigorous: same masks as the engine's forward -> only fp32-accumulate / bf16-rounding noise remains
     ref = _reference_backward_with_engine_masks(eng, eng.last_acts, eng.last_dlogits, STD).cuda()
     for i in range(B):
@@ -425,7 +436,10 @@ def test_halo_conv3x3_forward_and_backward_vs_fp64(C, B, H, W):
     y = torch.empty_like(x)
     sign = torch.zeros(B, H, W, C // 8, dtype=torch.uint8, device='cuda')
     sp = _lib.stream_ptr()
-    _lib.check(lib.rart_conv3x3_halo_bf16(_lib.ptr(x), _lib.ptr(c.w_fwd), _lib.ptr(c.bias), None, _lib.ptr(sign), _lib.ptr(y),
+    wf, wb_ = (torch.empty(9 * C * C, dtype=torch.bfloat16, device='cuda') for _ in range(2))
+    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(c.w_fwd), _lib.ptr(wf), C, sp))
+    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(c.bwd[0][2]), _lib.ptr(wb_), C, sp))
+    _lib.check(lib.rart_conv3x3_halo_bf16(_lib.ptr(x), _lib.ptr(wf), _lib.ptr(c.bias), None, _lib.ptr(sign), _lib.ptr(y),
                                           B, H, W, C, _cints([t[0] for t in c.fwd_taps]), _cints([t[1] for t in c.fwd_taps]),
                                           1, sp))
     wq = conv.weight.detach().to(torch.bfloat16).double()
@@ -440,7 +454,7 @@ def test_halo_conv3x3_forward_and_backward_vs_fp64(C, B, H, W):
     mask = torch.randint(0, 256, (B, H, W, C // 8), generator=g, dtype=torch.uint8).cuda()
     dx = torch.empty_like(dz)
     taps = c.bwd[0][1]
-    _lib.check(lib.rart_conv3x3_halo_bf16(_lib.ptr(dz), _lib.ptr(c.bwd[0][2]), None, _lib.ptr(mask), None, _lib.ptr(dx),
+    _lib.check(lib.rart_conv3x3_halo_bf16(_lib.ptr(dz), _lib.ptr(wb_), None, _lib.ptr(mask), None, _lib.ptr(dx),
                                           B, H, W, C, _cints([t[0] for t in taps]), _cints([t[1] for t in taps]), 0, sp))
     refg = torch.nn.grad.conv2d_input((B, C, H, W), wq, dz.cpu().double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     mb = torch.from_numpy(np.unpackbits(mask.cpu().numpy(), axis=-1, bitorder='little')).double()
@@ -530,8 +544,8 @@ def test_fused_bottleneck_forward_and_backward_vs_fp64(B):
     sp = _lib.stream_ptr()
     dy, dx_ = _cints([t[0] for t in cb.fwd_taps]), _cints([t[1] for t in cb.fwd_taps])
     w2f, w2b = torch.empty(64 * 576, dtype=torch.bfloat16, device='cuda'), torch.empty(64 * 576, dtype=torch.bfloat16, device='cuda')
-    _lib.check(lib.rart_bottleneck_pack_w2(_lib.ptr(cb.w_fwd), _lib.ptr(w2f), 64, sp))
-    _lib.check(lib.rart_bottleneck_pack_w2(_lib.ptr(cb.bwd[0][2]), _lib.ptr(w2b), 64, sp))
+    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(cb.w_fwd), _lib.ptr(w2f), 64, sp))
+    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(cb.bwd[0][2]), _lib.ptr(w2b), 64, sp))
     _lib.check(lib.rart_bottleneck_fused_bf16(_lib.ptr(x), _lib.ptr(ca.w_fwd), _lib.ptr(w2f), _lib.ptr(cc.w_fwd),
                                               _lib.ptr(ca.bias), _lib.ptr(cb.bias), _lib.ptr(cc.bias), _lib.ptr(s1), _lib.ptr(s2),
                                               _lib.ptr(s3), _lib.ptr(y), B, H, W, 256, 64, dy, dx_, 0, sp))
