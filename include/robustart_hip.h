@@ -307,6 +307,8 @@ int rart_igemm_set_bk64_min_k(long long k);
  * (otherwise use rart_conv_igemm_bf16, which computes the same function). */
 int rart_conv3x3_halo_supported(int channels, int h, int w);
 int rart_conv3x3_pack_frag_bf16(const void* w_rows, void* w_frag, int channels, rart_stream_t stream);
+/* The same re-ordering for any bf16 [rows][k] row-major matrix (rows % 32 == 0, k % 64 == 0): fragment (st, wn, ks) as above. */
+int rart_pack_frag_bf16(const void* w_rows, void* w_frag, int rows, int k, rart_stream_t stream);
 int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const float* bias, const void* mask_bits, void* sign_out,
                            void* dst, int n, int h, int w, int channels, const int* tap_dy, const int* tap_dx, int relu,
                            rart_stream_t stream);
@@ -325,6 +327,20 @@ int rart_bottleneck_fused_supported(int c_io, int c_mid, int h, int w);
 int rart_bottleneck_fused_bf16(const void* x, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
                                const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
                                int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);
+
+/* The FIRST Bottleneck of the layer (projection shortcut, stride 1) as one kernel; supported geometry: c_in 64, c_mid 64,
+ * c_out 256, 56 x 56 (ResNet-50 layer1 block 0).  Same kernel family and conventions as rart_bottleneck_fused_bf16.
+ *   backward = 0: x bf16 [n][h][w][c_in]; w1 [c_mid][c_in]; w2 fragment-ordered 3x3 table; w3 [c_out][c_mid]; w4 = the
+ *                 shortcut's [c_out][c_in] table in fragment order (rart_pack_frag_bf16(rows c_out, k c_in)); b3 = conv3 bias +
+ *                 shortcut bias; out [n][h][w][c_out] = relu(w3.a2 + w4.x + b3); m1..m3 sign OUTPUTS or NULL.
+ *   backward = 1: x = gradient at the block output [n][h][w][c_out]; w1 = conv3's transposed table [c_mid][c_out]; w2 = conv2's
+ *                 backward table (fragment order, flipped taps); w3 = the shortcut's transposed table [c_in][c_out]; w4 = conv1's
+ *                 transposed table [c_in][c_mid] (row-major); out [n][h][w][c_in] = m3 . (w4.(m2.(w2*(m1.(w1.x)))) + w3.x). */
+int rart_bottleneck_first_supported(int c_in, int c_mid, int c_out, int h, int w);
+int rart_bottleneck_first_bf16(const void* x, const void* w1, const void* w2, const void* w3, const void* w4, const float* b1,
+                               const float* b2, const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w,
+                               int c_in, int c_mid, int c_out, const int* tap_dy, const int* tap_dx, int backward,
+                               rart_stream_t stream);
 
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
  * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:

@@ -38,7 +38,8 @@ struct RartBneckDesc {
   const uint16_t* x;        // [n][56][56][256] bf16: the block input (forward) / the masked gradient at the block output (backward)
   const uint16_t* w1;       // [64][256]   rows = stage-A output channel
   const uint16_t* w2;       // fragment-major 3x3 table (rart_conv3x3_pack_frag_bf16): [tap][blk][s][lane][8]
-  const uint16_t* w3;       // [256][64]   rows = stage-C output channel
+  const uint16_t* w3;       // [256][64]   rows = stage-C output channel ([64][256] in the first block's backward)
+  const uint16_t* w4;       // first block only: the projection-shortcut table (see rart_bottleneck_first_bf16)
   const float* b1;
   const float* b2;
   const float* b3;          // fp32 biases or null
@@ -95,8 +96,14 @@ constexpr int BF_BIAS = (64 + 64 + 256) * 4;            // the three bias vector
 constexpr int BF_LDE = 68;                              // staging row: 64 floats + 4
 static_assert(4 * 32 * BF_LDE * 4 <= BF_T1, "epilogue staging must fit the halo tile");
 
-template <bool BWD>
+// FIRST = the layer's first block (64 input channels, projection shortcut W4 instead of the identity): stage A reads 64
+// channels (forward) and stage C folds the shortcut in as extra K (forward: [a2 | x] . [W3 | W4]^T; backward: 64 output
+// channels = d_a1 . W1^T + g . W4^T)
+template <bool BWD, bool FIRST>
 __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) {
+  constexpr bool FF = FIRST && !BWD, FB = FIRST && BWD;
+  constexpr int CIN = FF ? 64 : 256;          // channels of d.x
+  constexpr int NJ = CIN / 32;                // 32-channel K steps of stage A
   __shared__ __attribute__((aligned(16))) uint8_t lds[BF_T1 + BF_WB + BF_BIAS];
   uint8_t* const sT = lds;
   uint8_t* const sW = lds + BF_T1;
@@ -120,11 +127,20 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
   const long long pos0 = ((long long)img * BF_H + y0) * BF_W;      // raster index of the first output position
 
   // ---- prologue: W1 -> LDS (chunk c of row r at chunk c ^ (r & 31)), zero columns of T1
+  if constexpr (FF) {      // W1 is 64 x 64: 128-byte rows, chunk c of row r at chunk c ^ ((r >> 1) & 7)
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int idx = u * 256 + tid, row = idx >> 5, chunk = idx & 31;
-    const uint4 v = *reinterpret_cast<const uint4*>(d.w1 + idx * 8);
-    *reinterpret_cast<uint4*>(sW + row * 512 + ((chunk ^ (row & 31)) << 4)) = v;
+    for (int u = 0; u < 2; ++u) {
+      const int idx = u * 256 + tid, row = idx >> 3, chunk = idx & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(d.w1 + idx * 8);
+      *reinterpret_cast<uint4*>(sW + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u * 256 + tid, row = idx >> 5, chunk = idx & 31;
+      const uint4 v = *reinterpret_cast<const uint4*>(d.w1 + idx * 8);
+      *reinterpret_cast<uint4*>(sW + row * 512 + ((chunk ^ (row & 31)) << 4)) = v;
+    }
   }
   {
     float b = 0.f;                                   // tid: 0..63 b1, 64..127 b2; b3 below
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
   {
     const int c16 = lane & 15, kq = lane >> 4;
     constexpr int NU = (BF_NQ + 31) / 32;
-    bf16x8 xf[2][2][8];
+    bf16x8 xf[2][2][NJ];
     bool valid[2][2];
     int q[2][2];
     unsigned long long mbits[2][2];
@@ -154,9 +170,9 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
     q[SET][t] = (U) * 32 + t * 16 + c16;                                                                        \
     const int hr_ = q[SET][t] / BF_W;                                                                           \
     valid[SET][t] = q[SET][t] < BF_NQ && (unsigned)(y0 - 1 + hr_) < (unsigned)BF_H;                             \
-    const uint16_t* src_ = d.x + (pos0 - BF_W + q[SET][t]) * 256 + kq * 8;                                      \
+    const uint16_t* src_ = d.x + (pos0 - BF_W + q[SET][t]) * CIN + kq * 8;                                      \
     mbits[SET][t] = 0;                                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                             \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                             \
       uint4 v_ = make_uint4(0, 0, 0, 0);                                                                        \
       if (valid[SET][t]) v_ = *reinterpret_cast<const uint4*>(src_ + j * 32);                                   \
       xf[SET][t][j] = __builtin_bit_cast(bf16x8, v_);                                                           \
@@ -182,11 +198,12 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
         acc[1][blk] = bv;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NJ; ++j) {
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
           const int row = blk * 16 + c16;
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + row * 512 + (((j * 4 + kq) ^ (row & 31)) << 4));
+          const bf16x8 wf = FF ? *reinterpret_cast<const bf16x8*>(sW + row * 128 + (((j * 4 + kq) ^ ((row >> 1) & 7)) << 4))
+                               : *reinterpret_cast<const bf16x8*>(sW + row * 512 + (((j * 4 + kq) ^ (row & 31)) << 4));
           acc[0][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[cur][0][j], acc[0][blk], 0, 0, 0);
           acc[1][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[cur][1][j], acc[1][blk], 0, 0, 0);
         }
@@ -329,7 +346,10 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
   RART_STAMP(4)
   // W3 -> LDS: chunk c of row r at chunk c ^ ((r >> 1) & 7) (stage A's readers of this region passed the barrier above)
 #define RART_W3_STORE(U)                                                                          \
-  {                                                                                               \
+  if constexpr (FB) {      /* 64 x 256 shortcut table: the stage-A layout (512-byte rows) */       \
+    const int idx = (U) * 256 + tid, row = idx >> 5, chunk = idx & 31;                            \
+    *reinterpret_cast<uint4*>(sW + row * 512 + ((chunk ^ (row & 31)) << 4)) = w3r##U;             \
+  } else {                                                                                        \
     const int idx = (U) * 256 + tid, row = idx >> 3, chunk = idx & 7;                             \
     *reinterpret_cast<uint4*>(sW + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = w3r##U;       \
   }
@@ -344,50 +364,126 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
   uint32_t woff[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) woff[s] = (uint32_t)(p32 * 128 + (((2 * s + h) ^ ((p32 >> 1) & 7)) << 4));
-  // rounds r8 = t * 4 + rd: the residual / mask loads of round r8 + 1 are in flight during round r8's MFMAs and epilogue
-  u32x4 rv[2][4];
-  uint32_t mb[2][4];
-#define RART_BN_LOAD_C(SET, R8)                                                                   \
-  _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {                                              \
-    const long long e_ = (pos0 + pt[(R8) >> 2] * 32 + qd * 8 + rw) * 256 + ((R8)&3) * 64 + cw * 8; \
-    rv[SET][qd] = *reinterpret_cast<const u32x4*>(d.x + e_);                                      \
-    mb[SET][qd] = 0xFFu;                                                                          \
-    if (BWD && d.m3) mb[SET][qd] = d.m3[e_ >> 3];                                                 \
-  }
-  const int n_rounds = two ? 8 : 4;
-  RART_BN_LOAD_C(0, 0)
+  if constexpr (FF) {
+    // ---- first block, forward: out[p][256] = [a2 | x][p][128] . [W3 | W4]^T: W3 from LDS, the shortcut table W4 in fragment
+    //      order from L2 one round ahead, x fragments straight from global memory; rounds outer, tiles inner (W4 fragments
+    //      serve both tiles)
+    bf16x8 xcf[2][4];
 #pragma unroll
-  for (int r8 = 0; r8 < 8; ++r8) {
-    if (r8 >= 4 && !two) continue;             // (a `break` on a run-time bound keeps hipcc from unrolling: a2f[t] would go to scratch)
-    const int t = r8 >> 2, rd = r8 & 3, cur = r8 & 1;
-    const long long pb = pos0 + pt[t] * 32;
-    if (r8 + 1 < n_rounds) {
-      if (cur == 0) { RART_BN_LOAD_C(1, r8 + 1) } else { RART_BN_LOAD_C(0, r8 + 1) }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        xcf[t][s] = *reinterpret_cast<const bf16x8*>(d.x + (pos0 + pt[t] * 32 + p32) * 64 + (2 * s + h) * 8);
+    const uint16_t* w4p = d.w4 + lane * 8;
+    bf16x8 wd[2][2][4];
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wd[0][b2][s] = *reinterpret_cast<const bf16x8*>(w4p + (b2 * 4 + s) * 512);
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      if (rd + 1 < 4) {
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            wd[(rd + 1) & 1][b2][s] = *reinterpret_cast<const bf16x8*>(w4p + (((rd + 1) * 2 + b2) * 4 + s) * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two) continue;
+        const long long pb = pos0 + pt[t] * 32;
+        f32x16 acc[2];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + 128 + (rd * 2 + b2) * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[b2][4 * g + i] = bv[i];
+          }
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + (rd * 2 + b2) * 4096 + woff[s]);
+            acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a2f[t][s], acc[b2], 0, 0, 0);
+          }
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wd[rd & 1][b2][s], xcf[t][s], acc[b2], 0, 0, 0);
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[b2][4 * g], acc[b2][4 * g + 1], acc[b2][4 * g + 2], acc[b2][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(sE + p32 * BF_LDE + b2 * 32 + 8 * g + 4 * h) = v;
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int r = qd * 8 + rw;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sE + r * BF_LDE + cw * 8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(sE + r * BF_LDE + cw * 8 + 4);
+          const uint4 o = make_uint4(relu_bf16x2(pack_bf16x2(v0[0], v0[1])), relu_bf16x2(pack_bf16x2(v0[2], v0[3])),
+                                     relu_bf16x2(pack_bf16x2(v1[0], v1[1])), relu_bf16x2(pack_bf16x2(v1[2], v1[3])));
+          const long long e = (pb + r) * 256 + rd * 64 + cw * 8;
+          *reinterpret_cast<uint4*>(d.out + e) = o;
+          if (d.m3) d.m3[e >> 3] = (uint8_t)sign_byte(o);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    {
+  } else if constexpr (FB) {
+    // ---- first block, backward: dx[p][64] = d_a1[p][64] . W1^T + g[p][256] . W4^T: W1^T fragments (d.w4, 64 x 64 row-major) in
+    //      registers, W4^T (64 x 256) from LDS, g fragments of the centre rows straight from global memory
+    bf16x8 w1t[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        w1t[blk][s] = *reinterpret_cast<const bf16x8*>(d.w4 + (blk * 32 + p32) * 64 + (2 * s + h) * 8);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && !two) continue;
+      const long long pb = pos0 + pt[t] * 32;
+      bf16x8 gf[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) gf[s] = *reinterpret_cast<const bf16x8*>(d.x + (pb + p32) * 256 + (2 * s + h) * 8);
+      uint32_t mbq[4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        mbq[qd] = 0xFFu;
+        if (d.m3) mbq[qd] = d.m3[((pb + qd * 8 + rw) * 64 + cw * 8) >> 3];
+      }
       f32x16 acc[2];
 #pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2)
+      for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + 128 + (rd * 2 + b2) * 32 + 8 * g + 4 * h);
+        for (int i = 0; i < 16; ++i) acc[blk][i] = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[b2][4 * g + i] = bv[i];
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1t[blk][s], a2f[t][s], acc[blk], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + (blk * 32 + p32) * 512 + (((2 * s + h) ^ p32) << 4));
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, gf[s], acc[blk], 0, 0, 0);
         }
 #pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + (rd * 2 + b2) * 4096 + woff[s]);
-          acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a2f[t][s], acc[b2], 0, 0, 0);
-        }
-#pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2)
+      for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 v = {acc[b2][4 * g], acc[b2][4 * g + 1], acc[b2][4 * g + 2], acc[b2][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(sE + p32 * BF_LDE + b2 * 32 + 8 * g + 4 * h) = v;
+          const f32x4 v = {acc[blk][4 * g], acc[blk][4 * g + 1], acc[blk][4 * g + 2], acc[blk][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(sE + p32 * BF_LDE + blk * 32 + 8 * g + 4 * h) = v;
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -397,26 +493,90 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
         const int r = qd * 8 + rw;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(sE + r * BF_LDE + cw * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(sE + r * BF_LDE + cw * 8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const uint32_t rr[4] = {rv[cur][qd][0], rv[cur][qd][1], rv[cur][qd][2], rv[cur][qd][3]};
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[2 * j] += __uint_as_float(rr[j] << 16);
-          v[2 * j + 1] += __uint_as_float(rr[j] & 0xFFFF0000u);
-          o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-          if (BWD) o[j] &= halves_from_bits(mb[cur][qd], j);
-          else o[j] = relu_bf16x2(o[j]);
-        }
-        const long long e = (pb + r) * 256 + rd * 64 + cw * 8;
-        *reinterpret_cast<uint4*>(d.out + e) = make_uint4(o[0], o[1], o[2], o[3]);
-        if (!BWD && d.m3) d.m3[e >> 3] = (uint8_t)sign_byte(make_uint4(o[0], o[1], o[2], o[3]));
+        const uint4 o = make_uint4(pack_bf16x2(v0[0], v0[1]) & halves_from_bits(mbq[qd], 0),
+                                   pack_bf16x2(v0[2], v0[3]) & halves_from_bits(mbq[qd], 1),
+                                   pack_bf16x2(v1[0], v1[1]) & halves_from_bits(mbq[qd], 2),
+                                   pack_bf16x2(v1[2], v1[3]) & halves_from_bits(mbq[qd], 3));
+        *reinterpret_cast<uint4*>(d.out + (pb + r) * 64 + cw * 8) = o;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-  }
+  } else {
+    // rounds r8 = t * 4 + rd: the residual / mask loads of round r8 + 1 are in flight during round r8's MFMAs and epilogue
+    u32x4 rv[2][4];
+    uint32_t mb[2][4];
+#define RART_BN_LOAD_C(SET, R8)                                                                   \
+    _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {                                              \
+      const long long e_ = (pos0 + pt[(R8) >> 2] * 32 + qd * 8 + rw) * 256 + ((R8)&3) * 64 + cw * 8; \
+      rv[SET][qd] = *reinterpret_cast<const u32x4*>(d.x + e_);                                      \
+      mb[SET][qd] = 0xFFu;                                                                          \
+      if (BWD && d.m3) mb[SET][qd] = d.m3[e_ >> 3];                                                 \
+    }
+    const int n_rounds = two ? 8 : 4;
+    RART_BN_LOAD_C(0, 0)
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+      if (r8 >= 4 && !two) continue;             // (a `break` on a run-time bound keeps hipcc from unrolling: a2f[t] would go to scratch)
+      const int t = r8 >> 2, rd = r8 & 3, cur = r8 & 1;
+      const long long pb = pos0 + pt[t] * 32;
+      if (r8 + 1 < n_rounds) {
+        if (cur == 0) { RART_BN_LOAD_C(1, r8 + 1) } else { RART_BN_LOAD_C(0, r8 + 1) }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        f32x16 acc[2];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + 128 + (rd * 2 + b2) * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[b2][4 * g + i] = bv[i];
+          }
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + (rd * 2 + b2) * 4096 + woff[s]);
+            acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a2f[t][s], acc[b2], 0, 0, 0);
+          }
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[b2][4 * g], acc[b2][4 * g + 1], acc[b2][4 * g + 2], acc[b2][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(sE + p32 * BF_LDE + b2 * 32 + 8 * g + 4 * h) = v;
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int r = qd * 8 + rw;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sE + r * BF_LDE + cw * 8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(sE + r * BF_LDE + cw * 8 + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          const uint32_t rr[4] = {rv[cur][qd][0], rv[cur][qd][1], rv[cur][qd][2], rv[cur][qd][3]};
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] += __uint_as_float(rr[j] << 16);
+            v[2 * j + 1] += __uint_as_float(rr[j] & 0xFFFF0000u);
+            o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+            if (BWD) o[j] &= halves_from_bits(mb[cur][qd], j);
+            else o[j] = relu_bf16x2(o[j]);
+          }
+          const long long e = (pb + r) * 256 + rd * 64 + cw * 8;
+          *reinterpret_cast<uint4*>(d.out + e) = make_uint4(o[0], o[1], o[2], o[3]);
+          if (!BWD && d.m3) d.m3[e >> 3] = (uint8_t)sign_byte(make_uint4(o[0], o[1], o[2], o[3]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
 #undef RART_BN_LOAD_C
+  }
 #ifdef RART_BNECK_TS
   RART_STAMP(6)
   if (d.ts && lane == 0)
@@ -430,29 +590,58 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
 extern "C" int rart_bottleneck_fused_supported(int c_io, int c_mid, int h, int w) {
   return (c_io == 256 && c_mid == 64 && h == BF_H && w == BF_W) ? 1 : 0;
 }
+// 1 if rart_bottleneck_first_bf16 runs this block geometry
+extern "C" int rart_bottleneck_first_supported(int c_in, int c_mid, int c_out, int h, int w) {
+  return (c_in == 64 && c_mid == 64 && c_out == 256 && h == BF_H && w == BF_W) ? 1 : 0;
+}
+
+static int bneck_launch(const void* x, const void* w1, const void* w2, const void* w3, const void* w4, const float* b1,
+                        const float* b2, const float* b3, void* m1, void* m2, void* m3, void* out, int n, const int* tap_dy,
+                        const int* tap_dx, int backward, int first, rart_stream_t stream, const char* who) {
+  RART_CHECK_ARG(x && w1 && w2 && w3 && out && tap_dy && tap_dx && n > 0 && (!first || w4), "%s: bad arguments", who);
+  RART_CHECK_ARG(x != out, "%s: out must not alias x (neighbouring tiles read each other's halo rows)", who);
+  RART_CHECK_ARG(!backward || (m1 && m2), "%s: the backward pass needs both inner masks", who);
+  RART_CHECK_ARG((long long)n * BF_H * BF_W * 256 < (1ll << 31), "%s: tensor must stay below 2^31 elements", who);
+  RartBneckDesc d;
+  d.x = (const uint16_t*)x; d.w1 = (const uint16_t*)w1; d.w2 = (const uint16_t*)w2; d.w3 = (const uint16_t*)w3;
+  d.w4 = (const uint16_t*)w4;
+  d.b1 = b1; d.b2 = b2; d.b3 = b3;
+  d.m1 = (uint8_t*)m1; d.m2 = (uint8_t*)m2; d.m3 = (uint8_t*)m3;
+  d.out = (uint16_t*)out;
+  d.tiles = (uint32_t)n * BF_TPI;
+#ifdef RART_BNECK_TS
+  d.ts = nullptr;
+#endif
+  for (int t = 0; t < 9; ++t) {
+    RART_CHECK_ARG(tap_dy[t] >= -1 && tap_dy[t] <= 1 && tap_dx[t] >= -1 && tap_dx[t] <= 1, "%s: taps must lie in -1..1", who);
+    d.tap_off[t] = (tap_dy[t] * BF_SW + tap_dx[t]) * 16;
+  }
+  const dim3 grid(d.tiles), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (first && backward) hipLaunchKernelGGL((k_bottleneck56<true, true>), grid, block, 0, st, d);
+  else if (first) hipLaunchKernelGGL((k_bottleneck56<false, true>), grid, block, 0, st, d);
+  else if (backward) hipLaunchKernelGGL((k_bottleneck56<true, false>), grid, block, 0, st, d);
+  else hipLaunchKernelGGL((k_bottleneck56<false, false>), grid, block, 0, st, d);
+  RART_CHECK_LAUNCH(who);
+  return RART_OK;
+}
 
 extern "C" int rart_bottleneck_fused_bf16(const void* x, const void* w1, const void* w2, const void* w3, const float* b1,
                                           const float* b2, const float* b3, void* m1, void* m2, void* m3, void* out, int n,
                                           int h, int w, int c_io, int c_mid, const int* tap_dy, const int* tap_dx, int backward,
                                           rart_stream_t stream) {
-  RART_CHECK_ARG(x && w1 && w2 && w3 && out && tap_dy && tap_dx && n > 0, "rart_bottleneck_fused_bf16: bad arguments");
   RART_CHECK_ARG(rart_bottleneck_fused_supported(c_io, c_mid, h, w),
                  "rart_bottleneck_fused_bf16: unsupported geometry (256 -> 64 -> 256 channels at 56 x 56 only)");
-  RART_CHECK_ARG(x != out, "rart_bottleneck_fused_bf16: out must not alias x (neighbouring tiles read each other's halo rows)");
-  RART_CHECK_ARG(!backward || (m1 && m2), "rart_bottleneck_fused_bf16: the backward pass needs both inner masks");
-  RART_CHECK_ARG((long long)n * h * w * c_io < (1ll << 31), "rart_bottleneck_fused_bf16: tensor must stay below 2^31 elements");
-  RartBneckDesc d;
-  d.x = (const uint16_t*)x; d.w1 = (const uint16_t*)w1; d.w2 = (const uint16_t*)w2; d.w3 = (const uint16_t*)w3;
-  d.b1 = b1; d.b2 = b2; d.b3 = b3;
-  d.m1 = (uint8_t*)m1; d.m2 = (uint8_t*)m2; d.m3 = (uint8_t*)m3;
-  d.out = (uint16_t*)out;
-  d.tiles = (uint32_t)n * BF_TPI;
-  for (int t = 0; t < 9; ++t) {
-    RART_CHECK_ARG(tap_dy[t] >= -1 && tap_dy[t] <= 1 && tap_dx[t] >= -1 && tap_dx[t] <= 1, "rart_bottleneck_fused_bf16: taps must lie in -1..1");
-    d.tap_off[t] = (tap_dy[t] * BF_SW + tap_dx[t]) * 16;
-  }
-  if (backward) hipLaunchKernelGGL(k_bottleneck56<true>, dim3(d.tiles), dim3(256), 0, (hipStream_t)stream, d);
-  else hipLaunchKernelGGL(k_bottleneck56<false>, dim3(d.tiles), dim3(256), 0, (hipStream_t)stream, d);
-  RART_CHECK_LAUNCH("rart_bottleneck_fused_bf16");
-  return RART_OK;
+  return bneck_launch(x, w1, w2, w3, nullptr, b1, b2, b3, m1, m2, m3, out, n, tap_dy, tap_dx, backward, 0, stream,
+                      "rart_bottleneck_fused_bf16");
+}
+
+extern "C" int rart_bottleneck_first_bf16(const void* x, const void* w1, const void* w2, const void* w3, const void* w4,
+                                          const float* b1, const float* b2, const float* b3, void* m1, void* m2, void* m3,
+                                          void* out, int n, int h, int w, int c_in, int c_mid, int c_out, const int* tap_dy,
+                                          const int* tap_dx, int backward, rart_stream_t stream) {
+  RART_CHECK_ARG(rart_bottleneck_first_supported(c_in, c_mid, c_out, h, w),
+                 "rart_bottleneck_first_bf16: unsupported geometry (64 -> 64 -> 256 channels at 56 x 56 only)");
+  return bneck_launch(x, w1, w2, w3, w4, b1, b2, b3, m1, m2, m3, out, n, tap_dy, tap_dx, backward, 1, stream,
+                      "rart_bottleneck_first_bf16");
 }

@@ -387,15 +387,15 @@ __global__ __launch_bounds__(IM_T, 1) void k_conv3x3_image256(const RartHaloDesc
   }
 }
 
-// w [C][9C] (k = tap*C + c) -> fragment-major: element e of lane l of fragment (K step st of 64, column tile wn, ks) =
-// w[wn*32 + (l & 31)][st*64 + ks*16 + (l >> 5)*8 + e]; fragment index (st * C/32 + wn) * 4 + ks, 512 elements each
-__global__ void k_conv3x3_pack_frag(const uint16_t* __restrict__ w, uint16_t* __restrict__ o, int C) {
+// w [rows][k] row-major -> fragment-major: element e of lane l of fragment (K step st of 64, row tile wn, ks) =
+// w[wn*32 + (l & 31)][st*64 + ks*16 + (l >> 5)*8 + e]; fragment index (st * rows/32 + wn) * 4 + ks, 512 elements each
+__global__ void k_pack_frag(const uint16_t* __restrict__ w, uint16_t* __restrict__ o, int rows, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread
-  if (i >= 9 * C * C / 8) return;
-  const int nwn = C / 32;
+  if (i >= rows * k / 8) return;
+  const int nwn = rows / 32;
   const int l = i & 63, ks = (i >> 6) & 3, f = i >> 8, wn = f % nwn, st = f / nwn;
   *reinterpret_cast<uint4*>(o + (size_t)i * 8) =
-      *reinterpret_cast<const uint4*>(w + (size_t)(wn * 32 + (l & 31)) * (9 * C) + st * 64 + ks * 16 + (l >> 5) * 8);
+      *reinterpret_cast<const uint4*>(w + (size_t)(wn * 32 + (l & 31)) * k + st * 64 + ks * 16 + (l >> 5) * 8);
 }
 
 void magic_for(uint32_t dv, uint32_t& mg, uint32_t& sh) {      // exact for dividends < 2^31
@@ -422,14 +422,19 @@ extern "C" int rart_conv3x3_halo_supported(int channels, int h, int w) {
   return halo_rows_per_block(channels, w) > 0 ? 1 : 0;
 }
 
-extern "C" int rart_conv3x3_pack_frag_bf16(const void* w_rows, void* w_frag, int channels, rart_stream_t stream) {
-  RART_CHECK_ARG(w_rows && w_frag && w_rows != w_frag, "rart_conv3x3_pack_frag_bf16: bad arguments");
-  RART_CHECK_ARG(channels == 64 || channels == 128 || channels == 256, "rart_conv3x3_pack_frag_bf16: channels must be 64, 128 or 256");
-  const int chunks = 9 * channels * channels / 8;
-  hipLaunchKernelGGL(k_conv3x3_pack_frag, dim3((chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w_rows,
-                     (uint16_t*)w_frag, channels);
-  RART_CHECK_LAUNCH("rart_conv3x3_pack_frag_bf16");
+extern "C" int rart_pack_frag_bf16(const void* w_rows, void* w_frag, int rows, int k, rart_stream_t stream) {
+  RART_CHECK_ARG(w_rows && w_frag && w_rows != w_frag, "rart_pack_frag_bf16: bad arguments");
+  RART_CHECK_ARG(rows > 0 && rows % 32 == 0 && k > 0 && k % 64 == 0, "rart_pack_frag_bf16: rows must be a multiple of 32, k of 64");
+  const int chunks = rows * k / 8;
+  hipLaunchKernelGGL(k_pack_frag, dim3((chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w_rows,
+                     (uint16_t*)w_frag, rows, k);
+  RART_CHECK_LAUNCH("rart_pack_frag_bf16");
   return RART_OK;
+}
+
+extern "C" int rart_conv3x3_pack_frag_bf16(const void* w_rows, void* w_frag, int channels, rart_stream_t stream) {
+  RART_CHECK_ARG(channels == 64 || channels == 128 || channels == 256, "rart_conv3x3_pack_frag_bf16: channels must be 64, 128 or 256");
+  return rart_pack_frag_bf16(w_rows, w_frag, channels, 9 * channels, stream);
 }
 
 extern "C" int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const float* bias, const void* mask_bits, void* sign_out,

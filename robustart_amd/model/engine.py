@@ -153,6 +153,14 @@ class ResNet50Engine:
                     if getattr(cb, name, None) is None:
                         setattr(cb, name, torch.empty(9 * cb.cin * cb.cin, dtype=torch.bfloat16, device=self.device))
                     _lib.check(self.lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), cb.cin, sp))
+            if (ds is not None and ds.stride == 1 and ds.r == 1 and cb.stride == 1 and ca.cin == 64 and ca.cout == 64
+                    and cc.cout == 256):
+                # first block of layer1 for the fused kernel: the shortcut table in fragment order, conv3 + shortcut bias
+                if getattr(ds, 'w_fwd_frag', None) is None:
+                    ds.w_fwd_frag = torch.empty(ds.cout * ds.cin, dtype=torch.bfloat16, device=self.device)
+                    ds.bias_sum = torch.empty_like(cc.bias)
+                _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(ds.w_fwd), _lib.ptr(ds.w_fwd_frag), ds.cout, ds.cin, sp))
+                torch.add(cc.bias, ds.bias, out=ds.bias_sum)
 
     @staticmethod
     def _stem_bwd_table(wb):
@@ -300,19 +308,32 @@ class ResNet50Engine:
                 and ca.cin == cc.cout and getattr(cb, 'w_fwd_frag', None) is not None
                 and self.lib.rart_bottleneck_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]))
 
-    def _bneck(self, x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward):
-        """One identity Bottleneck as a single launch (csrc/bottleneck_fused.hip), forward or backward-to-input."""
+    def _first_ok(self, ca, cb, cc, ds, xhw):
+        return (self.fused_bottleneck and ds is not None and getattr(ds, 'w_fwd_frag', None) is not None
+                and getattr(cb, 'w_fwd_frag', None) is not None
+                and self.lib.rart_bottleneck_first_supported(ca.cin, ca.cout, cc.cout, xhw[0], xhw[1]))
+
+    def _bneck(self, x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward, w4=None, c_in=None):
+        """One Bottleneck as a single launch (csrc/bottleneck_fused.hip), forward or backward-to-input; w4: the projection
+        shortcut's table for the layer's first block (c_in input channels)."""
         if self.profile is not None:
             torch = _lib.require_gpu()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             prof, self.profile = self.profile, None
             try:
-                self._bneck(x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward)
+                self._bneck(x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward, w4, c_in)
             finally:
                 self.profile = prof
             e1.record()
-            self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * (2 * c_io + 9 * c_mid), e0, e1, 'bottleneck'))
+            k_all = (2 * c_io + 9 * c_mid) if w4 is None else (c_in + 9 * c_mid + c_io + c_in * c_io // c_mid)
+            self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * k_all, e0, e1, 'bottleneck'))
+            return
+        if w4 is not None:
+            _lib.check(self.lib.rart_bottleneck_first_bf16(
+                _lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(w4), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(b3),
+                _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, hw[0], hw[1], c_in, c_mid, c_io,
+                _cints([t[0] for t in taps]), _cints([t[1] for t in taps]), 1 if backward else 0, _lib.stream_ptr()))
             return
         _lib.check(self.lib.rart_bottleneck_fused_bf16(
             _lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(m1),
@@ -401,6 +422,13 @@ class ResNet50Engine:
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
                 continue
+            if (bits or not keep) and self._first_ok(ca, cb, cc, ds, xhw):
+                self._bneck(x, ca.w_fwd, cb.w_fwd_frag, cc.w_fwd, ca.bias, cb.bias, ds.bias_sum, sa, sb, sc, yc, B, xhw, cc.cout,
+                            ca.cout, cb.fwd_taps, False, w4=ds.w_fwd_frag, c_in=ca.cin)
+                acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
+                acts['b%d_masks' % bi] = (xs, sa, sb)
+                x, xhw, xs = yc, ohw, sc
+                continue
             self._conv_fwd(ca, x, xhw, ya, True, sign=sa)
             self._conv_fwd(cb, ya, xhw, yb, True, sign=sb)
             if ds is not None:
@@ -462,6 +490,12 @@ class ResNet50Engine:
                 dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
                 self._bneck(dz, cc.bwd[0][2], cb.w_bwd_frag, ca.bwd[0][2], None, None, None, mb, ma, mx, dx, B, xhw, cc.cout,
                             ca.cout, cb.bwd[0][1], True)
+                dz = dx
+                continue
+            if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._first_ok(ca, cb, cc, ds, xhw)):
+                dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
+                self._bneck(dz, cc.bwd[0][2], cb.w_bwd_frag, ds.bwd[0][2], None, None, None, mb, ma, mx, dx, B, xhw, cc.cout,
+                            ca.cout, cb.bwd[0][1], True, w4=ca.bwd[0][2], c_in=ca.cin)
                 dz = dx
                 continue
             dzb = self._get('g_b', tuple(yb.shape))

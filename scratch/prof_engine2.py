@@ -40,12 +40,14 @@ def wrapped_halo(src, w, dst, B_, hw, ch, taps, **kw):
     rows.append(((M, 9 * ch, ch, 99), 2.0 * M * 9 * ch * ch, by, e0, e1))      # taps column 99 = k_conv3x3_halo
     return r
 orig_bneck = eng._bneck
-def wrapped_bneck(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid, taps, backward):
+def wrapped_bneck(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid, taps, backward, w4=None, c_in=None):
     M = B_ * hw[0] * hw[1]
-    by = 2 * M * c_io * 2 + (2 * c_io * c_mid + 9 * c_mid * c_mid) * 2 + sum(M * c * 0.125 for c, m_ in ((c_mid, m1), (c_mid, m2), (c_io, m3)) if m_ is not None)
+    cin = c_io if w4 is None else c_in
+    by = M * (c_io + cin) * 2 + ((c_io + cin) * c_mid + 9 * c_mid * c_mid + (0 if w4 is None else c_in * c_io)) * 2 + sum(M * c * 0.125 for c, m_ in ((c_mid, m1), (c_mid, m2), (c_io, m3)) if m_ is not None)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); r = orig_bneck(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid, taps, backward); e1.record()
-    rows.append(((M, 2 * c_io + 9 * c_mid, c_mid, 98), 2.0 * M * c_mid * (2 * c_io + 9 * c_mid), by, e0, e1))   # taps column 98 = fused block
+    e0.record(); r = orig_bneck(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid, taps, backward, w4, c_in); e1.record()
+    k_all = (2 * c_io + 9 * c_mid) if w4 is None else (c_in + 9 * c_mid + c_io + c_in * c_io // c_mid)
+    rows.append(((M, k_all, c_mid, 98), 2.0 * M * c_mid * k_all, by, e0, e1))   # taps column 98 = fused block
     return r
 for _ in range(2): eng.forward_backward(x, MEAN, STD, y, 0)
 eng._gemm = wrapped

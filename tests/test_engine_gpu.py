@@ -193,9 +193,14 @@ def _reference_backward_with_engine_masks(eng, acts, dl, std):
     for bi in range(len(eng.blocks) - 1, -1, -1):
         ca, cb, cc, ds = eng.blocks[bi]
         x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
-        dzb = q(dgrad(cc, dz, ohw) * (nchw(yb) > 0))
-        dza = q(dgrad(cb, dzb, xhw) * (nchw(ya) > 0))
-        m = (nchw(x) > 0).to(dt)
+        # the engine's own ReLU decisions: its 1-bit sign tensors (the fused Bottleneck kernels never write ya / yb), or the
+        # bf16 activations when sign_bit_masks is off
+        mx, ma, mb = acts['b%d_masks' % bi]
+        sign = lambda t: (torch.from_numpy(np.unpackbits(t.cpu().numpy(), axis=-1, bitorder='little')).permute(0, 3, 1, 2).to(dt)  # noqa: E731
+                          if t.dtype == torch.uint8 else (nchw(t) > 0).to(dt))
+        dzb = q(dgrad(cc, dz, ohw) * sign(mb))
+        dza = q(dgrad(cb, dzb, xhw) * sign(ma))
+        m = sign(mx)
         if ds is None:
             dx = q((dgrad(ca, dza, xhw) + dz) * m)
         else:
@@ -229,17 +234,6 @@ def test_backward_to_input(setup, B, HW, kind):
             assert torch.equal(acts_u['p1'], acts['p1'])
         finally:
             eng.fused_stem_fwd = True
-        eng.last_acts, eng.last_dlogits = acts, dl_keep
-    if eng.fused_bottleneck:
-        # the fused Bottleneck kernel never writes the two inner activations of layer1's identity blocks; the reference below
-        # wants them for the ReLU decisions: the three-launch chain fills the same buffers (and must agree on the logits)
-        acts, dl_keep = eng.last_acts, eng.last_dlogits
-        try:
-            eng.fused_bottleneck = False
-            lg_u, _ = eng._forward(x.detach().float().contiguous(), False, MEAN, STD, keep=True)
-        finally:
-            eng.fused_bottleneck = True
-        assert torch.equal(lg_u, logits)
         eng.last_acts, eng.last_dlogits = acts, dl_keep
     # (1) rigorous: same masks as the engine's forward -> only fp32-accumulate / bf16-rounding noise remains
     ref = _reference_backward_with_engine_masks(eng, eng.last_acts, eng.last_dlogits, STD).cuda()
@@ -592,6 +586,83 @@ def test_fused_bottleneck_forward_and_backward_vs_fp64(B):
     close(dx.cpu().double(), refg, 'backward')
 
 
+@pytest.mark.parametrize('B', [1, 3])
+def test_fused_first_bottleneck_forward_and_backward_vs_fp64(B):
+    """rart_bottleneck_first_bf16 (layer1 block 0: 64 -> 64 -> 256 with the projection shortcut folded into the last GEMM as
+    extra K) against fp64 with bf16 rounding of the two intermediates; same bounds as the identity-block test."""
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import _Conv, _cints
+    lib = _lib.load()
+    H = W = 56
+    assert lib.rart_bottleneck_first_supported(64, 64, 256, H, W)
+    g = torch.Generator().manual_seed(70 + B)
+
+    def mk(cin, cout, k):
+        conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5)
+        c = _Conv(conv, None, 'cuda')
+        c.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        return conv, c
+
+    (c1, ca), (c2, cb), (c3, cc), (c4, ds) = mk(64, 64, 1), mk(64, 64, 3), mk(64, 256, 1), mk(64, 256, 1)
+    wq = [c.weight.detach().to(torch.bfloat16).double() for c in (c1, c2, c3, c4)]
+    bq = [c.bias.cpu().double() for c in (ca, cb, cc, ds)]
+    rb = lambda t: t.to(torch.bfloat16).double()
+    sp = _lib.stream_ptr()
+    new = lambda n: torch.empty(n, dtype=torch.bfloat16, device='cuda')
+    w2f, w2b, w4f = new(64 * 576), new(64 * 576), new(256 * 64)
+    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(cb.w_fwd), _lib.ptr(w2f), 64, sp))
+    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(cb.bwd[0][2]), _lib.ptr(w2b), 64, sp))
+    _lib.check(lib.rart_pack_frag_bf16(_lib.ptr(ds.w_fwd), _lib.ptr(w4f), 256, 64, sp))
+    b3 = (cc.bias + ds.bias).contiguous()
+    x = _rand_bf16((B, H, W, 64), 5, relu=True).cuda()
+    y = torch.empty(B, H, W, 256, dtype=torch.bfloat16, device='cuda')
+    s1 = torch.zeros(B, H, W, 8, dtype=torch.uint8, device='cuda')
+    s2 = torch.zeros_like(s1)
+    s3 = torch.zeros(B, H, W, 32, dtype=torch.uint8, device='cuda')
+    dy, dx_ = _cints([t[0] for t in cb.fwd_taps]), _cints([t[1] for t in cb.fwd_taps])
+    _lib.check(lib.rart_bottleneck_first_bf16(_lib.ptr(x), _lib.ptr(ca.w_fwd), _lib.ptr(w2f), _lib.ptr(cc.w_fwd), _lib.ptr(w4f),
+                                              _lib.ptr(ca.bias), _lib.ptr(cb.bias), _lib.ptr(b3), _lib.ptr(s1), _lib.ptr(s2),
+                                              _lib.ptr(s3), _lib.ptr(y), B, H, W, 64, 64, 256, dy, dx_, 0, sp))
+    xd = x.cpu().double().permute(0, 3, 1, 2)
+    a1 = rb(F.relu(F.conv2d(xd, wq[0], bq[0])))
+    a2 = rb(F.relu(F.conv2d(a1, wq[1], bq[1], padding=1)))
+    ref = F.relu(F.conv2d(a2, wq[2], bq[2]) + F.conv2d(xd, wq[3], bq[3])).permute(0, 2, 3, 1)
+
+    def close(got, ref, what):
+        err = (got - ref).abs()
+        ulp = ref.abs().clamp_min(2.0 ** -20) * 2.0 ** -8 + 1e-6
+        frac = (err > ulp).double().mean().item()
+        print('%s: beyond 1 ulp %.2e of the elements, max err %.4f (scale %.2f)' % (what, frac, err.max().item(), ref.abs().max().item()))
+        assert frac < 1e-3 and err.max() <= 0.01 * ref.abs().max(), what
+
+    close(y.cpu().double(), ref, 'first block forward')
+    unpack = lambda t: torch.from_numpy(np.unpackbits(t.cpu().numpy(), axis=-1, bitorder='little')).bool()
+    assert torch.equal(unpack(s3), y.cpu() > 0)
+    for s_, a, name in ((s1, a1, 'a1'), (s2, a2, 'a2')):
+        mism = (unpack(s_) != (a.permute(0, 2, 3, 1) > 0)).double().mean().item()
+        assert mism < 1e-4, (name, mism)
+    # backward to the 64-channel input
+    gz = _rand_bf16((B, H, W, 256), 6).cuda()
+    mb = torch.randint(0, 256, (B, H, W, 8), generator=g, dtype=torch.uint8).cuda()
+    ma = torch.randint(0, 256, (B, H, W, 8), generator=g, dtype=torch.uint8).cuda()
+    mx = torch.randint(0, 256, (B, H, W, 8), generator=g, dtype=torch.uint8).cuda()
+    dx = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device='cuda')
+    taps = cb.bwd[0][1]
+    _lib.check(lib.rart_bottleneck_first_bf16(_lib.ptr(gz), _lib.ptr(cc.bwd[0][2]), _lib.ptr(w2b), _lib.ptr(ds.bwd[0][2]),
+                                              _lib.ptr(ca.bwd[0][2]), None, None, None, _lib.ptr(mb), _lib.ptr(ma), _lib.ptr(mx),
+                                              _lib.ptr(dx), B, H, W, 64, 64, 256, _cints([t[0] for t in taps]),
+                                              _cints([t[1] for t in taps]), 1, sp))
+    bits = lambda t: unpack(t).double().permute(0, 3, 1, 2)
+    gd = gz.cpu().double().permute(0, 3, 1, 2)
+    d2 = rb(torch.nn.grad.conv2d_input((B, 64, H, W), wq[2], gd) * bits(mb))
+    d1 = rb(torch.nn.grad.conv2d_input((B, 64, H, W), wq[1], d2, padding=1) * bits(ma))
+    refg = ((torch.nn.grad.conv2d_input((B, 64, H, W), wq[0], d1) + torch.nn.grad.conv2d_input((B, 64, H, W), wq[3], gd))
+            * bits(mx)).permute(0, 2, 3, 1)
+    close(dx.cpu().double(), refg, 'first block backward')
+
+
 def test_fused_bottleneck_engine_matches_three_launch_chain(setup):
     m, eng = setup
     g = torch.Generator().manual_seed(321)
@@ -603,7 +674,7 @@ def test_fused_bottleneck_engine_matches_three_launch_chain(setup):
         la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
         kinds = [p[3] for p in eng.profile]
         eng.profile = None
-        assert kinds.count('bottleneck') == 4, kinds          # layer1 blocks 1 and 2, forward and backward
+        assert kinds.count('bottleneck') == 6, kinds          # layer1 blocks 0, 1 and 2, forward and backward
         ga = ga.clone()
         ea = eng.logits(x, MEAN, STD).clone()
         eng.fused_bottleneck = False
@@ -617,4 +688,9 @@ def test_fused_bottleneck_engine_matches_three_launch_chain(setup):
     a, b = ga.flatten().double(), gb.flatten().double()
     cos = (a @ b / (a.norm() * b.norm())).item()
     print('fused bottleneck vs chain: logits max diff %.4f (scale %.2f), grad cos %.6f' % ((la - lb).abs().max().item(), lb.abs().max().item(), cos))
-    assert cos > 0.995
+    # the identity blocks alone reproduce the chain bit for bit; the fused FIRST block adds the projection shortcut in fp32
+    # where the chain rounds it to bf16 first, and on this random-init network that one rounding flips ReLU decisions through
+    # all 16 blocks (the same effect test_backward_to_input bounds by 0.85 end to end).  The arithmetic itself is pinned by
+    # the fp64 tests above and by test_backward_to_input's same-mask comparison; tests/test_outcome_gpu.py measures the
+    # gradient direction on a fitted network.
+    assert cos > 0.9
