@@ -258,11 +258,17 @@ def measure_igemm_roofline(path, images, labels):
         out['hbm_view'] = {'achieved': out['traffic'] / (secs / len(ig)) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                            'frac': out['traffic'] / (secs / len(ig)) / HBM_PEAK}
     if halo:
+        names = {'halo3x3': 'k_conv3x3_halo / k_conv3x3_image256 (layer1-3 3x3, input tile resident in LDS)',
+                 'bottleneck': 'k_bottleneck56 (layer1 blocks fused: 1x1 + 3x3 + 1x1 + shortcut in one launch)'}
+        out['other_mfma_kernels'] = {}
+        for kind in sorted(set(p[3] for p in halo)):
+            grp = [p for p in halo if p[3] == kind]
+            gs = sum(a.elapsed_time(b) for _, a, b, _ in grp) * 1e-3
+            gf = sum(f for f, _, _, _ in grp)
+            out['other_mfma_kernels']['%s, %d launches' % (names.get(kind, kind), len(grp))] = {
+                'achieved': gf / gs / 1e12, 'unit': 'TFLOP/s', 'frac': gf / gs / MFMA_BF16_PEAK, 'avg_launch_us': gs / len(grp) * 1e6}
         hs = sum(a.elapsed_time(b) for _, a, b, _ in halo) * 1e-3
         hf = sum(f for f, _, _, _ in halo)
-        out['other_mfma_kernels'] = {'k_conv3x3_halo (layer1 / layer2 3x3, %d launches)' % len(halo):
-                                     {'achieved': hf / hs / 1e12, 'unit': 'TFLOP/s', 'frac': hf / hs / MFMA_BF16_PEAK,
-                                      'avg_launch_us': hs / len(halo) * 1e6}}
         out['all_conv_launches'] = {'achieved': (flops + hf) / (secs + hs) / 1e12, 'unit': 'TFLOP/s',
                                     'frac': (flops + hf) / (secs + hs) / MFMA_BF16_PEAK, 'seconds_per_fwd_bwd': secs + hs}
     return out
