@@ -18,13 +18,13 @@ void run(int n) {
   const size_t nblk = (size_t)n * BF_TPI;
   hipMalloc(&ts, nblk * 4 * 7 * 8);
   RartBneckDesc d{};
-  d.x = x; d.w1 = w1; d.w2 = w2; d.w3 = w3; d.b1 = d.b2 = d.b3 = BWD ? nullptr : bias; d.m1 = m1; d.m2 = m2; d.m3 = m3; d.out = out;
+  d.x = x; d.w4 = nullptr; d.w1 = w1; d.w2 = w2; d.w3 = w3; d.b1 = d.b2 = d.b3 = BWD ? nullptr : bias; d.m1 = m1; d.m2 = m2; d.m3 = m3; d.out = out;
   d.tiles = (uint32_t)nblk; d.ts = ts;
   for (int t = 0; t < 9; ++t) d.tap_off[t] = ((t / 3 - 1) * BF_SW + (t % 3 - 1)) * 16;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_bottleneck56<BWD>, dim3(nblk), dim3(256), 0, 0, d);
+    hipLaunchKernelGGL((k_bottleneck56<BWD, false>), dim3(nblk), dim3(256), 0, 0, d);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%s n=%d: %.1f us (%zu blocks)\n", BWD ? "bwd" : "fwd", n, ms * 1e3, nblk);

@@ -12,6 +12,9 @@ eng = ResNet50Engine(get_model({'type': 'resnet50_official'}).eval(), 'cuda')
 for a in sys.argv[1:]:
     if '=' in a:
         k, v = a.split('='); setattr(eng, k, bool(int(v)))
+import os
+if os.environ.get('BK64'):
+    eng.lib.rart_igemm_set_bk64_min_k(int(os.environ['BK64']))
 B = 256
 x = torch.rand(B, 3, 224, 224, device='cuda'); y = torch.randint(0, 1000, (B,), device='cuda')
 rows = []
