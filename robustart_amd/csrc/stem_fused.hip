@@ -40,6 +40,54 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2));
 }
 
+
+// the halo positions whose stem row has parity EY and whose stem column has parity EX (tile origins are multiples of 16, so
+// halo row hy has stem-row parity (hy + 1) & 1): windows q with 2q-1 <= p <= 2q+1 -> one window per even coordinate, two per odd
+template <int EY, int EX>
+__device__ __forceinline__ void pool_bwd_class(uint4* sDz1, const uint4* sDp, const uint2* sArg,
+                                               int tid, int a0, int b0, int qy0, int qx0, int oh, int ow) {
+  constexpr int NY = EY ? (HT + 1) / 2 : HT / 2, NX = EX ? (HT + 1) / 2 : HT / 2;      // 10 / 9 halo rows (columns) of the class
+  constexpr int NYS = EY ? 2 : 1, NXS = EX ? 2 : 1;
+  for (int i = tid; i < 8 * NY * NX; i += 256) {
+    const int c = i / (NY * NX), j = i - c * (NY * NX);
+    const int iy = j / NX, ix = j - iy * NX;
+    const int hy = 2 * iy + (EY ? 0 : 1), hx = 2 * ix + (EX ? 0 : 1);
+    const int py = a0 - 1 + hy, px = b0 - 1 + hx;           // stem-output coordinates
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)py < (unsigned)oh && (unsigned)px < (unsigned)ow) {
+#pragma unroll
+      for (int ia = 0; ia < NYS; ++ia) {
+        const int qy = (py >> 1) + ia;
+        const uint32_t ky = (uint32_t)(py - (2 * qy - 1));
+#pragma unroll
+        for (int ib = 0; ib < NXS; ++ib) {
+          const int qx = (px >> 1) + ib;
+          const uint32_t mine = (ky * 3 + (uint32_t)(px - (2 * qx - 1))) * 0x01010101u;
+          const int lp = (qy - qy0) * PT + (qx - qx0);      // out-of-grid windows hold code 15 / zeros
+          const uint2 cd = sArg[lp * 8 + c];
+          const uint4 dv = sDp[lp * 8 + c];
+          const uint32_t cw[2] = {cd.x, cd.y};
+          const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+          for (int hw = 0; hw < 2; ++hw) {
+            // codes are < 16, so (code ^ mine) + 0x7F sets bit 7 of a byte exactly when the byte differs
+            const uint32_t ne = ((cw[hw] ^ mine) + 0x7F7F7F7Fu) & 0x80808080u;
+            const uint32_t eq = (ne ^ 0x80808080u) >> 7;              // 1 per equal byte
+            const uint32_t m = (eq << 8) - eq;                         // 0xFF per equal byte
+            const uint32_t w0 = dw[2 * hw] & __builtin_amdgcn_perm(m, m, 0x01010000u);
+            const uint32_t w1 = dw[2 * hw + 1] & __builtin_amdgcn_perm(m, m, 0x03030202u);
+            g[4 * hw + 0] += __uint_as_float(w0 << 16);
+            g[4 * hw + 1] += __uint_as_float(w0 & 0xFFFF0000u);
+            g[4 * hw + 2] += __uint_as_float(w1 << 16);
+            g[4 * hw + 3] += __uint_as_float(w1 & 0xFFFF0000u);
+          }
+        }
+      }
+    }
+    sDz1[c * NPOS_PAD + hy * HT + hx] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
+  }
+}
+
 struct Istd3 { float v[3]; };
 
 __global__ __launch_bounds__(256, 2) void k_stem_bwd_fused(const uint4* __restrict__ dpool,   // [n][oh2][ow2][64] bf16
@@ -79,35 +127,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd_fused(const uint4* __restri
   }
   __syncthreads();
 
-  // ---- max-pool backward into the halo tile: dz1[p] = sum over the <= 4 windows holding p whose argmax is p
-  for (int i = tid; i < 8 * NPOS; i += 256) {
-    const int c = i / NPOS, pos = i - c * NPOS;
-    const int hy = pos / HT, hx = pos - hy * HT;
-    const int py = a0 - 1 + hy, px = b0 - 1 + hx;           // stem-output coordinates
-    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)py < (unsigned)oh && (unsigned)px < (unsigned)ow) {
-      const int nys = (py & 1) ? 2 : 1, nxs = (px & 1) ? 2 : 1;
-      for (int ia = 0; ia < nys; ++ia) {
-        const int qy = (py >> 1) + ia;                     // windows q with 2q-1 <= p <= 2q+1
-        const uint32_t ky = (uint32_t)(py - (2 * qy - 1));
-        for (int ib = 0; ib < nxs; ++ib) {
-          const int qx = (px >> 1) + ib;
-          const uint32_t mine = ky * 3 + (uint32_t)(px - (2 * qx - 1));
-          const int lp = (qy - qy0) * PT + (qx - qx0);      // out-of-grid windows hold code 15 / zeros
-          const uint2 cd = sArg[lp * 8 + c];
-          const uint4 dv = sDp[lp * 8 + c];
-          const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const uint32_t cj = ((j < 4 ? cd.x : cd.y) >> (8 * (j & 3))) & 0xFFu;
-            const float d = (j & 1) ? __uint_as_float(dw[j >> 1] & 0xFFFF0000u) : __uint_as_float(dw[j >> 1] << 16);
-            if (cj == mine) g[j] += d;
-          }
-        }
-      }
-    }
-    sDz1[c * NPOS_PAD + pos] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
-  }
+  // ---- max-pool backward into the halo tile: dz1[p] = sum over the <= 4 windows holding p whose argmax is p.
+  //      One pass per pixel-parity class (even / odd row x even / odd column of the stem grid: 1, 2, 2 or 4 windows) so that
+  //      the lanes of a wave walk the same number of windows (mixed parities made every wave pay for 4), and the eight
+  //      argmax codes of a 16-byte chunk are compared at once (SWAR: equal bytes -> 0xFF) instead of byte by byte.
+  pool_bwd_class<0, 0>(sDz1, sDp, sArg, tid, a0, b0, qy0, qx0, oh, ow);
+  pool_bwd_class<0, 1>(sDz1, sDp, sArg, tid, a0, b0, qy0, qx0, oh, ow);
+  pool_bwd_class<1, 0>(sDz1, sDp, sArg, tid, a0, b0, qy0, qx0, oh, ow);
+  pool_bwd_class<1, 1>(sDz1, sDp, sArg, tid, a0, b0, qy0, qx0, oh, ow);
   __syncthreads();
 
   // ---- implicit GEMM over the 16 taps: wave w owns tile rows 4w..4w+3 (one 16-position M tile each)

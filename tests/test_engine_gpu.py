@@ -360,7 +360,8 @@ def test_fused_stem_backward_kernel_vs_fp64(B, H, W):
     wt = ResNet50Engine._stem_bwd_table(wb).cuda()
     grad = torch.full((B, 3, H, W), float('nan'), device='cuda')
     stdf = (ctypes.c_float * 3)(*STD)
-    _lib.check(lib.rart_engine_stem_bwd_fused(_lib.ptr(dpool.cuda()), _lib.ptr(code.cuda()), _lib.ptr(wt), _lib.ptr(grad),
+    dpool_d, code_d = dpool.cuda(), code.cuda()      # named: a temporary's block may be handed to the next .cuda() before the launch
+    _lib.check(lib.rart_engine_stem_bwd_fused(_lib.ptr(dpool_d), _lib.ptr(code_d), _lib.ptr(wt), _lib.ptr(grad),
                                               B, H, W, stdf, _lib.stream_ptr()))
     got = grad.cpu().double()
     assert torch.isfinite(got).all()
