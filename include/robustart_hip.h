@@ -295,6 +295,9 @@ int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
 /* Tuning knob: problems with n_taps*k_per_tap >= k (and k_per_tap % 64 == 0) use the 128x{128,64}x64 pipeline
  * (default 1024); others the x32 pipeline with loads two K steps ahead. */
 int rart_igemm_set_bk64_min_k(long long k);
+/* Tuning knob: plain row-major products (one tap, unit strides, no batching, flags within GELU / GELU') with at least 512 tiles of
+ * 256 x 256 run on the 8-wave 256 x 256 x 64 kernel with direct-to-LDS tiles (the transformer layers); 0 disables it. */
+int rart_igemm_set_gemm256(int enable);
 
 /* 3x3 stride-1 "same" convolution, channels in = channels out = 64, 128 or 256 (256: images of at most 224 positions, one
  * image per workgroup), bf16 NHWC, with the input halo tile resident in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 /

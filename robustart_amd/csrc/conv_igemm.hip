@@ -494,6 +494,165 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     __builtin_amdgcn_wave_barrier();
   }
 }
+
+// ---- 256 x 256 x 64 GEMM for the transformer layers ------------------------------------------------------------------------
+// C[M][N] = A[M][K] . W[N][K]^T (+ bias, + residual, GELU / GELU') for PLAIN products with enough tiles to fill the chip (ViT-B/16
+// at B = 256: M = 50 432, N = 768 ... 3 072: 600-2 400 tiles).  The 128 x 128 kernel above gives each wave a 64 x 64 sub-tile:
+// 1 KiB of LDS fragment reads per MFMA, which at 8 waves per CU is exactly the LDS bandwidth (128 B / clk) the matrix pipe would
+// need at full rate -- K-deep launches stall at ~700 TFLOP/s.  Here 8 waves (2 x 4) own 128 x 64 sub-tiles (0.75 KiB per MFMA),
+// and the tiles arrive by global_load_lds_dwordx4: no VGPR staging, no ds_write.  A wave-wide direct load writes 8 rows x 128 B
+// contiguously (lane l -> row l >> 3, slot l & 7), so rows cannot be padded; slot s of row r holds chunk s ^ ((r >> 1) & 7), the
+// swizzle being applied on the GLOBAL side (each lane fetches the chunk its slot must hold: same 128-byte row, coalescing
+// unchanged), which puts the 16 rows of a quarter-wave fragment read in 16 different 16-byte bank groups.  Two LDS stages of
+// 64 KiB: one workgroup per CU.  Measured (scratch/exp/gemm256.hip): 880-900 TFLOP/s on the ViT shapes, 1 160 on 8192^3
+// (128 x 128 kernel: 791).
+struct RartGemm256Desc {
+  const uint16_t* a;      // [M][lda]
+  const uint16_t* w;      // [N][K]
+  const float* bias;      // [N] or null
+  const uint16_t* res;    // [M][ldc] or null
+  const uint16_t* mask;   // F_GELU_BWD: the GELU's pre-activation [M][ldc]
+  uint16_t* c;            // [M][ldc]
+  int M, N, K, lda, ldc, flags;
+};
+__device__ __attribute__((aligned(16))) const uint32_t g_gemm_zero16[4] = {0u, 0u, 0u, 0u};   // source of rows past M
+constexpr int G2_TM = 256, G2_TN = 256, G2_STAGE = (G2_TM + G2_TN) * 128, G2_LDE = 68;
+static_assert(8 * 32 * G2_LDE * 4 <= 2 * G2_STAGE, "epilogue staging must fit the tile buffers");
+
+__global__ __launch_bounds__(512, 1) void k_gemm256_bf16(const RartGemm256Desc d) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * G2_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int n_tiles = d.N / G2_TN;
+  // all column tiles of a row tile on one XCD (the A tile is re-read from its L2)
+  const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+  const int m_tile = (slot / n_tiles) * 8 + xcd, n_tile = slot % n_tiles;
+  if (m_tile * G2_TM >= d.M) return;
+  const int m0 = m_tile * G2_TM, n0 = n_tile * G2_TN;
+  const int lrow = lane >> 3, swz = ((8 * wave + lrow) >> 1) & 7, csrc = (lane & 7) ^ swz;
+  const uint32_t wrow = (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 8u;
+  const char* asrc[4];
+  const char* bsrc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 64 * q + 8 * wave + lrow;
+    asrc[q] = (m0 + r < d.M) ? reinterpret_cast<const char*>(d.a + (size_t)(m0 + r) * d.lda + csrc * 8) : nullptr;
+    bsrc[q] = reinterpret_cast<const char*>(d.w + (size_t)(n0 + r) * d.K + csrc * 8);
+  }
+#define RART_G2_DL(SRC, DST)                                                                                    \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                        \
+                                   (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);
+#define RART_G2_ISSUE(KT, BUF)                                                                                  \
+  {                                                                                                             \
+    uint8_t* const st_ = lds + (BUF)*G2_STAGE;                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
+      const char* s_ = asrc[q] ? asrc[q] + (size_t)(KT)*128 : reinterpret_cast<const char*>(g_gemm_zero16);     \
+      RART_G2_DL(s_, st_ + (64 * q + wrow) * 128)                                                               \
+    }                                                                                                           \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
+      RART_G2_DL(bsrc[q] + (size_t)(KT)*128, st_ + (G2_TM + 64 * q + wrow) * 128)                               \
+    }                                                                                                           \
+  }
+  const int fr = lane & 31, h = lane >> 5;
+  uint32_t xo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xo[ks] = (uint32_t)(fr * 128 + (((2 * ks + h) ^ ((fr >> 1) & 7)) << 4));
+  // accumulators start at the bias of their column (lane & 31 is the column of a 32 x 32 MFMA tile), as in k_conv_igemm_bf16
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float bv = d.bias ? d.bias[n0 + wn * 64 + j * 32 + fr] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+  }
+  const int KT = d.K / 64;
+  RART_G2_ISSUE(0, 0)
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) RART_G2_ISSUE(kt + 1, buf ^ 1)
+    const uint8_t* Ab = lds + buf * G2_STAGE + wm * 128 * 128;
+    const uint8_t* Bb = lds + buf * G2_STAGE + (G2_TM + wn * 64) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * 128 + xo[ks]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * 128 + xo[ks]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);          // the next tile has landed in LDS
+    __syncthreads();
+  }
+#undef RART_G2_ISSUE
+#undef RART_G2_DL
+  // ---- epilogue: per wave, 32 rows x 64 columns at a time through LDS -> 128-byte row segments; residual / GELU operands of a
+  //      pass are requested before its transposition
+  float* sE = reinterpret_cast<float*>(lds) + wave * 32 * G2_LDE;
+  const int cw = lane & 7, rw = lane >> 3;
+  const int col = n0 + wn * 64 + cw * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint4 rv[4], mv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = m0 + wm * 128 + i * 32 + q * 8 + rw;
+      rv[q] = make_uint4(0, 0, 0, 0);
+      mv[q] = make_uint4(0, 0, 0, 0);
+      if (row < d.M) {
+        const size_t e = (size_t)row * d.ldc + col;
+        if (d.res) rv[q] = *reinterpret_cast<const uint4*>(d.res + e);
+        if (d.flags & F_GELU_BWD) mv[q] = *reinterpret_cast<const uint4*>(d.mask + e);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sE[((r & 3) + 8 * (r >> 2) + 4 * h) * G2_LDE + j * 32 + fr] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = q * 8 + rw, row = m0 + wm * 128 + i * 32 + r;
+      const float4 v0 = *reinterpret_cast<const float4*>(sE + r * G2_LDE + cw * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(sE + r * G2_LDE + cw * 8 + 4);
+      if (row < d.M) {
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const uint32_t rr[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
+        const uint32_t mw[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
+        if (d.res) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] += __uint_as_float(rr[j] << 16);
+            v[2 * j + 1] += __uint_as_float(rr[j] & 0xFFFF0000u);
+          }
+        }
+        if (d.flags & F_GELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        }
+        if (d.flags & F_GELU_BWD) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] *= gelu_grad_erf(__uint_as_float(mw[j] << 16));
+            v[2 * j + 1] *= gelu_grad_erf(__uint_as_float(mw[j] & 0xFFFF0000u));
+          }
+        }
+        *reinterpret_cast<uint4*>(d.c + (size_t)row * d.ldc + col) =
+            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
 }  // namespace
 
 // tuning knob (tests / profiling): smallest K that takes the BK = 64 pipeline; a huge value disables it
@@ -501,6 +660,30 @@ static long long g_bk64_min_k = 256;    // A/B on MI355X (scratch/ab_bk64.py): R
 extern "C" int rart_igemm_set_bk64_min_k(long long k) {
   g_bk64_min_k = k;
   return RART_OK;
+}
+
+// tuning knob (tests / profiling): 0 keeps every problem on the 128 x 128 kernel
+static int g_gemm256_enabled = 1;
+extern "C" int rart_igemm_set_gemm256(int enable) {
+  g_gemm256_enabled = enable ? 1 : 0;
+  return RART_OK;
+}
+
+// plain row-major products with at least two rounds of 256 x 256 tiles take k_gemm256_bf16
+static bool gemm256_takes(const rart_conv_desc* h, long long* m_out) {
+  if (!g_gemm256_enabled || h->n_taps != 1 || h->tap_dy[0] != 0 || h->tap_dx[0] != 0 || h->tap_src_off[0] != 0) return false;
+  if (h->sy != 1 || h->sx != 1 || h->grid_w != 1 || h->src_w != 1 || h->dst_w != 1 || h->dst_sy != 1 || h->dst_oy != 0 || h->dst_ox != 0)
+    return false;
+  if (h->src_h != h->grid_h || h->dst_h != h->grid_h || h->n_batched > 1 || h->sign_out) return false;
+  if (h->wgt_row_stride != 0 && h->wgt_row_stride != h->k_per_tap) return false;
+  if (h->flags & ~(F_GELU | F_GELU_BWD)) return false;
+  if ((h->flags & F_GELU_BWD) ? !h->mask : (h->mask != nullptr)) return false;
+  if (h->k_per_tap % 64 != 0 || h->n_cols % G2_TN != 0 || h->src_pix_stride % 8 != 0 || h->dst_pix_stride % 8 != 0) return false;
+  const long long M = (long long)h->batch * h->grid_h;
+  if (M * h->src_pix_stride >= (1ll << 31) || M * h->dst_pix_stride >= (1ll << 31)) return false;
+  if (((M + G2_TM - 1) / G2_TM) * (h->n_cols / G2_TN) < 512) return false;
+  *m_out = M;
+  return true;
 }
 
 extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t stream) {
@@ -513,6 +696,19 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   RART_CHECK_ARG(h->src_pix_stride % 8 == 0 || h->src_pix_stride == 4,
                  "rart_conv_igemm_bf16: source pixels must keep 16-byte alignment of the K chunks");
   RART_CHECK_ARG(h->dst_pix_stride % 8 == 0, "rart_conv_igemm_bf16: dst_pix_stride must be a multiple of 8");
+  {
+    long long gm = 0;
+    if (gemm256_takes(h, &gm)) {
+      RartGemm256Desc g;
+      g.a = (const uint16_t*)h->src; g.w = (const uint16_t*)h->wgt; g.bias = h->bias; g.res = (const uint16_t*)h->res;
+      g.mask = (const uint16_t*)h->mask; g.c = (uint16_t*)h->dst;
+      g.M = (int)gm; g.N = h->n_cols; g.K = h->k_per_tap; g.lda = h->src_pix_stride; g.ldc = h->dst_pix_stride; g.flags = h->flags;
+      const int m_tiles = (int)((gm + G2_TM - 1) / G2_TM), m8 = (m_tiles + 7) / 8 * 8;
+      hipLaunchKernelGGL(k_gemm256_bf16, dim3((uint32_t)(m8 * (g.N / G2_TN))), dim3(512), 0, (hipStream_t)stream, g);
+      RART_CHECK_LAUNCH("rart_conv_igemm_bf16 (256 x 256 GEMM)");
+      return RART_OK;
+    }
+  }
   RartConvDescDev d;
   d.src = (const uint16_t*)h->src; d.wgt = (const uint16_t*)h->wgt; d.bias = h->bias;
   d.res = (const uint16_t*)h->res; d.mask = (const uint16_t*)h->mask; d.dst = h->dst;

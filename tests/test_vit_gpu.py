@@ -294,3 +294,55 @@ def test_vit_train_engine_parameter_gradients_match_torch_autograd():
     cs = np.array([c for c, _, _ in rep])
     assert np.median(cs) > 0.999 and cs.min() > 0.98, rep[:8]
     assert all(0.9 < r < 1.1 for _, r, _ in rep), [x for x in rep if not 0.9 < x[1] < 1.1][:8]
+
+
+@pytest.mark.parametrize('flags,use_res', [(0, False), (0, True), (4, False), (8, False)])
+def test_gemm256_kernel_vs_torch_and_the_128_kernel(flags, use_res):
+    """The 256 x 256 x 64 direct-to-LDS GEMM (k_gemm256_bf16, taken by plain products with >= 512 tiles) against fp64 and
+    against the 128 x 128 kernel on the same descriptor: ragged M (rows past M come from the zero page and are never stored),
+    bias, residual, GELU, GELU' epilogues.  Same operands, same K order, same epilogue arithmetic: bit-identical outputs."""
+    import ctypes
+    from robustart_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(flags + 3)
+    M, K, N = 256 * 32 + 37, 192, 4096
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if use_res else None
+    u = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if flags == 8 else None
+
+    def run(enable):
+        lib.rart_igemm_set_gemm256(enable)
+        out = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+        d = _lib.ConvDesc()
+        d.src, d.wgt, d.dst = a.data_ptr(), w.data_ptr(), out.data_ptr()
+        d.bias = bias.data_ptr()
+        d.res = res.data_ptr() if res is not None else None
+        d.mask = u.data_ptr() if u is not None else None
+        d.batch, d.grid_h, d.grid_w = 1, M, 1
+        d.src_h, d.src_w, d.src_pix_stride = M, 1, K
+        d.k_per_tap, d.n_taps, d.sy, d.sx = K, 1, 1, 1
+        d.n_cols, d.dst_h, d.dst_w = N, M, 1
+        d.dst_sy, d.dst_sx, d.dst_oy, d.dst_ox, d.dst_pix_stride = 1, 1, 0, 0, N
+        d.flags = flags
+        _lib.check(lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        big, small = run(1), run(0)
+    finally:
+        lib.rart_igemm_set_gemm256(1)
+    assert torch.isfinite(big.float()).all()
+    assert torch.equal(big, small)
+    ref = a.double() @ w.double().t() + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    if flags == 4:
+        ref = torch.nn.functional.gelu(ref)
+    if flags == 8:
+        ud = u.double()
+        ref = ref * (0.5 * (1 + torch.erf(ud / 2 ** 0.5)) + ud * torch.exp(-ud * ud / 2) / (2 * torch.pi) ** 0.5)
+    err = (big.double() - ref).abs()
+    assert (err <= ref.abs() * 2.0 ** -7 + 2e-3).all(), err.max().item()
