@@ -43,6 +43,7 @@ static Family family_of(int id) {
 static bool needs_staging(int id) {
   switch (id) {
     case RART_ZOOM_BLUR: case RART_DEFOCUS_BLUR: case RART_MOTION_BLUR:
+    case RART_GAUSSIAN_BLUR:   // the fused separable kernel reads a tile's halo from `in` while neighbouring tiles write `out`
       return true;   // every other gathering corruption already goes through its own intermediate buffer
     default:
       return false;
