@@ -441,6 +441,7 @@ extern "C" int rart_conv3x3_halo_bf16(const void* src, const void* wgt, const fl
                                       void* dst, int n, int h, int w, int channels, const int* tap_dy, const int* tap_dx,
                                       int relu, rart_stream_t stream) {
   RART_CHECK_ARG(src && wgt && dst && tap_dy && tap_dx && n > 0, "rart_conv3x3_halo_bf16: bad arguments");
+  RART_CHECK_ARG(src != dst, "rart_conv3x3_halo_bf16: dst must not alias src (workgroups read each other's halo rows)");
   RART_CHECK_ARG(rart_conv3x3_halo_supported(channels, h, w), "rart_conv3x3_halo_bf16: unsupported geometry (channels 64 / 128 / 256, the halo tile must fit LDS)");
   const long long G = (long long)n * h * w;
   RART_CHECK_ARG(G * channels < (1ll << 31), "rart_conv3x3_halo_bf16: tensor must stay below 2^31 elements");
