@@ -345,6 +345,16 @@ int rart_bottleneck_first_bf16(const void* x, const void* w1, const void* w2, co
                                int c_in, int c_mid, int c_out, const int* tap_dy, const int* tap_dx, int backward,
                                rart_stream_t stream);
 
+/* One identity Bottleneck at 14 x 14 (ResNet-50 layer3 blocks 1-5: c_io 1024, c_mid 256) as one kernel, ONE IMAGE PER WORKGROUP
+ * (csrc/bottleneck14_fused.hip).  Same conventions as rart_bottleneck_fused_bf16 (forward / backward, biases, the three 1-bit
+ * mask tensors m1 [P][c_mid/8], m2 [P][c_mid/8], m3 [P][c_io/8]), except that ALL THREE weight tables are passed in fragment order:
+ * w1 = rart_pack_frag_bf16(rows c_mid, k c_io) of [c_mid][c_io]; w2 = rart_conv3x3_pack_frag_bf16 of [c_mid][9*c_mid];
+ * w3 = rart_pack_frag_bf16(rows c_io, k c_mid) of [c_io][c_mid]. */
+int rart_bottleneck14_fused_supported(int c_io, int c_mid, int h, int w);
+int rart_bottleneck14_fused_bf16(const void* x, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
+                                 const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
+                                 int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);
+
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
  * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:
  * the stem convolution's operand (normalisation of imfgsm_attack.py:14-23 / autoattack.py:17-20 fused). */

@@ -69,6 +69,9 @@ SIGNATURES = {
     'rart_pack_frag_bf16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'rart_conv3x3_halo_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_void_p]),
+    'rart_bottleneck14_fused_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'rart_bottleneck14_fused_bf16': (c_int, [c_void_p] * 11 + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
+                                             c_void_p]),
     'rart_bottleneck_fused_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rart_bottleneck_first_supported': (c_int, [c_int] * 5),
     'rart_bottleneck_first_bf16': (c_int, [c_void_p] * 12 + [c_int] * 6 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
