@@ -355,6 +355,15 @@ int rart_bottleneck14_fused_bf16(const void* x, const void* w1, const void* w2, 
                                  const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
                                  int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);
 
+/* One identity Bottleneck at 28 x 28 (ResNet-50 layer2 blocks 1-3: c_io 512, c_mid 128) as one kernel, a 14 x 14 quarter of an
+ * image per workgroup, two workgroups per CU (csrc/bottleneck28_fused.hip).  Conventions and table formats as for
+ * rart_bottleneck14_fused_bf16: w1 = rart_pack_frag_bf16(rows c_mid, k c_io), w2 = rart_conv3x3_pack_frag_bf16,
+ * w3 = rart_pack_frag_bf16(rows c_io, k c_mid); masks m1 / m2 [P][c_mid/8], m3 [P][c_io/8]. */
+int rart_bottleneck28_fused_supported(int c_io, int c_mid, int h, int w);
+int rart_bottleneck28_fused_bf16(const void* x, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
+                                 const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
+                                 int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);
+
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
  * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:
  * the stem convolution's operand (normalisation of imfgsm_attack.py:14-23 / autoattack.py:17-20 fused). */

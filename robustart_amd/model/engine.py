@@ -122,7 +122,8 @@ class ResNet50Engine:
         self.halo_conv3x3 = True         # False: layer1 / layer2 3x3 convs on the generic implicit GEMM (cross-check)
         self.fused_stem_fwd = True       # False: prep_input -> row-tap GEMM -> max pool (cross-check; keeps acts['y1'])
         self.fused_bottleneck = True     # False: layer1's identity blocks as three conv launches each (cross-check)
-        self.fused_bottleneck14 = True   # False: layer3's identity blocks as three conv launches each (cross-check)
+        self.fused_bottleneck14 = True   # False: layer3's (and layer2's) identity blocks as three conv launches each (cross-check)
+        self.fused_bottleneck28 = True   # False: only layer2's
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -154,9 +155,9 @@ class ResNet50Engine:
                     if getattr(cb, name, None) is None:
                         setattr(cb, name, torch.empty(9 * cb.cin * cb.cin, dtype=torch.bfloat16, device=self.device))
                     _lib.check(self.lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), cb.cin, sp))
-            if ds is None and cb.stride == 1 and ca.cin == 1024 and ca.cout == 256 and cc.cout == 1024:
-                # identity blocks of layer3 for the one-image-per-workgroup fused kernel: both 1x1 tables in fragment order
-                for c_, rows, k in ((ca, 256, 1024), (cc, 1024, 256)):
+            if ds is None and cb.stride == 1 and (ca.cin, ca.cout, cc.cout) in ((1024, 256, 1024), (512, 128, 512)):
+                # identity blocks of layer3 / layer2 for the image-resident fused kernels: both 1x1 tables in fragment order
+                for c_, rows, k in ((ca, ca.cout, ca.cin), (cc, cc.cout, cc.cin)):
                     for name, tab in (('w_fwd_frag', c_.w_fwd), ('w_bwd_frag', c_.bwd[0][2])):
                         r_, k_ = (rows, k) if name == 'w_fwd_frag' else (k, rows)
                         if getattr(c_, name, None) is None:
@@ -318,25 +319,33 @@ class ResNet50Engine:
                 and self.lib.rart_bottleneck_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]))
 
     def _b14_ok(self, ca, cb, cc, ds, xhw):
-        return (self.fused_bottleneck14 and ds is None and getattr(ca, 'w_fwd_frag', None) is not None
-                and getattr(cb, 'w_fwd_frag', None) is not None and getattr(cc, 'w_fwd_frag', None) is not None
-                and self.lib.rart_bottleneck14_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]))
+        """-> the C entry point of the image-resident fused kernel for this block (layer3: 14 x 14, layer2: 28 x 28) or None."""
+        if not (self.fused_bottleneck14 and ds is None and getattr(ca, 'w_fwd_frag', None) is not None
+                and getattr(cb, 'w_fwd_frag', None) is not None and getattr(cc, 'w_fwd_frag', None) is not None):
+            return None
+        if self.lib.rart_bottleneck14_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]):
+            return self.lib.rart_bottleneck14_fused_bf16
+        if self.fused_bottleneck28 and self.lib.rart_bottleneck28_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]):
+            return self.lib.rart_bottleneck28_fused_bf16
+        return None
 
-    def _bneck14(self, x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward):
-        """One layer3 identity Bottleneck as a single launch (csrc/bottleneck14_fused.hip)."""
+    def _bneck14(self, x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward, fn=None):
+        """One layer3 / layer2 identity Bottleneck as a single launch (csrc/bottleneck14_fused.hip, bottleneck28_fused.hip)."""
+        fn = fn or self.lib.rart_bottleneck14_fused_bf16
         if self.profile is not None:
             torch = _lib.require_gpu()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             prof, self.profile = self.profile, None
             try:
-                self._bneck14(x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward)
+                self._bneck14(x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward, fn)
             finally:
                 self.profile = prof
             e1.record()
-            self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * (2 * c_io + 9 * c_mid), e0, e1, 'bottleneck14'))
+            self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * (2 * c_io + 9 * c_mid), e0, e1,
+                                 'bottleneck14' if hw[0] == 14 else 'bottleneck28'))
             return
-        _lib.check(self.lib.rart_bottleneck14_fused_bf16(
+        _lib.check(fn(
             _lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(m1),
             _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, hw[0], hw[1], c_io, c_mid, _cints([t[0] for t in taps]),
             _cints([t[1] for t in taps]), 1 if backward else 0, _lib.stream_ptr()))
@@ -455,9 +464,10 @@ class ResNet50Engine:
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
                 continue
-            if (bits or not keep) and self._b14_ok(ca, cb, cc, ds, xhw):
+            fn14 = self._b14_ok(ca, cb, cc, ds, xhw) if (bits or not keep) else None
+            if fn14 is not None:
                 self._bneck14(x, ca.w_fwd_frag, cb.w_fwd_frag, cc.w_fwd_frag, ca.bias, cb.bias, cc.bias, sa, sb, sc, yc, B, xhw,
-                              cc.cout, ca.cout, cb.fwd_taps, False)
+                              cc.cout, ca.cout, cb.fwd_taps, False, fn14)
                 acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
@@ -532,10 +542,11 @@ class ResNet50Engine:
                             ca.cout, cb.bwd[0][1], True)
                 dz = dx
                 continue
-            if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._b14_ok(ca, cb, cc, ds, xhw)):
+            fn14 = self._b14_ok(ca, cb, cc, ds, xhw) if (ma is not None and ma.dtype == torch.uint8 and mb is not None) else None
+            if fn14 is not None:
                 dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
                 self._bneck14(dz, cc.w_bwd_frag, cb.w_bwd_frag, ca.w_bwd_frag, None, None, None, mb, ma, mx, dx, B, xhw,
-                              cc.cout, ca.cout, cb.bwd[0][1], True)
+                              cc.cout, ca.cout, cb.bwd[0][1], True, fn14)
                 dz = dx
                 continue
             if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._first_ok(ca, cb, cc, ds, xhw)):
