@@ -364,6 +364,15 @@ int rart_bottleneck28_fused_bf16(const void* x, const void* w1, const void* w2, 
                                  const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
                                  int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);
 
+/* One identity Bottleneck at 7 x 7 (ResNet-50 layer4 blocks 1-2: c_io 2048, c_mid 512) as one kernel, one image per workgroup
+ * (csrc/bottleneck7_fused.hip).  Conventions as for rart_bottleneck14_fused_bf16; all three tables in fragment order:
+ * w1 = rart_pack_frag_bf16(rows c_mid, k c_io), w2 = rart_pack_frag_bf16(rows c_mid, k 9*c_mid), w3 = rart_pack_frag_bf16(rows c_io,
+ * k c_mid); masks m1 / m2 [P][c_mid/8], m3 [P][c_io/8]. */
+int rart_bottleneck7_fused_supported(int c_io, int c_mid, int h, int w);
+int rart_bottleneck7_fused_bf16(const void* x, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
+                                const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w, int c_io,
+                                int c_mid, const int* tap_dy, const int* tap_dx, int backward, rart_stream_t stream);
+
 /* src: fp32 NCHW in [0,1] (src_is_u8 = 0) or uint8 NHWC (src_is_u8 = 1) -> (x - mean)/std as two bf16
  * planes hi, lo (hi + lo ~ fp32 value), each [n][h+8][w+8][4] with the image at (3,3) and zeros around:
  * the stem convolution's operand (normalisation of imfgsm_attack.py:14-23 / autoattack.py:17-20 fused). */

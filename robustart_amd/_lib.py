@@ -72,6 +72,9 @@ SIGNATURES = {
     'rart_bottleneck28_fused_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rart_bottleneck28_fused_bf16': (c_int, [c_void_p] * 11 + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
                                              c_void_p]),
+    'rart_bottleneck7_fused_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'rart_bottleneck7_fused_bf16': (c_int, [c_void_p] * 11 + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
+                                            c_void_p]),
     'rart_bottleneck14_fused_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rart_bottleneck14_fused_bf16': (c_int, [c_void_p] * 11 + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
                                              c_void_p]),

@@ -124,6 +124,7 @@ class ResNet50Engine:
         self.fused_bottleneck = True     # False: layer1's identity blocks as three conv launches each (cross-check)
         self.fused_bottleneck14 = True   # False: layer3's (and layer2's) identity blocks as three conv launches each (cross-check)
         self.fused_bottleneck28 = True   # False: only layer2's
+        self.fused_bottleneck7 = True    # False: only layer4's
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -150,13 +151,13 @@ class ResNet50Engine:
         torch = _lib.require_gpu()
         sp = _lib.stream_ptr()
         for ca, cb, cc, ds in self.blocks:
-            if cb.r == 3 and cb.stride == 1 and cb.cin == cb.cout and cb.cin in (64, 128, 256):
+            if cb.r == 3 and cb.stride == 1 and cb.cin == cb.cout and cb.cin in (64, 128, 256, 512):
                 for name, tab in (('w_fwd_frag', cb.w_fwd), ('w_bwd_frag', cb.bwd[0][2])):
                     if getattr(cb, name, None) is None:
                         setattr(cb, name, torch.empty(9 * cb.cin * cb.cin, dtype=torch.bfloat16, device=self.device))
-                    _lib.check(self.lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), cb.cin, sp))
-            if ds is None and cb.stride == 1 and (ca.cin, ca.cout, cc.cout) in ((1024, 256, 1024), (512, 128, 512)):
-                # identity blocks of layer3 / layer2 for the image-resident fused kernels: both 1x1 tables in fragment order
+                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), cb.cin, 9 * cb.cin, sp))
+            if ds is None and cb.stride == 1 and (ca.cin, ca.cout, cc.cout) in ((1024, 256, 1024), (512, 128, 512), (2048, 512, 2048)):
+                # identity blocks of layer2 / layer3 / layer4 for the image-resident fused kernels: both 1x1 tables in fragment order
                 for c_, rows, k in ((ca, ca.cout, ca.cin), (cc, cc.cout, cc.cin)):
                     for name, tab in (('w_fwd_frag', c_.w_fwd), ('w_bwd_frag', c_.bwd[0][2])):
                         r_, k_ = (rows, k) if name == 'w_fwd_frag' else (k, rows)
@@ -327,6 +328,8 @@ class ResNet50Engine:
             return self.lib.rart_bottleneck14_fused_bf16
         if self.fused_bottleneck28 and self.lib.rart_bottleneck28_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]):
             return self.lib.rart_bottleneck28_fused_bf16
+        if self.fused_bottleneck7 and self.lib.rart_bottleneck7_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]):
+            return self.lib.rart_bottleneck7_fused_bf16
         return None
 
     def _bneck14(self, x, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B, hw, c_io, c_mid, taps, backward, fn=None):
@@ -343,7 +346,7 @@ class ResNet50Engine:
                 self.profile = prof
             e1.record()
             self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * (2 * c_io + 9 * c_mid), e0, e1,
-                                 'bottleneck14' if hw[0] == 14 else 'bottleneck28'))
+                                 {14: 'bottleneck14', 28: 'bottleneck28', 7: 'bottleneck7'}[hw[0]]))
             return
         _lib.check(fn(
             _lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(m1),

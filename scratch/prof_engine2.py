@@ -58,7 +58,7 @@ def wrapped_b14(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid
     by = 2 * M * c_io * 2 + (2 * c_io * c_mid + 9 * c_mid * c_mid) * 2 + sum(M * c * 0.125 for c, m_ in ((c_mid, m1), (c_mid, m2), (c_io, m3)) if m_ is not None)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); r = orig_b14(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid, taps, backward, fn); e1.record()
-    rows.append(((M, 2 * c_io + 9 * c_mid, c_mid, 97 if hw[0] == 14 else 96), 2.0 * M * c_mid * (2 * c_io + 9 * c_mid), by, e0, e1))   # taps column 97 / 96 = fused layer3 / layer2 block
+    rows.append(((M, 2 * c_io + 9 * c_mid, c_mid, {14: 97, 28: 96, 7: 95}[hw[0]]), 2.0 * M * c_mid * (2 * c_io + 9 * c_mid), by, e0, e1))   # taps column 97 / 96 = fused layer3 / layer2 block
     return r
 for _ in range(2): eng.forward_backward(x, MEAN, STD, y, 0)
 eng._bneck14 = wrapped_b14
@@ -83,7 +83,7 @@ for key, (us, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     floor = max(fl / PEAK_F, by / PEAK_B) * 1e6
     tot += us; totf += floor
     print('%9d %6d %6d %4d %4d %9.1f %8.1f %8.1f %9.1f %6.3f' % (*key, cnt, us, fl / us / 1e6, by / us / 1e3, floor, floor / us))
-print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 = the fused Bottleneck kernels of layer1 / layer3 / layer2: one row = 1x1 + 3x3 + 1x1)')
+print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 / 95 = the fused Bottleneck kernels of layer1 / layer3 / layer2 / layer4: one row = 1x1 + 3x3 + 1x1)')
 print('conv launches %d: measured %.1f us, roofline floor %.1f us, fraction of the per-layer floor %.3f' %
       (len(rows), tot, totf, totf / tot))
 for name, fn in (('fwd+bwd', lambda: eng.forward_backward(x, MEAN, STD, y, 0)), ('fwd', lambda: eng.logits(x, MEAN, STD))):

@@ -678,6 +678,7 @@ def test_fused_bottleneck_engine_matches_three_launch_chain(setup):
         assert kinds.count('bottleneck') == 6, kinds          # layer1 blocks 0, 1 and 2, forward and backward
         assert kinds.count('bottleneck14') == 10, kinds       # layer3 identity blocks, forward and backward
         assert kinds.count('bottleneck28') == 6, kinds        # layer2 identity blocks, forward and backward
+        assert kinds.count('bottleneck7') == 4, kinds         # layer4 identity blocks, forward and backward
         ga = ga.clone()
         ea = eng.logits(x, MEAN, STD).clone()
         eng.fused_bottleneck = eng.fused_bottleneck14 = False
@@ -699,18 +700,19 @@ def test_fused_bottleneck_engine_matches_three_launch_chain(setup):
     assert cos > 0.9
 
 
-@pytest.mark.parametrize('B,geo', [(1, 14), (3, 14), (1, 28), (3, 28)])
+@pytest.mark.parametrize('B,geo', [(1, 14), (3, 14), (1, 28), (3, 28), (1, 7), (3, 7)])
 def test_fused_bottleneck14_and_28_forward_and_backward_vs_fp64(B, geo):
     """rart_bottleneck14_fused_bf16 (layer3 identity block, one image per workgroup) and rart_bottleneck28_fused_bf16 (layer2,
-    a quarter image per workgroup with its a1 halo recomputed): x streamed through LDS slices, both intermediates LDS resident;
+    a quarter image per workgroup with its a1 halo recomputed), rart_bottleneck7_fused_bf16 (layer4, two 32-channel blocks per wave): x streamed through LDS slices, both intermediates LDS resident;
     against fp64 with bf16 rounding where the kernels round; same bounds as the layer1 test."""
     from robustart_amd import _lib
     from robustart_amd.model.engine import _Conv, _cints
     lib = _lib.load()
     H = W = geo
-    CIO, CM = (1024, 256) if geo == 14 else (512, 128)
-    fused = lib.rart_bottleneck14_fused_bf16 if geo == 14 else lib.rart_bottleneck28_fused_bf16
-    assert (lib.rart_bottleneck14_fused_supported if geo == 14 else lib.rart_bottleneck28_fused_supported)(CIO, CM, H, W)
+    CIO, CM = {14: (1024, 256), 28: (512, 128), 7: (2048, 512)}[geo]
+    fused = {14: lib.rart_bottleneck14_fused_bf16, 28: lib.rart_bottleneck28_fused_bf16, 7: lib.rart_bottleneck7_fused_bf16}[geo]
+    assert {14: lib.rart_bottleneck14_fused_supported, 28: lib.rart_bottleneck28_fused_supported,
+            7: lib.rart_bottleneck7_fused_supported}[geo](CIO, CM, H, W)
     g = torch.Generator().manual_seed(140 + B)
 
     def mk(cin, cout, k):
@@ -736,8 +738,8 @@ def test_fused_bottleneck14_and_28_forward_and_backward_vs_fp64(B, geo):
     w1f, w3f = frag(ca.w_fwd, CM, CIO), frag(cc.w_fwd, CIO, CM)
     w1b, w3b = frag(cc.bwd[0][2], CM, CIO), frag(ca.bwd[0][2], CIO, CM)
     w2f, w2b = new(9 * CM * CM), new(9 * CM * CM)
-    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(cb.w_fwd), _lib.ptr(w2f), CM, sp))
-    _lib.check(lib.rart_conv3x3_pack_frag_bf16(_lib.ptr(cb.bwd[0][2]), _lib.ptr(w2b), CM, sp))
+    _lib.check(lib.rart_pack_frag_bf16(_lib.ptr(cb.w_fwd), _lib.ptr(w2f), CM, 9 * CM, sp))
+    _lib.check(lib.rart_pack_frag_bf16(_lib.ptr(cb.bwd[0][2]), _lib.ptr(w2b), CM, 9 * CM, sp))
     x = _rand_bf16((B, H, W, CIO), 5, relu=True).cuda()
     y = torch.empty_like(x)
     s1 = torch.zeros(B, H, W, CM // 8, dtype=torch.uint8, device='cuda')
@@ -759,7 +761,8 @@ def test_fused_bottleneck14_and_28_forward_and_backward_vs_fp64(B, geo):
         print('%s: beyond 1 ulp %.2e of the elements, max err %.4f (scale %.2f)' % (what, frac, err.max().item(), ref.abs().max().item()))
         assert frac < frac_max and err.max() <= 0.01 * ref.abs().max(), what
 
-    close(y.cpu().double(), ref, 'fused block forward', frac_max=3e-3)
+    # (the K = 2048 / 4608 sums of the 7 x 7 block flip more 1-ulp roundings of the intermediates; the absolute bound is what matters)
+    close(y.cpu().double(), ref, 'fused block forward', frac_max=3e-3 if geo != 7 else 3e-2)
     unpack = lambda t: torch.from_numpy(np.unpackbits(t.cpu().numpy(), axis=-1, bitorder='little')).bool()
     assert torch.equal(unpack(s3), y.cpu() > 0)
     for s_, a, name in ((s1, a1, 'a1'), (s2, a2, 'a2')):
@@ -786,4 +789,4 @@ def test_fused_bottleneck14_and_28_forward_and_backward_vs_fp64(B, geo):
     refg = ((torch.nn.grad.conv2d_input((B, CIO, H, W), wq[0], d1) + gd) * bits(mx)).permute(0, 2, 3, 1)
     # K = 1024 sums of signed values: more 1-ulp flips of the two intermediates than in the 256-channel block, and many outputs
     # near zero where "1 ulp of the reference" is tiny; the absolute bound (1 % of the scale) is the meaningful one here
-    close(dx.cpu().double(), refg, 'fused block backward', frac_max=2e-2)
+    close(dx.cpu().double(), refg, 'fused block backward', frac_max=2e-2 if geo != 7 else 5e-2)
