@@ -12,11 +12,7 @@
 // robustart_amd/model/resnet_torch.py) and its autograd inside every attack iteration
 // (RobustART/noise/utils/adv/attack.py:21-22, Attacks/autoattack/autopgd_base.py:271-289).
 #include "rart_common.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#include "rart_bf16_helpers.h"
 
 struct RartBneck7Desc {
   const uint16_t* x;        // [n][7][7][2048] bf16: block input (forward) / masked gradient at the block output (backward)
@@ -34,30 +30,7 @@ struct RartBneck7Desc {
 };
 
 namespace {
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) short i16x2_t;
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  f32x2_t f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-}
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
-  const i16x2_t z = {0, 0};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
-}
-__device__ __forceinline__ uint32_t halves_from_bits(uint32_t byte, uint32_t pair) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe(byte, 2u * pair, 1u);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe(byte, 2u * pair + 1u, 1u);
-  return __builtin_amdgcn_perm(hi, lo, 0x07060100u);
-}
-__device__ __forceinline__ uint32_t bits_from_halves(uint32_t w) {
-  const i16x2_t z = {0, 0}, one = {1, 1};
-  const uint32_t t = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z), one));
-  return (t | (t >> 15)) & 3u;
-}
-__device__ __forceinline__ uint32_t sign_byte(uint4 v) {
-  return bits_from_halves(v.x) | (bits_from_halves(v.y) << 2) | (bits_from_halves(v.z) << 4) | (bits_from_halves(v.w) << 6);
-}
+using namespace rart_bf16;
 __device__ __attribute__((aligned(16))) const uint32_t g_b7_zero16[4] = {0u, 0u, 0u, 0u};   // source of the padding slots of an x slice
 
 constexpr int B7_HW = 7, B7_NP = 49;

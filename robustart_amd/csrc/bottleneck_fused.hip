@@ -28,11 +28,7 @@
 // robustart_amd/model/resnet_torch.py) and its autograd inside every attack iteration
 // (RobustART/noise/utils/adv/attack.py:21-22, Attacks/autoattack/autopgd_base.py:271-289).
 #include "rart_common.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // (arrays of HIP's uint4 struct end up in scratch; ext vectors do not)
+#include "rart_bf16_helpers.h"
 
 struct RartBneckDesc {
   const uint16_t* x;        // [n][56][56][256] bf16: the block input (forward) / the masked gradient at the block output (backward)
@@ -55,32 +51,7 @@ struct RartBneckDesc {
 };
 
 namespace {
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) short i16x2_t;
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  f32x2_t f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-}
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
-  const i16x2_t z = {0, 0};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
-}
-// bits (2*pair, 2*pair+1) of `byte` -> 0xFFFF / 0 halves
-__device__ __forceinline__ uint32_t halves_from_bits(uint32_t byte, uint32_t pair) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe(byte, 2u * pair, 1u);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe(byte, 2u * pair + 1u, 1u);
-  return __builtin_amdgcn_perm(hi, lo, 0x07060100u);
-}
-// a packed bf16 pair -> 2 bits (value > 0)
-__device__ __forceinline__ uint32_t bits_from_halves(uint32_t w) {
-  const i16x2_t z = {0, 0}, one = {1, 1};
-  const uint32_t t = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z), one));
-  return (t | (t >> 15)) & 3u;
-}
-__device__ __forceinline__ uint32_t sign_byte(uint4 v) {
-  return bits_from_halves(v.x) | (bits_from_halves(v.y) << 2) | (bits_from_halves(v.z) << 4) | (bits_from_halves(v.w) << 6);
-}
+using namespace rart_bf16;
 
 constexpr int BF_W = 56, BF_H = 56, BF_R = 4;          // image size; output rows per workgroup
 constexpr int BF_TPI = BF_H / BF_R;                     // 14 tiles per image
