@@ -122,7 +122,8 @@ class ResNet50Engine:
         self.halo_conv3x3 = True         # False: layer1 / layer2 3x3 convs on the generic implicit GEMM (cross-check)
         self.fused_stem_fwd = True       # False: prep_input -> row-tap GEMM -> max pool (cross-check; keeps acts['y1'])
         self.fused_bottleneck = True     # False: layer1's identity blocks as three conv launches each (cross-check)
-        self.fused_bottleneck14 = True   # False: layer3's (and layer2's) identity blocks as three conv launches each (cross-check)
+        # identity blocks of layer2 / layer3 / layer4 on the image-resident fused kernels (bottleneck{28,14,7}_fused.hip):
+        self.fused_bottleneck14 = True   # False: all of them as three conv launches each (cross-check)
         self.fused_bottleneck28 = True   # False: only layer2's
         self.fused_bottleneck7 = True    # False: only layer4's
         self.blocks = []
@@ -319,7 +320,7 @@ class ResNet50Engine:
                 and ca.cin == cc.cout and getattr(cb, 'w_fwd_frag', None) is not None
                 and self.lib.rart_bottleneck_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]))
 
-    def _b14_ok(self, ca, cb, cc, ds, xhw):
+    def _image_block_fn(self, ca, cb, cc, ds, xhw):
         """-> the C entry point of the image-resident fused kernel for this block (layer3: 14 x 14, layer2: 28 x 28) or None."""
         if not (self.fused_bottleneck14 and ds is None and getattr(ca, 'w_fwd_frag', None) is not None
                 and getattr(cb, 'w_fwd_frag', None) is not None and getattr(cc, 'w_fwd_frag', None) is not None):
@@ -467,7 +468,7 @@ class ResNet50Engine:
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
                 continue
-            fn14 = self._b14_ok(ca, cb, cc, ds, xhw) if (bits or not keep) else None
+            fn14 = self._image_block_fn(ca, cb, cc, ds, xhw) if (bits or not keep) else None
             if fn14 is not None:
                 self._bneck14(x, ca.w_fwd_frag, cb.w_fwd_frag, cc.w_fwd_frag, ca.bias, cb.bias, cc.bias, sa, sb, sc, yc, B, xhw,
                               cc.cout, ca.cout, cb.fwd_taps, False, fn14)
@@ -545,7 +546,7 @@ class ResNet50Engine:
                             ca.cout, cb.bwd[0][1], True)
                 dz = dx
                 continue
-            fn14 = self._b14_ok(ca, cb, cc, ds, xhw) if (ma is not None and ma.dtype == torch.uint8 and mb is not None) else None
+            fn14 = self._image_block_fn(ca, cb, cc, ds, xhw) if (ma is not None and ma.dtype == torch.uint8 and mb is not None) else None
             if fn14 is not None:
                 dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
                 self._bneck14(dz, cc.w_bwd_frag, cb.w_bwd_frag, ca.w_bwd_frag, None, None, None, mb, ma, mx, dx, B, xhw,
