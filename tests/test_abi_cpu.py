@@ -43,6 +43,19 @@ def test_argument_validation_without_gpu():
     assert lib.rart_corrupt_u8(None, None, 0, 224, 224, 0, 3, 0, 0, None, 0, None, 0, None) == 0
     assert lib.rart_corrupt_workspace_bytes(11, 3, 4, 224, 224) > 0     # contrast needs channel sums
     assert lib.rart_attack_workspace_bytes(256) >= 256 * 32 * 4
+    # gaussian_blur stages its input when called in place (fused separable kernel): the workspace covers the staging copy
+    assert lib.rart_corrupt_workspace_bytes(16, 3, 4, 224, 224) >= 4 * 224 * 224 * 3 * 9        # + the fp64 two-pass scratch
+    # geometry predicates of the fused Bottleneck kernels (host-only functions)
+    assert lib.rart_bottleneck_fused_supported(256, 64, 56, 56) == 1 and lib.rart_bottleneck_fused_supported(256, 64, 28, 28) == 0
+    assert lib.rart_bottleneck_first_supported(64, 64, 256, 56, 56) == 1 and lib.rart_bottleneck_first_supported(64, 64, 256, 24, 24) == 0
+    assert lib.rart_bottleneck28_fused_supported(512, 128, 28, 28) == 1 and lib.rart_bottleneck28_fused_supported(512, 128, 14, 14) == 0
+    assert lib.rart_bottleneck14_fused_supported(1024, 256, 14, 14) == 1 and lib.rart_bottleneck14_fused_supported(1024, 256, 6, 6) == 0
+    assert lib.rart_bottleneck7_fused_supported(2048, 512, 7, 7) == 1 and lib.rart_bottleneck7_fused_supported(2048, 512, 3, 3) == 0
+    assert lib.rart_conv3x3_halo_supported(64, 56, 56) == 1 and lib.rart_conv3x3_halo_supported(512, 7, 7) == 0
+    # aliasing / argument checks happen before any launch
+    st = lib.rart_bottleneck14_fused_bf16(None, None, None, None, None, None, None, None, None, None, None, 1, 14, 14, 1024, 256,
+                                          None, None, 0, None)
+    assert st == 1 and b'bad arguments' in lib.rart_last_error_string()
 
 
 def test_addnoise_api_matches_reference_behaviour():
