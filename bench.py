@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-reference-precision', action='store_true',
+                    help="skip the second block: the same step on the reference-precision ('bf16x3') engine")
     ap.add_argument('--cpu-sample', type=int, default=64, help='images of the bounded model leg of the CPU baseline')
     ap.add_argument('--cpu-sweep', action='store_true', help='only run the CPU 14 corruptions x 5 severities sweep (BASELINE.md 3b)')
     ap.add_argument('--workload', choices=['headline', 'vit_inc', 'vit_pgd', 'adv_train'], default='headline',
@@ -120,12 +122,15 @@ class HipEngine:
     name = 'hip-igemm-bf16'
     MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
-    def __init__(self, model, device, two_streams=True):
+    def __init__(self, model, device, two_streams=True, precision='bf16'):
         from robustart_amd.model.engine import ResNet50Engine, EngineModel
-        self.eng = ResNet50Engine(model, device)
+        self.precision = precision
+        if precision != 'bf16':
+            self.name = 'hip-igemm-' + precision
+        self.eng = ResNet50Engine(model, device, precision)
         self.f_model = EngineModel(None, takes_normalized=False, mean=self.MEAN, std=self.STD, engine=self.eng)
         n_side = int(os.environ.get('RART_BENCH_SIDE_STREAMS', '1')) if two_streams else 0
-        self.eval_engs = [ResNet50Engine(model, device) for _ in range(n_side)] or [self.eng]
+        self.eval_engs = [ResNet50Engine(model, device, precision) for _ in range(n_side)] or [self.eng]
         self.sides = [torch.cuda.Stream(device=device) for _ in range(n_side)]
         self.side = self.sides[0] if self.sides else None
 
@@ -275,6 +280,48 @@ def measure_igemm_roofline(path, images, labels):
         out['all_conv_launches'] = {'achieved': (flops + hf) / (secs + hs) / 1e12, 'unit': 'TFLOP/s',
                                     'frac': (flops + hf) / (secs + hs) / MFMA_BF16_PEAK, 'seconds_per_fwd_bwd': secs + hs}
     return out
+
+
+MFMA_F32_PEAK = 157.3e12               # v_mfma_f32_32x32x2_f32, the rate fp32 operands would get
+
+
+def measure_reference_precision(model, device, images, labels, scratch, norm_buf, rank, B, steps, two_streams):
+    """The SAME step on the reference-precision engine (precision 'bf16x3': hi + lo bf16 pairs, three MFMA products per
+    contraction, fp32 accumulate -- logits within ~1e-5 of the fp32 network where the bf16 headline is ~3e-3; the
+    reference's arithmetic is fp32, adv/attack.py:20-23).  One warm-up step, `steps` timed steps, then one gradient
+    evaluation timed launch by launch for the roofline block."""
+    path = HipEngine(model, device, two_streams=two_streams, precision='bf16x3')
+    one_step(images, labels, path, scratch, norm_buf, 0, rank, B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        acc = one_step(images, labels, path, scratch, norm_buf, 1 + i, rank, B)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng = path.eng
+    x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
+    eng.profile = []
+    eng.forward_backward(x01, path.MEAN, path.STD, labels, 0)
+    torch.cuda.synchronize()
+    prof, eng.profile = eng.profile, None
+    secs = sum(a.elapsed_time(b) for _, a, b, _ in prof) * 1e-3
+    issued = sum(f for f, _, _, _ in prof)               # MFMA FLOPs issued: three bf16 products per algorithmic product
+    algo = issued / 3.0
+    step_flops = (5 + 15) * B * FLOP_FWD
+    return {'value': 6 * B * steps / dt, 'unit': 'images/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'dtype': 'bf16x3',
+            'arithmetic': 'activations / gradients / weights as hi + lo bf16 pairs (16 significand bits), x.w = hi.hi + hi.lo + lo.hi '
+                          'on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; logits within 1e-4 of the fp32 network '
+                          '(tests/test_engine_x3_gpu.py, tests/test_outcome_gpu.py)',
+            'model_path': path.name, 'correct_corrupted': int(acc[0]), 'correct_adv': int(acc[1]),
+            'step_algorithmic': {'achieved': step_flops * steps / dt / 1e12, 'unit': 'TFLOP/s',
+                                 'vs_fp32_mfma_peak': step_flops * steps / dt / MFMA_F32_PEAK,
+                                 'note': 'fp32-equivalent FLOPs of the step / time; 157.3 TFLOP/s is what fp32 MFMA operands peak at'},
+            'roofline': {'kernel': 'k_conv_igemm_bf16<.., PAIR> (ResNet-50 forward + backward-to-input, B=%d, %d launches)' % (B, len(prof)),
+                         'bound': 'mfma', 'achieved': issued / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                         'frac': issued / secs / MFMA_BF16_PEAK, 'traffic': None,
+                         'achieved_fp32_equivalent': algo / secs / 1e12, 'avg_launch_us': secs / len(prof) * 1e6,
+                         'kernel_seconds_per_fwd_bwd': secs,
+                         'note': 'achieved counts the bf16 MFMA FLOPs actually issued (3 per algorithmic product)'}}
 
 
 def _cpu_model_name():
@@ -653,6 +700,9 @@ def main():
                                 'note': 'whole-step algorithmic FLOPs (20 forward-equivalents) / step time'}
             if isinstance(path, HipEngine):
                 out['roofline'] = measure_igemm_roofline(path, images, labels)
+                if not args.no_reference_precision:
+                    out['reference_precision'] = measure_reference_precision(
+                        model, device, images, labels, scratch, norm_buf, rank, B, max(2, min(args.steps, 5)), not args.one_stream)
             if model_cpu is not None:
                 out['cpu_baseline'] = cpu_baseline(args.cpu_sample, model_cpu)
         print(json.dumps(out))

@@ -274,11 +274,12 @@ typedef struct rart_conv_desc {
   int32_t src_h, src_w, src_pix_stride;
   int32_t k_per_tap, n_taps;
   int32_t sy, sx;
-  int32_t tap_dy[16], tap_dx[16];
-  int64_t tap_src_off[16];
+  int32_t tap_dy[32], tap_dx[32];
+  int64_t tap_src_off[32];
   int32_t n_cols;
   int32_t dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
-  int32_t flags;          /* 1 = ReLU, 2 = fp32 output, 4 = exact GELU, 8 = GELU' of `mask`, 16 = `mask` is a 1-bit tensor */
+  int32_t flags;          /* 1 = ReLU, 2 = fp32 output, 4 = exact GELU, 8 = GELU' of `mask`, 16 = `mask` is a 1-bit tensor,
+                           * 32 = split-bf16 tensors (dst_pair_off / res_pair_off below) */
   /* batched problems (attention: one GEMM per (image, head)): problem z in [0, n_batched) splits into
    * zo = z / z_inner, zi = z % z_inner; zo*_z_outer + zi*_z_inner elements are added to src / wgt / dst (res and
    * mask follow dst).  n_batched <= 1 = a single problem.  wgt_row_stride: elements between consecutive weight
@@ -289,6 +290,14 @@ typedef struct rart_conv_desc {
    * needs activations only for their ReLU sign, so the forward GEMM writes (output > 0) here (nullable) and the backward
    * GEMM reads it through `mask` with flag 16 -- 1/16 of the bytes of a bf16 mask.  bf16 output, unbatched problems. */
   void* sign_out;
+  /* flag 32, the reference-precision ("bf16x3") mode: every activation is a PAIR of bf16 planes, value = hi + lo with
+   * hi = bf16(v), lo = bf16(v - hi) (16 significand bits), every weight likewise; the caller lists the three products
+   * x_hi.w_hi + x_hi.w_lo + x_lo.w_hi as 3x the taps (tap_src_off selects the operand plane, the weight row is the
+   * concatenation [w_hi | w_lo | w_hi]) so they accumulate in the same fp32 registers.  dst / res then name the hi plane and
+   * the lo plane sits dst_pair_off / res_pair_off ELEMENTS behind it (multiples of 8); `mask` must be a 1-bit tensor;
+   * with flag 2 the output is plain fp32 and no residual / mask is applied.  Reference arithmetic: fp32 everywhere
+   * (adv/attack.py:20-23, autopgd_base.py:271-289); this mode reproduces it to ~1e-5 of the logit scale. */
+  int64_t dst_pair_off, res_pair_off;
 } rart_conv_desc;
 
 int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
@@ -396,6 +405,28 @@ int rart_engine_avgpool_bwd(const void* y, const void* dpool, void* dz, int n, i
  * the [0,1] image (the 1/std of the normalisation applied). */
 int rart_engine_stem_col2im(const void* patches, float* grad, int n, int h, int w, int patch_cols,
                             const float* std_host, rart_stream_t stream);
+/* ---- reference-precision ("bf16x3") forms of the pools / converters (csrc/engine_aux_pair.hip) -----------------------------
+ * Every tensor is a PAIR of bf16 planes, value = hi + lo (see rart_conv_desc flag 32): `*_hi` names the hi plane and the lo
+ * plane sits `*_lo_off` ELEMENTS behind it (a positive multiple of 8).  Arithmetic: unpack to fp32 (hi + lo is exact),
+ * compute as the bf16 kernel of the same name, split again.  Reference: the fp32 max_pool2d / adaptive_avg_pool2d and their
+ * autograd inside `model(x)` of adv/attack.py:20-23, autopgd_base.py:271-289. */
+int rart_engine_maxpool_pair(const void* in_hi, long long in_lo_off, void* out_hi, long long out_lo_off, void* argmax_out,
+                             void* sign_out, int n, int h, int w, int c, rart_stream_t stream);
+/* dz (at the pool input, masked by the ReLU in front of the pool) from the argmax codes alone: code 15 marks windows whose
+ * maximum is <= 0, any other code names a position whose value is that positive maximum. */
+int rart_engine_maxpool_bwd_pair(const void* argmax, const void* dpool_hi, long long dpool_lo_off, void* dz_hi,
+                                 long long dz_lo_off, int n, int h, int w, int c, rart_stream_t stream);
+int rart_engine_avgpool_pair(const void* in_hi, long long in_lo_off, void* out_hi, long long out_lo_off, int n, int hw, int c,
+                             rart_stream_t stream);
+/* y_sign_bits: uint8 [n][hw][c/8], the 1-bit (y > 0) tensor the last block's forward GEMM wrote through sign_out. */
+int rart_engine_avgpool_bwd_pair(const void* y_sign_bits, const void* dpool_hi, long long dpool_lo_off, void* dz_hi,
+                                 long long dz_lo_off, int n, int hw, int c, rart_stream_t stream);
+/* fp32 [rows][cols] -> pair [rows][dst_cols] (zero padded): the loss gradient entering the fc backward. */
+int rart_f32_to_pair_rows(const float* src, void* dst_hi, long long dst_lo_off, int rows, int cols, int dst_cols,
+                          rart_stream_t stream);
+/* rart_engine_stem_col2im for fp32 patches (the stem's backward GEMM run with flags 32 | 2); h % 8 == 0, w % 16 == 0. */
+int rart_engine_stem_col2im_f32(const float* patches, float* grad, int n, int h, int w, int patch_cols, const float* std_host,
+                                rart_stream_t stream);
 /* The same stem backward as ONE kernel: pooled gradient dpool [n][h/4][w/4][64] bf16 + the max pool's argmax codes
  * (rart_engine_maxpool; code 15 = window maximum <= 0) -> fp32 NCHW gradient w.r.t. the [0,1] image.  Max-pool backward,
  * the ReLU mask and the transposed 7x7/2 convolution are fused: an implicit GEMM over the 4x4 neighbourhood of

@@ -97,6 +97,12 @@ SIGNATURES = {
     'rart_engine_stem_fwd_fused': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                            c_int, c_void_p, c_void_p, c_void_p]),
     'rart_engine_stem_bwd_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'rart_engine_maxpool_pair': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_maxpool_bwd_pair': (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_avgpool_pair': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_avgpool_bwd_pair': (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
+    'rart_f32_to_pair_rows': (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_void_p]),
+    'rart_engine_stem_col2im_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_f32_to_bf16_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_vit_patchify': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),
@@ -151,7 +157,7 @@ class ConvDesc(ctypes.Structure):
                 ('batch', ctypes.c_int32), ('grid_h', ctypes.c_int32), ('grid_w', ctypes.c_int32),
                 ('src_h', ctypes.c_int32), ('src_w', ctypes.c_int32), ('src_pix_stride', ctypes.c_int32),
                 ('k_per_tap', ctypes.c_int32), ('n_taps', ctypes.c_int32), ('sy', ctypes.c_int32), ('sx', ctypes.c_int32),
-                ('tap_dy', ctypes.c_int32 * 16), ('tap_dx', ctypes.c_int32 * 16), ('tap_src_off', ctypes.c_int64 * 16),
+                ('tap_dy', ctypes.c_int32 * 32), ('tap_dx', ctypes.c_int32 * 32), ('tap_src_off', ctypes.c_int64 * 32),
                 ('n_cols', ctypes.c_int32),
                 ('dst_h', ctypes.c_int32), ('dst_w', ctypes.c_int32), ('dst_sy', ctypes.c_int32), ('dst_sx', ctypes.c_int32),
                 ('dst_oy', ctypes.c_int32), ('dst_ox', ctypes.c_int32), ('dst_pix_stride', ctypes.c_int32),
@@ -160,7 +166,7 @@ class ConvDesc(ctypes.Structure):
                 ('reserved_', ctypes.c_int32),
                 ('src_z_outer', ctypes.c_int64), ('src_z_inner', ctypes.c_int64), ('wgt_z_outer', ctypes.c_int64),
                 ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64),
-                ('sign_out', c_void_p)]
+                ('sign_out', c_void_p), ('dst_pair_off', ctypes.c_int64), ('res_pair_off', ctypes.c_int64)]
 
 
 _lib = None

@@ -41,8 +41,8 @@ struct RartConvDescDev {
   int src_h, src_w, src_pix_stride;
   int k_per_tap, n_taps;
   int sy, sx;
-  int tap_dy[16], tap_dx[16];
-  long long tap_src_off[16];
+  int tap_dy[32], tap_dx[32];
+  long long tap_src_off[32];
   int n_cols;
   int dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
   int flags;
@@ -56,12 +56,15 @@ struct RartConvDescDev {
   // 1-bit-per-element side tensors, indexed like dst (byte (off + col) / 8, bit col % 8): sign_out receives (output > 0)
   // of a bf16 store (the ReLU mask the backward pass will need); with F_MASK_BITS `mask` is such a tensor instead of bf16
   uint8_t* sign_out;
+  // split-bf16 ("bf16x3") tensors: a value is the pair hi + lo of two bf16 planes; the lo plane of dst / res sits this many
+  // ELEMENTS after the hi plane (PAIR kernel instances only; src planes are reached through tap_src_off)
+  long long dst_pair_off, res_pair_off;
 };
 
 namespace {
 constexpr int BM = 128;
 constexpr int kThreads = 256;
-enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8, F_MASK_BITS = 16 };
+enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8, F_MASK_BITS = 16, F_PAIR = 32 };
 
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
@@ -130,7 +133,10 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 // BK = 32: two register sets, loads two K steps ahead (memory-latency-bound 1x1 layers, 3 blocks/CU).
 // BK = 64: one register set, loads one (twice as long) K step ahead, half the barriers per FLOP
 //          (compute-bound 3x3 layers and transformer GEMMs; 73 KB of LDS -> 2 blocks/CU).
-template <int BN, int BK>
+// PAIR: the split-bf16 reference-precision mode (flag 32).  The K loop is unchanged -- the host lists every product of the
+// scheme (x_hi.w_hi, x_hi.w_lo, x_lo.w_hi) as extra taps whose tap_src_off selects the operand plane, so all three
+// accumulate in the same fp32 registers -- and the epilogue reads a residual pair and writes hi = bf16(v), lo = bf16(v - hi).
+template <int BN, int BK, bool PAIR>
 __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(const RartConvDescDev d) {
   constexpr int LDK = BK + 8;  // LDS row: 80 B (BK 32) / 144 B (BK 64): ds_read_b128 fragment reads are conflict free
   // batched problems: block-uniform base shifts, kept in scalars (copying the descriptor would move its tap
@@ -401,16 +407,20 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   for (int i = 0; i < 2; ++i) {
     // issue the residual / mask reads of this pass first: their HBM latency overlaps the LDS transposition
     uint32_t offs[NQ];
-    uint4 rv[NQ], mv[NQ];
+    uint4 rv[NQ], mv[NQ], rl[PAIR ? NQ : 1];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const uint32_t off = col_ok ? row_dst[wm * 64 + i * 32 + q * RPI + rw0] : 0xFFFFFFFFu;
       offs[q] = off;
       rv[q] = make_uint4(0, 0, 0, 0);
+      if constexpr (PAIR) rl[q] = make_uint4(0, 0, 0, 0);
       mv[q] = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 pairs: mask passes
       if (off != 0xFFFFFFFFu) {
         const size_t bo = (size_t)((off + (uint32_t)col) * 2u);
-        if (p_res) rv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_res) + bo);
+        if (p_res) {
+          rv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_res) + bo);
+          if constexpr (PAIR) rl[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_res + d.res_pair_off) + bo);
+        }
         if (p_mask) {
           if (mask_bits) mv[q].x = reinterpret_cast<const uint8_t*>(p_mask)[(off + (uint32_t)col) >> 3];
           else mv[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_mask) + bo);
@@ -438,10 +448,19 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
         const uint32_t rw[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
         const uint32_t mw[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
         if (p_res) {
+          if constexpr (PAIR) {   // hi + lo is exact in fp32 (two 8-bit significands, lo below half an ulp of hi)
+            const uint32_t rlw[4] = {rl[q].x, rl[q].y, rl[q].z, rl[q].w};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[2 * j] += __uint_as_float(rw[j] << 16);
-            v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
+            for (int j = 0; j < 4; ++j) {
+              v[2 * j] += __uint_as_float(rw[j] << 16) + __uint_as_float(rlw[j] << 16);
+              v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u) + __uint_as_float(rlw[j] & 0xFFFF0000u);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[2 * j] += __uint_as_float(rw[j] << 16);
+              v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
+            }
           }
         }
         if (d.flags & F_GELU) {   // exact (erf) GELU, timm's nn.GELU default
@@ -470,6 +489,30 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
           float* o = reinterpret_cast<float*>(d.dst) + p_dst_off + off + col;
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if constexpr (PAIR) {
+          // split-bf16 output: 1-bit mask and ReLU on the fp32 value, then hi = bf16(v), lo = bf16(v - hi): 16 significand bits
+          uint32_t oh[4], ol[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (p_mask) {
+              if (!((mw[0] >> (2 * j)) & 1u)) v[2 * j] = 0.f;
+              if (!((mw[0] >> (2 * j + 1)) & 1u)) v[2 * j + 1] = 0.f;
+            }
+            if (relu) {
+              v[2 * j] = fmaxf(v[2 * j], 0.f);
+              v[2 * j + 1] = fmaxf(v[2 * j + 1], 0.f);
+            }
+            oh[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+            ol[j] = pack_bf16x2(v[2 * j] - __uint_as_float(oh[j] << 16), v[2 * j + 1] - __uint_as_float(oh[j] & 0xFFFF0000u));
+          }
+          if (p_sign) {
+            const uint32_t sb = bits_from_halves(oh[0]) | (bits_from_halves(oh[1]) << 2) | (bits_from_halves(oh[2]) << 4) |
+                                (bits_from_halves(oh[3]) << 6);
+            p_sign[(off + (uint32_t)col) >> 3] = (uint8_t)sb;
+          }
+          uint16_t* const o16 = reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col;
+          *reinterpret_cast<uint4*>(o16) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+          *reinterpret_cast<uint4*>(o16 + d.dst_pair_off) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
         } else {
           // bf16 output: hardware RNE pack (v_cvt_pk_bf16_f32), then mask and ReLU on the packed pairs with
           // 16-bit integer ops (a bf16 is > 0 exactly when its bits, read as int16, are > 0)
@@ -690,7 +733,7 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   RART_CHECK_ARG(h != nullptr, "rart_conv_igemm_bf16: null descriptor");
   RART_CHECK_ARG(h->src && h->wgt && h->dst, "rart_conv_igemm_bf16: null tensor pointer");
   RART_CHECK_ARG(h->batch > 0 && h->grid_h > 0 && h->grid_w > 0, "rart_conv_igemm_bf16: empty row grid");
-  RART_CHECK_ARG(h->n_taps >= 1 && h->n_taps <= 16, "rart_conv_igemm_bf16: n_taps must be 1..16");
+  RART_CHECK_ARG(h->n_taps >= 1 && h->n_taps <= 32, "rart_conv_igemm_bf16: n_taps must be 1..32");
   RART_CHECK_ARG(h->k_per_tap > 0 && h->k_per_tap % 32 == 0, "rart_conv_igemm_bf16: k_per_tap must be a multiple of 32");
   RART_CHECK_ARG(h->n_cols > 0 && h->n_cols % 8 == 0, "rart_conv_igemm_bf16: n_cols must be a multiple of 8");
   RART_CHECK_ARG(h->src_pix_stride % 8 == 0 || h->src_pix_stride == 4,
@@ -715,7 +758,7 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   d.batch = h->batch; d.grid_h = h->grid_h; d.grid_w = h->grid_w;
   d.src_h = h->src_h; d.src_w = h->src_w; d.src_pix_stride = h->src_pix_stride;
   d.k_per_tap = h->k_per_tap; d.n_taps = h->n_taps; d.sy = h->sy; d.sx = h->sx;
-  for (int i = 0; i < 16; ++i) { d.tap_dy[i] = h->tap_dy[i]; d.tap_dx[i] = h->tap_dx[i]; d.tap_src_off[i] = h->tap_src_off[i]; }
+  for (int i = 0; i < 32; ++i) { d.tap_dy[i] = h->tap_dy[i]; d.tap_dx[i] = h->tap_dx[i]; d.tap_src_off[i] = h->tap_src_off[i]; }
   d.n_cols = h->n_cols; d.dst_h = h->dst_h; d.dst_w = h->dst_w; d.dst_sy = h->dst_sy; d.dst_sx = h->dst_sx;
   d.dst_oy = h->dst_oy; d.dst_ox = h->dst_ox; d.dst_pix_stride = h->dst_pix_stride; d.flags = h->flags;
   const int nz = h->n_batched > 1 ? h->n_batched : 1;
@@ -724,6 +767,12 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   d.src_zo = h->src_z_outer; d.src_zi = h->src_z_inner; d.wgt_zo = h->wgt_z_outer; d.wgt_zi = h->wgt_z_inner;
   d.dst_zo = h->dst_z_outer; d.dst_zi = h->dst_z_inner;
   d.sign_out = (uint8_t*)h->sign_out;
+  const bool pair = (h->flags & F_PAIR) != 0;
+  d.dst_pair_off = h->dst_pair_off; d.res_pair_off = h->res_pair_off;
+  RART_CHECK_ARG(!pair || (nz == 1 && !(d.flags & (F_GELU | F_GELU_BWD)) && (!d.mask || (d.flags & F_MASK_BITS)) &&
+                           ((d.flags & F_OUT_F32) ? (!d.res && !d.mask) : (d.dst_pair_off > 0 && d.dst_pair_off % 8 == 0)) &&
+                           (!d.res || (d.res_pair_off > 0 && d.res_pair_off % 8 == 0))),
+                 "rart_conv_igemm_bf16: split-bf16 (flag 32) needs an unbatched problem, 1-bit masks and 16-byte aligned lo planes");
   RART_CHECK_ARG(!(d.sign_out || (d.flags & F_MASK_BITS)) || (nz == 1 && !(d.flags & (F_OUT_F32 | F_GELU_BWD))),
                  "rart_conv_igemm_bf16: sign_out / bit masks need a single bf16-output problem");
   {
@@ -759,10 +808,15 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   const bool deep = (d.k_per_tap % 64 == 0) && ((long long)d.k_per_tap * d.n_taps >= g_bk64_min_k);
   const dim3 grid((uint32_t)blocks, nz);
   hipStream_t st = (hipStream_t)stream;
-  if (wide && deep) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 64>), grid, dim3(kThreads), 0, st, d);
-  else if (wide) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 32>), grid, dim3(kThreads), 0, st, d);
-  else if (deep) hipLaunchKernelGGL((k_conv_igemm_bf16<64, 64>), grid, dim3(kThreads), 0, st, d);
-  else hipLaunchKernelGGL((k_conv_igemm_bf16<64, 32>), grid, dim3(kThreads), 0, st, d);
+  if (pair) {
+    if (wide && deep) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 64, true>), grid, dim3(kThreads), 0, st, d);
+    else if (wide) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 32, true>), grid, dim3(kThreads), 0, st, d);
+    else if (deep) hipLaunchKernelGGL((k_conv_igemm_bf16<64, 64, true>), grid, dim3(kThreads), 0, st, d);
+    else hipLaunchKernelGGL((k_conv_igemm_bf16<64, 32, true>), grid, dim3(kThreads), 0, st, d);
+  } else if (wide && deep) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 64, false>), grid, dim3(kThreads), 0, st, d);
+  else if (wide) hipLaunchKernelGGL((k_conv_igemm_bf16<128, 32, false>), grid, dim3(kThreads), 0, st, d);
+  else if (deep) hipLaunchKernelGGL((k_conv_igemm_bf16<64, 64, false>), grid, dim3(kThreads), 0, st, d);
+  else hipLaunchKernelGGL((k_conv_igemm_bf16<64, 32, false>), grid, dim3(kThreads), 0, st, d);
   RART_CHECK_LAUNCH("rart_conv_igemm_bf16");
   return RART_OK;
 }

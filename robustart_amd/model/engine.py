@@ -17,7 +17,8 @@ import ctypes
 
 from .. import _lib
 
-F_RELU, F_OUT_F32, F_MASK_BITS = 1, 2, 16
+F_RELU, F_OUT_F32, F_MASK_BITS, F_PAIR = 1, 2, 16, 32
+PRECISIONS = {'bf16': 'bf16', 'bf16x3': 'bf16x3', 'fp32x': 'bf16x3'}
 
 
 def _bf16(t):
@@ -41,7 +42,7 @@ def _rows_mult(n_cols):
 class _Conv:
     """One folded conv layer: forward table + backward-to-input tables."""
 
-    def __init__(self, conv, bn, device):
+    def __init__(self, conv, bn, device, split=False):
         import torch
         w = conv.weight.detach().float()
         if bn is not None:
@@ -55,13 +56,29 @@ class _Conv:
         self.pad = conv.padding[0]
         self.w_folded = w                    # fp32, for the reference emulation in tests
         self.b_folded = b
-        wb = w.to(torch.bfloat16).float()    # the values the kernels see
-        # forward: rows = cout, k = (r*S + s)*Cin + c
-        self.w_fwd = _bf16(_pad_rows(wb.permute(0, 2, 3, 1).reshape(self.cout, -1), _rows_mult(self.cout))).to(device)
         self.bias = b.contiguous().to(device)
         self.fwd_taps = [(r - self.pad, s - self.pad) for r in range(self.r) for s in range(self.s)]
+        wb = w.to(torch.bfloat16).float()    # the values the bf16 kernels see
+        if not split:
+            self.w_fwd, self.bwd = self._tables(wb, device)
+        else:
+            # reference-precision mode: w = hi + lo (two bf16 pieces, 16 significand bits); a weight row is the
+            # concatenation [hi | lo | hi] matching the products x_hi.w_hi + x_hi.w_lo + x_lo.w_hi (rart_conv_desc flag 32)
+            wl = (w - wb).to(torch.bfloat16).float()
+            fh, bh = self._tables(wb, device)
+            fl, bl = self._tables(wl, device)
+            self.w_fwd = torch.cat([fh, fl, fh], 1).contiguous()
+            self.bwd = [(par, taps, None if th is None else torch.cat([th, tl, th], 1).contiguous())
+                        for (par, taps, th), (_, _, tl) in zip(bh, bl)]
+
+    def _tables(self, wb, device):
+        """-> (forward table [cout][tap][cin], backward-to-input tables [(parity, taps, [cin][tap][cout])]) of the bf16-exact
+        fp32 weights wb [cout][cin][r][s]."""
+        import torch
+        # forward: rows = cout, k = (r*S + s)*Cin + c
+        w_fwd = _bf16(_pad_rows(wb.permute(0, 2, 3, 1).reshape(self.cout, -1), _rows_mult(self.cout))).to(device)
         # backward to input: rows = cin, k = tap*Cout + cout
-        self.bwd = []    # list of (parity (ph,pw) or None, taps [(dy,dx)], weight)
+        bwd = []    # list of (parity (ph,pw) or None, taps [(dy,dx)], weight)
         if self.stride == 1:
             taps, cols = [], []
             for r in range(self.r):
@@ -69,7 +86,7 @@ class _Conv:
                     taps.append((self.pad - r, self.pad - s))
                     cols.append(wb[:, :, r, s].t())                     # [cin][cout]
             wd = torch.cat(cols, 1)
-            self.bwd.append((None, taps, _bf16(_pad_rows(wd, _rows_mult(self.cin))).to(device)))
+            bwd.append((None, taps, _bf16(_pad_rows(wd, _rows_mult(self.cin))).to(device)))
         else:
             assert self.stride == 2
             for ph in range(2):
@@ -84,10 +101,11 @@ class _Conv:
                             taps.append(((ph + self.pad - r) // 2, (pw + self.pad - s) // 2))
                             cols.append(wb[:, :, r, s].t())
                     if not taps:
-                        self.bwd.append(((ph, pw), [], None))
+                        bwd.append(((ph, pw), [], None))
                         continue
                     wd = torch.cat(cols, 1)
-                    self.bwd.append(((ph, pw), taps, _bf16(_pad_rows(wd, _rows_mult(self.cin))).to(device)))
+                    bwd.append(((ph, pw), taps, _bf16(_pad_rows(wd, _rows_mult(self.cin))).to(device)))
+        return w_fwd, bwd
 
 
 def _cints(vals):
@@ -97,15 +115,24 @@ def _cints(vals):
 class ResNet50Engine:
     """Hand-written HIP eval engine for robustart_amd.model.resnet_torch.ResNet."""
 
-    def __init__(self, model, device='cuda'):
+    def __init__(self, model, device='cuda', precision='bf16'):
+        """precision: 'bf16' -- bf16 storage, fp32 accumulation (the fast path; logits within ~3e-3 of the fp32 network);
+        'bf16x3' (alias 'fp32x') -- the REFERENCE-PRECISION mode: the reference runs fp32 (adv/attack.py:20-23,
+        autopgd_base.py:271-289) and the north star asks for logits within 1e-4 of it, so every activation, gradient and
+        weight is a hi + lo pair of bf16 values (16 significand bits) and every contraction the three MFMA products
+        hi.hi + hi.lo + lo.hi with fp32 accumulation (`_forward_x3`): logits within ~1e-5 of the fp32 network's scale."""
         torch = _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
+        if precision not in PRECISIONS:
+            raise ValueError('precision must be one of %s' % sorted(PRECISIONS))
+        self.precision = PRECISIONS[precision]
+        split = self.precision == 'bf16x3'
         m = model
         assert not m.training, 'the attack / eval engine folds BatchNorm: call model.eval() first'
         dev = self.device
         # ---- stem: 7x7/2 conv on the padded 4-channel hi/lo image; a "tap" = one filter row, 8 px x 4 ch
-        st = _Conv(m.conv1, m.bn1, dev)
+        st = _Conv(m.conv1, m.bn1, dev, split)
         self.stem = st
         wb = st.w_folded.to(torch.bfloat16).float()                       # [64][3][7][7]
         wrow = torch.zeros(64, 7, 8, 4)
@@ -117,6 +144,14 @@ class ResNet50Engine:
         self.stem_patch_cols = 152                                        # 147 rounded up to 8
         self.stem_wd = _bf16(_pad_rows(wp, _rows_mult(self.stem_patch_cols))).to(dev)
         self.stem_wt = self._stem_bwd_table(wb).to(dev)                  # fused stem backward (stem_fused.hip)
+        if split:
+            wl = (st.w_folded - wb).to(torch.bfloat16).float()
+            wrow_l = torch.zeros(64, 7, 8, 4)
+            wrow_l[:, :, :7, :3] = wl.permute(0, 2, 3, 1)
+            wrow_l = wrow_l.reshape(64, 7 * 32)
+            self.stem_w = _bf16(torch.cat([wrow, wrow_l, wrow], 1)).to(dev)      # x_hi.w_hi, x_hi.w_lo, x_lo.w_hi row taps
+            wpl = wl.permute(2, 3, 1, 0).reshape(147, 64)
+            self.stem_wd = _bf16(_pad_rows(torch.cat([wp, wpl, wp], 1), _rows_mult(self.stem_patch_cols))).to(dev)
         self.fused_stem_bwd = True       # False: max-pool bwd -> patches GEMM -> col2im (kept as the cross-check)
         self.sign_bit_masks = True       # False: the backward reads the bf16 activations for their ReLU sign (cross-check)
         self.halo_conv3x3 = True         # False: layer1 / layer2 3x3 convs on the generic implicit GEMM (cross-check)
@@ -129,9 +164,9 @@ class ResNet50Engine:
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
-                ds = _Conv(blk.downsample[0], blk.downsample[1], dev) if blk.downsample is not None else None
-                self.blocks.append((_Conv(blk.conv1, blk.bn1, dev), _Conv(blk.conv2, blk.bn2, dev),
-                                    _Conv(blk.conv3, blk.bn3, dev), ds))
+                ds = _Conv(blk.downsample[0], blk.downsample[1], dev, split) if blk.downsample is not None else None
+                self.blocks.append((_Conv(blk.conv1, blk.bn1, dev, split), _Conv(blk.conv2, blk.bn2, dev, split),
+                                    _Conv(blk.conv3, blk.bn3, dev, split), ds))
         # ---- classifier
         wfc = m.fc.weight.detach().float()
         self.n_classes, self.fc_in = wfc.shape
@@ -142,9 +177,17 @@ class ResNet50Engine:
         wt = torch.zeros(self.fc_in, self.fc_kpad)
         wt[:, :self.n_classes] = wfb.t()
         self.fc_wd = _bf16(wt).to(dev)                                    # [2048][1024]
+        if split:
+            wfl = (wfc - wfb).to(torch.bfloat16).float()
+            fh, fl = _pad_rows(wfb, 128), _pad_rows(wfl, 128)
+            self.fc_w = _bf16(torch.cat([fh, fl, fh], 1)).to(dev)         # [1024][3 * 2048]
+            wtl = torch.zeros(self.fc_in, self.fc_kpad)
+            wtl[:, :self.n_classes] = wfl.t()
+            self.fc_wd = _bf16(torch.cat([wt, wtl, wt], 1)).to(dev)       # [2048][3 * 1024]
         self._buf = {}
         self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
-        self._pack_frag_tables()
+        if not split:
+            self._pack_frag_tables()
 
     def _pack_frag_tables(self):
         """MFMA-fragment-ordered copies of the 3x3 tables the LDS-resident kernels (conv3x3_halo.hip, bottleneck_fused.hip)
@@ -200,6 +243,9 @@ class ResNet50Engine:
         (rart_pack_conv_weight_bf16 with the BatchNorm scale folded in): the adversarial-training loop attacks the
         model it is training (cifar10/code/train.py:105-111), so the attack engine is refreshed every iteration."""
         torch = _lib.require_gpu()
+        if self.precision != 'bf16':
+            raise NotImplementedError('refold() serves the adversarial-training loop, which attacks on the bf16 engine; build a '
+                                      'new ResNet50Engine(model, precision=%r) from the updated weights instead' % self.precision)
         lib, sp = self.lib, _lib.stream_ptr()
         m = model
 
@@ -263,8 +309,20 @@ class ResNet50Engine:
 
     def _gemm(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix,
               bias=None, res=None, mask=None, flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0),
-              tap_src_off=None, sign_out=None):
+              tap_src_off=None, sign_out=None, pair=False):
         d = _lib.ConvDesc()
+        if pair:
+            # split-bf16 tensors [2][...] (hi plane, lo plane): the three products as 3x the taps, the lo planes of dst / res
+            # by their element offsets (rart_conv_desc flag 32); an fp32 destination (F_OUT_F32) is a plain tensor
+            assert tap_src_off is None and src.shape[0] == 2
+            lo = (src[1].data_ptr() - src[0].data_ptr()) // 2
+            tap_src_off = [0] * (2 * len(taps)) + [lo] * len(taps)
+            taps = list(taps) * 3
+            flags |= F_PAIR
+            if not (flags & F_OUT_F32):
+                d.dst_pair_off = (dst[1].data_ptr() - dst[0].data_ptr()) // 2
+            if res is not None:
+                d.res_pair_off = (res[1].data_ptr() - res[0].data_ptr()) // 2
         d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
         d.bias = bias.data_ptr() if bias is not None else None
         d.res = res.data_ptr() if res is not None else None
@@ -386,35 +444,41 @@ class ResNet50Engine:
             _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, hw[0], hw[1], c_io, c_mid, _cints([t[0] for t in taps]),
             _cints([t[1] for t in taps]), 1 if backward else 0, _lib.stream_ptr()))
 
-    def _conv_fwd(self, c, x, xhw, out, relu, res=None, sign=None):
-        B = x.shape[0]
+    def _conv_fwd(self, c, x, xhw, out, relu, res=None, sign=None, pair=False):
+        B = x.shape[1] if pair else x.shape[0]
         oh, ow = xhw[0] // c.stride, xhw[1] // c.stride
+        if pair:
+            return self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout, bias=c.bias,
+                              res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride), sign_out=sign, pair=True)
         if res is None and self._halo_ok(c, xhw):
             return self._halo(x, c.w_fwd_frag, out, B, xhw, c.cin, c.fwd_taps, bias=c.bias, sign=sign, relu=relu)
         self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
                    bias=c.bias, res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride), sign_out=sign)
 
-    def _conv_bwd(self, c, dz, dz_hw, dx, dx_hw, res=None, mask=None):
+    def _conv_bwd(self, c, dz, dz_hw, dx, dx_hw, res=None, mask=None, pair=False):
         """dx = backward-to-input of conv c applied to dz (then + res, masked).  mask: the forward activation at dx's
         place (bf16) or its 1-bit sign tensor (uint8, written by the forward GEMM's sign_out)."""
         torch = _lib.require_gpu()
-        B = dz.shape[0]
+        B = dz.shape[1] if pair else dz.shape[0]
         fl = F_MASK_BITS if (mask is not None and mask.dtype == torch.uint8) else 0
-        if res is None and (mask is None or fl) and self._halo_ok(c, dx_hw):
+        assert not pair or mask is None or fl, 'the split-bf16 mode reads ReLU masks as 1-bit tensors only'
+        if not pair and res is None and (mask is None or fl) and self._halo_ok(c, dx_hw):
             return self._halo(dz, c.w_bwd_frag, dx, B, dx_hw, c.cin, c.bwd[0][1], mask=mask)
         for parity, taps, w in c.bwd:
             if parity is None:
                 self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res, mask=mask,
-                           flags=fl)
+                           flags=fl, pair=pair)
             else:
                 ph, pw = parity
                 if not taps:
                     continue        # this input-parity class receives no gradient from a 1x1/2 conv
                 self._gemm(dz, w, dx, B, (dx_hw[0] // 2, dx_hw[1] // 2), dz_hw, c.cout, c.cout, taps, c.cin, dx_hw,
-                           c.cin, res=res, mask=mask, flags=fl, dst_stride=(2, 2), dst_off=(ph, pw))
+                           c.cin, res=res, mask=mask, flags=fl, dst_stride=(2, 2), dst_off=(ph, pw), pair=pair)
 
     # ------------------------------------------------------------------ forward
     def _forward(self, src, src_is_u8, mean, std, keep):
+        if self.precision == 'bf16x3':
+            return self._forward_x3(src, src_is_u8, mean, std, keep)
         torch = _lib.require_gpu()
         lib = self.lib
         if src_is_u8:
@@ -504,6 +568,113 @@ class ResNet50Engine:
         acts['in_shape'] = (B, H, W)
         return logits, acts
 
+    # ------------------------------------------------------------------ reference-precision ("bf16x3") mode
+    @staticmethod
+    def _lo(t):
+        """element offset of the lo plane of a pair tensor [2][...]"""
+        return (t[1].data_ptr() - t[0].data_ptr()) // 2
+
+    def _forward_x3(self, src, src_is_u8, mean, std, keep):
+        """The forward of `_forward` with every tensor a hi + lo pair of bf16 planes and every contraction the three
+        products hi.hi + hi.lo + lo.hi (fp32 accumulate) on the implicit-GEMM kernel; one launch per layer."""
+        torch = _lib.require_gpu()
+        lib = self.lib
+        if src_is_u8:
+            B, H, W = src.shape[0], src.shape[1], src.shape[2]
+        else:
+            B, H, W = src.shape[0], src.shape[2], src.shape[3]
+        assert H % 32 == 0 and W % 32 == 0, 'input height/width must be multiples of 32'
+        sp = _lib.stream_ptr()
+        meanf = (ctypes.c_float * 3)(*mean)
+        stdf = (ctypes.c_float * 3)(*std)
+        acts = {}
+        h1, w1 = H // 2, W // 2
+        h2, w2 = h1 // 2, w1 // 2
+        hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
+        _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]),
+                                              B, H, W, meanf, stdf, sp))
+        y1 = self._get('x3_y1', (2, B, h1, w1, 64))
+        self._gemm(hi, self.stem_w, y1, B, (h1, w1), (H + 8, W + 8), 4, 32, [(r, 0) for r in range(7)], 64, (h1, w1), 64,
+                   bias=self.stem.bias, flags=F_RELU, stride=(2, 2), pair=True)
+        p1 = self._get('x3_p1', (2, B, h2, w2, 64))
+        parg = self._get('p1_argmax', (B, h2, w2, 64), torch.uint8) if keep else None
+        xs = self._get('p1_sign', (B, h2, w2, 8), torch.uint8) if keep else None
+        _lib.check(lib.rart_engine_maxpool_pair(_lib.ptr(y1), self._lo(y1), _lib.ptr(p1), self._lo(p1), _lib.ptr(parg),
+                                                _lib.ptr(xs), B, h1, w1, 64, sp))
+        acts['p1_argmax'] = parg
+        x, xhw = p1, (h2, w2)
+        for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
+            ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
+            ya = self._get('x3_b%d_a' % bi, (2, B, xhw[0], xhw[1], ca.cout))
+            yb = self._get('x3_b%d_b' % bi, (2, B, ohw[0], ohw[1], cb.cout))
+            yc = self._get('x3_b%d_c' % bi, (2, B, ohw[0], ohw[1], cc.cout))
+            sa = self._get('b%d_a_sign' % bi, (B, xhw[0], xhw[1], ca.cout // 8), torch.uint8) if keep else None
+            sb = self._get('b%d_b_sign' % bi, (B, ohw[0], ohw[1], cb.cout // 8), torch.uint8) if keep else None
+            sc = self._get('b%d_c_sign' % bi, (B, ohw[0], ohw[1], cc.cout // 8), torch.uint8) if keep else None
+            self._conv_fwd(ca, x, xhw, ya, True, sign=sa, pair=True)
+            self._conv_fwd(cb, ya, xhw, yb, True, sign=sb, pair=True)
+            if ds is not None:
+                sk = self._get('x3_b%d_ds' % bi, (2, B, ohw[0], ohw[1], cc.cout))
+                self._conv_fwd(ds, x, xhw, sk, False, pair=True)
+            else:
+                sk = x
+            self._conv_fwd(cc, yb, ohw, yc, True, res=sk, sign=sc, pair=True)
+            acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
+            acts['b%d_masks' % bi] = (xs, sa, sb)
+            x, xhw, xs = yc, ohw, sc
+        pooled = self._get('x3_pooled', (2, B, self.fc_in))
+        _lib.check(lib.rart_engine_avgpool_pair(_lib.ptr(x), self._lo(x), _lib.ptr(pooled), self._lo(pooled), B,
+                                                xhw[0] * xhw[1], self.fc_in, sp))
+        logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
+        self._gemm(pooled, self.fc_w, logits, B, (1, 1), (1, 1), self.fc_in, self.fc_in, [(0, 0)], self.n_classes,
+                   (1, 1), self.n_classes, bias=self.fc_b, flags=F_OUT_F32, pair=True)
+        acts['last'] = (x, xhw)
+        acts['last_sign'] = xs
+        acts['in_shape'] = (B, H, W)
+        return logits, acts
+
+    def _backward_x3(self, acts, dl, std):
+        """d(loss)/d(x01) from the fp32 loss gradient dl [B][classes]: the backward-to-input chain on pairs."""
+        torch = _lib.require_gpu()
+        lib, sp = self.lib, _lib.stream_ptr()
+        B, H, W = acts['in_shape']
+        dlp = self._get('x3_dl', (2, B, self.fc_kpad))
+        _lib.check(lib.rart_f32_to_pair_rows(_lib.ptr(dl), _lib.ptr(dlp), self._lo(dlp), B, self.n_classes, self.fc_kpad, sp))
+        dpool = self._get('x3_dpool', (2, B, self.fc_in))
+        self._gemm(dlp, self.fc_wd, dpool, B, (1, 1), (1, 1), self.fc_kpad, self.fc_kpad, [(0, 0)], self.fc_in, (1, 1),
+                   self.fc_in, pair=True)
+        xl, xlhw = acts['last']
+        dz = self._get('x3_g_out_%d' % (len(self.blocks) - 1), tuple(xl.shape))
+        _lib.check(lib.rart_engine_avgpool_bwd_pair(_lib.ptr(acts['last_sign']), _lib.ptr(dpool), self._lo(dpool), _lib.ptr(dz),
+                                                    self._lo(dz), B, xlhw[0] * xlhw[1], self.fc_in, sp))
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            ca, cb, cc, ds = self.blocks[bi]
+            x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
+            mx, ma, mb = acts['b%d_masks' % bi]
+            dzb = self._get('x3_g_b', tuple(yb.shape))
+            self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb, pair=True)
+            dza = self._get('x3_g_a', tuple(ya.shape))
+            self._conv_bwd(cb, dzb, ohw, dza, xhw, mask=ma, pair=True)
+            dx = self._get('x3_g_out_%d' % (bi - 1), tuple(x.shape))
+            if ds is None:
+                self._conv_bwd(ca, dza, xhw, dx, xhw, res=dz, mask=mx, pair=True)            # identity skip
+            else:
+                self._conv_bwd(ca, dza, xhw, dx, xhw, mask=mx, pair=True)
+                self._conv_bwd(ds, dz, ohw, dx, xhw, res=dx, mask=mx, pair=True)             # accumulate the projection skip
+            dz = dx
+        grad = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
+        stdf = (ctypes.c_float * 3)(*std)
+        h1, w1 = H // 2, W // 2
+        dz1 = self._get('x3_g_y1', (2, B, h1, w1, 64))
+        _lib.check(lib.rart_engine_maxpool_bwd_pair(_lib.ptr(acts['p1_argmax']), _lib.ptr(dz), self._lo(dz), _lib.ptr(dz1),
+                                                    self._lo(dz1), B, h1, w1, 64, sp))
+        pc = self.stem_patch_cols
+        patches = self._get('x3_patches', (B, h1, w1, pc), torch.float32)
+        self._gemm(dz1, self.stem_wd, patches, B, (h1, w1), (h1, w1), 64, 64, [(0, 0)], pc, (h1, w1), pc, flags=F_OUT_F32,
+                   pair=True)
+        _lib.check(lib.rart_engine_stem_col2im_f32(_lib.ptr(patches), _lib.ptr(grad), B, H, W, pc, stdf, sp))
+        return grad
+
     def logits(self, x01, mean, std):
         """x01: fp32 NCHW in [0,1]; mean/std: 3-tuples applied inside the stem's input kernel."""
         return self._forward(x01.detach().float().contiguous(), False, mean, std, keep=False)[0]
@@ -524,6 +695,8 @@ class ResNet50Engine:
         self.last_acts = acts            # exposed for the parity tests (ReLU masks of this forward)
         loss, dl, pred = logit_loss(logits, y, kind, y_target, scale)
         self.last_dlogits = dl
+        if self.precision == 'bf16x3':
+            return logits, loss, self._backward_x3(acts, dl, std), pred
         B, H, W = acts['in_shape']
         # fc backward: dpool[B][2048] = dlogits[B][1024 padded] . Wfc
         dlb = self._get('dl_bf16', (B, self.fc_kpad))
@@ -591,15 +764,18 @@ class ResNet50Engine:
         return logits, loss, grad, pred
 
 
-def make_engine(torch_model, device='cuda'):
+def make_engine(torch_model, device='cuda', precision='bf16'):
     """HIP engine for a model from robustart_amd.model.get_model: ResNet-50 or ViT-B/16, each with forward and
-    backward-to-input (`forward_backward`) on the hand-written kernels."""
+    backward-to-input (`forward_backward`) on the hand-written kernels.  precision 'bf16x3' / 'fp32x': the
+    reference-precision mode (ResNet-50)."""
     from .resnet_torch import ResNet
     from .vit_torch import VisionTransformer
     if isinstance(torch_model, ResNet):
-        return ResNet50Engine(torch_model, device)
+        return ResNet50Engine(torch_model, device, precision)
     if isinstance(torch_model, VisionTransformer):
         from .vit_engine import ViTEngine
+        if PRECISIONS.get(precision, precision) != 'bf16':
+            raise NotImplementedError('the reference-precision mode exists for ResNet-50 only; ViT-B/16 runs bf16')
         return ViTEngine(torch_model, device)
     raise NotImplementedError('no HIP engine for %s (ResNet-50 / ViT-B/16 only)' % type(torch_model).__name__)
 
@@ -613,8 +789,8 @@ class EngineModel:
                                dict(mean, std, axis=-3)) -- the `f_model` of pgd_linf / pgd_l2 / fgsm."""
 
     def __init__(self, torch_model, takes_normalized, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
-                 engine=None, device='cuda'):
-        self.rart_engine = engine or make_engine(torch_model, device)
+                 engine=None, device='cuda', precision='bf16'):
+        self.rart_engine = engine or make_engine(torch_model, device, precision)
         self.takes_normalized = takes_normalized
         self.rart_mean_std = (tuple(mean), tuple(std))
 

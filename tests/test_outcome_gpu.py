@@ -120,6 +120,66 @@ def test_pgd7_outcome_bf16_engine_vs_fp32_module(fitted):
     assert rep['grad_cos_median'] > 0.97 and rep['grad_sign_agreement'] > 0.85    # the PGD sign step sees the same direction
 
 
+def test_pgd7_outcome_reference_precision_engine_vs_fp32_module(fitted):
+    """The north star's tolerance on a network with real decision margins: the reference-precision engine
+    (precision 'fp32x' = split-bf16, three MFMA products) against the fp32 PyTorch module on the fitted ResNet-50:
+    logits within 1e-4 (relative to the image's logit scale) on every held-out image, PGD-7 per-image agreement >= 99.5 %
+    (reference arithmetic: fp32 `f_model`, adv/attack.py:20-23)."""
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.noise import adv
+    S, cfg, model = fitted
+    ds = S.make_dataset(cfg['data'], 4096, 224)
+    eng = EngineModel(model, takes_normalized=False, precision='fp32x')
+    mean = torch.tensor(MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(STD, device='cuda').view(1, 3, 1, 1)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    f32 = lambda z: model((z - mean) / std)      # noqa: E731
+    eps, n_img, bs = 4 / 255, 1024, 64
+    stats = {'clean_e': 0, 'clean_t': 0, 'adv_e': 0, 'adv_t': 0, 'agree_adv': 0, 'agree_clean': 0}
+    errs, errs_adv, lin = [], [], []
+    for s in range(0, n_img, bs):
+        items = list(range(8192 + s, 8192 + s + bs))
+        imgs, y = ds.batch(items, 'cuda')
+        x = imgs.permute(0, 3, 1, 2).float().div(255.0).contiguous()
+        with torch.no_grad():
+            le, lt = eng(x).float(), f32(x).float()
+        errs.append(((le - lt).abs().max(1)[0] / lt.abs().max(1)[0]).cpu())
+        u = ((torch.rand(x.shape, generator=torch.Generator().manual_seed(s)) * 2 - 1) * eps).cuda()
+        xa_e = adv.pgd_linf(x, y, eng, eps, 3 / 40, 7, init_u=u)
+        xa_t = adv.pgd_linf(x, y, f32, eps, 3 / 40, 7, init_u=u)
+        with torch.no_grad():
+            la_e, la_t = eng(xa_e).float(), f32(xa_t).float()
+            errs_adv.append(((eng(xa_t).float() - la_t).abs().max(1)[0] / la_t.abs().max(1)[0]).cpu())
+        lin.append((xa_e - xa_t).abs().flatten(1).max(1)[0].cpu())
+        stats['clean_e'] += int((le.argmax(1) == y).sum()); stats['clean_t'] += int((lt.argmax(1) == y).sum())
+        stats['agree_clean'] += int((le.argmax(1) == lt.argmax(1)).sum())
+        stats['adv_e'] += int((la_e.argmax(1) == y).sum()); stats['adv_t'] += int((la_t.argmax(1) == y).sum())
+        stats['agree_adv'] += int((la_e.argmax(1) == la_t.argmax(1)).sum())
+    imgs, y = ds.batch(list(range(20000, 20064)), 'cuda')
+    x = imgs.permute(0, 3, 1, 2).float().div(255.0).contiguous()
+    _, _, g_e, _ = eng.rart_engine.forward_backward(x, MEAN, STD, y, 0)
+    xr = x.clone().requires_grad_(True)
+    g_t, = torch.autograd.grad(torch.nn.functional.cross_entropy(f32(xr), y, reduction='sum'), xr)
+    a, b = g_e.flatten(1).double(), g_t.flatten(1).double()
+    cos = ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).cpu()
+    errs, errs_adv, lin = torch.cat(errs), torch.cat(errs_adv), torch.cat(lin)
+    rep = {k: v / n_img for k, v in stats.items()}
+    rep.update(logit_rel_err_max=float(errs.max()), logit_rel_err_median=float(errs.median()),
+               logit_rel_err_on_adversarial_max=float(errs_adv.max()), grad_cos_median=float(cos.median()),
+               grad_cos_min=float(cos.min()), grad_sign_agreement=float((torch.sign(g_e) == torch.sign(g_t)).float().mean()),
+               identical_adversarial_examples=float((lin == 0).float().mean()), n_images=n_img)
+    print('PGD-7 eps 4/255 outcome, reference-precision HIP engine vs fp32 module: ' + json.dumps(rep))
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(rep, open('gpurun_out/outcome_x3_vs_fp32.json', 'w'), indent=1)
+    assert rep['clean_t'] > 0.9 and rep['adv_t'] < rep['clean_t'] - 0.03
+    assert rep['logit_rel_err_max'] <= 1e-4 and rep['logit_rel_err_on_adversarial_max'] <= 1e-4    # the north star's bound
+    assert rep['agree_clean'] == 1.0
+    assert rep['agree_adv'] >= 0.995
+    assert abs(rep['adv_e'] - rep['adv_t']) <= 0.005
+    assert rep['grad_cos_min'] > 0.999
+
+
 def test_b256_matches_small_batches_bit_for_bit():
     """Every 32nd image of a B = 256 forward / forward_backward equals the same image run in a batch of 2 (the kernels'
     arithmetic per output element does not depend on the batch: same K order, same tiles), and rart_corrupt_u8 on the
