@@ -4,6 +4,9 @@
 #include <stdarg.h>
 #include <string.h>
 #include "rart_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -12,6 +15,23 @@ void rart_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+bool rart_raise_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> raised;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = raised[std::make_pair(kernel, dev)];
+  if (bytes <= have) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    rart_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", what, bytes);
+    return false;
+  }
+  have = bytes;
+  return true;
 }
 
 static const char* kNames[RART_NUM_CORRUPTIONS] = {

@@ -250,15 +250,7 @@ int rart_launch_jpeg(const RartCorruptArgs& a) {
   RART_CHECK_ARG(lds <= 160 * 1024, "jpeg_compression: image too large for the one-image-per-CU LDS layout");
   const int q = quality[a.severity - 1];
   const int scale = q < 50 ? 5000 / q : 200 - q * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_jpeg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess) {
-      rart_set_error("jpeg_compression: cannot raise the dynamic LDS limit");
-      return RART_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  if (!rart_raise_dynamic_lds((const void*)k_jpeg, 160 * 1024, "jpeg_compression")) return RART_ERR_HIP;
   hipLaunchKernelGGL(k_jpeg, dim3(a.n), dim3(kThreads), lds, a.stream, a.in, a.out, a.h, a.w, scale);
   RART_CHECK_LAUNCH("jpeg_compression");
   return RART_OK;

@@ -258,15 +258,9 @@ __global__ __launch_bounds__(kT) void k_spatter_finish(const uint8_t* __restrict
 // >= n * 224 * 224 ints.  in / out: uint8 [n][224][224][3] (may alias).
 int rart_launch_spatter_water(const uint8_t* in, uint8_t* out, const double* liquid, int n, double thresh, double c4,
                               uint8_t* scratch_u8, int* scratch_i32, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_spatter_canny, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NPIX) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_spatter_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NPIX) != hipSuccess) {
-      rart_set_error("spatter: cannot raise the dynamic LDS limit");
-      return RART_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  if (!rart_raise_dynamic_lds((const void*)k_spatter_canny, 2 * NPIX, "spatter") ||
+      !rart_raise_dynamic_lds((const void*)k_spatter_finish, 2 * NPIX, "spatter"))
+    return RART_ERR_HIP;
   uint8_t* l8 = scratch_u8;
   uint8_t* src8 = scratch_u8 + (size_t)n * NPIX;
   const size_t total = (size_t)n * NPIX;

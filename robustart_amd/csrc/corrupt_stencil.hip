@@ -430,12 +430,7 @@ void gauss_u8_to_u8(const uint8_t* in, uint8_t* out, double* tmp, int n, int h, 
                     hipStream_t s) {
   if (g.radius <= GF_RMAX && n <= 65535) {
     const size_t lds = gauss_fused_lds(g.radius);
-    static size_t lds_set[3] = {0, 0, 0};
-    if (lds > lds_set[FINISH]) {
-      if (hipFuncSetAttribute((const void*)k_gauss_fused<FINISH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-        lds_set[FINISH] = lds;
-    }
-    if (lds <= lds_set[FINISH]) {
+    if (rart_raise_dynamic_lds((const void*)k_gauss_fused<FINISH>, lds, "gaussian filter")) {
       hipLaunchKernelGGL((k_gauss_fused<FINISH>), dim3((w + GF_TW - 1) / GF_TW, (h + GF_TH - 1) / GF_TH, n), dim3(kBlock), lds, s,
                          in, out, h, w, g);
       return;
@@ -489,15 +484,7 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
       double* tmp = (double*)a.workspace;
       uint8_t* mid = (uint8_t*)a.workspace + rart_align_up((size_t)a.n * a.h * a.w * 3 * sizeof(double), 256);
       gauss_u8_to_u8<1>(a.in, mid, tmp, a.n, a.h, a.w, g, a.stream);
-      static bool attr_set = false;
-      if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_glass_shuffle, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                224 * 224 * 3) != hipSuccess) {
-          rart_set_error("glass_blur: cannot raise the dynamic LDS limit");
-          return RART_ERR_HIP;
-        }
-        attr_set = true;
-      }
+      if (!rart_raise_dynamic_lds((const void*)k_glass_shuffle, 224 * 224 * 3, "glass_blur")) return RART_ERR_HIP;
       hipLaunchKernelGGL(k_glass_shuffle, dim3(a.n), dim3(kGlassThreads), 224 * 224 * 3, a.stream, mid,
                          (int)kGlass[s][1], (int)kGlass[s][2], (const int8_t*)inj0, (uint32_t)a.seed,
                          (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
@@ -517,15 +504,9 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
       }
       RART_CHECK_ARG(a.n <= 65535, "defocus_blur: at most 65535 images per call");
       const size_t lds = filter2d_lds(ksz[s]);
-      static size_t lds_set = 0;
-      if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)k_filter2d<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter2d_lds(21)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_filter2d<21>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter2d_lds(21)) != hipSuccess) {
-          rart_set_error("defocus_blur: cannot raise the dynamic LDS limit");
-          return RART_ERR_HIP;
-        }
-        lds_set = filter2d_lds(21);
-      }
+      if (!rart_raise_dynamic_lds((const void*)k_filter2d<17>, filter2d_lds(21), "defocus_blur") ||
+          !rart_raise_dynamic_lds((const void*)k_filter2d<21>, filter2d_lds(21), "defocus_blur"))
+        return RART_ERR_HIP;
       const dim3 f2grid((a.w + F2_TW - 1) / F2_TW, (a.h + F2_TH - 1) / F2_TH, a.n);
       if (ksz[s] == 17)
         hipLaunchKernelGGL(k_filter2d<17>, f2grid, dim3(kBlock), lds, a.stream, a.in, a.out, a.n, a.h, a.w, (const double*)a.workspace);

@@ -9,6 +9,10 @@
 
 // ---- error plumbing ---------------------------------------------------------------
 void rart_set_error(const char* fmt, ...);
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) to at least `bytes` on the CURRENT device.
+// The attribute is per device, so the cache behind it is keyed by (kernel, device): a process driving several GPUs sets it on
+// each of them.  Returns false (and sets the error string) when the runtime refuses.
+bool rart_raise_dynamic_lds(const void* kernel, size_t bytes, const char* what);
 
 #define RART_CHECK_ARG(cond, ...)                \
   do {                                           \

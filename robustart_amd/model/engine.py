@@ -352,8 +352,14 @@ class ResNet50Engine:
             return
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
-    def _halo_ok(self, c, hw):
-        return (self.halo_conv3x3 and c.r == 3 and c.s == 3 and c.stride == 1 and c.pad == 1
+    @staticmethod
+    def _fits32(n, hw, channels):
+        """the fused / LDS-resident kernels address with 32-bit element offsets (their C entry points check n*H*W*C < 2^31):
+        beyond that the engine falls back to the generic implicit GEMM instead of raising"""
+        return n * hw[0] * hw[1] * channels < (1 << 31)
+
+    def _halo_ok(self, c, hw, n=1):
+        return (self._fits32(n, hw, c.cin) and self.halo_conv3x3 and c.r == 3 and c.s == 3 and c.stride == 1 and c.pad == 1
                 and c.cin == c.cout and getattr(c, 'w_fwd_frag', None) is not None and self.lib.rart_conv3x3_halo_supported(c.cin, hw[0], hw[1]))
 
     def _halo(self, src, w, dst, B, hw, ch, taps, bias=None, mask=None, sign=None, relu=False):
@@ -373,14 +379,14 @@ class ResNet50Engine:
                                                    _lib.ptr(dst), B, hw[0], hw[1], ch, _cints([t[0] for t in taps]),
                                                    _cints([t[1] for t in taps]), 1 if relu else 0, _lib.stream_ptr()))
 
-    def _bneck_ok(self, ca, cb, cc, ds, xhw):
-        return (self.fused_bottleneck and ds is None and cb.stride == 1 and cb.r == 3 and ca.r == 1 and cc.r == 1
+    def _bneck_ok(self, ca, cb, cc, ds, xhw, n=1):
+        return (self._fits32(n, xhw, cc.cout) and self.fused_bottleneck and ds is None and cb.stride == 1 and cb.r == 3 and ca.r == 1 and cc.r == 1
                 and ca.cin == cc.cout and getattr(cb, 'w_fwd_frag', None) is not None
                 and self.lib.rart_bottleneck_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]))
 
-    def _image_block_fn(self, ca, cb, cc, ds, xhw):
+    def _image_block_fn(self, ca, cb, cc, ds, xhw, n=1):
         """-> the C entry point of the image-resident fused kernel for this block (layer3: 14 x 14, layer2: 28 x 28) or None."""
-        if not (self.fused_bottleneck14 and ds is None and getattr(ca, 'w_fwd_frag', None) is not None
+        if not (self._fits32(n, xhw, cc.cout) and self.fused_bottleneck14 and ds is None and getattr(ca, 'w_fwd_frag', None) is not None
                 and getattr(cb, 'w_fwd_frag', None) is not None and getattr(cc, 'w_fwd_frag', None) is not None):
             return None
         if self.lib.rart_bottleneck14_fused_supported(cc.cout, ca.cout, xhw[0], xhw[1]):
@@ -412,8 +418,8 @@ class ResNet50Engine:
             _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, hw[0], hw[1], c_io, c_mid, _cints([t[0] for t in taps]),
             _cints([t[1] for t in taps]), 1 if backward else 0, _lib.stream_ptr()))
 
-    def _first_ok(self, ca, cb, cc, ds, xhw):
-        return (self.fused_bottleneck and ds is not None and getattr(ds, 'w_fwd_frag', None) is not None
+    def _first_ok(self, ca, cb, cc, ds, xhw, n=1):
+        return (self._fits32(n, xhw, cc.cout) and self.fused_bottleneck and ds is not None and getattr(ds, 'w_fwd_frag', None) is not None
                 and getattr(cb, 'w_fwd_frag', None) is not None
                 and self.lib.rart_bottleneck_first_supported(ca.cin, ca.cout, cc.cout, xhw[0], xhw[1]))
 
@@ -450,7 +456,7 @@ class ResNet50Engine:
         if pair:
             return self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout, bias=c.bias,
                               res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride), sign_out=sign, pair=True)
-        if res is None and self._halo_ok(c, xhw):
+        if res is None and self._halo_ok(c, xhw, B):
             return self._halo(x, c.w_fwd_frag, out, B, xhw, c.cin, c.fwd_taps, bias=c.bias, sign=sign, relu=relu)
         self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
                    bias=c.bias, res=res, flags=F_RELU if relu else 0, stride=(c.stride, c.stride), sign_out=sign)
@@ -462,7 +468,7 @@ class ResNet50Engine:
         B = dz.shape[1] if pair else dz.shape[0]
         fl = F_MASK_BITS if (mask is not None and mask.dtype == torch.uint8) else 0
         assert not pair or mask is None or fl, 'the split-bf16 mode reads ReLU masks as 1-bit tensors only'
-        if not pair and res is None and (mask is None or fl) and self._halo_ok(c, dx_hw):
+        if not pair and res is None and (mask is None or fl) and self._halo_ok(c, dx_hw, B):
             return self._halo(dz, c.w_bwd_frag, dx, B, dx_hw, c.cin, c.bwd[0][1], mask=mask)
         for parity, taps, w in c.bwd:
             if parity is None:
@@ -518,13 +524,12 @@ class ResNet50Engine:
         x, xhw = p1, (h2, w2)
         for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
             ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
-            ya = self._get('b%d_a' % bi, (B, xhw[0], xhw[1], ca.cout))
-            yb = self._get('b%d_b' % bi, (B, ohw[0], ohw[1], cb.cout))
+            ya = yb = None       # the fused kernels keep both intermediates on chip: allocated on the unfused branch only
             yc = self._get('b%d_c' % bi, (B, ohw[0], ohw[1], cc.cout))
             sa = self._get('b%d_a_sign' % bi, (B, xhw[0], xhw[1], ca.cout // 8), torch.uint8) if bits else None
             sb = self._get('b%d_b_sign' % bi, (B, ohw[0], ohw[1], cb.cout // 8), torch.uint8) if bits else None
             sc = self._get('b%d_c_sign' % bi, (B, ohw[0], ohw[1], cc.cout // 8), torch.uint8) if bits else None
-            if (bits or not keep) and self._bneck_ok(ca, cb, cc, ds, xhw):
+            if (bits or not keep) and self._bneck_ok(ca, cb, cc, ds, xhw, B):
                 # the two 64-channel intermediates stay on chip; the backward pass gets their sign bits
                 self._bneck(x, ca.w_fwd, cb.w_fwd_frag, cc.w_fwd, ca.bias, cb.bias, cc.bias, sa, sb, sc, yc, B, xhw, cc.cout,
                             ca.cout, cb.fwd_taps, False)
@@ -532,7 +537,7 @@ class ResNet50Engine:
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
                 continue
-            fn14 = self._image_block_fn(ca, cb, cc, ds, xhw) if (bits or not keep) else None
+            fn14 = self._image_block_fn(ca, cb, cc, ds, xhw, B) if (bits or not keep) else None
             if fn14 is not None:
                 self._bneck14(x, ca.w_fwd_frag, cb.w_fwd_frag, cc.w_fwd_frag, ca.bias, cb.bias, cc.bias, sa, sb, sc, yc, B, xhw,
                               cc.cout, ca.cout, cb.fwd_taps, False, fn14)
@@ -540,13 +545,15 @@ class ResNet50Engine:
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
                 continue
-            if (bits or not keep) and self._first_ok(ca, cb, cc, ds, xhw):
+            if (bits or not keep) and self._first_ok(ca, cb, cc, ds, xhw, B):
                 self._bneck(x, ca.w_fwd, cb.w_fwd_frag, cc.w_fwd, ca.bias, cb.bias, ds.bias_sum, sa, sb, sc, yc, B, xhw, cc.cout,
                             ca.cout, cb.fwd_taps, False, w4=ds.w_fwd_frag, c_in=ca.cin)
                 acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
                 continue
+            ya = self._get('b%d_a' % bi, (B, xhw[0], xhw[1], ca.cout))
+            yb = self._get('b%d_b' % bi, (B, ohw[0], ohw[1], cb.cout))
             self._conv_fwd(ca, x, xhw, ya, True, sign=sa)
             self._conv_fwd(cb, ya, xhw, yb, True, sign=sb)
             if ds is not None:
@@ -713,20 +720,20 @@ class ResNet50Engine:
             ca, cb, cc, ds = self.blocks[bi]
             x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
             mx, ma, mb = acts['b%d_masks' % bi]
-            if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._bneck_ok(ca, cb, cc, ds, xhw)):
+            if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._bneck_ok(ca, cb, cc, ds, xhw, B)):
                 dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
                 self._bneck(dz, cc.bwd[0][2], cb.w_bwd_frag, ca.bwd[0][2], None, None, None, mb, ma, mx, dx, B, xhw, cc.cout,
                             ca.cout, cb.bwd[0][1], True)
                 dz = dx
                 continue
-            fn14 = self._image_block_fn(ca, cb, cc, ds, xhw) if (ma is not None and ma.dtype == torch.uint8 and mb is not None) else None
+            fn14 = self._image_block_fn(ca, cb, cc, ds, xhw, B) if (ma is not None and ma.dtype == torch.uint8 and mb is not None) else None
             if fn14 is not None:
                 dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
                 self._bneck14(dz, cc.w_bwd_frag, cb.w_bwd_frag, ca.w_bwd_frag, None, None, None, mb, ma, mx, dx, B, xhw,
                               cc.cout, ca.cout, cb.bwd[0][1], True, fn14)
                 dz = dx
                 continue
-            if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._first_ok(ca, cb, cc, ds, xhw)):
+            if (ma is not None and ma.dtype == torch.uint8 and mb is not None and self._first_ok(ca, cb, cc, ds, xhw, B)):
                 dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
                 self._bneck(dz, cc.bwd[0][2], cb.w_bwd_frag, ds.bwd[0][2], None, None, None, mb, ma, mx, dx, B, xhw, cc.cout,
                             ca.cout, cb.bwd[0][1], True, w4=ca.bwd[0][2], c_in=ca.cin)

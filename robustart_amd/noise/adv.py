@@ -701,7 +701,14 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
         robust_flags = y_orig.eq(prov.logits(x_orig).max(1)[1])                  # :95-109
         x_adv = x_orig.clone()
         base_seed = _seed(seed)
-        first = _offset(None, x_orig.shape[0])       # the call's samples keep their global indices through every sub-attack
+        # global index of the call's first sample.  NOTE: every sub-attack receives the still-robust SUBSET
+        # x_orig[idcs] together with this offset, and the restarts / target classes inside a sub-attack subset again, so row k of
+        # a subset draws its random start at counter index first + k, not at the sample's own index: the draws are reproducible
+        # for a given (seed, batch composition) but -- like the reference's torch.manual_seed(self.seed) per perturb() call,
+        # whose i-th row of noise also lands on whichever sample is i-th among the survivors -- they are NOT invariant to how
+        # the dataset is batched or sharded once samples have dropped out.  Only the first launch of the first sub-attack sees
+        # every sample at its own index.
+        first = _offset(None, x_orig.shape[0])
         C, H, W = x_orig.shape[1:]
         for ai, attack in enumerate(plan):
             if attack in skipped:

@@ -157,6 +157,23 @@ class HipOptimizer:
                 self._lib_mod.check(lib.rart_sgd_step_f32(p, g, m, e, n, self.lr, self.momentum, wd,
                                                            1 if self.nesterov else 0, grad_scale, dec, 1, st))
 
+    def state_dict(self):
+        """Everything a resumed run needs besides the parameters: momentum / first moment, Adam's second moment, the step
+        count (Adam's bias correction) -- tensors and numbers only, so the checkpoint loads with weights_only=True.  The EMA
+        travels under the checkpoint's own 'ema' key (module names)."""
+        sd = {'kind': self.kind, 'step_count': int(self.step_count), 'm': self.m.detach().cpu()}
+        if self.v is not None:
+            sd['v'] = self.v.detach().cpu()
+        return sd
+
+    def load_state_dict(self, sd):
+        if sd.get('kind', self.kind) != self.kind or sd['m'].numel() != self.m.numel():
+            raise ValueError('HipOptimizer.load_state_dict: the checkpoint belongs to another optimizer / parameter arena')
+        self.step_count = int(sd.get('step_count', 0))
+        self.m.copy_(sd['m'].to(self.m.device))
+        if self.v is not None and sd.get('v') is not None:
+            self.v.copy_(sd['v'].to(self.v.device))
+
     def ema_state_dict(self, model):
         """EMA parameters under the module's names (floating-point buffers are tracked by the solver)."""
         out = {}

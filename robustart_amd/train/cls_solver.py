@@ -98,18 +98,155 @@ class StructuredFakeImageNet(FakeImageNet):
         return img.clamp_(0, 255).to(torch.uint8), lab
 
 
-def make_dataset(dcfg, n, size):
-    if dcfg.get('read_from', 'fake') == 'structured':
+def read_meta_file(path):
+    """`data.{train,test}.meta_file`: one sample per line, either "relative/path.JPEG label" (the ImageNet lists of the
+    reference configs, pgd_adv_train/resnet50/config.yaml:45,55) or a JSON object {"filename": ..., "label": ...} (the
+    imagenet-c / imagenet-s lists, exp/imagenet_c_loop_mini/config_vit_base.yaml:82).  -> [(relpath, label)]"""
+    out = []
+    with open(path) as f:
+        for ln in f:
+            ln = ln.strip()
+            if not ln:
+                continue
+            if ln.startswith('{'):
+                o = json.loads(ln)
+                out.append((o['filename'], int(o['label'])))
+            else:
+                name, lab = ln.rsplit(None, 1)
+                out.append((name, int(lab)))
+    return out
+
+
+class FileImageNet(torch.utils.data.Dataset):
+    """`data.read_from: fs` with `data.<split>.{root_dir, meta_file, image_reader.type: pil, transforms.type}`
+    (exp/imagenet_c_loop_mini/config_vit_base.yaml:80-104): files are decoded on the host by PIL (the reference's 'pil'
+    reader) and the transform's arithmetic runs on the GPU:
+      ONECROP  = Resize([test_resize, test_resize]) (PIL bilinear, what torchvision applies to a PIL image) + CenterCrop(
+                 input_size) -> rart_pil_resize_u8 with the fused centre crop, bit-exact with Pillow;
+      STANDARD = RandomResizedCrop(input_size) + RandomHorizontalFlip: the crop box / flip are drawn on the host from
+                 (seed, global index) (a pure function of the sample, like every draw of this path), the resize runs in
+                 the same kernel.  ColorJitter of the reference's commented variant is not applied.
+    Output is the uint8 NHWC batch the corruption kernels and the engines' u8 entry consume; normalisation happens in
+    the engine's input kernel."""
+
+    def __init__(self, root_dir, meta_file, size=224, test_resize=256, transform='ONECROP', reader='pil', limit=None, seed=0):
+        if reader != 'pil':
+            raise NotImplementedError("image_reader.type %r: only 'pil' is available in this build" % (reader,))
+        if transform not in ('ONECROP', 'STANDARD'):
+            raise NotImplementedError('transforms.type %r (ONECROP / STANDARD)' % (transform,))
+        self.root, self.items = root_dir, read_meta_file(meta_file)
+        if limit:
+            self.items = self.items[:int(limit)]
+        self.size, self.test_resize, self.transform, self.seed = int(size), int(test_resize), transform, int(seed)
+        self.n = len(self.items)
+
+    def __len__(self):
+        return self.n
+
+    def decode(self, i):
+        """host side: (HxWx3 uint8 ndarray, label) of sample i"""
+        from ..noise.imagenet_s import decode
+        name, lab = self.items[i]
+        return decode(os.path.join(self.root, name), 'pil'), lab
+
+    def __getitem__(self, i):
+        img, lab = self.batch([i], 'cuda')
+        return img[0], int(lab[0]), i
+
+    def box(self, i, hw):
+        """STANDARD: (y, x, h, w, flip) of sample i, drawn from (seed, i) with the reference's get_params loop"""
+        import random as _random
+        from ..noise.imagenet_s import _train_params
+        r = _random.Random(self.seed * 1000003 + i)
+        y, x, h, w = _train_params(hw, r)
+        return y, x, h, w, r.random() < 0.5
+
+    def batch(self, indices, device):
+        from ..noise.imagenet_s import pil_resize
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            raise RuntimeError('FileImageNet: the resize / crop of the transform runs on the GPU (no CPU fallback)')
+        out = torch.empty(len(indices), self.size, self.size, 3, dtype=torch.uint8, device=dev)
+        labs = []
+        for k, i in enumerate(indices):
+            arr, lab = self.decode(i)
+            labs.append(lab)
+            if self.transform == 'ONECROP':
+                r, t = self.test_resize, self.size
+                o = int(round((r - t) / 2.0))                         # torchvision CenterCrop
+                src = torch.from_numpy(arr).to(dev, non_blocking=True)[None]
+                out[k] = pil_resize(src, (r, r), 1, crop=(o, o, t, t))[0]
+            else:
+                y, x, h, w, flip = self.box(i, arr.shape[:2])
+                src = torch.from_numpy(arr[y:y + h, x:x + w].copy()).to(dev, non_blocking=True)[None]
+                img = pil_resize(src, (self.size, self.size), 1)[0]
+                out[k] = img.flip(1) if flip else img
+        return out, torch.tensor(labs, dtype=torch.int64, device=dev)
+
+
+def make_dataset(dcfg, n, size, split='test'):
+    """`data.read_from`: 'fake' (the reference configs' own setting) / 'structured' -> synthetic sets of n samples;
+    'fs' (or 'file' / 'folder') -> FileImageNet over data.<split>.{root_dir, meta_file} (n = limit, 0 / None = all)."""
+    rf = dcfg.get('read_from', 'fake')
+    if rf == 'structured':
         return StructuredFakeImageNet(n, size, int(dcfg.get('structured_classes', 16)),
                                       float(dcfg.get('structured_contrast', 48.0)), float(dcfg.get('structured_noise', 40.0)))
+    if rf in ('fs', 'file', 'folder'):
+        sec = dcfg.get(split) or {}
+        if not sec.get('root_dir') or not sec.get('meta_file'):
+            raise ValueError('data.read_from: %s needs data.%s.root_dir and data.%s.meta_file' % (rf, split, split))
+        return FileImageNet(sec['root_dir'], sec['meta_file'], size, int(dcfg.get('test_resize', 256)),
+                            (sec.get('transforms') or {}).get('type', 'ONECROP' if split == 'test' else 'STANDARD'),
+                            (sec.get('image_reader') or {}).get('type', 'pil'), dcfg.get('limit_samples'),
+                            int(dcfg.get('seed', 0)))
+    if rf != 'fake':
+        raise NotImplementedError("data.read_from %r ('fake', 'structured', 'fs')" % (rf,))
     return FakeImageNet(n, size)
+
+
+def resolve_schedule(cfg, n_train, batch_size, world, default_max_iter=20):
+    """-> (max_iter, warmup_steps) from the reference's key set (pgd_adv_train/resnet50/config.yaml:18-29): the
+    iteration keys `lr_scheduler.kwargs.{max_iter, warmup_steps}` when present, else the epoch keys `max_epoch` /
+    `warmup_epoch` times the iterations of one epoch of the distributed_iteration sampler,
+    ceil(len(train set) / (batch_size * world_size)).  A top-level `max_iter` (this build's own shortcut, used by the
+    tests) wins over both."""
+    lk = (cfg.get('lr_scheduler') or {}).get('kwargs') or {}
+    per_epoch = max(1, -(-int(n_train) // (int(batch_size) * int(world))))
+    if cfg.get('max_iter') is not None:
+        max_iter = int(cfg['max_iter'])
+    elif lk.get('max_iter') is not None:
+        max_iter = int(lk['max_iter'])
+    elif lk.get('max_epoch') is not None:
+        max_iter = int(round(float(lk['max_epoch']) * per_epoch))
+    else:
+        max_iter = int(default_max_iter)
+    if lk.get('warmup_steps') is not None:
+        warm = int(lk['warmup_steps'])
+    elif lk.get('warmup_epoch') is not None:
+        warm = int(round(float(lk['warmup_epoch']) * per_epoch))
+    else:
+        warm = max(max_iter // 20, 1)
+    return max_iter, min(warm, max_iter)
+
+
+def load_checkpoint_file(path):
+    """torch.load restricted to tensors / containers / numbers (weights_only=True): a checkpoint is data, and a pickle from
+    an untrusted source would execute code.  Checkpoints of this solver and plain state dicts load this way; a legacy
+    reference checkpoint that pickles other objects needs the explicit opt-in RART_ALLOW_PICKLE_CHECKPOINT=1."""
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:  # noqa: BLE001  (pickle.UnpicklingError and friends)
+        if os.environ.get('RART_ALLOW_PICKLE_CHECKPOINT') == '1':
+            return torch.load(path, map_location='cpu', weights_only=False)
+        raise RuntimeError('%s does not load with weights_only=True (%s); set RART_ALLOW_PICKLE_CHECKPOINT=1 to unpickle a '
+                           'TRUSTED legacy checkpoint' % (path, e)) from e
 
 
 def load_pretrain(model, path, prefer='model', strict=True):
     """`saver.pretrain.path` / --recover: load a checkpoint written by this solver or by the reference's
     (torch.save of {'model': state_dict, 'ema': {...}, ...} or a bare state_dict; DistributedDataParallel's 'module.'
     prefix stripped).  prefer = 'ema' picks the EMA weights when the file has them."""
-    ck = torch.load(path, map_location='cpu', weights_only=False)
+    ck = load_checkpoint_file(path)
     sd = ck
     if isinstance(ck, dict):
         for key in ((prefer, 'model', 'state_dict', 'ema') if prefer else ('model', 'state_dict')):
@@ -120,6 +257,10 @@ def load_pretrain(model, path, prefer='model', strict=True):
         sd = sd['ema_state_dict']
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
     missing, unexpected = model.load_state_dict(sd, strict=strict)
+    if missing or unexpected:                       # only reachable with strict=False
+        import warnings
+        warnings.warn('load_pretrain(%s): missing keys %s, unexpected keys %s' % (path, list(missing), list(unexpected)),
+                      RuntimeWarning)
     return ck if isinstance(ck, dict) else {}
 
 
@@ -185,8 +326,13 @@ def build_model(cfg, args=None):
     model = get_model(cfg['model'])
     pre = (cfg.get('saver', {}) or {}).get('pretrain', {}) or {}
     path = getattr(args, 'recover', None) or pre.get('path')
+    build_model.last_checkpoint = None
     if path:
-        load_pretrain(model, path, prefer='ema' if pre.get('use_ema', False) else 'model')
+        ck = load_pretrain(model, path, prefer='ema' if pre.get('use_ema', False) else 'model')
+        # `saver.pretrain.ignore.key: [optimizer, last_iter]` (pgd_adv_train/resnet50/config.yaml:67-70): fine-tuning from a
+        # checkpoint instead of resuming it
+        drop = set(((pre.get('ignore') or {}).get('key')) or [])
+        build_model.last_checkpoint = {k: v for k, v in ck.items() if k not in drop and k != 'model'}
     return model
 
 
@@ -196,7 +342,8 @@ def evaluate(cfg, args, rank, world, device, model=None):
     n = int(dcfg.get('fake_size', dcfg.get('limit_samples', 256)))
     bs = int(dcfg.get('batch_size', 64))
     size = int(dcfg.get('input_size', 224))
-    ds = make_dataset(dcfg, n, size)
+    ds = make_dataset(dcfg, n, size, 'test')
+    n = len(ds)                                              # a file-backed set brings its own length
     idx = shard_indices(n, rank, world)
     model = model or build_model(cfg, args)
     model = model.to(device).eval()
@@ -204,7 +351,10 @@ def evaluate(cfg, args, rank, world, device, model=None):
     noise = None
     if use_hip:
         from ..model.engine import EngineModel
-        f_model = EngineModel(model, takes_normalized=False)
+        # `engine_precision: fp32x` (or --precision fp32x): the reference-precision engine mode (logits within 1e-4 of the
+        # fp32 network, ~3x the MFMA work); default bf16
+        prec = getattr(args, 'precision', None) or cfg.get('engine_precision', 'bf16')
+        f_model = EngineModel(model, takes_normalized=False, precision=prec)
         n_model = EngineModel(None, takes_normalized=True, engine=f_model.rart_engine)
     if args.corruption:
         from ..noise import AddNoise
@@ -288,9 +438,11 @@ def train(cfg, args, rank, world, device):
     n = int(dcfg.get('fake_size', 512))
     bs = int(dcfg.get('batch_size', 32))
     size = int(dcfg.get('input_size', 224))
-    max_iter = int(cfg.get('max_iter', args.max_iter))
-    ds = make_dataset(dcfg, n, size)
+    ds = make_dataset(dcfg, n, size, 'train')
+    n = len(ds)
+    max_iter, warmup_steps = resolve_schedule(cfg, n, bs, world, getattr(args, 'max_iter', 20))
     model = build_model(cfg, args).to(device)
+    resume = getattr(build_model, 'last_checkpoint', None) or {}
     ocfg = cfg.get('optimizer', {'type': 'SGD', 'kwargs': {'nesterov': True, 'momentum': 0.9, 'weight_decay': 1e-4}})
     okw = dict(ocfg.get('kwargs', {}))
     lcfg = cfg.get('lr_scheduler', {}).get('kwargs', {})
@@ -352,8 +504,55 @@ def train(cfg, args, rank, world, device):
     idx = shard_indices(n, rank, world)
     loss_v = float('nan')
     attack_model = None
-    for it in range(max_iter):
-        lr = cosine_lr(it, max_iter, base_lr, warmup_lr, int(lcfg.get('warmup_steps', max(max_iter // 20, 1))), min_lr)
+    scfg = cfg.get('saver', {}) or {}
+    save_dir = scfg.get('save_dir') or getattr(args, 'ckpt_dir', None)
+    save_freq = int(scfg.get('save_freq', scfg.get('val_freq', 0)) or 0)     # the reference solver saves at val_freq
+    # ---- resume (--recover / saver.pretrain.path with 'optimizer' + 'last_iter' in the file and not ignored): the
+    # momentum / Adam moments, the EMA (parameters and buffers) and the schedule position continue where they stopped
+    start_iter = 0
+    if resume.get('last_iter') is not None and resume.get('optimizer') is not None:
+        start_iter = min(int(resume['last_iter']), max_iter)
+        ost = resume['optimizer']
+        if use_hip_opt:
+            opt.load_state_dict(ost)
+        else:
+            if ost.get('torch') is not None:
+                opt.load_state_dict(ost['torch'])
+        if ema_on and resume.get('ema') is not None:
+            esd = {(k[7:] if k.startswith('module.') else k): v for k, v in resume['ema'].items()}
+            for nm, p_, o in zip(arena.names, arena.params, arena.offsets):
+                if nm in esd:
+                    tgt = opt.ema if use_hip_opt else ema
+                    tgt[o:o + p_.numel()].copy_(esd[nm].reshape(-1).to(tgt.device))
+            for k in ema_buffers:
+                if k in esd:
+                    ema_buffers[k].copy_(esd[k].to(ema_buffers[k].device))
+        if train_engine is not None:
+            train_engine.repack()
+    train.start_iter = start_iter
+
+    def ema_state():
+        sd = None
+        if ema_on:
+            if use_hip_opt:
+                sd = opt.ema_state_dict(model)
+            elif ema is not None:
+                sd = {nm: ema[o:o + p_.numel()].view_as(p_).clone() for nm, p_, o in zip(arena.names, arena.params, arena.offsets)}
+            if sd is not None:
+                sd.update({k: v.clone() for k, v in ema_buffers.items()})
+                for k, v in model.named_buffers():              # integer buffers (num_batches_tracked) are not averaged
+                    if k not in sd:
+                        sd[k] = v.detach().clone()
+        return sd
+
+    def save(step):
+        if save_dir and rank == 0:
+            ost = opt.state_dict() if use_hip_opt else {'torch': opt.state_dict()}
+            name = 'ckpt_%d.pth.tar' % step if scfg.get('save_many', False) and step != max_iter else 'ckpt.pth.tar'
+            save_checkpoint(os.path.join(save_dir, name), model, ema_state(), ost, step)
+
+    for it in range(start_iter, max_iter):
+        lr = cosine_lr(it, max_iter, base_lr, warmup_lr, warmup_steps, min_lr)
         sel = [idx[(it * bs + j) % len(idx)] for j in range(bs)]
         items = sel
         imgs, labels = ds.batch(sel, device)
@@ -411,24 +610,13 @@ def train(cfg, args, rank, world, device):
                     if k in ema_buffers:
                         ema_buffers[k].mul_(decay).add_(v.detach(), alpha=1 - decay)
         loss_v = float(loss.detach())
-        if rank == 0 and (it % int(cfg.get('saver', {}).get('print_freq', 10)) == 0 or it == max_iter - 1):
+        if rank == 0 and (it % int(scfg.get('print_freq', 10)) == 0 or it == max_iter - 1):
             print(json.dumps({'iter': it, 'loss': loss_v, 'lr': lr}))
-    # checkpoint (rank 0): model, EMA (parameters from the optimizer's arena + the EMA'd buffers), last iteration
-    save_dir = (cfg.get('saver', {}) or {}).get('save_dir') or getattr(args, 'ckpt_dir', None)
-    ema_sd = None
-    if ema_on:
-        if use_hip_opt:
-            ema_sd = opt.ema_state_dict(model)
-        elif ema is not None:
-            ema_sd = {nm: ema[o:o + p.numel()].view_as(p).clone() for nm, p, o in zip(arena.names, arena.params, arena.offsets)}
-        if ema_sd is not None:
-            ema_sd.update(ema_buffers)
-            for k, v in model.named_buffers():                  # integer buffers (num_batches_tracked) are not averaged
-                if k not in ema_sd:
-                    ema_sd[k] = v.detach().clone()
-    train.last_ema_state = ema_sd
-    if save_dir and rank == 0:
-        save_checkpoint(os.path.join(save_dir, 'ckpt.pth.tar'), model, ema_sd, None, max_iter)
+        if save_freq and (it + 1) % save_freq == 0 and it + 1 < max_iter:
+            save(it + 1)                                     # an interrupted run resumes from here with --recover
+    # checkpoint (rank 0): model, EMA (parameters from the optimizer's arena + the EMA'd buffers), optimizer, last iteration
+    train.last_ema_state = ema_state()
+    save(max_iter)
     return loss_v, model
 
 
@@ -443,6 +631,8 @@ def main(argv=None):
     ap.add_argument('--severity', type=int, default=3)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--engine', choices=['hip', 'torch'], default='hip')
+    ap.add_argument('--precision', choices=['bf16', 'bf16x3', 'fp32x'], default=None,
+                    help="evaluation engine arithmetic: bf16 (default) or the reference-precision mode 'fp32x' (= 'bf16x3')")
     ap.add_argument('--max-iter', type=int, default=20)
     ap.add_argument('--train-engine', choices=['hip', 'torch'], default='hip', dest='train_engine',
                     help='train-mode forward/backward: hip = ResNet50TrainEngine, torch = autograd scaffold')

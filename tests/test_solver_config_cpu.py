@@ -1,0 +1,210 @@
+"""cls_solver host logic on the CPU: the reference's YAML key set (schedule in epochs, `saver` keys), checkpoint resume
+(`--recover`: optimizer state, EMA, schedule position), safe checkpoint loading, and the file-backed dataset's host side
+(meta files, PIL decode, crop boxes).  Reference: exprs/nips_benchmark/pgd_adv_train/resnet50/config.yaml,
+exprs/exp/imagenet_c_loop_mini/config_vit_base.yaml:80-104 (the dict below is rebuilt key by key, not copied)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from robustart_amd.train import cls_solver as S
+
+
+def reference_shaped_config(**over):
+    """A dict with exactly the key set of the reference's pgd_adv_train/resnet50/config.yaml."""
+    cfg = {
+        'model': {'type': 'resnet50_official', 'kwargs': {'bn': {'use_sync_bn': False, 'kwargs': {}}}},
+        'dist': {'sync': True},
+        'optimizer': {'type': 'SGD', 'kwargs': {'nesterov': True, 'momentum': 0.9, 'weight_decay': 0.0001}},
+        'lr_scheduler': {'type': 'CosineEpoch',
+                         'kwargs': {'base_lr': 0.1, 'warmup_lr': 0.4, 'min_lr': 0.0, 'warmup_epoch': 2, 'max_epoch': 100}},
+        'label_smooth': 0.1,
+        'ema': {'enable': True, 'kwargs': {'decay': 0.9999}},
+        'data': {'type': 'imagenet', 'read_from': 'fake', 'use_dali': True, 'batch_size': 32, 'num_workers': 4,
+                 'pin_memory': True, 'input_size': 224, 'test_resize': 256,
+                 'train': {'root_dir': '/mnt/lustre/share/images/train/', 'meta_file': '/mnt/lustre/share/images/meta/train.txt',
+                           'image_reader': {'type': 'pil'}, 'sampler': {'type': 'distributed_iteration'},
+                           'transforms': {'type': 'STANDARD'}},
+                 'test': {'root_dir': '/mnt/lustre/share/images/val/', 'meta_file': '/mnt/lustre/share/images/meta/val.txt',
+                          'image_reader': {'type': 'pil'}, 'sampler': {'type': 'distributed'},
+                          'transforms': {'type': 'ONECROP'},
+                          'evaluator': {'type': 'imagenet', 'kwargs': {'topk': [1, 5]}}}},
+        'saver': {'print_freq': 10, 'val_freq': 5000, 'save_many': False},
+    }
+    for k, v in over.items():
+        node = cfg
+        *path, leaf = k.split('.')
+        for p in path:
+            node = node[p]
+        node[leaf] = v
+    return cfg
+
+
+def test_epoch_keys_of_the_reference_yaml_resolve_to_iterations():
+    cfg = reference_shaped_config()
+    # ImageNet-1k, the reference's launch of this config: 16 GPUs x 32 images (run.sh:2)
+    max_iter, warm = S.resolve_schedule(cfg, 1281167, 32, 16)
+    per_epoch = -(-1281167 // 512)
+    assert (max_iter, warm) == (100 * per_epoch, 2 * per_epoch) == (250300, 5006)
+    # the iteration keys (commented in the reference file) win over the epoch keys; this build's top-level max_iter over both
+    cfg['lr_scheduler']['kwargs'].update(max_iter=125000, warmup_steps=2500)
+    assert S.resolve_schedule(cfg, 1281167, 32, 16) == (125000, 2500)
+    cfg['max_iter'] = 7
+    assert S.resolve_schedule(cfg, 1281167, 32, 16) == (7, 7)
+    # neither: the caller's default, warm-up a twentieth of it
+    assert S.resolve_schedule({}, 100, 10, 1, default_max_iter=40) == (40, 2)
+    # the schedule those numbers drive: linear warm-up base_lr -> warmup_lr, cosine to min_lr
+    lr = [S.cosine_lr(i, 250300, 0.1, 0.4, 5006, 0.0) for i in (0, 2503, 5006, 250299)]
+    assert lr[0] == 0.1 and abs(lr[1] - 0.25) < 1e-12 and abs(lr[2] - 0.4) < 1e-12 and lr[3] < 1e-9
+
+
+class _Args:
+    engine = 'torch'
+    train_engine = 'torch'
+    corruption = None
+    attack = None
+    eps = '2/255'
+    steps = 0
+    severity = 3
+    seed = 0
+    max_iter = 20
+    recover = None
+    ckpt_dir = None
+
+
+def _tiny_registered():
+    import robustart_amd.model as M
+
+    def tiny(**kw):
+        torch.manual_seed(0)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, stride=4), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                                   torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(4, 1000))
+    M._REGISTRY['tiny_cfg_test'] = tiny
+
+
+def test_train_with_the_reference_key_set_and_resume(tmp_path):
+    """The loop accepts the reference's dict as is (epochs -> iterations from the dataset length), saves at val_freq, and a
+    run interrupted at the saved iteration and resumed with --recover ends bit-identical to the uninterrupted run:
+    parameters, EMA (parameters and BatchNorm buffers), momentum, schedule position."""
+    _tiny_registered()
+    dev = torch.device('cpu')
+    over = {'model.type': 'tiny_cfg_test', 'data.batch_size': 4, 'data.input_size': 32, 'lr_scheduler.kwargs.max_epoch': 3,
+            'lr_scheduler.kwargs.warmup_epoch': 1, 'lr_scheduler.kwargs.base_lr': 0.01, 'lr_scheduler.kwargs.warmup_lr': 0.02,
+            'ema.kwargs.decay': 0.9, 'saver.val_freq': 4}
+    cfg = reference_shaped_config(**over)
+    cfg['data']['fake_size'] = 12                                     # 3 iterations per epoch -> 9 iterations, warm-up 3
+    cfg['bf16'] = False
+    full_dir, part_dir = str(tmp_path / 'full'), str(tmp_path / 'part')
+    cfg['saver']['save_dir'] = full_dir
+    loss_full, m_full = S.train(cfg, _Args(), 0, 1, dev)
+    assert S.train.start_iter == 0
+    ck_full = torch.load(os.path.join(full_dir, 'ckpt.pth.tar'), weights_only=True)      # tensors and numbers only
+    assert ck_full['last_iter'] == 9 and set(ck_full) >= {'model', 'ema', 'optimizer', 'last_iter'}
+    # "interrupted": the same config with save_many, so the checkpoint of iteration 4 survives the later saves
+    cfg_i = reference_shaped_config(**over)
+    cfg_i['data']['fake_size'] = 12
+    cfg_i['bf16'] = False
+    cfg_i['saver'].update(save_dir=part_dir, save_many=True)
+    S.train(cfg_i, _Args(), 0, 1, dev)
+    mid = os.path.join(part_dir, 'ckpt_4.pth.tar')                  # written at iteration 4 and 8 (save_many keeps both)
+    assert os.path.exists(mid) and os.path.exists(os.path.join(part_dir, 'ckpt_8.pth.tar'))
+    ck_mid = torch.load(mid, weights_only=True)
+    assert ck_mid['last_iter'] == 4 and 'torch' in ck_mid['optimizer']
+    a = _Args()
+    a.recover = mid
+    cfg_r = reference_shaped_config(**over)
+    cfg_r['data']['fake_size'] = 12
+    cfg_r['bf16'] = False
+    cfg_r['saver']['save_dir'] = str(tmp_path / 'resumed')
+    loss_res, m_res = S.train(cfg_r, a, 0, 1, dev)
+    assert S.train.start_iter == 4
+    for (k, v), (_, w) in zip(m_full.state_dict().items(), m_res.state_dict().items()):
+        assert torch.equal(v, w), k
+    ck_res = torch.load(os.path.join(str(tmp_path / 'resumed'), 'ckpt.pth.tar'), weights_only=True)
+    for k in ck_full['ema']:
+        assert torch.equal(ck_full['ema'][k], ck_res['ema'][k]), k
+    assert loss_full == loss_res
+    # saver.pretrain.ignore.key: [optimizer, last_iter] -> fine-tuning: weights only, the schedule starts at 0
+    cfg_f = reference_shaped_config(**over)
+    cfg_f['data']['fake_size'] = 12
+    cfg_f['bf16'] = False
+    cfg_f['saver']['pretrain'] = {'path': mid, 'ignore': {'key': ['optimizer', 'last_iter']}}
+    S.train(cfg_f, _Args(), 0, 1, dev)
+    assert S.train.start_iter == 0
+
+
+def test_checkpoints_load_without_unpickling_objects(tmp_path):
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+    p = str(tmp_path / 'evil.pth')
+    with open(p, 'wb') as f:
+        pickle.dump({'model': {}, 'x': Evil()}, f)
+    m = torch.nn.Linear(2, 2)
+    with pytest.raises(RuntimeError, match='weights_only'):
+        S.load_pretrain(m, p)
+    good = str(tmp_path / 'good.pth')
+    torch.save({'model': {('module.' + k): v for k, v in m.state_dict().items()}, 'last_iter': 3}, good)
+    m2 = torch.nn.Linear(2, 2)
+    ck = S.load_pretrain(m2, good)
+    assert ck['last_iter'] == 3 and torch.equal(m2.weight, m.weight)
+    with pytest.warns(RuntimeWarning, match='missing keys'):
+        S.load_pretrain(torch.nn.Linear(2, 2), _partial(tmp_path, m), strict=False)
+
+
+def _partial(tmp_path, m):
+    p = str(tmp_path / 'partial.pth')
+    torch.save({'weight': m.weight.detach()}, p)
+    return p
+
+
+def _write_images(root, n=6):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    os.makedirs(os.path.join(root, 'val', 'n01'), exist_ok=True)
+    lines, arrays = [], []
+    for i in range(n):
+        h, w = 40 + 7 * i, 60 + 5 * (i % 3)
+        arr = (rs.rand(h, w, 3) * 255).astype(np.uint8)
+        name = 'n01/img_%d.%s' % (i, 'png' if i % 2 else 'jpg')
+        Image.fromarray(arr).save(os.path.join(root, 'val', name), **({} if i % 2 else {'quality': 95}))
+        lines.append((name, i % 5))
+        arrays.append(arr)
+    return lines, arrays
+
+
+def test_file_dataset_host_side(tmp_path):
+    root = str(tmp_path)
+    lines, arrays = _write_images(root)
+    meta_txt = os.path.join(root, 'val.txt')
+    with open(meta_txt, 'w') as f:
+        f.write('\n'.join('%s %d' % ln for ln in lines) + '\n\n')
+    meta_json = os.path.join(root, 'val.json')
+    with open(meta_json, 'w') as f:
+        for name, lab in lines:
+            f.write(json.dumps({'filename': name, 'label': lab, 'label_name': 'x'}) + '\n')
+    assert S.read_meta_file(meta_txt) == lines == S.read_meta_file(meta_json)
+    dcfg = {'read_from': 'fs', 'input_size': 32, 'test_resize': 36,
+            'test': {'root_dir': os.path.join(root, 'val'), 'meta_file': meta_txt, 'image_reader': {'type': 'pil'},
+                     'transforms': {'type': 'ONECROP'}}}
+    ds = S.make_dataset(dcfg, 0, 32, 'test')
+    assert len(ds) == 6 and ds.transform == 'ONECROP' and ds.test_resize == 36
+    arr, lab = ds.decode(1)                                         # PNG: lossless
+    assert lab == 1 and np.array_equal(arr, arrays[1])
+    arr0, _ = ds.decode(0)                                          # JPEG: the PIL decoder's output, same shape
+    assert arr0.shape == arrays[0].shape and arr0.dtype == np.uint8
+    y, x, h, w, flip = ds.box(3, arrays[3].shape[:2])
+    assert (y, x, h, w, flip) == ds.box(3, arrays[3].shape[:2])     # a pure function of (seed, index)
+    assert 0 <= y and y + h <= arrays[3].shape[0] and 0 <= x and x + w <= arrays[3].shape[1]
+    with pytest.raises(RuntimeError, match='GPU'):
+        ds.batch([0], 'cpu')                                        # the transform's arithmetic has no CPU fallback
+    with pytest.raises(ValueError):
+        S.make_dataset({'read_from': 'fs', 'test': {}}, 0, 32, 'test')
+    with pytest.raises(NotImplementedError):
+        S.make_dataset(dict(dcfg, test=dict(dcfg['test'], image_reader={'type': 'opencv'})), 0, 32, 'test')
+    # the reference configs keep read_from: fake next to cluster paths: still the synthetic set
+    fake = S.make_dataset(reference_shaped_config()['data'], 8, 32, 'test')
+    assert isinstance(fake, S.FakeImageNet) and len(fake) == 8
