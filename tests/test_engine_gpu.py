@@ -215,13 +215,21 @@ def _reference_backward_with_engine_masks(eng, acts, dl, std):
     return g / torch.tensor(std, dtype=dt).view(1, 3, 1, 1)
 
 
-@pytest.mark.parametrize('B,HW,kind', [(3, 96, 0), (2, 224, 0), (3, 96, 1)])
+@pytest.mark.parametrize('B,HW,kind', [(3, 96, 0), (2, 224, 0), (3, 96, 1), (3, 96, 4), (2, 224, 4)])
 def test_backward_to_input(setup, B, HW, kind):
     m, eng = setup
     g = torch.Generator().manual_seed(10 + B)
     x = torch.rand(B, 3, HW, HW, generator=g).cuda()
     y = torch.randint(0, 1000, (B,), generator=g).cuda()
-    logits, loss, grad, pred = eng.forward_backward(x, MEAN, STD, y, kind)
+    # kind 4 = FAB's gradient of a logit DIFFERENCE z_target - z_y (fab_pt.py:102-117): a +1 / -1 pair in dlogits
+    yt = ((y + 1 + torch.randint(0, 998, (B,), generator=g).cuda()) % 1000) if kind == 4 else None
+    logits, loss, grad, pred = eng.forward_backward(x, MEAN, STD, y, kind, yt)
+    if kind == 4:
+        dl = eng.last_dlogits
+        rows = torch.arange(B, device='cuda')
+        assert torch.equal(dl[rows, yt], torch.ones(B, device='cuda')) and torch.equal(dl[rows, y], -torch.ones(B, device='cuda'))
+        assert float(dl.abs().sum()) == 2.0 * B
+        torch.testing.assert_close(loss, logits[rows, yt] - logits[rows, y], rtol=0, atol=1e-4 * float(logits.abs().max()))
     assert torch.equal(pred.long(), logits.argmax(1))
     if eng.last_acts['y1'] is None:
         # the fused stem forward never materialises the stem output; the reference below needs it for the ReLU / max-pool
@@ -247,7 +255,7 @@ def test_backward_to_input(setup, B, HW, kind):
     # bf16 rounding flips in the forward change ~0.5% of the masks per stage and the difference compounds
     # over 16 blocks, so this is a sanity bound, not a pin (see DESIGN.md "engine numerics").
     if kind != 0:
-        return      # DLR depends on the ORDER of near-tied logits of a random-init net: not comparable end to end
+        return      # DLR depends on the ORDER of near-tied logits of a random-init net: not comparable end to end (4: pinned above)
     from robustart_amd.noise.adv import logit_loss
     xr = x.cpu().double().requires_grad_(True)
     out = _emulated_forward(eng, xr)

@@ -162,7 +162,7 @@ def _x3_reference_backward_with_engine_masks(m, eng, acts, dl, std):
     return g / torch.tensor(std, dtype=dt).view(1, 3, 1, 1)
 
 
-@pytest.mark.parametrize('kind', [0, 1])
+@pytest.mark.parametrize('kind', [0, 1, 4])
 def test_x3_gradient_vs_fp64(setup, kind):
     """forward_backward (CE and DLR) on the pair engine: (1) against an fp64 backward of the fp32 weights with the engine's own
     ReLU / max-pool decisions (pins the backward arithmetic: rel L2 <= 5e-4), (2) end to end against fp64 autograd of the
@@ -173,7 +173,8 @@ def test_x3_gradient_vs_fp64(setup, kind):
     B = 4
     x = torch.rand(B, 3, 128, 128, generator=g).cuda()
     y = torch.randint(0, 1000, (B,), generator=g).cuda()
-    logits, loss, grad, pred = eng.forward_backward(x, MEAN, STD, y, kind)
+    yt = ((y + 1 + torch.randint(0, 998, (B,), generator=g).cuda()) % 1000) if kind == 4 else None     # 4: FAB's z_t - z_y
+    logits, loss, grad, pred = eng.forward_backward(x, MEAN, STD, y, kind, yt)
     dl = eng.last_dlogits
     ref = _x3_reference_backward_with_engine_masks(m, eng, eng.last_acts, dl, STD).cuda()
     a, b = grad.double().flatten(1), ref.flatten(1)
@@ -187,7 +188,7 @@ def test_x3_gradient_vs_fp64(setup, kind):
     m64 = copy.deepcopy(m).cpu().double()
     xr = x.cpu().double().requires_grad_(True)
     lg = m64((xr - mean) / std)
-    _, dl_at_ref, _ = logit_loss(lg.detach().float().cuda(), y, kind, None, 1.0)
+    _, dl_at_ref, _ = logit_loss(lg.detach().float().cuda(), y, kind, yt, 1.0)
     assert (dl - dl_at_ref).abs().max().item() <= 2e-2 * dl_at_ref.abs().max().item()
     want, = torch.autograd.grad((lg * dl.double().cpu()).sum(), xr)
     want, lg = want.cuda(), lg.detach().cuda()

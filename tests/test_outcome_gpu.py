@@ -182,6 +182,77 @@ def test_pgd7_outcome_reference_precision_engine_vs_fp32_module(fitted):
     assert rep['grad_cos_median'] > 0.999999 and rep['grad_cos_min'] > 0.99 and rep['grad_sign_agreement'] > 0.995
 
 
+def _norm_of(delta, norm):
+    d = delta.flatten(1)
+    return {'Linf': d.abs().max(1)[0], 'L2': d.norm(dim=1), 'L1': d.abs().sum(1)}[norm]
+
+
+def test_every_attack_through_the_engines_at_224_vs_the_fp32_module(fitted):
+    """every attack of the registry (and the AutoAttack members) driven through EngineModel on ResNet-50 at
+    224 x 224 -- bf16 engine and reference-precision engine -- against the same attack driven by torch autograd through the fp32
+    module, same counter-based draws (seed, sample index): the threat-model invariants hold (eps ball of the attack's norm,
+    [0,1] box), and the adversarial examples have the same per-image outcome when scored by the fp32 module.
+    Reference: attack.py:20-52, imfgsm_attack.py:62-93, autopgd_base.py:571-690, fab_pt.py:102-117, square.py:221-294."""
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.noise import adv, rng
+    S, cfg, model = fitted
+    ds = S.make_dataset(cfg['data'], 4096, 224)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    mean = torch.tensor(MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(STD, device='cuda').view(1, 3, 1, 1)
+    f32 = lambda z: model((z - mean) / std)      # noqa: E731   the reference's f_model (takes [0,1])
+    paths = {'fp32-module': (f32, model)}
+    for name, prec in (('bf16-engine', 'bf16'), ('fp32x-engine', 'fp32x')):
+        f = EngineModel(model, takes_normalized=False, precision=prec)
+        paths[name] = (f, EngineModel(None, takes_normalized=True, engine=f.rart_engine))      # `f_model` and `model` keys
+    n = 64
+    imgs, y = ds.batch(list(range(30000, 30000 + n)), 'cuda')
+    x = imgs.permute(0, 3, 1, 2).float().div(255.0).contiguous()
+    e8 = 4 / 255
+    aa = dict(apgd_iter=8, apgdt_iter=5, apgdt_classes=2, fab_iter=5, fab_classes=2, square_queries=30)
+    attacks = [
+        ('fgsm', 'Linf', e8, lambda f, m: adv.fgsm(x, y, f, e8)),
+        ('pgd_l2', 'L2', 3.0, lambda f, m: adv.pgd_l2(x, y, f, 3.0, 0.2, 5, seed=3, sample_offset=0)),
+        ('mim_linf', 'Linf', e8, lambda f, m: adv.mim_linf(x, y, m, e8, 5, 2 / 255, 1.0, seed=3, sample_offset=0)),
+        ('pgd_l1', 'L1', 600.0, lambda f, m: adv.pgd_l1(x, y, m, 600.0, 224, 150.0, 5, 16, seed=3, sample_offset=0)),
+        ('apgd-ce', 'Linf', e8, lambda f, m: adv.apgd_perturb(f, x, y, 'Linf', e8, 8, 'ce', 1, seed=3, sample_offset=0)),
+        ('apgd-l2-dlr', 'L2', 3.0, lambda f, m: adv.apgd_perturb(f, x, y, 'L2', 3.0, 8, 'dlr', 1, seed=3, sample_offset=0)),
+        ('apgd-t', 'Linf', e8, lambda f, m: adv.apgd_targeted_perturb(f, x, y, 'Linf', e8, 6, 2, seed=3, sample_offset=0)),
+        ('apgd-l1', 'L1', 600.0, lambda f, m: adv.apgd_l1_perturb(f, x, y, 600.0, 8, 'ce', 1, False, seed=3, sample_offset=0)),
+        ('fab-t', 'Linf', e8, lambda f, m: adv.fab_targeted_perturb(f, x, y, e8, 6, 2)),
+        ('square', 'Linf', e8, lambda f, m: adv.square_perturb(f, x, y, e8, 60, seed=3, sample_offset=0)),
+        ('autoattack_linf', 'Linf', e8, lambda f, m: adv.autoattack_linf(x, y, m, 'Linf', e8, 'standard', False, seed=3,
+                                                                       _overrides=dict(aa))),
+    ]
+    report = {}
+    for name, norm, eps, run in attacks:
+        out = {}
+        for pname, (f, m) in paths.items():
+            rng.manual_seed(3, 0)                              # autoattack_linf reads the process-wide sample counter
+            xa = run(f, m)
+            assert xa.shape == x.shape and torch.isfinite(xa).all(), (name, pname)
+            assert float(xa.min()) >= -1e-6 and float(xa.max()) <= 1.0 + 1e-6, (name, pname, float(xa.min()), float(xa.max()))
+            nrm = _norm_of(xa - x, norm)
+            assert float(nrm.max()) <= eps * (1 + 1e-4) + 1e-6, (name, pname, float(nrm.max()), eps)
+            with torch.no_grad():
+                out[pname] = (f32(xa).argmax(1), nrm)
+        base = out['fp32-module'][0]
+        row = {'robust_fp32_module': float((base == y).float().mean())}
+        for pname in ('bf16-engine', 'fp32x-engine'):
+            pr = out[pname][0]
+            row[pname] = {'robust': float((pr == y).float().mean()), 'agreement': float((pr == base).float().mean())}
+        report[name] = row
+        print('%-16s %s' % (name, json.dumps(row)))
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(report, open('gpurun_out/attacks_through_engines_224.json', 'w'), indent=1)
+    assert report['apgd-ce']['robust_fp32_module'] < 0.9 and report['autoattack_linf']['robust_fp32_module'] < 0.9   # the attacks bite
+    for name, row in report.items():
+        # one image of 64 = 1.6 points.  The reference-precision engine reproduces the fp32 outcome; bf16 within a few images
+        assert row['fp32x-engine']['agreement'] >= 0.95 and abs(row['fp32x-engine']['robust'] - row['robust_fp32_module']) <= 0.05, (name, row)
+        assert row['bf16-engine']['agreement'] >= 0.85 and abs(row['bf16-engine']['robust'] - row['robust_fp32_module']) <= 0.10, (name, row)
+
+
 def test_b256_matches_small_batches_bit_for_bit():
     """Every 32nd image of a B = 256 forward / forward_backward equals the same image run in a batch of 2 (the kernels'
     arithmetic per output element does not depend on the batch: same K order, same tiles), and rart_corrupt_u8 on the
