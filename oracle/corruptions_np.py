@@ -696,9 +696,11 @@ def glass_blur(x, severity, draws):
             for b, w in enumerate(range(224 - delta, delta, -1)):
                 dx, dy = int(d[i, a, b, 0]), int(d[i, a, b, 1])
                 hp, wp = h + dy, w + dx
-                tmp = x[h, w].copy()
+                # the reference writes `x[h, w], x[h_prime, w_prime] = x[h_prime, w_prime], x[h, w]` (:181-182) on a numpy
+                # array: both right-hand sides are VIEWS, so after x[h, w] has received the neighbour's pixel the second
+                # assignment copies that same pixel back onto the neighbour.  What executes is a COPY x[h, w] <- x[h', w'],
+                # not a swap (found by the pinned-modulo-shim golden, tests/golden/make_golden_shim.py)
                 x[h, w] = x[hp, wp]
-                x[hp, wp] = tmp
     return np.clip(sk_gaussian(x / 255., sigma=sigma, multichannel=True), 0, 1) * 255
 
 

@@ -140,12 +140,16 @@ size_t gauss_fused_lds(int r) {
 }
 
 // ---- glass_blur local shuffle -------------------------------------------------------------
-// corruptions.py:176-182: for h in 224-d..d+1 (desc), w likewise: swap (h,w) <-> (h+dy, w+dx).
-// Sequential per image, but swap (h,w) can only touch pixels within d of (h,w), so two swaps
-// conflict only if both coordinates differ by <= 2d.  Rows are therefore pipelined with a skew of
-// S = 2d+1 columns: at time t row index a (h = 224-d-a) handles column index b = t - a*S.  Swaps
-// issued in the same time step are >= S columns apart (no conflict) and every earlier-in-scan
-// conflicting swap has a strictly smaller time.  One workgroup per image, image resident in LDS.
+// corruptions.py:176-182: for h in 224-d..d+1 (desc), w likewise: `x[h, w], x[h', w'] = x[h', w'], x[h, w]` with
+// (h', w') = (h+dy, w+dx).  On a numpy array both right-hand sides are VIEWS, so the statement does not swap: after
+// x[h, w] has received the neighbour's pixel, the second assignment copies that same pixel back onto the neighbour.  What the
+// reference executes -- and what the golden vectors of the unmodified function show (tests/golden/make_golden_shim.py; rounds
+// 1-2 implemented the swap the code appears to say) -- is the COPY CHAIN x[h, w] <- x[h+dy, w+dx] in scan order.
+// Sequential per image: an operation reads a pixel within d of the one it writes, so two operations conflict (one reads what
+// the other writes) only if both coordinates differ by <= d.  Rows are therefore pipelined with a skew of S = d+1 columns: at
+// time t row index a (h = 224-d-a) handles column index b = t - a*S.  Operations issued in the same time step are >= S columns
+// apart (no conflict) and every earlier-in-scan conflicting operation has a strictly smaller time ((a'-a)*S + (b'-b) >= S - d).
+// One workgroup per image, image resident in LDS.
 constexpr int kGlassThreads = 128;
 
 __global__ __launch_bounds__(kGlassThreads) void k_glass_shuffle(uint8_t* __restrict__ img_all, int delta, int iters,
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(kGlassThreads) void k_glass_shuffle(uint8_t* __rest
   for (int i = threadIdx.x; i < HW * HW * 3 / 16; i += kGlassThreads) l4[i] = g4[i];
   __syncthreads();
   const int N = HW - 2 * delta;  // loop trip count per axis
-  const int S = 2 * delta + 1;
+  const int S = delta + 1;
   const int8_t* dr = inj ? inj + (size_t)blockIdx.x * iters * N * N * 2 : nullptr;
   const uint32_t sample = sample_base + blockIdx.x;
   for (int it = 0; it < iters; ++it) {
@@ -180,11 +184,9 @@ __global__ __launch_bounds__(kGlassThreads) void k_glass_shuffle(uint8_t* __rest
           }
           const int hh = HW - delta - a, ww = HW - delta - b;
           uint8_t* p = lds + ((size_t)hh * HW + ww) * 3;
-          uint8_t* q = lds + ((size_t)(hh + dy) * HW + (ww + dx)) * 3;
-          const uint8_t p0 = p[0], p1 = p[1], p2 = p[2];
+          const uint8_t* q = lds + ((size_t)(hh + dy) * HW + (ww + dx)) * 3;
           const uint8_t q0 = q[0], q1 = q[1], q2 = q[2];
           p[0] = q0; p[1] = q1; p[2] = q2;
-          q[0] = p0; q[1] = p1; q[2] = p2;
         }
       }
       __syncthreads();
