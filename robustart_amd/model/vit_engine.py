@@ -20,6 +20,7 @@ class ViTEngine:
         torch = _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
+        self.precision = 'bf16'          # the reference-precision mode exists for ResNet-50 only (model/engine.py)
         m = model
         self.D, self.H, self.ps = m.embed_dim, m.num_heads, m.patch_size
         self.hd = self.D // self.H

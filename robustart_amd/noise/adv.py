@@ -643,6 +643,12 @@ def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_class
     random restarts, so there are no draws to inject."""
     torch = _lib.require_gpu()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
+    if getattr(prov.engine, 'precision', 'bf16x3') == 'bf16':
+        # measured (tests/test_outcome_gpu.py, fitted ResNet-50, eps 4/255): FAB-T leaves 34 % robust on the bf16 engine where
+        # the fp32 module and the reference-precision engine leave 5 %: its projections work on the logit difference near zero
+        warnings.warn("FAB runs on a bf16 engine: its boundary projections need the logit difference near zero, where bf16 "
+                      "storage dominates; build EngineModel(..., precision='fp32x') for FAB / AutoAttack's fab-t stage",
+                      RuntimeWarning)
     x, y = _check_inputs(x, y)
     adv = x.clone()
     acc = prov.logits(x).max(1)[1] == y
