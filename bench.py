@@ -217,7 +217,18 @@ def measure_gaussian_roofline(B, device, launches=40):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in ev)
     avg = sum(ms) / len(ms)
-    return avg * 1e-3, ms[len(ms) // 2] * 1e-3
+    # calibration beside it: a plain device copy of the SAME bytes over the same rotating pairs (PyTorch's copy kernel): what a
+    # read + write stream of this size sustains on this part, next to the 8 TB/s spec the fraction is quoted against
+    for i in range(npairs):
+        dst[i].copy_(src[i])
+    torch.cuda.synchronize()
+    for i in range(launches):
+        ev[i][0].record()
+        dst[i % npairs].copy_(src[i % npairs])
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    cp = sorted(a.elapsed_time(b) for a, b in ev)
+    return avg * 1e-3, ms[len(ms) // 2] * 1e-3, sum(cp) / len(cp) * 1e-3
 
 
 def pmc_traffic(key):
@@ -254,7 +265,8 @@ def measure_igemm_roofline(path, images, labels):
     out = {'kernel': 'k_conv_igemm_bf16 (ResNet-50 forward + backward-to-input, B=256, %d launches)' % len(ig),
            'bound': 'mfma', 'achieved': flops / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
            'frac': flops / secs / MFMA_BF16_PEAK, 'traffic': pmc_traffic('igemm'),
-           'traffic_note': 'HBM bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB units',
+           'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/r02_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 '
+                           '(gfx950 correction) + WRITE_SIZE, KiB units), not re-measured in this run',
            'avg_launch_us': secs / len(ig) * 1e6, 'launches': len(ig),
            'algorithmic_flops_per_launch': flops / len(ig), 'kernel_seconds_per_fwd_bwd': secs}
     if out['traffic']:
@@ -669,8 +681,8 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        stats = torch.stack([acc[0], acc[1], torch.tensor(B, device=device)]).to(torch.int64)
-        dist.all_reduce(stats)                                   # the eval metric exchange
+        stats = torch.stack([acc[0], acc[1], torch.tensor(B, device=device), torch.tensor(rank + 1, device=device)]).to(torch.int64)
+        dist.all_reduce(stats)                                   # the eval metric exchange + a rank checksum
     imgs_per_step = 6 * B * world
     value = imgs_per_step * args.steps / dt
 
@@ -685,15 +697,29 @@ def main():
                    'model_path': path.name, 'parallelism': 'dp%d' % world,
                    'streams': 1 + len(getattr(path, 'sides', None) or [])},
     }
+    if dist is not None:
+        # evidence in the driver's SCALE record that the collective really spanned N ranks: world size as torch.distributed saw
+        # it, the all-reduced sum of (rank + 1) against N (N + 1) / 2, and the images the ranks reported together
+        out['world_size_seen'] = dist.get_world_size()
+        out['rccl_rank_sum'] = int(stats[3].item())
+        out['rccl_rank_sum_expected'] = world * (world + 1) // 2
+        out['images_per_step_all_ranks'] = int(stats[2].item()) * 6
     if rank == 0:
         if world == 1:
-            avg, med = measure_gaussian_roofline(B, device)
+            avg, med, copy_s = measure_gaussian_roofline(B, device)
             algo = BYTES_PER_IMAGE * B
             out['roofline'] = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, B=256, u8 NHWC in/out)',
                                'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
                                'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': pmc_traffic('k_normal_noise_mfma'),
+                               'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/r02_pmc_traffic.json '
+                                               '(FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run',
                                'avg_launch_us': avg * 1e6, 'median_launch_us': med * 1e6,
-                               'algorithmic_bytes_per_launch': algo}
+                               'algorithmic_bytes_per_launch': algo,
+                               'device_copy_same_bytes': {'avg_launch_us': copy_s * 1e6, 'achieved': algo / copy_s / 1e9, 'unit': 'GB/s',
+                                                          'frac_of_peak': algo / copy_s / HBM_PEAK,
+                                                          'kernel_vs_copy': copy_s / avg,
+                                                          'note': 'torch Tensor.copy_ over the same 9 rotating buffer pairs: the read+write '
+                                                                  'rate this part sustains at this size'}}
             out['hbm_roofline_gaussian_noise'] = out.pop('roofline')
             step_flops = (5 + 15) * B * FLOP_FWD
             out['step_mfma'] = {'achieved': step_flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',

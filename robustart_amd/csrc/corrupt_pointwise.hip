@@ -142,32 +142,42 @@ __device__ __forceinline__ void clt_sums16(uint32_t k0, uint32_t k1, uint32_t ch
   for (int e = 0; e < 16; ++e) s[e] = (float)acc[e];
 }
 
-__device__ __forceinline__ uint32_t pack4_floor_sat(float a, float b, float c, float d) {
-  // v_cvt_pk_u8_f32 saturates to [0,255] and rounds to nearest even; floor first = np.uint8 truncation of the
-  // clipped value (negative values saturate to 0 either way)
-  uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(a), 0, 0u);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(b), 1, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c), 2, w);
-  return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(d), 3, w);
+// v_cvt_pk_u8_f32 saturates to [0,255] and converts with the wave's CURRENT rounding mode; the kernel below runs with MODE.fp_round
+// = toward zero, which makes it np.uint8's truncation of the clipped value (negative values saturate to 0 either way) without a
+// v_floor per element.
+__device__ __forceinline__ uint32_t pack4_sat(float a, float b, float c, float d) {
+  uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, w);
+  return __builtin_amdgcn_cvt_pk_u8_f32(d, 3, w);
 }
 
 // One wave = one aligned 1 KiB chunk (chunk ids run across samples, so any batch packs exactly).
-// Measured alternatives: 4 chunks per wave with the loads issued up front loses to grid-tail
-// quantisation (9408 waves on 8192 slots); a persistent wave loop with the next chunk prefetched is defeated
-// by hipcc's conservative s_waitcnt vmcnt(0) at the loop header (stores and loads share the counter).
+// Round 3 (scratch/exp/noise_variants.hip, all variants in one run, outputs compared byte for byte): 207 -> 164 VALU
+// instructions per wave and 20.75 -> 18.2 us per launch at B = 256 (0.46 -> 0.53 of the 8 TB/s peak; a plain copy of the same
+// bytes takes ~16 us on this part) from
+//   * the chunk index held in SGPRs (readfirstlane of the wave id: hipcc otherwise runs the sample / chunk division, a ~25
+//     instruction sequence, on the vector unit) with a host-computed multiply-shift reciprocal;
+//   * MODE.fp_round = toward zero for the wave (s_setreg), so the 16 conversions need no v_floor; the packed FMAs round toward
+//     zero as well, which left all 38.5 M output bytes of the test batch unchanged.
+// Measured and not adopted: 2 chunks per wave with both loads issued up front (24.5 us: 2.3 rounds of waves -> grid tail);
+// persistent waves with inline-asm loads two chunks ahead and s_waitcnt vmcnt(1) (21.7-23 us at 768-2048 workgroups): the
+// kernel is not waiting on load latency -- 8 resident waves per SIMD already cover it.
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_normal_noise_mfma(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                               uint32_t chunks_per_sample, uint32_t total_chunks,
-                                                              float c, uint32_t k0, uint32_t k1, uint32_t sample_base) {
+                                                              float c, uint32_t k0, uint32_t k1, uint32_t sample_base,
+                                                              uint32_t cps_magic, uint32_t cps_shift) {
+  __builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 3);        // hwreg(HW_REG_MODE, 0, 2): single-precision rounding = toward zero
   const int lane = threadIdx.x & 63;
-  const uint32_t g = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (g >= total_chunks) return;                                // wave-uniform
   const uint4 cur = in[(size_t)g * 64 + lane];
   const i32x4 hb = clt_hadamard_operand(lane);
   const float gsc = KIND == 0 ? 255.0f * c : c;
   const float ga = gsc * kCltA, gb = gsc * kCltB;
   const f32x2 ga2 = {ga, ga}, gb2 = {gb, gb};
-  const uint32_t sample = g / chunks_per_sample, chunk = g - sample * chunks_per_sample;
+  const uint32_t sample = (uint32_t)(((uint64_t)g * cps_magic) >> cps_shift), chunk = g - sample * chunks_per_sample;
   float s[16];
   clt_sums16(k0, k1, chunk, sample_base + sample, lane, hb, s);
   const uint32_t wi[4] = {cur.x, cur.y, cur.z, cur.w};
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_normal_noise_mfma(const uint4* __res
       if (KIND == 1) t = t * x;                                  // speckle: x + x*c*z
       y[hh] = __builtin_elementwise_fma(t, sv, x);
     }
-    wo[j] = pack4_floor_sat(y[0].x, y[0].y, y[1].x, y[1].y);
+    wo[j] = pack4_sat(y[0].x, y[0].y, y[1].x, y[1].y);
   }
   out[(size_t)g * 64 + lane] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
 }
@@ -562,13 +572,17 @@ int rart_launch_pointwise(int id, const RartCorruptArgs& a) {
                              (const double*)inj0, total);
       } else if (vec_ok && g_normal_generator == 1 && eps % 1024 == 0) {
         const uint32_t cps = (uint32_t)(eps / 1024), total = cps * (uint32_t)a.n;
+        RART_CHECK_ARG((unsigned long long)cps * (unsigned long long)a.n < (1ull << 31), "noise: too many 1 KiB chunks per call");
+        uint32_t lg = 0;                                     // exact g / cps for g < 2^31: q = (g * magic) >> (31 + ceil(log2 cps))
+        while ((1ull << lg) < cps) ++lg;
+        const uint32_t cshift = 31 + lg, cmagic = (uint32_t)(((1ull << cshift) + cps - 1) / cps);
         const dim3 g((total + kBlock / 64 - 1) / (kBlock / 64));
         if (id == RART_GAUSSIAN_NOISE)
           hipLaunchKernelGGL(k_normal_noise_mfma<0>, g, dim3(kBlock), 0, a.stream, (const uint4*)a.in, (uint4*)a.out,
-                             cps, total, (float)c, k0, k1, sbase);
+                             cps, total, (float)c, k0, k1, sbase, cmagic, cshift);
         else
           hipLaunchKernelGGL(k_normal_noise_mfma<1>, g, dim3(kBlock), 0, a.stream, (const uint4*)a.in, (uint4*)a.out,
-                             cps, total, (float)c, k0, k1, sbase);
+                             cps, total, (float)c, k0, k1, sbase, cmagic, cshift);
       } else if (vec_ok) {
         const uint32_t vps = (uint32_t)(eps / 16);
         const dim3 g = grid2d(vps, a.n);
