@@ -434,6 +434,87 @@ __global__ __launch_bounds__(kBlock) void k_contrast_apply(const uint8_t* __rest
   }
 }
 
+// contrast as ONE kernel, one workgroup per image with the image resident in LDS (150 528 B of the 160 KiB): HBM is touched
+// once each way.  The result of a byte depends only on (channel, byte value, channel mean), so after the exact integer channel
+// sums each workgroup evaluates the reference's fp64 expression 768 times into a lookup table (the same statements as
+// k_contrast_apply: bit-identical by construction) and the 150 528 bytes go through the table -- no fp64 per element.
+// Round 2's two-launch form (k_channel_sums with 64-bit atomics + a per-element fp64 kernel) took 178 us per 256-image batch.
+constexpr int kCiThreads = 1024;
+__global__ __launch_bounds__(kCiThreads) void k_contrast_image(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                               uint32_t pixels_per_sample, double c) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t ci_lds[];      // image bytes, then sums[3] (u32), then lut[768]
+  const uint32_t elems = pixels_per_sample * 3;                         // multiple of 48 (host check): 16-byte vectors start at
+  uint32_t* const ssum = reinterpret_cast<uint32_t*>(ci_lds + elems);   //   element 16 v, i.e. channel phase v % 3
+  uint8_t* const lut = ci_lds + elems + 16;
+  const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)blockIdx.x * elems);
+  uint4* img = reinterpret_cast<uint4*>(ci_lds);
+  const uint32_t nvec = elems / 16;
+  if (threadIdx.x < 3) ssum[threadIdx.x] = 0;
+  // byte j of a vector belongs to class j % 3; per dword q the class of byte b is (4 q + b) % 3 = (q + b) % 3
+  uint32_t t0 = 0, t1 = 0, t2 = 0;                                      // per-thread sums by (phase-corrected) channel
+  for (uint32_t v = threadIdx.x; v < nvec; v += kCiThreads) {
+    const uint4 p = src[v];
+    img[v] = p;
+    const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+    uint32_t a0 = 0, a1 = 0, a2 = 0;                                    // class sums of this vector
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // masks of the bytes of dword q whose class (q + b) % 3 is 0 / 1 / 2
+      const uint32_t m0 = q == 0 ? 0xFF0000FFu : q == 1 ? 0x00FF0000u : q == 2 ? 0x0000FF00u : 0xFF0000FFu;
+      const uint32_t m1 = q == 0 ? 0x0000FF00u : q == 1 ? 0xFF0000FFu : q == 2 ? 0x00FF0000u : 0x0000FF00u;
+      const uint32_t m2 = q == 0 ? 0x00FF0000u : q == 1 ? 0x0000FF00u : q == 2 ? 0xFF0000FFu : 0x00FF0000u;
+      a0 = __builtin_amdgcn_sad_u8(w[q] & m0, 0u, a0);
+      a1 = __builtin_amdgcn_sad_u8(w[q] & m1, 0u, a1);
+      a2 = __builtin_amdgcn_sad_u8(w[q] & m2, 0u, a2);
+    }
+    const uint32_t ph = v % 3;                                          // channel of the vector's first byte
+    t0 += ph == 0 ? a0 : (ph == 1 ? a2 : a1);                           // channel 0 = class (0 - ph) mod 3
+    t1 += ph == 0 ? a1 : (ph == 1 ? a0 : a2);
+    t2 += ph == 0 ? a2 : (ph == 1 ? a1 : a0);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    t0 += __shfl_xor(t0, off, 64);
+    t1 += __shfl_xor(t1, off, 64);
+    t2 += __shfl_xor(t2, off, 64);
+  }
+  __syncthreads();                                                      // ssum zeroed, image in LDS
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&ssum[0], t0);                                            // integer sums: order does not matter
+    atomicAdd(&ssum[1], t1);
+    atomicAdd(&ssum[2], t2);
+  }
+  __syncthreads();
+  if (threadIdx.x < 768) {
+    const uint32_t ch = threadIdx.x >> 8, xb = threadIdx.x & 255;
+    const double npx = (double)pixels_per_sample;
+    const double m = (double)(unsigned long long)ssum[ch] / 255.0 / npx;
+    const double x = (double)xb / 255.0;
+    const double d = x - m;
+    const double dc = d * c;
+    lut[threadIdx.x] = finish_unit(dc + m);
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * elems);
+  for (uint32_t v = threadIdx.x; v < nvec; v += kCiThreads) {
+    const uint4 p = img[v];
+    const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+    uint32_t o[4];
+    uint32_t chn = v % 3;                                               // channel of the next byte, advanced as we go
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t r = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        r |= (uint32_t)lut[chn * 256 + ((w[q] >> (8 * b)) & 0xFFu)] << (8 * b);
+        chn = chn == 2 ? 0 : chn + 1;
+      }
+      o[q] = r;
+    }
+    dst[v] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // brightness / saturate (corruptions.py:353-372): skimage rgb2hsv -> edit V or S -> hsv2rgb, fp64.
 // MODE 0: V = clip(V + p0, 0, 1);  MODE 1: S = clip(S*p0 + p1, 0, 1)
 template <int MODE>
@@ -628,6 +709,14 @@ int rart_launch_pointwise(int id, const RartCorruptArgs& a) {
       break;
     }
     case RART_CONTRAST: {
+      const size_t lds = eps + 16 + 768;
+      if (vec_ok && eps % 48 == 0 && lds <= 160 * 1024 && pixels < (1u << 24)) {
+        // one kernel, image resident in LDS; 255 * pixels < 2^32 keeps the channel sums in 32 bits
+        if (!rart_raise_dynamic_lds((const void*)k_contrast_image, lds, "contrast")) return RART_ERR_HIP;
+        hipLaunchKernelGGL(k_contrast_image, dim3(a.n), dim3(kCiThreads), lds, a.stream, a.in, a.out, (uint32_t)pixels,
+                           RartSeverity::contrast[s]);
+        break;
+      }
       const size_t need = rart_ws_pointwise(id, a.severity, a.n, a.h, a.w);
       if (!a.workspace || a.workspace_bytes < need) {
         rart_set_error("contrast: workspace of %zu bytes required", need);

@@ -18,9 +18,7 @@ struct BoxEntry {
 
 // Pillow precompute_coeffs + normalize_coeffs_8bpc for the BOX filter (support 0.5), one thread per
 // output index; double arithmetic in the same order as Resample.c.
-__global__ void k_box_table(BoxEntry* __restrict__ tab, int in_size, int out_size) {
-  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (xx >= out_size) return;
+__device__ __forceinline__ BoxEntry box_entry(int xx, int in_size, int out_size) {
   const double scale = (double)in_size / (double)out_size;
   const double fs = scale < 1.0 ? 1.0 : scale;
   const double support = 0.5 * fs;
@@ -47,7 +45,13 @@ __global__ void k_box_table(BoxEntry* __restrict__ tab, int in_size, int out_siz
     if (ww != 0.0) v = v / ww;
     e.k[x] = (int)(0.5 + v * 4194304.0);  // 1 << 22; weights are >= 0
   }
-  tab[xx] = e;
+  return e;
+}
+
+__global__ void k_box_table(BoxEntry* __restrict__ tab, int in_size, int out_size) {
+  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xx >= out_size) return;
+  tab[xx] = box_entry(xx, in_size, out_size);
 }
 
 // One separable pass.  AXIS 1: along width (in [n][h][win][3] -> out [n][h][wout][3]);
@@ -73,6 +77,133 @@ __global__ __launch_bounds__(kBlock) void k_box_pass(const uint8_t* __restrict__
     }
     acc >>= 22;
     out[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+  }
+}
+
+// ---- pixelate as ONE kernel: one workgroup per 224 x 224 image, every intermediate in LDS --------------------------------------
+// Pillow's resize is two separable passes with a uint8 intermediate (horizontal, then vertical), and pixelate resizes twice
+// (224 -> s -> 224, BOX): four passes, which round 2 ran as four launches through HBM buffers (350 us per 256-image batch, 0.03 of
+// the HBM roofline).  Here a workgroup owns an image: the input streams in three 75-row chunks through LDS (16-byte loads, the
+// next chunk requested before the current one is reduced), b1 [224][s][3], b2 [s][s][3] and b3 [s][224][3] (over b1) never leave
+// LDS, and the last pass writes whole dwords.  Same integer arithmetic per output as k_box_pass: bit-identical.
+constexpr int kPxThreads = 1024;
+constexpr int PX_HW = 224, PX_ROW = PX_HW * 3;                       // 672 bytes per image row
+constexpr int PX_SMAX = 134;                                          // int(224 * 0.6)
+constexpr int PX_TAB = 512 * (int)sizeof(BoxEntry);                   // tdown[256] | tup[256]
+constexpr int PX_B1 = PX_HW * PX_SMAX * 3;                            // 90 048: b1, later b3
+constexpr int PX_CHUNK_ROWS = 75, PX_CHUNK = PX_CHUNK_ROWS * PX_ROW;  // 50 400 B per input chunk
+constexpr int PX_R2 = PX_SMAX * PX_SMAX * 3 > PX_CHUNK ? PX_SMAX * PX_SMAX * 3 : PX_CHUNK;    // b2 / chunk buffer: 53 868
+constexpr int PX_LDS = PX_TAB + PX_B1 + ((PX_R2 + 15) / 16) * 16;
+static_assert(PX_LDS <= 160 * 1024, "pixelate: LDS budget");
+static_assert(PX_B1 % 16 == 0 && PX_CHUNK % 16 == 0 && PX_TAB % 16 == 0, "pixelate: 16-byte aligned LDS regions");
+
+__global__ __launch_bounds__(kPxThreads) void k_pixelate_image(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int s) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t px_lds[];
+  BoxEntry* const tdown = reinterpret_cast<BoxEntry*>(px_lds);
+  BoxEntry* const tup = tdown + 256;
+  uint8_t* const b1 = px_lds + PX_TAB;                                // [224][s][3]; later b3 [s][224][3]
+  uint8_t* const r2 = b1 + PX_B1;                                     // input chunk during pass 1; then b2 [s][s][3]
+  const int tid = threadIdx.x;
+  const uint8_t* img = in + (size_t)blockIdx.x * PX_HW * PX_ROW;
+  const int s3 = s * 3;
+  if (tid < s) tdown[tid] = box_entry(tid, PX_HW, s);
+  else if (tid >= 256 && tid < 256 + PX_HW) tup[tid - 256] = box_entry(tid - 256, s, PX_HW);
+
+  // ---- pass 1 (horizontal, 224 -> s) over 3 chunks of input rows; chunk k + 1 is in flight while chunk k is reduced
+  constexpr int NV = PX_CHUNK / 16;                                   // 3 150 vectors per full chunk: <= 4 per thread
+  uint4 q0, q1, q2, q3;
+  q0 = q1 = q2 = q3 = make_uint4(0, 0, 0, 0);
+#define RART_PX_FETCH(CK)                                                                                       \
+  {                                                                                                             \
+    const int r0_ = (CK)*PX_CHUNK_ROWS, rows_ = (PX_HW - r0_) < PX_CHUNK_ROWS ? (PX_HW - r0_) : PX_CHUNK_ROWS;  \
+    const int nv_ = rows_ * PX_ROW / 16;                                                                        \
+    const uint4* g_ = reinterpret_cast<const uint4*>(img + (size_t)r0_ * PX_ROW);                               \
+    if (tid < nv_) q0 = g_[tid];                                                                                \
+    if (tid + 1024 < nv_) q1 = g_[tid + 1024];                                                                  \
+    if (tid + 2048 < nv_) q2 = g_[tid + 2048];                                                                  \
+    if (tid + 3072 < nv_) q3 = g_[tid + 3072];                                                                  \
+  }
+  RART_PX_FETCH(0)
+  const int col = tid & 511, sub = tid >> 9;                          // two rows per sweep, one output column (x, c) per thread
+  const bool col_ok = col < s3;
+  BoxEntry ed;
+  int cc = 0;
+  __syncthreads();                                                    // tables visible
+  if (col_ok) { ed = tdown[col / 3]; cc = col % 3; }
+  for (int ck = 0; ck < 3; ++ck) {
+    const int r0 = ck * PX_CHUNK_ROWS, rows = (PX_HW - r0) < PX_CHUNK_ROWS ? (PX_HW - r0) : PX_CHUNK_ROWS;
+    uint4* c4 = reinterpret_cast<uint4*>(r2);
+    c4[tid] = q0;                                                     // NV = 3150 < 4096: slots past the chunk are scratch space
+    if (tid + 1024 < NV) c4[tid + 1024] = q1;
+    if (tid + 2048 < NV) c4[tid + 2048] = q2;
+    if (tid + 3072 < NV) c4[tid + 3072] = q3;
+    __syncthreads();
+    if (ck + 1 < 3) RART_PX_FETCH(ck + 1)
+    if (col_ok) {
+      for (int y = sub; y < rows; y += 2) {
+        const uint8_t* row = r2 + y * PX_ROW + ed.xmin * 3 + cc;
+        int acc = 1 << 21;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)                                  // static indices: the entry stays in registers
+          if (j < ed.n) acc += (int)row[3 * j] * ed.k[j];
+        acc >>= 22;
+        b1[(r0 + y) * s3 + col] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+      }
+    }
+    __syncthreads();                                                  // chunk consumed before the next one overwrites it
+  }
+#undef RART_PX_FETCH
+  // ---- pass 2 (vertical, 224 -> s): b2[yo][col] from b1
+  uint8_t* const b2 = r2;
+  if (col_ok) {
+    for (int yo = sub; yo < s; yo += 2) {
+      const BoxEntry e = tdown[yo];
+      const uint8_t* colp = b1 + e.xmin * s3 + col;
+      int acc = 1 << 21;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j)
+        if (j < e.n) acc += (int)colp[j * s3] * e.k[j];
+      acc >>= 22;
+      b2[yo * s3 + col] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    }
+  }
+  __syncthreads();
+  // ---- pass 3 (horizontal, s -> 224): b3[yo][x][c] over b1's memory
+  uint8_t* const b3 = b1;
+  for (int i = tid; i < s * PX_ROW; i += kPxThreads) {
+    const int yo = i / PX_ROW, cx = i - yo * PX_ROW, x = cx / 3, c = cx - x * 3;
+    const BoxEntry e = tup[x];
+    const uint8_t* row = b2 + yo * s3 + e.xmin * 3 + c;
+    int acc = 1 << 21;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < e.n) acc += (int)row[3 * j] * e.k[j];
+    acc >>= 22;
+    b3[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+  }
+  __syncthreads();
+  // ---- pass 4 (vertical, s -> 224): four output bytes (one dword) per step, coalesced stores
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(out + (size_t)blockIdx.x * PX_HW * PX_ROW);
+  for (int d = tid; d < PX_HW * (PX_ROW / 4); d += kPxThreads) {
+    const int y = d / (PX_ROW / 4), cd = d - y * (PX_ROW / 4);
+    const BoxEntry e = tup[y];
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21, a3 = 1 << 21;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j >= e.n) break;
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(b3 + (e.xmin + j) * PX_ROW + cd * 4);
+      const int k = e.k[j];
+      a0 += (int)(w & 0xFFu) * k;
+      a1 += (int)((w >> 8) & 0xFFu) * k;
+      a2 += (int)((w >> 16) & 0xFFu) * k;
+      a3 += (int)(w >> 24) * k;
+    }
+    a0 >>= 22; a1 >>= 22; a2 >>= 22; a3 >>= 22;
+    a0 = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0);
+    a1 = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1);
+    a2 = a2 < 0 ? 0 : (a2 > 255 ? 255 : a2);
+    a3 = a3 < 0 ? 0 : (a3 > 255 ? 255 : a3);
+    o32[d] = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
   }
 }
 
@@ -155,6 +286,13 @@ int rart_launch_resample(int id, const RartCorruptArgs& a) {
   if (id == RART_PIXELATE) {
     RART_CHECK_ARG(a.h == 224 && a.w == 224, "pixelate: reference hard-codes 224x224 (corruptions.py:388-389)");
     const int s = (int)(224 * kPixelate[a.severity - 1]);
+    if (s <= PX_SMAX && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 3) == 0) {
+      // one kernel, one workgroup per image, intermediates in LDS
+      if (!rart_raise_dynamic_lds((const void*)k_pixelate_image, PX_LDS, "pixelate")) return RART_ERR_HIP;
+      hipLaunchKernelGGL(k_pixelate_image, dim3(a.n), dim3(kPxThreads), PX_LDS, a.stream, a.in, a.out, s);
+      RART_CHECK_LAUNCH("pixelate");
+      return RART_OK;
+    }
     uint8_t* ws = (uint8_t*)a.workspace;
     BoxEntry* t_down = (BoxEntry*)ws;
     BoxEntry* t_up = t_down + 256;
