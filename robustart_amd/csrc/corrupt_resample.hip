@@ -203,6 +203,10 @@ __global__ __launch_bounds__(kPxThreads) void k_pixelate_image(const uint8_t* __
     a1 = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1);
     a2 = a2 < 0 ? 0 : (a2 > 255 ? 255 : a2);
     a3 = a3 < 0 ? 0 : (a3 > 255 ? 255 : a3);
+    // hipcc (ROCm 7.2) fuses "arithmetic shift + clamp to 0..255 + pack two bytes" into gfx950's v_ashr_pk_u8_i32 and then ORs
+    // bytes 2 and 3 into its result as if the upper half were zero -- on the MI355X it is not (measured: bytes 2 and 3 of every
+    // dword came out as value | garbage).  An empty asm between the clamp and the pack keeps the four values apart.
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
     o32[d] = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
   }
 }
