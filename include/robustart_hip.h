@@ -354,6 +354,19 @@ int rart_bottleneck_first_bf16(const void* x, const void* w1, const void* w2, co
                                int c_in, int c_mid, int c_out, const int* tap_dy, const int* tap_dx, int backward,
                                rart_stream_t stream);
 
+/* The FIRST Bottleneck of layer2 / layer3 -- stride 2 on the 3x3, projection shortcut -- FORWARD as one kernel
+ * (csrc/bottleneck_s2_fused.hip): out = relu(w3 . relu(w2 *s2 relu(w1 . x + b1) + b2) + wd . x[::2, ::2] + b3), b3 = conv3 bias +
+ * shortcut bias.  Supported: c_in 256 -> c_mid 128 -> c_out 512 at 56 x 56 and 512 -> 256 -> 1024 at 28 x 28 (x is h x w, out
+ * h/2 x w/2).  All four tables in fragment order: w1 = rart_pack_frag_bf16(rows c_mid, k c_in) of [c_mid][c_in]; w2 = of
+ * [c_mid][9*c_mid] with k = (r*3+s)*c_mid + c and taps (r-1, s-1); w3 = of [c_out][c_mid]; wd = of [c_out][c_in].
+ * m1 / m2 / m3 (nullable): 1-bit sign OUTPUTS of a1 [n][h][w][c_mid/8], a2 [n][h/2][w/2][c_mid/8], out [n][h/2][w/2][c_out/8].
+ * Replaces four rart_conv_igemm_bf16 launches and computes the same function (the shortcut is not rounded to bf16 on its own).
+ * Reference: Bottleneck.forward with a downsample branch inside `model(x)` of adv/attack.py:21-22, autopgd_base.py:271-289. */
+int rart_bottleneck_s2_fwd_supported(int c_in, int c_mid, int c_out, int h, int w);
+int rart_bottleneck_s2_fwd_bf16(const void* x, const void* w1, const void* w2, const void* w3, const void* wd, const float* b1,
+                                const float* b2, const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w,
+                                int c_in, int c_mid, int c_out, rart_stream_t stream);
+
 /* One identity Bottleneck at 14 x 14 (ResNet-50 layer3 blocks 1-5: c_io 1024, c_mid 256) as one kernel, ONE IMAGE PER WORKGROUP
  * (csrc/bottleneck14_fused.hip).  Same conventions as rart_bottleneck_fused_bf16 (forward / backward, biases, the three 1-bit
  * mask tensors m1 [P][c_mid/8], m2 [P][c_mid/8], m3 [P][c_io/8]), except that ALL THREE weight tables are passed in fragment order:

@@ -161,6 +161,7 @@ class ResNet50Engine:
         self.fused_bottleneck14 = True   # False: all of them as three conv launches each (cross-check)
         self.fused_bottleneck28 = True   # False: only layer2's
         self.fused_bottleneck7 = True    # False: only layer4's
+        self.fused_bottleneck_s2 = True  # False: the stride-2 first blocks of layer2 / layer3 as four conv launches in the forward (cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -208,6 +209,18 @@ class ResNet50Engine:
                         if getattr(c_, name, None) is None:
                             setattr(c_, name, torch.empty(rows * k, dtype=torch.bfloat16, device=self.device))
                         _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(c_, name)), r_, k_, sp))
+            if (ds is not None and cb.stride == 2 and cb.r == 3 and ds.stride == 2 and ds.r == 1
+                    and (ca.cin, ca.cout, cc.cout) in ((256, 128, 512), (512, 256, 1024))):
+                # stride-2 first block of layer2 / layer3 for the fused forward kernel (bottleneck_s2_fused.hip): all four tables in
+                # fragment order, conv3 + shortcut bias
+                for c_, name, rows, k in ((ca, 's2_w1', ca.cout, ca.cin), (cb, 's2_w2', cb.cout, 9 * cb.cin), (cc, 's2_w3', cc.cout, cc.cin),
+                                          (ds, 's2_wd', ds.cout, ds.cin)):
+                    if getattr(c_, name, None) is None:
+                        setattr(c_, name, torch.empty(rows * k, dtype=torch.bfloat16, device=self.device))
+                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(c_.w_fwd), _lib.ptr(getattr(c_, name)), rows, k, sp))
+                if getattr(ds, 'bias_sum', None) is None:
+                    ds.bias_sum = torch.empty_like(cc.bias)
+                torch.add(cc.bias, ds.bias, out=ds.bias_sum)
             if (ds is not None and ds.stride == 1 and ds.r == 1 and cb.stride == 1 and ca.cin == 64 and ca.cout == 64
                     and cc.cout == 256):
                 # first block of layer1 for the fused kernel: the shortcut table in fragment order, conv3 + shortcut bias
@@ -418,6 +431,31 @@ class ResNet50Engine:
             _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, hw[0], hw[1], c_io, c_mid, _cints([t[0] for t in taps]),
             _cints([t[1] for t in taps]), 1 if backward else 0, _lib.stream_ptr()))
 
+    def _s2_ok(self, ca, cb, cc, ds, xhw, n=1):
+        return (self.fused_bottleneck_s2 and ds is not None and getattr(ds, 's2_wd', None) is not None
+                and self._fits32(n, xhw, ca.cin) and self.lib.rart_bottleneck_s2_fwd_supported(ca.cin, ca.cout, cc.cout, xhw[0], xhw[1]))
+
+    def _bneck_s2(self, x, ca, cb, cc, ds, m1, m2, m3, out, B, xhw):
+        """The stride-2 first block of layer2 / layer3, forward, as one launch (csrc/bottleneck_s2_fused.hip)."""
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            prof, self.profile = self.profile, None
+            try:
+                self._bneck_s2(x, ca, cb, cc, ds, m1, m2, m3, out, B, xhw)
+            finally:
+                self.profile = prof
+            e1.record()
+            pin, pout = xhw[0] * xhw[1], xhw[0] * xhw[1] // 4
+            self.profile.append((2.0 * B * (pin * ca.cin * ca.cout + pout * (9 * cb.cin * cb.cout + cc.cin * cc.cout + ds.cin * ds.cout)),
+                                 e0, e1, 'bottleneck_s2'))
+            return
+        _lib.check(self.lib.rart_bottleneck_s2_fwd_bf16(
+            _lib.ptr(x), _lib.ptr(ca.s2_w1), _lib.ptr(cb.s2_w2), _lib.ptr(cc.s2_w3), _lib.ptr(ds.s2_wd), _lib.ptr(ca.bias),
+            _lib.ptr(cb.bias), _lib.ptr(ds.bias_sum), _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, xhw[0], xhw[1],
+            ca.cin, ca.cout, cc.cout, _lib.stream_ptr()))
+
     def _first_ok(self, ca, cb, cc, ds, xhw, n=1):
         return (self._fits32(n, xhw, cc.cout) and self.fused_bottleneck and ds is not None and getattr(ds, 'w_fwd_frag', None) is not None
                 and getattr(cb, 'w_fwd_frag', None) is not None
@@ -548,6 +586,12 @@ class ResNet50Engine:
             if (bits or not keep) and self._first_ok(ca, cb, cc, ds, xhw, B):
                 self._bneck(x, ca.w_fwd, cb.w_fwd_frag, cc.w_fwd, ca.bias, cb.bias, ds.bias_sum, sa, sb, sc, yc, B, xhw, cc.cout,
                             ca.cout, cb.fwd_taps, False, w4=ds.w_fwd_frag, c_in=ca.cin)
+                acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
+                acts['b%d_masks' % bi] = (xs, sa, sb)
+                x, xhw, xs = yc, ohw, sc
+                continue
+            if (bits or not keep) and self._s2_ok(ca, cb, cc, ds, xhw, B):
+                self._bneck_s2(x, ca, cb, cc, ds, sa, sb, sc, yc, B, xhw)
                 acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
                 acts['b%d_masks' % bi] = (xs, sa, sb)
                 x, xhw, xs = yc, ohw, sc
@@ -739,9 +783,10 @@ class ResNet50Engine:
                             ca.cout, cb.bwd[0][1], True, w4=ca.bwd[0][2], c_in=ca.cin)
                 dz = dx
                 continue
-            dzb = self._get('g_b', tuple(yb.shape))
+            # (shapes from the layer geometry: a fused forward never materialises ya / yb)
+            dzb = self._get('g_b', (B, ohw[0], ohw[1], cb.cout))
             self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb)
-            dza = self._get('g_a', tuple(ya.shape))
+            dza = self._get('g_a', (B, xhw[0], xhw[1], ca.cout))
             self._conv_bwd(cb, dzb, ohw, dza, xhw, mask=ma)
             dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
             if ds is None:

@@ -798,3 +798,93 @@ def test_fused_bottleneck14_and_28_forward_and_backward_vs_fp64(B, geo):
     # K = 1024 sums of signed values: more 1-ulp flips of the two intermediates than in the 256-channel block, and many outputs
     # near zero where "1 ulp of the reference" is tiny; the absolute bound (1 % of the scale) is the meaningful one here
     close(dx.cpu().double(), refg, 'fused block backward', frac_max=2e-2 if geo != 7 else 5e-2)
+
+
+@pytest.mark.parametrize('B,geo', [(1, 56), (3, 56), (1, 28), (2, 28)])
+def test_fused_stride2_bottleneck_forward_vs_fp64(B, geo):
+    """rart_bottleneck_s2_fwd_bf16: the stride-2 first block of layer2 (56 x 56, 256 -> 128 -> 512) and layer3 (28 x 28, 512 -> 256 ->
+    1024) with its projection shortcut as one kernel: a1 on the 16 x 16 input grid behind a 7 x 7 output tile, the 3x3 / 2 as a
+    stride in the slot -> address map, the shortcut as extra K of the last stage.  Against fp64 with bf16 rounding where the kernel
+    rounds (a1, a2, the output); the three 1-bit sign tensors against the same reference."""
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import _Conv
+    lib = _lib.load()
+    H = W = geo
+    CIN, CM, COUT = {56: (256, 128, 512), 28: (512, 256, 1024)}[geo]
+    assert lib.rart_bottleneck_s2_fwd_supported(CIN, CM, COUT, H, W)
+    assert not lib.rart_bottleneck_s2_fwd_supported(1024, 512, 2048, 14, 14)        # layer4's block: a1 image does not fit LDS
+    g = torch.Generator().manual_seed(300 + B + geo)
+
+    def mk(cin, cout, k, stride):
+        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5)
+        c = _Conv(conv, None, 'cuda')
+        c.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        return conv, c
+
+    (c1, ca), (c2, cb), (c3, cc), (c4, ds) = mk(CIN, CM, 1, 1), mk(CM, CM, 3, 2), mk(CM, COUT, 1, 1), mk(CIN, COUT, 1, 2)
+    wq = [c.weight.detach().to(torch.bfloat16).double() for c in (c1, c2, c3, c4)]
+    bq = [c.bias.cpu().double() for c in (ca, cb, cc, ds)]
+    rb = lambda t: t.to(torch.bfloat16).double()      # noqa: E731
+    sp = _lib.stream_ptr()
+
+    def frag(tab, rows, k):
+        o = torch.empty(rows * k, dtype=torch.bfloat16, device='cuda')
+        _lib.check(lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(o), rows, k, sp))
+        return o
+
+    w1, w2, w3, wd = frag(ca.w_fwd, CM, CIN), frag(cb.w_fwd, CM, 9 * CM), frag(cc.w_fwd, COUT, CM), frag(ds.w_fwd, COUT, CIN)
+    b3 = (cc.bias + ds.bias).contiguous()
+    x = _rand_bf16((B, H, W, CIN), 7, relu=True).cuda()
+    y = torch.full((B, H // 2, W // 2, COUT), float('nan'), dtype=torch.bfloat16, device='cuda')
+    s1 = torch.zeros(B, H, W, CM // 8, dtype=torch.uint8, device='cuda')
+    s2 = torch.zeros(B, H // 2, W // 2, CM // 8, dtype=torch.uint8, device='cuda')
+    s3 = torch.zeros(B, H // 2, W // 2, COUT // 8, dtype=torch.uint8, device='cuda')
+    _lib.check(lib.rart_bottleneck_s2_fwd_bf16(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(wd), _lib.ptr(ca.bias),
+                                               _lib.ptr(cb.bias), _lib.ptr(b3), _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(s3), _lib.ptr(y),
+                                               B, H, W, CIN, CM, COUT, sp))
+    xd = x.cpu().double().permute(0, 3, 1, 2)
+    a1 = rb(F.relu(F.conv2d(xd, wq[0], bq[0])))
+    a2 = rb(F.relu(F.conv2d(a1, wq[1], bq[1], stride=2, padding=1)))
+    ref = F.relu(F.conv2d(a2, wq[2], bq[2]) + F.conv2d(xd, wq[3], bq[3], stride=2)).permute(0, 2, 3, 1)
+    got = y.cpu().double()
+    assert torch.isfinite(got).all()                                   # every output position was written
+    err = (got - ref).abs()
+    ulp = ref.abs().clamp_min(2.0 ** -20) * 2.0 ** -8 + 1e-6
+    frac = (err > ulp).double().mean().item()
+    print('fused stride-2 block forward %d x %d: beyond 1 ulp %.2e of the elements, max err %.4f (scale %.2f)'
+          % (geo, geo, frac, err.max().item(), ref.abs().max().item()))
+    assert frac < 3e-3 and err.max() <= 0.01 * ref.abs().max()
+    unpack = lambda t: torch.from_numpy(np.unpackbits(t.cpu().numpy(), axis=-1, bitorder='little')).bool()      # noqa: E731
+    assert torch.equal(unpack(s3), y.cpu() > 0)
+    for s_, a, name in ((s1, a1, 'a1'), (s2, a2, 'a2')):
+        mism = (unpack(s_) != (a.permute(0, 2, 3, 1) > 0)).double().mean().item()
+        assert mism < 1e-4, (name, mism)
+    y2 = torch.empty_like(y)
+    _lib.check(lib.rart_bottleneck_s2_fwd_bf16(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(wd), _lib.ptr(ca.bias),
+                                               _lib.ptr(cb.bias), _lib.ptr(b3), None, None, None, _lib.ptr(y2), B, H, W, CIN, CM, COUT, sp))
+    assert torch.equal(y, y2)                                          # the sign outputs are optional
+
+
+def test_engine_with_and_without_the_fused_stride2_blocks(setup):
+    """Engine switch fused_bottleneck_s2: the one-kernel stride-2 blocks against the four-launch chains end to end (logits, and the
+    gradient w.r.t. the input, whose backward pass reads the sign tensors the fused forward wrote)."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(3, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    try:
+        eng.fused_bottleneck_s2 = True
+        la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        la, ga = la.clone(), ga.clone()
+        eng.fused_bottleneck_s2 = False
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.fused_bottleneck_s2 = True
+    scale = lb.abs().max().item()
+    print('fused stride-2 blocks vs chains: logits max diff %.3g of scale %.2f' % ((la - lb).abs().max().item(), scale))
+    assert (la - lb).abs().max().item() <= 2e-2 * scale          # the chain rounds the shortcut to bf16 on its own, the fused block does not
+    a, b = ga.flatten(1).double(), gb.flatten(1).double()
+    cos = (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))
+    assert (cos > 0.98).all(), cos
