@@ -75,28 +75,32 @@ __global__ __launch_bounds__(512, 1) void k_bottleneck14(const RartBneck14Desc d
   {
     // a wave-wide direct load covers 4 slots x 256 B: lane l -> slot 4 j + (l >> 4), chunk position l & 15, fetching chunk
     // (l & 15) ^ (slot & 15); instruction j of a slice = wave + 8 q, q = 0..6
-    const char* xsrc[7];
+    uint32_t xsrc[7];                                                    // byte offset from d.x (tensor < 2^31 elements), ~0u = zero page
     uint32_t xdst[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
       const int j = wave + 8 * q, slot = 4 * j + (lane >> 4);          // slot = tile * 32 + row-in-tile * 16 + column
       const int t = slot >> 5, sy = 2 * t + ((slot >> 4) & 1), sx = slot & 15;
       const int chunk = (lane & 15) ^ (slot & 15);
-      xsrc[q] = sx < B14_HW ? reinterpret_cast<const char*>(d.x + (pos0 + sy * B14_HW + sx) * B14_CIO + chunk * 8) : nullptr;
+      xsrc[q] = sx < B14_HW ? (uint32_t)(((pos0 + sy * B14_HW + sx) * B14_CIO + chunk * 8) * 2) : 0xFFFFFFFFu;
       xdst[q] = (uint32_t)__builtin_amdgcn_readfirstlane(4 * j) * 256u;
     }
 #define RART_B14_ISSUE(S, BUF)                                                                                  \
   _Pragma("unroll") for (int q = 0; q < 7; ++q) {                                                               \
-    const char* s_ = xsrc[q] ? xsrc[q] + (S)*256 : reinterpret_cast<const char*>(g_b14_zero16);                 \
+    const char* s_ = xsrc[q] != 0xFFFFFFFFu ? reinterpret_cast<const char*>(d.x) + (size_t)(xsrc[q] + (uint32_t)((S)*256))  \
+                                            : reinterpret_cast<const char*>(g_b14_zero16);                        \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,                         \
                                      (__attribute__((address_space(3))) void*)(sImg + (BUF)*B14_SLICE + xdst[q]), 16, 0, 0); \
   }
     // weights of this wave: output channels 32 wave .. +31; fragment (K step st of 64, row tile wave, ks) of the [256][1024] table
     const uint16_t* wp = d.w1 + (size_t)wave * 2048 + lane * 8;
-    bf16x8 wq[2][8];
-#define RART_B14_LOADW(S, SET)                                                                                  \
-  _Pragma("unroll") for (int f = 0; f < 8; ++f)                                                                 \
-    wq[SET][f] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((2 * (S) + (f >> 2)) * 8) * 2048 + (f & 3) * 512);
+    // weight fragments are pipelined per K STEP of 64 (two per 128-channel slice of x), one step ahead: four fragments per set.
+    // (Round 2 prefetched a whole slice -- eight fragments per set, 64 VGPRs -- which put the stage at the 256-register cap with
+    // 6 / 10 spilled registers; half a slice, 28 MFMAs, still covers the L2 round trip.)
+    bf16x8 wq[2][4];
+#define RART_B14_LOADW(A, SET)                                                                                  \
+  _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                                 \
+    wq[SET][f] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((A) * 8) * 2048 + f * 512);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -114,19 +118,23 @@ __global__ __launch_bounds__(512, 1) void k_bottleneck14(const RartBneck14Desc d
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int buf = s & 1;
-      if (s + 1 < 8) {
-        RART_B14_ISSUE(s + 1, buf ^ 1)
-        if (buf) { RART_B14_LOADW(s + 1, 0) } else { RART_B14_LOADW(s + 1, 1) }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < 8) RART_B14_ISSUE(s + 1, buf ^ 1)
       const uint8_t* xb = sImg + buf * B14_SLICE + xrow;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const uint32_t co = ((uint32_t)(2 * ks + h) ^ xsw) << 4;
+      for (int half = 0; half < 2; ++half) {
+        const int a = 2 * s + half;                        // K step of 64 channels; its fragments sit in set a & 1
+        if (a + 1 < 16) {
+          if (a & 1) { RART_B14_LOADW(a + 1, 0) } else { RART_B14_LOADW(a + 1, 1) }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < B14_MT; ++t) {
-          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(xb + t * 32 * 256 + co);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[buf][ks], pf, acc[t], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint32_t co = ((uint32_t)(2 * (4 * half + ks) + h) ^ xsw) << 4;
+#pragma unroll
+          for (int t = 0; t < B14_MT; ++t) {
+            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(xb + t * 32 * 256 + co);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[a & 1][ks], pf, acc[t], 0, 0, 0);
+          }
         }
       }
       __builtin_amdgcn_s_waitcnt(0);        // the next slice (and the next weights) have landed
@@ -177,12 +185,9 @@ __global__ __launch_bounds__(512, 1) void k_bottleneck14(const RartBneck14Desc d
   RART_B14_SIGN_IMG(d.m1)
 
   // ================================ stage B: a2 = 3x3 over the a1 image (k_conv3x3_image256's loop, operands swapped) ==========
-  uint32_t abase[B14_MT];
-#pragma unroll
-  for (int t = 0; t < B14_MT; ++t) {
-    const int y = 2 * t + prow, xc = px < B14_HW ? px : B14_HW - 1;       // padding slots read a valid position; never stored
-    abase[t] = (uint32_t)(((y + 1) * 16 + xc + 1) * 16 + h * B14_PLANE);
-  }
+  // position tile t reads the image at abase0 + t * 512 (two image rows = 32 slots of 16 B further down): one register, the tile
+  // offset is an immediate (an array of seven bases cost six more VGPRs at the 256-register cap)
+  const uint32_t abase0 = (uint32_t)(((prow + 1) * 16 + (px < B14_HW ? px : B14_HW - 1) + 1) * 16 + h * B14_PLANE);   // padding slots read a valid position; never stored
   {
     const uint16_t* wp = d.w2 + wave * 2048 + lane * 8;                    // fragment (st, wave, ks): (st * 8 + wave) * 4 + ks
     bf16x8 bq[2][4];
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void k_bottleneck14(const RartBneck14Desc d
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int t = 0; t < B14_MT; ++t) {
-          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sImg + (int)abase[t] + toff + (kh * 8 + ks * 2) * B14_PLANE);
+          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sImg + (int)abase0 + t * 512 + toff + (kh * 8 + ks * 2) * B14_PLANE);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[st & 1][ks], pf, acc[t], 0, 0, 0);
         }
       }
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void k_bottleneck14(const RartBneck14Desc d
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int t = 0; t < B14_MT; ++t) {
-          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sImg + (int)abase[t] + (st * 8 + ks * 2) * B14_PLANE);
+          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sImg + (int)abase0 + t * 512 + (st * 8 + ks * 2) * B14_PLANE);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[st & 1][ks], pf, acc[t], 0, 0, 0);
         }
       }
@@ -265,12 +270,12 @@ __global__ __launch_bounds__(512, 1) void k_bottleneck14(const RartBneck14Desc d
     for (int t = 0; t < B14_MT; ++t) {
       u32x4 rv[2];
       uint32_t mb[2];
-      long long eoff[2];
+      int eoff[2];                                          // element offsets: the host guarantees the tensor stays below 2^31 elements
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int v = q * 16 + rw;                          // valid-slot index 0..27
         const int vy = v >= B14_HW ? 1 : 0, vx = v - vy * B14_HW;
-        eoff[q] = v < 28 ? (pos0 + (2 * t + vy) * B14_HW + vx) * B14_CIO + ch0 + cw * 8 : -1;
+        eoff[q] = v < 28 ? (int)((pos0 + (2 * t + vy) * B14_HW + vx) * B14_CIO) + ch0 + cw * 8 : -1;
         rv[q] = (u32x4){0u, 0u, 0u, 0u};
         mb[q] = 0xFFu;
         if (eoff[q] >= 0) {

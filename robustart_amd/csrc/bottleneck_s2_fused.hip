@@ -179,9 +179,14 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
       abase[t] = (uint32_t)(((2 * rc + 1) * 16 + 2 * cc + 1) * 16 + h * S2_PLANE);
     }
     const uint16_t* wp = d.w2 + (size_t)wave * 2048 + lane * 8;              // fragment (st, wave, ks): (st * NW + wave) * 4 + ks
-    bf16x8 bq[2][4];
+    // three register sets: the fragments of step st + 2 are requested before the MFMAs of step st (a step is only 8 MFMAs per
+    // wave -- one step of cover is shorter than an L2 round trip)
+    bf16x8 bq[3][4];
+    constexpr int KH = CM / 64, NSB = 9 * KH;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bq[0][ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
+    for (int s0 = 0; s0 < 2; ++s0)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bq[s0][ks] = *reinterpret_cast<const bf16x8*>(wp + (size_t)s0 * NW * 2048 + ks * 512);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -191,14 +196,13 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = bv[i];
     }
-    constexpr int KH = CM / 64, NSB = 9 * KH;
 #pragma unroll
     for (int st = 0; st < NSB; ++st) {
       const int tap = st / KH, kh = st - tap * KH;
-      if (st + 1 < NSB) {
+      if (st + 2 < NSB) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-          bq[(st + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(st + 1) * NW * 2048 + ks * 512);
+          bq[(st + 2) % 3][ks] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(st + 2) * NW * 2048 + ks * 512);
       }
       __builtin_amdgcn_sched_barrier(0);                    // keep the prefetch ahead of this step's MFMAs
       const int toff = ((tap / 3 - 1) * 16 + (tap % 3 - 1)) * 16;        // tap (dy, dx) = (tap / 3 - 1, tap % 3 - 1)
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sImg + (int)abase[t] + toff + (kh * 8 + ks * 2) * S2_PLANE);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[st & 1][ks], pf, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[st % 3][ks], pf, acc[t], 0, 0, 0);
         }
       }
     }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
       xc[t] = d.x + (ipos0 + (long long)(2 * (oy0 + rc)) * HIN + 2 * (ox0 + cc)) * CIN + h * 8;
     }
     const uint16_t* wp = d.wd + (size_t)wave * 2048 + lane * 8;              // fragment (st, rd * NW + wave, ks)
-    bf16x8 xq[2][2], wq[2][4];
+    bf16x8 xq[3][2], wq[3][4];                                               // three sets: two groups (16 MFMAs) of cover
 #define RART_S2_LOADG(G, SET)                                                                                   \
   {                                                                                                             \
     const int st_ = (G) >> 2, ks_ = (G)&3;                                                                      \
@@ -265,17 +269,18 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
       wq[SET][rd] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)st_ * RT + rd * NW) * 2048 + ks_ * 512);     \
   }
     RART_S2_LOADG(0, 0)
+    RART_S2_LOADG(1, 1)
 #pragma unroll
     for (int gidx = 0; gidx < KA * 4; ++gidx) {
-      if (gidx + 1 < KA * 4) {
-        if (gidx & 1) { RART_S2_LOADG(gidx + 1, 0) } else { RART_S2_LOADG(gidx + 1, 1) }
+      if (gidx + 2 < KA * 4) {
+        if ((gidx + 2) % 3 == 0) { RART_S2_LOADG(gidx + 2, 0) } else if ((gidx + 2) % 3 == 1) { RART_S2_LOADG(gidx + 2, 1) } else { RART_S2_LOADG(gidx + 2, 2) }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rd = 0; rd < 4; ++rd)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          acc[rd][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[gidx & 1][rd], xq[gidx & 1][t], acc[rd][t], 0, 0, 0);
+          acc[rd][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[gidx % 3][rd], xq[gidx % 3][t], acc[rd][t], 0, 0, 0);
     }
 #undef RART_S2_LOADG
   }
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
     // ---- W3 . a2: positions operand from the a2 planes in LDS (slot t * 32 + p32)
     const uint16_t* wp = d.w3 + (size_t)wave * 2048 + lane * 8;
     const uint32_t abase = (uint32_t)(p32 * 16 + h * S2_PLANE);
-    bf16x8 wq[2][4];
+    bf16x8 wq[3][4];
 #define RART_S2_LOADW3(G, SET)                                                                                  \
   {                                                                                                             \
     const int st_ = (G) >> 2, ks_ = (G)&3;                                                                      \
@@ -291,11 +296,12 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
       wq[SET][rd] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)st_ * RT + rd * NW) * 2048 + ks_ * 512);    \
   }
     RART_S2_LOADW3(0, 0)
+    RART_S2_LOADW3(1, 1)
     constexpr int NG = (CM / 64) * 4;
 #pragma unroll
     for (int gidx = 0; gidx < NG; ++gidx) {
-      if (gidx + 1 < NG) {
-        if (gidx & 1) { RART_S2_LOADW3(gidx + 1, 0) } else { RART_S2_LOADW3(gidx + 1, 1) }
+      if (gidx + 2 < NG) {
+        if ((gidx + 2) % 3 == 0) { RART_S2_LOADW3(gidx + 2, 0) } else if ((gidx + 2) % 3 == 1) { RART_S2_LOADW3(gidx + 2, 1) } else { RART_S2_LOADW3(gidx + 2, 2) }
       }
       __builtin_amdgcn_sched_barrier(0);
       const int st = gidx >> 2, ks = gidx & 3;
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
         const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sImg + abase + t * 32 * 16 + (st * 8 + ks * 2) * S2_PLANE);
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd)
-          acc[rd][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[gidx & 1][rd], pf, acc[rd][t], 0, 0, 0);
+          acc[rd][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[gidx % 3][rd], pf, acc[rd][t], 0, 0, 0);
       }
     }
 #undef RART_S2_LOADW3

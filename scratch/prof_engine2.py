@@ -1,7 +1,7 @@
 """Per-launch table of one ResNet-50 gradient evaluation (forward + backward-to-input) at B = 256: every igemm launch with
 its algorithmic FLOPs and HBM bytes, the measured time (events on the launch stream) and the roofline floor
-max(FLOPs / 2.5 PFLOP/s, bytes / 8 TB/s).  Output -> profiles/r02_igemm_per_shape.txt."""
-import sys; sys.path.insert(0, '/root/repo')
+max(FLOPs / 2.5 PFLOP/s, bytes / 8 TB/s).  Output -> profiles/r0N_igemm_per_shape.txt."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, torch
 from robustart_amd.model import get_model
 from robustart_amd.model.engine import ResNet50Engine
@@ -60,8 +60,19 @@ def wrapped_b14(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid
     e0.record(); r = orig_b14(x_, w1, w2, w3, b1, b2, b3, m1, m2, m3, out, B_, hw, c_io, c_mid, taps, backward, fn); e1.record()
     rows.append(((M, 2 * c_io + 9 * c_mid, c_mid, {14: 97, 28: 96, 7: 95}[hw[0]]), 2.0 * M * c_mid * (2 * c_io + 9 * c_mid), by, e0, e1))   # taps column 97 / 96 = fused layer3 / layer2 block
     return r
+orig_s2 = eng._bneck_s2
+def wrapped_s2(x_, ca, cb, cc, ds, m1, m2, m3, out, B_, xhw):
+    pin, pout = B_ * xhw[0] * xhw[1], B_ * xhw[0] * xhw[1] // 4
+    fl = 2.0 * (pin * ca.cin * ca.cout + pout * (9 * cb.cin * cb.cout + cc.cin * cc.cout + ds.cin * ds.cout))
+    by = pin * ca.cin * 2 + pout * cc.cout * 2 + (ca.cin * ca.cout + 9 * cb.cin * cb.cout + cc.cin * cc.cout + ds.cin * ds.cout) * 2 + \
+        sum(n_ * c * 0.125 for n_, c, m_ in ((pin, ca.cout, m1), (pout, cb.cout, m2), (pout, cc.cout, m3)) if m_ is not None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r = orig_s2(x_, ca, cb, cc, ds, m1, m2, m3, out, B_, xhw); e1.record()
+    rows.append(((pout, ca.cin * 4 + 9 * cb.cin + cc.cin + ds.cin, cc.cout, 94), fl, by, e0, e1))   # taps column 94 = fused stride-2 block (forward)
+    return r
 for _ in range(2): eng.forward_backward(x, MEAN, STD, y, 0)
 eng._bneck14 = wrapped_b14
+eng._bneck_s2 = wrapped_s2
 eng._gemm = wrapped
 eng._halo = wrapped_halo
 eng._bneck = wrapped_bneck
@@ -73,6 +84,7 @@ eng._gemm = orig
 eng._halo = orig_halo
 eng._bneck = orig_bneck
 eng._bneck14 = orig_b14
+eng._bneck_s2 = orig_s2
 agg = {}
 for key, fl, by, a, b in rows:
     us = a.elapsed_time(b) * 1e3
@@ -83,7 +95,7 @@ for key, (us, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     floor = max(fl / PEAK_F, by / PEAK_B) * 1e6
     tot += us; totf += floor
     print('%9d %6d %6d %4d %4d %9.1f %8.1f %8.1f %9.1f %6.3f' % (*key, cnt, us, fl / us / 1e6, by / us / 1e3, floor, floor / us))
-print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 / 95 = the fused Bottleneck kernels of layer1 / layer3 / layer2 / layer4: one row = 1x1 + 3x3 + 1x1)')
+print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 / 95 = the fused Bottleneck kernels of layer1 / layer3 / layer2 / layer4: one row = 1x1 + 3x3 + 1x1; 94 = the fused stride-2 first blocks of layer2 / layer3, forward)')
 print('conv launches %d: measured %.1f us, roofline floor %.1f us, fraction of the per-layer floor %.3f' %
       (len(rows), tot, totf, totf / tot))
 for name, fn in (('fwd+bwd', lambda: eng.forward_backward(x, MEAN, STD, y, 0)), ('fwd', lambda: eng.logits(x, MEAN, STD))):
