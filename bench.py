@@ -197,12 +197,11 @@ def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
 one_step.extra = {}
 
 
-def measure_gaussian_roofline(B, device, launches=40):
+def measure_gaussian_roofline(B, device, launches=40, npairs=9):
     """HBM roofline of the dominant hand-written kernel of the corruption half
     (k_normal_noise_native<0>): rotate > 600 MB of distinct buffer pairs so the 256 MiB Infinity
     Cache cannot serve the stream, time with events on the launch stream."""
     from robustart_amd.noise import imagenet_c as C
-    npairs = 9
     g = torch.Generator().manual_seed(7)
     src = [torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(device) for _ in range(npairs)]
     dst = [torch.empty_like(s) for s in src]
@@ -721,6 +720,11 @@ def main():
                                                           'kernel_vs_copy': copy_s / avg,
                                                           'note': 'torch Tensor.copy_ over the same 9 rotating buffer pairs: the read+write '
                                                                   'rate this part sustains at this size'}}
+            # the same kernel on a 4x larger launch (B = 1024 by default, 3 rotating pairs = 925 MB): how much of the B = 256 gap to the peak is
+            # launch ramp / tail of a 18 us kernel rather than the steady-state rate
+            avg4, med4, copy4 = measure_gaussian_roofline(4 * B, device, launches=12, npairs=3)
+            out['roofline']['at_4x_batch'] = {'batch': 4 * B, 'avg_launch_us': avg4 * 1e6, 'achieved': 4 * algo / avg4 / 1e9, 'unit': 'GB/s',
+                                                'frac': 4 * algo / avg4 / HBM_PEAK, 'device_copy_frac_of_peak': 4 * algo / copy4 / HBM_PEAK}
             out['hbm_roofline_gaussian_noise'] = out.pop('roofline')
             step_flops = (5 + 15) * B * FLOP_FWD
             out['step_mfma'] = {'achieved': step_flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
