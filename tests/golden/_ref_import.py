@@ -24,7 +24,8 @@ def import_reference_noise():
     for m in stub:
         if m not in sys.modules:
             sys.modules[m] = unittest.mock.MagicMock()
-    sys.modules['wand.image'].Image = type('W', (), {})
+    if isinstance(sys.modules['wand.image'], unittest.mock.MagicMock):      # (a shim installed before this call keeps its Image class)
+        sys.modules['wand.image'].Image = type('W', (), {})
     if not hasattr(numpy, 'float_'):
         numpy.float_ = numpy.float64
     torch.Tensor.cuda = lambda self, *a, **k: self

@@ -1,7 +1,7 @@
-"""Golden vectors "pinned modulo shim": the UNMODIFIED reference functions impulse_noise, gaussian_blur, glass_blur, spatter
-(severities 4-5, the mud branch), brightness and saturate (RobustART/noise/utils/imagenet_c/corruptions.py) run with the
-three scikit-image entry points they call supplied by tests/golden/skimage_shim.py (scikit-image itself is not installed;
-every other absent wheel stays a MagicMock and is not touched by these functions).
+"""Golden vectors "pinned modulo shim": the UNMODIFIED reference functions impulse_noise, gaussian_blur, glass_blur, spatter,
+brightness, saturate, defocus_blur, motion_blur, snow and elastic_transform (RobustART/noise/utils/imagenet_c/corruptions.py) run
+with the scikit-image entry points they call supplied by tests/golden/skimage_shim.py and the OpenCV / ImageMagick entry points by
+tests/golden/cv2_wand_shim.py (none of the three libraries is installed).
 
 Run in the build container only:   python tests/golden/make_golden_shim.py
 Output: tests/golden/corruptions_shim_ref.npz -- sha256 of the full uint8 output + a 64 x 64 crop per (name, severity),
@@ -19,9 +19,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import skimage_shim  # noqa: E402
+import cv2_wand_shim  # noqa: E402
 
 skimage_shim.install(sys.modules)
+cv2_wand_shim.install(sys.modules)
+if True:                                                  # numpy 2 made the binary mode of fromstring an error-level warning;
+    np.fromstring = lambda s, dtype=float, **k: np.frombuffer(s, dtype=dtype)      # noqa: E731  the reference decodes PNG blobs with it
 from _ref_import import import_reference_noise  # noqa: E402
 
 import_reference_noise()
@@ -30,7 +35,10 @@ from RobustART.noise.utils.imagenet_c import corrupt as ref_corrupt  # noqa: E40
 from _inputs import make_image, case_seed  # noqa: E402
 
 CASES = [('impulse_noise', (1, 2, 3, 4, 5)), ('gaussian_blur', (1, 2, 3, 4, 5)), ('glass_blur', (1, 2, 3, 4, 5)),
-         ('spatter', (4, 5)), ('brightness', (1, 2, 3, 4, 5)), ('saturate', (1, 2, 3, 4, 5))]
+         ('spatter', (1, 2, 3, 4, 5)), ('brightness', (1, 2, 3, 4, 5)), ('saturate', (1, 2, 3, 4, 5)),
+         # with the OpenCV / ImageMagick calls supplied by cv2_wand_shim.py (which forwards to the oracle's restatements):
+         ('defocus_blur', (1, 2, 3, 4, 5)), ('motion_blur', (1, 2, 3, 4, 5)), ('snow', (1, 2, 3, 4, 5)),
+         ('elastic_transform', (1, 2, 3, 4, 5))]
 
 
 def sha(a):

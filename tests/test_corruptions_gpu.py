@@ -90,8 +90,9 @@ def test_hip_matches_reference_golden_crops():
 
 
 SHIM_CASES = [(n, s) for n, sevs in (('impulse_noise', (1, 2, 3, 4, 5)), ('gaussian_blur', (1, 2, 3, 4, 5)),
-                                     ('glass_blur', (1, 2, 3, 4, 5)), ('spatter', (4, 5)), ('brightness', (1, 2, 3, 4, 5)),
-                                     ('saturate', (1, 2, 3, 4, 5))) for s in sevs]
+                                     ('glass_blur', (1, 2, 3, 4, 5)), ('spatter', (1, 2, 3, 4, 5)), ('brightness', (1, 2, 3, 4, 5)),
+                                     ('saturate', (1, 2, 3, 4, 5)), ('defocus_blur', (1, 2, 3, 4, 5)), ('motion_blur', (1, 2, 3, 4, 5)),
+                                     ('snow', (1, 2, 3, 4, 5)), ('elastic_transform', (1, 2, 3, 4, 5))) for s in sevs]
 
 
 @pytest.mark.parametrize('name,sev', SHIM_CASES)

@@ -306,12 +306,15 @@ def test_apgd_l1_largereps_matches_reference(gold_a, gold_l1):
     np.testing.assert_allclose(adv.numpy(), gold_l1['largereps/ce/adv'], atol=2e-6)
 
 
-# ---- "pinned modulo shim": unmodified reference functions with scikit-image's three entry points supplied by
-#      tests/golden/skimage_shim.py (tests/golden/make_golden_shim.py) -----------------------------------------------------------
+# ---- "pinned modulo shim": unmodified reference functions with scikit-image's entry points supplied by tests/golden/skimage_shim.py
+#      and the OpenCV / ImageMagick ones by tests/golden/cv2_wand_shim.py (which forwards to the oracle's own restatements of those
+#      primitives, so for defocus / motion / snow / elastic / spatter 1-3 the COMPOSITION is what is pinned: parameter tables, the
+#      order and shapes of the np.random draws, BGR / RGB flips, blends, clipping) -- tests/golden/make_golden_shim.py ------------
 
 SHIM_CASES = [(n, s) for n, sevs in (('impulse_noise', (1, 2, 3, 4, 5)), ('gaussian_blur', (1, 2, 3, 4, 5)),
-                                     ('glass_blur', (1, 2, 3, 4, 5)), ('spatter', (4, 5)), ('brightness', (1, 2, 3, 4, 5)),
-                                     ('saturate', (1, 2, 3, 4, 5))) for s in sevs]
+                                     ('glass_blur', (1, 2, 3, 4, 5)), ('spatter', (1, 2, 3, 4, 5)), ('brightness', (1, 2, 3, 4, 5)),
+                                     ('saturate', (1, 2, 3, 4, 5)), ('defocus_blur', (1, 2, 3, 4, 5)), ('motion_blur', (1, 2, 3, 4, 5)),
+                                     ('snow', (1, 2, 3, 4, 5)), ('elastic_transform', (1, 2, 3, 4, 5))) for s in sevs]
 
 
 @pytest.fixture(scope='module')
