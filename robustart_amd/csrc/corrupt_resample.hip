@@ -140,14 +140,24 @@ __global__ __launch_bounds__(kPxThreads) void k_pixelate_image(const uint8_t* __
     __syncthreads();
     if (ck + 1 < 3) RART_PX_FETCH(ck + 1)
     if (col_ok) {
-      for (int y = sub; y < rows; y += 2) {
-        const uint8_t* row = r2 + y * PX_ROW + ed.xmin * 3 + cc;
-        int acc = 1 << 21;
+      // four outputs per sweep, all their LDS reads issued before the first store (byte stores into LDS would otherwise order
+      // every read behind them: the chain of dependent ds_read latencies was most of round 3's first version)
+      for (int y = sub; y < rows; y += 8) {
+        int acc[4];
 #pragma unroll
-        for (int j = 0; j < KMAX; ++j)                                  // static indices: the entry stays in registers
-          if (j < ed.n) acc += (int)row[3 * j] * ed.k[j];
-        acc >>= 22;
-        b1[(r0 + y) * s3 + col] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+        for (int u = 0; u < 4; ++u) {
+          const int yu = y + 2 * u < rows ? y + 2 * u : y;
+          const uint8_t* row = r2 + yu * PX_ROW + ed.xmin * 3 + cc;
+          acc[u] = 1 << 21;
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j)                                // static indices: the entry stays in registers
+            if (j < ed.n) acc[u] += (int)row[3 * j] * ed.k[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int a = acc[u] >> 22;
+          if (y + 2 * u < rows) b1[(r0 + y + 2 * u) * s3 + col] = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
+        }
       }
     }
     __syncthreads();                                                  // chunk consumed before the next one overwrites it
@@ -156,30 +166,45 @@ __global__ __launch_bounds__(kPxThreads) void k_pixelate_image(const uint8_t* __
   // ---- pass 2 (vertical, 224 -> s): b2[yo][col] from b1
   uint8_t* const b2 = r2;
   if (col_ok) {
-    for (int yo = sub; yo < s; yo += 2) {
-      const BoxEntry e = tdown[yo];
-      const uint8_t* colp = b1 + e.xmin * s3 + col;
-      int acc = 1 << 21;
+    for (int yo = sub; yo < s; yo += 8) {
+      int acc[4];
 #pragma unroll
-      for (int j = 0; j < KMAX; ++j)
-        if (j < e.n) acc += (int)colp[j * s3] * e.k[j];
-      acc >>= 22;
-      b2[yo * s3 + col] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+      for (int u = 0; u < 4; ++u) {
+        const BoxEntry e = tdown[yo + 2 * u < s ? yo + 2 * u : yo];
+        const uint8_t* colp = b1 + e.xmin * s3 + col;
+        acc[u] = 1 << 21;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (j < e.n) acc[u] += (int)colp[j * s3] * e.k[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = acc[u] >> 22;
+        if (yo + 2 * u < s) b2[(yo + 2 * u) * s3 + col] = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
+      }
     }
   }
   __syncthreads();
   // ---- pass 3 (horizontal, s -> 224): b3[yo][x][c] over b1's memory
   uint8_t* const b3 = b1;
-  for (int i = tid; i < s * PX_ROW; i += kPxThreads) {
-    const int yo = i / PX_ROW, cx = i - yo * PX_ROW, x = cx / 3, c = cx - x * 3;
-    const BoxEntry e = tup[x];
-    const uint8_t* row = b2 + yo * s3 + e.xmin * 3 + c;
-    int acc = 1 << 21;
+  for (int i0 = tid; i0 < s * PX_ROW; i0 += 4 * kPxThreads) {
+    int acc[4];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j < e.n) acc += (int)row[3 * j] * e.k[j];
-    acc >>= 22;
-    b3[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kPxThreads < s * PX_ROW ? i0 + u * kPxThreads : i0;
+      const int yo = i / PX_ROW, cx = i - yo * PX_ROW, x = cx / 3, c = cx - x * 3;
+      const BoxEntry e = tup[x];
+      const uint8_t* row = b2 + yo * s3 + e.xmin * 3 + c;
+      acc[u] = 1 << 21;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j)
+        if (j < e.n) acc[u] += (int)row[3 * j] * e.k[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int a = acc[u] >> 22;
+      if (i0 + u * kPxThreads < s * PX_ROW) b3[i0 + u * kPxThreads] = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
+    }
   }
   __syncthreads();
   // ---- pass 4 (vertical, s -> 224): four output bytes (one dword) per step, coalesced stores
