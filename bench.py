@@ -232,9 +232,13 @@ def measure_gaussian_roofline(B, device, launches=40, npairs=9):
 
 def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r02_pmc_traffic.json, produced by profiles/summarize_pmc.py); None if absent."""
+    (profiles/r03_pmc_traffic.json, else r02; produced by profiles/summarize_pmc.py); None if absent."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+        path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        pmc_traffic.source = os.path.basename(path)
+        with open(path) as f:
             d = json.load(f)
         if key == 'igemm':
             return d['k_conv_igemm_bf16_all']['hbm_bytes']
@@ -264,8 +268,8 @@ def measure_igemm_roofline(path, images, labels):
     out = {'kernel': 'k_conv_igemm_bf16 (ResNet-50 forward + backward-to-input, B=256, %d launches)' % len(ig),
            'bound': 'mfma', 'achieved': flops / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
            'frac': flops / secs / MFMA_BF16_PEAK, 'traffic': pmc_traffic('igemm'),
-           'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/r02_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 '
-                           '(gfx950 correction) + WRITE_SIZE, KiB units), not re-measured in this run',
+           'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s (rocprofv3 FETCH_SIZE x2 '
+                           '(gfx950 correction) + WRITE_SIZE, KiB units), not re-measured in this run' % getattr(pmc_traffic, 'source', '?'),
            'avg_launch_us': secs / len(ig) * 1e6, 'launches': len(ig),
            'algorithmic_flops_per_launch': flops / len(ig), 'kernel_seconds_per_fwd_bwd': secs}
     if out['traffic']:
@@ -711,8 +715,8 @@ def main():
             out['roofline'] = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, B=256, u8 NHWC in/out)',
                                'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
                                'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': pmc_traffic('k_normal_noise_mfma'),
-                               'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/r02_pmc_traffic.json '
-                                               '(FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run',
+                               'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s '
+                                               '(FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run' % getattr(pmc_traffic, 'source', '?'),
                                'avg_launch_us': avg * 1e6, 'median_launch_us': med * 1e6,
                                'algorithmic_bytes_per_launch': algo,
                                'device_copy_same_bytes': {'avg_launch_us': copy_s * 1e6, 'achieved': algo / copy_s / 1e9, 'unit': 'GB/s',
