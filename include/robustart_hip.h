@@ -367,6 +367,19 @@ int rart_bottleneck_s2_fwd_bf16(const void* x, const void* w1, const void* w2, c
                                 const float* b2, const float* b3, void* m1, void* m2, void* m3, void* out, int n, int h, int w,
                                 int c_in, int c_mid, int c_out, rart_stream_t stream);
 
+/* The backward-to-input of the same stride-2 blocks as one kernel:
+ *   dx = m0 . ( w1t . ( m1 . ( w2t *s2^T ( m2 . ( w3t . g ) ) ) ) + wdt . g [at even / even input positions] ),
+ * g = bf16 gradient at the block output [n][h/2][w/2][c_out] (already masked by that output's ReLU), dx [n][h][w][c_in].
+ * Tables in fragment order (rart_pack_frag_bf16): w3t = conv3's transposed table [c_mid][c_out]; w1t = conv1's [c_in][c_mid];
+ * wdt = the shortcut's [c_in][c_out]; w2t = the four input-parity-class tables of the 3x3 / 2's transpose, class order (0,0) (0,1)
+ * (1,0) (1,1), class (ph, pw) = [c_mid][ntaps * c_mid] with k = tap * c_mid + c and its taps = the filter taps (r, s) with
+ * (ph + 1 - r), (pw + 1 - s) even, r then s ascending (1 / 2 / 2 / 4 taps), each packed on its own and concatenated (element offsets
+ * 0, 1, 3, 5 times c_mid^2).  m2 / m1 / m0: the 1-bit sign tensors of a2 / a1 / the block input written by the forward (m0 nullable).
+ * Replaces seven rart_conv_igemm_bf16 launches.  Reference: autograd of the same Bottleneck (adv/attack.py:21-22). */
+int rart_bottleneck_s2_bwd_bf16(const void* g, const void* w3t, const void* w2t, const void* w1t, const void* wdt, const void* m2,
+                                const void* m1, const void* m0, void* dx, int n, int h, int w, int c_in, int c_mid, int c_out,
+                                rart_stream_t stream);
+
 /* One identity Bottleneck at 14 x 14 (ResNet-50 layer3 blocks 1-5: c_io 1024, c_mid 256) as one kernel, ONE IMAGE PER WORKGROUP
  * (csrc/bottleneck14_fused.hip).  Same conventions as rart_bottleneck_fused_bf16 (forward / backward, biases, the three 1-bit
  * mask tensors m1 [P][c_mid/8], m2 [P][c_mid/8], m3 [P][c_io/8]), except that ALL THREE weight tables are passed in fragment order:

@@ -77,6 +77,7 @@ SIGNATURES = {
                                             c_void_p]),
     'rart_bottleneck_s2_fwd_supported': (c_int, [c_int] * 5),
     'rart_bottleneck_s2_fwd_bf16': (c_int, [c_void_p] * 12 + [c_int] * 6 + [c_void_p]),
+    'rart_bottleneck_s2_bwd_bf16': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p]),
     'rart_bottleneck14_fused_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rart_bottleneck14_fused_bf16': (c_int, [c_void_p] * 11 + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
                                              c_void_p]),

@@ -162,6 +162,7 @@ class ResNet50Engine:
         self.fused_bottleneck28 = True   # False: only layer2's
         self.fused_bottleneck7 = True    # False: only layer4's
         self.fused_bottleneck_s2 = True  # False: the stride-2 first blocks of layer2 / layer3 as four conv launches in the forward (cross-check)
+        self.fused_bottleneck_s2_bwd = True   # False: their backward-to-input as seven conv launches (cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -221,6 +222,21 @@ class ResNet50Engine:
                 if getattr(ds, 'bias_sum', None) is None:
                     ds.bias_sum = torch.empty_like(cc.bias)
                 torch.add(cc.bias, ds.bias, out=ds.bias_sum)
+                # ... and the backward kernel's: transposed tables of conv3 / conv1 / the shortcut, and the four input-parity-class
+                # tables of the 3x3 / 2 (1 / 2 / 2 / 4 taps) packed one by one into a single buffer
+                cm = ca.cout
+                for c_, name, tab, rows, k in ((cc, 's2_w3t', cc.bwd[0][2], cm, cc.cout), (ca, 's2_w1t', ca.bwd[0][2], ca.cin, cm),
+                                               (ds, 's2_wdt', ds.bwd[0][2], ds.cin, ds.cout)):
+                    if getattr(c_, name, None) is None:
+                        setattr(c_, name, torch.empty(rows * k, dtype=torch.bfloat16, device=self.device))
+                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(c_, name)), rows, k, sp))
+                if getattr(cb, 's2_w2t', None) is None:
+                    cb.s2_w2t = torch.empty(9 * cm * cm, dtype=torch.bfloat16, device=self.device)
+                off = 0
+                for (_, taps, tab) in cb.bwd:                  # parity classes (0,0) (0,1) (1,0) (1,1)
+                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(cb.s2_w2t[off:]), cm, len(taps) * cm, sp))
+                    off += len(taps) * cm * cm
+                assert off == 9 * cm * cm
             if (ds is not None and ds.stride == 1 and ds.r == 1 and cb.stride == 1 and ca.cin == 64 and ca.cout == 64
                     and cc.cout == 256):
                 # first block of layer1 for the fused kernel: the shortcut table in fragment order, conv3 + shortcut bias
@@ -455,6 +471,26 @@ class ResNet50Engine:
             _lib.ptr(x), _lib.ptr(ca.s2_w1), _lib.ptr(cb.s2_w2), _lib.ptr(cc.s2_w3), _lib.ptr(ds.s2_wd), _lib.ptr(ca.bias),
             _lib.ptr(cb.bias), _lib.ptr(ds.bias_sum), _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(out), B, xhw[0], xhw[1],
             ca.cin, ca.cout, cc.cout, _lib.stream_ptr()))
+
+    def _bneck_s2_bwd(self, g, ca, cb, cc, ds, m2, m1, m0, dx, B, xhw):
+        """Backward-to-input of the stride-2 first block of layer2 / layer3 as one launch (csrc/bottleneck_s2_fused.hip)."""
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            prof, self.profile = self.profile, None
+            try:
+                self._bneck_s2_bwd(g, ca, cb, cc, ds, m2, m1, m0, dx, B, xhw)
+            finally:
+                self.profile = prof
+            e1.record()
+            pin, pout = xhw[0] * xhw[1], xhw[0] * xhw[1] // 4
+            self.profile.append((2.0 * B * (pin * ca.cin * ca.cout + pout * (9 * cb.cin * cb.cout + cc.cin * cc.cout + ds.cin * ds.cout)),
+                                 e0, e1, 'bottleneck_s2'))
+            return
+        _lib.check(self.lib.rart_bottleneck_s2_bwd_bf16(
+            _lib.ptr(g), _lib.ptr(cc.s2_w3t), _lib.ptr(cb.s2_w2t), _lib.ptr(ca.s2_w1t), _lib.ptr(ds.s2_wdt), _lib.ptr(m2), _lib.ptr(m1),
+            _lib.ptr(m0), _lib.ptr(dx), B, xhw[0], xhw[1], ca.cin, ca.cout, cc.cout, _lib.stream_ptr()))
 
     def _first_ok(self, ca, cb, cc, ds, xhw, n=1):
         return (self._fits32(n, xhw, cc.cout) and self.fused_bottleneck and ds is not None and getattr(ds, 'w_fwd_frag', None) is not None
@@ -781,6 +817,12 @@ class ResNet50Engine:
                 dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
                 self._bneck(dz, cc.bwd[0][2], cb.w_bwd_frag, ds.bwd[0][2], None, None, None, mb, ma, mx, dx, B, xhw, cc.cout,
                             ca.cout, cb.bwd[0][1], True, w4=ca.bwd[0][2], c_in=ca.cin)
+                dz = dx
+                continue
+            if (self.fused_bottleneck_s2_bwd and ma is not None and ma.dtype == torch.uint8 and mb is not None
+                    and getattr(cb, 's2_w2t', None) is not None and self._s2_ok(ca, cb, cc, ds, xhw, B)):
+                dx = self._get('g_out_%d' % (bi - 1), tuple(x.shape))
+                self._bneck_s2_bwd(dz, ca, cb, cc, ds, mb, ma, mx, dx, B, xhw)
                 dz = dx
                 continue
             # (shapes from the layer geometry: a fused forward never materialises ya / yb)

@@ -875,13 +875,22 @@ def test_engine_with_and_without_the_fused_stride2_blocks(setup):
     x = torch.rand(3, 3, 224, 224, generator=g).cuda()
     y = torch.randint(0, 1000, (3,), generator=g).cuda()
     try:
-        eng.fused_bottleneck_s2 = True
+        eng.fused_bottleneck_s2 = eng.fused_bottleneck_s2_bwd = True
         la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
         la, ga = la.clone(), ga.clone()
+        # same forward (same masks), the backward of the two blocks as seven conv launches each: only bf16 rounding of the chain's
+        # extra intermediates differs
+        eng.fused_bottleneck_s2_bwd = False
+        _, _, gc, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        gc = gc.clone()
         eng.fused_bottleneck_s2 = False
         lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
     finally:
-        eng.fused_bottleneck_s2 = True
+        eng.fused_bottleneck_s2 = eng.fused_bottleneck_s2_bwd = True
+    a_, c_ = ga.flatten(1).double(), gc.flatten(1).double()
+    cos_bwd = (a_ * c_).sum(1) / (a_.norm(dim=1) * c_.norm(dim=1))
+    print('   fused vs chained BACKWARD of the stride-2 blocks (same masks): gradient cosine %s' % cos_bwd.tolist())
+    assert (cos_bwd > 0.999).all(), cos_bwd
     scale = lb.abs().max().item()
     print('fused stride-2 blocks vs chains: logits max diff %.3g of scale %.2f' % ((la - lb).abs().max().item(), scale))
     assert (la - lb).abs().max().item() <= 2e-2 * scale          # the chain rounds the shortcut to bf16 on its own, the fused block does not
@@ -891,3 +900,68 @@ def test_engine_with_and_without_the_fused_stride2_blocks(setup):
     # of test_backward_to_input); the kernel itself is pinned by test_fused_stride2_bottleneck_forward_vs_fp64
     print('   gradient cosine fused vs chains: %s' % cos.tolist())
     assert (cos > 0.85).all(), cos
+
+
+@pytest.mark.parametrize('B,geo', [(1, 56), (3, 56), (1, 28), (2, 28)])
+def test_fused_stride2_bottleneck_backward_vs_fp64(B, geo):
+    """rart_bottleneck_s2_bwd_bf16: backward-to-input of the stride-2 first block of layer2 / layer3 as one kernel (d_a2 on the 8 x 8
+    output grid behind a 14 x 14 input tile, the transposed 3x3 / 2 by input-parity class, the projection shortcut's gradient as extra
+    K of class (0, 0)), random masks; against fp64 with bf16 rounding of the two intermediates."""
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import _Conv
+    lib = _lib.load()
+    H = W = geo
+    CIN, CM, COUT = {56: (256, 128, 512), 28: (512, 256, 1024)}[geo]
+    g = torch.Generator().manual_seed(500 + B + geo)
+
+    def mk(cin, cout, k, stride):
+        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5)
+        return conv, _Conv(conv, None, 'cuda')
+
+    (c1, ca), (c2, cb), (c3, cc), (c4, ds) = mk(CIN, CM, 1, 1), mk(CM, CM, 3, 2), mk(CM, COUT, 1, 1), mk(CIN, COUT, 1, 2)
+    wq = [c.weight.detach().to(torch.bfloat16).double() for c in (c1, c2, c3, c4)]
+    rb = lambda t: t.to(torch.bfloat16).double()      # noqa: E731
+    sp = _lib.stream_ptr()
+
+    def frag(tab, rows, k, out=None):
+        o = torch.empty(rows * k, dtype=torch.bfloat16, device='cuda') if out is None else out
+        _lib.check(lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(o), rows, k, sp))
+        return o
+
+    w3t, w1t, wdt = frag(cc.bwd[0][2], CM, COUT), frag(ca.bwd[0][2], CIN, CM), frag(ds.bwd[0][2], CIN, COUT)
+    assert [len(t) for _, t, _ in cb.bwd] == [1, 2, 2, 4] and [p_ for p_, _, _ in cb.bwd] == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    w2t = torch.empty(9 * CM * CM, dtype=torch.bfloat16, device='cuda')
+    off = 0
+    for _, taps, tab in cb.bwd:
+        frag(tab, CM, len(taps) * CM, w2t[off:])
+        off += len(taps) * CM * CM
+    gz = _rand_bf16((B, H // 2, W // 2, COUT), 8).cuda()
+    mb = torch.randint(0, 256, (B, H // 2, W // 2, CM // 8), generator=g, dtype=torch.uint8).cuda()
+    ma = torch.randint(0, 256, (B, H, W, CM // 8), generator=g, dtype=torch.uint8).cuda()
+    mx = torch.randint(0, 256, (B, H, W, CIN // 8), generator=g, dtype=torch.uint8).cuda()
+    dx = torch.full((B, H, W, CIN), float('nan'), dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.rart_bottleneck_s2_bwd_bf16(_lib.ptr(gz), _lib.ptr(w3t), _lib.ptr(w2t), _lib.ptr(w1t), _lib.ptr(wdt), _lib.ptr(mb),
+                                               _lib.ptr(ma), _lib.ptr(mx), _lib.ptr(dx), B, H, W, CIN, CM, COUT, sp))
+    unpack = lambda t: torch.from_numpy(np.unpackbits(t.cpu().numpy(), axis=-1, bitorder='little')).bool()      # noqa: E731
+    bits = lambda t: unpack(t).double().permute(0, 3, 1, 2)      # noqa: E731
+    gd = gz.cpu().double().permute(0, 3, 1, 2)
+    ci = torch.nn.grad.conv2d_input
+    d2 = rb(ci((B, CM, H // 2, W // 2), wq[2], gd) * bits(mb))
+    d1 = rb(ci((B, CM, H, W), wq[1], d2, stride=2, padding=1) * bits(ma))
+    ref = ((ci((B, CIN, H, W), wq[0], d1) + ci((B, CIN, H, W), wq[3], gd, stride=2)) * bits(mx)).permute(0, 2, 3, 1)
+    got = dx.cpu().double()
+    assert torch.isfinite(got).all()                                   # every input position was written
+    err = (got - ref).abs()
+    ulp = ref.abs().clamp_min(2.0 ** -20) * 2.0 ** -8 + 1e-6
+    frac = (err > ulp).double().mean().item()
+    print('fused stride-2 block backward %d x %d: beyond 1 ulp %.2e of the elements, max err %.4f (scale %.2f)'
+          % (geo, geo, frac, err.max().item(), ref.abs().max().item()))
+    assert frac < 2e-2 and err.max() <= 0.01 * ref.abs().max()
+    # without the input mask (the first block of a network has none)
+    dx2 = torch.empty_like(dx)
+    _lib.check(lib.rart_bottleneck_s2_bwd_bf16(_lib.ptr(gz), _lib.ptr(w3t), _lib.ptr(w2t), _lib.ptr(w1t), _lib.ptr(wdt), _lib.ptr(mb),
+                                               _lib.ptr(ma), None, _lib.ptr(dx2), B, H, W, CIN, CM, COUT, sp))
+    keep = unpack(mx)
+    assert torch.equal(dx2.cpu()[keep], dx.cpu()[keep])
