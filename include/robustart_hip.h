@@ -450,7 +450,7 @@ int rart_engine_avgpool_bwd_pair(const void* y_sign_bits, const void* dpool_hi, 
 /* fp32 [rows][cols] -> pair [rows][dst_cols] (zero padded): the loss gradient entering the fc backward. */
 int rart_f32_to_pair_rows(const float* src, void* dst_hi, long long dst_lo_off, int rows, int cols, int dst_cols,
                           rart_stream_t stream);
-/* rart_engine_stem_col2im for fp32 patches (the stem's backward GEMM run with flags 32 | 2); h % 8 == 0, w % 16 == 0. */
+/* rart_engine_stem_col2im for fp32 patches (the stem's backward GEMM run with flags 32 | 2); h % 16 == 0, w % 32 == 0. */
 int rart_engine_stem_col2im_f32(const float* patches, float* grad, int n, int h, int w, int patch_cols, const float* std_host,
                                 rart_stream_t stream);
 /* The same stem backward as ONE kernel: pooled gradient dpool [n][h/4][w/4][64] bf16 + the max pool's argmax codes

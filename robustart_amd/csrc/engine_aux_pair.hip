@@ -182,12 +182,15 @@ __global__ __launch_bounds__(kBlock) void k_f32_to_pair_rows(const float* __rest
   }
 }
 
-// Stem backward from fp32 patches [n][oh][ow][pc] (column (r*7+s)*3+c, pc = 152) -> grad fp32 NCHW; k_stem_col2im
-// (engine_aux.hip) with an 8 x 16 pixel tile so the fp32 patch rows that reach it (7 x 11 x 608 B) fit 64 KB of LDS
-constexpr int C2F_TH = 8, C2F_TW = 16, C2F_PH = C2F_TH / 2 + 3, C2F_PW = C2F_TW / 2 + 3, C2F_PC = 152;
+// Stem backward from fp32 patches [n][oh][ow][pc] (column (r*7+s)*3+c, pc = 152) -> grad fp32 NCHW; k_stem_col2im (engine_aux.hip)
+// with the fp32 patch rows that reach a 16 x 32 pixel tile (11 x 19 x 608 B = 127 KB) in dynamic LDS.  (The first version used an
+// 8 x 16 tile in static LDS: 1.2 ms per 256 images, 5 % of a reference-precision gradient evaluation, half of it halo re-reads.)
+constexpr int C2F_TH = 16, C2F_TW = 32, C2F_PH = C2F_TH / 2 + 3, C2F_PW = C2F_TW / 2 + 3, C2F_PC = 152;
+constexpr int C2F_LDS = C2F_PH * C2F_PW * C2F_PC * 4;
 __global__ __launch_bounds__(kBlock) void k_stem_col2im_f32(const float* __restrict__ patches, float* __restrict__ grad, int n,
                                                             int h, int w, float istd0, float istd1, float istd2) {
-  __shared__ __attribute__((aligned(16))) float sp[C2F_PH * C2F_PW * C2F_PC];
+  extern __shared__ __attribute__((aligned(16))) float c2f_sp[];
+  float* const sp = c2f_sp;
   const int oh = h / 2, ow = w / 2;
   const int x0 = blockIdx.x * C2F_TW, y0 = blockIdx.y * C2F_TH, img = blockIdx.z;
   const int p0 = y0 / 2 - 1, q0 = x0 / 2 - 1;
@@ -286,10 +289,11 @@ int rart_f32_to_pair_rows(const float* src, void* dst_hi, long long dst_lo_off, 
 int rart_engine_stem_col2im_f32(const float* patches, float* grad, int n, int h, int w, int patch_cols, const float* std_host,
                                 rart_stream_t stream) {
   RART_CHECK_ARG(patches && grad && n > 0 && n <= 65535 && h % C2F_TH == 0 && w % C2F_TW == 0 && patch_cols == C2F_PC,
-                 "rart_engine_stem_col2im_f32: h %% 8 == 0, w %% 16 == 0, patch_cols == 152, n <= 65535");
+                 "rart_engine_stem_col2im_f32: h %% 16 == 0, w %% 32 == 0, patch_cols == 152, n <= 65535");
+  if (!rart_raise_dynamic_lds((const void*)k_stem_col2im_f32, C2F_LDS, "rart_engine_stem_col2im_f32")) return RART_ERR_HIP;
   const float i0 = std_host ? 1.0f / std_host[0] : 1.f, i1 = std_host ? 1.0f / std_host[1] : 1.f,
               i2 = std_host ? 1.0f / std_host[2] : 1.f;
-  hipLaunchKernelGGL(k_stem_col2im_f32, dim3(w / C2F_TW, h / C2F_TH, n), dim3(kBlock), 0, (hipStream_t)stream, patches, grad, n, h,
+  hipLaunchKernelGGL(k_stem_col2im_f32, dim3(w / C2F_TW, h / C2F_TH, n), dim3(kBlock), C2F_LDS, (hipStream_t)stream, patches, grad, n, h,
                      w, i0, i1, i2);
   RART_CHECK_LAUNCH("rart_engine_stem_col2im_f32");
   return RART_OK;

@@ -70,8 +70,19 @@ def wrapped_s2(x_, ca, cb, cc, ds, m1, m2, m3, out, B_, xhw):
     e0.record(); r = orig_s2(x_, ca, cb, cc, ds, m1, m2, m3, out, B_, xhw); e1.record()
     rows.append(((pout, ca.cin * 4 + 9 * cb.cin + cc.cin + ds.cin, cc.cout, 94), fl, by, e0, e1))   # taps column 94 = fused stride-2 block (forward)
     return r
+orig_s2b = eng._bneck_s2_bwd
+def wrapped_s2b(g_, ca, cb, cc, ds, m2, m1, m0, dx_, B_, xhw):
+    pin, pout = B_ * xhw[0] * xhw[1], B_ * xhw[0] * xhw[1] // 4
+    fl = 2.0 * (pin * ca.cin * ca.cout + pout * (9 * cb.cin * cb.cout + cc.cin * cc.cout + ds.cin * ds.cout))
+    by = pin * ca.cin * 2 + pout * cc.cout * 2 + (ca.cin * ca.cout + 9 * cb.cin * cb.cout + cc.cin * cc.cout + ds.cin * ds.cout) * 2 + \
+        (pin * ca.cout + pout * cb.cout + (pin * ca.cin if m0 is not None else 0)) * 0.125
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r = orig_s2b(g_, ca, cb, cc, ds, m2, m1, m0, dx_, B_, xhw); e1.record()
+    rows.append(((pout, ca.cin * 4 + 9 * cb.cin + cc.cin + ds.cin, cc.cout, 93), fl, by, e0, e1))   # taps column 93 = fused stride-2 block (backward)
+    return r
 for _ in range(2): eng.forward_backward(x, MEAN, STD, y, 0)
 eng._bneck14 = wrapped_b14
+eng._bneck_s2_bwd = wrapped_s2b
 eng._bneck_s2 = wrapped_s2
 eng._gemm = wrapped
 eng._halo = wrapped_halo
@@ -85,6 +96,7 @@ eng._halo = orig_halo
 eng._bneck = orig_bneck
 eng._bneck14 = orig_b14
 eng._bneck_s2 = orig_s2
+eng._bneck_s2_bwd = orig_s2b
 agg = {}
 for key, fl, by, a, b in rows:
     us = a.elapsed_time(b) * 1e3
@@ -95,7 +107,7 @@ for key, (us, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     floor = max(fl / PEAK_F, by / PEAK_B) * 1e6
     tot += us; totf += floor
     print('%9d %6d %6d %4d %4d %9.1f %8.1f %8.1f %9.1f %6.3f' % (*key, cnt, us, fl / us / 1e6, by / us / 1e3, floor, floor / us))
-print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 / 95 = the fused Bottleneck kernels of layer1 / layer3 / layer2 / layer4: one row = 1x1 + 3x3 + 1x1; 94 = the fused stride-2 first blocks of layer2 / layer3, forward)')
+print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 / 95 = the fused Bottleneck kernels of layer1 / layer3 / layer2 / layer4: one row = 1x1 + 3x3 + 1x1; 94 / 93 = the fused stride-2 first blocks of layer2 / layer3, forward / backward)')
 print('conv launches %d: measured %.1f us, roofline floor %.1f us, fraction of the per-layer floor %.3f' %
       (len(rows), tot, totf, totf / tot))
 for name, fn in (('fwd+bwd', lambda: eng.forward_backward(x, MEAN, STD, y, 0)), ('fwd', lambda: eng.logits(x, MEAN, STD))):
