@@ -206,6 +206,13 @@ int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0,
  * rart_fab_backoff: rows with mask != 0: x1 = x0 + (x1 - x0)*beta. */
 int rart_fab_project_linf(const float* points, const float* w, const float* b, float* d_out, float* rowmax_out, int rows,
                           size_t n, rart_stream_t stream);
+/* rart_fab_project: the same step for norm 0 = Linf (projection_linf), 1 = L1 (projection_l1, fab_projections.py:120-166),
+ * 2 = L2 (projection_l2, :62-117); rownorm_out[r] = ||d[r]||_norm (fab_base.py:194-203).  Sort-free: per row a bisection on the
+ * bit pattern of the multiplier (L2) / of the |w| threshold (L1), then the exact solve of the segment.
+ * rart_row_norm_diff: out[r] = ||a[r] - b[r]||_norm (fab_base.py:226-236). */
+int rart_fab_project(const float* points, const float* w, const float* b, float* d_out, float* rownorm_out, int rows, size_t n,
+                     int norm, rart_stream_t stream);
+int rart_row_norm_diff(const float* a, const float* b, float* out, int rows, size_t n, int norm, rart_stream_t stream);
 int rart_row_dot(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream);
 int rart_row_absmax_diff(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream);
 int rart_fab_update(float* x1, const float* x0, const float* d1, const float* d2, const float* alpha, int batch,

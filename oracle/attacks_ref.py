@@ -553,8 +553,8 @@ def square_linf_perturb(model_fn, x, y, eps, n_queries, p_init, rescale, init_si
 
 
 # ---------------------------------------------------------------------------------------
-# FAB, targeted, Linf (Attacks/autoattack/fab_base.py:84-336, fab_pt.py:102-117,
-# fab_projections.py:7-59) -- pinned
+# FAB, targeted, Linf / L2 / L1 (Attacks/autoattack/fab_base.py:84-336, fab_pt.py:102-117,
+# fab_projections.py:7-166) -- pinned (tests/golden/attacks_ref.npz: fabproj/*, fabproj_l2/*, fabproj_l1/*, fabt/{Linf,L2,L1}/adv)
 # ---------------------------------------------------------------------------------------
 
 def fab_projection_linf(t, w, b):
@@ -601,8 +601,98 @@ def fab_projection_linf(t, w, b):
     return d * nz
 
 
-def fab_targeted_single_run(model_fn, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9):
-    """fab_base.py:84-270 with is_targeted=True, use_rand_start=False, norm Linf."""
+def fab_projection_l2(t, w, b):
+    """fab_projections.py:62-117: box-constrained L2 projection step.  Same sort / cumsum / binary-search structure:
+    r_i = the multiplier at which coordinate i meets the box, s[k] = -F(r_(k)) with F(alpha) = sum w^2 min(alpha, r)."""
+    w = w.clone()
+    c = (w * t).sum(1) - b
+    sign = 2 * (c >= 0).to(t.dtype) - 1
+    w = w * sign.unsqueeze(1)
+    c = c * sign
+    live = (w.abs() > 1e-8).to(t.dtype)
+    r = torch.max(t / w, (t - 1) / w).clamp(min=-1e12, max=1e12)
+    r = torch.where(w.abs() < 1e-8, torch.full_like(r, 1e12), r)
+    r = torch.where(r == -1e12, -r, r)
+    rs, order = torch.sort(r, dim=1)
+    nxt = torch.cat((rs[:, 1:], torch.zeros_like(rs[:, :1])), 1)
+    rs = torch.where(rs == 1e12, torch.zeros_like(rs), rs)
+    nxt = torch.where(nxt == 1e12, torch.zeros_like(nxt), nxt)
+    w2s = (w ** 2).gather(1, order)
+    w2tot = w2s.sum(dim=1, keepdim=True)
+    tail = w2tot - torch.cumsum(w2s, dim=1)                      # slope of F after breakpoint k
+    d = -(r * w) * live
+    head = -w2tot * rs[:, 0:1]
+    s = torch.cat((head, torch.cumsum((rs - nxt) * tail, dim=1) + head), 1)
+    free = s[:, 0] + c < 0                                        # c4: no coordinate meets the box
+    unreachable = (d * w).sum(dim=1) + c > 0                      # c3
+    mixed = ~(free | unreachable)                                 # c2
+    n = w.shape[1]
+    lb = torch.zeros(int(mixed.sum()))
+    ub = torch.full_like(lb, n - 1)
+    s_, c_ = s[mixed], c[mixed]
+    for _ in range(math.ceil(math.log2(n))):
+        mid = torch.floor((lb + ub) / 2)
+        above = s_.gather(1, mid.long().unsqueeze(1)).squeeze(1) + c_ > 0
+        lb = torch.where(above, mid, lb)
+        ub = torch.where(above, ub, mid)
+    lb = lb.long()
+    if free.any():
+        d[free] = -(c[free] / w2tot[free].squeeze(-1)).unsqueeze(-1) * w[free]
+    if mixed.any():
+        u = torch.arange(int(mixed.sum()))
+        tl = tail[mixed][u, lb]
+        alpha = (s_[u, lb] + c_) / tl + rs[mixed][u, lb]
+        alpha[tl == 0] = 0
+        sat = (alpha.unsqueeze(-1) > r[mixed]).to(t.dtype)
+        d[mixed] = d[mixed] * sat - alpha.unsqueeze(-1) * w[mixed] * (1 - sat)
+    return d * live
+
+
+def fab_projection_l1(t, w, b):
+    """fab_projections.py:120-166: box-constrained L1 projection step: greedy in decreasing |w| -- the first lb coordinates go to
+    their bound, coordinate number lb goes part of the way, the rest stay."""
+    w = w.clone()
+    c = (w * t).sum(1) - b
+    sign = 2 * (c >= 0).to(t.dtype) - 1
+    w = w * sign.unsqueeze(1)
+    c = c * sign
+    order = torch.argsort((1 / w).abs().clamp_max(1e12), dim=1)
+    rank = torch.argsort(order)
+    up = (w < 0).to(t.dtype)
+    d = (up - t) * (w != 0).to(t.dtype)
+    gains = torch.min(-w * t, w * (1 - t)).gather(1, order)       # <= 0
+    s = torch.cumsum(torch.cat((c.unsqueeze(-1), gains), 1), dim=1)
+    reach = s[:, -1] < 0
+    lb = torch.zeros(int(reach.sum()))
+    ub = torch.full_like(lb, s.shape[1])
+    s_ = s[reach]
+    for _ in range(math.ceil(math.log2(w.shape[1]))):
+        mid = torch.floor((lb + ub) / 2)
+        above = s_.gather(1, mid.long().unsqueeze(1)).squeeze(1) > 0
+        lb = torch.where(above, mid, lb)
+        ub = torch.where(above, ub, mid)
+    lbi = lb.long()
+    if reach.any():
+        u = torch.arange(int(reach.sum()))
+        part = order[reach][u, lbi]
+        alpha = -s_[u, lbi] / w[reach][u, part]
+        dr = d[reach] * (rank[reach] < lbi.unsqueeze(-1)).to(t.dtype)
+        dr[u, part] = alpha
+        d[reach] = dr
+    return d * (w.abs() > 1e-8).to(t.dtype)
+
+
+FAB_PROJECTIONS = {'Linf': fab_projection_linf, 'L2': fab_projection_l2, 'L1': fab_projection_l1}
+
+
+def _fab_row_norm(v, norm):
+    v = v.reshape(v.shape[0], -1)
+    return v.abs().max(dim=1)[0] if norm == 'Linf' else ((v ** 2).sum(dim=1).sqrt() if norm == 'L2' else v.abs().sum(dim=1))
+
+
+def fab_targeted_single_run(model_fn, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9, norm='Linf'):
+    """fab_base.py:84-270 with is_targeted=True, use_rand_start=False; norm Linf / L2 / L1."""
+    project = FAB_PROJECTIONS[norm]
     x = x.detach().clone().float()
     y_pred = model_fn(x).max(1)[1]
     pred = y_pred == y
@@ -628,9 +718,9 @@ def fab_targeted_single_run(model_fn, x, y, target_class, eps, n_iter, alpha_max
             df = diffy.detach()
             w = g.reshape([bs, -1])
             b = -df + (g * x1).reshape(bs, -1).sum(dim=-1)
-            d3 = fab_projection_linf(torch.cat((x1.reshape([bs, -1]), x0), 0), torch.cat((w, w), 0), torch.cat((b, b), 0))
+            d3 = project(torch.cat((x1.reshape([bs, -1]), x0), 0), torch.cat((w, w), 0), torch.cat((b, b), 0))
             d1, d2 = d3[:bs].reshape(x1.shape), d3[-bs:].reshape(x1.shape)
-            a0 = d3.abs().max(dim=1, keepdim=True)[0].view(-1, 1, 1, 1)
+            a0 = _fab_row_norm(d3, norm).view(-1, 1, 1, 1)                                    # fab_base.py:194-203
             a0 = torch.max(a0, 1e-8 * torch.ones_like(a0))
             a1, a2 = a0[:bs], a0[-bs:]
             alpha = torch.min(torch.max(a1 / (a1 + a2), torch.zeros_like(a1)), alpha_max * torch.ones_like(a1))
@@ -638,7 +728,7 @@ def fab_targeted_single_run(model_fn, x, y, target_class, eps, n_iter, alpha_max
             is_adv = model_fn(x1).max(1)[1] != la2
             if is_adv.sum() > 0:
                 ia = is_adv.nonzero().flatten()
-                t = (x1[ia] - im2[ia]).reshape([ia.shape[0], -1]).abs().max(dim=1)[0]
+                t = _fab_row_norm(x1[ia] - im2[ia], norm)                                     # fab_base.py:226-236
                 better = (t < res2[ia]).float().view(-1, 1, 1, 1)
                 adv[ia] = x1[ia] * better + adv[ia] * (1 - better)
                 res2[ia] = t * (t < res2[ia]).float() + res2[ia] * (t >= res2[ia]).float()
@@ -648,7 +738,7 @@ def fab_targeted_single_run(model_fn, x, y, target_class, eps, n_iter, alpha_max
     return adv_c
 
 
-def fab_targeted_perturb(model_fn, x, y, eps, n_iter, n_target_classes=9):
+def fab_targeted_perturb(model_fn, x, y, eps, n_iter, n_target_classes=9, norm='Linf'):
     """fab_base.py:272-336, targeted branch, n_restarts 1."""
     adv = x.clone()
     with torch.no_grad():
@@ -658,10 +748,10 @@ def fab_targeted_perturb(model_fn, x, y, eps, n_iter, n_target_classes=9):
         if ind.numel() == 0:
             continue
         xs, ys = x[ind].clone(), y[ind].clone()
-        adv_curr = fab_targeted_single_run(model_fn, xs, ys, target_class, eps, n_iter)
+        adv_curr = fab_targeted_single_run(model_fn, xs, ys, target_class, eps, n_iter, norm=norm)
         with torch.no_grad():
             acc_curr = model_fn(adv_curr).max(1)[1] == ys
-        res = (xs - adv_curr).abs().reshape(xs.shape[0], -1).max(1)[0]
+        res = _fab_row_norm(xs - adv_curr, norm)                                               # fab_base.py:296-301
         acc_curr = torch.max(acc_curr, res > eps)
         fooled = (acc_curr == 0).nonzero().flatten()
         acc[ind[fooled]] = False

@@ -529,6 +529,189 @@ __global__ __launch_bounds__(kFabThreads) void k_fab_project_linf(const float* _
   if (threadIdx.x == 0 && rowmax) rowmax[row] = mx;
 }
 
+// ---- FAB (L2, L1) ----------------------------------------------------------------------------------
+// Box-constrained L2 projection (fab_projections.py:62-117).  With the sign chosen so that c = w.t - b >= 0, coordinate i can
+// follow the steepest direction d_i = -alpha w_i until alpha reaches r_i = max(t_i / w_i, (t_i - 1) / w_i), where it meets the
+// box; the step is d_i = -min(alpha, r_i) w_i and alpha solves F(alpha) = sum_i w_i^2 min(alpha, r_i) = c (monotone, piecewise
+// linear).  The reference sorts r, builds two cumulative sums and binary-searches the segment; here one workgroup per row
+// bisects on the BIT PATTERN of alpha (non-negative floats order like their bits, r spans 0 .. 1e8 so a linear bisection
+// would lose the small roots), then solves the segment exactly.  Coordinates with |w_i| <= 1e-8 do not move (:67,:117).
+// Also returns ||d||_2 (fab_base.py:198-200).
+__device__ __forceinline__ float fab_l2_reach(float t, float w) {          // r_i, for |w| > 1e-8 (finite, >= 0)
+  return fmaxf(__fdiv_rn(t, w), __fdiv_rn(t - 1.f, w));
+}
+__global__ __launch_bounds__(kFabThreads) void k_fab_project_l2(const float* __restrict__ pts, const float* __restrict__ wv,
+                                                                const float* __restrict__ bv, float* __restrict__ dout,
+                                                                float* __restrict__ rownorm, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  const float* t = pts + row * n;
+  const float* w = wv + row * n;
+  float* d = dout + row * n;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) acc += (double)(w[i] * t[i]);
+  const double wt = fab_block_sum(acc, sh);
+  const float sgn = (wt - (double)bv[row] >= 0.0) ? 1.f : -1.f;
+  const double c = fabs(wt - (double)bv[row]);
+  double w5 = 0.0, fmax_ = 0.0;
+  float rmin = INFINITY, rmax = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float wi = sgn * w[i];
+    w5 += (double)(wi * wi);
+    if (fabsf(wi) > 1e-8f) {
+      const float r = fab_l2_reach(t[i], wi);
+      rmin = fminf(rmin, r);
+      rmax = fmaxf(rmax, r);
+      fmax_ += (double)(wi * wi) * (double)r;
+    }
+  }
+  w5 = fab_block_sum(w5, sh);
+  fmax_ = fab_block_sum(fmax_, sh);
+  rmin = fab_block_min(rmin, sh, false);
+  rmax = fab_block_min(rmax, sh, true);
+  float alpha;
+  if (rmin == INFINITY) {
+    alpha = 0.f;                                      // no coordinate can move
+  } else if (c < w5 * (double)rmin) {                 // c4 (:87,:104-106): nobody reaches the box
+    alpha = (float)(c / w5);
+  } else if (c > fmax_) {                             // c3 (:88): out of reach, every coordinate goes to its bound
+    alpha = INFINITY;
+  } else {                                            // c2 (:89-102,:108-112)
+    uint32_t lo = __float_as_uint(rmin), hi = __float_as_uint(rmax);      // F(lo) <= c <= F(hi)
+    while (hi - lo > 1u) {
+      const uint32_t midb = lo + ((hi - lo) >> 1);
+      const float mid = __uint_as_float(midb);
+      double f = 0.0;
+      for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+        const float wi = sgn * w[i];
+        if (fabsf(wi) > 1e-8f) f += (double)(wi * wi) * (double)fminf(mid, fab_l2_reach(t[i], wi));
+      }
+      f = fab_block_sum(f, sh);
+      if (f > c) hi = midb; else lo = midb;
+    }
+    const float lof = __uint_as_float(lo);
+    double sat = 0.0, act = 0.0;                      // the segment [lo, hi] holds no breakpoint inside: solve it exactly
+    for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+      const float wi = sgn * w[i];
+      if (fabsf(wi) > 1e-8f) {
+        const float r = fab_l2_reach(t[i], wi);
+        if (r <= lof) sat += (double)(wi * wi) * (double)r; else act += (double)(wi * wi);
+      }
+    }
+    sat = fab_block_sum(sat, sh);
+    act = fab_block_sum(act, sh);
+    alpha = act > 0.0 ? fminf(fmaxf((float)((c - sat) / act), lof), __uint_as_float(hi)) : lof;
+  }
+  double nn = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float wi = sgn * w[i];
+    float dv = 0.f;
+    if (fabsf(wi) > 1e-8f) dv = -fminf(alpha, fab_l2_reach(t[i], wi)) * wi;
+    d[i] = dv;
+    nn += (double)dv * (double)dv;
+  }
+  nn = fab_block_sum(nn, sh);
+  if (threadIdx.x == 0 && rownorm) rownorm[row] = (float)sqrt(nn);
+}
+
+// Box-constrained L1 projection (fab_projections.py:120-166).  With c = w.t - b >= 0, sending coordinate i to its helpful
+// bound (0 when w_i > 0, 1 when w_i < 0) lowers w.x by gain_i = |w_i| * room_i; the L1-cheapest way to remove c is greedy in
+// decreasing |w_i|: the first coordinates go all the way, one goes part of the way, the rest stay.  The reference argsorts
+// 1 / |w| and binary-searches the cumulative gains; here one workgroup per row finds the |w| of the partial coordinate by
+// bisection on its bit pattern (kappa = the largest key with sum_{|w_i| >= kappa} gain_i >= c), ties between equal |w| are
+// taken in index order (a second bisection, on the index, only when there are ties).  Also returns ||d||_1 (fab_base.py:201-203).
+__device__ __forceinline__ float fab_l1_gain(float t, float wi) { return wi > 0.f ? wi * t : -wi * (1.f - t); }
+__global__ __launch_bounds__(kFabThreads) void k_fab_project_l1(const float* __restrict__ pts, const float* __restrict__ wv,
+                                                                const float* __restrict__ bv, float* __restrict__ dout,
+                                                                float* __restrict__ rownorm, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  const float* t = pts + row * n;
+  const float* w = wv + row * n;
+  float* d = dout + row * n;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) acc += (double)(w[i] * t[i]);
+  const double wt = fab_block_sum(acc, sh);
+  const float sgn = (wt - (double)bv[row] >= 0.0) ? 1.f : -1.f;
+  const double c = fabs(wt - (double)bv[row]);
+  double total = 0.0;
+  float wmax = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float wi = sgn * w[i];
+    total += (double)fab_l1_gain(t[i], wi);
+    wmax = fmaxf(wmax, fabsf(wi));
+  }
+  total = fab_block_sum(total, sh);
+  wmax = fab_block_min(wmax, sh, true);
+  uint32_t kappa = 0xFFFFFFFFu;                       // unreachable (:135 c2 false): everything with w != 0 goes to its bound
+  size_t tie_end = 0;                                 // with ties: tied coordinates of index < tie_end go all the way, tie_end part of it
+  bool have_ties = false;
+  double before = 0.0;                                // gain of everything taken all the way
+  if (total > c) {
+    uint32_t lo = 0u, hi = __float_as_uint(wmax) + 1u;                   // G(lo) >= c > G(hi) = 0, G(k) = sum_{key >= k} gain
+    while (hi - lo > 1u) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      double g = 0.0;
+      for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+        const float wi = sgn * w[i];
+        if ((__float_as_uint(wi) & 0x7FFFFFFFu) >= mid) g += (double)fab_l1_gain(t[i], wi);
+      }
+      g = fab_block_sum(g, sh);
+      if (g >= c && g > 0.0) lo = mid; else hi = mid;
+    }
+    kappa = lo;
+    double above = 0.0, ties = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+      const float wi = sgn * w[i];
+      const uint32_t key = __float_as_uint(wi) & 0x7FFFFFFFu;
+      if (key > kappa) above += (double)fab_l1_gain(t[i], wi);
+      ties += key == kappa ? 1.0 : 0.0;
+    }
+    above = fab_block_sum(above, sh);
+    ties = fab_block_sum(ties, sh);
+    before = above;
+    have_ties = ties > 1.0;
+    if (have_ties) {                                  // the smallest m with above + sum_{tied, i < m} gain_i >= c is one past the partial coordinate
+      size_t mlo = 0, mhi = n;                        // P(mlo) < c <= P(mhi)
+      while (mhi - mlo > 1) {
+        const size_t mid = mlo + ((mhi - mlo) >> 1);
+        double g = 0.0;
+        for (size_t i = threadIdx.x; i < mid; i += kFabThreads) {
+          const float wi = sgn * w[i];
+          if ((__float_as_uint(wi) & 0x7FFFFFFFu) == kappa) g += (double)fab_l1_gain(t[i], wi);
+        }
+        g = fab_block_sum(g, sh);
+        if (above + g >= c) mhi = mid; else mlo = mid;
+      }
+      tie_end = mhi - 1;                              // index of the partial coordinate (tied or not; non-tied ones add nothing)
+      double g = 0.0;
+      for (size_t i = threadIdx.x; i < tie_end; i += kFabThreads) {
+        const float wi = sgn * w[i];
+        if ((__float_as_uint(wi) & 0x7FFFFFFFu) == kappa) g += (double)fab_l1_gain(t[i], wi);
+      }
+      before = above + fab_block_sum(g, sh);
+    }
+  }
+  double nn = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float wi = sgn * w[i];
+    const uint32_t key = __float_as_uint(wi) & 0x7FFFFFFFu;
+    float dv = 0.f;
+    if (fabsf(wi) > 1e-8f) {                          // (:166; also w != 0 of :131)
+      const float full = wi < 0.f ? 1.f - t[i] : -t[i];
+      if (key > kappa || kappa == 0xFFFFFFFFu) dv = full;
+      else if (key == kappa) {
+        if (have_ties && i < tie_end) dv = full;
+        else if (!have_ties || i == tie_end) dv = (float)(-(c - before) / (double)wi);   // alpha of :158: one coordinate only
+      }
+    }
+    d[i] = dv;
+    nn += (double)fabsf(dv);
+  }
+  nn = fab_block_sum(nn, sh);
+  if (threadIdx.x == 0 && rownorm) rownorm[row] = (float)nn;
+}
+
 // ---- APGD, L1 threat model (autopgd_base.py:19-83, 222-226, 351-364, 431-441) -----------------------------------------
 // L1_projection: delta with ||y + delta||_1 <= eps and 0 <= x + y + delta <= 1.  Per coordinate |y_i| shrinks by
 // clip(alpha, lo_i, a_i), a_i = |y_i|, lo_i = -min(min(1 - x_i - y_i, x_i + y_i), 0) (what the box alone demands), and alpha
@@ -695,6 +878,27 @@ __global__ __launch_bounds__(kFabThreads) void k_row_absmax_diff(const float* __
   for (size_t i = threadIdx.x; i < n; i += kFabThreads) m = fmaxf(m, fabsf(a[row * n + i] - b[row * n + i]));
   m = fab_block_min(m, sh, true);
   if (threadIdx.x == 0) out[row] = m;
+}
+// out[r] = ||a[r] - b[r]||_p, NORM 0 = Linf, 1 = L1, 2 = L2  (fab_base.py:226-236, :296-301)
+template <int NORM>
+__global__ __launch_bounds__(kFabThreads) void k_row_norm_diff(const float* __restrict__ a, const float* __restrict__ b,
+                                                               float* __restrict__ out, size_t n) {
+  __shared__ double sh[kFabThreads / 64];
+  const size_t row = blockIdx.x;
+  double acc = 0.0;
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const float v = a[row * n + i] - b[row * n + i];
+    if (NORM == 0) m = fmaxf(m, fabsf(v));
+    else acc += NORM == 1 ? (double)fabsf(v) : (double)v * (double)v;
+  }
+  if (NORM == 0) {
+    m = fab_block_min(m, sh, true);
+    if (threadIdx.x == 0) out[row] = m;
+  } else {
+    acc = fab_block_sum(acc, sh);
+    if (threadIdx.x == 0) out[row] = NORM == 1 ? (float)acc : (float)sqrt(acc);
+  }
 }
 // x1 = clamp((x1 + eta*d1)*(1 - alpha) + (x0 + eta*d2)*alpha, 0, 1)   (fab_base.py:218-219)
 __global__ __launch_bounds__(kBlock) void k_fab_update(float* __restrict__ x1, const float* __restrict__ x0,
@@ -1017,6 +1221,21 @@ int rart_fab_project_linf(const float* points, const float* w, const float* b, f
   hipLaunchKernelGGL(k_fab_project_linf, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, points, w, b, d_out,
                      rowmax_out, n);
   RART_CHECK_LAUNCH("rart_fab_project_linf");
+  return RART_OK;
+}
+int rart_fab_project(const float* points, const float* w, const float* b, float* d_out, float* rownorm_out, int rows, size_t n,
+                     int norm, rart_stream_t stream) {
+  RART_CHECK_ARG(points && w && b && d_out && rows > 0 && n > 0 && norm >= 0 && norm <= 2, "rart_fab_project: bad arguments");
+  auto kern = norm == 0 ? k_fab_project_linf : (norm == 2 ? k_fab_project_l2 : k_fab_project_l1);
+  hipLaunchKernelGGL(kern, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, points, w, b, d_out, rownorm_out, n);
+  RART_CHECK_LAUNCH("rart_fab_project");
+  return RART_OK;
+}
+int rart_row_norm_diff(const float* a, const float* b, float* out, int rows, size_t n, int norm, rart_stream_t stream) {
+  RART_CHECK_ARG(a && b && out && rows > 0 && n > 0 && norm >= 0 && norm <= 2, "rart_row_norm_diff: bad arguments");
+  auto kern = norm == 0 ? k_row_norm_diff<0> : (norm == 1 ? k_row_norm_diff<1> : k_row_norm_diff<2>);
+  hipLaunchKernelGGL(kern, dim3(rows), dim3(kFabThreads), 0, (hipStream_t)stream, a, b, out, n);
+  RART_CHECK_LAUNCH("rart_row_norm_diff");
   return RART_OK;
 }
 int rart_row_dot(const float* a, const float* b, float* out, int rows, size_t n, rart_stream_t stream) {

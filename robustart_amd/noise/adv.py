@@ -597,8 +597,33 @@ def fab_project_linf(points, w, b):
     return d, rm
 
 
-def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9):
-    """FABAttack.attack_single_run, is_targeted, no random start, Linf (fab_base.py:84-270)."""
+_FAB_NORM = {'Linf': 0, 'L1': 1, 'L2': 2}
+
+
+def fab_project(points, w, b, norm='Linf'):
+    """-> (d, rownorm): rart_fab_project -- projection_linf / projection_l2 / projection_l1 (fab_projections.py:7-166) on
+    [R, ...] fp32 tensors, rownorm[r] = ||d[r]||_norm."""
+    torch = _lib.require_gpu()
+    R = points.shape[0]
+    n = points[0].numel()
+    d = torch.empty_like(points)
+    rm = torch.empty(R, dtype=torch.float32, device=points.device)
+    _lib.check(_lib.load().rart_fab_project(_lib.ptr(points), _lib.ptr(w), _lib.ptr(b), _lib.ptr(d), _lib.ptr(rm), R, n,
+                                            _FAB_NORM[norm], _lib.stream_ptr()))
+    return d, rm
+
+
+def row_norm_diff(a, b, norm='Linf', out=None):
+    """out[r] = ||a[r] - b[r]||_norm (rart_row_norm_diff)."""
+    torch = _lib.require_gpu()
+    R, n = a.shape[0], a[0].numel()
+    out = torch.empty(R, dtype=torch.float32, device=a.device) if out is None else out
+    _lib.check(_lib.load().rart_row_norm_diff(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), R, n, _FAB_NORM[norm], _lib.stream_ptr()))
+    return out
+
+
+def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9, norm='Linf'):
+    """FABAttack.attack_single_run, is_targeted, no random start, norm Linf / L2 / L1 (fab_base.py:84-270)."""
     torch = _lib.require_gpu()
     lib, sp = _lib.load(), _lib.stream_ptr
     logits0 = prov.logits(x)
@@ -620,14 +645,14 @@ def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.
         logits, df, g, _ = prov.logits_and_grad(x1, la2, LOSS_TARGETED_DIFF, la_t)       # fab_pt.py:102-117
         _lib.check(lib.rart_row_dot(_lib.ptr(g), _lib.ptr(x1), _lib.ptr(dotb), bs, nps, sp()))
         b = (dotb - df).contiguous()                                                       # fab_base.py:170-171
-        d1, a1 = fab_project_linf(x1, g, b)                                                # fab_base.py:174-178
-        d2, a2 = fab_project_linf(im2, g, b)
+        d1, a1 = fab_project(x1, g, b, norm)                                               # fab_base.py:174-203
+        d2, a2 = fab_project(im2, g, b, norm)
         a1, a2 = torch.clamp(a1, min=1e-8), torch.clamp(a2, min=1e-8)
         alpha = torch.clamp(a1 / (a1 + a2), 0.0, alpha_max).contiguous()
         _lib.check(lib.rart_fab_update(_lib.ptr(x1), _lib.ptr(im2), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(alpha), bs, nps,
                                        float(eta), sp()))
         is_adv = prov.logits(x1).max(1)[1] != la2                                          # fab_base.py:221
-        _lib.check(lib.rart_row_absmax_diff(_lib.ptr(x1), _lib.ptr(im2), _lib.ptr(tbuf), bs, nps, sp()))
+        row_norm_diff(x1, im2, norm, out=tbuf)                                             # fab_base.py:226-236
         better = is_adv & (tbuf < res2)
         select_rows_(adv, x1, better)
         res2 = torch.where(better, tbuf, res2)
@@ -638,10 +663,12 @@ def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.
     return adv_c
 
 
-def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_classes=9, _prov=None):
-    """FABAttack.perturb, targeted, Linf, n_restarts 1 (fab_base.py:272-336).  FAB is deterministic without
+def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_classes=9, _prov=None, norm='Linf'):
+    """FABAttack.perturb, targeted, norm Linf / L2 / L1, n_restarts 1 (fab_base.py:272-336).  FAB is deterministic without
     random restarts, so there are no draws to inject."""
     torch = _lib.require_gpu()
+    if norm not in _FAB_NORM:
+        raise ValueError('norm not supported')                                             # fab_base.py:164
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     if getattr(prov.engine, 'precision', 'bf16x3') == 'bf16':
         # measured (tests/test_outcome_gpu.py, fitted ResNet-50, eps 4/255): FAB-T leaves 34 % robust on the bf16 engine where
@@ -657,9 +684,9 @@ def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_class
         if ind.numel() == 0:
             break
         xs, ys = x[ind].contiguous(), y[ind].contiguous()
-        adv_curr = _fab_targeted_single_run(prov, xs, ys, target_class, eps, n_iter)
+        adv_curr = _fab_targeted_single_run(prov, xs, ys, target_class, eps, n_iter, norm=norm)
         acc_curr = prov.logits(adv_curr).max(1)[1] == ys
-        res = (xs - adv_curr).abs().flatten(1).max(1)[0]
+        res = row_norm_diff(xs, adv_curr, norm)                                            # fab_base.py:296-301
         acc_curr = acc_curr | (res > eps)
         fooled = (~acc_curr).nonzero().flatten()
         acc[ind[fooled]] = False
@@ -672,8 +699,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     (autoattack.py:90-211).  `model` takes normalised input (NormalizeModel, autoattack.py:12-23).
     standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); the
     untargeted `fab` of version 'plus' (a 1000-class Jacobian per step, unusable on ImageNet in the reference too)
-    and the L2 variants of fab-t / square are reported as skipped (the result is then an upper bound
-    on robust accuracy, never silently presented as the full ensemble).
+    and Square for L2 / L1 are reported as skipped (the result is then an upper bound on robust accuracy, never silently
+    presented as the full ensemble); fab-t runs for all three norms.
     _overrides (parity tests only; the reference shrinks the same attributes, autoattack.py:253-267): dict with any of
     plan, apgd_iter, apgdt_iter, apgdt_classes, fab_iter, fab_classes, square_queries, and `draws` -- an object like
     oracle.attacks_ref.TorchStreamDraws replaying the reference's torch random stream instead of the counter-based RNG."""
@@ -695,9 +722,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     apgdt_classes, fab_iter, fab_classes = int(ov.get('apgdt_classes', 9)), int(ov.get('fab_iter', 100)), int(ov.get('fab_classes', 9))
     square_queries = int(ov.get('square_queries', 5000))
     draws = ov.get('draws')
-    skipped = [a for a in plan if a in ('fab',)] + ([a for a in plan if a == 'fab-t'] if norm != 'Linf' else [])
-    if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes; FAB-T / Square L1: not built
-        skipped += [a for a in plan if a == 'square']
+    skipped = [a for a in plan if a in ('fab',)] + ([a for a in plan if a == 'square'] if norm != 'Linf' else [])
+    if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes; Square L2 / L1: not built
         n_restarts, apgdt_classes = int(ov.get('apgd_restarts', 5)), int(ov.get('apgdt_classes', 5))
     if skipped:
         warnings.warn('autoattack_linf: %s not implemented on this build yet -- running %s only; robust accuracy '
@@ -740,7 +766,7 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
                 adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, apgdt_iter, apgdt_classes, sd, first, init_ts=ts,
                                                  _prov=prov)
             elif attack == 'fab-t':
-                adv_curr = fab_targeted_perturb(None, x, y, eps, fab_iter, fab_classes, _prov=prov)
+                adv_curr = fab_targeted_perturb(None, x, y, eps, fab_iter, fab_classes, _prov=prov, norm=norm)
             elif attack == 'square':
                 if norm != 'Linf':
                     raise NotImplementedError('Square L2 (square.py:296-530) is not implemented')

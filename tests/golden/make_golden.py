@@ -186,8 +186,43 @@ def gen_apgd_l1():
           int((model_fn(torch.from_numpy(out['perturb/ce/adv'])).max(1)[1] == y).sum()), 'of', len(x))
 
 
+def gen_fab_l2_l1():
+    """projection_l2 / projection_l1 themselves (fab_projections.py:62-166) on random rows -- hyperplanes near, far and out of reach,
+    zero and tiny gradient entries, points on the box faces -- and FABAttack_PT, targeted, norm='L2' / 'L1', on the tiny CNN
+    -> fab_l2_l1_ref.npz."""
+    from RobustART.noise.utils.adv.Attacks.autoattack.fab_projections import projection_l2, projection_l1
+    out = {}
+    gp = torch.Generator().manual_seed(5)
+    pt, pw = torch.rand(8, 600, generator=gp), torch.randn(8, 600, generator=gp)
+    pw[:, ::7] = 0
+    pw[:, 3::11] *= 1e-9                    # below the |w| > 1e-8 gate
+    pt[:, 5::13] = 0.0                      # on a face of the box
+    pt[:, 6::17] = 1.0
+    pw[6] *= 1e-3
+    shift = torch.tensor([0.1, 5.0, -3.0, 400.0, -600.0, 0.0, 0.01, -40.0])
+    pb = (pw * pt).sum(1) + shift
+    out['proj/t'], out['proj/w'], out['proj/b'] = pt.numpy(), pw.numpy(), pb.numpy()
+    out['proj/d_l2'] = projection_l2(pt.clone(), pw.clone(), pb.clone()).numpy()
+    out['proj/d_l1'] = projection_l1(pt.clone(), pw.clone(), pb.clone()).numpy()
+    net = make_tinynet()
+    model_fn = lambda z: net(normalize(z))  # noqa: E731
+    x = make_batch()
+    y = model_fn(x).max(1)[1]
+    out['x'], out['y'] = x.numpy(), y.numpy()
+    for norm, eps in (('L2', 1.0), ('L1', 12.0)):
+        fab = FABAttack_PT(model_fn, n_restarts=1, n_iter=6, eps=eps, seed=0, norm=norm, verbose=False, device='cpu',
+                           targeted=True, n_target_classes=3)
+        adv = fab.perturb(x.clone(), y.clone()).detach()
+        out[f'fabt/{norm}/adv'] = adv.numpy()
+        print('fab-t', norm, 'robust', int((model_fn(adv).max(1)[1] == y).sum()), 'of', len(x))
+    np.savez_compressed(os.path.join(HERE, 'fab_l2_l1_ref.npz'), **out)
+    print('fab_l2_l1_ref.npz', len(out), 'entries')
+
+
 if __name__ == '__main__':
-    if 'apgd_l1' in sys.argv[1:]:
+    if 'fab_l2_l1' in sys.argv[1:]:
+        gen_fab_l2_l1()
+    elif 'apgd_l1' in sys.argv[1:]:
         gen_apgd_l1()
     elif 'autoattack' in sys.argv[1:]:
         gen_autoattack()
@@ -196,3 +231,4 @@ if __name__ == '__main__':
         gen_attacks()
         gen_autoattack()
         gen_apgd_l1()
+        gen_fab_l2_l1()

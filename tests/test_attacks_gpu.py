@@ -212,6 +212,48 @@ def test_fab_projection_and_fab_t_match_reference():
     torch.testing.assert_close(got.cpu(), torch.from_numpy(g['fabt/Linf/adv']), atol=5e-5, rtol=0)
 
 
+def test_fab_l2_l1_projections_and_fab_t_match_reference():
+    """rart_fab_project, norm L2 / L1 (bit-pattern bisection, no sort) vs the reference's sort-based projection_l2 / projection_l1
+    outputs (golden: near / far / unreachable hyperplanes, zero and sub-1e-8 gradient entries, points on the box faces), the same at
+    ImageNet row length vs the oracle with the constraint properties, then the whole targeted FAB run vs the reference's output."""
+    from robustart_amd.noise import adv
+    g = np.load(os.path.join(GOLD, 'fab_l2_l1_ref.npz'))
+    t, w, b = (torch.from_numpy(g['proj/' + k]).cuda().contiguous() for k in 'twb')
+    for norm, key in (('L2', 'd_l2'), ('L1', 'd_l1')):
+        d, rn = adv.fab_project(t, w, b, norm)
+        ref = torch.from_numpy(g['proj/' + key])
+        torch.testing.assert_close(d.cpu(), ref, atol=3e-6 if norm == 'L2' else 3e-5, rtol=2e-5)   # (L1: the partly-moved coordinate is a residual / w)
+        want = ref.abs().sum(1) if norm == 'L1' else ref.pow(2).sum(1).sqrt()
+        torch.testing.assert_close(rn.cpu(), want, atol=1e-5, rtol=1e-5)
+    gen = torch.Generator().manual_seed(2)
+    n = 3 * 224 * 224
+    t2 = torch.rand(5, n, generator=gen)
+    w2 = torch.randn(5, n, generator=gen) * 1e-3
+    w2[4] = (w2[4] * 64).round() / 64 * 0.05            # many tied |w| values: the L1 greedy order is then by index
+    b2 = ((w2 * t2).sum(1) + torch.tensor([0.5, -0.3, 2.0, -1e3, 0.7])).contiguous()
+    t2c, w2c, b2c = t2.cuda(), w2.cuda(), b2.cuda()
+    for norm, fn in (('L2', A.fab_projection_l2), ('L1', A.fab_projection_l1)):
+        d2, rn2 = adv.fab_project(t2c, w2c, b2c, norm)
+        y2 = t2c + d2
+        assert y2.min() >= -1e-6 and y2.max() <= 1 + 1e-6                                  # inside the box
+        resid = ((w2c.double() * y2.double()).sum(1) - b2c.double()).abs().cpu()
+        assert (resid[:3] < 2e-3).all() and resid[4] < 2e-3                                # reachable rows sit on the hyperplane
+        assert resid[3] > 100                                                               # the unreachable one went to the bounds
+        want = fn(t2.double(), w2.double(), b2.double()).float()           # the oracle in fp64: the kernel accumulates in fp64
+        wn = want.abs().sum(1) if norm == 'L1' else want.pow(2).sum(1).sqrt()
+        torch.testing.assert_close(rn2.cpu(), wn, atol=1e-4, rtol=2e-4)                    # the same minimal step length
+        rows = [0, 1, 2, 3] if norm == 'L1' else [0, 1, 2, 3, 4]                            # (tied row: any tie order is a minimiser)
+        assert (d2.cpu()[rows] - want[rows]).abs().max() < 5e-5
+    netc = make_tinynet().cuda()
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    mean = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()
+    std = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1).cuda()
+    f_gpu = lambda z: netc((z - mean) / std)  # noqa: E731
+    for norm, eps, tol in (('L2', 1.0, 5e-5), ('L1', 12.0, 2e-4)):
+        got = adv.fab_targeted_perturb(f_gpu, x.cuda(), y.cuda(), eps, 6, 3, norm=norm)
+        torch.testing.assert_close(got.cpu(), torch.from_numpy(g[f'fabt/{norm}/adv']), atol=tol, rtol=0)
+
+
 def test_native_pgd_linf_invariants_at_imagenet_size():
     """BASELINE-size property checks (no oracle run needed): eps-ball, box, determinism, sharding."""
     from robustart_amd.noise import adv

@@ -238,6 +238,21 @@ def gold_aa():
     return np.load(os.path.join(GOLD, 'autoattack_ref.npz'))
 
 
+def test_fab_l2_l1_projections_and_fab_t_match_reference():
+    """projection_l2 / projection_l1 (fab_projections.py:62-166) restated: bit-exact on the reference's outputs for rows with near, far
+    and unreachable hyperplanes, zero / sub-1e-8 gradient entries and points on the box faces; then the whole targeted FAB run."""
+    g = np.load(os.path.join(GOLD, 'fab_l2_l1_ref.npz'))
+    t, w, b = (torch.from_numpy(g['proj/' + k]) for k in 'twb')
+    np.testing.assert_array_equal(A.fab_projection_l2(t, w, b).numpy(), g['proj/d_l2'])
+    np.testing.assert_array_equal(A.fab_projection_l1(t, w, b).numpy(), g['proj/d_l1'])
+    net = make_tinynet()
+    model_fn = lambda z: net(A.normalize(z))  # noqa: E731
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    for norm, eps, tol in (('L2', 1.0, 2e-6), ('L1', 12.0, 5e-5)):       # L1: one partly-moved coordinate = a small residual / w
+        adv = A.fab_targeted_perturb(model_fn, x, y, eps, 6, 3, norm=norm)
+        np.testing.assert_allclose(adv.numpy(), g[f'fabt/{norm}/adv'], atol=tol)
+
+
 AA_CASES = {'standard': (1 / 255, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 10, 3, 60),
             'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40)}
 
