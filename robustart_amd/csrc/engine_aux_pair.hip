@@ -183,21 +183,22 @@ __global__ __launch_bounds__(kBlock) void k_f32_to_pair_rows(const float* __rest
 }
 
 // Stem backward from fp32 patches [n][oh][ow][pc] (column (r*7+s)*3+c, pc = 152) -> grad fp32 NCHW; k_stem_col2im (engine_aux.hip)
-// with the fp32 patch rows that reach a 16 x 32 pixel tile (11 x 19 x 608 B = 127 KB) in dynamic LDS.  (The first version used an
-// 8 x 16 tile in static LDS: 1.2 ms per 256 images, 5 % of a reference-precision gradient evaluation, half of it halo re-reads.)
-constexpr int C2F_TH = 16, C2F_TW = 32, C2F_PH = C2F_TH / 2 + 3, C2F_PW = C2F_TW / 2 + 3, C2F_PC = 152;
-constexpr int C2F_LDS = C2F_PH * C2F_PW * C2F_PC * 4;
-__global__ __launch_bounds__(kBlock) void k_stem_col2im_f32(const float* __restrict__ patches, float* __restrict__ grad, int n,
-                                                            int h, int w, float istd0, float istd1, float istd2) {
+// with the fp32 patch rows that reach a TH x TW pixel tile ((TH/2+3) x (TW/2+3) x 608 B) in dynamic LDS, NT threads.
+constexpr int C2F_PC = 152;
+template <int TH, int TW, int NT>
+__global__ __launch_bounds__(NT) void k_stem_col2im_f32(const float* __restrict__ patches, float* __restrict__ grad, int n,
+                                                        int h, int w, float istd0, float istd1, float istd2) {
+  constexpr int PH = TH / 2 + 3, PW = TW / 2 + 3;
   extern __shared__ __attribute__((aligned(16))) float c2f_sp[];
   float* const sp = c2f_sp;
   const int oh = h / 2, ow = w / 2;
-  const int x0 = blockIdx.x * C2F_TW, y0 = blockIdx.y * C2F_TH, img = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, img = blockIdx.z;
   const int p0 = y0 / 2 - 1, q0 = x0 / 2 - 1;
   constexpr int VEC = C2F_PC / 4;                                     // 38 sixteen-byte vectors per patch row
-  for (int i = threadIdx.x; i < C2F_PH * C2F_PW * VEC; i += kBlock) {
+#pragma unroll 4
+  for (int i = threadIdx.x; i < PH * PW * VEC; i += NT) {
     const int v = i % VEC, pos = i / VEC;
-    const int pp = p0 + pos / C2F_PW, qq = q0 + pos % C2F_PW;
+    const int pp = p0 + pos / PW, qq = q0 + pos % PW;
     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((unsigned)pp < (unsigned)oh && (unsigned)qq < (unsigned)ow)
       val = *reinterpret_cast<const float4*>(patches + (((size_t)img * oh + pp) * ow + qq) * C2F_PC + v * 4);
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(kBlock) void k_stem_col2im_f32(const float* __restr
   }
   __syncthreads();
   const size_t plane = (size_t)h * w;
-  for (int i = threadIdx.x; i < C2F_TH * C2F_TW; i += kBlock) {
-    const int x = x0 + i % C2F_TW, y = y0 + i / C2F_TW;
+  for (int i = threadIdx.x; i < TH * TW; i += NT) {
+    const int x = x0 + i % TW, y = y0 + i / TW;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     for (int r = (y + 3) & 1; r < 7; r += 2) {
       const int pp = (y + 3 - r) >> 1;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_stem_col2im_f32(const float* __restr
       for (int sft = (x + 3) & 1; sft < 7; sft += 2) {
         const int qq = (x + 3 - sft) >> 1;
         if (x + 3 - sft < 0 || qq >= ow) continue;
-        const float* pt = sp + ((size_t)(pp - p0) * C2F_PW + (qq - q0)) * C2F_PC + (r * 7 + sft) * 3;
+        const float* pt = sp + ((size_t)(pp - p0) * PW + (qq - q0)) * C2F_PC + (r * 7 + sft) * 3;
         g0 += pt[0];
         g1 += pt[1];
         g2 += pt[2];
@@ -225,6 +226,14 @@ __global__ __launch_bounds__(kBlock) void k_stem_col2im_f32(const float* __restr
     o[plane] = g1 * istd1;
     o[2 * plane] = g2 * istd2;
   }
+}
+template <int TH, int TW, int NT>
+int launch_c2f(const float* patches, float* grad, int n, int h, int w, float i0, float i1, float i2, hipStream_t stream) {
+  constexpr int LDS = (TH / 2 + 3) * (TW / 2 + 3) * C2F_PC * 4;
+  if (h % TH || w % TW) return RART_ERR_INVALID;
+  if (!rart_raise_dynamic_lds((const void*)k_stem_col2im_f32<TH, TW, NT>, LDS, "rart_engine_stem_col2im_f32")) return RART_ERR_HIP;
+  hipLaunchKernelGGL((k_stem_col2im_f32<TH, TW, NT>), dim3(w / TW, h / TH, n), dim3(NT), LDS, stream, patches, grad, n, h, w, i0, i1, i2);
+  return RART_OK;
 }
 
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
@@ -288,13 +297,14 @@ int rart_f32_to_pair_rows(const float* src, void* dst_hi, long long dst_lo_off, 
 
 int rart_engine_stem_col2im_f32(const float* patches, float* grad, int n, int h, int w, int patch_cols, const float* std_host,
                                 rart_stream_t stream) {
-  RART_CHECK_ARG(patches && grad && n > 0 && n <= 65535 && h % C2F_TH == 0 && w % C2F_TW == 0 && patch_cols == C2F_PC,
+  RART_CHECK_ARG(patches && grad && n > 0 && n <= 65535 && h % 16 == 0 && w % 32 == 0 && patch_cols == C2F_PC,
                  "rart_engine_stem_col2im_f32: h %% 16 == 0, w %% 32 == 0, patch_cols == 152, n <= 65535");
-  if (!rart_raise_dynamic_lds((const void*)k_stem_col2im_f32, C2F_LDS, "rart_engine_stem_col2im_f32")) return RART_ERR_HIP;
   const float i0 = std_host ? 1.0f / std_host[0] : 1.f, i1 = std_host ? 1.0f / std_host[1] : 1.f,
               i2 = std_host ? 1.0f / std_host[2] : 1.f;
-  hipLaunchKernelGGL(k_stem_col2im_f32, dim3(w / C2F_TW, h / C2F_TH, n), dim3(kBlock), C2F_LDS, (hipStream_t)stream, patches, grad, n, h,
-                     w, i0, i1, i2);
+  // 16 x 32 pixel tiles, 1 024 threads (measured at B = 256: 0.78 ms; 8 x 16 / 256 threads 1.29, 16 x 32 / 256 threads 1.86,
+  // 8 x 32 / 512 0.84, 16 x 16 / 512 0.80: the fill phase wants many loads in flight per CU, the tile few halo re-reads)
+  const int rc = launch_c2f<16, 32, 1024>(patches, grad, n, h, w, i0, i1, i2, (hipStream_t)stream);
+  if (rc != RART_OK) return rc;
   RART_CHECK_LAUNCH("rart_engine_stem_col2im_f32");
   return RART_OK;
 }

@@ -194,8 +194,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int ATT_HD = 64, ATT_LDK = ATT_HD + 8;
 
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+  f2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2_t));
+}
+
 template <int NKT>
-__global__ __launch_bounds__(kBlock, 1) void k_vit_attention(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ att,
+__global__ __launch_bounds__(kBlock, 2) void k_vit_attention(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ att,
                                                              int T, int H, int ld, int D, float scale_log2e) {
   constexpr int TP = NKT * 32, LDV = TP + 4;     // 228-element rows: conflict-free 8-byte reads across 32 lanes
   __shared__ __attribute__((aligned(16))) uint16_t sK[TP * ATT_LDK];
@@ -203,19 +210,30 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention(const uint16_t* __r
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
   const uint16_t* base = qkv + (size_t)b * T * ld + h * ATT_HD;
-  for (int i = tid; i < TP * 8; i += kBlock) {
+  for (int i = tid; i < TP * 8; i += kBlock) {                       // K rows: 16-byte chunks, coalesced
     const int t = i >> 3, c = i & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (t < T) {
-      kv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + c * 8);
-      vv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + 2 * D + c * 8);
-    }
+    uint4 kv = make_uint4(0, 0, 0, 0);
+    if (t < T) kv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + c * 8);
     *reinterpret_cast<uint4*>(sK + t * ATT_LDK + c * 8) = kv;
-    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+  }
+  // V transposed: a thread takes 8 channels of FOUR consecutive tokens and writes eight 8-byte runs (one per channel); consecutive
+  // lanes take consecutive token quads, so a wave's writes to a channel row are contiguous (conflict free)
+  for (int i = tid; i < (TP / 4) * 8; i += kBlock) {
+    const int tq = i % (TP / 4), c = i / (TP / 4);
+    uint32_t w[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      uint4 vv = make_uint4(0, 0, 0, 0);
+      if (tq * 4 + u < T) vv = *reinterpret_cast<const uint4*>(base + (size_t)(tq * 4 + u) * ld + 2 * D + c * 8);
+      w[u][0] = vv.x; w[u][1] = vv.y; w[u][2] = vv.z; w[u][3] = vv.w;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      sVt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(w[j] & 0xFFFF);
-      sVt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(w[j] >> 16);
+      uint16_t* row = sVt + (c * 8 + 2 * j) * LDV + tq * 4;
+      *reinterpret_cast<uint2*>(row) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x05040100u),
+                                                  __builtin_amdgcn_perm(w[3][j], w[2][j], 0x05040100u));
+      *reinterpret_cast<uint2*>(row + LDV) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x07060302u),
+                                                        __builtin_amdgcn_perm(w[3][j], w[2][j], 0x07060302u));
     }
   }
   __syncthreads();
@@ -238,30 +256,46 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention(const uint16_t* __r
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + (kt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kb], sacc[kt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);          // keep the K fragments of later key tiles out of the register file
     }
-    // sacc[kt][r] = q . k for key kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q
+    // sacc[kt][r] = q . k for key kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q: the soft-max statistics of a query live in one lane pair
     float m = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt * 32 + 32 <= T) {                    // (uniform) every key of the tile exists
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float v = key < T ? sacc[kt][r] * scale_log2e : -INFINITY;
-        sacc[kt][r] = v;
-        m = fmaxf(m, v);
+        for (int r = 0; r < 16; ++r) {
+          const float v = sacc[kt][r] * scale_log2e;
+          sacc[kt][r] = v;
+          m = fmaxf(m, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float v = key < T ? sacc[kt][r] * scale_log2e : -INFINITY;
+          sacc[kt][r] = v;
+          m = fmaxf(m, v);
+        }
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    // un-normalised probabilities, packed to bf16 as the B operand of O^T = V^T . P^T (the MFMA's k index is only a summation label:
+    // V^T is read from LDS in the key order the accumulator registers already have); the sum is taken over the ROUNDED values so
+    // that the row of P the matrix core sees sums to one after the final scaling
     float sum = 0.f;
+    uint32_t pk[NKT][8];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - m);
-        sacc[kt][r] = e;
-        sum += e;
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t w = pack_bf16x2(__builtin_amdgcn_exp2f(sacc[kt][2 * j] - m), __builtin_amdgcn_exp2f(sacc[kt][2 * j + 1] - m));
+        pk[kt][j] = w;
+        sum += __uint_as_float(w << 16) + __uint_as_float(w & 0xFFFF0000u);
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 o[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -271,29 +305,26 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention(const uint16_t* __r
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
-        uint32_t pw[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          pw[j] = (uint32_t)f2bf(sacc[kt][8 * kb2 + 2 * j] * inv) | ((uint32_t)f2bf(sacc[kt][8 * kb2 + 2 * j + 1] * inv) << 16);
-        uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-        const bf16x8 pa = *reinterpret_cast<bf16x8*>(&pv);
+        uint4 pv = make_uint4(pk[kt][4 * kb2], pk[kt][4 * kb2 + 1], pk[kt][4 * kb2 + 2], pk[kt][4 * kb2 + 3]);
+        const bf16x8 pb = *reinterpret_cast<bf16x8*>(&pv);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const uint16_t* vr = sVt + (nt * 32 + l31) * LDV + kt * 32 + 16 * kb2 + 4 * hh;
           const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 8);
-          uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, *reinterpret_cast<bf16x8*>(&bv), o[nt], 0, 0, 0);
+          uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av), pb, o[nt], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-    // o[nt][r] = O[query qt*32 + (r&3) + 8*(r>>2) + 4*hh][d = nt*32 + l31]
+    // o[nt][r] = O[query q][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]: a lane owns runs of four channels of ITS query -> 8-byte stores
+    if (q < T) {
+      uint16_t* orow = att + ((size_t)b * T + q) * D + h * ATT_HD;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (qq < T) {
-        uint16_t* orow = att + ((size_t)b * T + qq) * D + h * ATT_HD;
-        orow[l31] = f2bf(o[0][r]);
-        orow[32 + l31] = f2bf(o[1][r]);
-      }
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(orow + nt * 32 + 8 * g + 4 * hh) =
+              make_uint2(pack_bf16x2(o[nt][4 * g] * inv, o[nt][4 * g + 1] * inv), pack_bf16x2(o[nt][4 * g + 2] * inv, o[nt][4 * g + 3] * inv));
     }
   }
 }

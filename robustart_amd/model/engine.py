@@ -486,7 +486,7 @@ class ResNet50Engine:
             e1.record()
             pin, pout = xhw[0] * xhw[1], xhw[0] * xhw[1] // 4
             self.profile.append((2.0 * B * (pin * ca.cin * ca.cout + pout * (9 * cb.cin * cb.cout + cc.cin * cc.cout + ds.cin * ds.cout)),
-                                 e0, e1, 'bottleneck_s2'))
+                                 e0, e1, 'bottleneck_s2_bwd'))
             return
         _lib.check(self.lib.rart_bottleneck_s2_bwd_bf16(
             _lib.ptr(g), _lib.ptr(cc.s2_w3t), _lib.ptr(cb.s2_w2t), _lib.ptr(ca.s2_w1t), _lib.ptr(ds.s2_wdt), _lib.ptr(m2), _lib.ptr(m1),

@@ -36,6 +36,26 @@ def host_uniform(seed, sample, stream_id, index=0):
     return ((w0 >> 5) * 67108864.0 + (w1 >> 6)) / 9007199254740992.0
 
 
+def host_uniform_many(seed, samples, stream_id, index=0):
+    """host_uniform for an array of sample indices at once (numpy uint64 lanes; same values as the scalar form)."""
+    import numpy as np
+    M = np.uint64(_M)
+    k0, k1 = np.uint64(seed & _M), np.uint64((seed >> 32) & _M)
+    ks = (k0, k1, np.uint64(0x1BD11BDA) ^ k0 ^ k1)
+    x0 = (np.full(len(samples), ctr0(index, stream_id), dtype=np.uint64) + ks[0]) & M
+    x1 = ((np.asarray(samples, dtype=np.uint64) & M) + ks[1]) & M
+    for r in range(ROUNDS):
+        x0 = (x0 + x1) & M
+        rot = np.uint64(_R[r & 7])
+        x1 = ((x1 << rot) | (x1 >> (np.uint64(32) - rot))) & M
+        x1 ^= x0
+        if (r & 3) == 3:
+            sft = (r >> 2) + 1
+            x0 = (x0 + ks[sft % 3]) & M
+            x1 = (x1 + ks[(sft + 1) % 3] + np.uint64(sft)) & M
+    return ((x0 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (x1 >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
+
+
 class _State:
     seed = 0
     sample_offset = 0

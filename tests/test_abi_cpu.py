@@ -121,3 +121,13 @@ def test_threefry_known_answers():
            (20, (0x243f6a88, 0x85a308d3), (0x13198a2e, 0x03707344), (0xc4923a9c, 0x483df7a0))]
     for rounds, ctr, key, want in kat:
         assert threefry2x32(key[0], key[1], ctr[0], ctr[1], rounds) == want
+
+
+def test_host_uniform_vector_form_equals_the_scalar_form():
+    """rng.host_uniform_many (numpy lanes; the per-image frost draws of a batch) == rng.host_uniform element by element."""
+    import numpy as np
+    from robustart_amd.noise import rng
+    for seed, stream, index in ((0, 8, 0), (0x1234567890ABCDEF, 9, 3), (2 ** 64 - 1, 10, 0x0FFFFFFF)):
+        samples = np.array([0, 1, 2, 255, 2 ** 31, 2 ** 32 - 1, 2 ** 32 + 5], dtype=np.int64)
+        want = np.array([rng.host_uniform(seed, int(s), stream, index) for s in samples])
+        np.testing.assert_array_equal(rng.host_uniform_many(seed, samples, stream, index), want)

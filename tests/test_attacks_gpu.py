@@ -229,7 +229,7 @@ def test_fab_l2_l1_projections_and_fab_t_match_reference():
     n = 3 * 224 * 224
     t2 = torch.rand(5, n, generator=gen)
     w2 = torch.randn(5, n, generator=gen) * 1e-3
-    w2[4] = (w2[4] * 64).round() / 64 * 0.05            # many tied |w| values: the L1 greedy order is then by index
+    w2[4] = (w2[4] * 4e3).round() / 4e3                  # multiples of 2.5e-4: many tied |w| values: the L1 greedy order is then by index
     b2 = ((w2 * t2).sum(1) + torch.tensor([0.5, -0.3, 2.0, -1e3, 0.7])).contiguous()
     t2c, w2c, b2c = t2.cuda(), w2.cuda(), b2.cuda()
     for norm, fn in (('L2', A.fab_projection_l2), ('L1', A.fab_projection_l1)):

@@ -161,6 +161,31 @@ def test_frost_blend_bit_exact():
         np.testing.assert_array_equal(got, want)
 
 
+def test_frost_native_crops_are_gathered_on_the_device():
+    """Native frost (corruptions.py:247-266): the texture index and the crop origin are per-image counter draws; the photographs are
+    uploaded once and the 224 x 224 crops gathered on the device.  Against the oracle blend of the same crops taken on the host."""
+    from robustart_amd.noise import imagenet_c as C, rng as _rng
+    rs = np.random.RandomState(5)
+    texs = [rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in ((300, 340), (260, 400), (512, 512), (225, 225), (330, 250), (280, 280))]
+    C.set_frost_textures(texs)
+    try:
+        batch = make_batch_u8(6, seed=32)
+        seed, off = 1234, 40
+        for sev in (2, 4):
+            x = torch.from_numpy(batch.copy()).cuda()
+            C.corrupt_batch_(x, _cid('frost'), sev, seed=seed, sample_offset=off)
+            want = []
+            for i in range(6):
+                idx = int(_rng.host_uniform(seed, off + i, 8) * 5)
+                t = texs[idx]
+                xs = int(_rng.host_uniform(seed, off + i, 9) * (t.shape[0] - 224))
+                ys = int(_rng.host_uniform(seed, off + i, 10) * (t.shape[1] - 224))
+                want.append(O.corrupt('frost', batch[i], sev, {'texture': t[xs:xs + 224, ys:ys + 224]}))
+            np.testing.assert_array_equal(x.cpu().numpy(), np.stack(want))
+    finally:
+        C.set_frost_textures([])
+
+
 def test_frost_without_textures_raises():
     from robustart_amd.noise import imagenet_c as C
     C.set_frost_textures([])
