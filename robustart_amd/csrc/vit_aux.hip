@@ -258,40 +258,32 @@ __global__ __launch_bounds__(kBlock, 2) void k_vit_attention(const uint16_t* __r
       }
       __builtin_amdgcn_sched_barrier(0);          // keep the K fragments of later key tiles out of the register file
     }
-    // sacc[kt][r] = q . k for key kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q: the soft-max statistics of a query live in one lane pair
+    // sacc[kt][r] = q . k for key kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q: the soft-max statistics of a query live in one lane pair.
+    // The soft-max is the VALU-bound part of the kernel (112 scores per lane), so it is kept to max (v_max3), one fma folding the
+    // 1/sqrt(d) log2(e) scale into the exponent, v_exp, one add and the bf16 pack per score.
     float m = -INFINITY;
+    // keys past the sequence must not win the maximum: only the LAST key tile can hold any (the host picks NKT = ceil(T / 32))
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt * 32 + 32 <= T) {                    // (uniform) every key of the tile exists
+    for (int r = 0; r < 16; ++r)
+      if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= T) sacc[NKT - 1][r] = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = sacc[kt][r] * scale_log2e;
-          sacc[kt][r] = v;
-          m = fmaxf(m, v);
-        }
-      } else {
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float v = key < T ? sacc[kt][r] * scale_log2e : -INFINITY;
-          sacc[kt][r] = v;
-          m = fmaxf(m, v);
-        }
-      }
-    }
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kt][r]);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mneg = -m * scale_log2e;            // scale > 0: max(s) * scale == max(s * scale)
     // un-normalised probabilities, packed to bf16 as the B operand of O^T = V^T . P^T (the MFMA's k index is only a summation label:
-    // V^T is read from LDS in the key order the accumulator registers already have); the sum is taken over the ROUNDED values so
-    // that the row of P the matrix core sees sums to one after the final scaling
+    // V^T is read from LDS in the key order the accumulator registers already have); O is scaled by 1 / sum at the end
     float sum = 0.f;
     uint32_t pk[NKT][8];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const uint32_t w = pack_bf16x2(__builtin_amdgcn_exp2f(sacc[kt][2 * j] - m), __builtin_amdgcn_exp2f(sacc[kt][2 * j + 1] - m));
-        pk[kt][j] = w;
-        sum += __uint_as_float(w << 16) + __uint_as_float(w & 0xFFFF0000u);
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][2 * j], scale_log2e, mneg));
+        const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][2 * j + 1], scale_log2e, mneg));
+        pk[kt][j] = pack_bf16x2(e0, e1);
+        sum += e0 + e1;
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
@@ -657,8 +649,16 @@ int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads,
   RART_CHECK_ARG(tokens <= 224, "rart_vit_attention: at most 224 tokens (197 for 224x224 / patch 16)");
   const int D = heads * head_dim;
   const float scale_log2e = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(k_vit_attention<7>, dim3((uint32_t)(n * heads)), dim3(kBlock), 0, (hipStream_t)stream,
-                     (const uint16_t*)qkv, (uint16_t*)out, tokens, heads, 3 * D, D, scale_log2e);
+  const dim3 grid((uint32_t)(n * heads));
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t* q = (const uint16_t*)qkv;
+  uint16_t* o = (uint16_t*)out;
+#define RART_ATT_CASE(N) case N: hipLaunchKernelGGL(k_vit_attention<N>, grid, dim3(kBlock), 0, st, q, o, tokens, heads, 3 * D, D, scale_log2e); break;
+  switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
+    RART_ATT_CASE(1) RART_ATT_CASE(2) RART_ATT_CASE(3) RART_ATT_CASE(4) RART_ATT_CASE(5) RART_ATT_CASE(6)
+    default: hipLaunchKernelGGL(k_vit_attention<7>, grid, dim3(kBlock), 0, st, q, o, tokens, heads, 3 * D, D, scale_log2e); break;
+  }
+#undef RART_ATT_CASE
   RART_CHECK_LAUNCH("rart_vit_attention");
   return RART_OK;
 }
