@@ -197,6 +197,18 @@ int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int 
 int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0, int batch, int c, int h, int w,
                              float eps, int vh, int vw, int s, const float* sign_host, rart_stream_t stream);
 
+/* Square attack, norm 2 = L2 / 1 = L1 (Attacks/autoattack/square.py:123-190, 296-530); all pointers are device pointers.
+ * rart_square_init_lp: the start perturbation -- tiles of side s on a tiles_h x tiles_w grid from (sp, sp), tile t carries
+ *   eta2[transposed[t]] (eta2 = [2][s*s]: eta(s) and its transpose, :172-190) times signs[t][image][channel] (+-1).  L2: out = the start
+ *   point clamp(x0 + delta / (||delta||_2 + 1e-12) * eps, 0, 1); L1: out = delta (add rart_l1_project(x0, delta, eps (1 - 1e-6)), :425-426).
+ * rart_square_propose_lp: one query -- window (vh, vw) of side s gets eta * signs[image][channel] + delta / (1e-12 + |delta|_window),
+ *   rescaled to the budget left (:347-362 / :461-476), window (vh2, vw2) is cleared.  L2: out = the candidate point; L1: out = the new
+ *   delta (then rart_l1_project, :483-484).  One workgroup per image; c <= 4. */
+int rart_square_init_lp(float* out, const float* x0, int batch, int c, int h, int w, float eps, int norm, int s, int sp, int tiles_h,
+                        int tiles_w, const float* eta2, const uint8_t* transposed, const float* signs, rart_stream_t stream);
+int rart_square_propose_lp(float* out, const float* x_best, const float* x0, int batch, int c, int h, int w, float eps, int norm, int vh,
+                           int vw, int vh2, int vw2, int s, const float* eta, const float* signs, rart_stream_t stream);
+
 /* FAB, Linf (Attacks/autoattack/fab_projections.py:7-59, fab_base.py:168-245).
  * rart_fab_project_linf: per row r, the box-constrained Linf projection step d of points[r] onto {x: w[r].x = b[r]};
  *   rowmax_out[r] = max|d[r]| (nullable).  One workgroup per row, bisection on the monotone piecewise-linear

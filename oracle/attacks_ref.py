@@ -553,6 +553,129 @@ def square_linf_perturb(model_fn, x, y, eps, n_queries, p_init, rescale, init_si
 
 
 # ---------------------------------------------------------------------------------------
+# Square attack, L2 and L1 (Attacks/autoattack/square.py:123-190, 296-530) -- pinned (tests/golden/square_lp_ref.npz)
+# ---------------------------------------------------------------------------------------
+
+def square_eta_rectangles(x, y, norm):
+    """square.py:146-170: concentric rectangles of weight 1 / k^2 (L2) or 1 / k^4 (L1), normalised."""
+    delta = torch.zeros([x, y])
+    x_c, y_c = x // 2 + 1, y // 2 + 1
+    c0, c1 = x_c - 1, y_c - 1
+    power = 2 if norm == 'L2' else 4
+    for k in range(0, max(x_c, y_c)):
+        delta[max(c0, 0):min(c0 + (2 * k + 1), x), max(0, c1):min(c1 + (2 * k + 1), y)] += \
+            1.0 / (torch.Tensor([k + 1]).view(1, 1) ** power)
+        c0 -= 1
+        c1 -= 1
+    if norm == 'L2':
+        delta /= (delta ** 2).sum(dim=(0, 1), keepdim=True).sqrt()
+    else:
+        delta /= delta.abs().sum()
+    return delta
+
+
+def square_eta(s, norm, transpose):
+    """square.py:172-190; `transpose` is the torch.rand([1]) > 0.5 draw of :187."""
+    delta = torch.zeros([s, s])
+    delta[:s // 2] = square_eta_rectangles(s // 2, s, norm)
+    delta[s // 2:] = -1. * square_eta_rectangles(s - s // 2, s, norm)
+    if norm == 'L2':
+        delta /= (delta ** 2).sum(dim=(0, 1), keepdim=True).sqrt()
+    else:
+        delta /= delta.abs().sum()
+    return delta.permute([1, 0]) if transpose else delta
+
+
+def _square_lp_norm(v, norm):
+    f = v.reshape(v.shape[0], -1)
+    t = (f ** 2).sum(-1).sqrt() if norm == 'L2' else f.abs().sum(dim=-1)
+    return t.view(-1, 1, 1, 1)
+
+
+def square_lp_single_run(model_fn, x, y, eps, n_queries, p_init, rescale, norm, draws):
+    """square.py:296-530 (norm 'L2' / 'L1', loss 'margin').  draws.square_lp_init_tile(n, c) -> (transpose, signs [n, c]) per start
+    tile in the reference's order; draws.square_lp_query(h, w, s, n_curr, c) -> (vh, vw, vh2, vw2, transpose, signs [n_curr, c])."""
+    with torch.no_grad():
+        c, h, w = x.shape[1:]
+        n_features = c * h * w
+        delta_init = torch.zeros_like(x)
+        s = h // 5
+        sp_init = (h - s * 5) // 2
+        vh = sp_init
+        for _ in range(h // s):
+            vw = sp_init
+            for _ in range(w // s):
+                tr, sg = draws.square_lp_init_tile(x.shape[0], c)
+                delta_init[:, :, vh:vh + s, vw:vw + s] += square_eta(s, norm, tr).view(1, 1, s, s) * sg.view(-1, c, 1, 1)
+                vw += s
+            vh += s
+        if norm == 'L2':
+            x_best = torch.clamp(x + delta_init / (_square_lp_norm(delta_init, norm) + 1e-12) * eps, 0., 1.)
+        else:
+            x_best = x + delta_init + l1_projection(x, delta_init, eps * (1. - 1e-6))
+        margin_min = margin_loss(model_fn(x_best), y)
+        loss_min = margin_min.clone()
+        for i_iter in range(n_queries):
+            idx = (margin_min > 0.0).nonzero().flatten()
+            if idx.numel() == 0:
+                break
+            x_curr, x_best_curr, y_curr = x[idx], x_best[idx], y[idx]
+            delta_curr = x_best_curr - x_curr
+            p = square_p_selection(i_iter, p_init, n_queries, rescale)
+            s = max(int(round(math.sqrt(p * n_features / c))), 3)
+            if s % 2 == 0:
+                s += 1
+            vh, vw, vh2, vw2, tr, sg = draws.square_lp_query(h, w, s, idx.numel(), c)
+            win1 = delta_curr[:, :, vh:vh + s, vw:vw + s]
+            mask = torch.zeros_like(x_curr)
+            mask[:, :, vh:vh + s, vw:vw + s] = 1.0
+            mask[:, :, vh2:vh2 + s, vw2:vw2 + s] = 1.0
+            norms_image = _square_lp_norm(x_best_curr - x_curr, norm)
+            new_deltas = torch.ones([x_curr.shape[0], c, s, s]) * (square_eta(s, norm, tr).view(1, 1, s, s) * sg.view(-1, c, 1, 1))
+            if norm == 'L2':
+                norms_window_1 = (win1 ** 2).sum(dim=(-2, -1), keepdim=True).sqrt()
+                norms_windows = ((delta_curr * mask) ** 2).sum(dim=(-2, -1), keepdim=True).sqrt()
+                new_deltas += win1 / (1e-12 + norms_window_1)
+                new_deltas = new_deltas / (1e-12 + (new_deltas ** 2).sum(dim=(-2, -1), keepdim=True).sqrt()) * (torch.max(
+                    (eps * torch.ones_like(new_deltas)) ** 2 - norms_image ** 2, torch.zeros_like(new_deltas)) / c +
+                    norms_windows ** 2).sqrt()
+            else:
+                norms_window_1 = win1.abs().sum(dim=(-2, -1), keepdim=True)
+                norms_windows = (delta_curr * mask).abs().sum(dim=(-2, -1), keepdim=True)
+                new_deltas += win1 / (1e-12 + norms_window_1)
+                new_deltas = new_deltas / (1e-12 + new_deltas.abs().sum(dim=(-2, -1), keepdim=True)) * (torch.max(
+                    eps * torch.ones_like(norms_image) - norms_image, torch.zeros_like(norms_image)) / c + norms_windows) * c
+            delta_curr[:, :, vh2:vh2 + s, vw2:vw2 + s] = 0.
+            delta_curr[:, :, vh:vh + s, vw:vw + s] = new_deltas + 0
+            if norm == 'L2':
+                x_new = torch.clamp(x_curr + delta_curr / (_square_lp_norm(delta_curr, norm) + 1e-12) * eps, 0., 1.)
+            else:
+                x_new = x_curr + delta_curr + l1_projection(x_curr, delta_curr, eps * (1. - 1e-6))
+            margin = margin_loss(model_fn(x_new), y_curr)
+            loss = margin
+            improved = (loss < loss_min[idx]).float()
+            loss_min[idx] = improved * loss + (1. - improved) * loss_min[idx]
+            improved = torch.max(improved, (margin <= 0.).float())
+            margin_min[idx] = improved * margin + (1. - improved) * margin_min[idx]
+            improved = improved.view(-1, 1, 1, 1)
+            x_best[idx] = improved * x_new + (1. - improved) * x_best_curr
+        return x_best
+
+
+def square_lp_perturb(model_fn, x, y, eps, n_queries, p_init, rescale, norm, draws):
+    """square.py:532-600 (n_restarts = 1)."""
+    x = x.detach().clone()
+    adv = x.clone()
+    acc = model_fn(x).max(1)[1] == y
+    ind = acc.nonzero().flatten()
+    if ind.numel() != 0:
+        adv_curr = square_lp_single_run(model_fn, x[ind], y[ind], eps, n_queries, p_init, rescale, norm, draws)
+        fooled = (model_fn(adv_curr).max(1)[1] != y[ind]).nonzero().flatten()
+        adv[ind[fooled]] = adv_curr[fooled]
+    return adv
+
+
+# ---------------------------------------------------------------------------------------
 # FAB, targeted, Linf / L2 / L1 (Attacks/autoattack/fab_base.py:84-336, fab_pt.py:102-117,
 # fab_projections.py:7-166) -- pinned (tests/golden/attacks_ref.npz: fabproj/*, fabproj_l2/*, fabproj_l1/*, fabt/{Linf,L2,L1}/adv)
 # ---------------------------------------------------------------------------------------
@@ -785,6 +908,18 @@ class TorchStreamDraws:
     def square_init(self, n, c, w):
         return torch.sign(2 * torch.rand([n, c, 1, w]) - 1)
 
+    def square_lp_init_tile(self, n, c):                 # eta(): rand([1]) > 0.5 (square.py:187), then random_choice([n, c, 1, 1]) (:304-306)
+        tr = bool(torch.rand([1]) > 0.5)
+        return tr, torch.sign(2 * torch.rand([n, c, 1, 1]) - 1).view(n, c)
+
+    def square_lp_query(self, h, w, s, n_curr, c):       # square.py:333-355: four random_int, eta's transposition, the signs
+        vh = int((0 + (h - s) * torch.rand([1])).long())
+        vw = int((0 + (w - s) * torch.rand([1])).long())
+        vh2 = int((0 + (h - s) * torch.rand([1])).long())
+        vw2 = int((0 + (w - s) * torch.rand([1])).long())
+        tr = bool(torch.rand([1]) > 0.5)
+        return vh, vw, vh2, vw2, tr, torch.sign(2 * torch.rand([n_curr, c, 1, 1]) - 1).view(n_curr, c)
+
     def square_draws(self, c, h, w, n_queries, p_init=0.8, rescale=False):
         outer = self
 
@@ -800,7 +935,7 @@ class TorchStreamDraws:
 
 
 def autoattack_linf(model_fn, x_orig, y_orig, eps, draws, plan=('apgd-ce', 'apgd-t', 'fab-t', 'square'), apgd_iter=100,
-                    apgdt_iter=100, apgdt_classes=9, fab_iter=100, fab_classes=9, square_queries=5000, trace=None):
+                    apgdt_iter=100, apgdt_classes=9, fab_iter=100, fab_classes=9, square_queries=5000, trace=None, norm='Linf'):
     """AutoAttack.run_standard_evaluation (autoattack.py:90-211) with bs >= len(x), version 'standard' hyper-parameters
     (autoattack.py:253-267) unless overridden.  model_fn takes x in [0,1] (NormalizeModel already applied).
     draws: a TorchStreamDraws-like object; trace (list) receives (attack, robust_flags copy) after every attack."""
@@ -814,13 +949,16 @@ def autoattack_linf(model_fn, x_orig, y_orig, eps, draws, plan=('apgd-ce', 'apgd
             idcs = robust.nonzero().flatten()                                # :125-135
             x, y = x_orig[idcs].clone(), y_orig[idcs].clone()
             draws.reseed()                                                   # each perturb() re-seeds with the same seed
+            start = draws.randn if norm == 'L2' else draws.pm1              # autopgd_base.py:214-221 (norm 'Linf' / 'L2' here)
             with torch.enable_grad():
                 if attack == 'apgd-ce':
-                    adv_curr = apgd_perturb(model_fn, x, y, 'Linf', eps, apgd_iter, 'ce', draws.pm1, 1)
+                    adv_curr = apgd_perturb(model_fn, x, y, norm, eps, apgd_iter, 'ce', start, 1)
                 elif attack == 'apgd-t':
-                    adv_curr = apgd_targeted_perturb(model_fn, x, y, 'Linf', eps, apgdt_iter, draws.pm1, apgdt_classes)
+                    adv_curr = apgd_targeted_perturb(model_fn, x, y, norm, eps, apgdt_iter, start, apgdt_classes)
                 elif attack == 'fab-t':
-                    adv_curr = fab_targeted_perturb(model_fn, x, y, eps, fab_iter, fab_classes)
+                    adv_curr = fab_targeted_perturb(model_fn, x, y, eps, fab_iter, fab_classes, norm=norm)
+                elif attack == 'square' and norm != 'Linf':
+                    adv_curr = square_lp_perturb(model_fn, x, y, eps, square_queries, 0.8, False, norm, draws)
                 elif attack == 'square':
                     adv_curr = square_linf_perturb(model_fn, x, y, eps, square_queries, 0.8, False,
                                                    lambda n: draws.square_init(n, c, w),

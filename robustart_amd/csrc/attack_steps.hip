@@ -900,6 +900,135 @@ __global__ __launch_bounds__(kFabThreads) void k_row_norm_diff(const float* __re
     if (threadIdx.x == 0) out[row] = NORM == 1 ? (float)acc : (float)sqrt(acc);
   }
 }
+// ---- Square attack, L2 / L1 (Attacks/autoattack/square.py:296-530) ---------------------------------------------------------
+// One workgroup per image (the norms couple all channels of an image).  NORM 2: sums of squares and square roots; NORM 1: sums
+// of absolute values.  kSqC = channels supported (images are RGB).
+constexpr int kSqC = 4;
+template <int NORM>
+__device__ __forceinline__ float sq_mag(float v) { return NORM == 2 ? v * v : fabsf(v); }
+template <int NORM>
+__device__ __forceinline__ float sq_root(double v) { return NORM == 2 ? sqrtf((float)v) : (float)v; }
+
+// Start point (:297-312 / :410-426): delta_init = on each tile of the tiles_h x tiles_w grid (side s, origin sp) the pattern eta(s)
+// (transposed when the tile's draw says so) times the tile's per-(image, channel) sign.  NORM 2: out = clamp(x0 + delta /
+// (||delta||_2 + 1e-12) * eps, 0, 1).  NORM 1: out = delta_init (the caller adds L1_projection(x0, delta, eps (1 - 1e-6))).
+template <int NORM>
+__global__ __launch_bounds__(kFabThreads) void k_square_init_lp(float* __restrict__ out, const float* __restrict__ x0, int B, int C,
+                                                                int H, int W, float eps, int s, int sp, int tiles_h, int tiles_w,
+                                                                const float* __restrict__ eta2, const uint8_t* __restrict__ transposed,
+                                                                const float* __restrict__ signs) {
+  __shared__ double sh[kFabThreads / 64];
+  const int b = blockIdx.x;
+  const size_t plane = (size_t)H * W, n = (size_t)C * plane, base = (size_t)b * n;
+  auto delta_at = [&](int c, int y, int x) -> float {
+    const int ry = y - sp, rx = x - sp;
+    if (ry < 0 || rx < 0) return 0.f;
+    const int ty = ry / s, tx = rx / s;
+    if (ty >= tiles_h || tx >= tiles_w) return 0.f;
+    const int t = ty * tiles_w + tx;
+    const float e = eta2[(size_t)(transposed[t] ? 1 : 0) * s * s + (size_t)(ry - ty * s) * s + (rx - tx * s)];
+    return e * signs[((size_t)t * B + b) * C + c];
+  };
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const int c = (int)(i / plane), r = (int)(i - (size_t)c * plane);
+    const float d = delta_at(c, r / W, r % W);
+    if (NORM == 1) out[base + i] = d;
+    acc += (double)sq_mag<NORM>(d);
+  }
+  if (NORM == 1) return;
+  const float t = sq_root<NORM>(fab_block_sum(acc, sh));
+  for (size_t i = threadIdx.x; i < n; i += kFabThreads) {
+    const int c = (int)(i / plane), r = (int)(i - (size_t)c * plane);
+    const float d = delta_at(c, r / W, r % W);
+    out[base + i] = clampf(x0[base + i] + d / (t + 1e-12f) * eps, 0.f, 1.f);
+  }
+}
+
+// One query (:314-377 / :428-486).  delta = x_best - x0; window 1 at (vh, vw) receives eta * sign + delta / (1e-12 + |delta|_win1),
+// rescaled to the budget the image has left plus what the two windows held; window 2 at (vh2, vw2) is cleared (where it does not
+// overlap window 1).  NORM 2: out = clamp(x0 + delta' / (||delta'||_2 + 1e-12) * eps, 0, 1); NORM 1: out = delta'.
+template <int NORM>
+__global__ __launch_bounds__(kFabThreads) void k_square_propose_lp(float* __restrict__ out, const float* __restrict__ xb,
+                                                                   const float* __restrict__ x0, int C, int H, int W, float eps, int vh,
+                                                                   int vw, int vh2, int vw2, int s, const float* __restrict__ eta,
+                                                                   const float* __restrict__ signs) {
+  __shared__ double sh[kFabThreads / 64];
+  const int b = blockIdx.x;
+  const size_t plane = (size_t)H * W, n = (size_t)C * plane, base = (size_t)b * n;
+  double s_all = 0.0, s_w1[kSqC], s_un[kSqC];
+#pragma unroll
+  for (int c = 0; c < kSqC; ++c) s_w1[c] = s_un[c] = 0.0;
+#pragma unroll
+  for (int c = 0; c < kSqC; ++c) {
+    if (c >= C) break;
+    for (size_t r = threadIdx.x; r < plane; r += kFabThreads) {
+      const int y = (int)(r / W), x = (int)(r - (size_t)y * W);
+      const size_t i = base + (size_t)c * plane + r;
+      const double v = (double)sq_mag<NORM>(xb[i] - x0[i]);
+      const bool in1 = (unsigned)(y - vh) < (unsigned)s && (unsigned)(x - vw) < (unsigned)s;
+      const bool in2 = (unsigned)(y - vh2) < (unsigned)s && (unsigned)(x - vw2) < (unsigned)s;
+      s_all += v;
+      if (in1) s_w1[c] += v;
+      if (in1 || in2) s_un[c] += v;
+    }
+  }
+  const float n_img = sq_root<NORM>(fab_block_sum(s_all, sh));
+  float n_w1[kSqC], n_un[kSqC], fac[kSqC], n_new[kSqC];
+#pragma unroll
+  for (int c = 0; c < kSqC; ++c) {
+    n_w1[c] = n_un[c] = fac[c] = n_new[c] = 0.f;
+    if (c < C) {
+      n_w1[c] = sq_root<NORM>(fab_block_sum(s_w1[c], sh));
+      n_un[c] = sq_root<NORM>(fab_block_sum(s_un[c], sh));
+    }
+  }
+  auto fresh = [&](int c, int wy, int wx) -> float {           // eta * sign + delta / (1e-12 + |delta|_win1), before the rescaling
+    const size_t i = base + (size_t)c * plane + (size_t)(vh + wy) * W + (vw + wx);
+    return eta[wy * s + wx] * signs[(size_t)b * C + c] + (xb[i] - x0[i]) / (1e-12f + n_w1[c]);
+  };
+#pragma unroll
+  for (int c = 0; c < kSqC; ++c) {
+    if (c >= C) break;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < s * s; i += kFabThreads) acc += (double)sq_mag<NORM>(fresh(c, i / s, i % s));
+    n_new[c] = sq_root<NORM>(fab_block_sum(acc, sh));
+    if (NORM == 2) fac[c] = sqrtf(fmaxf(eps * eps - n_img * n_img, 0.f) / (float)C + n_un[c] * n_un[c]);
+    else fac[c] = fmaxf(eps - n_img, 0.f) / (float)C + n_un[c];
+  }
+  auto delta_new = [&](int c, int y, int x, size_t i) -> float {
+    if ((unsigned)(y - vh) < (unsigned)s && (unsigned)(x - vw) < (unsigned)s) {
+      const float v = fresh(c, y - vh, x - vw) / (1e-12f + n_new[c]) * fac[c];
+      return NORM == 2 ? v : v * (float)C;
+    }
+    if ((unsigned)(y - vh2) < (unsigned)s && (unsigned)(x - vw2) < (unsigned)s) return 0.f;
+    return xb[i] - x0[i];
+  };
+  double tot = 0.0;
+#pragma unroll
+  for (int c = 0; c < kSqC; ++c) {
+    if (c >= C) break;
+    for (size_t r = threadIdx.x; r < plane; r += kFabThreads) {
+      const int y = (int)(r / W), x = (int)(r - (size_t)y * W);
+      const size_t i = base + (size_t)c * plane + r;
+      const float d = delta_new(c, y, x, i);
+      if (NORM == 1) out[i] = d;
+      tot += (double)sq_mag<NORM>(d);
+    }
+  }
+  if (NORM == 1) return;
+  const float t = sq_root<NORM>(fab_block_sum(tot, sh));
+#pragma unroll
+  for (int c = 0; c < kSqC; ++c) {
+    if (c >= C) break;
+    for (size_t r = threadIdx.x; r < plane; r += kFabThreads) {
+      const int y = (int)(r / W), x = (int)(r - (size_t)y * W);
+      const size_t i = base + (size_t)c * plane + r;
+      out[i] = clampf(x0[i] + delta_new(c, y, x, i) / (t + 1e-12f) * eps, 0.f, 1.f);
+    }
+  }
+}
+
 // x1 = clamp((x1 + eta*d1)*(1 - alpha) + (x0 + eta*d2)*alpha, 0, 1)   (fab_base.py:218-219)
 __global__ __launch_bounds__(kBlock) void k_fab_update(float* __restrict__ x1, const float* __restrict__ x0,
                                                        const float* __restrict__ d1, const float* __restrict__ d2,
@@ -1201,6 +1330,30 @@ int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int 
   return RART_OK;
 }
 
+int rart_square_init_lp(float* out, const float* x0, int batch, int c, int h, int w, float eps, int norm, int s, int sp, int tiles_h,
+                        int tiles_w, const float* eta2, const uint8_t* transposed, const float* signs, rart_stream_t stream) {
+  RART_CHECK_ARG(out && x0 && eta2 && transposed && signs && batch > 0 && c > 0 && c <= kSqC && h > 0 && w > 0 && (norm == 1 || norm == 2),
+                 "rart_square_init_lp: bad arguments");
+  RART_CHECK_ARG(s > 0 && sp >= 0 && tiles_h > 0 && tiles_w > 0 && sp + tiles_h * s <= h && sp + tiles_w * s <= w,
+                 "rart_square_init_lp: the tile grid must lie inside the image");
+  auto kern = norm == 2 ? k_square_init_lp<2> : k_square_init_lp<1>;
+  hipLaunchKernelGGL(kern, dim3(batch), dim3(kFabThreads), 0, (hipStream_t)stream, out, x0, batch, c, h, w, eps, s, sp, tiles_h, tiles_w,
+                     eta2, transposed, signs);
+  RART_CHECK_LAUNCH("rart_square_init_lp");
+  return RART_OK;
+}
+int rart_square_propose_lp(float* out, const float* x_best, const float* x0, int batch, int c, int h, int w, float eps, int norm, int vh,
+                           int vw, int vh2, int vw2, int s, const float* eta, const float* signs, rart_stream_t stream) {
+  RART_CHECK_ARG(out && x_best && x0 && eta && signs && batch > 0 && c > 0 && c <= kSqC && h > 0 && w > 0 && (norm == 1 || norm == 2),
+                 "rart_square_propose_lp: bad arguments");
+  RART_CHECK_ARG(s > 0 && vh >= 0 && vw >= 0 && vh + s <= h && vw + s <= w && vh2 >= 0 && vw2 >= 0 && vh2 + s <= h && vw2 + s <= w,
+                 "rart_square_propose_lp: window outside the image");
+  auto kern = norm == 2 ? k_square_propose_lp<2> : k_square_propose_lp<1>;
+  hipLaunchKernelGGL(kern, dim3(batch), dim3(kFabThreads), 0, (hipStream_t)stream, out, x_best, x0, c, h, w, eps, vh, vw, vh2, vw2, s,
+                     eta, signs);
+  RART_CHECK_LAUNCH("rart_square_propose_lp");
+  return RART_OK;
+}
 int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0, int batch, int c, int h, int w,
                              float eps, int vh, int vw, int s, const float* sign_host, rart_stream_t stream) {
   RART_CHECK_ARG(x_new && x_best && x0 && sign_host && batch > 0 && c > 0 && c <= 8 && h > 0 && w > 0 && s > 0,

@@ -16,6 +16,8 @@ and the ImageNet mean/std are applied here (imfgsm_attack.py:14-23, autoattack.p
 """
 import warnings
 
+import numpy as np
+
 from .. import _lib
 from . import rng as _rng
 
@@ -585,6 +587,125 @@ def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, resc
     return adv
 
 
+def _square_eta(s, norm):
+    """SquareAttack.eta without its random transposition (square.py:146-186): the +/- pattern of concentric rectangles, weights
+    1 / k^2 (L2) or 1 / k^4 (L1), normalised in the attack's norm.  Host side, s x s fp32, once per window size."""
+    import torch
+
+    def rectangles(x, y):
+        delta = torch.zeros([x, y])
+        c0, c1 = x // 2, y // 2
+        for k in range(0, max(x // 2 + 1, y // 2 + 1)):
+            delta[max(c0, 0):min(c0 + (2 * k + 1), x), max(0, c1):min(c1 + (2 * k + 1), y)] += \
+                1.0 / (torch.Tensor([k + 1]).view(1, 1) ** (2 if norm == 'L2' else 4))
+            c0 -= 1
+            c1 -= 1
+        return delta / ((delta ** 2).sum().sqrt() if norm == 'L2' else delta.abs().sum())
+    delta = torch.zeros([s, s])
+    delta[:s // 2] = rectangles(s // 2, s)
+    delta[s // 2:] = -1. * rectangles(s - s // 2, s)
+    return delta / ((delta ** 2).sum().sqrt() if norm == 'L2' else delta.abs().sum())
+
+
+def square_lp_perturb(model_fn, x, y, norm='L2', eps=0.5, n_queries=5000, p_init=0.8, rescale=False, seed=None, sample_offset=None,
+                      draws=None, check_every=50, _prov=None, _return_best=False):
+    """SquareAttack.perturb, norm 'L2' / 'L1', loss 'margin', n_restarts 1 (Attacks/autoattack/square.py:296-530, 532-600).
+    Per query: one proposal kernel (one workgroup per image: the window and image norms, the fresh window, the rescaling and -- L2 --
+    the renormalised candidate), for L1 the box-constrained L1 projection (rart_l1_project), one model forward, the margin kernel
+    and a masked row select.  The full batch runs with masks (the reference gathers the still-unfooled subset every query).
+    draws (parity tests): an object with square_lp_init_tile(n, c) and square_lp_query(h, w, s, n_curr, c) replaying the reference's
+    random stream, whose sign rows belong to the CURRENT unfooled subset -- that mode reads the subset size back every query.
+    _return_best (tests): also return the best point of every initially-correct image (attack_single_run's x_best) and their index."""
+    import math
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    if norm not in ('L2', 'L1'):
+        raise ValueError('norm not supported')
+    nid = 2 if norm == 'L2' else 1
+    prov = _prov or _Provider(model_fn, normalize_inside=False)
+    x, y = _check_inputs(x, y)
+    sample_offset = _offset(sample_offset, x.shape[0])
+    adv = x.clone()
+    acc = prov.logits(x).max(1)[1] == y
+    ind = acc.nonzero().flatten()
+    if ind.numel() == 0:
+        return adv
+    x0, yy = x[ind].contiguous(), y[ind].contiguous()
+    B, C, H, W = x0.shape
+    dev = x0.device
+    sd = _seed(seed)
+    samples = sample_offset + np.arange(B, dtype=np.int64)
+    eps_p = float(eps) * (1. - 1e-6)                                   # square.py:425, :483
+    etas = {}
+
+    def eta_dev(s):                                                     # [2][s*s]: eta(s) and its transpose
+        if s not in etas:
+            e = _square_eta(s, norm)
+            etas[s] = torch.stack([e, e.t().contiguous()]).reshape(2, s * s).contiguous().to(dev)
+        return etas[s]
+
+    def native_signs(stream_index):
+        u = np.stack([_rng.host_uniform_many(sd, samples, 11, stream_index * 4 + c) for c in range(C)], axis=1)
+        return torch.from_numpy(np.where(u >= 0.5, 1.0, -1.0).astype(np.float32))
+
+    # ---- start point (:297-312 / :410-426)
+    s0 = H // 5
+    sp = (H - s0 * 5) // 2
+    tiles_h, tiles_w = H // s0, W // s0
+    trs, sgs = [], []
+    for t in range(tiles_h * tiles_w):
+        if draws is not None:
+            tr, sg = draws.square_lp_init_tile(B, C)
+        else:
+            tr, sg = _rng.host_uniform(sd, t, 10, 0) > 0.5, native_signs((1 << 20) + t)
+        trs.append(1 if tr else 0)
+        sgs.append(sg.reshape(B, C).float())
+    tr_dev = torch.tensor(trs, dtype=torch.uint8).to(dev)
+    sg_dev = torch.stack(sgs).contiguous().to(dev)
+    x_best = torch.empty_like(x0)
+    _lib.check(lib.rart_square_init_lp(_lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), nid, s0, sp, tiles_h, tiles_w,
+                                       _lib.ptr(eta_dev(s0)), _lib.ptr(tr_dev), _lib.ptr(sg_dev), _lib.stream_ptr()))
+    if norm == 'L1':
+        x_best = l1_projection(x0, x_best, eps_p, point_out=True)
+    margin_min, _, _ = logit_loss(prov.logits(x_best), yy, LOSS_MARGIN, want_grad=False)
+    loss_min = margin_min.clone()
+    x_new = torch.empty_like(x0)
+    n_features = C * H * W
+    for it in range(int(n_queries)):
+        todo = margin_min > 0
+        if draws is not None:
+            n_curr = int(todo.sum())                                    # the replayed sign rows are those of the current subset
+            if n_curr == 0:
+                break
+        elif it % check_every == 0 and not bool(todo.any()):            # square.py:405-406 / :527-528
+            break
+        p = _square_p_selection(it, p_init, n_queries, rescale)
+        s = max(int(round(math.sqrt(p * n_features / C))), 3)
+        if s % 2 == 0:
+            s += 1
+        if draws is not None:
+            vh, vw, vh2, vw2, tr, sg = draws.square_lp_query(H, W, s, n_curr, C)
+            rank = (torch.cumsum(todo.long(), 0) - 1).clamp_(min=0)
+            sg = sg.reshape(n_curr, C).float().to(dev)[rank].contiguous()
+        else:
+            vh, vw, vh2, vw2 = (int(_rng.host_uniform(sd, it, 9, k) * ((H if k % 2 == 0 else W) - s)) for k in range(4))
+            tr = _rng.host_uniform(sd, it, 9, 4) > 0.5
+            sg = native_signs(it).to(dev)
+        e = eta_dev(s)[1 if tr else 0]
+        _lib.check(lib.rart_square_propose_lp(_lib.ptr(x_new), _lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), nid, int(vh),
+                                              int(vw), int(vh2), int(vw2), s, _lib.ptr(e), _lib.ptr(sg), _lib.stream_ptr()))
+        cand = l1_projection(x0, x_new, eps_p, point_out=True) if norm == 'L1' else x_new
+        margin, _, _ = logit_loss(prov.logits(cand), yy, LOSS_MARGIN, want_grad=False)
+        improved = (margin < loss_min) & todo
+        loss_min = torch.where(improved, margin, loss_min)
+        accept = (improved | (margin <= 0)) & todo
+        margin_min = torch.where(accept, margin, margin_min)
+        select_rows_(x_best, cand, accept)
+    fooled = (prov.logits(x_best).max(1)[1] != yy).nonzero().flatten()
+    adv[ind[fooled]] = x_best[fooled]
+    return (adv, x_best, ind) if _return_best else adv
+
+
 def fab_project_linf(points, w, b):
     """-> (d, rowmax): rart_fab_project_linf on [R, ...] fp32 tensors."""
     torch = _lib.require_gpu()
@@ -699,8 +820,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     (autoattack.py:90-211).  `model` takes normalised input (NormalizeModel, autoattack.py:12-23).
     standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); the
     untargeted `fab` of version 'plus' (a 1000-class Jacobian per step, unusable on ImageNet in the reference too)
-    and Square for L2 / L1 are reported as skipped (the result is then an upper bound on robust accuracy, never silently
-    presented as the full ensemble); fab-t runs for all three norms.
+    is reported as skipped (the result is then an upper bound on robust accuracy, never silently presented as the full
+    ensemble); apgd-ce / apgd-t / fab-t / square run for all three norms.
     _overrides (parity tests only; the reference shrinks the same attributes, autoattack.py:253-267): dict with any of
     plan, apgd_iter, apgdt_iter, apgdt_classes, fab_iter, fab_classes, square_queries, and `draws` -- an object like
     oracle.attacks_ref.TorchStreamDraws replaying the reference's torch random stream instead of the counter-based RNG."""
@@ -722,8 +843,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     apgdt_classes, fab_iter, fab_classes = int(ov.get('apgdt_classes', 9)), int(ov.get('fab_iter', 100)), int(ov.get('fab_classes', 9))
     square_queries = int(ov.get('square_queries', 5000))
     draws = ov.get('draws')
-    skipped = [a for a in plan if a in ('fab',)] + ([a for a in plan if a == 'square'] if norm != 'Linf' else [])
-    if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes; Square L2 / L1: not built
+    skipped = [a for a in plan if a in ('fab',)]
+    if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes
         n_restarts, apgdt_classes = int(ov.get('apgd_restarts', 5)), int(ov.get('apgdt_classes', 5))
     if skipped:
         warnings.warn('autoattack_linf: %s not implemented on this build yet -- running %s only; robust accuracy '
@@ -751,7 +872,7 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
             x, y = x_orig[idcs].contiguous(), y_orig[idcs].contiguous()
             if draws is not None:
                 draws.reseed()                       # every perturb() of the reference re-seeds torch with self.seed
-            ts = draws.pm1 if draws is not None else None
+            ts = (draws.randn if norm == 'L2' else draws.pm1) if draws is not None else None      # autopgd_base.py:214-221
             sd = base_seed + 1000 * ai
             if norm == 'L1' and attack in ('apgd-ce', 'apgd-dlr', 'apgd-t'):
                 adv_curr = apgd_l1_perturb(None, x, y, eps, apgdt_iter if attack == 'apgd-t' else apgd_iter,
@@ -767,9 +888,9 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
                                                  _prov=prov)
             elif attack == 'fab-t':
                 adv_curr = fab_targeted_perturb(None, x, y, eps, fab_iter, fab_classes, _prov=prov, norm=norm)
+            elif attack == 'square' and norm != 'Linf':
+                adv_curr = square_lp_perturb(None, x, y, norm, eps, square_queries, 0.8, False, sd, first, draws=draws, _prov=prov)
             elif attack == 'square':
-                if norm != 'Linf':
-                    raise NotImplementedError('Square L2 (square.py:296-530) is not implemented')
                 if draws is not None:
                     adv_curr = square_perturb(None, x, y, eps, square_queries, 0.8, False, sd, first,
                                               init_sign=lambda n: draws.square_init(n, C, W),

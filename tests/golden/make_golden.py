@@ -110,9 +110,11 @@ def gen_attacks():
     print('attacks_ref.npz', len(out), 'entries')
 
 
-AA_CASES = {   # name -> (eps, plan or None (= the 'standard' order), apgd n_iter, apgd-t n_iter, apgd-t classes, fab n_iter, fab classes, square queries)
+AA_CASES = {   # name -> (eps, plan or None (= the 'standard' order), apgd n_iter, apgd-t n_iter, apgd-t classes, fab n_iter, fab classes, square queries[, norm])
     'standard': (1 / 255, None, 2, 2, 2, 10, 3, 60),
     'reordered': (1 / 255, ['square', 'fab-t', 'apgd-t', 'apgd-ce'], 4, 4, 2, 6, 3, 40),
+    'standard_L2': (0.12, None, 2, 2, 2, 6, 3, 40, 'L2'),
+    'reordered_L2': (0.12, ['square', 'fab-t', 'apgd-t', 'apgd-ce'], 3, 3, 2, 5, 2, 30, 'L2'),
 }
 
 
@@ -132,8 +134,9 @@ def gen_autoattack():
     from RobustART.noise.utils.adv.Attacks.autoattack.autoattack import AutoAttack
     net, x, y = aa_inputs()
     out = {'x': x.numpy(), 'y': y.numpy()}
-    for name, (eps, plan, ai, ti, tc, fi, fc, sq) in AA_CASES.items():
-        aa = AutoAttack(net, norm='Linf', eps=eps, seed=0, verbose=False, version='standard', device='cpu')
+    for name, case in AA_CASES.items():
+        eps, plan, ai, ti, tc, fi, fc, sq = case[:8]
+        aa = AutoAttack(net, norm=case[8] if len(case) > 8 else 'Linf', eps=eps, seed=0, verbose=False, version='standard', device='cpu')
         aa.apgd.n_iter = ai
         aa.apgd_targeted.n_iter, aa.apgd_targeted.n_target_classes = ti, tc
         aa.fab.n_iter, aa.fab.n_target_classes = fi, fc
@@ -219,8 +222,32 @@ def gen_fab_l2_l1():
     print('fab_l2_l1_ref.npz', len(out), 'entries')
 
 
+def gen_square_lp():
+    """SquareAttack with norm='L2' / 'L1' (square.py:296-530) on the tiny CNN -> square_lp_ref.npz."""
+    net = make_tinynet()
+    model_fn = lambda z: net(normalize(z))  # noqa: E731
+    x = make_batch(n=6, seed=41)
+    y = model_fn(x).max(1)[1]
+    out = {'x': x.numpy(), 'y': y.numpy()}
+    for norm, eps, nq in (('L2', 0.5, 60), ('L2', 2.0, 25), ('L1', 12.0, 60), ('L1', 40.0, 25)):
+        sq = SquareAttack(model_fn, p_init=.8, n_queries=nq, eps=eps, norm=norm, n_restarts=1, seed=0, resc_schedule=False,
+                          device='cpu')
+        adv = sq.perturb(x.clone(), y.clone()).detach()
+        out[f'square/{norm}/{eps}/adv'] = adv.numpy()
+        # the single run itself: the best point of EVERY image (perturb() only returns the fooled ones), same seed as perturb()
+        sq.init_hyperparam(x)
+        torch.random.manual_seed(0)
+        _, x_best = sq.attack_single_run(x.clone(), y.clone())
+        out[f'square/{norm}/{eps}/x_best'] = x_best.detach().numpy()
+        print('square', norm, eps, 'robust', int((model_fn(adv).max(1)[1] == y).sum()), 'of', len(x))
+    np.savez_compressed(os.path.join(HERE, 'square_lp_ref.npz'), **out)
+    print('square_lp_ref.npz', len(out), 'entries')
+
+
 if __name__ == '__main__':
-    if 'fab_l2_l1' in sys.argv[1:]:
+    if 'square_lp' in sys.argv[1:]:
+        gen_square_lp()
+    elif 'fab_l2_l1' in sys.argv[1:]:
         gen_fab_l2_l1()
     elif 'apgd_l1' in sys.argv[1:]:
         gen_apgd_l1()
@@ -232,3 +259,4 @@ if __name__ == '__main__':
         gen_autoattack()
         gen_apgd_l1()
         gen_fab_l2_l1()
+        gen_square_lp()

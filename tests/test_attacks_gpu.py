@@ -254,6 +254,42 @@ def test_fab_l2_l1_projections_and_fab_t_match_reference():
         torch.testing.assert_close(got.cpu(), torch.from_numpy(g[f'fabt/{norm}/adv']), atol=tol, rtol=0)
 
 
+SQUARE_LP_CASES = (('L2', 0.5, 60), ('L2', 2.0, 25), ('L1', 12.0, 60), ('L1', 40.0, 25))
+
+
+def test_square_l2_l1_match_reference():
+    """rart_square_init_lp / rart_square_propose_lp (+ rart_l1_project for L1) driven by adv.square_lp_perturb, with the reference's
+    torch random stream replayed (window origins, eta's transposition, per-subset sign rows): the best point of EVERY image after the
+    run and perturb()'s output vs the unmodified SquareAttack(norm='L2' / 'L1') (square.py:296-530)."""
+    from robustart_amd.noise import adv
+    g = np.load(os.path.join(GOLD, 'square_lp_ref.npz'))
+    netc = make_tinynet().cuda()
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    mean = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()
+    std = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1).cuda()
+    f_gpu = lambda z: netc((z - mean) / std)  # noqa: E731
+    for norm, eps, nq in SQUARE_LP_CASES:
+        d = A.TorchStreamDraws(0)
+        d.reseed()
+        got, xb, ind = adv.square_lp_perturb(f_gpu, x.cuda(), y.cuda(), norm, eps, nq, draws=d, _return_best=True)
+        assert ind.numel() == len(x)
+        torch.testing.assert_close(xb.cpu(), torch.from_numpy(g[f'square/{norm}/{eps}/x_best']), atol=5e-5, rtol=0)
+        torch.testing.assert_close(got.cpu(), torch.from_numpy(g[f'square/{norm}/{eps}/adv']), atol=5e-5, rtol=0)
+    # native draws at ImageNet size: the ball, the box, and determinism in (seed, sample_offset)
+    gen = torch.Generator().manual_seed(4)
+    xi = torch.rand(3, 3, 224, 224, generator=gen).cuda()
+    wv = torch.randn(3 * 224 * 224, 10, generator=gen).cuda() * 0.01
+    lin = lambda z: z.flatten(1) @ wv  # noqa: E731
+    yi = lin(xi).argmax(1)
+    for norm, eps in (('L2', 3.0), ('L1', 60.0)):
+        a, xb, _ = adv.square_lp_perturb(lin, xi, yi, norm, eps, 12, seed=5, sample_offset=9, _return_best=True)
+        b = adv.square_lp_perturb(lin, xi, yi, norm, eps, 12, seed=5, sample_offset=9)
+        assert torch.equal(a, b)
+        r = (xb - xi).flatten(1)
+        nr = r.norm(dim=1) if norm == 'L2' else r.abs().sum(1)
+        assert (nr <= eps * (1 + 1e-4)).all() and (nr >= eps * 0.5).all() and xb.min() >= -1e-6 and xb.max() <= 1 + 1e-6
+
+
 def test_native_pgd_linf_invariants_at_imagenet_size():
     """BASELINE-size property checks (no oracle run needed): eps-ball, box, determinism, sharding."""
     from robustart_amd.noise import adv
@@ -341,7 +377,9 @@ def test_apgd_targeted_matches_reference_golden():
 
 
 AA_CASES = {'standard': (1 / 255, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 10, 3, 60),
-            'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40)}
+            'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40),
+            'standard_L2': (0.12, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 6, 3, 40, 'L2'),
+            'reordered_L2': (0.12, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 3, 3, 2, 5, 2, 30, 'L2')}
 
 
 @pytest.mark.parametrize('case', sorted(AA_CASES))
@@ -354,10 +392,11 @@ def test_autoattack_linf_orchestrator_matches_reference_golden(case):
     g, netc, f_gpu = _f_gpu_and_gold()
     ga = np.load(os.path.join(GOLD, 'autoattack_ref.npz'))
     x, y = torch.from_numpy(ga['x']), torch.from_numpy(ga['y'])
-    eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case]
+    eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case][:8]
+    norm = AA_CASES[case][8] if len(AA_CASES[case]) > 8 else 'Linf'       # L2: APGD / APGD-T / FAB-T / Square all in their L2 forms
     ov = dict(plan=plan, apgd_iter=ai, apgdt_iter=ti, apgdt_classes=tc, fab_iter=fi, fab_classes=fc, square_queries=sq,
               draws=A.TorchStreamDraws(0))
-    got = adv.autoattack_linf(x.cuda(), y.cuda(), netc, 'Linf', eps, 'standard', False, _overrides=ov).cpu()
+    got = adv.autoattack_linf(x.cuda(), y.cuda(), netc, norm, eps, 'standard', False, _overrides=ov).cpu()
     want = torch.from_numpy(ga[f'{case}/adv'])
     torch.testing.assert_close(got, want, atol=5e-5, rtol=0)
     robust = (netc((got.cuda() - torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()) /
@@ -367,11 +406,12 @@ def test_autoattack_linf_orchestrator_matches_reference_golden(case):
     # native (counter-based) draws through the AddNoise plugin entry: eps-ball, box, reproducible
     from robustart_amd.noise import AddNoise, rng
     an = AddNoise('autoattack_linf')
-    an.set_config(model=netc, norm='Linf', eps=eps, version='standard', verbose=False)
+    an.set_config(model=netc, norm=norm, eps=eps, version='standard', verbose=False)
     rng.manual_seed(5)
-    a = adv.autoattack_linf(x.cuda(), y.cuda(), netc, 'Linf', eps, 'standard', False,
+    a = adv.autoattack_linf(x.cuda(), y.cuda(), netc, norm, eps, 'standard', False,
                             _overrides=dict(apgd_iter=3, apgdt_iter=2, apgdt_classes=2, fab_iter=3, fab_classes=2, square_queries=20))
-    assert (a.cpu() - x).abs().max() <= eps + 1e-6 and a.min() >= 0 and a.max() <= 1
+    r = (a.cpu() - x).flatten(1)
+    assert ((r.abs().max(1)[0] if norm == 'Linf' else r.norm(dim=1)) <= eps * (1 + 1e-5) + 1e-6).all() and a.min() >= 0 and a.max() <= 1
 
 
 def test_l1_projection_and_kth_select_kernels():

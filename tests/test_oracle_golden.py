@@ -253,8 +253,32 @@ def test_fab_l2_l1_projections_and_fab_t_match_reference():
         np.testing.assert_allclose(adv.numpy(), g[f'fabt/{norm}/adv'], atol=tol)
 
 
+SQUARE_LP_CASES = (('L2', 0.5, 60), ('L2', 2.0, 25), ('L1', 12.0, 60), ('L1', 40.0, 25))
+
+
+def test_square_l2_l1_match_reference():
+    """SquareAttack norm 'L2' / 'L1' (square.py:123-190, 296-530) restated: with torch's random stream replayed in the reference's call
+    order the best point of EVERY image after the run (attack_single_run) and perturb()'s output are bit-identical."""
+    g = np.load(os.path.join(GOLD, 'square_lp_ref.npz'))
+    net = make_tinynet()
+    model_fn = lambda z: net(A.normalize(z))  # noqa: E731
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    for norm, eps, nq in SQUARE_LP_CASES:
+        d = A.TorchStreamDraws(0)
+        d.reseed()
+        xb = A.square_lp_single_run(model_fn, x, y, eps, nq, 0.8, False, norm, d)
+        np.testing.assert_array_equal(xb.numpy(), g[f'square/{norm}/{eps}/x_best'])
+        d.reseed()
+        adv = A.square_lp_perturb(model_fn, x, y, eps, nq, 0.8, False, norm, d)
+        np.testing.assert_array_equal(adv.numpy(), g[f'square/{norm}/{eps}/adv'])
+        r = (xb - x).flatten(1)
+        assert ((r.norm(dim=1) if norm == 'L2' else r.abs().sum(1)) <= eps * (1 + 1e-5)).all() and xb.min() >= -1e-6 and xb.max() <= 1 + 1e-6   # (L1: x + delta + projection, no clamp)
+
+
 AA_CASES = {'standard': (1 / 255, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 10, 3, 60),
-            'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40)}
+            'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40),
+            'standard_L2': (0.12, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 6, 3, 40, 'L2'),
+            'reordered_L2': (0.12, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 3, 3, 2, 5, 2, 30, 'L2')}
 
 
 @pytest.mark.parametrize('case', sorted(AA_CASES))
@@ -264,8 +288,9 @@ def test_autoattack_orchestrator_matches_reference(gold_a, gold_aa, case):
     update, early exit, in two attack orders; plus every attack run alone (run_standard_evaluation_individual)."""
     net, model_fn = _model(gold_a)
     x, y = torch.from_numpy(gold_aa['x']), torch.from_numpy(gold_aa['y'])
-    eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case]
-    kw = dict(apgd_iter=ai, apgdt_iter=ti, apgdt_classes=tc, fab_iter=fi, fab_classes=fc, square_queries=sq)
+    eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case][:8]
+    kw = dict(apgd_iter=ai, apgdt_iter=ti, apgdt_classes=tc, fab_iter=fi, fab_classes=fc, square_queries=sq,
+              norm=AA_CASES[case][8] if len(AA_CASES[case]) > 8 else 'Linf')       # (the L2 ensemble: APGD / FAB-T / Square in their L2 forms)
     trace = []
     adv = A.autoattack_linf(model_fn, x, y, eps, A.TorchStreamDraws(0), plan=plan, trace=trace, **kw)
     np.testing.assert_allclose(adv.numpy(), gold_aa[f'{case}/adv'], atol=1e-6)

@@ -222,6 +222,12 @@ def test_every_attack_through_the_engines_at_224_vs_the_fp32_module(fitted):
         ('apgd-l1', 'L1', 150.0, lambda f, m: adv.apgd_l1_perturb(f, x, y, 150.0, 8, 'ce', 1, False, seed=3, sample_offset=0)),
         ('fab-t', 'Linf', e8, lambda f, m: adv.fab_targeted_perturb(f, x, y, e8, 6, 2)),
         ('square', 'Linf', e8, lambda f, m: adv.square_perturb(f, x, y, e8, 60, seed=3, sample_offset=0)),
+        ('fab-t-l2', 'L2', 1.0, lambda f, m: adv.fab_targeted_perturb(f, x, y, 1.0, 6, 2, norm='L2')),
+        ('fab-t-l1', 'L1', 150.0, lambda f, m: adv.fab_targeted_perturb(f, x, y, 150.0, 6, 2, norm='L1')),
+        ('square-l2', 'L2', 1.0, lambda f, m: adv.square_lp_perturb(f, x, y, 'L2', 1.0, 40, seed=3, sample_offset=0)),
+        ('square-l1', 'L1', 150.0, lambda f, m: adv.square_lp_perturb(f, x, y, 'L1', 150.0, 40, seed=3, sample_offset=0)),
+        ('autoattack_l2', 'L2', 1.0, lambda f, m: adv.autoattack_linf(x, y, m, 'L2', 1.0, 'standard', False, seed=3,
+                                                                    _overrides=dict(aa))),
         ('autoattack_linf', 'Linf', e8, lambda f, m: adv.autoattack_linf(x, y, m, 'Linf', e8, 'standard', False, seed=3,
                                                                        _overrides=dict(aa))),
     ]
@@ -254,7 +260,7 @@ def test_every_attack_through_the_engines_at_224_vs_the_fp32_module(fitted):
         e = row['fp32x-engine']
         assert e['outcome_agreement'] >= 0.92 and abs(e['robust'] - row['robust_fp32_module']) <= 0.08, (name, row)
         b = row['bf16-engine']
-        if name == 'fab-t':
+        if name.startswith('fab-t'):
             # measured in round 3: FAB's alternating projections onto the linearised decision boundary need the logit DIFFERENCE
             # near zero, where the bf16 engine's ~3e-3 logit error dominates -- the attack is much weaker on the bf16 engine
             # (robust accuracy 0.34 vs 0.05 at eps 4/255).  adv.fab_targeted_perturb warns; use precision='fp32x' for FAB
