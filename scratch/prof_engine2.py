@@ -2,13 +2,13 @@
 its algorithmic FLOPs and HBM bytes, the measured time (events on the launch stream) and the roofline floor
 max(FLOPs / 2.5 PFLOP/s, bytes / 8 TB/s).  Output -> profiles/r0N_igemm_per_shape.txt."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import time, torch
+import os, time, torch
 from robustart_amd.model import get_model
 from robustart_amd.model.engine import ResNet50Engine
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 PEAK_F, PEAK_B = 2.5e15, 8.0e12
 torch.manual_seed(0)
-eng = ResNet50Engine(get_model({'type': 'resnet50_official'}).eval(), 'cuda')
+eng = ResNet50Engine(get_model({'type': 'resnet50_official'}).eval(), 'cuda', os.environ.get('PREC', 'bf16'))   # PREC=fp32x: the reference-precision chain
 for a in sys.argv[1:]:
     if '=' in a:
         k, v = a.split('='); setattr(eng, k, bool(int(v)))
