@@ -131,3 +131,38 @@ def test_host_uniform_vector_form_equals_the_scalar_form():
         samples = np.array([0, 1, 2, 255, 2 ** 31, 2 ** 32 - 1, 2 ** 32 + 5], dtype=np.int64)
         want = np.array([rng.host_uniform(seed, int(s), stream, index) for s in samples])
         np.testing.assert_array_equal(rng.host_uniform_many(seed, samples, stream, index), want)
+
+
+def test_argument_checks_of_the_round3_attack_entries_without_gpu():
+    """rart_fab_project / rart_row_norm_diff / rart_square_init_lp / rart_square_propose_lp validate before any launch."""
+    import ctypes
+    from robustart_amd import _lib
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)           # never dereferenced: the checks run first
+    assert lib.rart_fab_project(one, one, one, one, None, 2, 100, 3, None) == 1 and b'rart_fab_project' in lib.rart_last_error_string()
+    assert lib.rart_fab_project(None, one, one, one, None, 2, 100, 2, None) == 1
+    assert lib.rart_row_norm_diff(one, one, one, 2, 100, 5, None) == 1 and b'rart_row_norm_diff' in lib.rart_last_error_string()
+    # Square L2 / L1: norm in {1, 2}, at most 4 channels, the tile grid / windows inside the image
+    assert lib.rart_square_init_lp(one, one, 2, 3, 32, 32, 0.5, 0, 6, 1, 5, 5, one, one, one, None) == 1
+    assert lib.rart_square_init_lp(one, one, 2, 5, 32, 32, 0.5, 2, 6, 1, 5, 5, one, one, one, None) == 1
+    assert lib.rart_square_init_lp(one, one, 2, 3, 32, 32, 0.5, 2, 6, 4, 5, 5, one, one, one, None) == 1
+    assert b'tile grid' in lib.rart_last_error_string()
+    assert lib.rart_square_propose_lp(one, one, one, 2, 3, 32, 32, 0.5, 2, 4, 0, 0, 0, 29, one, one, None) == 1
+    assert b'window outside' in lib.rart_last_error_string()
+    assert lib.rart_square_propose_lp(one, one, one, 2, 3, 32, 32, 0.5, 1, 0, 0, 3, 4, 29, one, one, None) == 1
+
+
+def test_square_eta_pattern_host_side():
+    """adv._square_eta (the host-side eta of SquareAttack, square.py:146-186, without the random transposition): unit norm in the
+    attack's norm, top half positive / bottom half negative, symmetric left-right for odd sides -- for the window sizes the schedule produces."""
+    import torch
+    from robustart_amd.noise.adv import _square_eta
+    for norm in ('L2', 'L1'):
+        for s in (3, 6, 7, 29, 44, 201):
+            e = _square_eta(s, norm)
+            assert e.shape == (s, s) and e.dtype == torch.float32
+            n = e.pow(2).sum().sqrt() if norm == 'L2' else e.abs().sum()
+            assert abs(float(n) - 1.0) < 1e-5
+            assert (e[:s // 2] > 0).all() and (e[s // 2:] < 0).all()
+            if s % 2 == 1:
+                assert torch.allclose(e, e.flip(1), atol=1e-7)       # (odd sides: the rectangles are centred)
