@@ -69,7 +69,8 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
   uint8_t* const sImg = lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p32 = lane & 31, h = lane >> 5;
-  const int img = blockIdx.x / (TPS * TPS), tile = blockIdx.x - img * (TPS * TPS);
+  const int lb = (int)rart_xcd_block(blockIdx.x, gridDim.x);          // the tiles of an image on one XCD (shared halo in its L2)
+  const int img = lb / (TPS * TPS), tile = lb - img * (TPS * TPS);
   const int oy0 = (tile / TPS) * S2_T, ox0 = (tile % TPS) * S2_T;      // first output position of the tile
   const int gy0 = 2 * oy0 - 1, gx0 = 2 * ox0 - 1;                       // input position of grid slot (0, 0)
   const long long ipos0 = (long long)img * HIN * HIN;                   // raster index of the image's first input position
@@ -406,7 +407,8 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2_bwd
   uint8_t* const sD2 = lds + IMG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p32 = lane & 31, h = lane >> 5;
-  const int img = blockIdx.x / (TPS * TPS), tile = blockIdx.x - img * (TPS * TPS);
+  const int lb = (int)rart_xcd_block(blockIdx.x, gridDim.x);          // the tiles of an image on one XCD (shared halo in its L2)
+  const int img = lb / (TPS * TPS), tile = lb - img * (TPS * TPS);
   const int oy0 = (tile / TPS) * S2_T, ox0 = (tile % TPS) * S2_T;      // first output position the tile's centre class reads
   const int iy0 = 2 * oy0, ix0 = 2 * ox0;                               // first input position of the tile
   const long long ipos0 = (long long)img * HIN * HIN, opos0 = (long long)img * HOUT * HOUT;

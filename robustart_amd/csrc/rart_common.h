@@ -129,6 +129,16 @@ __device__ __forceinline__ float rart_wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
+// Workgroups are dealt to the 8 XCDs round-robin by block id; tiles of one image share halo rows / columns, so a kernel whose
+// neighbouring tiles are consecutive block ids remaps: the returned LOGICAL id is contiguous per XCD (XCD k owns the k-th eighth of
+// the ids, bijective for any grid size), and its L2 serves the overlap.
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t rart_xcd_block(uint32_t bid, uint32_t nb) {
+  const uint32_t xcd = bid & 7u, slot = bid >> 3, q = nb >> 3, r = nb & 7u;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
+}
+#endif
+
 #endif  // __HIPCC__
 
 // ---- internal launchers (one translation unit per kernel family) ---------------------

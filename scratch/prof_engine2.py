@@ -3,6 +3,8 @@ its algorithmic FLOPs and HBM bytes, the measured time (events on the launch str
 max(FLOPs / 2.5 PFLOP/s, bytes / 8 TB/s).  Output -> profiles/r0N_igemm_per_shape.txt."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os, time, torch
+if os.environ.get('RART_LIB'):          # A/B against another build of the library
+    from robustart_amd import _lib as _l; _l.LIB_PATH = os.environ['RART_LIB']
 from robustart_amd.model import get_model
 from robustart_amd.model.engine import ResNet50Engine
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
