@@ -89,6 +89,26 @@ def test_fused_attention_matches_torch_and_unfused_path(setup):
     assert (out2.float() - ref).abs().max().item() < 0.03 * ref.abs().max().item() + 2e-2
 
 
+@pytest.mark.parametrize('T', [1, 17, 32, 33, 65, 96, 128, 129, 160, 192, 193, 224])
+def test_fused_attention_every_key_tile_count(T):
+    """rart_vit_attention instantiates k_vit_attention for ceil(T / 32) key tiles and masks only the last one: token counts on both
+    sides of every tile boundary (and a full last tile, where nothing is masked) against torch's soft-max attention."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    B, H, hd = 2, 3, 64
+    D = H * hd
+    g = torch.Generator().manual_seed(100 + T)
+    qkv = (torch.randn(B * T + 256, 3 * D, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    qkv[B * T:] = 7.0                                     # rows past the batch must never be read into a result
+    out = torch.full((B * T + 8, D), 3.0, dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.rart_vit_attention(_lib.ptr(qkv), _lib.ptr(out), B, T, H, hd, _lib.stream_ptr()))
+    q3 = qkv[:B * T].float().view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q3[0] @ q3[1].transpose(-2, -1) * hd ** -0.5, -1) @ q3[2]).transpose(1, 2).reshape(B * T, D)
+    err = (out[:B * T].float() - ref).abs().max().item()
+    assert err < 0.02 * ref.abs().max().item() + 2e-2, (T, err)
+    assert (out[B * T:] == 3.0).all()                     # nothing written past the last token
+
+
 def test_vit_backward_kernels():
     """GELU, GELU', LayerNorm backward, soft-max backward rows, un-patchify vs torch."""
     from robustart_amd import _lib
