@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t
   __shared__ __attribute__((aligned(16))) uint16_t sV[TP * ATT_LDK];     // phase A: dO^T [64][LDV]
   __shared__ __attribute__((aligned(16))) uint16_t sdO[TP * ATT_LDK];
   __shared__ __attribute__((aligned(16))) uint16_t sKt[ATT_HD * LDV];
-  __shared__ float sStat[TP * 3];
+  __shared__ __attribute__((aligned(16))) float4 sStat[TP];              // per query: max (log2 units), 1 / sum, delta, -
   static_assert(ATT_HD * LDV <= TP * ATT_LDK, "transposed operands reuse the K / V arrays");
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
@@ -361,13 +361,30 @@ __global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t
     *reinterpret_cast<uint4*>(sK + t * ATT_LDK + c * 8) = kv;
     *reinterpret_cast<uint4*>(sV + t * ATT_LDK + c * 8) = vv;
     *reinterpret_cast<uint4*>(sdO + t * ATT_LDK + c * 8) = dv;
-    const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      sKt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(w[j] & 0xFFFF);
-      sKt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(w[j] >> 16);
-    }
   }
+  __syncthreads();
+  // transposed copy [channel][token] of a token-major LDS array: a thread turns 8 channels of FOUR consecutive tokens into eight 8-byte
+  // runs; consecutive lanes take consecutive token quads, so the writes to a channel row are contiguous (the forward kernel's staging)
+  auto transpose_rows = [&](const uint16_t* src, uint16_t* dst) {
+    for (int i = tid; i < (TP / 4) * 8; i += NT) {
+      const int tq = i % (TP / 4), c = i / (TP / 4);
+      uint32_t w[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (tq * 4 + u) * ATT_LDK + c * 8);
+        w[u][0] = v.x; w[u][1] = v.y; w[u][2] = v.z; w[u][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint16_t* row = dst + (c * 8 + 2 * j) * LDV + tq * 4;
+        *reinterpret_cast<uint2*>(row) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x05040100u),
+                                                    __builtin_amdgcn_perm(w[3][j], w[2][j], 0x05040100u));
+        *reinterpret_cast<uint2*>(row + LDV) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x07060302u),
+                                                          __builtin_amdgcn_perm(w[3][j], w[2][j], 0x07060302u));
+      }
+    }
+  };
+  transpose_rows(sK, sKt);
   __syncthreads();
   uint16_t* gq = dqkv + (size_t)b * T * ld + h * ATT_HD;      // dQ | dK (+D) | dV (+2D), same layout as qkv
 
@@ -408,35 +425,33 @@ __global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t
         const bf16x8 ak = *reinterpret_cast<const bf16x8*>(sK + (kt * 32 + l31) * ATT_LDK + kb * 16 + hh * 8);
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, bq[kb], sacc[kt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // lane = query qt*32 + l31; register r of tile kt = key kt*32 + (r&3) + 8*(r>>2) + 4*hh
+    // lane = query qt*32 + l31; register r of tile kt = key kt*32 + (r&3) + 8*(r>>2) + 4*hh.  Only the LAST key tile can hold keys past
+    // the sequence (the host picks NKT = ceil(T / 32)): they must not win the maximum and get probability 0
     float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= T) sacc[NKT - 1][r] = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float v = key < T ? sacc[kt][r] * scale_log2e : -INFINITY;
-        sacc[kt][r] = v;
-        m = fmaxf(m, v);
-      }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64)) * scale_log2e;       // scale > 0: max(s) * scale == max(s * scale)
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - m);
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], scale_log2e, -m));
         sacc[kt][r] = e;
         sum += e;
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (hh == 0) {
-      sStat[q * 3 + 0] = m;
-      sStat[q * 3 + 1] = inv;
-      sStat[q * 3 + 2] = delta;
-    }
+    if (hh == 0) sStat[q] = make_float4(m, inv, delta, 0.f);
+    const float sinv = scale * inv;
+    // dQ^T = K^T . dS^T (operands swapped like the forward's O^T): a lane owns runs of four channels of ITS query
     f32x16 dq[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -458,30 +473,29 @@ __global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r0 = 8 * kb2 + 2 * j;
-          const float d0 = scale * inv * sacc[kt][r0] * (dp[r0] - delta);
-          const float d1 = scale * inv * sacc[kt][r0 + 1] * (dp[r0 + 1] - delta);
-          pw[j] = (uint32_t)f2bf(d0) | ((uint32_t)f2bf(d1) << 16);
+          pw[j] = pack_bf16x2(sinv * sacc[kt][r0] * (dp[r0] - delta), sinv * sacc[kt][r0 + 1] * (dp[r0 + 1] - delta));
         }
         uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-        const bf16x8 da = *reinterpret_cast<bf16x8*>(&pv);
+        const bf16x8 ds = *reinterpret_cast<bf16x8*>(&pv);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const uint16_t* kr = sKt + (nt * 32 + l31) * LDV + kt * 32 + 16 * kb2 + 4 * hh;
           const uint2 lo = *reinterpret_cast<const uint2*>(kr), hi = *reinterpret_cast<const uint2*>(kr + 8);
-          uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          dq[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, *reinterpret_cast<bf16x8*>(&bv), dq[nt], 0, 0, 0);
+          uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          dq[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av), ds, dq[nt], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);     // one key tile at a time: interleaving the unrolled tiles multiplies the live dP tiles
     }
+    // dq[nt][r] = dQ[query q][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]
+    if (q < T) {
+      uint16_t* orow = gq + (size_t)q * ld;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (qq < T) {
-        uint16_t* orow = gq + (size_t)qq * ld;
-        orow[l31] = f2bf(dq[0][r]);
-        orow[32 + l31] = f2bf(dq[1][r]);
-      }
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(orow + nt * 32 + 8 * g + 4 * hh) =
+              make_uint2(pack_bf16x2(dq[nt][4 * g], dq[nt][4 * g + 1]), pack_bf16x2(dq[nt][4 * g + 2], dq[nt][4 * g + 3]));
     }
   }
 
@@ -506,25 +520,16 @@ __global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t
   __syncthreads();
   uint16_t* sQt = sK;
   uint16_t* sdOt = sV;
-  for (int i = tid; i < TP * 8; i += NT) {
-    const int t = i >> 3, c = i & 7;
-    const uint4 qv = *reinterpret_cast<const uint4*>(sQ + t * ATT_LDK + c * 8);
-    const uint4 dv = *reinterpret_cast<const uint4*>(sdO + t * ATT_LDK + c * 8);
-    const uint32_t wq[4] = {qv.x, qv.y, qv.z, qv.w}, wd[4] = {dv.x, dv.y, dv.z, dv.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      sQt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(wq[j] & 0xFFFF);
-      sQt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(wq[j] >> 16);
-      sdOt[(c * 8 + 2 * j) * LDV + t] = (uint16_t)(wd[j] & 0xFFFF);
-      sdOt[(c * 8 + 2 * j + 1) * LDV + t] = (uint16_t)(wd[j] >> 16);
-    }
-  }
+  transpose_rows(sQ, sQt);
+  transpose_rows(sdO, sdOt);
   __syncthreads();
 #pragma unroll
   for (int ki = 0; ki < KI; ++ki) {
     const int kt = wave + ki * NW;
     if (kt >= NKT) break;
-    const bool key_ok = kt * 32 + l31 < T;
+    const int key = kt * 32 + l31;
+    const bool key_ok = key < T;
+    // dV^T = dO^T . P and dK^T = Q^T . dS (operands swapped): lane = key, registers = channels
     f32x16 dvv[2], dkk[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -542,13 +547,14 @@ __global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bk[ki][kb], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bvv[ki][kb], dp, 0, 0, 0);
       }
-      // lane = key kt*32 + l31; register r = query qt*32 + (r&3) + 8*(r>>2) + 4*hh
+      // lane = key kt*32 + l31; register r = query qt*32 + (r&3) + 8*(r>>2) + 4*hh (queries past the sequence have zero Q / dO rows:
+      // whatever probability they get multiplies zeros)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float p = key_ok ? __builtin_amdgcn_exp2f(s[r] * scale_log2e - sStat[q * 3]) * sStat[q * 3 + 1] : 0.f;
+        const float4 st = sStat[qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+        const float p = key_ok ? __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -st.x)) * st.y : 0.f;
         s[r] = p;
-        dp[r] = scale * p * (dp[r] - sStat[q * 3 + 2]);
+        dp[r] = scale * p * (dp[r] - st.z);
       }
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
@@ -556,33 +562,35 @@ __global__ __launch_bounds__(NW * 64, 1) void k_vit_attention_bwd(const uint16_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r0 = 8 * kb2 + 2 * j;
-          pw[j] = (uint32_t)f2bf(s[r0]) | ((uint32_t)f2bf(s[r0 + 1]) << 16);
-          dw[j] = (uint32_t)f2bf(dp[r0]) | ((uint32_t)f2bf(dp[r0 + 1]) << 16);
+          pw[j] = pack_bf16x2(s[r0], s[r0 + 1]);
+          dw[j] = pack_bf16x2(dp[r0], dp[r0 + 1]);
         }
         uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]), dv = make_uint4(dw[0], dw[1], dw[2], dw[3]);
-        const bf16x8 pa = *reinterpret_cast<bf16x8*>(&pv), da = *reinterpret_cast<bf16x8*>(&dv);
+        const bf16x8 pb = *reinterpret_cast<bf16x8*>(&pv), db = *reinterpret_cast<bf16x8*>(&dv);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const uint16_t* orow = sdOt + (nt * 32 + l31) * LDV + qt * 32 + 16 * kb2 + 4 * hh;
           const uint16_t* qrow = sQt + (nt * 32 + l31) * LDV + qt * 32 + 16 * kb2 + 4 * hh;
           const uint2 olo = *reinterpret_cast<const uint2*>(orow), ohi = *reinterpret_cast<const uint2*>(orow + 8);
           const uint2 qlo = *reinterpret_cast<const uint2*>(qrow), qhi = *reinterpret_cast<const uint2*>(qrow + 8);
-          uint4 bo = make_uint4(olo.x, olo.y, ohi.x, ohi.y), bqv = make_uint4(qlo.x, qlo.y, qhi.x, qhi.y);
-          dvv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, *reinterpret_cast<bf16x8*>(&bo), dvv[nt], 0, 0, 0);
-          dkk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, *reinterpret_cast<bf16x8*>(&bqv), dkk[nt], 0, 0, 0);
+          uint4 ao = make_uint4(olo.x, olo.y, ohi.x, ohi.y), aqv = make_uint4(qlo.x, qlo.y, qhi.x, qhi.y);
+          dvv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&ao), pb, dvv[nt], 0, 0, 0);
+          dkk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&aqv), db, dkk[nt], 0, 0, 0);
         }
       }
     }
+    // dkk / dvv[nt][r] = dK / dV[key][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]: 8-byte runs of the lane's own key row
+    if (key_ok) {
+      uint16_t* orow = gq + (size_t)key * ld;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (kk < T) {
-        uint16_t* orow = gq + (size_t)kk * ld;
-        orow[D + l31] = f2bf(dkk[0][r]);
-        orow[D + 32 + l31] = f2bf(dkk[1][r]);
-        orow[2 * D + l31] = f2bf(dvv[0][r]);
-        orow[2 * D + 32 + l31] = f2bf(dvv[1][r]);
-      }
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          *reinterpret_cast<uint2*>(orow + D + nt * 32 + 8 * g + 4 * hh) =
+              make_uint2(pack_bf16x2(dkk[nt][4 * g], dkk[nt][4 * g + 1]), pack_bf16x2(dkk[nt][4 * g + 2], dkk[nt][4 * g + 3]));
+          *reinterpret_cast<uint2*>(orow + 2 * D + nt * 32 + 8 * g + 4 * hh) =
+              make_uint2(pack_bf16x2(dvv[nt][4 * g], dvv[nt][4 * g + 1]), pack_bf16x2(dvv[nt][4 * g + 2], dvv[nt][4 * g + 3]));
+        }
     }
   }
 }
@@ -670,9 +678,16 @@ int rart_vit_attention_bwd(const void* qkv, const void* out, const void* dout, v
   RART_CHECK_ARG(tokens <= 224, "rart_vit_attention_bwd: at most 224 tokens (197 for 224x224 / patch 16)");
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
-  hipLaunchKernelGGL((k_vit_attention_bwd<7, 8>), dim3((uint32_t)(n * heads)), dim3(512), 0, (hipStream_t)stream,
-                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, (uint16_t*)dqkv, tokens, heads, 3 * D, D, scale,
-                     scale * 1.4426950408889634f);
+  const dim3 grid((uint32_t)(n * heads));
+  hipStream_t st = (hipStream_t)stream;
+#define RART_ATTB_CASE(N) case N: hipLaunchKernelGGL((k_vit_attention_bwd<N, 8>), grid, dim3(512), 0, st, (const uint16_t*)qkv, (const uint16_t*)out, \
+    (const uint16_t*)dout, (uint16_t*)dqkv, tokens, heads, 3 * D, D, scale, scale * 1.4426950408889634f); break;
+  switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
+    RART_ATTB_CASE(1) RART_ATTB_CASE(2) RART_ATTB_CASE(3) RART_ATTB_CASE(4) RART_ATTB_CASE(5) RART_ATTB_CASE(6)
+    default: hipLaunchKernelGGL((k_vit_attention_bwd<7, 8>), grid, dim3(512), 0, st, (const uint16_t*)qkv, (const uint16_t*)out,
+                                (const uint16_t*)dout, (uint16_t*)dqkv, tokens, heads, 3 * D, D, scale, scale * 1.4426950408889634f); break;
+  }
+#undef RART_ATTB_CASE
   RART_CHECK_LAUNCH("rart_vit_attention_bwd");
   return RART_OK;
 }
