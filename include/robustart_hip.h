@@ -197,6 +197,10 @@ int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int 
 int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0, int batch, int c, int h, int w,
                              float eps, int vh, int vw, int s, const float* sign_host, rart_stream_t stream);
 
+/* Expectation over transformation of APGD (autopgd_base.py:271-289, :367-384; AutoAttack version 'rand'): mode 0: acc += g over n fp32
+ * elements; mode 1: acc /= divisor (the reference divides by float(eot_iter)). */
+int rart_eot_accumulate(float* acc, const float* g, size_t n, int mode, float divisor, rart_stream_t stream);
+
 /* Square attack, norm 2 = L2 / 1 = L1 (Attacks/autoattack/square.py:123-190, 296-530); all pointers are device pointers.
  * rart_square_init_lp: the start perturbation -- tiles of side s on a tiles_h x tiles_w grid from (sp, sp), tile t carries
  *   eta2[transposed[t]] (eta2 = [2][s*s]: eta(s) and its transpose, :172-190) times signs[t][image][channel] (+-1).  L2: out = the start

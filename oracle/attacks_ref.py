@@ -29,13 +29,17 @@ def normalize(x):
     return (x - mean) / std
 
 
-def _grad_of_sum(loss_fn, model_fn, x, y):
+def _grad_of_sum(loss_fn, model_fn, x, y, eot_iter=1):
+    """autopgd_base.py:271-289 / :367-384: the gradient averaged over eot_iter passes (logits / losses of the last one)."""
     x = x.detach().clone().requires_grad_(True)
-    with torch.enable_grad():
-        logits = model_fn(x)
-        loss_indiv = loss_fn(logits, y)
-        loss = loss_indiv.sum()
-    g = torch.autograd.grad(loss, [x])[0].detach()
+    g = torch.zeros_like(x)
+    for _ in range(eot_iter):
+        with torch.enable_grad():
+            logits = model_fn(x)
+            loss_indiv = loss_fn(logits, y)
+            loss = loss_indiv.sum()
+        g += torch.autograd.grad(loss, [x])[0].detach()
+    g /= float(eot_iter)
     return logits.detach(), loss_indiv.detach(), g
 
 
@@ -192,7 +196,7 @@ def apgd_step_l2(x_adv, x_adv_old, grad, x, eps, step_size, a):
     return x_adv_1
 
 
-def apgd_single_run(model_fn, x, y, norm, eps, n_iter, loss, init_t, y_target=None, rho=0.75, trace=None):
+def apgd_single_run(model_fn, x, y, norm, eps, n_iter, loss, init_t, y_target=None, rho=0.75, trace=None, eot_iter=1):
     """autopgd_base.py:208-448 (eot_iter = 1, Linf / L2).  init_t = the torch.rand*2-1 (Linf)
     or torch.randn (L2) start direction.  Returns (x_best, acc, loss_best, x_best_adv)."""
     if loss == 'ce':
@@ -213,7 +217,7 @@ def apgd_single_run(model_fn, x, y, norm, eps, n_iter, loss, init_t, y_target=No
     B = x.shape[0]
     loss_steps = torch.zeros([n_iter, B])
 
-    logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y)          # :271-289
+    logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y, eot_iter)          # :271-289
     grad_best = grad.clone()
     acc = logits.max(1)[1] == y
     loss_best = loss_indiv.clone()
@@ -232,7 +236,7 @@ def apgd_single_run(model_fn, x, y, norm, eps, n_iter, loss, init_t, y_target=No
         x_adv_old = x_adv.clone()
         x_adv = x_new + 0.
 
-        logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y)      # :367-384
+        logits, loss_indiv, grad = _grad_of_sum(crit, model_fn, x_adv, y, eot_iter)      # :367-384
         pred = logits.max(1)[1] == y
         acc = torch.min(acc, pred)
         ind_pred = ~pred
@@ -427,7 +431,7 @@ def apgd_l1_perturb(model_fn, x, y, eps, n_iter, loss, draws, n_restarts=1, use_
     return adv
 
 
-def apgd_perturb(model_fn, x, y, norm, eps, n_iter, loss, init_ts, n_restarts=1):
+def apgd_perturb(model_fn, x, y, norm, eps, n_iter, loss, init_ts, n_restarts=1, eot_iter=1):
     """autopgd_base.py:450-529 (best_loss=False).  init_ts[r] = start direction for restart r,
     shaped like the still-robust subset at that restart."""
     x = x.detach().clone().float()
@@ -439,7 +443,7 @@ def apgd_perturb(model_fn, x, y, norm, eps, n_iter, loss, init_ts, n_restarts=1)
         if ind_to_fool.numel() != 0:
             t = init_ts(counter, x[ind_to_fool].shape) if callable(init_ts) else init_ts[counter]
             _, acc_curr, _, adv_curr = apgd_single_run(model_fn, x[ind_to_fool].clone(), y[ind_to_fool].clone(),
-                                                       norm, eps, n_iter, loss, t)
+                                                       norm, eps, n_iter, loss, t, eot_iter=eot_iter)
             ind_curr = (acc_curr == 0).nonzero().flatten()
             acc[ind_to_fool[ind_curr]] = False
             adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
@@ -935,7 +939,7 @@ class TorchStreamDraws:
 
 
 def autoattack_linf(model_fn, x_orig, y_orig, eps, draws, plan=('apgd-ce', 'apgd-t', 'fab-t', 'square'), apgd_iter=100,
-                    apgdt_iter=100, apgdt_classes=9, fab_iter=100, fab_classes=9, square_queries=5000, trace=None, norm='Linf'):
+                    apgdt_iter=100, apgdt_classes=9, fab_iter=100, fab_classes=9, square_queries=5000, trace=None, norm='Linf', eot_iter=1):
     """AutoAttack.run_standard_evaluation (autoattack.py:90-211) with bs >= len(x), version 'standard' hyper-parameters
     (autoattack.py:253-267) unless overridden.  model_fn takes x in [0,1] (NormalizeModel already applied).
     draws: a TorchStreamDraws-like object; trace (list) receives (attack, robust_flags copy) after every attack."""
@@ -951,8 +955,8 @@ def autoattack_linf(model_fn, x_orig, y_orig, eps, draws, plan=('apgd-ce', 'apgd
             draws.reseed()                                                   # each perturb() re-seeds with the same seed
             start = draws.randn if norm == 'L2' else draws.pm1              # autopgd_base.py:214-221 (norm 'Linf' / 'L2' here)
             with torch.enable_grad():
-                if attack == 'apgd-ce':
-                    adv_curr = apgd_perturb(model_fn, x, y, norm, eps, apgd_iter, 'ce', start, 1)
+                if attack in ('apgd-ce', 'apgd-dlr'):                        # (version 'rand': both, with eot_iter passes per gradient)
+                    adv_curr = apgd_perturb(model_fn, x, y, norm, eps, apgd_iter, attack[5:], start, 1, eot_iter)
                 elif attack == 'apgd-t':
                     adv_curr = apgd_targeted_perturb(model_fn, x, y, norm, eps, apgdt_iter, start, apgdt_classes)
                 elif attack == 'fab-t':

@@ -54,6 +54,7 @@ SIGNATURES = {
     'rart_fab_project_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_row_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'rart_row_absmax_diff': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'rart_eot_accumulate': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p]),
     'rart_square_init_lp': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
     'rart_square_propose_lp': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int,

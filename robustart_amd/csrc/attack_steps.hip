@@ -900,6 +900,14 @@ __global__ __launch_bounds__(kFabThreads) void k_row_norm_diff(const float* __re
     if (threadIdx.x == 0) out[row] = NORM == 1 ? (float)acc : (float)sqrt(acc);
   }
 }
+// ---- expectation over transformation (autopgd_base.py:271-289): acc += g, and after the last pass acc /= eot_iter ----------------
+// mode 0: acc[i] += g[i]     mode 1: acc[i] = acc[i] / divisor   (a division, as the reference's `grad /= float(eot_iter)`)
+__global__ __launch_bounds__(kBlock) void k_eot_accumulate(float* __restrict__ acc, const float* __restrict__ g, size_t n, int mode,
+                                                           float divisor) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    acc[i] = mode == 0 ? acc[i] + g[i] : acc[i] / divisor;
+}
+
 // ---- Square attack, L2 / L1 (Attacks/autoattack/square.py:296-530) ---------------------------------------------------------
 // One workgroup per image (the norms couple all channels of an image).  NORM 2: sums of squares and square roots; NORM 1: sums
 // of absolute values.  kSqC = channels supported (images are RGB).
@@ -1330,6 +1338,13 @@ int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int 
   return RART_OK;
 }
 
+int rart_eot_accumulate(float* acc, const float* g, size_t n, int mode, float divisor, rart_stream_t stream) {
+  RART_CHECK_ARG(acc && n > 0 && (mode == 0 ? g != nullptr : (mode == 1 && divisor != 0.f)), "rart_eot_accumulate: bad arguments");
+  hipLaunchKernelGGL(k_eot_accumulate, dim3(rart_grid_for(n, kBlock, 256 * 16)), dim3(kBlock), 0, (hipStream_t)stream, acc, g, n, mode,
+                     divisor);
+  RART_CHECK_LAUNCH("rart_eot_accumulate");
+  return RART_OK;
+}
 int rart_square_init_lp(float* out, const float* x0, int batch, int c, int h, int w, float eps, int norm, int s, int sp, int tiles_h,
                         int tiles_w, const float* eta2, const uint8_t* transposed, const float* signs, rart_stream_t stream) {
   RART_CHECK_ARG(out && x0 && eta2 && transposed && signs && batch > 0 && c > 0 && c <= kSqC && h > 0 && w > 0 && (norm == 1 || norm == 2),

@@ -266,9 +266,24 @@ def mim_linf(input, label, model, eps, num_steps, step_size, decay_factor, seed=
     return x
 
 
+def _grad_eot(prov, x_adv, y, loss_kind, y_target, eot_iter):
+    """One gradient evaluation of APGD: the gradient averaged over eot_iter passes, logits / losses / predictions of the last pass
+    (autopgd_base.py:271-289, :367-384).  eot_iter = 1 is the plain evaluation."""
+    logits, loss_indiv, grad, pred = prov.logits_and_grad(x_adv, y, loss_kind, y_target)
+    if eot_iter > 1:
+        lib = _lib.load()
+        acc = grad.contiguous().clone()                       # (the provider may hand out the same gradient buffer on every call)
+        for _ in range(eot_iter - 1):
+            logits, loss_indiv, g, pred = prov.logits_and_grad(x_adv, y, loss_kind, y_target)
+            _lib.check(lib.rart_eot_accumulate(_lib.ptr(acc), _lib.ptr(g.contiguous()), acc.numel(), 0, 1.0, _lib.stream_ptr()))
+        _lib.check(lib.rart_eot_accumulate(_lib.ptr(acc), None, acc.numel(), 1, float(eot_iter), _lib.stream_ptr()))
+        grad = acc
+    return logits, loss_indiv, grad, pred
+
+
 def _apgd_single_run(prov, x, y, norm, eps, n_iter, loss_kind, y_target=None, rho=0.75, seed=None,
-                     sample_offset=0, init_t=None):
-    """autopgd_base.py:208-448 (Linf / L2, eot_iter 1).  Returns (x_best, acc, loss_best, x_best_adv).
+                     sample_offset=0, init_t=None, eot_iter=1):
+    """autopgd_base.py:208-448 (Linf / L2).  Returns (x_best, acc, loss_best, x_best_adv).
     Heavy tensors move only through HIP kernels; the [B]-sized step-size / checkpoint state is
     control-plane bookkeeping on small torch tensors, without host synchronisation."""
     torch = _lib.require_gpu()
@@ -279,7 +294,7 @@ def _apgd_single_run(prov, x, y, norm, eps, n_iter, loss_kind, y_target=None, rh
     x_best_adv = x_adv.clone()
     loss_steps = torch.zeros(n_iter, B, device=x.device)
 
-    logits, loss_indiv, grad, pred = prov.logits_and_grad(x_adv, y, loss_kind, y_target)
+    logits, loss_indiv, grad, pred = _grad_eot(prov, x_adv, y, loss_kind, y_target, eot_iter)
     grad_best = grad.clone()
     acc = pred.to(torch.int64) == y
     loss_best = loss_indiv.clone()
@@ -293,7 +308,7 @@ def _apgd_single_run(prov, x, y, norm, eps, n_iter, loss_kind, y_target=None, rh
     for i in range(n_iter):
         a = 0.75 if i > 0 else 1.0
         apgd_step_(x_adv, x_adv_old, grad, x, step_size, norm, eps, a)          # :327-348 (x_adv_old <- x_adv)
-        logits, loss_indiv, grad, pred = prov.logits_and_grad(x_adv, y, loss_kind, y_target)
+        logits, loss_indiv, grad, pred = _grad_eot(prov, x_adv, y, loss_kind, y_target, eot_iter)
         pred_ok = pred.to(torch.int64) == y
         acc = acc & pred_ok
         select_rows_(x_best_adv, x_adv, ~pred_ok)                               # :389-390
@@ -332,7 +347,7 @@ def _injected_start(init_ts, index, x_sub):
 
 
 def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce', n_restarts=1, seed=None,
-                 sample_offset=None, init_ts=None, _prov=None):
+                 sample_offset=None, init_ts=None, _prov=None, eot_iter=1):
     """APGDAttack.perturb (autopgd_base.py:450-529, best_loss=False)."""
     torch = _lib.require_gpu()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
@@ -348,7 +363,7 @@ def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce'
             x_f, y_f = x[ind_to_fool].contiguous(), y[ind_to_fool].contiguous()
             t = _injected_start(init_ts, counter, x_f)
             _, acc_curr, _, adv_curr = _apgd_single_run(prov, x_f, y_f, norm, eps, n_iter, kind, None, 0.75,
-                                                        _seed(seed) + counter, sample_offset, t)
+                                                        _seed(seed) + counter, sample_offset, t, eot_iter)
             ind_curr = (~acc_curr).nonzero().flatten()
             acc[ind_to_fool[ind_curr]] = False
             adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr]
@@ -821,7 +836,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); the
     untargeted `fab` of version 'plus' (a 1000-class Jacobian per step, unusable on ImageNet in the reference too)
     is reported as skipped (the result is then an upper bound on robust accuracy, never silently presented as the full
-    ensemble); apgd-ce / apgd-t / fab-t / square run for all three norms.
+    ensemble); apgd-ce / apgd-t / fab-t / square run for all three norms; version 'rand' = apgd-ce + apgd-dlr with the gradient
+    averaged over 20 passes (rart_eot_accumulate; Linf / L2).
     _overrides (parity tests only; the reference shrinks the same attributes, autoattack.py:253-267): dict with any of
     plan, apgd_iter, apgdt_iter, apgdt_classes, fab_iter, fab_classes, square_queries, and `draws` -- an object like
     oracle.attacks_ref.TorchStreamDraws replaying the reference's torch random stream instead of the counter-based RNG."""
@@ -835,15 +851,16 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
             'rand': ['apgd-ce', 'apgd-dlr']}.get(version)
     if plan is None:
         raise ValueError('unknown AutoAttack version %r' % (version,))
-    if version == 'rand':
-        raise NotImplementedError("AutoAttack version 'rand' (EOT over 20 forward passes) is not implemented")
     plan = list(ov.get('plan', plan))
     n_restarts = 5 if version == 'plus' else 1
+    eot_iter = int(ov.get('eot_iter', 20 if version == 'rand' else 1))          # autoattack.py:281-284
     apgd_iter, apgdt_iter = int(ov.get('apgd_iter', 100)), int(ov.get('apgdt_iter', 100))
     apgdt_classes, fab_iter, fab_classes = int(ov.get('apgdt_classes', 9)), int(ov.get('fab_iter', 100)), int(ov.get('fab_classes', 9))
     square_queries = int(ov.get('square_queries', 5000))
     draws = ov.get('draws')
     skipped = [a for a in plan if a in ('fab',)]
+    if norm == 'L1' and eot_iter > 1:
+        raise NotImplementedError("AutoAttack version 'rand' with norm 'L1': the EOT average is not wired into the L1 APGD loop")
     if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes
         n_restarts, apgdt_classes = int(ov.get('apgd_restarts', 5)), int(ov.get('apgdt_classes', 5))
     if skipped:
@@ -880,9 +897,9 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
                                            draws=(lambda j, shape: draws.randn(j, shape)) if draws is not None else None,
                                            n_target_classes=apgdt_classes if attack == 'apgd-t' else 0, _prov=prov)
             elif attack == 'apgd-ce':
-                adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'ce', n_restarts, sd, first, init_ts=ts, _prov=prov)
+                adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'ce', n_restarts, sd, first, init_ts=ts, _prov=prov, eot_iter=eot_iter)
             elif attack == 'apgd-dlr':
-                adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'dlr', n_restarts, sd, first, init_ts=ts, _prov=prov)
+                adv_curr = apgd_perturb(None, x, y, norm, eps, apgd_iter, 'dlr', n_restarts, sd, first, init_ts=ts, _prov=prov, eot_iter=eot_iter)
             elif attack == 'apgd-t':
                 adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, apgdt_iter, apgdt_classes, sd, first, init_ts=ts,
                                                  _prov=prov)

@@ -115,6 +115,7 @@ AA_CASES = {   # name -> (eps, plan or None (= the 'standard' order), apgd n_ite
     'reordered': (1 / 255, ['square', 'fab-t', 'apgd-t', 'apgd-ce'], 4, 4, 2, 6, 3, 40),
     'standard_L2': (0.12, None, 2, 2, 2, 6, 3, 40, 'L2'),
     'reordered_L2': (0.12, ['square', 'fab-t', 'apgd-t', 'apgd-ce'], 3, 3, 2, 5, 2, 30, 'L2'),
+    'rand': (1 / 255, None, 4, 0, 0, 0, 0, 0, 'Linf', 'rand', 3),       # version 'rand': apgd-ce + apgd-dlr with eot_iter passes (20 -> 3)
 }
 
 
@@ -136,7 +137,10 @@ def gen_autoattack():
     out = {'x': x.numpy(), 'y': y.numpy()}
     for name, case in AA_CASES.items():
         eps, plan, ai, ti, tc, fi, fc, sq = case[:8]
-        aa = AutoAttack(net, norm=case[8] if len(case) > 8 else 'Linf', eps=eps, seed=0, verbose=False, version='standard', device='cpu')
+        version = case[9] if len(case) > 9 else 'standard'
+        aa = AutoAttack(net, norm=case[8] if len(case) > 8 else 'Linf', eps=eps, seed=0, verbose=False, version=version, device='cpu')
+        if version == 'rand':
+            aa.apgd.eot_iter = case[10]
         aa.apgd.n_iter = ai
         aa.apgd_targeted.n_iter, aa.apgd_targeted.n_target_classes = ti, tc
         aa.fab.n_iter, aa.fab.n_target_classes = fi, fc
@@ -147,7 +151,7 @@ def gen_autoattack():
         out[f'{name}/adv'] = adv.detach().numpy()
         out[f'{name}/robust'] = (net(normalize(adv)).max(1)[1] == y).numpy()
         # the same run one attack at a time (run_standard_evaluation_individual, autoattack.py:228-249)
-        aa.attacks_to_run = list(plan) if plan is not None else ['apgd-ce', 'apgd-t', 'fab-t', 'square']
+        aa.attacks_to_run = list(plan) if plan is not None else (['apgd-ce', 'apgd-dlr'] if version == 'rand' else ['apgd-ce', 'apgd-t', 'fab-t', 'square'])
         indiv = aa.run_standard_evaluation_individual(x.clone(), y.clone(), bs=len(x))
         for k, v in indiv.items():
             out[f'{name}/individual/{k}'] = v.detach().numpy()

@@ -379,7 +379,8 @@ def test_apgd_targeted_matches_reference_golden():
 AA_CASES = {'standard': (1 / 255, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 10, 3, 60),
             'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40),
             'standard_L2': (0.12, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 6, 3, 40, 'L2'),
-            'reordered_L2': (0.12, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 3, 3, 2, 5, 2, 30, 'L2')}
+            'reordered_L2': (0.12, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 3, 3, 2, 5, 2, 30, 'L2'),
+            'rand': (1 / 255, ('apgd-ce', 'apgd-dlr'), 4, 0, 0, 0, 0, 0, 'Linf', 'rand', 3)}      # version 'rand', eot_iter 20 -> 3
 
 
 @pytest.mark.parametrize('case', sorted(AA_CASES))
@@ -394,9 +395,12 @@ def test_autoattack_linf_orchestrator_matches_reference_golden(case):
     x, y = torch.from_numpy(ga['x']), torch.from_numpy(ga['y'])
     eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case][:8]
     norm = AA_CASES[case][8] if len(AA_CASES[case]) > 8 else 'Linf'       # L2: APGD / APGD-T / FAB-T / Square all in their L2 forms
+    version = AA_CASES[case][9] if len(AA_CASES[case]) > 9 else 'standard'
     ov = dict(plan=plan, apgd_iter=ai, apgdt_iter=ti, apgdt_classes=tc, fab_iter=fi, fab_classes=fc, square_queries=sq,
               draws=A.TorchStreamDraws(0))
-    got = adv.autoattack_linf(x.cuda(), y.cuda(), netc, norm, eps, 'standard', False, _overrides=ov).cpu()
+    if version == 'rand':
+        ov['eot_iter'] = AA_CASES[case][10]                  # (20 in the reference; the golden run shrank it like the iteration counts)
+    got = adv.autoattack_linf(x.cuda(), y.cuda(), netc, norm, eps, version, False, _overrides=ov).cpu()
     want = torch.from_numpy(ga[f'{case}/adv'])
     torch.testing.assert_close(got, want, atol=5e-5, rtol=0)
     robust = (netc((got.cuda() - torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1).cuda()) /
@@ -406,10 +410,10 @@ def test_autoattack_linf_orchestrator_matches_reference_golden(case):
     # native (counter-based) draws through the AddNoise plugin entry: eps-ball, box, reproducible
     from robustart_amd.noise import AddNoise, rng
     an = AddNoise('autoattack_linf')
-    an.set_config(model=netc, norm=norm, eps=eps, version='standard', verbose=False)
+    an.set_config(model=netc, norm=norm, eps=eps, version=version, verbose=False)
     rng.manual_seed(5)
-    a = adv.autoattack_linf(x.cuda(), y.cuda(), netc, norm, eps, 'standard', False,
-                            _overrides=dict(apgd_iter=3, apgdt_iter=2, apgdt_classes=2, fab_iter=3, fab_classes=2, square_queries=20))
+    a = adv.autoattack_linf(x.cuda(), y.cuda(), netc, norm, eps, version, False,
+                            _overrides=dict(apgd_iter=3, apgdt_iter=2, apgdt_classes=2, fab_iter=3, fab_classes=2, square_queries=20, eot_iter=2))
     r = (a.cpu() - x).flatten(1)
     assert ((r.abs().max(1)[0] if norm == 'Linf' else r.norm(dim=1)) <= eps * (1 + 1e-5) + 1e-6).all() and a.min() >= 0 and a.max() <= 1
 

@@ -278,7 +278,8 @@ def test_square_l2_l1_match_reference():
 AA_CASES = {'standard': (1 / 255, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 10, 3, 60),
             'reordered': (1 / 255, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 4, 4, 2, 6, 3, 40),
             'standard_L2': (0.12, ('apgd-ce', 'apgd-t', 'fab-t', 'square'), 2, 2, 2, 6, 3, 40, 'L2'),
-            'reordered_L2': (0.12, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 3, 3, 2, 5, 2, 30, 'L2')}
+            'reordered_L2': (0.12, ('square', 'fab-t', 'apgd-t', 'apgd-ce'), 3, 3, 2, 5, 2, 30, 'L2'),
+            'rand': (1 / 255, ('apgd-ce', 'apgd-dlr'), 4, 0, 0, 0, 0, 0, 'Linf', 'rand', 3)}      # version 'rand', eot_iter 20 -> 3
 
 
 @pytest.mark.parametrize('case', sorted(AA_CASES))
@@ -290,7 +291,8 @@ def test_autoattack_orchestrator_matches_reference(gold_a, gold_aa, case):
     x, y = torch.from_numpy(gold_aa['x']), torch.from_numpy(gold_aa['y'])
     eps, plan, ai, ti, tc, fi, fc, sq = AA_CASES[case][:8]
     kw = dict(apgd_iter=ai, apgdt_iter=ti, apgdt_classes=tc, fab_iter=fi, fab_classes=fc, square_queries=sq,
-              norm=AA_CASES[case][8] if len(AA_CASES[case]) > 8 else 'Linf')       # (the L2 ensemble: APGD / FAB-T / Square in their L2 forms)
+              norm=AA_CASES[case][8] if len(AA_CASES[case]) > 8 else 'Linf',       # (the L2 ensemble: APGD / FAB-T / Square in their L2 forms)
+              eot_iter=AA_CASES[case][10] if len(AA_CASES[case]) > 10 else 1)      # (version 'rand': gradients averaged over eot_iter passes)
     trace = []
     adv = A.autoattack_linf(model_fn, x, y, eps, A.TorchStreamDraws(0), plan=plan, trace=trace, **kw)
     np.testing.assert_allclose(adv.numpy(), gold_aa[f'{case}/adv'], atol=1e-6)
