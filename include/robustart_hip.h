@@ -330,6 +330,9 @@ int rart_igemm_set_bk64_min_k(long long k);
 /* Tuning knob: plain row-major products (one tap, unit strides, no batching, flags within GELU / GELU') with at least 512 tiles of
  * 256 x 256 run on the 8-wave 256 x 256 x 64 kernel with direct-to-LDS tiles (the transformer layers); 0 disables it. */
 int rart_igemm_set_gemm256(int enable);
+/* 1 when a plain product of `rows` x k (leading dimension src_ld) by n_cols columns takes the 256 x 256 GEMM kernel -- the only kernel that
+ * serves flag 64 (GELU with the pre-activation kept: dst = gelu(u), `mask` RECEIVES the bf16 pre-activation u; ViT fc1 in keep mode). */
+int rart_gemm256_supported(long long rows, int k, int n_cols, int src_ld, int dst_ld);
 
 /* 3x3 stride-1 "same" convolution, channels in = channels out = 64, 128 or 256 (256: images of at most 224 positions, one
  * image per workgroup), bf16 NHWC, with the input halo tile resident in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 /

@@ -96,6 +96,7 @@ SIGNATURES = {
                                            c_void_p]),
     'rart_igemm_set_bk64_min_k': (c_int, [ctypes.c_longlong]),
     'rart_igemm_set_gemm256': (c_int, [c_int]),
+    'rart_gemm256_supported': (c_int, [ctypes.c_longlong, c_int, c_int, c_int, c_int]),
     'rart_engine_prep_input': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),
     'rart_engine_maxpool': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

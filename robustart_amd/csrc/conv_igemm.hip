@@ -64,7 +64,7 @@ struct RartConvDescDev {
 namespace {
 constexpr int BM = 128;
 constexpr int kThreads = 256;
-enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8, F_MASK_BITS = 16, F_PAIR = 32 };
+enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8, F_MASK_BITS = 16, F_PAIR = 32, F_GELU_KEEP = 64 };
 
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
@@ -681,6 +681,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm256_bf16(const RartGemm256Desc d
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
         }
+        if (d.flags & F_GELU_KEEP) {
+          // two outputs: the bf16 pre-activation u (the backward's GELU' operand) goes to `mask`, dst receives gelu(u) of the ROUNDED u --
+          // bit-identical to writing u and running k_gelu over it, without the second pass over the hidden tensor
+          const uint4 up = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+          *reinterpret_cast<uint4*>(const_cast<uint16_t*>(d.mask) + (size_t)row * d.ldc + col) = up;
+          const uint32_t uw[4] = {up.x, up.y, up.z, up.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] = gelu_erf(__uint_as_float(uw[j] << 16));
+            v[2 * j + 1] = gelu_erf(__uint_as_float(uw[j] & 0xFFFF0000u));
+          }
+        }
         if (d.flags & F_GELU_BWD) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -719,14 +731,22 @@ static bool gemm256_takes(const rart_conv_desc* h, long long* m_out) {
     return false;
   if (h->src_h != h->grid_h || h->dst_h != h->grid_h || h->n_batched > 1 || h->sign_out) return false;
   if (h->wgt_row_stride != 0 && h->wgt_row_stride != h->k_per_tap) return false;
-  if (h->flags & ~(F_GELU | F_GELU_BWD)) return false;
-  if ((h->flags & F_GELU_BWD) ? !h->mask : (h->mask != nullptr)) return false;
+  if (h->flags & ~(F_GELU | F_GELU_BWD | F_GELU_KEEP)) return false;
+  if ((h->flags & (F_GELU_BWD | F_GELU_KEEP)) ? !h->mask : (h->mask != nullptr)) return false;
+  if ((h->flags & F_GELU_KEEP) && (h->flags & (F_GELU | F_GELU_BWD))) return false;
   if (h->k_per_tap % 64 != 0 || h->n_cols % G2_TN != 0 || h->src_pix_stride % 8 != 0 || h->dst_pix_stride % 8 != 0) return false;
   const long long M = (long long)h->batch * h->grid_h;
   if (M * h->src_pix_stride >= (1ll << 31) || M * h->dst_pix_stride >= (1ll << 31)) return false;
   if (((M + G2_TM - 1) / G2_TM) * (h->n_cols / G2_TN) < 512) return false;
   *m_out = M;
   return true;
+}
+
+// would a plain rows x k (leading dimension src_ld) by n_cols product (output leading dimension dst_ld) take the 256 x 256 GEMM?
+extern "C" int rart_gemm256_supported(long long rows, int k, int n_cols, int src_ld, int dst_ld) {
+  if (!g_gemm256_enabled || rows <= 0 || k <= 0 || k % 64 != 0 || n_cols <= 0 || n_cols % G2_TN != 0 || src_ld % 8 != 0 || dst_ld % 8 != 0) return 0;
+  if (rows * src_ld >= (1ll << 31) || rows * dst_ld >= (1ll << 31)) return 0;
+  return ((rows + G2_TM - 1) / G2_TM) * (n_cols / G2_TN) >= 512 ? 1 : 0;
 }
 
 extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t stream) {
@@ -750,6 +770,11 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
       hipLaunchKernelGGL(k_gemm256_bf16, dim3((uint32_t)(m8 * (g.N / G2_TN))), dim3(512), 0, (hipStream_t)stream, g);
       RART_CHECK_LAUNCH("rart_conv_igemm_bf16 (256 x 256 GEMM)");
       return RART_OK;
+    }
+    if (h->flags & F_GELU_KEEP) {
+      rart_set_error("rart_conv_igemm_bf16: flag 64 (GELU with the pre-activation kept) is served by the 256 x 256 GEMM only: ask "
+                     "rart_gemm256_supported first");
+      return RART_ERR_UNSUPPORTED;
     }
   }
   RartConvDescDev d;

@@ -13,6 +13,7 @@ import ctypes
 from .. import _lib
 
 F_RELU, F_OUT_F32, F_GELU, F_GELU_BWD = 1, 2, 4, 8
+F_GELU_KEEP = 64          # dst = gelu(u), `mask` receives the pre-activation u (256 x 256 GEMM only)
 
 
 class ViTEngine:
@@ -173,8 +174,12 @@ class ViTEngine:
             hid = self._get('hid', (B, T, L['hidden']))
             if keep:
                 u = self._get('u%d' % li, (B, T, L['hidden']))
-                self._gemm(ln, L['fc1_w'], u, rows, D, L['hidden'], D, L['hidden'], bias=L['fc1_b'])
-                _lib.check(lib.rart_gelu_bf16(_lib.ptr(u), _lib.ptr(hid), u.numel(), sp))
+                if lib.rart_gemm256_supported(rows, D, L['hidden'], D, L['hidden']):
+                    # one launch writes both the pre-activation (for GELU' in the backward) and gelu of it
+                    self._gemm(ln, L['fc1_w'], hid, rows, D, L['hidden'], D, L['hidden'], bias=L['fc1_b'], mask=u, flags=F_GELU_KEEP)
+                else:
+                    self._gemm(ln, L['fc1_w'], u, rows, D, L['hidden'], D, L['hidden'], bias=L['fc1_b'])
+                    _lib.check(lib.rart_gelu_bf16(_lib.ptr(u), _lib.ptr(hid), u.numel(), sp))
                 saved.append((x, xm, qkv, u, att))
             else:
                 self._gemm(ln, L['fc1_w'], hid, rows, D, L['hidden'], D, L['hidden'], bias=L['fc1_b'], flags=F_GELU)

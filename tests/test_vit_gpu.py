@@ -316,6 +316,56 @@ def test_vit_train_engine_parameter_gradients_match_torch_autograd():
     assert all(0.9 < r < 1.1 for _, r, _ in rep), [x for x in rep if not 0.9 < x[1] < 1.1][:8]
 
 
+def test_gemm256_gelu_keep_equals_the_two_launch_form():
+    """Flag 64 of the 256 x 256 GEMM (dst = gelu(u), `mask` receives the bf16 pre-activation u: ViT fc1 when the backward will need u)
+    against the plain product followed by rart_gelu_bf16: u bit-identical, gelu(u) within bf16 rounding; the 128 x 128 kernel refuses the flag and
+    rart_gemm256_supported tells the engine which launches qualify."""
+    import ctypes
+    from robustart_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 256 * 32 + 37, 192, 4096
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+
+    def run(flags, keep_out):
+        out = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+        d = _lib.ConvDesc()
+        d.src, d.wgt, d.dst = a.data_ptr(), w.data_ptr(), out.data_ptr()
+        d.bias = bias.data_ptr()
+        d.mask = keep_out.data_ptr() if keep_out is not None else None
+        d.batch, d.grid_h, d.grid_w = 1, M, 1
+        d.src_h, d.src_w, d.src_pix_stride = M, 1, K
+        d.k_per_tap, d.n_taps, d.sy, d.sx = K, 1, 1, 1
+        d.n_cols, d.dst_h, d.dst_w = N, M, 1
+        d.dst_sy, d.dst_sx, d.dst_oy, d.dst_ox, d.dst_pix_stride = 1, 1, 0, 0, N
+        d.flags = flags
+        st = lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        return st, out
+
+    assert lib.rart_gemm256_supported(M, K, N, K, N) == 1 and lib.rart_gemm256_supported(64, K, N, K, N) == 0
+    st, u_ref = run(0, None)
+    assert st == 0
+    hid_ref = torch.empty_like(u_ref)
+    _lib.check(lib.rart_gelu_bf16(_lib.ptr(u_ref), _lib.ptr(hid_ref), u_ref.numel(), _lib.stream_ptr()))
+    u = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+    st, hid = run(64, u)
+    assert st == 0 and torch.equal(u, u_ref)              # the pre-activation is the plain product's output, bit for bit
+    # gelu of the ROUNDED u: within bf16 rounding of the exact function, and within one bf16 step of the stand-alone kernel
+    # (which evaluates erff; the GEMM epilogues use the 1.5e-7 Abramowitz-Stegun form shared with flag 4)
+    exact = torch.nn.functional.gelu(u_ref.double())
+    assert ((hid.double() - exact).abs() <= exact.abs() * 2.0 ** -8 + 1e-6).all()
+    assert ((hid.double() - hid_ref.double()).abs() <= hid_ref.double().abs() * 2.0 ** -7 + 1e-6).all()
+    try:
+        lib.rart_igemm_set_gemm256(0)
+        st, _ = run(64, u)
+        assert st == 2 and b'flag 64' in lib.rart_last_error_string()
+    finally:
+        lib.rart_igemm_set_gemm256(1)
+
+
 @pytest.mark.parametrize('flags,use_res', [(0, False), (0, True), (4, False), (8, False)])
 def test_gemm256_kernel_vs_torch_and_the_128_kernel(flags, use_res):
     """The 256 x 256 x 64 direct-to-LDS GEMM (k_gemm256_bf16, taken by plain products with >= 512 tiles) against fp64 and
