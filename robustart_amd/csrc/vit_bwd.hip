@@ -169,14 +169,20 @@ __global__ __launch_bounds__(kBlock) void k_softmax_bwd_rows(const uint16_t* __r
 struct Istd3 { float v[3]; };
 __global__ __launch_bounds__(kBlock) void k_unpatchify(const uint16_t* __restrict__ dp, float* __restrict__ grad, int n, int h,
                                                        int w, int ps, long long ld, Istd3 is) {
-  const int gw = w / ps, gh = h / ps;
-  const size_t total = (size_t)n * 3 * h * w;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const int x = (int)(i % w), y = (int)((i / w) % h), c = (int)((i / ((size_t)w * h)) % 3);
-    const int img = (int)(i / ((size_t)3 * w * h));
-    const int px = x / ps, py = y / ps;
+  // eight consecutive x of one image row (ps % 8 == 0, ld % 8 == 0: they sit in one patch row): one 16-byte load, two 16-byte stores
+  const uint32_t gw = (uint32_t)(w / ps), gh = (uint32_t)(h / ps), w8 = (uint32_t)w / 8;
+  const uint32_t total = (uint32_t)n * 3u * (uint32_t)h * w8;              // host: < 2^32
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+    const uint32_t x8 = i % w8, t = i / w8, y = t % (uint32_t)h, t2 = t / (uint32_t)h, c = t2 % 3u, img = t2 / 3u;
+    const uint32_t x = x8 * 8, px = x / (uint32_t)ps, py = y / (uint32_t)ps;
     const size_t prow = (size_t)img * gh * gw + (size_t)py * gw + px;
-    grad[i] = bf2f(dp[prow * ld + (size_t)c * ps * ps + (y % ps) * ps + (x % ps)]) * is.v[c];
+    const uint4 v = *reinterpret_cast<const uint4*>(dp + prow * ld + (size_t)c * ps * ps + (y % (uint32_t)ps) * ps + (x % (uint32_t)ps));
+    const float sc = is.v[c];
+    float4* o = reinterpret_cast<float4*>(grad + (size_t)i * 8);
+    o[0] = make_float4(__uint_as_float(v.x << 16) * sc, __uint_as_float(v.x & 0xFFFF0000u) * sc, __uint_as_float(v.y << 16) * sc,
+                       __uint_as_float(v.y & 0xFFFF0000u) * sc);
+    o[1] = make_float4(__uint_as_float(v.z << 16) * sc, __uint_as_float(v.z & 0xFFFF0000u) * sc, __uint_as_float(v.w << 16) * sc,
+                       __uint_as_float(v.w & 0xFFFF0000u) * sc);
   }
 }
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
@@ -230,9 +236,11 @@ int rart_vit_unpatchify_f32(const void* dpatches, float* grad, int n, int h, int
                             const float* std_host, rart_stream_t stream) {
   RART_CHECK_ARG(dpatches && grad && std_host && n > 0 && patch > 0 && h % patch == 0 && w % patch == 0 &&
                      ld >= 3 * patch * patch, "rart_vit_unpatchify_f32: bad arguments");
+  RART_CHECK_ARG(patch % 8 == 0 && ld % 8 == 0 && (size_t)n * 3 * h * w / 8 < (1ull << 32),
+                 "rart_vit_unpatchify_f32: patch side and row stride must be multiples of 8 (eight pixels per thread)");
   Istd3 is;
   for (int c = 0; c < 3; ++c) is.v[c] = 1.0f / std_host[c];
-  hipLaunchKernelGGL(k_unpatchify, dim3(grid_for((size_t)n * 3 * h * w)), dim3(kBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_unpatchify, dim3(grid_for((size_t)n * 3 * h * w / 8)), dim3(kBlock), 0, (hipStream_t)stream,
                      (const uint16_t*)dpatches, grad, n, h, w, patch, (long long)ld, is);
   RART_CHECK_LAUNCH("rart_vit_unpatchify_f32");
   return RART_OK;
