@@ -290,6 +290,32 @@ def test_square_l2_l1_match_reference():
         assert (nr <= eps * (1 + 1e-4)).all() and (nr >= eps * 0.5).all() and xb.min() >= -1e-6 and xb.max() <= 1 + 1e-6
 
 
+def test_l2_l1_attack_edge_batches():
+    """FAB-T / Square (L2, L1) and AutoAttack on degenerate batches: every label already wrong (nothing is attacked: the input comes
+    back), a batch of one, and a batch where only one image is still correct (the reference squeezes such index tensors, fab_base.py:112,
+    square.py:572-574)."""
+    from robustart_amd.noise import adv
+    gen = torch.Generator().manual_seed(12)
+    x = torch.rand(3, 3, 32, 32, generator=gen).cuda()
+    wv = torch.randn(3 * 32 * 32, 10, generator=gen).cuda() * 0.05
+    lin = lambda z: z.flatten(1) @ wv  # noqa: E731
+    y = lin(x).argmax(1)
+    wrong = (y + 1) % 10
+    for norm, eps in (('L2', 0.5), ('L1', 8.0)):
+        assert torch.equal(adv.fab_targeted_perturb(lin, x, wrong, eps, 3, 2, norm=norm), x)
+        assert torch.equal(adv.square_lp_perturb(lin, x, wrong, norm, eps, 5, seed=1, sample_offset=0), x)
+        one = adv.fab_targeted_perturb(lin, x[:1], y[:1], eps, 3, 2, norm=norm)
+        assert one.shape == (1, 3, 32, 32) and torch.isfinite(one).all()
+        one = adv.square_lp_perturb(lin, x[:1], y[:1], norm, eps, 5, seed=1, sample_offset=0)
+        assert one.shape == (1, 3, 32, 32) and torch.isfinite(one).all()
+        mixed = torch.stack([wrong[0], y[1], wrong[2]])
+        for out in (adv.fab_targeted_perturb(lin, x, mixed, eps, 3, 2, norm=norm),
+                    adv.square_lp_perturb(lin, x, mixed, norm, eps, 5, seed=1, sample_offset=0)):
+            assert torch.equal(out[0], x[0]) and torch.equal(out[2], x[2]) and torch.isfinite(out).all()
+            r = (out[1] - x[1]).flatten()
+            assert (r.norm() if norm == 'L2' else r.abs().sum()) <= eps * (1 + 1e-4)
+
+
 def test_native_pgd_linf_invariants_at_imagenet_size():
     """BASELINE-size property checks (no oracle run needed): eps-ball, box, determinism, sharding."""
     from robustart_amd.noise import adv
