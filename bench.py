@@ -293,7 +293,8 @@ def measure_igemm_roofline(path, images, labels):
                  'bottleneck28': 'k_bottleneck28 (layer2 identity blocks fused, a quarter image per workgroup)',
                  'bottleneck7': 'k_bottleneck7 (layer4 identity blocks fused, one image per workgroup)',
                  'bottleneck_s2': 'k_bottleneck_s2 (stride-2 first blocks of layer2 / layer3, forward: 1x1 + 3x3/2 + 1x1 + projection in one launch)',
-                 'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd (the same blocks, backward-to-input in one launch)'}
+                 'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd (the same blocks, backward-to-input in one launch)',
+                 'fc_small_m': 'k_gemm_small_m (classifier head and its backward: one 32 x 32 tile per workgroup, waves split K)'}
         out['other_mfma_kernels'] = {}
         for kind in sorted(set(p[3] for p in halo)):
             grp = [p for p in halo if p[3] == kind]

@@ -329,6 +329,11 @@ int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
 int rart_igemm_set_bk64_min_k(long long k);
 /* Tuning knob: plain row-major products (one tap, unit strides, no batching, flags within GELU / GELU') with at least 512 tiles of
  * 256 x 256 run on the 8-wave 256 x 256 x 64 kernel with direct-to-LDS tiles (the transformer layers); 0 disables it. */
+/* Small-M product C[m][n] = A[m][k] . W[n][k]^T (+ bias[n]) for the classifier head and its backward (m = the batch): one workgroup per
+ * 32 x 32 output tile, four waves split k (k % 64 == 0), fragments straight from global memory.  out: fp32 (out_is_f32) or bf16, leading
+ * dimension ldo.  Replaces the 16-workgroup implicit-GEMM launch of the fc layer (RobustART/model -> public ResNet-50 `fc`). */
+int rart_gemm_small_m_bf16(const void* a, int lda, const void* w, int ldw, const float* bias, void* out, int ldo, int out_is_f32, int m,
+                           int n, int k, rart_stream_t stream);
 int rart_igemm_set_gemm256(int enable);
 /* 1 when a plain product of `rows` x k (leading dimension src_ld) by n_cols columns takes the 256 x 256 GEMM kernel -- the only kernel that
  * serves flag 64 (GELU with the pre-activation kept: dst = gelu(u), `mask` RECEIVES the bf16 pre-activation u; ViT fc1 in keep mode). */

@@ -95,6 +95,7 @@ SIGNATURES = {
     'rart_bottleneck_fused_bf16': (c_int, [c_void_p] * 11 + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
                                            c_void_p]),
     'rart_igemm_set_bk64_min_k': (c_int, [ctypes.c_longlong]),
+    'rart_gemm_small_m_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_igemm_set_gemm256': (c_int, [c_int]),
     'rart_gemm256_supported': (c_int, [ctypes.c_longlong, c_int, c_int, c_int, c_int]),
     'rart_engine_prep_input': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -267,6 +267,48 @@ Norm3 make_norm(const float* mean, const float* std) {
   return nm;
 }
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
+
+// ---- small-M GEMM: C[M][N] = A[M][K] . W[N][K]^T (+ bias) for the classifier head and its backward (M = the batch, 256) ------------------
+// The implicit-GEMM kernel gives such a product 2 x 8 tiles of 128 x 128: 16 workgroups for 256 CUs, each walking the whole K (43 us for
+// 1 GFLOP).  Here a workgroup owns ONE 32 x 32 output tile (8 x 32 = 256 of them for the head) and its four waves split K; the operands
+// are used once per workgroup, so the MFMA fragments come straight from global memory (A is 1 MB, W 4 MB: L2 resident), 16 bytes per
+// lane, and the four partial tiles are summed through LDS in a fixed order.
+typedef __attribute__((ext_vector_type(8))) __bf16 sm_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float sm_f32x16;
+__global__ __launch_bounds__(kBlock) void k_gemm_small_m(const uint16_t* __restrict__ a, int lda, const uint16_t* __restrict__ wgt, int ldw,
+                                                         const float* __restrict__ bias, void* __restrict__ out, int ldo, int out_f32,
+                                                         int M, int N, int K) {
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int row_a = min(m0 + l31, M - 1), row_w = min(n0 + l31, N - 1);       // rows past the edge recompute the last one; never stored
+  const int kq = K / 4;                                                        // host: K % 64 == 0
+  const uint16_t* pa = a + (size_t)row_a * lda + wave * kq + hh * 8;
+  const uint16_t* pw = wgt + (size_t)row_w * ldw + wave * kq + hh * 8;
+  sm_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < kq; k += 16) {
+    const uint4 av = *reinterpret_cast<const uint4*>(pa + k), wv = *reinterpret_cast<const uint4*>(pw + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sm_bf16x8, av), __builtin_bit_cast(sm_bf16x8, wv), acc, 0, 0, 0);
+  }
+  // acc[r] = partial C[m0 + (r&3) + 8*(r>>2) + 4*hh][n0 + l31]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = wave * 4 + q;
+    const float v = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh, n = n0 + l31;
+    if (m < M && n < N) {
+      const float y = v + (bias ? bias[n] : 0.f);
+      if (out_f32) reinterpret_cast<float*>(out)[(size_t)m * ldo + n] = y;
+      else reinterpret_cast<uint16_t*>(out)[(size_t)m * ldo + n] = f2bf(y);
+    }
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -343,6 +385,17 @@ int rart_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int d
   hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3(grid_for((size_t)rows * dst_cols)), dim3(kBlock), 0, (hipStream_t)stream,
                      src, (uint16_t*)dst, rows, cols, dst_cols);
   RART_CHECK_LAUNCH("rart_f32_to_bf16_rows");
+  return RART_OK;
+}
+
+int rart_gemm_small_m_bf16(const void* a, int lda, const void* w, int ldw, const float* bias, void* out, int ldo, int out_is_f32, int m,
+                           int n, int k, rart_stream_t stream) {
+  RART_CHECK_ARG(a && w && out && m > 0 && n > 0 && k > 0 && k % 64 == 0 && lda >= k && ldw >= k && lda % 8 == 0 && ldw % 8 == 0 && ldo >= n,
+                 "rart_gemm_small_m_bf16: k must be a multiple of 64, leading dimensions multiples of 8 and at least k (a, w) / n (out)");
+  RART_CHECK_ARG((m + 31) / 32 <= 65535, "rart_gemm_small_m_bf16: m must stay below 2^21 rows (this is the small-M kernel)");
+  hipLaunchKernelGGL(k_gemm_small_m, dim3((n + 31) / 32, (m + 31) / 32), dim3(kBlock), 0, (hipStream_t)stream, (const uint16_t*)a, lda,
+                     (const uint16_t*)w, ldw, bias, out, ldo, out_is_f32, m, n, k);
+  RART_CHECK_LAUNCH("rart_gemm_small_m_bf16");
   return RART_OK;
 }
 

@@ -163,6 +163,7 @@ class ResNet50Engine:
         self.fused_bottleneck7 = True    # False: only layer4's
         self.fused_bottleneck_s2 = True  # False: the stride-2 first blocks of layer2 / layer3 as four conv launches in the forward (cross-check)
         self.fused_bottleneck_s2_bwd = True   # False: their backward-to-input as seven conv launches (cross-check)
+        self.small_m_fc = True           # False: the classifier head and its backward on the implicit GEMM (cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -380,6 +381,21 @@ class ResNet50Engine:
             self.profile.append((flops, e0, e1, 'igemm'))
             return
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _fc(self, a, w, out, m, n, k, bias=None):
+        """The classifier head / its backward: rart_gemm_small_m_bf16 (one workgroup per 32 x 32 tile, waves split K) instead of the
+        16-workgroup implicit-GEMM launch; `out` fp32 or bf16."""
+        torch = _lib.require_gpu()
+        args = (_lib.ptr(a), a.shape[-1], _lib.ptr(w), w.shape[-1], _lib.ptr(bias) if bias is not None else None, _lib.ptr(out),
+                out.shape[-1], 1 if out.dtype == torch.float32 else 0, m, n, k, _lib.stream_ptr())
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(self.lib.rart_gemm_small_m_bf16(*args))
+            e1.record()
+            self.profile.append((2.0 * m * n * k, e0, e1, 'fc_small_m'))
+            return
+        _lib.check(self.lib.rart_gemm_small_m_bf16(*args))
 
     @staticmethod
     def _fits32(n, hw, channels):
@@ -649,8 +665,11 @@ class ResNet50Engine:
         pooled = self._get('pooled', (B, self.fc_in))
         _lib.check(lib.rart_engine_avgpool(_lib.ptr(x), _lib.ptr(pooled), B, xhw[0] * xhw[1], self.fc_in, sp))
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
-        self._gemm(pooled, self.fc_w, logits, B, (1, 1), (1, 1), self.fc_in, self.fc_in, [(0, 0)], self.n_classes,
-                   (1, 1), self.n_classes, bias=self.fc_b, flags=F_OUT_F32)
+        if self.small_m_fc:
+            self._fc(pooled, self.fc_w, logits, B, self.n_classes, self.fc_in, bias=self.fc_b)
+        else:
+            self._gemm(pooled, self.fc_w, logits, B, (1, 1), (1, 1), self.fc_in, self.fc_in, [(0, 0)], self.n_classes,
+                       (1, 1), self.n_classes, bias=self.fc_b, flags=F_OUT_F32)
         acts['last'] = (x, xhw)
         acts['in_shape'] = (B, H, W)
         return logits, acts
@@ -789,8 +808,11 @@ class ResNet50Engine:
         dlb = self._get('dl_bf16', (B, self.fc_kpad))
         _lib.check(lib.rart_f32_to_bf16_rows(_lib.ptr(dl), _lib.ptr(dlb), B, self.n_classes, self.fc_kpad, sp))
         dpool = self._get('dpool', (B, self.fc_in))
-        self._gemm(dlb, self.fc_wd, dpool, B, (1, 1), (1, 1), self.fc_kpad, self.fc_kpad, [(0, 0)], self.fc_in, (1, 1),
-                   self.fc_in)
+        if self.small_m_fc:
+            self._fc(dlb, self.fc_wd, dpool, B, self.fc_in, self.fc_kpad)
+        else:
+            self._gemm(dlb, self.fc_wd, dpool, B, (1, 1), (1, 1), self.fc_kpad, self.fc_kpad, [(0, 0)], self.fc_in, (1, 1),
+                       self.fc_in)
         xl, xlhw = acts['last']
         dz = self._get('g_out_%d' % (len(self.blocks) - 1), tuple(xl.shape))
         _lib.check(lib.rart_engine_avgpool_bwd(_lib.ptr(xl), _lib.ptr(dpool), _lib.ptr(dz), B, xlhw[0] * xlhw[1],

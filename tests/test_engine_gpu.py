@@ -965,3 +965,37 @@ def test_fused_stride2_bottleneck_backward_vs_fp64(B, geo):
                                                _lib.ptr(ma), None, _lib.ptr(dx2), B, H, W, CIN, CM, COUT, sp))
     keep = unpack(mx)
     assert torch.equal(dx2.cpu()[keep], dx.cpu()[keep])
+
+
+def test_small_m_gemm_for_the_classifier_head():
+    """rart_gemm_small_m_bf16 (fc forward: fp32 logits + bias; fc backward: bf16 dpool) against fp64 on the same bf16 operands, ragged
+    m and n (rows / columns past the edge are never stored), and the engine switch small_m_fc against the implicit-GEMM head."""
+    from robustart_amd import _lib
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import ResNet50Engine
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for m, n, k, f32 in ((256, 1000, 2048, True), (37, 1000, 2048, True), (256, 2048, 1024, False), (5, 70, 64, False)):
+        a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        bias = torch.randn(n, generator=g).cuda() if f32 else None
+        out = torch.full((m + 3, n + 8), 7.0, dtype=torch.float32 if f32 else torch.bfloat16, device='cuda')
+        _lib.check(lib.rart_gemm_small_m_bf16(_lib.ptr(a), k, _lib.ptr(w), k, _lib.ptr(bias) if f32 else None, _lib.ptr(out), n + 8,
+                                              1 if f32 else 0, m, n, k, _lib.stream_ptr()))
+        ref = a.double() @ w.double().t() + (bias.double() if f32 else 0.0)
+        got = out[:m, :n].double()
+        tol = 1e-4 if f32 else 2.0 ** -8
+        assert ((got - ref).abs() <= tol * ref.abs() + 1e-3).all(), (m, n, k)
+        assert (out[m:] == 7.0).all() and (out[:, n:] == 7.0).all()
+    torch.manual_seed(0)
+    eng = ResNet50Engine(get_model({'type': 'resnet50_official'}).eval(), 'cuda')
+    x = torch.rand(4, 3, 64, 64, generator=g).cuda()
+    y = torch.tensor([1, 2, 3, 4]).cuda()
+    MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    l1, _, g1, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    l1, g1 = l1.clone(), g1.clone()
+    eng.small_m_fc = False
+    l0, _, g0, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    assert (l1 - l0).abs().max() <= 1e-4 * l0.abs().max()             # same bf16 operands, different fp32 summation order
+    a_, b_ = g1.flatten().double(), g0.flatten().double()
+    assert (a_ @ b_ / (a_.norm() * b_.norm())).item() > 0.9999
