@@ -288,7 +288,6 @@ __global__ __launch_bounds__(kBlock) void k_gemm_small_m(const uint16_t* __restr
   sm_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
   for (int k = 0; k < kq; k += 16) {
     const uint4 av = *reinterpret_cast<const uint4*>(pa + k), wv = *reinterpret_cast<const uint4*>(pw + k);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sm_bf16x8, av), __builtin_bit_cast(sm_bf16x8, wv), acc, 0, 0, 0);
