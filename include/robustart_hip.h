@@ -36,7 +36,7 @@ typedef void* rart_stream_t; /* hipStream_t */
 typedef enum rart_status {
   RART_OK = 0,
   RART_ERR_INVALID = 1,     /* bad argument (null pointer, severity outside 1..5, unknown id ...) */
-  RART_ERR_UNSUPPORTED = 2, /* valid request the library does not implement (e.g. spatter severity 1-3) */
+  RART_ERR_UNSUPPORTED = 2, /* valid request the library does not implement (e.g. a conv geometry no kernel instance covers) */
   RART_ERR_WORKSPACE = 3,   /* workspace missing or too small */
   RART_ERR_HIP = 4          /* a HIP runtime call failed */
 } rart_status;
@@ -50,6 +50,10 @@ enum {
   RART_SPATTER = 17, RART_SATURATE = 18, RART_NUM_CORRUPTIONS = 19
 };
 
+/* ABI version of THIS header.  Bumped whenever a struct layout or a signature changes (round 3 -> 4: rart_conv_desc grew
+ * its tap arrays from 16 to 32 entries and gained dst_pair_off / res_pair_off; several attack entries gained a per-row
+ * sample-index pointer).  A caller compiled against another header must refuse to run: compare with rart_version(). */
+#define RART_ABI_VERSION 104
 int rart_version(void);
 const char* rart_last_error_string(void);
 /* name of corruption id (static string), NULL if out of range */

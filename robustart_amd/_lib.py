@@ -13,6 +13,8 @@ c_void_p, c_int, c_size_t, c_u64, c_float = (ctypes.c_void_p, ctypes.c_int, ctyp
                                               ctypes.c_uint64, ctypes.c_float)
 c_double = ctypes.c_double
 
+ABI_VERSION = 104        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
+
 # name -> (restype, argtypes); every symbol include/robustart_hip.h declares
 SIGNATURES = {
     'rart_version': (c_int, []),
@@ -209,6 +211,10 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = header/library drift: fail loudly
         fn.restype = res
         fn.argtypes = args
+    got = lib.rart_version()
+    if got != ABI_VERSION:
+        raise RuntimeError('robustart_amd: %s reports ABI version %d, this binding expects %d (struct layouts / signatures '
+                           'differ) -- rebuild it with `python robustart_amd/csrc/build.py --force`' % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

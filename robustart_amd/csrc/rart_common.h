@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include "../../include/robustart_hip.h"
 
-#define RART_VERSION 100
+#define RART_VERSION RART_ABI_VERSION
 
 // ---- error plumbing ---------------------------------------------------------------
 void rart_set_error(const char* fmt, ...);

@@ -909,6 +909,24 @@ class EngineModel:
         self.rart_engine = engine or make_engine(torch_model, device, precision)
         self.takes_normalized = takes_normalized
         self.rart_mean_std = (tuple(mean), tuple(std))
+        self.rart_torch_model = torch_model          # kept so a reference-precision engine can be folded from the same weights
+        self._rart_ref_engine = None
+
+    def rart_reference_engine(self):
+        """The reference-precision ('fp32x') engine of the same module, built once and cached; the engine itself when it
+        already runs at that precision; None when this wrapper was given a bare engine (no module to fold from).
+        FAB needs it: its boundary projections work on the logit DIFFERENCE near zero, where bf16 storage dominates
+        (fab_pt.py:102-117; 34 % vs 5 % robust on the fitted network)."""
+        if self.rart_engine.precision != 'bf16':
+            return self.rart_engine
+        if self._rart_ref_engine is None and self.rart_torch_model is not None:
+            self._rart_ref_engine = make_engine(self.rart_torch_model, self.rart_engine.device, 'fp32x')
+        return self._rart_ref_engine
+
+    def rart_refold(self, torch_model=None):
+        """adversarial training: refresh the bf16 engine from the live weights and drop the cached reference engine"""
+        self.rart_engine.refold(torch_model or self.rart_torch_model)
+        self._rart_ref_engine = None
 
     def __call__(self, x):
         if self.takes_normalized:

@@ -171,6 +171,13 @@ class _Provider:
                 self.mean_std = getattr(fn, 'rart_mean_std', ((0., 0., 0.), (1., 1., 1.)))
         self._mean = self._std = None
 
+    def with_engine(self, engine):
+        """the same provider (normalisation convention, mean / std) on another engine of the same network"""
+        import copy
+        p = copy.copy(self)
+        p.engine = engine
+        return p
+
     def _prep(self, x):
         torch = _lib.require_gpu()
         if not self.normalize_inside:
@@ -799,19 +806,31 @@ def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.
     return adv_c
 
 
-def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_classes=9, _prov=None, norm='Linf'):
+def _fab_provider(prov, allow_bf16_fab):
+    """The provider FAB runs on.  Measured (tests/test_outcome_gpu.py, fitted ResNet-50, eps 4/255): FAB-T leaves 34 % robust on the
+    bf16 engine where the fp32 module and the reference-precision engine leave 5 % -- its projections linearise the boundary from the
+    logit difference near zero (fab_pt.py:102-117), where 3e-3 of logit error dominates.  The reference runs fp32, so a bf16
+    engine is swapped for the reference-precision engine of the same module (EngineModel.rart_reference_engine, built once and cached);
+    a bare bf16 engine without a module to fold from is refused unless the caller passes allow_bf16_fab=True."""
+    if prov.engine is None or getattr(prov.engine, 'precision', 'bf16x3') != 'bf16' or allow_bf16_fab:
+        return prov
+    ref = getattr(prov.fn, 'rart_reference_engine', None)
+    eng = ref() if ref is not None else None
+    if eng is None:
+        raise RuntimeError("FAB on a bf16 engine: its boundary projections need reference-precision logits. Wrap the torch module "
+                           "(EngineModel(module, ...)) so the 'fp32x' engine can be folded from it, build the engine with "
+                           "precision='fp32x', or pass allow_bf16_fab=True to accept a weaker attack")
+    return prov.with_engine(eng)
+
+
+def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_classes=9, _prov=None, norm='Linf', allow_bf16_fab=False):
     """FABAttack.perturb, targeted, norm Linf / L2 / L1, n_restarts 1 (fab_base.py:272-336).  FAB is deterministic without
-    random restarts, so there are no draws to inject."""
+    random restarts, so there are no draws to inject.  A bf16 engine is replaced by the reference-precision engine of the same
+    module (`_fab_provider`)."""
     torch = _lib.require_gpu()
     if norm not in _FAB_NORM:
         raise ValueError('norm not supported')                                             # fab_base.py:164
-    prov = _prov or _Provider(model_fn, normalize_inside=False)
-    if getattr(prov.engine, 'precision', 'bf16x3') == 'bf16':
-        # measured (tests/test_outcome_gpu.py, fitted ResNet-50, eps 4/255): FAB-T leaves 34 % robust on the bf16 engine where
-        # the fp32 module and the reference-precision engine leave 5 %: its projections work on the logit difference near zero
-        warnings.warn("FAB runs on a bf16 engine: its boundary projections need the logit difference near zero, where bf16 "
-                      "storage dominates; build EngineModel(..., precision='fp32x') for FAB / AutoAttack's fab-t stage",
-                      RuntimeWarning)
+    prov = _fab_provider(_prov or _Provider(model_fn, normalize_inside=False), allow_bf16_fab)
     x, y = _check_inputs(x, y)
     adv = x.clone()
     acc = prov.logits(x).max(1)[1] == y
@@ -830,7 +849,7 @@ def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_class
     return adv
 
 
-def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None, _overrides=None):
+def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None, _overrides=None, allow_bf16_fab=False):
     """attack.py:35-38 -> AutoAttack(model, norm, eps, version).run_standard_evaluation(x, y, bs=len(x))
     (autoattack.py:90-211).  `model` takes normalised input (NormalizeModel, autoattack.py:12-23).
     standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); the
@@ -904,7 +923,7 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
                 adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, apgdt_iter, apgdt_classes, sd, first, init_ts=ts,
                                                  _prov=prov)
             elif attack == 'fab-t':
-                adv_curr = fab_targeted_perturb(None, x, y, eps, fab_iter, fab_classes, _prov=prov, norm=norm)
+                adv_curr = fab_targeted_perturb(None, x, y, eps, fab_iter, fab_classes, _prov=prov, norm=norm, allow_bf16_fab=allow_bf16_fab)
             elif attack == 'square' and norm != 'Linf':
                 adv_curr = square_lp_perturb(None, x, y, norm, eps, square_queries, 0.8, False, sd, first, draws=draws, _prov=prov)
             elif attack == 'square':

@@ -36,7 +36,7 @@ _INJECT_LAYOUT = {
 }
 
 _frost_textures = []
-_frost_dev = None
+_frost_dev = {}          # device (str) -> stacked textures on that device
 
 
 def set_frost_textures(textures):
@@ -45,20 +45,22 @@ def set_frost_textures(textures):
     (corruptions.py:251-256); without textures `frost` raises FileNotFoundError here."""
     global _frost_textures, _frost_dev
     _frost_textures = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
-    _frost_dev = None
+    _frost_dev = {}
 
 
-def _frost_stack(torch):
-    """The registered photographs as one uint8 [k][Hmax][Wmax][3] device tensor (zero padded), built on first use."""
-    global _frost_dev
-    if _frost_dev is None:
+def _frost_stack(torch, device=None):
+    """The registered photographs as one uint8 [k][Hmax][Wmax][3] tensor (zero padded) on `device` (default: the current
+    device), built on first use and cached PER DEVICE: a process driving several GPUs gets one copy on each."""
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    key = str(dev)
+    if key not in _frost_dev:
         hm = max(t.shape[0] for t in _frost_textures)
         wm = max(t.shape[1] for t in _frost_textures)
         st = np.zeros((len(_frost_textures), hm, wm, 3), dtype=np.uint8)
         for i, t in enumerate(_frost_textures):
             st[i, :t.shape[0], :t.shape[1]] = t
-        _frost_dev = torch.from_numpy(st).cuda()
-    return _frost_dev
+        _frost_dev[key] = torch.from_numpy(st).to(dev)
+    return _frost_dev[key]
 
 
 def _as_device_batch(x):
@@ -82,7 +84,7 @@ def _as_device_batch(x):
     raise TypeError('expected (h, w, 3) or (n, h, w, 3) uint8 data')
 
 
-def _host_draws(name, n, severity, seed, offset):
+def _host_draws(name, n, severity, seed, offset, device=None):
     """Native-mode per-image scalar draws made on the host (counter based, stream ids >= 8)."""
     torch = _lib.require_gpu()
     if name == 'frost':
@@ -93,7 +95,7 @@ def _host_draws(name, n, severity, seed, offset):
         # corruptions.py:250,259: randint(5) over the 6-entry list, then the crop origin.  The photographs live on the device (uploaded
         # once, padded into one [k][H][W][3] stack); the n crops are ONE gather there -- the host loop used to copy 38 MB per 256
         # images through pageable memory (6.8 ms of a 7 ms frost call)
-        stack = _frost_stack(torch)
+        stack = _frost_stack(torch, device)          # on the BATCH's device (multi-GPU processes)
         k = min(5, len(_frost_textures))
         samples = offset + np.arange(n, dtype=np.int64)
         idx = (_rng.host_uniform_many(seed, samples, 8) * k).astype(np.int64)
@@ -121,7 +123,7 @@ def corrupt_batch_(batch, corruption_id, severity, seed=None, sample_offset=None
     if sample_offset is None:
         sample_offset = _rng.next_offset(n)
     if draws is None:
-        draws = _host_draws(name, n, severity, seed, sample_offset)
+        draws = _host_draws(name, n, severity, seed, sample_offset, batch.device)
     keep, held = [], []
     inj = None
     n_inj = 0

@@ -153,15 +153,17 @@ class FileImageNet(torch.utils.data.Dataset):
         img, lab = self.batch([i], 'cuda')
         return img[0], int(lab[0]), i
 
-    def box(self, i, hw):
-        """STANDARD: (y, x, h, w, flip) of sample i, drawn from (seed, i) with the reference's get_params loop"""
+    def box(self, i, hw, epoch=0):
+        """STANDARD: (y, x, h, w, flip) of sample i in `epoch`, drawn from (seed, epoch, i) with the reference's
+        get_params loop: torchvision's RandomResizedCrop / RandomHorizontalFlip redraw every time a sample is visited,
+        so the epoch is part of the key -- still a pure function of its arguments (resume-safe, world-size invariant)."""
         import random as _random
         from ..noise.imagenet_s import _train_params
-        r = _random.Random(self.seed * 1000003 + i)
+        r = _random.Random((self.seed * 1000003 + i) * 1000033 + int(epoch))
         y, x, h, w = _train_params(hw, r)
         return y, x, h, w, r.random() < 0.5
 
-    def batch(self, indices, device):
+    def batch(self, indices, device, epoch=0):
         from ..noise.imagenet_s import pil_resize
         dev = torch.device(device)
         if dev.type != 'cuda':
@@ -177,7 +179,7 @@ class FileImageNet(torch.utils.data.Dataset):
                 src = torch.from_numpy(arr).to(dev, non_blocking=True)[None]
                 out[k] = pil_resize(src, (r, r), 1, crop=(o, o, t, t))[0]
             else:
-                y, x, h, w, flip = self.box(i, arr.shape[:2])
+                y, x, h, w, flip = self.box(i, arr.shape[:2], epoch)
                 src = torch.from_numpy(arr[y:y + h, x:x + w].copy()).to(dev, non_blocking=True)[None]
                 img = pil_resize(src, (self.size, self.size), 1)[0]
                 out[k] = img.flip(1) if flip else img
@@ -233,9 +235,10 @@ def load_checkpoint_file(path):
     """torch.load restricted to tensors / containers / numbers (weights_only=True): a checkpoint is data, and a pickle from
     an untrusted source would execute code.  Checkpoints of this solver and plain state dicts load this way; a legacy
     reference checkpoint that pickles other objects needs the explicit opt-in RART_ALLOW_PICKLE_CHECKPOINT=1."""
+    import pickle
     try:
         return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception as e:  # noqa: BLE001  (pickle.UnpicklingError and friends)
+    except (pickle.UnpicklingError, RuntimeError) as e:      # a missing / unreadable file (OSError) propagates as itself
         if os.environ.get('RART_ALLOW_PICKLE_CHECKPOINT') == '1':
             return torch.load(path, map_location='cpu', weights_only=False)
         raise RuntimeError('%s does not load with weights_only=True (%s); set RART_ALLOW_PICKLE_CHECKPOINT=1 to unpickle a '
@@ -282,6 +285,43 @@ def shard_indices(n, rank, world):
     """`sampler.type: distributed` (non-repeating): contiguous ranges, the last ranks may get one fewer."""
     per = (n + world - 1) // world
     return list(range(min(rank * per, n), min((rank + 1) * per, n)))
+
+
+class EpochSampler:
+    """`sampler.type: distributed_iteration` of the training configs (pgd_adv_train/resnet50/config.yaml:39-41): every
+    epoch visits a fresh random permutation of the train set, dealt to the ranks by stride.  ImageNet's train list is
+    sorted by class, so file-order batches from contiguous per-rank ranges would hold one class each (degenerate
+    BatchNorm statistics and SGD).  The permutation is a pure function of (seed, epoch) -- numpy's RandomState stream --
+    so a resumed run and every world size of the same global batch see the same samples; the tail of an epoch wraps to
+    the permutation's head (DistributedSampler's padding), so every iteration has a full batch.
+    shuffle=False keeps file order (still strided over the ranks)."""
+
+    def __init__(self, n, batch_size, rank, world, seed=0, shuffle=True):
+        self.n, self.bs, self.rank, self.world = int(n), int(batch_size), int(rank), int(world)
+        self.seed, self.shuffle = int(seed), bool(shuffle)
+        self.per_epoch = max(1, -(-self.n // (self.bs * self.world)))
+        self._epoch, self._mine = None, None
+
+    def epoch_of(self, it):
+        return int(it) // self.per_epoch
+
+    def _order(self, epoch):
+        import numpy as np
+        if self._epoch != epoch:
+            if self.shuffle:
+                perm = np.random.RandomState((self.seed * 1000003 + epoch) % (2 ** 32)).permutation(self.n)
+            else:
+                perm = np.arange(self.n)
+            total = self.per_epoch * self.bs * self.world
+            perm = np.resize(perm, total)                      # repeats from the head when total > n
+            self._epoch, self._mine = epoch, perm[self.rank::self.world]
+        return self._mine
+
+    def batch(self, it):
+        """-> (global indices of this rank's batch at iteration `it`, epoch)"""
+        epoch = self.epoch_of(it)
+        k = int(it) % self.per_epoch
+        return [int(v) for v in self._order(epoch)[k * self.bs:(k + 1) * self.bs]], epoch
 
 
 def cosine_lr(step, total, base_lr, warmup_lr, warmup_steps, min_lr=0.0):
@@ -501,7 +541,7 @@ def train(cfg, args, rank, world, device):
     mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
     use_amp = device.type == 'cuda' and cfg.get('bf16', True)
-    idx = shard_indices(n, rank, world)
+    sampler = EpochSampler(n, bs, rank, world, int(dcfg.get('seed', 0)), bool(dcfg.get('shuffle', True)))
     loss_v = float('nan')
     attack_model = None
     scfg = cfg.get('saver', {}) or {}
@@ -513,11 +553,24 @@ def train(cfg, args, rank, world, device):
     if resume.get('last_iter') is not None and resume.get('optimizer') is not None:
         start_iter = min(int(resume['last_iter']), max_iter)
         ost = resume['optimizer']
+        # the two optimizer paths keep different state (flat arenas of the HIP step vs torch.optim's per-parameter
+        # dicts): resuming across them would either fail deep inside load_state_dict or silently restart the moments
+        # while the schedule continues -- refuse with a message that says so
+        is_torch_state = isinstance(ost, dict) and ost.get('torch') is not None
         if use_hip_opt:
+            if is_torch_state or not isinstance(ost, dict) or 'kind' not in ost:
+                raise RuntimeError("checkpoint's optimizer state was written by the torch scaffold (--engine torch); it cannot "
+                                   "resume the HIP optimizer. Resume with --engine torch, or drop it with "
+                                   "saver.pretrain.ignore.key: ['optimizer', 'last_iter'] to fine-tune from the weights")
+            if ost.get('kind') != kind:
+                raise RuntimeError('checkpoint optimizer kind %r != configured optimizer %r' % (ost.get('kind'), kind))
             opt.load_state_dict(ost)
         else:
-            if ost.get('torch') is not None:
-                opt.load_state_dict(ost['torch'])
+            if not is_torch_state:
+                raise RuntimeError("checkpoint's optimizer state was written by the HIP optimizer; it cannot resume the torch "
+                                   "scaffold (--engine torch / CPU). Resume on the GPU with --engine hip, or ignore "
+                                   "['optimizer', 'last_iter'] to fine-tune from the weights")
+            opt.load_state_dict(ost['torch'])
         if ema_on and resume.get('ema') is not None:
             esd = {(k[7:] if k.startswith('module.') else k): v for k, v in resume['ema'].items()}
             for nm, p_, o in zip(arena.names, arena.params, arena.offsets):
@@ -553,9 +606,9 @@ def train(cfg, args, rank, world, device):
 
     for it in range(start_iter, max_iter):
         lr = cosine_lr(it, max_iter, base_lr, warmup_lr, warmup_steps, min_lr)
-        sel = [idx[(it * bs + j) % len(idx)] for j in range(bs)]
+        sel, epoch = sampler.batch(it)
         items = sel
-        imgs, labels = ds.batch(sel, device)
+        imgs, labels = ds.batch(sel, device, epoch) if isinstance(ds, FileImageNet) else ds.batch(sel, device)
         x01 = imgs.permute(0, 3, 1, 2).float().div(255.0)
         if adv and device.type == 'cuda':
             # inner maximisation on the HIP eval engine with the CURRENT weights, BN in inference mode: the engine is
@@ -566,7 +619,7 @@ def train(cfg, args, rank, world, device):
                 model.eval()
                 attack_model = EngineModel(model, takes_normalized=False)
             else:
-                attack_model.rart_engine.refold(model)
+                attack_model.rart_refold(model)
             x01 = A.pgd_linf(x01.contiguous(), labels, attack_model, parse_eps(adv['eps']),
                              float(adv.get('rel_stepsize', 3 / 40)), int(adv.get('steps', 3)), seed=it,
                              sample_offset=sel[0])

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, s), 'header declares %s but the library does not export it' % s
     # and the ctypes table covers the header exactly (no drift in either direction)
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.load().rart_version() >= 100
+    assert _lib.load().rart_version() == _lib.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():

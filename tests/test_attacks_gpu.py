@@ -518,3 +518,32 @@ def test_apgd_l1_matches_reference_golden():
     b = adv.apgd_l1_perturb(net, xl, yl, 8.0, 10, 'ce', seed=2, sample_offset=0)
     assert torch.equal(a, b)
     assert ((a - xl).abs().flatten(1).sum(1) <= 8.0 * (1 + 1e-4)).all() and a.min() >= 0 and a.max() <= 1
+
+
+def test_fab_refuses_a_bare_bf16_engine_and_switches_when_it_has_the_module():
+    """FAB's projections need reference-precision logits (fab_pt.py:102-117).  A bf16 EngineModel built from a
+    module runs FAB on the cached 'fp32x' engine of the same module (no warning); a bare bf16 engine (no module to fold from) is
+    refused unless allow_bf16_fab=True."""
+    import warnings
+    from robustart_amd.noise import adv
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.model.resnet_torch import randomize_bn_stats
+    torch.manual_seed(0)
+    m = randomize_bn_stats(get_model({'type': 'resnet50_official'})).eval()
+    f = EngineModel(m, takes_normalized=False)
+    assert f.rart_engine.precision == 'bf16'
+    ref = f.rart_reference_engine()
+    assert ref is not None and ref.precision != 'bf16' and f.rart_reference_engine() is ref          # built once, cached
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    y = f(x).argmax(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        out = adv.fab_targeted_perturb(f, x, y, 4 / 255, 2, 1)
+    assert out.shape == x.shape and torch.isfinite(out).all()
+    bare = EngineModel(None, takes_normalized=False, engine=f.rart_engine)
+    with pytest.raises(RuntimeError, match='reference-precision'):
+        adv.fab_targeted_perturb(bare, x, y, 4 / 255, 2, 1)
+    out2 = adv.fab_targeted_perturb(bare, x, y, 4 / 255, 2, 1, allow_bf16_fab=True)
+    assert out2.shape == x.shape

@@ -208,3 +208,60 @@ def test_file_dataset_host_side(tmp_path):
     # the reference configs keep read_from: fake next to cluster paths: still the synthetic set
     fake = S.make_dataset(reference_shaped_config()['data'], 8, 32, 'test')
     assert isinstance(fake, S.FakeImageNet) and len(fake) == 8
+
+
+def test_epoch_sampler_shuffles_a_class_sorted_list_and_is_a_pure_function_of_seed_and_epoch():
+    """ImageNet's train list is sorted by class; file-order batches from contiguous per-rank ranges hold one class
+    each.  The `distributed_iteration` sampler of the reference configs (pgd_adv_train/resnet50/config.yaml:39-41) shuffles:
+    here a seeded permutation per epoch, dealt to the ranks by stride."""
+    from robustart_amd.train import cls_solver as S
+    n, bs, world = 1000, 10, 4
+    labels = [i // 100 for i in range(n)]                                  # class-sorted meta file: 10 classes x 100
+    samplers = [S.EpochSampler(n, bs, r, world, seed=5) for r in range(world)]
+    assert samplers[0].per_epoch == 25
+    seen = []
+    for it in range(25):
+        for sm in samplers:
+            sel, ep = sm.batch(it)
+            assert ep == 0 and len(sel) == bs
+            seen += sel
+            if it == 0:
+                assert len({labels[i] for i in sel}) >= 4                  # mixed classes inside a batch
+    assert sorted(seen) == list(range(n))                                  # one epoch visits every sample exactly once
+    # epoch 1 is another permutation; both are reproducible from (seed, epoch) alone -- a resumed run sees the same batches
+    e1 = samplers[0].batch(25)
+    assert e1[1] == 1 and e1[0] != samplers[0].batch(0)[0]
+    fresh = S.EpochSampler(n, bs, 0, world, seed=5)
+    assert fresh.batch(25) == e1 and fresh.batch(3) == samplers[0].batch(3)
+    assert S.EpochSampler(n, bs, 0, world, seed=6).batch(0)[0] != samplers[0].batch(0)[0]
+    # the ranks of a larger world see the same GLOBAL batch as one rank with world x the batch
+    one = S.EpochSampler(n, bs * world, 0, 1, seed=5)
+    assert sorted(one.batch(7)[0]) == sorted(i for sm in samplers for i in sm.batch(7)[0])
+    # ragged tail: wraps to the head of the permutation (DistributedSampler's padding): full batches always
+    rag = S.EpochSampler(23, 4, 1, 2, seed=0)
+    assert rag.per_epoch == 3 and all(len(rag.batch(k)[0]) == 4 for k in range(6))
+    # shuffle=False keeps file order, still strided
+    assert S.EpochSampler(100, 4, 1, 2, shuffle=False).batch(0)[0] == [1, 3, 5, 7]
+
+
+def test_standard_transform_redraws_the_crop_every_epoch(tmp_path):
+    """RandomResizedCrop / RandomHorizontalFlip redraw on every visit; the box is a pure function of
+    (seed, epoch, index)."""
+    from robustart_amd.train import cls_solver as S
+    root = str(tmp_path)
+    lines, arrays = _write_images(root)
+    meta = os.path.join(root, 'train.txt')
+    with open(meta, 'w') as f:
+        f.write('\n'.join('%s %d' % ln for ln in lines) + '\n')
+    ds = S.FileImageNet(os.path.join(root, 'val'), meta, 32, 36, 'STANDARD', seed=3)
+    hw = arrays[2].shape[:2]
+    boxes = [ds.box(2, hw, e) for e in range(8)]
+    assert len(set(boxes)) > 1                                             # not frozen over the epochs
+    assert boxes == [ds.box(2, hw, e) for e in range(8)]                   # reproducible (resume-safe)
+    assert ds.box(2, hw) == boxes[0]                                       # default epoch 0
+
+
+def test_missing_checkpoint_file_raises_oserror_not_a_pickle_message(tmp_path):
+    from robustart_amd.train import cls_solver as S
+    with pytest.raises(OSError):
+        S.load_checkpoint_file(str(tmp_path / 'nope.pth.tar'))
