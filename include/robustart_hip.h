@@ -343,6 +343,54 @@ int rart_igemm_set_gemm256(int enable);
  * serves flag 64 (GELU with the pre-activation kept: dst = gelu(u), `mask` RECEIVES the bf16 pre-activation u; ViT fc1 in keep mode). */
 int rart_gemm256_supported(long long rows, int k, int n_cols, int src_ld, int dst_ld);
 
+/* Split-bf16 ("fp32x" / "bf16x3") GEMM -- the dense contraction of the REFERENCE-PRECISION engines (csrc/gemm_pair.hip).  The
+ * reference computes fp32 (adv/attack.py:20-23, autopgd_base.py:271-289; exprs/exp/imagenet_c_loop_mini/config_vit_base.yaml:1-9 has
+ * no precision key).  Every operand is a PAIR of bf16 planes, value = hi + lo (16 significand bits):
+ *     C[m][n] = sum_k A[m][k] * W[n][k] ~= A_lo.W_hi + A_hi.W_lo + A_hi.W_hi        (fp32 accumulation, + bias[n])
+ * 256 x 256 tiles, the four operand planes of a 32-deep K step staged once in LDS (direct-to-LDS loads), three MFMAs per fragment pair.
+ * a_* : [rows][lda] bf16, K contiguous; w_* : [w_rows][ldw] bf16 (rows = output columns; rows >= w_rows read as zeros, so N may exceed
+ *       the rows that exist: attention products whose "weights" are activations); K % 32 == 0, N % 8 == 0, ld* % 8 == 0.
+ * dst : pair planes [rows][ldc] (hi = bf16(v), lo = bf16(v - hi)), or fp32 [rows][ldc] in dst_hi with flag 2 (dst_lo unused).
+ * res : optional residual PAIR indexed like dst, added in fp32.
+ * flags: 1 ReLU; 2 fp32 output; 4 exact GELU; 64 GELU with the pre-activation kept (aux RECEIVES the pair u, dst = gelu(u_hi + u_lo));
+ *        8 GELU' (v *= gelu'(aux_hi + aux_lo), aux indexed like dst).
+ * Row re-basing (0 = none): output row m of image m / rows_per_image reads source row img * src_rows_per_image + m % rows_per_image +
+ * src_row_off and writes destination row img * dst_rows_per_image + m % rows_per_image + dst_row_off (ViT's class-token slot).
+ * Batched (n_batched > 1, blockIdx.y = z -> zo = z / z_inner, zi = z % z_inner): element offsets zo * *_z_outer + zi * *_z_inner are
+ * added to a_* / w_* / (dst, res, aux). */
+typedef struct rart_gemm_pair_desc {
+  const void *a_hi, *a_lo, *w_hi, *w_lo;
+  const float* bias;
+  const void *res_hi, *res_lo;
+  void *dst_hi, *dst_lo;
+  void *aux_hi, *aux_lo;
+  int M, N, K, lda, ldw, ldc, w_rows;
+  int rows_per_image, src_rows_per_image, src_row_off, dst_rows_per_image, dst_row_off;
+  int flags, n_batched, z_inner;
+  int64_t a_z_outer, a_z_inner, w_z_outer, w_z_inner, c_z_outer, c_z_inner;
+} rart_gemm_pair_desc;
+int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stream);
+
+/* Row / elementwise kernels of the reference-precision ViT-B/16 engine (csrc/vit_pair.hip): every tensor a pair of bf16 planes, the
+ * arithmetic in fp32 as the fp32 module (timm ViT-B/16, RobustART/model/__init__.py:1 -> absent submodule) does it.
+ * add_pos_cls: x[b][0][:] = cls_pos0, x[b][t][:] += pos[t].  layernorm: eps inside the root, biased variance; rows of dim <= 1024.
+ * layernorm_bwd: dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ res pair], g = dy gamma.  softmax_rows: P = softmax(scale S) of fp32
+ * scores (the pair GEMM's fp32 output), zero beyond n_valid up to ld_out (<= 256 columns).  softmax_bwd_rows: dS = scale P (dP - <P, dP>),
+ * dP fp32.  unpatchify_from_f32: fp32 patch gradients -> fp32 NCHW image gradient / std. */
+int rart_vit_add_pos_cls_pair(void* x_hi, void* x_lo, const float* cls_pos0, const float* pos, int n, int tokens, int dim,
+                              rart_stream_t stream);
+int rart_layernorm_pair(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, void* out_hi, void* out_lo, int rows,
+                        int dim, int64_t in_row_stride, int64_t out_row_stride, float eps, rart_stream_t stream);
+int rart_layernorm_bwd_pair(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, const float* gamma,
+                            const void* res_hi, const void* res_lo, void* dx_hi, void* dx_lo, int rows, int dim, int64_t dy_row_stride,
+                            int64_t x_row_stride, int64_t res_row_stride, int64_t dx_row_stride, float eps, rart_stream_t stream);
+int rart_softmax_rows_pair(const float* scores, void* probs_hi, void* probs_lo, int64_t rows, int n_valid, int ld_in, int ld_out,
+                           float scale, rart_stream_t stream);
+int rart_softmax_bwd_rows_pair(const void* probs_hi, const void* probs_lo, const float* dprobs, void* ds_hi, void* ds_lo, int64_t rows,
+                               int n_valid, int ld_p, int ld_dp, int ld_out, float scale, rart_stream_t stream);
+int rart_vit_unpatchify_from_f32(const float* dpatches, float* grad, int n, int h, int w, int patch, int64_t ld, const float* std_host,
+                                 rart_stream_t stream);
+
 /* 3x3 stride-1 "same" convolution, channels in = channels out = 64, 128 or 256 (256: images of at most 224 positions, one
  * image per workgroup), bf16 NHWC, with the input halo tile resident in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 /
  * layer2 / layer3 conv2, forward (taps (r-1, s-1), bias + ReLU, sign_out =

@@ -100,6 +100,13 @@ SIGNATURES = {
     'rart_gemm_small_m_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_igemm_set_gemm256': (c_int, [c_int]),
     'rart_gemm256_supported': (c_int, [ctypes.c_longlong, c_int, c_int, c_int, c_int]),
+    'rart_gemm_pair_bf16': (c_int, [c_void_p, c_void_p]),
+    'rart_vit_add_pos_cls_pair': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rart_layernorm_pair': (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_int64, ctypes.c_int64, c_float, c_void_p]),
+    'rart_layernorm_bwd_pair': (c_int, [c_void_p] * 9 + [c_int, c_int] + [ctypes.c_int64] * 4 + [c_float, c_void_p]),
+    'rart_softmax_rows_pair': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'rart_softmax_bwd_rows_pair': (c_int, [c_void_p] * 5 + [ctypes.c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    'rart_vit_unpatchify_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64, ctypes.POINTER(c_float), c_void_p]),
     'rart_engine_prep_input': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),
     'rart_engine_maxpool': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -181,6 +188,14 @@ class ConvDesc(ctypes.Structure):
                 ('src_z_outer', ctypes.c_int64), ('src_z_inner', ctypes.c_int64), ('wgt_z_outer', ctypes.c_int64),
                 ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64),
                 ('sign_out', c_void_p), ('dst_pair_off', ctypes.c_int64), ('res_pair_off', ctypes.c_int64)]
+
+
+class GemmPairDesc(ctypes.Structure):
+    """rart_gemm_pair_desc (include/robustart_hip.h): the split-bf16 GEMM of the reference-precision engines."""
+    _fields_ = [(n, c_void_p) for n in ('a_hi', 'a_lo', 'w_hi', 'w_lo', 'bias', 'res_hi', 'res_lo', 'dst_hi', 'dst_lo', 'aux_hi', 'aux_lo')] + \
+               [(n, ctypes.c_int32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldc', 'w_rows', 'rows_per_image', 'src_rows_per_image',
+                                              'src_row_off', 'dst_rows_per_image', 'dst_row_off', 'flags', 'n_batched', 'z_inner')] + \
+               [(n, ctypes.c_int64) for n in ('a_z_outer', 'a_z_inner', 'w_z_outer', 'w_z_inner', 'c_z_outer', 'c_z_inner')]
 
 
 _lib = None

@@ -883,16 +883,14 @@ class ResNet50Engine:
 def make_engine(torch_model, device='cuda', precision='bf16'):
     """HIP engine for a model from robustart_amd.model.get_model: ResNet-50 or ViT-B/16, each with forward and
     backward-to-input (`forward_backward`) on the hand-written kernels.  precision 'bf16x3' / 'fp32x': the
-    reference-precision mode (ResNet-50)."""
+    reference-precision mode (both architectures: split-bf16 pairs, three MFMA products per contraction)."""
     from .resnet_torch import ResNet
     from .vit_torch import VisionTransformer
     if isinstance(torch_model, ResNet):
         return ResNet50Engine(torch_model, device, precision)
     if isinstance(torch_model, VisionTransformer):
         from .vit_engine import ViTEngine
-        if PRECISIONS.get(precision, precision) != 'bf16':
-            raise NotImplementedError('the reference-precision mode exists for ResNet-50 only; ViT-B/16 runs bf16')
-        return ViTEngine(torch_model, device)
+        return ViTEngine(torch_model, device, precision)
     raise NotImplementedError('no HIP engine for %s (ResNet-50 / ViT-B/16 only)' % type(torch_model).__name__)
 
 

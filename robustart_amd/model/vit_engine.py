@@ -14,14 +14,32 @@ from .. import _lib
 
 F_RELU, F_OUT_F32, F_GELU, F_GELU_BWD = 1, 2, 4, 8
 F_GELU_KEEP = 64          # dst = gelu(u), `mask` receives the pre-activation u (256 x 256 GEMM only)
+PRECISIONS = {'bf16': 'bf16', 'bf16x3': 'bf16x3', 'fp32x': 'bf16x3'}
+
+
+def _pair(t):
+    """fp32 tensor -> [2][...] bf16 planes (hi = bf16(v), lo = bf16(v - hi)): the split-bf16 representation"""
+    import torch
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).contiguous()
 
 
 class ViTEngine:
-    def __init__(self, model, device='cuda'):
+    def __init__(self, model, device='cuda', precision='bf16'):
+        """precision: 'bf16' -- bf16 storage, fp32 accumulation (the fast path; logits within ~3e-3 of the fp32 network);
+        'bf16x3' (alias 'fp32x') -- the REFERENCE-PRECISION mode (`_forward_x3` / `_backward_x3`): the reference evaluates and
+        attacks ViT in fp32 (exprs/exp/imagenet_c_loop_mini/config_vit_base.yaml:1-9 has no precision key; adv/attack.py:20-23;
+        autopgd_base.py:271-289) and the north star asks for logits within 1e-4 of it, so every activation, gradient and weight is
+        a hi + lo pair of bf16 planes, every contraction the three MFMA products of rart_gemm_pair_bf16, and LayerNorm / soft-max /
+        GELU are evaluated in fp32 on hi + lo (csrc/vit_pair.hip)."""
         torch = _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
-        self.precision = 'bf16'          # the reference-precision mode exists for ResNet-50 only (model/engine.py)
+        if precision not in PRECISIONS:
+            raise ValueError('precision must be one of %s' % sorted(PRECISIONS))
+        self.precision = PRECISIONS[precision]
+        self.profile = None              # a list collects (flops issued, event0, event1, kind) per GEMM launch (bench.py)
         m = model
         self.D, self.H, self.ps = m.embed_dim, m.num_heads, m.patch_size
         self.hd = self.D // self.H
@@ -83,6 +101,28 @@ class ViTEngine:
         self.head_kpad = (self.n_classes + 31) // 32 * 32
         self.head_wd = wd(m.head.weight, self.head_kpad)
         self.pe_wd = wd(pe)
+        if self.precision == 'bf16x3':
+            self._refold_pair(m)
+
+    def _refold_pair(self, m):
+        """Pair ([2][rows][K] bf16: hi, lo) forward tables W and backward-to-input tables W^T of every Linear; rows padded to the
+        256-row tile of rart_gemm_pair_bf16 (rows past the matrix are zero and never stored)."""
+        torch = _lib.require_gpu()
+        dev = self.device
+
+        def tab(w2d, k_pad=None):
+            w = w2d.detach().to(dev, torch.float32)
+            if k_pad is not None and k_pad > w.shape[1]:
+                w = torch.cat([w, torch.zeros(w.shape[0], k_pad - w.shape[1], device=dev)], 1)
+            r = (w.shape[0] + 255) // 256 * 256
+            if r != w.shape[0]:
+                w = torch.cat([w, torch.zeros(r - w.shape[0], w.shape[1], device=dev)], 0)
+            return _pair(w.contiguous())
+        pe = m.patch_embed.weight.detach().reshape(self.D, -1)
+        self.x3 = dict(pe_w=tab(pe), pe_wd=tab(pe.t()), head_w=tab(m.head.weight), head_wd=tab(m.head.weight.t(), self.head_kpad),
+                       layers=[dict(qkv_w=tab(b.attn.qkv.weight), proj_w=tab(b.attn.proj.weight), fc1_w=tab(b.fc1.weight),
+                                    fc2_w=tab(b.fc2.weight), qkv_wd=tab(b.attn.qkv.weight.t()), proj_wd=tab(b.attn.proj.weight.t()),
+                                    fc1_wd=tab(b.fc1.weight.t()), fc2_wd=tab(b.fc2.weight.t())) for b in m.blocks])
 
     def _get(self, name, shape, dtype=None, zero=False):
         torch = _lib.require_gpu()
@@ -126,6 +166,8 @@ class ViTEngine:
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
     def _forward(self, src, src_is_u8, mean, std, keep=False):
+        if self.precision == 'bf16x3':
+            return self._forward_x3(src, src_is_u8, mean, std, keep)
         torch = _lib.require_gpu()
         lib, sp = self.lib, _lib.stream_ptr()
         if src_is_u8:
@@ -267,6 +309,8 @@ class ViTEngine:
         saved, x_last, (B, Himg, Wimg, P, T) = self._saved
         loss, dl, pred = logit_loss(logits, y, kind, y_target, scale)
         self.last_dlogits = dl           # exposed for the parity tests (same upstream gradient for the reference)
+        if self.precision == 'bf16x3':
+            return logits, loss, self._backward_x3(dl, std), pred
         D, rows = self.D, B * T
         dlb = self._get('dl_bf16', (B, self.head_kpad))
         _lib.check(lib.rart_f32_to_bf16_rows(_lib.ptr(dl), _lib.ptr(dlb), B, self.n_classes, self.head_kpad, sp))
@@ -305,6 +349,208 @@ class ViTEngine:
         _lib.check(lib.rart_vit_unpatchify_f32(_lib.ptr(dpatch), _lib.ptr(grad), B, Himg, Wimg, self.ps, kk,
                                                (ctypes.c_float * 3)(*std), sp))
         return logits, loss, grad, pred
+
+
+    # ------------------------------------------------------------------ reference-precision ("bf16x3" / "fp32x") mode
+    def _gemm_pair(self, a, w, dst, M, N, K, lda, ldc, ldw=None, bias=None, res=None, flags=0, aux=None, w_rows=None,
+                   rows_per_image=0, src_rows_per_image=0, src_row_off=0, dst_rows_per_image=0, dst_row_off=0, batched=None,
+                   a_off=0, w_off=0, dst_off=0):
+        """(a_hi + a_lo)[M][K] . (w_hi + w_lo)[N][K]^T -> dst (pair, or fp32 with F_OUT_F32) on rart_gemm_pair_bf16.  a / w / dst /
+        res / aux are pair tensors [2][...] (dst fp32: a plain tensor); *_off are element offsets inside a plane (head / column
+        slices); batched = dict(n, inner, a=(outer, inner), w=(outer, inner), c=(outer, inner))."""
+        d = _lib.GemmPairDesc()
+        es = 2                                                         # bytes per bf16 element
+        d.a_hi, d.a_lo = a[0].data_ptr() + a_off * es, a[1].data_ptr() + a_off * es
+        d.w_hi, d.w_lo = w[0].data_ptr() + w_off * es, w[1].data_ptr() + w_off * es
+        d.bias = bias.data_ptr() if bias is not None else None
+        if res is not None:
+            d.res_hi, d.res_lo = res[0].data_ptr() + dst_off * es, res[1].data_ptr() + dst_off * es
+        if flags & F_OUT_F32:
+            d.dst_hi, d.dst_lo = dst.data_ptr() + dst_off * 4, None
+        else:
+            d.dst_hi, d.dst_lo = dst[0].data_ptr() + dst_off * es, dst[1].data_ptr() + dst_off * es
+        if aux is not None:
+            d.aux_hi, d.aux_lo = aux[0].data_ptr() + dst_off * es, aux[1].data_ptr() + dst_off * es
+        d.M, d.N, d.K, d.lda, d.ldw, d.ldc = M, N, K, lda, (ldw or K), ldc
+        d.w_rows = w_rows if w_rows is not None else w.shape[-2]
+        d.rows_per_image, d.src_rows_per_image, d.src_row_off = rows_per_image, src_rows_per_image, src_row_off
+        d.dst_rows_per_image, d.dst_row_off = dst_rows_per_image, dst_row_off
+        d.flags = flags
+        nz = 1
+        if batched:
+            nz = d.n_batched = batched['n']
+            d.z_inner = batched['inner']
+            d.a_z_outer, d.a_z_inner = batched['a']
+            d.w_z_outer, d.w_z_inner = batched['w']
+            d.c_z_outer, d.c_z_inner = batched['c']
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            e1.record()
+            self.profile.append((3 * 2.0 * nz * M * N * K, e0, e1, 'gemm_pair'))       # MFMA FLOPs issued: three products
+            return
+        _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _scores_probs_x3(self, qkv, B, T):
+        """S = Q K^T (fp32) and P = softmax(S / sqrt(d)) (pair) of one layer, batched over (image, head)"""
+        lib, sp = self.lib, _lib.stream_ptr()
+        D, H, hd = self.D, self.H, self.hd
+        t_pad, s_ld, BH = (T + 31) // 32 * 32, (T + 7) // 8 * 8, B * H
+        torch = _lib.require_gpu()
+        scores = self._get('x3_scores', (BH, T, s_ld), torch.float32)
+        probs = self._get('x3_probs', (2, BH, T, t_pad))
+        self._gemm_pair(qkv, qkv, scores, T, s_ld, hd, 3 * D, s_ld, ldw=3 * D, flags=F_OUT_F32, w_rows=T, w_off=D,
+                        batched=dict(n=BH, inner=H, a=(T * 3 * D, hd), w=(T * 3 * D, hd), c=(H * T * s_ld, T * s_ld)))
+        _lib.check(lib.rart_softmax_rows_pair(_lib.ptr(scores), _lib.ptr(probs[0]), _lib.ptr(probs[1]), BH * T, T, s_ld, t_pad,
+                                              float(hd) ** -0.5, sp))
+        return probs
+
+    def _transpose_heads_x3(self, src, name, B, T, ld, off):
+        """[2][B*H*hd][t_pad] token-contiguous copy of a per-head slice of a pair tensor [2][B*T][ld] (columns off + h*hd + d)"""
+        lib, sp = self.lib, _lib.stream_ptr()
+        H, hd = self.H, self.hd
+        t_pad = (T + 31) // 32 * 32
+        out = self._get(name, (2, B * H * hd, t_pad))
+        for p in range(2):
+            _lib.check(lib.rart_vit_transpose_v(_lib.ptr(src[p]), _lib.ptr(out[p]), B, T, H, hd, ld, off, t_pad, sp))
+        return out
+
+    def _forward_x3(self, src, src_is_u8, mean, std, keep=False):
+        """The forward of `_forward` on pairs: rart_gemm_pair_bf16 for every contraction (patch embedding, qkv, Q K^T and P V per
+        (image, head) as batched problems, proj, MLP with the exact GELU in the epilogue, head), csrc/vit_pair.hip for the rest."""
+        torch = _lib.require_gpu()
+        lib, sp = self.lib, _lib.stream_ptr()
+        if src_is_u8:
+            B, Himg, Wimg = src.shape[0], src.shape[1], src.shape[2]
+        else:
+            B, Himg, Wimg = src.shape[0], src.shape[2], src.shape[3]
+        D, H, hd, ps = self.D, self.H, self.hd, self.ps
+        P = (Himg // ps) * (Wimg // ps)
+        T = P + 1
+        assert T == self.tokens, 'image size does not match the position embedding'
+        assert T <= 256, 'the pair soft-max rows hold at most 256 keys'
+        kk = 3 * ps * ps
+        X = self.x3
+        patches = self._get('patches', (2, B, P, kk))
+        meanf, stdf = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+        _lib.check(lib.rart_vit_patchify(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(patches[0]), _lib.ptr(patches[1]),
+                                         B, Himg, Wimg, ps, meanf, stdf, sp))
+        x = self._get('x3_x0' if keep else 'x3_x', (2, B, T, D))
+        self._gemm_pair(patches, X['pe_w'], x, B * P, D, kk, kk, D, bias=self.pe_b, rows_per_image=P, dst_rows_per_image=T,
+                        dst_row_off=1)
+        _lib.check(lib.rart_vit_add_pos_cls_pair(_lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(self.cls_pos0), _lib.ptr(self.pos), B, T, D, sp))
+        rows = B * T
+        t_pad = (T + 31) // 32 * 32
+        ln = self._get('x3_ln', (2, B, T, D))
+        saved = []
+        for li, (L, XL) in enumerate(zip(self.layers, X['layers'])):
+            qkv = self._get('x3_qkv%d' % li if keep else 'x3_qkv', (2, rows, 3 * D))
+            xm = self._get('x3_xm%d' % li, (2, B, T, D)) if keep else x
+            att = self._get('x3_att', (2, B, T, D))
+            xo = self._get('x3_x%d' % (li + 1), (2, B, T, D)) if keep else x
+            _lib.check(lib.rart_layernorm_pair(_lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(L['n1g']), _lib.ptr(L['n1b']), _lib.ptr(ln[0]),
+                                               _lib.ptr(ln[1]), rows, D, D, D, 1e-6, sp))
+            self._gemm_pair(ln, XL['qkv_w'], qkv, rows, 3 * D, D, D, 3 * D, bias=L['qkv_b'])
+            probs = self._scores_probs_x3(qkv, B, T)
+            vt = self._transpose_heads_x3(qkv, 'x3_vt', B, T, 3 * D, 2 * D)
+            self._gemm_pair(probs, vt, att, T, hd, t_pad, t_pad, D, ldw=t_pad, w_rows=hd,
+                            batched=dict(n=B * H, inner=H, a=(H * T * t_pad, T * t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * D, hd)))
+            self._gemm_pair(att, XL['proj_w'], xm, rows, D, D, D, D, bias=L['proj_b'], res=x)
+            _lib.check(lib.rart_layernorm_pair(_lib.ptr(xm[0]), _lib.ptr(xm[1]), _lib.ptr(L['n2g']), _lib.ptr(L['n2b']), _lib.ptr(ln[0]),
+                                               _lib.ptr(ln[1]), rows, D, D, D, 1e-6, sp))
+            hid = self._get('x3_hid', (2, B, T, L['hidden']))
+            if keep:
+                u = self._get('x3_u%d' % li, (2, B, T, L['hidden']))
+                self._gemm_pair(ln, XL['fc1_w'], hid, rows, L['hidden'], D, D, L['hidden'], bias=L['fc1_b'], flags=F_GELU_KEEP, aux=u)
+                saved.append((x, xm, qkv, u))
+            else:
+                self._gemm_pair(ln, XL['fc1_w'], hid, rows, L['hidden'], D, D, L['hidden'], bias=L['fc1_b'], flags=F_GELU)
+            self._gemm_pair(hid, XL['fc2_w'], xo, rows, D, L['hidden'], L['hidden'], D, bias=L['fc2_b'], res=xm)
+            x = xo
+        if keep:
+            self._saved = (saved, x, (B, Himg, Wimg, P, T))
+        cls = self._get('x3_cls', (2, B, D))
+        _lib.check(lib.rart_layernorm_pair(_lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(self.ng), _lib.ptr(self.nb), _lib.ptr(cls[0]),
+                                           _lib.ptr(cls[1]), B, D, T * D, D, 1e-6, sp))
+        logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
+        self._gemm_pair(cls, X['head_w'], logits, B, self.n_classes, D, D, self.n_classes, bias=self.head_b, flags=F_OUT_F32)
+        return logits
+
+    def _backward_x3(self, dl, std):
+        """d(loss)/d(x01) from the fp32 loss gradient dl [B][classes]: the backward-to-input chain of `forward_backward` on pairs.
+        The attention backward is the decomposition into batched products (S = Q K^T recomputed, dP = dO V^T, dQ = dS K,
+        dK = dS^T Q, dV = P^T dO) with fp32 score-sized temporaries; GELU' runs in the fc2 dgrad epilogue."""
+        torch = _lib.require_gpu()
+        lib, sp = self.lib, _lib.stream_ptr()
+        saved, x_last, (B, Himg, Wimg, P, T) = self._saved
+        D, H, hd, rows = self.D, self.H, self.hd, B * T
+        X = self.x3
+        t_pad, s_ld, BH = (T + 31) // 32 * 32, (T + 7) // 8 * 8, B * H
+        scale = float(hd) ** -0.5
+        dlp = self._get('x3_dl', (2, B, self.head_kpad))
+        _lib.check(lib.rart_f32_to_pair_rows(_lib.ptr(dl), _lib.ptr(dlp[0]), (dlp[1].data_ptr() - dlp[0].data_ptr()) // 2, B,
+                                             self.n_classes, self.head_kpad, sp))
+        dcls = self._get('x3_dcls', (2, B, D))
+        self._gemm_pair(dlp, X['head_wd'], dcls, B, D, self.head_kpad, self.head_kpad, D)
+        dx = self._get('x3_g_x_a', (2, B, T, D))
+        dx.zero_()                                      # only the class token receives gradient from the head
+        _lib.check(lib.rart_layernorm_bwd_pair(_lib.ptr(dcls[0]), _lib.ptr(dcls[1]), _lib.ptr(x_last[0]), _lib.ptr(x_last[1]),
+                                               _lib.ptr(self.ng), None, None, _lib.ptr(dx[0]), _lib.ptr(dx[1]), B, D, D, T * D, 0, T * D,
+                                               1e-6, sp))
+        dqkv = self._get('x3_g_qkv', (2, rows, 3 * D))
+        zero = (ctypes.c_int * 1)(0)
+        m_all = BH * t_pad
+        for li in range(len(self.layers) - 1, -1, -1):
+            L, XL = self.layers[li], X['layers'][li]
+            x_in, xm, qkv, u = saved[li]
+            dh = self._get('x3_g_hid', (2, rows, L['hidden']))
+            self._gemm_pair(dx, XL['fc2_wd'], dh, rows, L['hidden'], D, D, L['hidden'], flags=F_GELU_BWD, aux=u)    # du = (dx W2) gelu'(u)
+            dln = self._get('x3_g_ln', (2, rows, D))
+            self._gemm_pair(dh, XL['fc1_wd'], dln, rows, D, L['hidden'], L['hidden'], D)
+            dxm = self._get('x3_g_xm', (2, B, T, D))
+            _lib.check(lib.rart_layernorm_bwd_pair(_lib.ptr(dln[0]), _lib.ptr(dln[1]), _lib.ptr(xm[0]), _lib.ptr(xm[1]), _lib.ptr(L['n2g']),
+                                                   _lib.ptr(dx[0]), _lib.ptr(dx[1]), _lib.ptr(dxm[0]), _lib.ptr(dxm[1]), rows, D, D, D, D, D,
+                                                   1e-6, sp))
+            datt = self._get('x3_g_att', (2, rows, D))
+            self._gemm_pair(dxm, XL['proj_wd'], datt, rows, D, D, D, D)
+            # ---- attention backward, batched over (image, head)
+            probs = self._scores_probs_x3(qkv, B, T)
+            dprobs = self._get('x3_dprobs', (BH, T, s_ld), torch.float32)
+            self._gemm_pair(datt, qkv, dprobs, T, s_ld, hd, D, s_ld, ldw=3 * D, flags=F_OUT_F32, w_rows=T, w_off=2 * D,
+                            batched=dict(n=BH, inner=H, a=(T * D, hd), w=(T * 3 * D, hd), c=(H * T * s_ld, T * s_ld)))       # dP = dO V^T
+            ds = self._get('x3_dscores', (2, BH, T, t_pad))
+            _lib.check(lib.rart_softmax_bwd_rows_pair(_lib.ptr(probs[0]), _lib.ptr(probs[1]), _lib.ptr(dprobs), _lib.ptr(ds[0]),
+                                                      _lib.ptr(ds[1]), BH * T, T, t_pad, s_ld, t_pad, scale, sp))
+            kt = self._transpose_heads_x3(qkv, 'x3_kt', B, T, 3 * D, D)
+            qt = self._transpose_heads_x3(qkv, 'x3_qt', B, T, 3 * D, 0)
+            dot = self._transpose_heads_x3(datt, 'x3_dot', B, T, D, 0)
+            hb = dict(n=BH, inner=H, a=(H * T * t_pad, T * t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * 3 * D, hd))
+            self._gemm_pair(ds, kt, dqkv, T, hd, t_pad, t_pad, 3 * D, ldw=t_pad, w_rows=hd, batched=hb)                   # dQ = dS K
+            # query-contiguous copies of dS and P: [t_pad (key)][BH * t_pad (image-head, query)]; queries past T are zero columns
+            ds_t = self._get('x3_ds_t', (2, t_pad, m_all))
+            p_t = self._get('x3_p_t', (2, t_pad, m_all))
+            for src_m, dst_m in ((ds, ds_t), (probs, p_t)):
+                for p in range(2):
+                    _lib.check(lib.rart_transpose_gather_bf16(_lib.ptr(src_m[p]), _lib.ptr(dst_m[p]), BH, T, 1, t_pad, t_pad, 1, 1, 1, 1,
+                                                              zero, zero, m_all, 0, 0, sp))
+            tb = dict(n=BH, inner=H, a=(H * t_pad, t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * 3 * D, hd))
+            self._gemm_pair(ds_t, qt, dqkv, T, hd, t_pad, m_all, 3 * D, ldw=t_pad, w_rows=hd, batched=tb, dst_off=D)      # dK = dS^T Q
+            self._gemm_pair(p_t, dot, dqkv, T, hd, t_pad, m_all, 3 * D, ldw=t_pad, w_rows=hd, batched=tb, dst_off=2 * D)  # dV = P^T dO
+            self._gemm_pair(dqkv, XL['qkv_wd'], dln, rows, D, 3 * D, 3 * D, D)
+            _lib.check(lib.rart_layernorm_bwd_pair(_lib.ptr(dln[0]), _lib.ptr(dln[1]), _lib.ptr(x_in[0]), _lib.ptr(x_in[1]),
+                                                   _lib.ptr(L['n1g']), _lib.ptr(dxm[0]), _lib.ptr(dxm[1]), _lib.ptr(dx[0]), _lib.ptr(dx[1]),
+                                                   rows, D, D, D, D, D, 1e-6, sp))
+        # patch embedding: d(patches)[b][p][:] = dx[b][1 + p][:] . Wpe (fp32) ; class token / position rows drop out
+        kk = 3 * self.ps * self.ps
+        dpatch = self._get('x3_g_patch', (B * P, kk), torch.float32)
+        self._gemm_pair(dx, X['pe_wd'], dpatch, B * P, kk, D, D, kk, flags=F_OUT_F32, rows_per_image=P, src_rows_per_image=T,
+                        src_row_off=1)
+        grad = torch.empty(B, 3, Himg, Wimg, dtype=torch.float32, device=self.device)
+        _lib.check(lib.rart_vit_unpatchify_from_f32(_lib.ptr(dpatch), _lib.ptr(grad), B, Himg, Wimg, self.ps, kk,
+                                                    (ctypes.c_float * 3)(*std), sp))
+        return grad
 
     def logits(self, x01, mean, std):
         return self._forward(x01.detach().float().contiguous(), False, mean, std)
