@@ -352,6 +352,7 @@ int rart_gemm256_supported(long long rows, int k, int n_cols, int src_ld, int ds
  *       the rows that exist: attention products whose "weights" are activations); K % 32 == 0, N % 8 == 0, ld* % 8 == 0.
  * dst : pair planes [rows][ldc] (hi = bf16(v), lo = bf16(v - hi)), or fp32 [rows][ldc] in dst_hi with flag 2 (dst_lo unused).
  * res : optional residual PAIR indexed like dst, added in fp32.
+ * 256- or 128-row tiles x 64 / 128 / 256-column tiles (chosen from the shape; tile_m / tile_n override).
  * flags: 1 ReLU; 2 fp32 output; 4 exact GELU; 64 GELU with the pre-activation kept (aux RECEIVES the pair u, dst = gelu(u_hi + u_lo));
  *        8 GELU' (v *= gelu'(aux_hi + aux_lo), aux indexed like dst).
  * Row re-basing (0 = none): output row m of image m / rows_per_image reads source row img * src_rows_per_image + m % rows_per_image +
@@ -368,6 +369,19 @@ typedef struct rart_gemm_pair_desc {
   int rows_per_image, src_rows_per_image, src_row_off, dst_rows_per_image, dst_row_off;
   int flags, n_batched, z_inner;
   int64_t a_z_outer, a_z_inner, w_z_outer, w_z_inner, c_z_outer, c_z_inner;
+  /* conv = 1: implicit-GEMM convolution, the row / tap / destination conventions of rart_conv_desc: row m = (image, oy, ox) of a
+   * batch x grid_h x grid_w grid, k = tap * k_per_tap + c (k_per_tap a power of two >= 32, <= 16 taps), source pixel
+   * (oy sy + tap_dy, ox sx + tap_dx) of a src_h x src_w image with lda elements per pixel (zeros outside), destination pixel
+   * (oy dst_sy + dst_oy, ox dst_sx + dst_ox) of a dst_h x dst_w image with ldc elements per pixel; M and K are derived.
+   * mask_bits: 1-bit tensor indexed like dst (byte (off + col) / 8, bit col % 8), the value is zeroed where the bit is clear (the
+   * ReLU mask of a backward-to-input); sign_out receives (output hi plane > 0) in the same indexing.  Unbatched, no row re-basing. */
+  int conv, batch, grid_h, grid_w, src_h, src_w, sy, sx, k_per_tap, n_taps;
+  int tap_dy[16], tap_dx[16];
+  int dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox;
+  const void* mask_bits;
+  void* sign_out;
+  int tile_n;               /* 0 = automatic (64 / 128 / 256 by N); tests / sweeps force a column tile */
+  int tile_m;               /* 0 = automatic (256; 128 for short-K or small convolutions); 128 / 256 force a row tile */
 } rart_gemm_pair_desc;
 int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stream);
 

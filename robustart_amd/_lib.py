@@ -195,7 +195,11 @@ class GemmPairDesc(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ('a_hi', 'a_lo', 'w_hi', 'w_lo', 'bias', 'res_hi', 'res_lo', 'dst_hi', 'dst_lo', 'aux_hi', 'aux_lo')] + \
                [(n, ctypes.c_int32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldc', 'w_rows', 'rows_per_image', 'src_rows_per_image',
                                               'src_row_off', 'dst_rows_per_image', 'dst_row_off', 'flags', 'n_batched', 'z_inner')] + \
-               [(n, ctypes.c_int64) for n in ('a_z_outer', 'a_z_inner', 'w_z_outer', 'w_z_inner', 'c_z_outer', 'c_z_inner')]
+               [(n, ctypes.c_int64) for n in ('a_z_outer', 'a_z_inner', 'w_z_outer', 'w_z_inner', 'c_z_outer', 'c_z_inner')] + \
+               [(n, ctypes.c_int32) for n in ('conv', 'batch', 'grid_h', 'grid_w', 'src_h', 'src_w', 'sy', 'sx', 'k_per_tap', 'n_taps')] + \
+               [('tap_dy', ctypes.c_int32 * 16), ('tap_dx', ctypes.c_int32 * 16)] + \
+               [(n, ctypes.c_int32) for n in ('dst_h', 'dst_w', 'dst_sy', 'dst_sx', 'dst_oy', 'dst_ox')] + \
+               [('mask_bits', c_void_p), ('sign_out', c_void_p), ('tile_n', ctypes.c_int32), ('tile_m', ctypes.c_int32)]
 
 
 _lib = None

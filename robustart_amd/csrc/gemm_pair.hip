@@ -22,6 +22,10 @@
 // pre-activation kept / GELU' of a kept pre-activation, then either hi = bf16(v), lo = bf16(v - hi) as two coalesced 16-byte
 // stores or fp32.  Rows may be re-based per image on either side (the class-token slot of ViT's patch embedding) and the problem
 // may be batched over blockIdx.y with operand planes anywhere in memory (attention products: the "weights" are K / V activations).
+// CONV instances gather the A planes on the fly like rart_conv_igemm_bf16 does (row m = (image, oy, ox) of a row grid, k = tap * k_per_tap
+// + c, source pixel (oy sy + dy[tap], ox sx + dx[tap]), the zero page outside the image) -- every convolution of the reference-precision
+// ResNet-50 (forward taps, flipped taps, the parity classes of a stride-2 backward, the stem's row taps) -- with 1-bit ReLU masks and
+// sign bits in the epilogue; column tiles of 64 / 128 / 256 so that the 64- and 128-channel layers do not pad their MFMA work.
 #include "rart_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -29,11 +33,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 enum { GP_OUT_F32 = 2, GP_GELU = 4, GP_GELU_BWD = 8, GP_GELU_KEEP = 64, GP_RELU = 1 };
-constexpr int GP_TM = 256, GP_TN = 256, GP_BK = 32;
-constexpr int GP_PLANE = 256 * GP_BK * 2;          // one operand plane of a stage: 256 rows x 64 B
-constexpr int GP_STAGE = 4 * GP_PLANE;             // A_hi | A_lo | W_hi | W_lo = 64 KB
+constexpr int GP_BK = 32;
 constexpr int GP_LDE = 68;                         // epilogue staging row (floats): 64 columns + 4
-static_assert(8 * 32 * GP_LDE * 4 <= 2 * GP_STAGE, "epilogue staging must fit the tile buffers");
 
 struct GemmPairDev {
   const uint16_t *a_hi, *a_lo, *w_hi, *w_lo;
@@ -45,7 +46,17 @@ struct GemmPairDev {
   int rpi, src_rpi, src_off, dst_rpi, dst_off, map_rows;
   int flags, z_inner;
   long long a_zo, a_zi, w_zo, w_zi, c_zo, c_zi;
+  // CONV instances: row grid, source / destination geometry, taps (k_per_tap / 32 a power of two: tap = kt >> tpt_shift)
+  int grid_h, grid_w, src_h, src_w, sy, sx, n_taps, tpt_shift;
+  int tap_dy[16], tap_dx[16];
+  int dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox;
+  uint32_t gw_magic, gw_shift, gh_magic, gh_shift;      // exact division by multiply-shift for dividends < 2^31
+  const uint8_t* mask_bits;                              // 1 bit per destination element (byte (off + col) / 8): v = 0 where clear
+  uint8_t* sign_out;                                     // receives (output hi plane > 0), same indexing
 };
+__device__ __forceinline__ uint32_t gp_fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
+  return (uint32_t)(((uint64_t)n * magic) >> shift);
+}
 
 __device__ __attribute__((aligned(16))) const uint32_t g_pair_zero16[4] = {0u, 0u, 0u, 0u};   // source of rows past M / N
 
@@ -81,20 +92,35 @@ __device__ __forceinline__ void gp_join8(const uint4& hi, const uint4& lo, float
   }
 }
 
-__global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * GP_STAGE];
+// TM x TN: the tile (rows 256 / 128, columns 256 / 128 / 64), TM / 32 waves (8 / 4) in a (NW / WN) x WN grid, WN = TN / 64; a wave owns
+// (TM / WM) rows x 64 columns.  The 256-row tiles are for the K-deep, MFMA-bound products (one workgroup per CU, 48 MFMAs per wave between
+// two barriers at TN = 256); the 128-row tiles (48-96 KB of LDS: two or three workgroups per CU whose load / multiply / store phases
+// overlap) for the short-K, HBM-bound 1x1 layers and the small-M layers of ResNet-50 whose 256-row tiling would not fill 256 CUs.
+template <int TM, int TN, bool CONV>
+__global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
+  constexpr int NW = TM / 32, NT = TM * 2;
+  constexpr int WN = (TN / 64 < NW) ? TN / 64 : NW, WM = NW / WN, RW = TM / WM, MI = RW / 32, NJ = TN / (32 * WN);
+  static_assert(NJ == 2, "a wave owns 64 columns");
+  constexpr int GP_PLANE_A = TM * GP_BK * 2;                        // one A plane of a stage: TM rows x 64 B
+  constexpr int PLANE_B = TN * GP_BK * 2, STAGE = 2 * GP_PLANE_A + 2 * PLANE_B;
+  constexpr int A_PIECES = TM / 16, AQ = A_PIECES / NW;             // 1 KiB pieces (16 rows x 64 B) of an A plane; per wave (2)
+  constexpr int B_PIECES = TN / 16, BQ = (B_PIECES + NW - 1) / NW;  // ... of a W plane
+  constexpr int GP_STAGING = NW * 32 * GP_LDE * 4;                  // NW waves x 32 rows of the epilogue transposition
+  static_assert(AQ == 2, "two A pieces per wave");
+  static_assert(GP_STAGING + TM * 4 <= 2 * STAGE, "epilogue staging + row table must fit the tile buffers");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
   // batched problems: block-uniform base shifts (element offsets)
   const uint16_t *a_hi = d.a_hi, *a_lo = d.a_lo, *w_hi = d.w_hi, *w_lo = d.w_lo;
   long long c_off = 0;
-  if (gridDim.y > 1) {
+  if (!CONV && gridDim.y > 1) {
     const int z = blockIdx.y, zo = z / d.z_inner, zi = z - zo * d.z_inner;
     const long long ao = zo * d.a_zo + zi * d.a_zi, wo = zo * d.w_zo + zi * d.w_zi;
     a_hi += ao; a_lo += ao; w_hi += wo; w_lo += wo;
     c_off = zo * d.c_zo + zi * d.c_zi;
   }
-  const int n_tiles = (d.N + GP_TN - 1) / GP_TN, m_tiles = (d.M + GP_TM - 1) / GP_TM;
+  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M + TM - 1) / TM;
   int m_tile, n_tile;
   if (m_tiles >= 16) {
     // all column tiles of a row tile on one XCD (the A tile is re-read from its L2)
@@ -106,21 +132,35 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
     m_tile = blockIdx.x / n_tiles;
     n_tile = blockIdx.x - m_tile * n_tiles;
   }
-  const int m0 = m_tile * GP_TM, n0 = n_tile * GP_TN;
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
 
-  // ---- loader: per plane, a wave brings rows [32 wave, 32 wave + 32) as two 1 KiB pieces (16 rows x 64 B); lane -> row
-  //      (lane >> 2), LDS chunk (lane & 3) <- the row's chunk (lane & 3) ^ ((row >> 2) & 3)
-  const char* asrc_h[2];
+  // ---- loader: a plane goes to LDS in 1 KiB pieces (16 rows x 64 B); wave w brings pieces w and w + 8; lane -> row (lane >> 2),
+  //      LDS chunk (lane & 3) <- the row's chunk (lane & 3) ^ ((row >> 2) & 3)
+  const char* asrc_h[2];            // plain GEMM: per-lane source rows (nullptr past M)
   const char* asrc_l[2];
-  const char* bsrc_h[2];
-  const char* bsrc_l[2];
+  int a_by[2], a_bx[2], a_img[2], a_cs[2];      // CONV: pixel of the row, byte offset of the lane's chunk inside a K slice
+  bool a_ok[2];
+  const char* bsrc_h[BQ];
+  const char* bsrc_l[BQ];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int r = 32 * wave + 16 * q + (lane >> 2);
+    const int r = 16 * (wave + NW * q) + (lane >> 2);
     const int csrc = (lane & 3) ^ ((r >> 2) & 3);
     const int m = m0 + r;
     asrc_h[q] = asrc_l[q] = nullptr;
-    if (m < d.M) {
+    a_by[q] = a_bx[q] = a_img[q] = 0;
+    a_cs[q] = csrc * 16;
+    a_ok[q] = m < d.M;
+    if (CONV) {
+      const uint32_t mm = a_ok[q] ? (uint32_t)m : 0u;
+      const uint32_t t = gp_fastdiv(mm, d.gw_magic, d.gw_shift);
+      const int ox = (int)(mm - t * (uint32_t)d.grid_w);
+      const int n = (int)gp_fastdiv(t, d.gh_magic, d.gh_shift);
+      const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
+      a_by[q] = oy * d.sy;
+      a_bx[q] = ox * d.sx;
+      a_img[q] = n * d.src_h * d.src_w;
+    } else if (a_ok[q]) {
       long long srow = m;
       if (d.map_rows) {
         const int img = m / d.rpi;
@@ -130,9 +170,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
       asrc_h[q] = reinterpret_cast<const char*>(a_hi + e);
       asrc_l[q] = reinterpret_cast<const char*>(a_lo + e);
     }
+  }
+#pragma unroll
+  for (int q = 0; q < BQ; ++q) {
+    const int r = 16 * (wave + NW * q) + (lane >> 2);
+    const int csrc = (lane & 3) ^ ((r >> 2) & 3);
     const int n = n0 + r;
     bsrc_h[q] = bsrc_l[q] = nullptr;
-    if (n < d.w_rows) {
+    if (r < TN && n < d.w_rows) {
       const long long e = (long long)n * d.ldw + csrc * 8;
       bsrc_h[q] = reinterpret_cast<const char*>(w_hi + e);
       bsrc_l[q] = reinterpret_cast<const char*>(w_lo + e);
@@ -144,13 +189,34 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
                                    (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);
 #define RART_GP_ISSUE(KT, BUF)                                                                                  \
   {                                                                                                             \
-    uint8_t* const st_ = lds + (BUF)*GP_STAGE + (32 * wave) * 64;                                               \
-    const size_t ko_ = (size_t)(KT)*64;                                                                         \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
-      RART_GP_DL(asrc_h[q] ? asrc_h[q] + ko_ : zsrc, st_ + q * 1024)                                            \
-      RART_GP_DL(asrc_l[q] ? asrc_l[q] + ko_ : zsrc, st_ + GP_PLANE + q * 1024)                                 \
-      RART_GP_DL(bsrc_h[q] ? bsrc_h[q] + ko_ : zsrc, st_ + 2 * GP_PLANE + q * 1024)                             \
-      RART_GP_DL(bsrc_l[q] ? bsrc_l[q] + ko_ : zsrc, st_ + 3 * GP_PLANE + q * 1024)                             \
+    uint8_t* const st_ = lds + (BUF)*STAGE;                                                                     \
+    const int kt_ = (KT);                                                                                       \
+    if (CONV) {                                                                                                 \
+      const int tap_ = kt_ >> d.tpt_shift;                                                                      \
+      const int kcb_ = (kt_ - (tap_ << d.tpt_shift)) * 64;                                                      \
+      const int dy_ = d.tap_dy[tap_], dx_ = d.tap_dx[tap_];                                                     \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+        const int iy_ = a_by[q] + dy_, ix_ = a_bx[q] + dx_;                                                     \
+        const bool ok_ = a_ok[q] && (unsigned)iy_ < (unsigned)d.src_h && (unsigned)ix_ < (unsigned)d.src_w;     \
+        const long long bo_ = (long long)(a_img[q] + iy_ * d.src_w + ix_) * d.lda * 2 + kcb_ + a_cs[q];         \
+        RART_GP_DL(ok_ ? reinterpret_cast<const char*>(a_hi) + bo_ : zsrc, st_ + (wave + NW * q) * 1024)         \
+        RART_GP_DL(ok_ ? reinterpret_cast<const char*>(a_lo) + bo_ : zsrc, st_ + GP_PLANE_A + (wave + NW * q) * 1024) \
+      }                                                                                                         \
+    } else {                                                                                                    \
+      const size_t ko_ = (size_t)kt_ * 64;                                                                      \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+        RART_GP_DL(asrc_h[q] ? asrc_h[q] + ko_ : zsrc, st_ + (wave + NW * q) * 1024)                             \
+        RART_GP_DL(asrc_l[q] ? asrc_l[q] + ko_ : zsrc, st_ + GP_PLANE_A + (wave + NW * q) * 1024)                \
+      }                                                                                                         \
+    }                                                                                                           \
+    {                                                                                                           \
+      const size_t ko_ = (size_t)kt_ * 64;                                                                      \
+      _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                                          \
+        if (wave + NW * q < B_PIECES) {                                                                         \
+          RART_GP_DL(bsrc_h[q] ? bsrc_h[q] + ko_ : zsrc, st_ + 2 * GP_PLANE_A + (wave + NW * q) * 1024)          \
+          RART_GP_DL(bsrc_l[q] ? bsrc_l[q] + ko_ : zsrc, st_ + 2 * GP_PLANE_A + PLANE_B + (wave + NW * q) * 1024) \
+        }                                                                                                       \
+      }                                                                                                         \
     }                                                                                                           \
   }
   const int fr = lane & 31, h = lane >> 5;
@@ -158,13 +224,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) xo[ks] = (uint32_t)(fr * 64 + (((2 * ks + h) ^ ((fr >> 2) & 3)) << 4));
   // accumulators start at the bias of their column (lane & 31 is the column of a 32 x 32 MFMA tile)
-  f32x16 acc[4][2];
+  f32x16 acc[MI][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int bc = n0 + wn * 64 + j * 32 + fr;
     const float bv = (d.bias && bc < d.N) ? d.bias[bc] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
   }
@@ -175,24 +241,24 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < KT) RART_GP_ISSUE(kt + 1, buf ^ 1)
-    const uint8_t* Ah = lds + buf * GP_STAGE + (wm * 128) * 64;
-    const uint8_t* Bh = lds + buf * GP_STAGE + 2 * GP_PLANE + (wn * 64) * 64;
+    const uint8_t* Ah = lds + buf * STAGE + (wm * RW) * 64;
+    const uint8_t* Bh = lds + buf * STAGE + 2 * GP_PLANE_A + (wn * 64) * 64;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[4], al[4], bh[2], bl[2];
+      bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         ah[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 32 * 64 + xo[ks]);
-        al[i] = *reinterpret_cast<const bf16x8*>(Ah + GP_PLANE + i * 32 * 64 + xo[ks]);
+        al[i] = *reinterpret_cast<const bf16x8*>(Ah + GP_PLANE_A + i * 32 * 64 + xo[ks]);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         bh[j] = *reinterpret_cast<const bf16x8*>(Bh + j * 32 * 64 + xo[ks]);
-        bl[j] = *reinterpret_cast<const bf16x8*>(Bh + GP_PLANE + j * 32 * 64 + xo[ks]);
+        bl[j] = *reinterpret_cast<const bf16x8*>(Bh + PLANE_B + j * 32 * 64 + xo[ks]);
       }
       // the two small products first, the large one last: all three land in the same fp32 accumulator
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
@@ -205,30 +271,54 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
   }
 #undef RART_GP_ISSUE
 #undef RART_GP_DL
-  // ---- epilogue: per wave, 32 rows x 64 columns at a time through LDS -> 128-byte row segments per plane; residual / GELU
+  // ---- epilogue: per wave, 32 rows x 64 columns at a time through LDS -> 128-byte row segments per plane; residual / mask / GELU
   //      operands of a pass are requested before its transposition
   float* sE = reinterpret_cast<float*>(lds) + wave * 32 * GP_LDE;
+  uint32_t* const row_dst = reinterpret_cast<uint32_t*>(lds + GP_STAGING);      // CONV: destination element offset of tile row r, ~0 past M
+  if (CONV) {
+    if (tid < TM) {
+      const uint32_t m = (uint32_t)(m0 + tid);
+      uint32_t off = 0xFFFFFFFFu;
+      if (m < (uint32_t)d.M) {
+        const uint32_t t = gp_fastdiv(m, d.gw_magic, d.gw_shift);
+        const int ox = (int)(m - t * (uint32_t)d.grid_w);
+        const int n = (int)gp_fastdiv(t, d.gh_magic, d.gh_shift);
+        const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
+        off = (uint32_t)(((n * d.dst_h + (oy * d.dst_sy + d.dst_oy)) * d.dst_w + (ox * d.dst_sx + d.dst_ox)) * d.ldc);
+      }
+      row_dst[tid] = off;
+    }
+    __syncthreads();
+  }
   const int cw = lane & 7, rw = lane >> 3;
   const int col = n0 + wn * 64 + cw * 8;
   const bool col_ok = col < d.N;
   const int flags = d.flags;
   const bool out_f32 = flags & GP_OUT_F32;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     long long eo[4];
     uint4 rh[4], rl[4], uh[4], ul[4];
+    uint32_t mb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int m = m0 + wm * 128 + i * 32 + q * 8 + rw;
+      const int rt = wm * RW + i * 32 + q * 8 + rw;       // row inside the tile
+      const int m = m0 + rt;
       eo[q] = -1;
       rh[q] = rl[q] = uh[q] = ul[q] = make_uint4(0, 0, 0, 0);
+      mb[q] = 0xFFu;
       if (m < d.M && col_ok) {
-        long long drow = m;
-        if (d.map_rows) {
-          const int img = m / d.rpi;
-          drow = (long long)img * d.dst_rpi + (m - img * d.rpi);
+        long long e;
+        if (CONV) {
+          e = (long long)row_dst[rt] + col;
+        } else {
+          long long drow = m;
+          if (d.map_rows) {
+            const int img = m / d.rpi;
+            drow = (long long)img * d.dst_rpi + (m - img * d.rpi);
+          }
+          e = c_off + (drow + d.dst_off) * d.ldc + col;
         }
-        const long long e = c_off + (drow + d.dst_off) * d.ldc + col;
         eo[q] = e;
         if (d.res_hi) {
           rh[q] = *reinterpret_cast<const uint4*>(d.res_hi + e);
@@ -238,6 +328,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
           uh[q] = *reinterpret_cast<const uint4*>(d.aux_hi + e);
           ul[q] = *reinterpret_cast<const uint4*>(d.aux_lo + e);
         }
+        if (CONV && d.mask_bits) mb[q] = d.mask_bits[e >> 3];
       }
     }
 #pragma unroll
@@ -282,6 +373,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] *= gp_gelu_grad(u[j]);
         }
+        if (CONV) {      // 1-bit ReLU mask of the destination (backward-to-input): bit k of the byte = column col + k
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (!((mb[q] >> j) & 1u)) v[j] = 0.f;
+        }
         if (flags & GP_RELU) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -295,6 +391,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
           gp_split8(v, ph, pl);
           *reinterpret_cast<uint4*>(d.dst_hi + e) = ph;
           *reinterpret_cast<uint4*>(d.dst_lo + e) = pl;
+          if (CONV && d.sign_out) {     // (hi plane > 0): a bf16 is > 0 exactly when its bits, read as int16, are > 0
+            const uint32_t hw[4] = {ph.x, ph.y, ph.z, ph.w};
+            uint32_t sb = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              sb |= ((short)(hw[j] & 0xFFFFu) > 0 ? 1u : 0u) << (2 * j);
+              sb |= ((short)(hw[j] >> 16) > 0 ? 1u : 0u) << (2 * j + 1);
+            }
+            d.sign_out[e >> 3] = (uint8_t)sb;
+          }
         }
       }
     }
@@ -302,14 +408,59 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair(const GemmPairDev d) {
     __builtin_amdgcn_wave_barrier();
   }
 }
+
+void gp_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividends < 2^31
+  uint32_t l = 0;
+  while ((1ull << l) < dv) ++l;
+  sh = 31 + l;
+  mg = (uint32_t)(((1ull << sh) + dv - 1) / dv);
+}
 }  // namespace
 
 extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t stream) {
   RART_CHECK_ARG(h != nullptr, "rart_gemm_pair_bf16: null descriptor");
   RART_CHECK_ARG(h->a_hi && h->a_lo && h->w_hi && h->w_lo && h->dst_hi, "rart_gemm_pair_bf16: null operand plane");
-  RART_CHECK_ARG(h->M > 0 && h->N > 0 && h->N % 8 == 0, "rart_gemm_pair_bf16: M > 0, N a positive multiple of 8");
-  RART_CHECK_ARG(h->K > 0 && h->K % GP_BK == 0, "rart_gemm_pair_bf16: K must be a positive multiple of 32");
-  RART_CHECK_ARG(h->lda % 8 == 0 && h->ldw % 8 == 0 && h->ldc % 8 == 0 && h->lda >= h->K && h->ldw >= h->K && h->ldc >= h->N,
+  const bool conv = h->conv != 0;
+  GemmPairDev d;
+  d.M = h->M; d.K = h->K;
+  if (conv) {
+    RART_CHECK_ARG(h->batch > 0 && h->grid_h > 0 && h->grid_w > 0 && h->src_h > 0 && h->src_w > 0 && h->dst_h > 0 && h->dst_w > 0,
+                   "rart_gemm_pair_bf16 (conv): empty geometry");
+    RART_CHECK_ARG(h->n_taps >= 1 && h->n_taps <= 16, "rart_gemm_pair_bf16 (conv): n_taps must be 1..16");
+    RART_CHECK_ARG(h->k_per_tap >= 32 && (h->k_per_tap & (h->k_per_tap - 1)) == 0,
+                   "rart_gemm_pair_bf16 (conv): k_per_tap must be a power of two >= 32");
+    RART_CHECK_ARG(h->n_batched <= 1 && h->rows_per_image == 0 && h->src_row_off == 0 && h->dst_row_off == 0,
+                   "rart_gemm_pair_bf16 (conv): no batching / row re-basing in conv mode");
+    const long long M = (long long)h->batch * h->grid_h * h->grid_w;
+    RART_CHECK_ARG(M < (1ll << 31), "rart_gemm_pair_bf16 (conv): row grid must stay below 2^31 rows");
+    RART_CHECK_ARG((long long)h->batch * h->src_h * h->src_w * h->lda < (1ll << 31) && (long long)h->batch * h->dst_h * h->dst_w * h->ldc < (1ll << 31),
+                   "rart_gemm_pair_bf16 (conv): tensors must stay below 2^31 elements (split the batch)");
+    RART_CHECK_ARG(h->lda % 8 == 0 || h->lda == 4, "rart_gemm_pair_bf16 (conv): source pixels must keep 16-byte alignment of the K chunks");
+    d.M = (int)M;
+    d.K = h->k_per_tap * h->n_taps;
+    d.grid_h = h->grid_h; d.grid_w = h->grid_w; d.src_h = h->src_h; d.src_w = h->src_w; d.sy = h->sy; d.sx = h->sx; d.n_taps = h->n_taps;
+    int sh = 0;
+    while ((32 << sh) < h->k_per_tap) ++sh;
+    d.tpt_shift = sh;
+    for (int i = 0; i < 16; ++i) { d.tap_dy[i] = i < h->n_taps ? h->tap_dy[i] : 0; d.tap_dx[i] = i < h->n_taps ? h->tap_dx[i] : 0; }
+    d.dst_h = h->dst_h; d.dst_w = h->dst_w; d.dst_sy = h->dst_sy; d.dst_sx = h->dst_sx; d.dst_oy = h->dst_oy; d.dst_ox = h->dst_ox;
+    gp_magic((uint32_t)d.grid_w, d.gw_magic, d.gw_shift);
+    gp_magic((uint32_t)d.grid_h, d.gh_magic, d.gh_shift);
+    d.mask_bits = (const uint8_t*)h->mask_bits; d.sign_out = (uint8_t*)h->sign_out;
+    RART_CHECK_ARG(!(d.sign_out && (h->flags & GP_OUT_F32)), "rart_gemm_pair_bf16 (conv): sign_out needs a pair destination");
+  } else {
+    RART_CHECK_ARG(!h->mask_bits && !h->sign_out, "rart_gemm_pair_bf16: mask_bits / sign_out are served by conv mode only");
+    RART_CHECK_ARG(h->lda % 8 == 0 && h->lda >= h->K, "rart_gemm_pair_bf16: lda must cover the row and keep 16-byte alignment");
+    d.grid_h = d.grid_w = d.src_h = d.src_w = d.sy = d.sx = d.n_taps = 1; d.tpt_shift = 0;
+    for (int i = 0; i < 16; ++i) d.tap_dy[i] = d.tap_dx[i] = 0;
+    d.dst_h = d.dst_w = d.dst_sy = d.dst_sx = 1; d.dst_oy = d.dst_ox = 0;
+    d.gw_magic = d.gw_shift = d.gh_magic = d.gh_shift = 0;
+    d.mask_bits = nullptr; d.sign_out = nullptr;
+  }
+  d.N = h->N;
+  RART_CHECK_ARG(d.M > 0 && d.N > 0 && d.N % 8 == 0, "rart_gemm_pair_bf16: M > 0, N a positive multiple of 8");
+  RART_CHECK_ARG(d.K > 0 && d.K % GP_BK == 0, "rart_gemm_pair_bf16: K must be a positive multiple of 32");
+  RART_CHECK_ARG(h->ldw % 8 == 0 && h->ldc % 8 == 0 && h->ldw >= d.K && h->ldc >= d.N,
                  "rart_gemm_pair_bf16: leading dimensions must cover the row and keep 16-byte alignment");
   const bool out_f32 = (h->flags & GP_OUT_F32) != 0;
   RART_CHECK_ARG(out_f32 || h->dst_lo, "rart_gemm_pair_bf16: a pair destination needs its lo plane");
@@ -321,14 +472,13 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
     const int g = (h->flags & GP_GELU ? 1 : 0) + (h->flags & GP_GELU_BWD ? 1 : 0) + (h->flags & GP_GELU_KEEP ? 1 : 0);
     RART_CHECK_ARG(g <= 1 && !((h->flags & GP_GELU_KEEP) && out_f32), "rart_gemm_pair_bf16: at most one GELU mode; GELU_KEEP writes pairs");
   }
-  GemmPairDev d;
   d.a_hi = (const uint16_t*)h->a_hi; d.a_lo = (const uint16_t*)h->a_lo; d.w_hi = (const uint16_t*)h->w_hi; d.w_lo = (const uint16_t*)h->w_lo;
   d.bias = h->bias; d.res_hi = (const uint16_t*)h->res_hi; d.res_lo = (const uint16_t*)h->res_lo;
   d.dst_hi = (uint16_t*)h->dst_hi; d.dst_lo = (uint16_t*)h->dst_lo; d.aux_hi = (uint16_t*)h->aux_hi; d.aux_lo = (uint16_t*)h->aux_lo;
-  d.M = h->M; d.N = h->N; d.K = h->K; d.lda = h->lda; d.ldw = h->ldw; d.ldc = h->ldc;
+  d.lda = h->lda; d.ldw = h->ldw; d.ldc = h->ldc;
   d.w_rows = h->w_rows > 0 ? h->w_rows : h->N;
-  d.map_rows = (h->rows_per_image > 0 && h->rows_per_image < h->M) ? 1 : 0;
-  d.rpi = d.map_rows ? h->rows_per_image : h->M;
+  d.map_rows = (!conv && h->rows_per_image > 0 && h->rows_per_image < d.M) ? 1 : 0;
+  d.rpi = d.map_rows ? h->rows_per_image : d.M;
   d.src_rpi = h->src_rows_per_image > 0 ? h->src_rows_per_image : d.rpi;
   d.dst_rpi = h->dst_rows_per_image > 0 ? h->dst_rows_per_image : d.rpi;
   d.src_off = h->src_row_off; d.dst_off = h->dst_row_off;
@@ -338,11 +488,42 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   RART_CHECK_ARG(nz <= 65535, "rart_gemm_pair_bf16: n_batched must be <= 65535");
   d.z_inner = h->z_inner > 0 ? h->z_inner : 1;
   d.a_zo = h->a_z_outer; d.a_zi = h->a_z_inner; d.w_zo = h->w_z_outer; d.w_zi = h->w_z_inner; d.c_zo = h->c_z_outer; d.c_zi = h->c_z_inner;
-  const int m_tiles = (d.M + GP_TM - 1) / GP_TM, n_tiles = (d.N + GP_TN - 1) / GP_TN;
+  // Tile policy, from the per-shape sweep of every launch of a ResNet-50 gradient evaluation at B = 256 (scratch/r4/sweep_pair_tiles.py,
+  // profiles/r04_pair_tile_sweep.txt).  Plain products (the transformer GEMMs): 256 rows x the widest of 64 / 128 / 256 columns that does not
+  // pad the MFMA work.  Convolutions: K <= 256 (the HBM-bound 1x1 layers: two K steps do not hide a tile's load and store phases) 256 x 64,
+  // 80 KB of LDS = two workgroups per CU; K < 1024 128 x {128, 64} (64 / 48 KB: two or three per CU); K-deep wide layers 256 x 256 unless
+  // that leaves fewer than 128 workgroups (layer4: 256 x 128), K-deep narrow layers (N <= 128) 128 x N.  tile_m / tile_n override.
+  int tn = d.N <= 64 ? 64 : (d.N <= 128 ? 128 : 256), tm = 256;
+  if (conv) {
+    if (d.K <= 256) { tm = 256; tn = 64; }
+    else if (d.K < 1024 || d.N <= 128) { tm = 128; tn = d.N <= 64 ? 64 : 128; }
+    else if ((long long)((d.M + 255) / 256) * ((d.N + 255) / 256) < 128) { tm = 256; tn = 128; }
+    if (d.M <= 256) { tm = 128; tn = 64; }
+  }
+  if (h->tile_n == 64 || h->tile_n == 128 || h->tile_n == 256) tn = h->tile_n;
+  if (h->tile_m == 128 || h->tile_m == 256) tm = h->tile_m;
+  const int m_tiles = (d.M + tm - 1) / tm, n_tiles = (d.N + tn - 1) / tn;
   const int m_enum = m_tiles >= 16 ? (m_tiles + 7) / 8 * 8 : m_tiles;     // the XCD remap enumerates row tiles in groups of 8
   const long long blocks = (long long)m_enum * n_tiles;
   RART_CHECK_ARG(blocks < (1ll << 31), "rart_gemm_pair_bf16: grid too large");
-  hipLaunchKernelGGL(k_gemm_pair, dim3((uint32_t)blocks, nz), dim3(512), 0, (hipStream_t)stream, d);
+  const dim3 grid((uint32_t)blocks, nz);
+  hipStream_t st = (hipStream_t)stream;
+#define RART_GP_LAUNCH(TM_, TN_, CONV_) hipLaunchKernelGGL((k_gemm_pair<TM_, TN_, CONV_>), grid, dim3(TM_ * 2), 0, st, d)
+#define RART_GP_BY_TN(TM_, CONV_)                                          \
+  do {                                                                     \
+    if (tn == 64) RART_GP_LAUNCH(TM_, 64, CONV_);                          \
+    else if (tn == 128) RART_GP_LAUNCH(TM_, 128, CONV_);                   \
+    else RART_GP_LAUNCH(TM_, 256, CONV_);                                  \
+  } while (0)
+  if (conv) {
+    if (tm == 128) RART_GP_BY_TN(128, true);
+    else RART_GP_BY_TN(256, true);
+  } else {
+    if (tm == 128) RART_GP_BY_TN(128, false);
+    else RART_GP_BY_TN(256, false);
+  }
+#undef RART_GP_BY_TN
+#undef RART_GP_LAUNCH
   RART_CHECK_LAUNCH("rart_gemm_pair_bf16");
   return RART_OK;
 }

@@ -164,6 +164,8 @@ class ResNet50Engine:
         self.fused_bottleneck_s2 = True  # False: the stride-2 first blocks of layer2 / layer3 as four conv launches in the forward (cross-check)
         self.fused_bottleneck_s2_bwd = True   # False: their backward-to-input as seven conv launches (cross-check)
         self.small_m_fc = True           # False: the classifier head and its backward on the implicit GEMM (cross-check)
+        self.pair_tile = (0, 0)
+        self.pair_gemm_kernel = True     # reference-precision mode: False = the three products as 3 x the taps of the implicit GEMM (round 3; cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in layer:
@@ -340,6 +342,9 @@ class ResNet50Engine:
     def _gemm(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix,
               bias=None, res=None, mask=None, flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0),
               tap_src_off=None, sign_out=None, pair=False):
+        if pair and self.pair_gemm_kernel and len(taps) <= 16 and k_per_tap >= 32 and (k_per_tap & (k_per_tap - 1)) == 0:
+            return self._gemm_pair(src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, bias, res,
+                                   mask, flags, stride, dst_stride, dst_off, sign_out)
         d = _lib.ConvDesc()
         if pair:
             # split-bf16 tensors [2][...] (hi plane, lo plane): the three products as 3x the taps, the lo planes of dst / res
@@ -381,6 +386,49 @@ class ResNet50Engine:
             self.profile.append((flops, e0, e1, 'igemm'))
             return
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _gemm_pair(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, bias, res, mask, flags,
+                   stride, dst_stride, dst_off, sign_out):
+        """One convolution / product of the reference-precision mode on rart_gemm_pair_bf16 (csrc/gemm_pair.hip, conv mode): the four
+        operand planes of a K step staged once, three MFMAs per fragment pair -- round 3 listed the three products as 3 x the taps of
+        rart_conv_igemm_bf16, which fetched x_hi twice and ran at a quarter of this kernel's MFMA rate.  src / dst / res: pair tensors
+        [2][...]; wgt: the [rows][hi | lo | hi] table of `_Conv(split=True)` (w_hi = columns 0..K, w_lo = columns K..2K, row stride 3K);
+        mask: 1-bit ReLU mask of the destination; an fp32 destination (F_OUT_F32) is a plain tensor."""
+        assert src.shape[0] == 2
+        k_tot = k_per_tap * len(taps)
+        assert wgt.shape[1] == 3 * k_tot
+        d = _lib.GemmPairDesc()
+        d.a_hi, d.a_lo = src[0].data_ptr(), src[1].data_ptr()
+        d.w_hi, d.w_lo = wgt.data_ptr(), wgt.data_ptr() + 2 * k_tot
+        d.bias = bias.data_ptr() if bias is not None else None
+        if res is not None:
+            d.res_hi, d.res_lo = res[0].data_ptr(), res[1].data_ptr()
+        if flags & F_OUT_F32:
+            d.dst_hi = dst.data_ptr()
+        else:
+            d.dst_hi, d.dst_lo = dst[0].data_ptr(), dst[1].data_ptr()
+        d.N, d.lda, d.ldw, d.ldc, d.w_rows = n_cols, src_pix, 3 * k_tot, dst_pix, wgt.shape[0]
+        d.flags = flags & (F_RELU | F_OUT_F32)
+        d.conv, d.batch, d.grid_h, d.grid_w = 1, batch, grid[0], grid[1]
+        d.src_h, d.src_w, d.sy, d.sx = src_hw[0], src_hw[1], stride[0], stride[1]
+        d.k_per_tap, d.n_taps = k_per_tap, len(taps)
+        for i, (dy, dx) in enumerate(taps):
+            d.tap_dy[i], d.tap_dx[i] = dy, dx
+        d.dst_h, d.dst_w = dst_hw
+        d.dst_sy, d.dst_sx = dst_stride
+        d.dst_oy, d.dst_ox = dst_off
+        d.mask_bits = mask.data_ptr() if mask is not None else None
+        d.sign_out = sign_out.data_ptr() if sign_out is not None else None
+        d.tile_m, d.tile_n = self.pair_tile          # (0, 0): the library's choice; profiling sweeps force a tile
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            e1.record()
+            self.profile.append((3 * 2.0 * batch * grid[0] * grid[1] * k_tot * n_cols, e0, e1, 'gemm_pair'))   # MFMA FLOPs issued
+            return
+        _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
     def _fc(self, a, w, out, m, n, k, bias=None):
         """The classifier head / its backward: rart_gemm_small_m_bf16 (one workgroup per 32 x 32 tile, waves split K) instead of the

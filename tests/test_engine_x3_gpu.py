@@ -227,3 +227,118 @@ def test_x3_through_engine_model_and_pgd(setup):
     with pytest.raises(ValueError):
         from robustart_amd.model.engine import ResNet50Engine
         ResNet50Engine(m, 'cuda', precision='fp16')
+
+
+@pytest.mark.parametrize('N,tile_n,tile_m', [(128, 0, 0), (128, 64, 256), (64, 0, 256), (256, 256, 256), (152, 0, 0), (256, 256, 128), (128, 128, 128),
+                                             (64, 64, 128)])
+def test_pair_conv_kernel_vs_fp64(N, tile_n, tile_m):
+    """rart_gemm_pair_bf16 in conv mode (round 4: the four operand planes of a K step staged once, three MFMAs per fragment pair) on a
+    3x3 stride-1 conv: pair in, pair out, bias + residual pair + ReLU + sign bits, against fp64 of the same hi / lo operands; every
+    column tile (64 / 128 / 256, forced and automatic) and an N that is not a multiple of the tile."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    B, Hh, Ww, C = 3, 10, 12, 64
+    x = torch.randn(B, Hh, Ww, C, generator=g).cuda()
+    w = (torch.randn(N, 3, 3, C, generator=g) * 0.05).cuda()             # [n][r][s][c]
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(B, Hh, Ww, N, generator=g).cuda()
+    xp, rp = _split(x), _split(res)
+    wh = w.to(torch.bfloat16)
+    wl = (w - wh.float()).to(torch.bfloat16)
+    rows = lambda t: t.reshape(N, 9 * C)                                # noqa: E731
+    w3 = torch.cat([rows(wh), rows(wl), rows(wh)], 1).contiguous()
+    out = torch.zeros(2, B, Hh, Ww, N, dtype=torch.bfloat16, device='cuda')
+    sign = torch.zeros(B, Hh, Ww, N // 8, dtype=torch.uint8, device='cuda')
+    d = _lib.GemmPairDesc()
+    d.a_hi, d.a_lo, d.w_hi, d.w_lo = xp[0].data_ptr(), xp[1].data_ptr(), w3.data_ptr(), w3.data_ptr() + 2 * 9 * C
+    d.bias, d.res_hi, d.res_lo, d.dst_hi, d.dst_lo = bias.data_ptr(), rp[0].data_ptr(), rp[1].data_ptr(), out[0].data_ptr(), out[1].data_ptr()
+    d.sign_out = sign.data_ptr()
+    d.N, d.lda, d.ldw, d.ldc, d.w_rows, d.flags, d.tile_n, d.tile_m = N, C, 27 * C, N, N, 1, tile_n, tile_m
+    d.conv, d.batch, d.grid_h, d.grid_w, d.src_h, d.src_w, d.sy, d.sx, d.k_per_tap, d.n_taps = 1, B, Hh, Ww, Hh, Ww, 1, 1, C, 9
+    for i, (dy, dx) in enumerate([(r - 1, s - 1) for r in range(3) for s in range(3)]):
+        d.tap_dy[i], d.tap_dx[i] = dy, dx
+    d.dst_h, d.dst_w, d.dst_sy, d.dst_sx = Hh, Ww, 1, 1
+    _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    f64 = lambda p: (p[0].double() + p[1].double())                     # noqa: E731
+    xv, wv = f64(xp).permute(0, 3, 1, 2), (wh.double() + wl.double()).permute(0, 3, 1, 2)
+    want = torch.relu(torch.nn.functional.conv2d(xv, wv, bias.double(), padding=1).permute(0, 2, 3, 1) + f64(rp))
+    got = f64(out)
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    print('pair conv kernel N=%d tile %d x %d: scale %.3f, max |err| %.3g (%.2g of scale)' % (N, tile_m, tile_n, scale, err, err / scale))
+    assert err <= 2.5e-5 * scale
+    unpacked = torch.stack([(sign >> j) & 1 for j in range(8)], -1).reshape(B, Hh, Ww, N).bool()
+    assert torch.equal(unpacked, out[0].float() > 0)
+    # 17 taps / a k_per_tap that is not a power of two are argument errors
+    d.n_taps = 17
+    assert lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()) != 0
+    d.n_taps, d.k_per_tap = 9, 96
+    assert lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()) != 0
+
+
+def test_pair_conv_kernel_stride2_backward_parity_classes_with_mask_bits():
+    """The backward-to-input of a 3x3 / 2 convolution as four input-parity classes (sub-grid + strided destination), 1-bit ReLU mask of
+    the destination, fp64 reference by conv_transpose -- the launch shape `_conv_bwd` uses for the stride-2 blocks."""
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import _Conv
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    B, Ho, Wo, Cin, Cout = 2, 7, 9, 64, 128
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 2, 1, bias=False)
+    conv.weight.data.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
+    c = _Conv(conv, None, 'cuda', split=True)
+    dz = _split(torch.randn(B, Ho, Wo, Cout, generator=g).cuda())
+    keep = torch.rand(B, 2 * Ho, 2 * Wo, Cin, generator=g) > 0.4
+    bits = torch.zeros(B, 2 * Ho, 2 * Wo, Cin // 8, dtype=torch.uint8)
+    for j in range(8):
+        bits |= (keep.view(B, 2 * Ho, 2 * Wo, Cin // 8, 8)[..., j].to(torch.uint8) << j)
+    bits = bits.cuda()
+    dx = torch.full((2, B, 2 * Ho, 2 * Wo, Cin), float('nan'), dtype=torch.bfloat16, device='cuda')
+    for (ph, pw), taps, w in c.bwd:
+        d = _lib.GemmPairDesc()
+        kt = Cout * len(taps)
+        d.a_hi, d.a_lo, d.w_hi, d.w_lo = dz[0].data_ptr(), dz[1].data_ptr(), w.data_ptr(), w.data_ptr() + 2 * kt
+        d.dst_hi, d.dst_lo, d.mask_bits = dx[0].data_ptr(), dx[1].data_ptr(), bits.data_ptr()
+        d.N, d.lda, d.ldw, d.ldc, d.w_rows = Cin, Cout, 3 * kt, Cin, w.shape[0]
+        d.conv, d.batch, d.grid_h, d.grid_w, d.src_h, d.src_w, d.sy, d.sx, d.k_per_tap, d.n_taps = 1, B, Ho, Wo, Ho, Wo, 1, 1, Cout, len(taps)
+        for i, (dy, dx_) in enumerate(taps):
+            d.tap_dy[i], d.tap_dx[i] = dy, dx_
+        d.dst_h, d.dst_w, d.dst_sy, d.dst_sx, d.dst_oy, d.dst_ox = 2 * Ho, 2 * Wo, 2, 2, ph, pw
+        _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    f64 = lambda p: (p[0].double() + p[1].double())                     # noqa: E731
+    wv = c.w_folded.double()
+    wv = (wv.to(torch.bfloat16).double() + (wv - wv.to(torch.bfloat16).double()).to(torch.bfloat16).double()).cuda()    # hi + lo of the table
+    want = torch.nn.grad.conv2d_input((B, Cin, 2 * Ho, 2 * Wo), wv, f64(dz).permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)
+    want = want * keep.cuda()
+    got = f64(dx)
+    assert torch.isfinite(got).all()                                     # every destination pixel belongs to exactly one parity class
+    assert (got - want).abs().max().item() <= 2.5e-5 * want.abs().max().item()
+
+
+def test_x3_engine_new_kernel_matches_the_round3_igemm_pair_path(setup):
+    """The whole reference-precision forward + backward on rart_gemm_pair_bf16 against the same engine on round 3's path (the three
+    products as 3 x the taps of rart_conv_igemm_bf16): same operands, fp32 accumulation in another order."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(3, 3, 96, 128, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    assert eng.pair_gemm_kernel
+    la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    la, ga = la.clone(), ga.clone()
+    eng.pair_gemm_kernel = False
+    try:
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.pair_gemm_kernel = True
+    assert (la - lb).abs().max().item() <= 2e-5 * lb.abs().max().item()
+    a, b = ga.double().flatten(1), gb.double().flatten(1)
+    rel = ((a - b).norm(dim=1) / b.norm(dim=1)).max().item()
+    print('x3 engine: new pair kernel vs igemm pair path: logits %.2e, gradient rel L2 %.2e'
+          % ((la - lb).abs().max().item() / lb.abs().max().item(), rel))
+    # ReLU decisions of near-zero pre-activations flip between two forwards that differ by 1e-5 (random-init network): the gradient
+    # moves discontinuously with them -- the fp64 tests with the engine's own masks are the pin, this is a sanity bound
+    cos = ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min().item()
+    assert rel <= 0.15 and cos >= 0.98
