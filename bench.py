@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--cpu-sweep', action='store_true', help='only run the CPU 14 corruptions x 5 severities sweep (BASELINE.md 3b)')
     ap.add_argument('--workload', choices=['headline', 'vit_inc', 'vit_pgd', 'adv_train'], default='headline',
                     help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 4: ViT-B/16 evaluated "
-                         "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost skipped: no textures)")
+                         "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost on synthetic textures)")
     ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
                     help="'hip' = hand-written engine (product); 'scaffold' = PyTorch-ROCm/MIOpen, for comparison only")
     ap.add_argument('--one-stream', action='store_true', help='run the two halves of a step back to back on one stream (A/B)')
@@ -173,15 +173,21 @@ def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
         if sd is not main:
             sd.wait_stream(main)                       # the previous step's consumers of the scratch buffers are done
     parts = []
+    # IN-C x5: ONE launch reads the batch once and writes gaussian_noise at severities 1..5, each with its own field (seed = severity:
+    # the reference's generation loop draws fresh noise per (image, severity)); the five evaluations then alternate over the streams
+    bufs = one_step.extra.setdefault(('sev', images.shape), [torch.empty_like(images) for _ in range(5)])
+    with torch.cuda.stream(sides[0]):
+        C.noise_severities_(images, bufs, (1, 2, 3, 4, 5), (1, 2, 3, 4, 5), sample_offset=base, corruption_id=0)
+    for sd in sides[1:]:
+        sd.wait_stream(sides[0])
     for sev in range(1, 6):
         k = (sev - 1) % len(sides)
         with torch.cuda.stream(sides[k]):
-            buf = scratch_u8 if k == 0 else one_step.extra.setdefault(k, torch.empty_like(scratch_u8))
-            C.corrupt_batch_(images, 0, sev, seed=0, sample_offset=base, out=buf)
+            buf = bufs[sev - 1]
             logits = path.logits_from_u8(buf, norm_buf, k) if isinstance(path, HipEngine) else path.logits_from_u8(buf, norm_buf)
             _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
             parts.append((pred.long() == labels).sum())
-    x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
+    x01 = C.to_unit_nchw(images, one_step.extra.setdefault(('x01', images.shape), torch.empty(B, 3, H, W, device=images.device)))
     x_adv = adv.pgd_linf(x01, labels, path.f_model, 2 / 255, 3 / 40, 7, seed=1, sample_offset=base)
     with torch.no_grad():
         logits = path.f_model(x_adv).float()
@@ -226,6 +232,7 @@ def measure_gaussian_roofline(B, device, launches=40, npairs=9):
 
     noise = lambda i: C.corrupt_batch_(src[i % npairs], 0, 3, seed=0, sample_offset=i * B, out=dst[i % npairs])  # noqa: E731
     avg = timed(noise)
+    measure_gaussian_roofline.extra = {}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
     for i in range(launches):
         ev[i][0].record()
@@ -236,33 +243,85 @@ def measure_gaussian_roofline(B, device, launches=40, npairs=9):
     # calibration beside it: a plain device copy of the SAME bytes over the same rotating pairs (PyTorch's copy kernel): what a
     # read + write stream of this size sustains on this part, next to the 8 TB/s spec the fraction is quoted against
     copy_s = timed(lambda i: dst[i % npairs].copy_(src[i % npairs]))
+    measure_gaussian_roofline.extra = extra = {}
+    if launches >= 20:
+        # (a) the same single-severity launches alternating over TWO streams: the tail of one launch overlaps the ramp of the next
+        #     (the five severities of the workload are independent); time = main-stream events around the fork / join
+        main = torch.cuda.current_stream(device)
+        st = [torch.cuda.Stream(device=device) for _ in range(2)]
+
+        def two_stream_pass():
+            for q in st:
+                q.wait_stream(main)
+            for i in range(launches):
+                with torch.cuda.stream(st[i & 1]):
+                    noise(i)
+            for q in st:
+                main.wait_stream(q)
+        two_stream_pass()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            two_stream_pass()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / launches * 1e-3)
+        extra['two_streams_s'] = sorted(ts)[1]
+        # (b) the workload's own form: ONE launch per source batch writes severities 1..5 (rart_noise_multi_u8: the chunk is read once,
+        #     five fields): 6 x 38.5 MB moved for 5 launch-equivalents of 2 x 38.5 MB algorithmic bytes each
+        m_pairs = max(2, min(npairs, 5))
+        outs = [[torch.empty_like(src[0]) for _ in range(5)] for _ in range(m_pairs)]
+        multi = lambda i: C.noise_severities_(src[i % npairs], outs[i % m_pairs], (1, 2, 3, 4, 5), (1, 2, 3, 4, 5),   # noqa: E731
+                                              sample_offset=i * B, corruption_id=0)
+        extra['multi_launch_s'] = timed(multi)
+        extra['multi_buffers_mb'] = (npairs + 5 * m_pairs) * src[0].numel() / 1e6
+        del outs
     return avg, bracket, copy_s
 
 
 def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r03_pmc_traffic.json, else r02; produced by profiles/summarize_pmc.py); None if absent."""
+    (profiles/r04_pmc_traffic.json, else r03 / r02; produced by profiles/summarize_pmc.py); None if absent."""
     try:
-        path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        path = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_pmc_traffic.json' % r) for r in (4, 3, 2)) if os.path.exists(q)), None)
         pmc_traffic.source = os.path.basename(path)
         with open(path) as f:
             d = json.load(f)
         if key == 'igemm':
             return d['k_conv_igemm_bf16_all']['hbm_bytes']
-        for k, v in d['kernels'].items():
-            if key in k:
-                return v['hbm_bytes']
+        # a kernel family: the launch-weighted mean over its template instances (forward / backward, identity / first block)
+        hit = [v for k, v in d['kernels'].items() if key in k]
+        if hit:
+            return sum(v['hbm_bytes'] * v.get('calls', 1) for v in hit) / sum(v.get('calls', 1) for v in hit)
     except Exception:
         pass
     return None
 
 
+KERNEL_NAMES = {
+    'igemm': 'k_conv_igemm_bf16 (layer4 first block, the unfused remainder)',
+    'halo3x3': 'k_conv3x3_halo / k_conv3x3_image256 (3x3, input tile resident in LDS)',
+    'bottleneck': 'k_bottleneck56 (layer1 blocks fused: 1x1 + 3x3 + 1x1 + shortcut in one launch)',
+    'bottleneck14': 'k_bottleneck14 (layer3 identity blocks fused, one image per workgroup)',
+    'bottleneck28': 'k_bottleneck28 (layer2 identity blocks fused, a quarter image per workgroup)',
+    'bottleneck7': 'k_bottleneck7 (layer4 identity blocks fused, one image per workgroup)',
+    'bottleneck_s2': 'k_bottleneck_s2 (stride-2 first blocks of layer2 / layer3, forward: 1x1 + 3x3/2 + 1x1 + projection in one launch)',
+    'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd (the same blocks, backward-to-input in one launch)',
+    'fc_small_m': 'k_gemm_small_m (classifier head and its backward: one 32 x 32 tile per workgroup, waves split K)',
+    'gemm_pair': 'k_gemm_pair (split-bf16 GEMM / implicit-GEMM convolution of the reference-precision engines)'}
+PMC_KEYS = {'bottleneck': 'k_bottleneck56', 'bottleneck14': 'k_bottleneck14', 'bottleneck28': 'k_bottleneck28', 'bottleneck7': 'k_bottleneck7',
+            'bottleneck_s2': '15k_bottleneck_s2I', 'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd', 'halo3x3': 'k_conv3x3', 'igemm': 'igemm'}
+
+
 def measure_igemm_roofline(path, images, labels):
-    """Dominant kernel of the step: k_conv_igemm_bf16 (every conv / fc of ResNet-50, forward and
-    backward-to-input).  One PGD gradient evaluation (forward + backward) at B = 256 is timed launch by
-    launch with events on the launch stream; achieved = algorithmic GEMM FLOPs / kernel time."""
+    """`roofline` = the kernel family with the LARGEST share of one PGD gradient evaluation (forward + backward-to-input at B = 256,
+    every launch timed with events on the launch stream).  Since round 2's fusions that is k_bottleneck56 (layer1), not the implicit
+    GEMM.  A fused block is priced against its BINDING roof -- max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s), where the algorithmic
+    bytes are x in + out + weight tables + 1-bit sign tensors, each once (the residual re-read and the halo rows are implementation
+    traffic: they show up in `traffic`, the PMC bytes per launch, and in `overfetch` = traffic / algorithmic bytes) -- with the MFMA
+    fraction beside it.  Every other family follows under `other_mfma_kernels`, the total under `all_conv_launches`."""
     eng = path.eng
     x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
     eng.forward_backward(x01, path.MEAN, path.STD, labels, 0)          # warm
@@ -270,42 +329,56 @@ def measure_igemm_roofline(path, images, labels):
     eng.forward_backward(x01, path.MEAN, path.STD, labels, 0)
     torch.cuda.synchronize()
     prof, eng.profile = eng.profile, None
-    ig = [p for p in prof if p[3] == 'igemm']
-    halo = [p for p in prof if p[3] != 'igemm']
-    secs = sum(a.elapsed_time(b) for _, a, b, _ in ig) * 1e-3
-    flops = sum(f for f, _, _, _ in ig)
-    out = {'kernel': 'k_conv_igemm_bf16 (ResNet-50 forward + backward-to-input, B=256, %d launches)' % len(ig),
-           'bound': 'mfma', 'achieved': flops / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-           'frac': flops / secs / MFMA_BF16_PEAK, 'traffic': pmc_traffic('igemm'),
-           'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s (rocprofv3 FETCH_SIZE x2 '
-                           '(gfx950 correction) + WRITE_SIZE, KiB units), not re-measured in this run' % getattr(pmc_traffic, 'source', '?'),
-           'avg_launch_us': secs / len(ig) * 1e6, 'launches': len(ig),
-           'algorithmic_flops_per_launch': flops / len(ig), 'kernel_seconds_per_fwd_bwd': secs}
-    if out['traffic']:
-        # what is left on this kernel is mostly the K <= 256 1x1 layers of layer1 / layer2, which sit on the HBM roofline:
-        # the same launches priced by bytes (PMC traffic per launch / measured launch time)
-        out['hbm_view'] = {'achieved': out['traffic'] / (secs / len(ig)) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                           'frac': out['traffic'] / (secs / len(ig)) / HBM_PEAK}
-    if halo:
-        names = {'halo3x3': 'k_conv3x3_halo / k_conv3x3_image256 (layer1-3 3x3, input tile resident in LDS)',
-                 'bottleneck': 'k_bottleneck56 (layer1 blocks fused: 1x1 + 3x3 + 1x1 + shortcut in one launch)',
-                 'bottleneck14': 'k_bottleneck14 (layer3 identity blocks fused, one image per workgroup)',
-                 'bottleneck28': 'k_bottleneck28 (layer2 identity blocks fused, a quarter image per workgroup)',
-                 'bottleneck7': 'k_bottleneck7 (layer4 identity blocks fused, one image per workgroup)',
-                 'bottleneck_s2': 'k_bottleneck_s2 (stride-2 first blocks of layer2 / layer3, forward: 1x1 + 3x3/2 + 1x1 + projection in one launch)',
-                 'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd (the same blocks, backward-to-input in one launch)',
-                 'fc_small_m': 'k_gemm_small_m (classifier head and its backward: one 32 x 32 tile per workgroup, waves split K)'}
-        out['other_mfma_kernels'] = {}
-        for kind in sorted(set(p[3] for p in halo)):
-            grp = [p for p in halo if p[3] == kind]
-            gs = sum(a.elapsed_time(b) for _, a, b, _ in grp) * 1e-3
-            gf = sum(f for f, _, _, _ in grp)
-            out['other_mfma_kernels']['%s, %d launches' % (names.get(kind, kind), len(grp))] = {
-                'achieved': gf / gs / 1e12, 'unit': 'TFLOP/s', 'frac': gf / gs / MFMA_BF16_PEAK, 'avg_launch_us': gs / len(grp) * 1e6}
-        hs = sum(a.elapsed_time(b) for _, a, b, _ in halo) * 1e-3
-        hf = sum(f for f, _, _, _ in halo)
-        out['all_conv_launches'] = {'achieved': (flops + hf) / (secs + hs) / 1e12, 'unit': 'TFLOP/s',
-                                    'frac': (flops + hf) / (secs + hs) / MFMA_BF16_PEAK, 'seconds_per_fwd_bwd': secs + hs}
+    fam = {}
+    for p in prof:
+        f = fam.setdefault(p[3], {'n': 0, 's': 0.0, 'flops': 0.0, 'bytes': 0.0, 'has_bytes': True})
+        f['n'] += 1
+        f['s'] += p[1].elapsed_time(p[2]) * 1e-3
+        f['flops'] += p[0]
+        if len(p) > 4 and p[4] is not None:
+            f['bytes'] += p[4]
+        else:
+            f['has_bytes'] = False
+    tot_s = sum(f['s'] for f in fam.values())
+    tot_f = sum(f['flops'] for f in fam.values())
+
+    def block(kind, f):
+        o = {'achieved': f['flops'] / f['s'] / 1e12, 'unit': 'TFLOP/s', 'frac': f['flops'] / f['s'] / MFMA_BF16_PEAK,
+             'avg_launch_us': f['s'] / f['n'] * 1e6, 'launches': f['n'], 'share_of_gradient_evaluation': f['s'] / tot_s}
+        if f['has_bytes']:
+            floor = max(f['flops'] / MFMA_BF16_PEAK, f['bytes'] / HBM_PEAK)
+            o['algorithmic_bytes_per_launch'] = f['bytes'] / f['n']
+            o['binding_roof'] = 'hbm' if f['bytes'] / HBM_PEAK > f['flops'] / MFMA_BF16_PEAK else 'mfma'
+            o['frac_of_binding_roof'] = floor / f['s']
+            o['hbm_algorithmic'] = {'achieved': f['bytes'] / f['s'] / 1e9, 'unit': 'GB/s', 'frac': f['bytes'] / f['s'] / HBM_PEAK}
+        tr = pmc_traffic(PMC_KEYS.get(kind, kind))
+        if tr:
+            o['traffic'] = tr
+            if f['has_bytes']:
+                o['overfetch'] = tr / (f['bytes'] / f['n'])
+        return o
+    dom = max(fam, key=lambda k: fam[k]['s'])
+    d = block(dom, fam[dom])
+    out = {'kernel': '%s, %d launches of one gradient evaluation (ResNet-50 forward + backward-to-input, B=%d)'
+                     % (KERNEL_NAMES.get(dom, dom), fam[dom]['n'], images.shape[0]),
+           'selection': 'the kernel family with the largest share of the gradient evaluation (%.0f %% of the kernel time)' % (100 * fam[dom]['s'] / tot_s),
+           'bound': d.get('binding_roof', 'mfma')}
+    if d.get('binding_roof') == 'hbm':
+        out.update({'achieved': d['hbm_algorithmic']['achieved'], 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': d['hbm_algorithmic']['frac'],
+                    'mfma': {'achieved': d['achieved'], 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': d['frac']}})
+    else:
+        out.update({'achieved': d['achieved'], 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': d['frac']})
+        if 'hbm_algorithmic' in d:
+            out['hbm_algorithmic'] = d['hbm_algorithmic']
+    out.update({'traffic': d.get('traffic'), 'overfetch': d.get('overfetch'),
+                'algorithmic_bytes_per_launch': d.get('algorithmic_bytes_per_launch'),
+                'algorithmic_flops_per_launch': fam[dom]['flops'] / fam[dom]['n'],
+                'avg_launch_us': d['avg_launch_us'], 'launches': fam[dom]['n'], 'share_of_gradient_evaluation': d['share_of_gradient_evaluation'],
+                'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s (rocprofv3 FETCH_SIZE x2 (gfx950 correction) + '
+                                'WRITE_SIZE, KiB units), not re-measured in this run' % getattr(pmc_traffic, 'source', '?')})
+    out['other_mfma_kernels'] = {'%s, %d launches' % (KERNEL_NAMES.get(k, k), f['n']): block(k, f) for k, f in sorted(fam.items()) if k != dom}
+    out['all_conv_launches'] = {'achieved': tot_f / tot_s / 1e12, 'unit': 'TFLOP/s', 'frac': tot_f / tot_s / MFMA_BF16_PEAK,
+                                'seconds_per_fwd_bwd': tot_s, 'launches': len(prof)}
     return out
 
 
@@ -480,9 +553,12 @@ def cpu_sweep(reps=5):
 
 
 def run_vit_inc(args, device, rank, world, dist):
-    """BASELINE config 4 (secondary mode, not the headline line): per step, one resident batch of 256 uint8 images is
-    corrupted by each of the 15 benchmark corruptions at 5 severities (frost needs textures the reference does not
-    ship -> 14 x 5 = 70 corrupted batches) and each is evaluated by ViT-B/16 on the HIP engine."""
+    """BASELINE config 4 (secondary mode, not the headline line): per step, one resident batch of 256 uint8 images is corrupted by each of
+    the 15 benchmark corruptions at 5 severities (75 corrupted batches; frost blends SYNTHETIC textures -- the reference's six photographs
+    are not in its repository, imagenet_c/corruptions.py:251-256 -- drawn and cropped on the device exactly as for real ones) and each is
+    evaluated by ViT-B/16 on the HIP engine.  A `reference_precision` block repeats the step on the 'fp32x' engine (logits within 1e-4 of
+    the fp32 network; the reference evaluates in fp32: exprs/exp/imagenet_c_loop_mini/config_vit_base.yaml:1-9)."""
+    import numpy as np
     from robustart_amd.model import get_model
     from robustart_amd.model.vit_engine import ViTEngine
     from robustart_amd.noise import imagenet_c as C, adv
@@ -491,59 +567,83 @@ def run_vit_inc(args, device, rank, world, dist):
     images = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(device)
     labels = torch.randint(0, 1000, (B,), generator=g).to(device)
     torch.manual_seed(0)
-    # the 70 (corruption, severity) items of a step are independent: they alternate between two streams, each with its own engine
+    rs = np.random.RandomState(77)
+    C.set_frost_textures([rs.randint(0, 256, (240 + 16 * i, 300 + 8 * i, 3)).astype(np.uint8) for i in range(6)])
+    # the 75 (corruption, severity) items of a step are independent: they alternate between two streams, each with its own engine
     # workspace, so the ragged last round of one launch (a 256 x 256-tile GEMM with N = 768 has 591 workgroups for 256 CUs) is
     # filled by the other stream's work.  --one-stream keeps a single queue.
     n_q = 1 if args.one_stream else 2
     model = get_model({'type': 'vit_base'}).eval()
-    engs = [ViTEngine(model, device) for _ in range(n_q)]
     scratches = [torch.empty_like(images) for _ in range(n_q)]
     queues = [torch.cuda.Stream(device=device) for _ in range(n_q)] if n_q > 1 else [torch.cuda.current_stream(device)]
-    ids = [i for i in range(15) if C.CORRUPTION_NAMES[i] != 'frost']
+    ids = list(range(15))
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
-    def step(k):
-        main = torch.cuda.current_stream(device)
-        tots = [torch.zeros((), dtype=torch.long, device=device) for _ in range(n_q)]
-        for q in queues:
-            q.wait_stream(main)
-        j = 0
-        for cid in ids:
-            for sev in range(1, 6):
-                qi = j % n_q
-                j += 1
-                with torch.cuda.stream(queues[qi]):
-                    C.corrupt_batch_(images, cid, sev, seed=0, sample_offset=k * 1_000_003 + rank * B, out=scratches[qi])
-                    logits = engs[qi].logits_from_u8(scratches[qi], mean, std)
-                    _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
-                    tots[qi] += (pred.long() == labels).sum()
-        for q in queues:
-            main.wait_stream(q)
-        return sum(tots)
-    for i in range(args.warmup):
-        step(i)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def make_step(engs):
+        def step(k):
+            main = torch.cuda.current_stream(device)
+            tots = [torch.zeros((), dtype=torch.long, device=device) for _ in range(n_q)]
+            for q in queues:
+                q.wait_stream(main)
+            j = 0
+            for cid in ids:
+                for sev in range(1, 6):
+                    qi = j % n_q
+                    j += 1
+                    with torch.cuda.stream(queues[qi]):
+                        C.corrupt_batch_(images, cid, sev, seed=0, sample_offset=k * 1_000_003 + rank * B, out=scratches[qi])
+                        logits = engs[qi].logits_from_u8(scratches[qi], mean, std)
+                        _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
+                        tots[qi] += (pred.long() == labels).sum()
+            for q in queues:
+                main.wait_stream(q)
+            return sum(tots)
+        return step
+
+    def timed(step, warmup, steps):
+        for i in range(warmup):
+            step(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+    engs = [ViTEngine(model, device) for _ in range(n_q)]
+    dt = timed(make_step(engs), args.warmup, args.steps)
     n_img = len(ids) * 5 * B * world
+    out = {'metric': 'corrupted images/sec/node (ViT-B/16, ImageNet-C 15 corruptions x 5 severities, on-GPU noise)',
+           'value': n_img * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': 'BASELINE config 4 (secondary): 75 corrupted batches of %d per step -> ViT-B/16 eval' % B,
+                      'corruptions': len(ids), 'frost_textures': 'synthetic (6 random uint8 photographs, cropped on the device)',
+                      'global_batch': B * world, 'parallelism': 'dp%d' % world, 'streams': n_q}}
+    if not args.no_reference_precision:
+        del engs
+        torch.cuda.empty_cache()
+        engs = [ViTEngine(model, device, precision='fp32x') for _ in range(n_q)]
+        rsteps = max(1, min(args.steps, 2))
+        rdt = timed(make_step(engs), 1, rsteps)
+        out['reference_precision'] = {
+            'value': n_img * rsteps / rdt, 'unit': 'images/s', 'ms_per_step': rdt / rsteps * 1e3, 'steps': rsteps, 'dtype': 'bf16x3',
+            'arithmetic': 'activations / weights as hi + lo bf16 pairs, x.w = lo.hi + hi.lo + hi.hi on v_mfma_f32_32x32x16_bf16 with fp32 '
+                          'accumulation (rart_gemm_pair_bf16), LayerNorm / soft-max / GELU in fp32; logits within 1e-4 of the fp32 network '
+                          '(tests/test_vit_x3_gpu.py)',
+            'step_algorithmic': {'achieved': n_img * rsteps * 35.1e9 / rdt / 1e12, 'unit': 'TFLOP/s',
+                                 'vs_fp32_mfma_peak': n_img * rsteps * 35.1e9 / rdt / MFMA_F32_PEAK,
+                                 'note': 'fp32-equivalent FLOPs (35.1 GFLOP per ViT-B/16 forward) / time; 157.3 TFLOP/s is what fp32 MFMA operands peak at'}}
     if rank == 0:
-        print(json.dumps({'metric': 'corrupted images/sec/node (ViT-B/16, ImageNet-C 14 corruptions x 5 severities, on-GPU noise)',
-                          'value': n_img * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-                          'config': {'workload': 'BASELINE config 4 (secondary): 70 corrupted batches of 256 per step -> ViT-B/16 eval',
-                                     'global_batch': B * world, 'parallelism': 'dp%d' % world, 'streams': n_q}}))
+        print(json.dumps(out))
 
 
 def run_vit_pgd(args, device, rank, world, dist):
@@ -675,9 +775,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('RART_FORCE_DIST') == '1':     # (forced: a one-rank RCCL group, tests/test_rccl_gpu.py)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)       # "nccl" == RCCL on ROCm
     if args.workload in ('vit_inc', 'vit_pgd', 'adv_train'):
         {'vit_inc': run_vit_inc, 'vit_pgd': run_vit_pgd, 'adv_train': run_adv_train}[args.workload](args, device, rank, world, dist)
@@ -737,6 +840,7 @@ def main():
     if rank == 0:
         if world == 1:
             avg, bracket, copy_s = measure_gaussian_roofline(B, device)
+            ex_first = dict(getattr(measure_gaussian_roofline, 'extra', {}) or {})
             algo = BYTES_PER_IMAGE * B
             out['roofline'] = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, B=256, u8 NHWC in/out)',
                                'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
@@ -759,7 +863,30 @@ def main():
                 out['roofline']['at_4x_batch'] = {'batch': 4 * B, 'avg_launch_us': avg4 * 1e6, 'achieved': 4 * algo / avg4 / 1e9,
                                                   'unit': 'GB/s', 'frac': 4 * algo / avg4 / HBM_PEAK,
                                                   'device_copy_frac_of_peak': 4 * algo / copy4 / HBM_PEAK}
-            out['hbm_roofline_gaussian_noise'] = out.pop('roofline')
+            single = out.pop('roofline')
+            ex = ex_first
+            if 'multi_launch_s' in ex:
+                # headline of this block: the launch the WORKLOAD issues -- five severities of the resident batch in one launch --
+                # per launch-equivalent (1 / 5 of its duration) against the algorithmic 2 x 38.5 MB of one severity; beside it the same
+                # duration against the bytes the launch really moves (6 x 38.5 MB), the single-severity launch (one stream: round 3's
+                # figure) and the single-severity launches alternating over two streams
+                t5 = ex['multi_launch_s']
+                moved = (1 + 5) * ELEMS * B
+                blk = {'kernel': 'k_normal_noise_mfma_multi<0> (gaussian_noise, severities 1..5 of B=%d u8 NHWC images in one launch, one field per severity)' % B,
+                       'bound': 'hbm', 'achieved': 5 * algo / t5 / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': 5 * algo / t5 / HBM_PEAK,
+                       'basis': 'per launch-equivalent: 5 x the algorithmic bytes of one severity (2 x 150528 B per image) / the duration of the '
+                                'five-severity launch; the launch itself moves 6/10 of those bytes (the source is read once)',
+                       'avg_launch_us': t5 * 1e6, 'launch_equivalent_us': t5 / 5 * 1e6, 'algorithmic_bytes_per_launch': 5 * algo,
+                       'bytes_moved_per_launch': moved,
+                       'against_bytes_moved': {'achieved': moved / t5 / 1e9, 'unit': 'GB/s', 'frac': moved / t5 / HBM_PEAK},
+                       'traffic': pmc_traffic('k_normal_noise_mfma_multi'),
+                       'timing': 'two events on the launch stream around 40 back-to-back launches / 40 (median of 3 passes), %d MB of rotating buffers' % ex['multi_buffers_mb'],
+                       'single_severity_launch_one_stream': single,
+                       'single_severity_launches_two_streams': {'avg_launch_us': ex['two_streams_s'] * 1e6, 'achieved': algo / ex['two_streams_s'] / 1e9,
+                                                                'unit': 'GB/s', 'frac': algo / ex['two_streams_s'] / HBM_PEAK}}
+                out['hbm_roofline_gaussian_noise'] = blk
+            else:
+                out['hbm_roofline_gaussian_noise'] = single
             step_flops = (5 + 15) * B * FLOP_FWD
             out['step_mfma'] = {'achieved': step_flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
                                 'note': 'whole-step algorithmic FLOPs (20 forward-equivalents) / step time'}

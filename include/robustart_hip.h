@@ -93,6 +93,15 @@ int rart_corrupt_u8(const uint8_t* in, uint8_t* out, int n, int h, int w,
                     const void* const* injected_host_array, int n_injected,
                     void* workspace, size_t workspace_bytes, rart_stream_t stream);
 
+/* gaussian_noise / speckle_noise at ns <= 8 (severity, seed) pairs of ONE source batch in one launch: every 1 KiB chunk is read once and
+ * written ns times, each output with its own field.  outs[i] is bit-identical to rart_corrupt_u8(in, outs[i], n, h, w, corruption_id,
+ * severities[i], seeds[i], sample_offset, NULL, 0, ...) with the native matrix-core generator.  ImageNet-C generation corrupts every
+ * image at five severities (imagenet_c/__init__.py:13-35 once per (image, severity)): five launches move 10 x the batch through HBM,
+ * this one 6 x.  outs: HOST array of ns device pointers.  RART_ERR_UNSUPPORTED unless h*w*3 % 1024 == 0 with 16-byte aligned
+ * buffers and the matrix-core generator selected (callers then issue ns rart_corrupt_u8 calls). */
+int rart_noise_multi_u8(const uint8_t* in, uint8_t* const* outs, int ns, int n, int h, int w, int corruption_id, const int* severities,
+                        const uint64_t* seeds, uint64_t sample_offset, rart_stream_t stream);
+
 /* ImageNet-S resize operators (imagenet_s_gen.py:19-34,127-166): Pillow's Image.resize((resize_w, resize_h), filter) on
  * uint8 NHWC images followed by a crop, bit-exact with Pillow (Resample.c 22-bit fixed point; Geometry.c for
  * NEAREST).  filter = PIL.Image constant: 0 nearest, 1 bilinear, 2 bicubic, 3 box, 4 hamming, 5 lanczos.
@@ -118,6 +127,9 @@ int rart_cv_resize_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int 
  * out_dtype : 0 = fp32, 1 = bf16.   out_layout : 0 = NCHW, 1 = NHWC. */
 int rart_u8_to_normalized(const uint8_t* in, void* out, int n, int h, int w,
                           int out_dtype, int out_layout, rart_stream_t stream);
+/* x01 fp32 NCHW = u8 NHWC / 255 (true division, bit-identical to torch's u8.permute(0, 3, 1, 2).float().div(255)): the hand-over from
+ * the uint8 images of the corruption kernels / datasets to the attack tensors (fp32 NCHW in [0,1], adv/attack.py:20-23) in one kernel. */
+int rart_u8_to_unit_f32_nchw(const uint8_t* in, float* out, int n, int h, int w, rart_stream_t stream);
 
 /* Fill helpers exposing the library's counter-based generator (used by the parity tests to
  * replay the native noise field on the host oracle, and by the attack random starts).
@@ -146,8 +158,12 @@ size_t rart_attack_workspace_bytes(int batch);
 /* x = clip(x0 + U(-eps, eps), lo, hi).  foolbox LinfPGD random start (adv/attack.py:20-23);
  * with clip_lo > clip_hi the clip is skipped = MIM start (Attacks/imfgsm_attack.py:73-74).
  * injected_u: NULL or fp32 U(-eps,eps) draws shaped like x. */
+/* row_samples (here and in the entries below that take it): NULL, or int64 [batch] on the device -- the GLOBAL sample index of every
+ * row.  Row b then draws at row_samples[b] instead of sample_offset + b: inside AutoAttack the sub-attacks receive the still-robust
+ * SUBSET of a batch (autoattack.py:117-136), and with its rows' own indices the draws of a sample do not depend on which other
+ * samples survived, i.e. on how the dataset is batched or sharded over GPUs. */
 int rart_attack_init_linf(float* x, const float* x0, int batch, size_t n_per_sample, float eps,
-                          float clip_lo, float clip_hi, uint64_t seed, uint64_t sample_offset,
+                          float clip_lo, float clip_hi, uint64_t seed, uint64_t sample_offset, const int64_t* row_samples,
                           const float* injected_u, rart_stream_t stream);
 
 /* x <- clip(x0 + clip(x + alpha*sign(g) - x0, -eps, eps), 0, 1): one fused PGD-Linf / FGSM step
@@ -167,7 +183,7 @@ int rart_pgd_step_l1(float* x, const float* g, const float* x0, int batch, size_
 /* ART random_sphere(norm=1) start: x = clip(x0 + r * s_i e_i / sum e, 0, 1), e ~ Exp(1), s = +-1, r = sqrt(U(0, eps^2)).
  * injected_signed_exp [batch][n] (s_i*e_i) and injected_radius [batch] replace the native draws (both or neither). */
 int rart_random_start_l1(float* x, const float* x0, int batch, size_t n_per_sample, float eps, uint64_t seed,
-                         uint64_t sample_offset, const float* injected_signed_exp, const float* injected_radius,
+                         uint64_t sample_offset, const int64_t* row_samples, const float* injected_signed_exp, const float* injected_radius,
                          void* workspace, size_t workspace_bytes, rart_stream_t stream);
 
 /* MIM step (Attacks/imfgsm_attack.py:85-90): g/=mean|g| per sample; m = decay*m + g;
@@ -181,7 +197,7 @@ int rart_mim_step(float* x, float* momentum, const float* g, const float* x0, in
  * x = clip(x0 + eps * t / (|t|_2 + 1e-12), 0, 1) for L2, t ~ N(0,1).
  * norm: 0 = Linf, 1 = L2.  injected_t: NULL or the fp32 draws.  workspace: rart_attack_workspace_bytes(batch). */
 int rart_apgd_init(float* x, const float* x0, int batch, size_t n_per_sample, int norm, float eps,
-                   uint64_t seed, uint64_t sample_offset, const float* injected_t,
+                   uint64_t seed, uint64_t sample_offset, const int64_t* row_samples, const float* injected_t,
                    void* workspace, size_t workspace_bytes, rart_stream_t stream);
 
 /* APGD step with momentum and double projection (autopgd_base.py:327-348).
@@ -197,7 +213,15 @@ int rart_apgd_step(float* x_adv, float* x_adv_old, const float* grad, const floa
  * Proposal: x_new = clamp(min(max(x_best + delta, x0-eps), x0+eps), 0, 1), delta = 2*eps*sign_host[ch] inside the
  * s x s window at (vh, vw), shared by the whole batch like the reference. */
 int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int h, int w, float eps, uint64_t seed,
-                          uint64_t sample_offset, const float* injected_sign, rart_stream_t stream);
+                          uint64_t sample_offset, const int64_t* row_samples, const float* injected_sign, rart_stream_t stream);
+/* out[b][j] = +1 / -1: the sign rows Square's L2 / L1 proposals multiply their windows with (square.py:343-345, 455-457), one per
+ * (image, channel), from the counter generator on the device: bit 31 of the first Threefry word of counter (index_base + j, stream_id) of
+ * row b's sample (the value noise/rng.py host_uniform(...) >= 0.5 gives).  Replaces a numpy draw + host-to-device copy per query.
+ * rart_rng_normal_rows_f32: rart_rng_normal_f32 for explicit rows (out[b][:] = the field of sample row_samples[b]). */
+int rart_rng_signs_f32(float* out, int batch, int n_per_row, uint64_t seed, uint64_t sample_offset, const int64_t* row_samples,
+                       int stream_id, uint32_t index_base, rart_stream_t stream);
+int rart_rng_normal_rows_f32(float* out, int batch, size_t elems, uint64_t seed, const int64_t* row_samples, int stream_id,
+                             rart_stream_t stream);
 int rart_square_propose_linf(float* x_new, const float* x_best, const float* x0, int batch, int c, int h, int w,
                              float eps, int vh, int vw, int s, const float* sign_host, rart_stream_t stream);
 

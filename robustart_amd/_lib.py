@@ -23,11 +23,14 @@ SIGNATURES = {
     'rart_corrupt_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'rart_corrupt_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_u64, c_u64,
                                 ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
+    'rart_noise_multi_u8': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
+                                    ctypes.POINTER(c_u64), c_u64, c_void_p]),
     'rart_pil_resize_workspace_bytes': (c_size_t, [c_int] * 10),
     'rart_pil_resize_u8': (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     'rart_cv_resize_workspace_bytes': (c_size_t, [c_int] * 10),
     'rart_cv_resize_u8': (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     'rart_u8_to_normalized': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_u8_to_unit_f32_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_rng_uniform_u32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),
     'rart_rng_normal_f32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_int, c_void_p]),
     'rart_set_normal_generator': (c_int, [c_int]),
@@ -35,22 +38,24 @@ SIGNATURES = {
     'rart_rng_noise_field_f32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_u64, c_void_p]),
     'rart_attack_workspace_bytes': (c_size_t, [c_int]),
     'rart_attack_init_linf': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, c_float, c_float,
-                                      c_u64, c_u64, c_void_p, c_void_p]),
+                                      c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
     'rart_pgd_step_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
     'rart_pgd_step_l2': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
                                  c_void_p, c_size_t, c_void_p]),
     'rart_pgd_step_l1': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
                                  c_void_p, c_size_t, c_void_p]),
-    'rart_random_start_l1': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, c_u64, c_u64, c_void_p, c_void_p,
+    'rart_random_start_l1': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, c_u64, c_u64, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
     'rart_mim_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_float, c_float,
                               c_float, c_void_p, c_size_t, c_void_p]),
-    'rart_apgd_init': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_int, c_float, c_u64, c_u64,
+    'rart_apgd_init': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_int, c_float, c_u64, c_u64, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     'rart_apgd_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int,
                                c_float, c_float, c_void_p, c_size_t, c_void_p]),
-    'rart_square_init_linf': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p,
+    'rart_square_init_linf': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p,
                                       c_void_p]),
+    'rart_rng_signs_f32': (c_int, [c_void_p, c_int, c_int, c_u64, c_u64, c_void_p, c_int, ctypes.c_uint32, c_void_p]),
+    'rart_rng_normal_rows_f32': (c_int, [c_void_p, c_int, c_size_t, c_u64, c_void_p, c_int, c_void_p]),
     'rart_square_propose_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
                                          c_int, c_void_p, c_void_p]),
     'rart_fab_project_linf': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),

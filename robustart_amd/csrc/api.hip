@@ -189,6 +189,20 @@ __global__ __launch_bounds__(kBlock) void k_u8_to_norm(const uint8_t* __restrict
     }
   }
 }
+// x01[n][c][h][w] = u8[n][h][w][c] / 255 (true division: bit-identical to torch's u8.permute(0, 3, 1, 2).float().div(255)): the attack
+// tensors are fp32 NCHW in [0,1] (adv/attack.py:20-23), the corruption kernels and datasets hand over uint8 NHWC.  Four pixels of one
+// channel per thread: 12 contiguous input bytes per 4 pixels are shared by the three channel threads through L1, stores are 16 bytes.
+__global__ __launch_bounds__(kBlock) void k_u8_to_unit_nchw(const uint8_t* __restrict__ in, float* __restrict__ out, uint32_t hw,
+                                                            uint32_t n) {
+  const uint32_t q = hw / 4;                             // host: hw % 4 == 0
+  const size_t total = (size_t)n * 3 * q;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const uint32_t p4 = (uint32_t)(i % q), c = (uint32_t)((i / q) % 3), img = (uint32_t)(i / ((size_t)3 * q));
+    const uint8_t* s = in + ((size_t)img * hw + (size_t)p4 * 4) * 3 + c;
+    const float4 v = make_float4((float)s[0] / 255.0f, (float)s[3] / 255.0f, (float)s[6] / 255.0f, (float)s[9] / 255.0f);
+    reinterpret_cast<float4*>(out)[((size_t)img * 3 + c) * q + p4] = v;
+  }
+}
 }  // namespace
 
 static dim3 fill_grid(uint32_t items, int n) {
@@ -244,6 +258,16 @@ int rart_u8_to_normalized(const uint8_t* in, void* out, int n, int h, int w, int
   else
     hipLaunchKernelGGL((k_u8_to_norm<uint16_t, true>), g, dim3(kBlock), 0, s, in, (uint16_t*)out, hw, (uint32_t)n);
   RART_CHECK_LAUNCH("rart_u8_to_normalized");
+  return RART_OK;
+}
+
+int rart_u8_to_unit_f32_nchw(const uint8_t* in, float* out, int n, int h, int w, rart_stream_t stream) {
+  g_err[0] = 0;
+  RART_CHECK_ARG(in && out && n > 0 && h > 0 && w > 0 && ((size_t)h * w) % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                 "rart_u8_to_unit_f32_nchw: h*w must be a multiple of 4 and the output 16-byte aligned");
+  hipLaunchKernelGGL(k_u8_to_unit_nchw, dim3(rart_grid_for((size_t)n * 3 * h * w / 4, kBlock, 256 * 16)), dim3(kBlock), 0,
+                     (hipStream_t)stream, in, out, (uint32_t)(h * w), (uint32_t)n);
+  RART_CHECK_LAUNCH("rart_u8_to_unit_f32_nchw");
   return RART_OK;
 }
 

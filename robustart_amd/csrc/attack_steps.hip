@@ -81,14 +81,22 @@ __device__ __forceinline__ float native_normal(uint32_t k0, uint32_t k1, size_t 
   return j == 0 ? z.x : (j == 1 ? z.y : (j == 2 ? z.z : z.w));
 }
 
+// Global sample index of batch row b: rows[b] when the caller passes the per-row index tensor (a still-robust SUBSET of a batch inside
+// AutoAttack: row k of the subset draws at its own sample's index, so the draws do not depend on how a dataset is batched or sharded),
+// else the contiguous sample_offset + b.
+__device__ __forceinline__ uint32_t row_sample(const int64_t* __restrict__ rows, uint32_t sbase, uint32_t b) {
+  return rows ? (uint32_t)rows[b] : row_sample(rows, sbase, b);
+}
+
 // ---- random starts -------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_init_linf(float* __restrict__ x, const float* __restrict__ x0,
                                                       size_t nps, float eps, float lo, float hi, uint32_t k0,
-                                                      uint32_t k1, uint32_t sbase, const float* __restrict__ inj) {
+                                                      uint32_t k1, uint32_t sbase, const float* __restrict__ inj,
+                                                      const int64_t* __restrict__ rows) {
   const uint32_t b = blockIdx.y;
   const size_t base = (size_t)b * nps;
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
-    const float u = inj ? inj[base + e] : eps * native_pm1(k0, k1, e, sbase + b);
+    const float u = inj ? inj[base + e] : eps * native_pm1(k0, k1, e, row_sample(rows, sbase, b));
     float v = x0[base + e] + u;
     if (lo <= hi) v = clampf(v, lo, hi);
     x[base + e] = v;
@@ -99,14 +107,14 @@ __global__ __launch_bounds__(kBlock) void k_init_linf(float* __restrict__ x, con
 template <int NORM>
 __global__ __launch_bounds__(kBlock) void k_apgd_init_reduce(float* __restrict__ part, size_t nps, uint32_t k0,
                                                              uint32_t k1, uint32_t sbase,
-                                                             const float* __restrict__ inj) {
+                                                             const float* __restrict__ inj, const int64_t* __restrict__ rows) {
   __shared__ float sh[kBlock / 64];
   const uint32_t b = blockIdx.y;
   const Chunk c = chunk_of(nps);
   float acc = 0.f;
   for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
     const float t = inj ? inj[(size_t)b * nps + e]
-                        : (NORM == 0 ? native_pm1(k0, k1, e, sbase + b) : native_normal(k0, k1, e, sbase + b));
+                        : (NORM == 0 ? native_pm1(k0, k1, e, row_sample(rows, sbase, b)) : native_normal(k0, k1, e, row_sample(rows, sbase, b)));
     acc = NORM == 0 ? fmaxf(acc, fabsf(t)) : acc + t * t;
   }
   const float r = NORM == 0 ? block_max(acc, sh) : block_sum(acc, sh);
@@ -116,14 +124,14 @@ template <int NORM>
 __global__ __launch_bounds__(kBlock) void k_apgd_init_apply(float* __restrict__ x, const float* __restrict__ x0,
                                                             const float* __restrict__ part, size_t nps, float eps,
                                                             uint32_t k0, uint32_t k1, uint32_t sbase,
-                                                            const float* __restrict__ inj) {
+                                                            const float* __restrict__ inj, const int64_t* __restrict__ rows) {
   const uint32_t b = blockIdx.y;
   const float red = NORM == 0 ? max_partials(part + (size_t)b * RCH) : sqrtf(sum_partials(part + (size_t)b * RCH));
   const float denom = red + 1e-12f;
   const size_t base = (size_t)b * nps;
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
     const float t = inj ? inj[base + e]
-                        : (NORM == 0 ? native_pm1(k0, k1, e, sbase + b) : native_normal(k0, k1, e, sbase + b));
+                        : (NORM == 0 ? native_pm1(k0, k1, e, row_sample(rows, sbase, b)) : native_normal(k0, k1, e, row_sample(rows, sbase, b)));
     const float tn = t / denom;
     const float v = x0[base + e] + eps * tn;  // eps * ones_like(x) * normalize(t)
     x[base + e] = clampf(v, 0.f, 1.f);
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_pgd_l1_project(float* __restrict__ x
 // draws, which is how they are formed here (no 150 527-key sort per sample).  injected: [batch][nps] signed
 // exponentials (sign * e_i) and injected_r[batch] radii for the parity tests.
 __global__ __launch_bounds__(kBlock) void k_l1_start_reduce(float* __restrict__ part, size_t nps, uint32_t k0, uint32_t k1,
-                                                            uint32_t sbase, const float* __restrict__ inj) {
+                                                            uint32_t sbase, const float* __restrict__ inj, const int64_t* __restrict__ rows) {
   __shared__ float sh[kBlock / 64];
   const uint32_t b = blockIdx.y;
   const Chunk c = chunk_of(nps);
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_l1_start_reduce(float* __restrict__ 
     float v;
     if (inj) v = fabsf(inj[(size_t)b * nps + e]);
     else {
-      const uint2 w = threefry2x32(k0, k1, rart_ctr0((uint32_t)e, 5), sbase + b);
+      const uint2 w = threefry2x32(k0, k1, rart_ctr0((uint32_t)e, 5), row_sample(rows, sbase, b));
       v = -logf(u01(w.x));
     }
     acc += v;
@@ -266,12 +274,13 @@ __global__ __launch_bounds__(kBlock) void k_l1_start_reduce(float* __restrict__ 
 __global__ __launch_bounds__(kBlock) void k_l1_start_apply(float* __restrict__ x, const float* __restrict__ x0,
                                                            const float* __restrict__ part, size_t nps, float eps,
                                                            uint32_t k0, uint32_t k1, uint32_t sbase,
-                                                           const float* __restrict__ inj, const float* __restrict__ inj_r) {
+                                                           const float* __restrict__ inj, const float* __restrict__ inj_r,
+                                                           const int64_t* __restrict__ rows) {
   const uint32_t b = blockIdx.y;
   float r;
   if (inj_r) r = inj_r[b];
   else {
-    const uint2 w = threefry2x32(k0, k1, rart_ctr0(0xFFFFFFFu, 5), sbase + b);
+    const uint2 w = threefry2x32(k0, k1, rart_ctr0(0xFFFFFFFu, 5), row_sample(rows, sbase, b));
     r = sqrtf(u01(w.y) * eps * eps);
   }
   const float scale = r / sum_partials(part + (size_t)b * RCH);
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_l1_start_apply(float* __restrict__ x
     float v;
     if (inj) v = inj[base + e];
     else {
-      const uint2 w = threefry2x32(k0, k1, rart_ctr0((uint32_t)e, 5), sbase + b);
+      const uint2 w = threefry2x32(k0, k1, rart_ctr0((uint32_t)e, 5), row_sample(rows, sbase, b));
       v = -logf(u01(w.x));
       if (w.y & 1u) v = -v;
     }
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void k_select_rows(float* __restrict__ dst,
 // start: x_best = clamp(x + eps * sign_stripes[b][c][w], 0, 1) (one sign per image column and channel)
 __global__ __launch_bounds__(kBlock) void k_square_init(float* __restrict__ xb, const float* __restrict__ x0, int C,
                                                         int H, int W, float eps, uint32_t k0, uint32_t k1,
-                                                        uint32_t sbase, const float* __restrict__ inj) {
+                                                        uint32_t sbase, const float* __restrict__ inj, const int64_t* __restrict__ rows) {
   const uint32_t b = blockIdx.y;
   const size_t nps = (size_t)C * H * W;
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_square_init(float* __restrict__ xb, 
     if (inj) {
       sg = inj[((size_t)b * C + c) * W + w];
     } else {
-      const uint2 wv = threefry2x32(k0, k1, rart_ctr0((uint32_t)(c * W + w), 3), sbase + b);
+      const uint2 wv = threefry2x32(k0, k1, rart_ctr0((uint32_t)(c * W + w), 3), row_sample(rows, sbase, b));
       sg = (wv.x & 1u) ? 1.f : -1.f;
     }
     xb[b * nps + e] = clampf(x0[b * nps + e] + eps * sg, 0.f, 1.f);
@@ -1202,15 +1211,65 @@ int need_ws(const char* who, void* ws, size_t have, size_t floats) {
 }
 }  // namespace
 
+namespace {
+// out[b][j] = +1 / -1 from bit 31 of the first Threefry word of counter (index_base + j, stream_id) of row b's sample: the value
+// noise/rng.py's host_uniform(seed, sample, stream_id, index_base + j) >= 0.5 gives, generated where it is consumed (Square's per-image
+// sign rows: 5 000 queries used to draw them in numpy and copy them to the device every query)
+__global__ __launch_bounds__(kBlock) void k_rng_signs(float* __restrict__ out, int batch, int n, uint32_t k0, uint32_t k1, uint32_t sbase,
+                                                      const int64_t* __restrict__ rows, int stream_id, uint32_t index_base) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= batch * n) return;
+  const uint32_t b = (uint32_t)(i / n), j = (uint32_t)(i - (int)b * n);
+  const uint2 w = threefry2x32(k0, k1, rart_ctr0(index_base + j, stream_id), rows ? (uint32_t)rows[b] : sbase + b);
+  out[i] = (w.x >> 31) ? 1.f : -1.f;
+}
+// standard normals for explicit rows: out[b][e] = the value rart_rng_normal_f32 gives sample rows[b] (four per Threefry pair)
+__global__ __launch_bounds__(kBlock) void k_rng_normal_rows(float* __restrict__ out, uint32_t elems, uint32_t k0, uint32_t k1,
+                                                            const int64_t* __restrict__ rows, int stream_id) {
+  const uint32_t b = blockIdx.y, smp = (uint32_t)rows[b];
+  float* o = out + (size_t)b * elems;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v * 4 < elems; v += gridDim.x * kBlock) {
+    const float4 z = rart_normal4(k0, k1, v, stream_id, smp);
+    const float zz[4] = {z.x, z.y, z.z, z.w};
+    for (int j = 0; j < 4; ++j)
+      if (v * 4 + j < elems) o[v * 4 + j] = zz[j];
+  }
+}
+}  // namespace
+
 extern "C" {
 
 size_t rart_attack_workspace_bytes(int batch) { return (size_t)(batch < 1 ? 1 : batch) * RCH * 4 * sizeof(float); }
 
+int rart_rng_signs_f32(float* out, int batch, int n_per_row, uint64_t seed, uint64_t sample_offset, const int64_t* row_samples,
+                       int stream_id, uint32_t index_base, rart_stream_t stream) {
+  RART_CHECK_ARG(out && batch > 0 && n_per_row > 0 && (long long)batch * n_per_row < (1ll << 31) && stream_id >= 0 && stream_id < 16,
+                 "rart_rng_signs_f32: bad arguments");
+  hipLaunchKernelGGL(k_rng_signs, dim3((batch * n_per_row + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, out, batch,
+                     n_per_row, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset, row_samples, stream_id, index_base);
+  RART_CHECK_LAUNCH("rart_rng_signs_f32");
+  return RART_OK;
+}
+
+int rart_rng_normal_rows_f32(float* out, int batch, size_t elems, uint64_t seed, const int64_t* row_samples, int stream_id,
+                             rart_stream_t stream) {
+  RART_CHECK_ARG(out && row_samples && batch > 0 && batch <= 65535 && elems > 0 && elems < (1ull << 30) && stream_id >= 0 && stream_id < 16,
+                 "rart_rng_normal_rows_f32: bad arguments");
+  uint32_t gx = (uint32_t)((elems + 3) / 4 + kBlock - 1) / kBlock;
+  const uint32_t cap = (uint32_t)(2048 / batch) < 1 ? 1 : (uint32_t)(2048 / batch);
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(k_rng_normal_rows, dim3(gx, batch), dim3(kBlock), 0, (hipStream_t)stream, out, (uint32_t)elems, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), row_samples, stream_id);
+  RART_CHECK_LAUNCH("rart_rng_normal_rows_f32");
+  return RART_OK;
+}
+
 int rart_attack_init_linf(float* x, const float* x0, int batch, size_t nps, float eps, float lo, float hi,
-                          uint64_t seed, uint64_t sample_offset, const float* injected_u, rart_stream_t stream) {
+                          uint64_t seed, uint64_t sample_offset, const int64_t* row_samples, const float* injected_u,
+                          rart_stream_t stream) {
   RART_CHECK_ARG(x && x0 && batch > 0 && nps > 0 && nps < (1ull << 29), "rart_attack_init_linf: bad arguments");
   hipLaunchKernelGGL(k_init_linf, grid_rows(nps, batch), dim3(kBlock), 0, (hipStream_t)stream, x, x0, nps, eps, lo,
-                     hi, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset, injected_u);
+                     hi, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset, injected_u, row_samples);
   RART_CHECK_LAUNCH("rart_attack_init_linf");
   return RART_OK;
 }
@@ -1262,7 +1321,7 @@ int rart_pgd_step_l1(float* x, const float* g, const float* x0, int batch, size_
 }
 
 int rart_random_start_l1(float* x, const float* x0, int batch, size_t nps, float eps, uint64_t seed, uint64_t sample_offset,
-                         const float* injected_signed_exp, const float* injected_radius, void* ws, size_t ws_bytes,
+                         const int64_t* row_samples, const float* injected_signed_exp, const float* injected_radius, void* ws, size_t ws_bytes,
                          rart_stream_t stream) {
   RART_CHECK_ARG(x && x0 && batch > 0 && nps > 0 && nps < (1ull << 28) - 1, "rart_random_start_l1: bad arguments");
   RART_CHECK_ARG((injected_signed_exp == nullptr) == (injected_radius == nullptr),
@@ -1270,9 +1329,10 @@ int rart_random_start_l1(float* x, const float* x0, int batch, size_t nps, float
   if (int e = need_ws("rart_random_start_l1", ws, ws_bytes, (size_t)batch * RCH)) return e;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), sb = (uint32_t)sample_offset;
-  hipLaunchKernelGGL(k_l1_start_reduce, dim3(RCH, batch), dim3(kBlock), 0, s, (float*)ws, nps, k0, k1, sb, injected_signed_exp);
+  hipLaunchKernelGGL(k_l1_start_reduce, dim3(RCH, batch), dim3(kBlock), 0, s, (float*)ws, nps, k0, k1, sb, injected_signed_exp,
+                     row_samples);
   hipLaunchKernelGGL(k_l1_start_apply, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, (const float*)ws, nps, eps, k0, k1,
-                     sb, injected_signed_exp, injected_radius);
+                     sb, injected_signed_exp, injected_radius, row_samples);
   RART_CHECK_LAUNCH("rart_random_start_l1");
   return RART_OK;
 }
@@ -1290,7 +1350,8 @@ int rart_mim_step(float* x, float* m, const float* g, const float* x0, int batch
 }
 
 int rart_apgd_init(float* x, const float* x0, int batch, size_t nps, int norm, float eps, uint64_t seed,
-                   uint64_t sample_offset, const float* inj, void* ws, size_t ws_bytes, rart_stream_t stream) {
+                   uint64_t sample_offset, const int64_t* row_samples, const float* inj, void* ws, size_t ws_bytes,
+                   rart_stream_t stream) {
   RART_CHECK_ARG(x && x0 && batch > 0 && nps > 0 && nps < (1ull << 29), "rart_apgd_init: bad arguments");
   RART_CHECK_ARG(norm == 0 || norm == 1, "rart_apgd_init: norm must be 0 (Linf) or 1 (L2)");
   if (int e = need_ws("rart_apgd_init", ws, ws_bytes, (size_t)batch * RCH)) return e;
@@ -1298,13 +1359,13 @@ int rart_apgd_init(float* x, const float* x0, int batch, size_t nps, int norm, f
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), sb = (uint32_t)sample_offset;
   float* part = (float*)ws;
   if (norm == 0) {
-    hipLaunchKernelGGL(k_apgd_init_reduce<0>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj);
+    hipLaunchKernelGGL(k_apgd_init_reduce<0>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj, row_samples);
     hipLaunchKernelGGL(k_apgd_init_apply<0>, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, part, nps, eps, k0,
-                       k1, sb, inj);
+                       k1, sb, inj, row_samples);
   } else {
-    hipLaunchKernelGGL(k_apgd_init_reduce<1>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj);
+    hipLaunchKernelGGL(k_apgd_init_reduce<1>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj, row_samples);
     hipLaunchKernelGGL(k_apgd_init_apply<1>, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, part, nps, eps, k0,
-                       k1, sb, inj);
+                       k1, sb, inj, row_samples);
   }
   RART_CHECK_LAUNCH("rart_apgd_init");
   return RART_OK;
@@ -1330,10 +1391,10 @@ int rart_apgd_step(float* xa, float* xold, const float* grad, const float* x0, c
 }
 
 int rart_square_init_linf(float* x_best, const float* x0, int batch, int c, int h, int w, float eps, uint64_t seed,
-                          uint64_t sample_offset, const float* injected_sign, rart_stream_t stream) {
+                          uint64_t sample_offset, const int64_t* row_samples, const float* injected_sign, rart_stream_t stream) {
   RART_CHECK_ARG(x_best && x0 && batch > 0 && c > 0 && h > 0 && w > 0, "rart_square_init_linf: bad arguments");
   hipLaunchKernelGGL(k_square_init, grid_rows((size_t)c * h * w, batch), dim3(kBlock), 0, (hipStream_t)stream, x_best,
-                     x0, c, h, w, eps, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset, injected_sign);
+                     x0, c, h, w, eps, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset, injected_sign, row_samples);
   RART_CHECK_LAUNCH("rart_square_init_linf");
   return RART_OK;
 }

@@ -199,6 +199,53 @@ __global__ __launch_bounds__(kBlock) void k_normal_noise_mfma(const uint4* __res
   out[(size_t)g * 64 + lane] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
 }
 
+// Several severities (or, generally, several (scale, seed) draws) of ONE source batch in one launch: a wave reads its 1 KiB chunk once and
+// writes `ns` outputs, each with its own field -- output i is bit-identical to k_normal_noise_mfma launched with (c[i], seed i) on the
+// same input.  ImageNet-C generation corrupts every image at five severities (imagenet_c/__init__.py:13-35 is called once per (image,
+// severity) by the generation scripts): five launches move 10 x the batch through HBM, this one 6 x, and a wave that lives five times as
+// long amortises the launch ramp / tail that bounds the 16 us single-severity launch at B = 256.
+struct NoiseMultiArgs {
+  uint4* out[8];
+  float c[8];
+  uint32_t k0[8], k1[8];
+  int ns;
+};
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_normal_noise_mfma_multi(const uint4* __restrict__ in, const NoiseMultiArgs m,
+                                                                    uint32_t chunks_per_sample, uint32_t total_chunks,
+                                                                    uint32_t sample_base, uint32_t cps_magic, uint32_t cps_shift) {
+  __builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 3);        // hwreg(HW_REG_MODE, 0, 2): single-precision rounding = toward zero
+  const int lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (g >= total_chunks) return;                                // wave-uniform
+  const uint4 cur = in[(size_t)g * 64 + lane];
+  const i32x4 hb = clt_hadamard_operand(lane);
+  const uint32_t sample = (uint32_t)(((uint64_t)g * cps_magic) >> cps_shift), chunk = g - sample * chunks_per_sample;
+  const uint32_t wi[4] = {cur.x, cur.y, cur.z, cur.w};
+  for (int i = 0; i < m.ns; ++i) {
+    const float gsc = KIND == 0 ? 255.0f * m.c[i] : m.c[i];
+    const float ga = gsc * kCltA, gb = gsc * kCltB;
+    const f32x2 ga2 = {ga, ga}, gb2 = {gb, gb};
+    float s[16];
+    clt_sums16(m.k0[i], m.k1[i], chunk, sample_base + sample, lane, hb, s);
+    uint32_t wo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 y[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x2 x = {(float)((wi[j] >> (16 * hh)) & 0xFFu), (float)((wi[j] >> (16 * hh + 8)) & 0xFFu)};
+        const f32x2 sv = {s[j * 4 + 2 * hh], s[j * 4 + 2 * hh + 1]};
+        f32x2 t = __builtin_elementwise_fma(gb2, sv * sv, ga2);   // g * (A + B s^2)
+        if (KIND == 1) t = t * x;                                  // speckle: x + x*c*z
+        y[hh] = __builtin_elementwise_fma(t, sv, x);
+      }
+      wo[j] = pack4_sat(y[0].x, y[0].y, y[1].x, y[1].y);
+    }
+    m.out[i][(size_t)g * 64 + lane] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+  }
+}
+
 // replay of the field for the parity tests: z[sample][element] exactly as the kernel above forms it
 __global__ __launch_bounds__(kBlock) void k_clt_field(float* __restrict__ out, uint32_t vec_per_sample, uint32_t k0,
                                                       uint32_t k1, uint32_t sample_base) {
@@ -826,4 +873,44 @@ extern "C" int rart_rng_noise_field_f32(float* out, int n_samples, size_t elems,
     return RART_OK;
   }
   return rart_rng_normal_f32(out, n_samples, elems, seed, sample_offset, 0, stream);
+}
+
+
+// gaussian_noise / speckle_noise at `ns` (severity, seed) pairs of ONE source batch in one launch (k_normal_noise_mfma_multi):
+// outs[i] is bit-identical to rart_corrupt_u8(in, outs[i], ..., corruption_id, severities[i], seeds[i], sample_offset) with the native
+// matrix-core generator.  Needs h*w*3 a multiple of 1024 and 16-byte aligned buffers (no other path: callers fall back to ns launches).
+extern "C" int rart_noise_multi_u8(const uint8_t* in, uint8_t* const* outs, int ns, int n, int h, int w, int corruption_id,
+                                   const int* severities, const uint64_t* seeds, uint64_t sample_offset, rart_stream_t stream) {
+  RART_CHECK_ARG(in && outs && severities && seeds && ns >= 1 && ns <= 8 && n > 0 && h > 0 && w > 0, "rart_noise_multi_u8: bad arguments (1..8 outputs)");
+  RART_CHECK_ARG(corruption_id == RART_GAUSSIAN_NOISE || corruption_id == RART_SPECKLE_NOISE, "rart_noise_multi_u8: gaussian_noise / speckle_noise only");
+  const size_t eps = (size_t)h * w * 3;
+  if (g_normal_generator != 1 || eps % 1024 != 0 || (reinterpret_cast<uintptr_t>(in) & 15)) {
+    rart_set_error("rart_noise_multi_u8: needs the matrix-core generator, h*w*3 %% 1024 == 0 and 16-byte aligned buffers");
+    return RART_ERR_UNSUPPORTED;
+  }
+  NoiseMultiArgs m;
+  m.ns = ns;
+  for (int i = 0; i < 8; ++i) { m.out[i] = nullptr; m.c[i] = 0.f; m.k0[i] = m.k1[i] = 0; }
+  for (int i = 0; i < ns; ++i) {
+    RART_CHECK_ARG(outs[i] && !(reinterpret_cast<uintptr_t>(outs[i]) & 15) && outs[i] != in, "rart_noise_multi_u8: outputs must be 16-byte aligned and distinct from the input");
+    RART_CHECK_ARG(severities[i] >= 1 && severities[i] <= 5, "rart_noise_multi_u8: severity must be 1..5");
+    m.out[i] = (uint4*)outs[i];
+    m.c[i] = (float)(corruption_id == RART_GAUSSIAN_NOISE ? RartSeverity::gaussian_noise[severities[i] - 1] : RartSeverity::speckle_noise[severities[i] - 1]);
+    m.k0[i] = (uint32_t)seeds[i];
+    m.k1[i] = (uint32_t)(seeds[i] >> 32);
+  }
+  const uint32_t cps = (uint32_t)(eps / 1024), total = cps * (uint32_t)n;
+  RART_CHECK_ARG((unsigned long long)cps * (unsigned long long)n < (1ull << 31), "rart_noise_multi_u8: too many 1 KiB chunks per call");
+  uint32_t lg = 0;
+  while ((1ull << lg) < cps) ++lg;
+  const uint32_t cshift = 31 + lg, cmagic = (uint32_t)(((1ull << cshift) + cps - 1) / cps);
+  const dim3 g((total + kBlock / 64 - 1) / (kBlock / 64));
+  if (corruption_id == RART_GAUSSIAN_NOISE)
+    hipLaunchKernelGGL(k_normal_noise_mfma_multi<0>, g, dim3(kBlock), 0, (hipStream_t)stream, (const uint4*)in, m, cps, total,
+                       (uint32_t)sample_offset, cmagic, cshift);
+  else
+    hipLaunchKernelGGL(k_normal_noise_mfma_multi<1>, g, dim3(kBlock), 0, (hipStream_t)stream, (const uint4*)in, m, cps, total,
+                       (uint32_t)sample_offset, cmagic, cshift);
+  RART_CHECK_LAUNCH("rart_noise_multi_u8");
+  return RART_OK;
 }

@@ -503,8 +503,11 @@ class ResNet50Engine:
             finally:
                 self.profile = prof
             e1.record()
+            # 5th element: ALGORITHMIC HBM bytes of the launch -- x in, out, the weight tables once, the 1-bit sign tensors
+            m_ = B * hw[0] * hw[1]
+            by = 2 * m_ * c_io * 2 + (2 * c_io * c_mid + 9 * c_mid * c_mid) * 2 + sum(m_ * c // 8 for c, t in ((c_mid, m1), (c_mid, m2), (c_io, m3)) if t is not None)
             self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * (2 * c_io + 9 * c_mid), e0, e1,
-                                 {14: 'bottleneck14', 28: 'bottleneck28', 7: 'bottleneck7'}[hw[0]]))
+                                 {14: 'bottleneck14', 28: 'bottleneck28', 7: 'bottleneck7'}[hw[0]], by))
             return
         _lib.check(fn(
             _lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(m1),
@@ -575,7 +578,12 @@ class ResNet50Engine:
                 self.profile = prof
             e1.record()
             k_all = (2 * c_io + 9 * c_mid) if w4 is None else (c_in + 9 * c_mid + c_io + c_in * c_io // c_mid)
-            self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * k_all, e0, e1, 'bottleneck'))
+            # 5th element: ALGORITHMIC HBM bytes of the launch -- x in (read ONCE: the residual re-read and the halo rows are
+            # implementation traffic), out, the weight tables once, the 1-bit sign tensors
+            m_, cin_ = B * hw[0] * hw[1], (c_io if w4 is None else c_in)
+            by = m_ * (c_io + cin_) * 2 + ((c_io + cin_) * c_mid + 9 * c_mid * c_mid + (0 if w4 is None else c_in * c_io)) * 2 + \
+                sum(m_ * c // 8 for c, t in ((c_mid, m1), (c_mid, m2), (c_io if not backward else cin_, m3)) if t is not None)
+            self.profile.append((2.0 * B * hw[0] * hw[1] * c_mid * k_all, e0, e1, 'bottleneck', by))
             return
         if w4 is not None:
             _lib.check(self.lib.rart_bottleneck_first_bf16(

@@ -57,8 +57,9 @@ def attack_init_linf(x0, eps, clip=True, seed=None, sample_offset=0, injected_u=
     B = x0.shape[0]
     nps = x0[0].numel()
     lo, hi = (0.0, 1.0) if clip else (1.0, 0.0)
+    off, rows = _rows(sample_offset)
     _lib.check(_lib.load().rart_attack_init_linf(_lib.ptr(x), _lib.ptr(x0), B, nps, float(eps), lo, hi,
-                                                 _seed(seed), sample_offset, _lib.ptr(injected_u), _lib.stream_ptr()))
+                                                 _seed(seed), off, _lib.ptr(rows), _lib.ptr(injected_u), _lib.stream_ptr()))
     return x
 
 
@@ -93,8 +94,9 @@ def random_start_l1(x0, eps, seed=None, sample_offset=0, init_signed_exp=None, i
     if init_signed_exp is not None:
         init_signed_exp = init_signed_exp.to(x0.device, torch.float32).contiguous()
         init_radius = init_radius.to(x0.device, torch.float32).contiguous()
+    off, rows = _rows(sample_offset)
     _lib.check(_lib.load().rart_random_start_l1(_lib.ptr(x), _lib.ptr(x0), B, x0[0].numel(), float(eps), _seed(seed),
-                                                sample_offset, _lib.ptr(init_signed_exp), _lib.ptr(init_radius),
+                                                off, _lib.ptr(rows), _lib.ptr(init_signed_exp), _lib.ptr(init_radius),
                                                 _lib.ptr(ws), nb, _lib.stream_ptr()))
     return x
 
@@ -113,8 +115,9 @@ def apgd_init(x0, norm, eps, seed=None, sample_offset=0, injected_t=None):
     x = torch.empty_like(x0)
     B = x0.shape[0]
     ws, nb = _ws(B, x0.device)
+    off, rows = _rows(sample_offset)
     _lib.check(_lib.load().rart_apgd_init(_lib.ptr(x), _lib.ptr(x0), B, x0[0].numel(), 0 if norm == 'Linf' else 1,
-                                          float(eps), _seed(seed), sample_offset, _lib.ptr(injected_t),
+                                          float(eps), _seed(seed), off, _lib.ptr(rows), _lib.ptr(injected_t),
                                           _lib.ptr(ws), nb, _lib.stream_ptr()))
     return x
 
@@ -140,11 +143,31 @@ def _seed(seed):
     return _rng.current_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
+def _rows(sample_offset):
+    """sample_offset as the C-ABI takes it: (contiguous offset, per-row index tensor or None).  An int means rows
+    sample_offset .. sample_offset + B - 1; an int64 tensor [B] names every row's GLOBAL sample index (the still-robust subsets
+    inside AutoAttack: a sample's draws must not depend on which other samples survived)."""
+    torch = _lib.require_gpu()
+    if torch.is_tensor(sample_offset):
+        return 0, sample_offset.to(torch.int64).contiguous()
+    return int(sample_offset), None
+
+
+def _row_tensor(sample_offset, n, device):
+    """the global sample index of each of n rows as an int64 device tensor (from a contiguous offset or already a tensor)"""
+    torch = _lib.require_gpu()
+    if torch.is_tensor(sample_offset):
+        return sample_offset.to(device=device, dtype=torch.int64).contiguous()
+    return int(sample_offset) + torch.arange(n, dtype=torch.int64, device=device)
+
+
 def _offset(sample_offset, n):
     """Global index of the call's first sample.  None (the AddNoise.add_noise path) advances the process-wide sample
     counter of noise/rng.py by n, exactly as corrupt_batch_ does: consecutive calls draw fresh random starts (the
     reference draws from torch's global generator per call) and the draws do not depend on how a dataset is batched;
     an explicit offset (solver / bench: the dataset index of the first image) pins them."""
+    if sample_offset is not None and not isinstance(sample_offset, int) and hasattr(sample_offset, 'dtype'):
+        return sample_offset                      # a per-row index tensor passes through
     return _rng.next_offset(n) if sample_offset is None else int(sample_offset)
 
 
@@ -360,7 +383,7 @@ def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce'
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
     kind = {'ce': LOSS_CE, 'dlr': LOSS_DLR}[loss]
-    sample_offset = _offset(sample_offset, x.shape[0])
+    rows = _row_tensor(_offset(sample_offset, x.shape[0]), x.shape[0], x.device)      # every row's global sample index
     y_pred = prov.logits(x).max(1)[1]
     adv = x.clone()
     acc = y_pred == y
@@ -370,7 +393,7 @@ def apgd_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, loss='ce'
             x_f, y_f = x[ind_to_fool].contiguous(), y[ind_to_fool].contiguous()
             t = _injected_start(init_ts, counter, x_f)
             _, acc_curr, _, adv_curr = _apgd_single_run(prov, x_f, y_f, norm, eps, n_iter, kind, None, 0.75,
-                                                        _seed(seed) + counter, sample_offset, t, eot_iter)
+                                                        _seed(seed) + counter, rows[ind_to_fool], t, eot_iter)
             ind_curr = (~acc_curr).nonzero().flatten()
             acc[ind_to_fool[ind_curr]] = False
             adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr]
@@ -383,7 +406,7 @@ def apgd_targeted_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, 
     torch = _lib.require_gpu()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
-    sample_offset = _offset(sample_offset, x.shape[0])
+    rows = _row_tensor(_offset(sample_offset, x.shape[0]), x.shape[0], x.device)
     y_pred = prov.logits(x).max(1)[1]
     adv = x.clone()
     acc = y_pred == y
@@ -395,7 +418,7 @@ def apgd_targeted_perturb(model_fn, x, y, norm='Linf', eps=8 / 255, n_iter=100, 
             y_target = output.sort(dim=1)[1][:, -target_class]
             t = _injected_start(init_ts, j, x_f)
             _, acc_curr, _, adv_curr = _apgd_single_run(prov, x_f, y_f, norm, eps, n_iter, LOSS_DLR_TARGETED,
-                                                        y_target, 0.75, _seed(seed) + 100 + j, sample_offset, t)
+                                                        y_target, 0.75, _seed(seed) + 100 + j, rows[ind_to_fool], t)
             ind_curr = (~acc_curr).nonzero().flatten()
             acc[ind_to_fool[ind_curr]] = False
             adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr]
@@ -426,6 +449,18 @@ def _row_count_diff(a, b):
     return out
 
 
+def _normal_rows(out, seed, sample_offset, stream_id):
+    """standard normals [B][...] of the counter generator for a contiguous offset or a per-row index tensor"""
+    lib = _lib.load()
+    off, rows = _rows(sample_offset)
+    if rows is None:
+        _lib.check(lib.rart_rng_normal_f32(_lib.ptr(out), out.shape[0], out[0].numel(), seed, off, stream_id, _lib.stream_ptr()))
+    else:
+        _lib.check(lib.rart_rng_normal_rows_f32(_lib.ptr(out), out.shape[0], out[0].numel(), seed, _lib.ptr(rows), stream_id,
+                                                _lib.stream_ptr()))
+    return out
+
+
 def _apgd_l1_single_run(prov, x, y, eps, n_iter, loss_kind, y_target=None, init_t=None, x_init=None, seed=None,
                         sample_offset=0):
     """attack_single_run, norm 'L1' (autopgd_base.py:208-448).  Heavy tensors move only through HIP kernels
@@ -437,7 +472,7 @@ def _apgd_l1_single_run(prov, x, y, eps, n_iter, loss_kind, y_target=None, init_
     if x_init is None:
         if init_t is None:
             init_t = torch.empty_like(x)
-            _lib.check(lib.rart_rng_normal_f32(_lib.ptr(init_t), B, n_fts, _seed(seed), sample_offset, 5, sp()))
+            _normal_rows(init_t, _seed(seed), sample_offset, 5)
         x_adv = l1_projection(x, init_t, eps, point_out=True, clamp01=True)           # :222-226, :237
     else:
         x_adv = x_init.clamp(0.0, 1.0).contiguous()
@@ -511,7 +546,7 @@ def apgd_l1_perturb(model_fn, x, y, eps=12.0, n_iter=100, loss='ce', n_restarts=
     torch = _lib.require_gpu()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
-    sample_offset = _offset(sample_offset, x.shape[0])
+    rows = _row_tensor(_offset(sample_offset, x.shape[0]), x.shape[0], x.device)
     adv = x.clone()
     acc = prov.logits(x).max(1)[1] == y
     targeted = n_target_classes > 0
@@ -527,8 +562,7 @@ def apgd_l1_perturb(model_fn, x, y, eps=12.0, n_iter=100, loss='ce', n_restarts=
             noise = draws(j, tuple(xs.shape)).to(xs.device, torch.float32).contiguous()
         else:
             noise = torch.empty_like(xs)
-            _lib.check(_lib.load().rart_rng_normal_f32(_lib.ptr(noise), xs.shape[0], xs[0].numel(), _seed(seed) + 7919 * j,
-                                                       sample_offset, 5, _lib.stream_ptr()))
+            _normal_rows(noise, _seed(seed) + 7919 * j, rows[ind], 5)
         if use_largereps:
             _, acc_curr, _, adv_curr = _apgd_l1_decr_eps(prov, xs, ys, eps, n_iter, kind, y_target, noise)
         else:
@@ -563,20 +597,21 @@ def square_perturb(model_fn, x, y, eps=8 / 255, n_queries=5000, p_init=0.8, resc
     lib = _lib.load()
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
-    sample_offset = _offset(sample_offset, x.shape[0])
+    rows = _row_tensor(_offset(sample_offset, x.shape[0]), x.shape[0], x.device)
     adv = x.clone()
     acc = prov.logits(x).max(1)[1] == y
     ind = acc.nonzero().flatten()
     if ind.numel() == 0:
         return adv
     x0, yy = x[ind].contiguous(), y[ind].contiguous()
+    rows0 = rows[ind].contiguous()                 # the start signs of an image are drawn at ITS index, whoever else is still robust
     B, C, H, W = x0.shape
     sd = _seed(seed)
     x_best = torch.empty_like(x0)
     if callable(init_sign):            # parity hook: start signs for the still-robust subset, [n, c, 1, w] or [n, c, w]
         init_sign = init_sign(B).reshape(B, C, W).to(x0.device, torch.float32)
     sg0 = init_sign.contiguous() if init_sign is not None else None
-    _lib.check(lib.rart_square_init_linf(_lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), sd, sample_offset,
+    _lib.check(lib.rart_square_init_linf(_lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), sd, 0, _lib.ptr(rows0),
                                          _lib.ptr(sg0), _lib.stream_ptr()))
     margin_min, _, _ = logit_loss(prov.logits(x_best), yy, LOSS_MARGIN, want_grad=False)
     loss_min = margin_min.clone()
@@ -646,17 +681,17 @@ def square_lp_perturb(model_fn, x, y, norm='L2', eps=0.5, n_queries=5000, p_init
     nid = 2 if norm == 'L2' else 1
     prov = _prov or _Provider(model_fn, normalize_inside=False)
     x, y = _check_inputs(x, y)
-    sample_offset = _offset(sample_offset, x.shape[0])
+    rows = _row_tensor(_offset(sample_offset, x.shape[0]), x.shape[0], x.device)
     adv = x.clone()
     acc = prov.logits(x).max(1)[1] == y
     ind = acc.nonzero().flatten()
     if ind.numel() == 0:
         return adv
     x0, yy = x[ind].contiguous(), y[ind].contiguous()
+    rows0 = rows[ind].contiguous()
     B, C, H, W = x0.shape
     dev = x0.device
     sd = _seed(seed)
-    samples = sample_offset + np.arange(B, dtype=np.int64)
     eps_p = float(eps) * (1. - 1e-6)                                   # square.py:425, :483
     etas = {}
 
@@ -667,8 +702,12 @@ def square_lp_perturb(model_fn, x, y, norm='L2', eps=0.5, n_queries=5000, p_init
         return etas[s]
 
     def native_signs(stream_index):
-        u = np.stack([_rng.host_uniform_many(sd, samples, 11, stream_index * 4 + c) for c in range(C)], axis=1)
-        return torch.from_numpy(np.where(u >= 0.5, 1.0, -1.0).astype(np.float32))
+        """[B][C] +-1 sign rows of one query / start tile, drawn ON THE DEVICE from (seed, the image's global index, query, channel)
+        (rart_rng_signs_f32: the values the host generator's host_uniform(sd, sample, 11, 4 * index + c) >= 0.5 gives) -- round 3 drew
+        them in numpy and copied them to the device every query (5 000 host draws + H2D copies per attack)"""
+        sg = torch.empty(B, C, dtype=torch.float32, device=dev)
+        _lib.check(lib.rart_rng_signs_f32(_lib.ptr(sg), B, C, sd, 0, _lib.ptr(rows0), 11, stream_index * 4, _lib.stream_ptr()))
+        return sg
 
     # ---- start point (:297-312 / :410-426)
     s0 = H // 5
@@ -681,9 +720,9 @@ def square_lp_perturb(model_fn, x, y, norm='L2', eps=0.5, n_queries=5000, p_init
         else:
             tr, sg = _rng.host_uniform(sd, t, 10, 0) > 0.5, native_signs((1 << 20) + t)
         trs.append(1 if tr else 0)
-        sgs.append(sg.reshape(B, C).float())
+        sgs.append(sg.reshape(B, C).float().to(dev))
     tr_dev = torch.tensor(trs, dtype=torch.uint8).to(dev)
-    sg_dev = torch.stack(sgs).contiguous().to(dev)
+    sg_dev = torch.stack(sgs).contiguous()
     x_best = torch.empty_like(x0)
     _lib.check(lib.rart_square_init_lp(_lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), nid, s0, sp, tiles_h, tiles_w,
                                        _lib.ptr(eta_dev(s0)), _lib.ptr(tr_dev), _lib.ptr(sg_dev), _lib.stream_ptr()))
@@ -712,7 +751,7 @@ def square_lp_perturb(model_fn, x, y, norm='L2', eps=0.5, n_queries=5000, p_init
         else:
             vh, vw, vh2, vw2 = (int(_rng.host_uniform(sd, it, 9, k) * ((H if k % 2 == 0 else W) - s)) for k in range(4))
             tr = _rng.host_uniform(sd, it, 9, 4) > 0.5
-            sg = native_signs(it).to(dev)
+            sg = native_signs(it)
         e = eta_dev(s)[1 if tr else 0]
         _lib.check(lib.rart_square_propose_lp(_lib.ptr(x_new), _lib.ptr(x_best), _lib.ptr(x0), B, C, H, W, float(eps), nid, int(vh),
                                               int(vw), int(vh2), int(vw2), s, _lib.ptr(e), _lib.ptr(sg), _lib.stream_ptr()))
@@ -890,14 +929,14 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
         robust_flags = y_orig.eq(prov.logits(x_orig).max(1)[1])                  # :95-109
         x_adv = x_orig.clone()
         base_seed = _seed(seed)
-        # global index of the call's first sample.  NOTE: every sub-attack receives the still-robust SUBSET
-        # x_orig[idcs] together with this offset, and the restarts / target classes inside a sub-attack subset again, so row k of
-        # a subset draws its random start at counter index first + k, not at the sample's own index: the draws are reproducible
-        # for a given (seed, batch composition) but -- like the reference's torch.manual_seed(self.seed) per perturb() call,
-        # whose i-th row of noise also lands on whichever sample is i-th among the survivors -- they are NOT invariant to how
-        # the dataset is batched or sharded once samples have dropped out.  Only the first launch of the first sub-attack sees
-        # every sample at its own index.
+        # every image's GLOBAL sample index.  The sub-attacks receive the still-robust SUBSET x_orig[idcs] together with ITS rows'
+        # indices (rows_all[idcs]), and the restarts / target classes inside a sub-attack subset the same way, so a sample's
+        # random starts and Square sign rows are a pure function of (seed, its own index, attack, restart): the result does not
+        # depend on how the dataset is batched or sharded over GPUs (the reference re-seeds torch per perturb() call and hands
+        # the i-th row of noise to whichever sample is i-th among the survivors, autopgd_base.py:502-503 -- reproducible only for a
+        # fixed batch composition).  tests/test_attacks_gpu.py::test_autoattack_is_invariant_to_batch_splitting.
         first = _offset(None, x_orig.shape[0])
+        rows_all = _row_tensor(first, x_orig.shape[0], x_orig.device)
         C, H, W = x_orig.shape[1:]
         for ai, attack in enumerate(plan):
             if attack in skipped:
@@ -906,6 +945,7 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
             if idcs.numel() == 0:
                 break
             x, y = x_orig[idcs].contiguous(), y_orig[idcs].contiguous()
+            first = rows_all[idcs]                   # (named `first` below: the sample_offset argument of the sub-attacks)
             if draws is not None:
                 draws.reseed()                       # every perturb() of the reference re-seeds torch with self.seed
             ts = (draws.randn if norm == 'L2' else draws.pm1) if draws is not None else None      # autopgd_base.py:214-221

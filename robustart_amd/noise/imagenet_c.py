@@ -159,6 +159,47 @@ def corrupt_batch_(batch, corruption_id, severity, seed=None, sample_offset=None
     return dst
 
 
+def to_unit_nchw(batch_u8, out=None):
+    """uint8 NHWC device batch -> fp32 NCHW in [0,1] (x / 255), one kernel (rart_u8_to_unit_f32_nchw): the input of the attacks
+    (adv/attack.py:20-23); bit-identical to batch.permute(0, 3, 1, 2).float().div(255)."""
+    torch = _lib.require_gpu()
+    n, h, w, _ = batch_u8.shape
+    if out is None:
+        out = torch.empty(n, 3, h, w, dtype=torch.float32, device=batch_u8.device)
+    if (h * w) % 4:
+        out.copy_(batch_u8.permute(0, 3, 1, 2).float().div_(255.0))
+        return out
+    _lib.check(_lib.load().rart_u8_to_unit_f32_nchw(_lib.ptr(batch_u8), _lib.ptr(out), n, h, w, _lib.stream_ptr()))
+    return out
+
+
+def noise_severities_(batch, outs, severities=(1, 2, 3, 4, 5), seeds=None, sample_offset=None, corruption_id=0):
+    """gaussian_noise (corruption_id 0) or speckle_noise (15) of ONE source batch at several severities in ONE launch
+    (rart_noise_multi_u8): the generation loop of ImageNet-C corrupts every image at all five severities
+    (imagenet_c/__init__.py:13-35, one call per (image, severity)); five launches read the source five times, this one once.
+    outs[i] receives severity severities[i] drawn with seeds[i] (default: the current seed + severity, i.e. an independent field per
+    severity, as the reference's successive np.random draws are) -- bit-identical to corrupt_batch_(batch, corruption_id,
+    severities[i], seeds[i], sample_offset, out=outs[i]).  Falls back to exactly those calls for sizes the fused kernel does not take."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    n, h, w, _ = batch.shape
+    ns = len(severities)
+    assert len(outs) == ns and 1 <= ns <= 8
+    if seeds is None:
+        seeds = [(_rng.current_seed() + int(sv)) & 0xFFFFFFFFFFFFFFFF for sv in severities]
+    if sample_offset is None:
+        sample_offset = _rng.next_offset(n)
+    ptrs = (ctypes.c_void_p * ns)(*[o.data_ptr() for o in outs])
+    rc = lib.rart_noise_multi_u8(_lib.ptr(batch), ptrs, ns, n, h, w, corruption_id, (ctypes.c_int * ns)(*[int(v) for v in severities]),
+                                 (ctypes.c_uint64 * ns)(*[int(v) for v in seeds]), sample_offset, _lib.stream_ptr())
+    if rc == 2:                                   # RART_ERR_UNSUPPORTED: size / alignment / generator -> the per-severity launches
+        for o, sv, sd in zip(outs, severities, seeds):
+            corrupt_batch_(batch, corruption_id, int(sv), int(sd), sample_offset, out=o)
+        return outs
+    _lib.check(rc)
+    return outs
+
+
 def _make(name, cid):
     def f(x, severity=1, **kw):
         return corrupt(x, severity=severity, corruption_number=cid, **kw)

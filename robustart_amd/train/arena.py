@@ -17,6 +17,8 @@ MI355X-first layout for the data-parallel training step (SURVEY.md 8e "Training"
 The arithmetic is torch.optim.SGD / AdamW (exprs/nips_benchmark/pgd_adv_train/resnet50/config.yaml:11-33,
 new_adv_train/vit_base/config.yaml:11-38); the kernels are pinned to it through oracle/train_ref.py.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -68,10 +70,13 @@ class ParamArena:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # the exchange runs whenever there is more than one rank -- and, with RART_FORCE_DIST=1, also in a one-rank process group, so that a
+        # single-GPU box executes the very same bucketed all_reduce calls on arena slices (tests/test_rccl_gpu.py)
+        self.exchange = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get('RART_FORCE_DIST') == '1')
         self._hooks = []
         self.overlap = overlap
         self._index = {id(p): i for i, p in enumerate(self.params)}
-        if self.world > 1 and overlap:      # dist.sync: True -> every bucket is reduced after backward instead
+        if self.exchange and overlap:      # dist.sync: True -> every bucket is reduced after backward instead
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -87,7 +92,7 @@ class ParamArena:
 
     def grad_ready(self, param):
         """Same bookkeeping as the autograd hook, for gradients produced outside autograd (the HIP train engine)."""
-        if self.world > 1 and self.overlap:
+        if self.exchange and self.overlap:
             i = self._index.get(id(param))
             if i is not None:
                 self._make_hook(i)(param)
@@ -96,7 +101,7 @@ class ParamArena:
         """Wait for the bucket all-reduces launched during backward; buckets whose parameters produced no gradient
         this step (unused branches) are reduced here so every rank issues the same collectives.  Returns the
         factor the optimizer must fold into the gradients (1 / world_size)."""
-        if self.world > 1:
+        if self.exchange:
             for b, (lo, hi, cnt) in enumerate(self.buckets):
                 if self._pending[b] != cnt:
                     self._handles.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))

@@ -345,7 +345,9 @@ def init_dist():
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    # RART_FORCE_DIST=1: join the process group even as a single rank (a one-GPU box then creates the RCCL communicator and runs
+    # the same collectives the 8-GPU launch does)
+    if (world > 1 or os.environ.get('RART_FORCE_DIST') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl' if use_cuda else 'gloo')       # "nccl" == RCCL on ROCm

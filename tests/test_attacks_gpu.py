@@ -547,3 +547,69 @@ def test_fab_refuses_a_bare_bf16_engine_and_switches_when_it_has_the_module():
         adv.fab_targeted_perturb(bare, x, y, 4 / 255, 2, 1)
     out2 = adv.fab_targeted_perturb(bare, x, y, 4 / 255, 2, 1, allow_bf16_fab=True)
     assert out2.shape == x.shape
+
+
+@pytest.mark.parametrize('norm,eps', [('Linf', 1.0 / 255), ('L2', 0.25)])
+def test_autoattack_is_invariant_to_batch_splitting(norm, eps):
+    """every sub-attack of AutoAttack receives the still-robust SUBSET of the batch together with its
+    rows' GLOBAL sample indices (rart_apgd_init / rart_square_init_linf / rart_rng_signs_f32 `row_samples`), so a sample's random
+    starts and Square sign rows do not depend on which other samples survived: autoattack on 16 images == the concatenation of two
+    8-image calls (the process-wide sample counter gives the second call the offset 8).  Driven through the HIP ResNet-50 engines,
+    whose per-image arithmetic does not depend on the batch (tests/test_outcome_gpu.py::test_b256_matches_small_batches_bit_for_bit).
+    Reference: autoattack.py:117-136 (robust-subset bookkeeping), autopgd_base.py:502-503 (re-seeding per perturb() call)."""
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.model.resnet_torch import randomize_bn_stats
+    from robustart_amd.noise import adv, rng
+    torch.manual_seed(0)
+    m = randomize_bn_stats(get_model({'type': 'resnet50_official'})).eval()
+    model = EngineModel(m, takes_normalized=True)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(16, 3, 64, 64, generator=g).cuda()
+    mean = torch.tensor(A.IMAGENET_MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(A.IMAGENET_STD, device='cuda').view(1, 3, 1, 1)
+    y = model((x - mean) / std).argmax(1)
+    y[5] = (y[5] + 1) % 1000                         # one image misclassified from the start
+    ov = dict(apgd_iter=4, apgdt_iter=3, apgdt_classes=2, fab_iter=3, fab_classes=2, square_queries=25)
+
+    def run(xs, ys):
+        return adv.autoattack_linf(xs, ys, model, norm, eps, 'standard', False, seed=3, _overrides=dict(ov))
+    rng.manual_seed(3, 0)
+    full = run(x, y)
+    rng.manual_seed(3, 0)
+    halves = torch.cat([run(x[:8].contiguous(), y[:8].contiguous()), run(x[8:].contiguous(), y[8:].contiguous())])
+    changed = (full != x).flatten(1).any(1)
+    print('autoattack %s: %d of 16 images moved' % (norm, int(changed.sum())))
+    assert torch.equal(full[5], x[5]) and int(changed.sum()) >= 1
+    assert torch.equal(full, halves)
+    # ... and the per-row index tensor is what makes it so: Square's start signs of a 3-image subset at its rows' own indices
+    rows = torch.tensor([4, 9, 2], dtype=torch.int64, device='cuda')
+    sub = x[rows].contiguous()
+    a = adv.apgd_init(sub, norm, eps, seed=7, sample_offset=rows)
+    for k, r in enumerate(rows.tolist()):
+        b = adv.apgd_init(x[r:r + 1].contiguous(), norm, eps, seed=7, sample_offset=r)
+        assert torch.equal(a[k], b[0])
+
+
+def test_square_sign_rows_come_from_the_device_generator():
+    """rart_rng_signs_f32 == the host generator's host_uniform(...) >= 0.5 for the same (seed, sample, stream, index)
+    -- Square's L2 / L1 proposals draw their per-image sign rows on the device instead of numpy + a host-to-device copy per query."""
+    from robustart_amd import _lib
+    from robustart_amd.noise import rng
+    lib = _lib.load()
+    B, C, seed = 5, 3, 1234567
+    rows = torch.tensor([11, 3, 700, 3, 42], dtype=torch.int64, device='cuda')
+    out = torch.empty(B, C, device='cuda')
+    for it in (0, 17, (1 << 20) + 3):
+        _lib.check(lib.rart_rng_signs_f32(_lib.ptr(out), B, C, seed, 0, _lib.ptr(rows), 11, it * 4, _lib.stream_ptr()))
+        want = [[1.0 if rng.host_uniform(seed, int(r), 11, it * 4 + c) >= 0.5 else -1.0 for c in range(C)] for r in rows.tolist()]
+        assert out.cpu().tolist() == want
+        _lib.check(lib.rart_rng_signs_f32(_lib.ptr(out), B, C, seed, 100, None, 11, it * 4, _lib.stream_ptr()))
+        want = [[1.0 if rng.host_uniform(seed, 100 + b, 11, it * 4 + c) >= 0.5 else -1.0 for c in range(C)] for b in range(B)]
+        assert out.cpu().tolist() == want
+    n = torch.empty(3, 1000, device='cuda')
+    r3 = torch.tensor([5, 6, 9], dtype=torch.int64, device='cuda')
+    _lib.check(lib.rart_rng_normal_rows_f32(_lib.ptr(n), 3, 1000, seed, _lib.ptr(r3), 5, _lib.stream_ptr()))
+    ref = torch.empty(5, 1000, device='cuda')
+    _lib.check(lib.rart_rng_normal_f32(_lib.ptr(ref), 5, 1000, seed, 5, 5, _lib.stream_ptr()))
+    assert torch.equal(n[0], ref[0]) and torch.equal(n[1], ref[1]) and torch.equal(n[2], ref[4])

@@ -374,3 +374,42 @@ def test_u8_to_normalized():
     outb = torch.empty(2, 224, 224, 3, device='cuda', dtype=torch.bfloat16)
     _lib.check(_lib.load().rart_u8_to_normalized(_lib.ptr(x), _lib.ptr(outb), 2, 224, 224, 1, 1, _lib.stream_ptr()))
     torch.testing.assert_close(outb.float(), want.permute(0, 2, 3, 1).bfloat16().float(), atol=1.6e-2, rtol=0)
+
+
+@pytest.mark.parametrize('name', ['gaussian_noise', 'speckle_noise'])
+def test_five_severities_in_one_launch_equal_five_launches(name):
+    """rart_noise_multi_u8: the source chunk is read once and written at every (severity, seed) pair; each output is bit-identical to
+    the single-severity launch with the same arguments (imagenet_c/corruptions.py:122-126, 143-147 called once per severity by the
+    generation loop).  A size the fused kernel does not take falls back to those launches."""
+    from robustart_amd.noise import imagenet_c as C
+    cid = _cid(name)
+    for shape in ((5, 224, 224, 3), (2, 60, 52, 3)):                       # 60*52*3 is not a multiple of 1024: the fallback
+        g = torch.Generator().manual_seed(7)
+        src = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).cuda()
+        keep = src.clone()
+        sevs, seeds = (1, 2, 3, 4, 5), (11, 12, 13, 14, 11)
+        outs = [torch.empty_like(src) for _ in sevs]
+        C.noise_severities_(src, outs, sevs, seeds, sample_offset=900, corruption_id=cid)
+        assert torch.equal(src, keep)                                      # the source is only read
+        for o, sv, sd in zip(outs, sevs, seeds):
+            want = torch.empty_like(src)
+            C.corrupt_batch_(src, cid, sv, seed=sd, sample_offset=900, out=want)
+            assert torch.equal(o, want), (name, shape, sv)
+        assert not torch.equal(outs[0], outs[1])
+    # default seeds: an independent field per severity (current seed + severity)
+    from robustart_amd.noise import rng
+    rng.manual_seed(5, 0)
+    outs = [torch.empty_like(src) for _ in range(2)]
+    C.noise_severities_(src, outs, (3, 3), sample_offset=0, corruption_id=cid)
+    assert torch.equal(outs[0], outs[1])                                   # same severity -> same default seed
+    want = torch.empty_like(src)
+    C.corrupt_batch_(src, cid, 3, seed=5 + 3, sample_offset=0, out=want)
+    assert torch.equal(outs[0], want)
+
+
+def test_u8_to_unit_nchw_is_the_torch_expression_bit_for_bit():
+    from robustart_amd.noise import imagenet_c as C
+    g = torch.Generator().manual_seed(4)
+    for shape in ((3, 224, 224, 3), (2, 32, 50, 3), (1, 5, 3, 3)):             # the last: h*w % 4 != 0 -> the torch fallback
+        u8 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).cuda()
+        assert torch.equal(C.to_unit_nchw(u8), u8.permute(0, 3, 1, 2).float().div(255.0).contiguous())
