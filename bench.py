@@ -409,14 +409,15 @@ def measure_reference_precision(model, device, images, labels, scratch, norm_buf
     algo = issued / 3.0
     step_flops = (5 + 15) * B * FLOP_FWD
     return {'value': 6 * B * steps / dt, 'unit': 'images/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'dtype': 'bf16x3',
-            'arithmetic': 'activations / gradients / weights as hi + lo bf16 pairs (16 significand bits), x.w = hi.hi + hi.lo + lo.hi '
-                          'on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; logits within 1e-4 of the fp32 network '
+            'arithmetic': 'activations / gradients / weights as hi + lo bf16 pairs (16 significand bits), x.w = lo.hi + hi.lo + hi.hi '
+                          'on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (rart_gemm_pair_bf16: the four operand planes of a K step staged '
+                          'once in LDS, three MFMAs per fragment pair); logits within 1e-4 of the fp32 network '
                           '(tests/test_engine_x3_gpu.py, tests/test_outcome_gpu.py)',
             'model_path': path.name, 'correct_corrupted': int(acc[0]), 'correct_adv': int(acc[1]),
             'step_algorithmic': {'achieved': step_flops * steps / dt / 1e12, 'unit': 'TFLOP/s',
                                  'vs_fp32_mfma_peak': step_flops * steps / dt / MFMA_F32_PEAK,
                                  'note': 'fp32-equivalent FLOPs of the step / time; 157.3 TFLOP/s is what fp32 MFMA operands peak at'},
-            'roofline': {'kernel': 'k_conv_igemm_bf16<.., PAIR> (ResNet-50 forward + backward-to-input, B=%d, %d launches)' % (B, len(prof)),
+            'roofline': {'kernel': 'k_gemm_pair<TM, TN, conv> (every contraction of the ResNet-50 forward + backward-to-input, B=%d, %d launches)' % (B, len(prof)),
                          'bound': 'mfma', 'achieved': issued / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
                          'frac': issued / secs / MFMA_BF16_PEAK, 'traffic': None,
                          'achieved_fp32_equivalent': algo / secs / 1e12, 'avg_launch_us': secs / len(prof) * 1e6,

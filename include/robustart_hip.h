@@ -127,7 +127,8 @@ int rart_cv_resize_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int 
  * out_dtype : 0 = fp32, 1 = bf16.   out_layout : 0 = NCHW, 1 = NHWC. */
 int rart_u8_to_normalized(const uint8_t* in, void* out, int n, int h, int w,
                           int out_dtype, int out_layout, rart_stream_t stream);
-/* x01 fp32 NCHW = u8 NHWC / 255 (true division, bit-identical to torch's u8.permute(0, 3, 1, 2).float().div(255)): the hand-over from
+/* x01 fp32 NCHW = u8 NHWC * (1 / 255) (bit-identical to torch's u8.permute(0, 3, 1, 2).float().div(255), which multiplies by the fp32
+ * reciprocal of a scalar divisor): the hand-over from
  * the uint8 images of the corruption kernels / datasets to the attack tensors (fp32 NCHW in [0,1], adv/attack.py:20-23) in one kernel. */
 int rart_u8_to_unit_f32_nchw(const uint8_t* in, float* out, int n, int h, int w, rart_stream_t stream);
 
@@ -428,6 +429,11 @@ int rart_softmax_bwd_rows_pair(const void* probs_hi, const void* probs_lo, const
                                int n_valid, int ld_p, int ld_dp, int ld_out, float scale, rart_stream_t stream);
 int rart_vit_unpatchify_from_f32(const float* dpatches, float* grad, int n, int h, int w, int patch, int64_t ld, const float* std_host,
                                  rart_stream_t stream);
+/* Fused multi-head self-attention on pairs (head_dim 64, <= 224 tokens), one workgroup per (image, head): qkv pair [n*tokens][3*D]
+ * (q | k | v column blocks, heads of 64 inside each) -> out pair [n*tokens][D] = softmax(q k^T / 8) v, every contraction three MFMA
+ * products, the soft-max in fp32 registers (timm Attention.forward; the reference runs it in fp32). */
+int rart_vit_attention_pair(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int n, int tokens, int heads, int head_dim,
+                            rart_stream_t stream);
 
 /* 3x3 stride-1 "same" convolution, channels in = channels out = 64, 128 or 256 (256: images of at most 224 positions, one
  * image per workgroup), bf16 NHWC, with the input halo tile resident in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 /

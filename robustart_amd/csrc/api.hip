@@ -189,7 +189,8 @@ __global__ __launch_bounds__(kBlock) void k_u8_to_norm(const uint8_t* __restrict
     }
   }
 }
-// x01[n][c][h][w] = u8[n][h][w][c] / 255 (true division: bit-identical to torch's u8.permute(0, 3, 1, 2).float().div(255)): the attack
+// x01[n][c][h][w] = u8[n][h][w][c] * (1 / 255) -- torch's u8.permute(0, 3, 1, 2).float().div(255) multiplies by the fp32 reciprocal of a
+// scalar divisor, so this is bit-identical to that expression (tests/test_corruptions_gpu.py): the attack
 // tensors are fp32 NCHW in [0,1] (adv/attack.py:20-23), the corruption kernels and datasets hand over uint8 NHWC.  Four pixels of one
 // channel per thread: 12 contiguous input bytes per 4 pixels are shared by the three channel threads through L1, stores are 16 bytes.
 __global__ __launch_bounds__(kBlock) void k_u8_to_unit_nchw(const uint8_t* __restrict__ in, float* __restrict__ out, uint32_t hw,
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(kBlock) void k_u8_to_unit_nchw(const uint8_t* __res
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
     const uint32_t p4 = (uint32_t)(i % q), c = (uint32_t)((i / q) % 3), img = (uint32_t)(i / ((size_t)3 * q));
     const uint8_t* s = in + ((size_t)img * hw + (size_t)p4 * 4) * 3 + c;
-    const float4 v = make_float4((float)s[0] / 255.0f, (float)s[3] / 255.0f, (float)s[6] / 255.0f, (float)s[9] / 255.0f);
+    const float r = 1.0f / 255.0f;
+    const float4 v = make_float4((float)s[0] * r, (float)s[3] * r, (float)s[6] * r, (float)s[9] * r);
     reinterpret_cast<float4*>(out)[((size_t)img * 3 + c) * q + p4] = v;
   }
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ float native_normal(uint32_t k0, uint32_t k1, size_t 
 // AutoAttack: row k of the subset draws at its own sample's index, so the draws do not depend on how a dataset is batched or sharded),
 // else the contiguous sample_offset + b.
 __device__ __forceinline__ uint32_t row_sample(const int64_t* __restrict__ rows, uint32_t sbase, uint32_t b) {
-  return rows ? (uint32_t)rows[b] : row_sample(rows, sbase, b);
+  return rows ? (uint32_t)rows[b] : sbase + b;
 }
 
 // ---- random starts -------------------------------------------------------------------

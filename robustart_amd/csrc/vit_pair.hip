@@ -271,6 +271,153 @@ __global__ __launch_bounds__(kBlock) void k_unpatchify_from_f32(const float* __r
     reinterpret_cast<float4*>(grad)[i] = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
   }
 }
+
+// ---- fused multi-head attention on pairs (head_dim 64, tokens <= NKT*32), one workgroup per (image, head) -------------------------
+// The structure of k_vit_attention (csrc/vit_aux.hip) with every contraction as three MFMA products: K_hi / K_lo rows and V_hi / V_lo
+// transposed are resident in LDS (122 KB at 224 tokens: one workgroup per CU), a wave owns 32 queries; S^T = K Q^T lands with lane
+// (l & 31) = the QUERY, so the soft-max statistics of a query live in one lane pair and the whole score row stays in registers (fp32, as
+// the fp32 module computes it); the un-normalised probabilities e = exp(s - max) are split into hi + lo and fed straight back as the
+// B operand of O^T = V^T P^T in the key order the accumulator registers already have; O is scaled by 1 / sum and written as a pair.
+// Replaces, per layer and forward pass, the batched S = Q K^T product (fp32 scores, 0.5 GB at B = 256), the soft-max row kernel, two
+// V transposes and the batched P V product of the unfused path (ViTEngine.fused_attention = False keeps that path as the cross-check).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int PATT_HD = 64, PATT_LDK = PATT_HD + 8;
+
+template <int NKT>
+__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+                                                                  uint16_t* __restrict__ att_h, uint16_t* __restrict__ att_l, int T, int H,
+                                                                  int ld, int D, float scale_log2e) {
+  constexpr int TP = NKT * 32, LDV = TP + 4;     // 228-element rows: conflict-free 8-byte reads across 32 lanes
+  __shared__ __attribute__((aligned(16))) uint16_t sK[2][TP * PATT_LDK];
+  __shared__ __attribute__((aligned(16))) uint16_t sVt[2][PATT_HD * LDV];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+  const size_t boff = (size_t)b * T * ld + h * PATT_HD;
+  const uint16_t* const base[2] = {qkv_h + boff, qkv_l + boff};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    for (int i = tid; i < TP * 8; i += kBlock) {                       // K rows: 16-byte chunks, coalesced
+      const int t = i >> 3, c = i & 7;
+      uint4 kv = make_uint4(0, 0, 0, 0);
+      if (t < T) kv = *reinterpret_cast<const uint4*>(base[p] + (size_t)t * ld + D + c * 8);
+      *reinterpret_cast<uint4*>(&sK[p][t * PATT_LDK + c * 8]) = kv;
+    }
+    // V transposed: a thread takes 8 channels of FOUR consecutive tokens and writes eight 8-byte runs (one per channel)
+    for (int i = tid; i < (TP / 4) * 8; i += kBlock) {
+      const int tq = i % (TP / 4), c = i / (TP / 4);
+      uint32_t w[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        uint4 vv = make_uint4(0, 0, 0, 0);
+        if (tq * 4 + u < T) vv = *reinterpret_cast<const uint4*>(base[p] + (size_t)(tq * 4 + u) * ld + 2 * D + c * 8);
+        w[u][0] = vv.x; w[u][1] = vv.y; w[u][2] = vv.z; w[u][3] = vv.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint16_t* row = &sVt[p][(c * 8 + 2 * j) * LDV + tq * 4];
+        *reinterpret_cast<uint2*>(row) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x05040100u),
+                                                    __builtin_amdgcn_perm(w[3][j], w[2][j], 0x05040100u));
+        *reinterpret_cast<uint2*>(row + LDV) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x07060302u),
+                                                          __builtin_amdgcn_perm(w[3][j], w[2][j], 0x07060302u));
+      }
+    }
+  }
+  __syncthreads();
+  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
+    const int q = qt * 32 + l31;
+    bf16x8 bqh[4], bql[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+      if (q < T) {
+        vh = *reinterpret_cast<const uint4*>(base[0] + (size_t)q * ld + kb * 16 + hh * 8);
+        vl = *reinterpret_cast<const uint4*>(base[1] + (size_t)q * ld + kb * 16 + hh * 8);
+      }
+      bqh[kb] = *reinterpret_cast<bf16x8*>(&vh);
+      bql[kb] = *reinterpret_cast<bf16x8*>(&vl);
+    }
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sK[0][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sK[1][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqh[kb], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bql[kb], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqh[kb], sacc[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // keep the K fragments of later key tiles out of the register file
+    }
+    // sacc[kt][r] = q . k for key kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q.  Keys past the sequence must not win the maximum: only
+    // the LAST key tile can hold any (the host picks NKT = ceil(T / 32))
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= T) sacc[NKT - 1][r] = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mneg = -m * scale_log2e;            // scale > 0: max(s) * scale == max(s * scale)
+    float sum = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      uint32_t ph[8], pl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][2 * j], scale_log2e, mneg));
+        const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][2 * j + 1], scale_log2e, mneg));
+        sum += e0 + e1;
+        ph[j] = pk2(e0, e1);
+        pl[j] = pk2(e0 - __uint_as_float(ph[j] << 16), e1 - __uint_as_float(ph[j] & 0xFFFF0000u));
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        uint4 pvh = make_uint4(ph[4 * kb2], ph[4 * kb2 + 1], ph[4 * kb2 + 2], ph[4 * kb2 + 3]);
+        uint4 pvl = make_uint4(pl[4 * kb2], pl[4 * kb2 + 1], pl[4 * kb2 + 2], pl[4 * kb2 + 3]);
+        const bf16x8 pbh = *reinterpret_cast<bf16x8*>(&pvh), pbl = *reinterpret_cast<bf16x8*>(&pvl);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int vo = (nt * 32 + l31) * LDV + kt * 32 + 16 * kb2 + 4 * hh;
+          const uint2 h0 = *reinterpret_cast<const uint2*>(&sVt[0][vo]), h1 = *reinterpret_cast<const uint2*>(&sVt[0][vo + 8]);
+          const uint2 l0 = *reinterpret_cast<const uint2*>(&sVt[1][vo]), l1 = *reinterpret_cast<const uint2*>(&sVt[1][vo + 8]);
+          uint4 avh = make_uint4(h0.x, h0.y, h1.x, h1.y), avl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          const bf16x8 ah = *reinterpret_cast<bf16x8*>(&avh), al = *reinterpret_cast<bf16x8*>(&avl);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pbh, o[nt], 0, 0, 0);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pbl, o[nt], 0, 0, 0);
+          o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pbh, o[nt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // o[nt][r] = O[query q][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]: a lane owns runs of four channels of ITS query -> 8-byte stores per plane
+    if (q < T) {
+      const size_t ro = ((size_t)b * T + q) * D + h * PATT_HD;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v[4] = {o[nt][4 * g] * inv, o[nt][4 * g + 1] * inv, o[nt][4 * g + 2] * inv, o[nt][4 * g + 3] * inv};
+          uint2 vh, vl;
+          split4(v, vh, vl);
+          *reinterpret_cast<uint2*>(att_h + ro + nt * 32 + 8 * g + 4 * hh) = vh;
+          *reinterpret_cast<uint2*>(att_l + ro + nt * 32 + 8 * g + 4 * hh) = vl;
+        }
+    }
+  }
+}
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
 }  // namespace
 
@@ -349,6 +496,27 @@ int rart_vit_unpatchify_from_f32(const float* dpatches, float* grad, int n, int 
   hipLaunchKernelGGL(k_unpatchify_from_f32, dim3(grid_for((size_t)n * 3 * h * w / 4)), dim3(kBlock), 0, (hipStream_t)stream, dpatches,
                      grad, n, h, w, patch, (long long)ld, is);
   RART_CHECK_LAUNCH("rart_vit_unpatchify_from_f32");
+  return RART_OK;
+}
+
+int rart_vit_attention_pair(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int n, int tokens, int heads, int head_dim,
+                            rart_stream_t stream) {
+  RART_CHECK_ARG(qkv_hi && qkv_lo && out_hi && out_lo && n > 0 && tokens > 0 && heads > 0, "rart_vit_attention_pair: bad arguments");
+  RART_CHECK_ARG(head_dim == 64, "rart_vit_attention_pair: head_dim must be 64 (ViT-B/16)");
+  RART_CHECK_ARG(tokens <= 224, "rart_vit_attention_pair: at most 224 tokens (197 for 224x224 / patch 16)");
+  const int D = heads * head_dim;
+  const float scale_log2e = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
+  const dim3 grid((uint32_t)(n * heads));
+  hipStream_t st = (hipStream_t)stream;
+#define RART_PATT_CASE(N) case N: hipLaunchKernelGGL(k_vit_attention_pair<N>, grid, dim3(kBlock), 0, st, (const uint16_t*)qkv_hi, \
+    (const uint16_t*)qkv_lo, (uint16_t*)out_hi, (uint16_t*)out_lo, tokens, heads, 3 * D, D, scale_log2e); break;
+  switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
+    RART_PATT_CASE(1) RART_PATT_CASE(2) RART_PATT_CASE(3) RART_PATT_CASE(4) RART_PATT_CASE(5) RART_PATT_CASE(6)
+    default: hipLaunchKernelGGL(k_vit_attention_pair<7>, grid, dim3(kBlock), 0, st, (const uint16_t*)qkv_hi, (const uint16_t*)qkv_lo,
+                                (uint16_t*)out_hi, (uint16_t*)out_lo, tokens, heads, 3 * D, D, scale_log2e); break;
+  }
+#undef RART_PATT_CASE
+  RART_CHECK_LAUNCH("rart_vit_attention_pair");
   return RART_OK;
 }
 

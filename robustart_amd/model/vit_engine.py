@@ -453,10 +453,13 @@ class ViTEngine:
             _lib.check(lib.rart_layernorm_pair(_lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(L['n1g']), _lib.ptr(L['n1b']), _lib.ptr(ln[0]),
                                                _lib.ptr(ln[1]), rows, D, D, D, 1e-6, sp))
             self._gemm_pair(ln, XL['qkv_w'], qkv, rows, 3 * D, D, D, 3 * D, bias=L['qkv_b'])
-            probs = self._scores_probs_x3(qkv, B, T)
-            vt = self._transpose_heads_x3(qkv, 'x3_vt', B, T, 3 * D, 2 * D)
-            self._gemm_pair(probs, vt, att, T, hd, t_pad, t_pad, D, ldw=t_pad, w_rows=hd,
-                            batched=dict(n=B * H, inner=H, a=(H * T * t_pad, T * t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * D, hd)))
+            if self.fused_attention and hd == 64 and T <= 224:
+                _lib.check(lib.rart_vit_attention_pair(_lib.ptr(qkv[0]), _lib.ptr(qkv[1]), _lib.ptr(att[0]), _lib.ptr(att[1]), B, T, H, hd, sp))
+            else:           # the decomposition into batched products with fp32 score-sized temporaries (cross-check)
+                probs = self._scores_probs_x3(qkv, B, T)
+                vt = self._transpose_heads_x3(qkv, 'x3_vt', B, T, 3 * D, 2 * D)
+                self._gemm_pair(probs, vt, att, T, hd, t_pad, t_pad, D, ldw=t_pad, w_rows=hd,
+                                batched=dict(n=B * H, inner=H, a=(H * T * t_pad, T * t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * D, hd)))
             self._gemm_pair(att, XL['proj_w'], xm, rows, D, D, D, D, bias=L['proj_b'], res=x)
             _lib.check(lib.rart_layernorm_pair(_lib.ptr(xm[0]), _lib.ptr(xm[1]), _lib.ptr(L['n2g']), _lib.ptr(L['n2b']), _lib.ptr(ln[0]),
                                                _lib.ptr(ln[1]), rows, D, D, D, 1e-6, sp))

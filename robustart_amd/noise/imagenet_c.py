@@ -161,7 +161,7 @@ def corrupt_batch_(batch, corruption_id, severity, seed=None, sample_offset=None
 
 def to_unit_nchw(batch_u8, out=None):
     """uint8 NHWC device batch -> fp32 NCHW in [0,1] (x / 255), one kernel (rart_u8_to_unit_f32_nchw): the input of the attacks
-    (adv/attack.py:20-23); bit-identical to batch.permute(0, 3, 1, 2).float().div(255)."""
+    (adv/attack.py:20-23); bit-identical to batch.permute(0, 3, 1, 2).float().div(255) (a multiplication by fp32 1/255)."""
     torch = _lib.require_gpu()
     n, h, w, _ = batch_u8.shape
     if out is None:

@@ -309,3 +309,42 @@ def test_vit_x3_through_engine_model_and_pgd(setup):
     with pytest.raises(ValueError):
         from robustart_amd.model.vit_engine import ViTEngine
         ViTEngine(m, 'cuda', precision='fp16')
+
+
+@pytest.mark.parametrize('T', [197, 33, 224, 64, 130])
+def test_fused_pair_attention_vs_fp64_every_key_tile_count(T):
+    """rart_vit_attention_pair (one workgroup per (image, head), K / V^T pairs resident in LDS, soft-max in fp32 registers, every
+    contraction three MFMA products) against fp64 soft-max attention on the values the pair REPRESENTS; key-tile counts 2 .. 7 with
+    full and partial last tiles."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(T)
+    B, H, hd = 2, 3, 64
+    D = H * hd
+    qkv = _split((torch.randn(B * T, 3 * D, generator=g) * 1.5).cuda())
+    out = torch.full((2, B * T, D), float('nan'), dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.rart_vit_attention_pair(_lib.ptr(qkv[0]), _lib.ptr(qkv[1]), _lib.ptr(out[0]), _lib.ptr(out[1]), B, T, H, hd,
+                                           _lib.stream_ptr()))
+    q = _f64(qkv).view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    want = (torch.softmax(q[0] @ q[1].transpose(-1, -2) / 8.0, -1) @ q[2]).permute(0, 2, 1, 3).reshape(B * T, D)
+    err = (_f64(out) - want).abs().max().item() / want.abs().max().item()
+    print('pair attention T=%d: max err %.2e of scale' % (T, err))
+    assert err <= 2.5e-5
+
+
+def test_vit_x3_fused_attention_matches_the_unfused_path(setup):
+    """The forward with the fused pair attention against the same engine on the decomposition into batched pair products (fp32 scores,
+    soft-max rows, V transposes): same operands, other summation order."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(3, 3, 224, 224, generator=g).cuda()
+    assert eng.fused_attention
+    a = eng.logits(x, MEAN, STD).clone()
+    eng.fused_attention = False
+    try:
+        b = eng.logits(x, MEAN, STD).clone()
+    finally:
+        eng.fused_attention = True
+    err = (a - b).abs().max().item() / b.abs().max().item()
+    print('ViT x3 logits, fused vs unfused attention: %.2e of scale' % err)
+    assert err <= 2e-5
