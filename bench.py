@@ -845,7 +845,7 @@ def main():
             algo = BYTES_PER_IMAGE * B
             out['roofline'] = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, B=256, u8 NHWC in/out)',
                                'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
-                               'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': pmc_traffic('k_normal_noise_mfma'),
+                               'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': pmc_traffic('k_normal_noise_mfmaI'),
                                'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s '
                                                '(FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run' % getattr(pmc_traffic, 'source', '?'),
                                'avg_launch_us': avg * 1e6, 'per_launch_event_bracket_us': bracket * 1e6,

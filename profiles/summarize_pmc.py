@@ -36,7 +36,7 @@ def main(fetch_db, write_db, out):
     res['k_conv_igemm_bf16_all'] = {'calls': n, 'hbm_bytes': sum(v['hbm_bytes'] * v['calls'] for v in ig) / n,
                                     'fetch_bytes': sum(v['fetch_bytes'] * v['calls'] for v in ig) / n,
                                     'write_bytes': sum(v['write_bytes'] * v['calls'] for v in ig) / n}
-    gn = [v for k, v in res['kernels'].items() if 'k_normal_noise_mfma' in k]
+    gn = [v for k, v in res['kernels'].items() if 'k_normal_noise_mfmaI' in k]      # the single-severity kernel (not ..._multi)
     if gn:
         res['calibration'] = {'kernel': 'k_normal_noise_mfma<0>', 'known_read_bytes': 256 * 150528,
                               'fetch_bytes_after_x2': gn[0]['fetch_bytes'], 'known_write_bytes': 256 * 150528,
