@@ -719,6 +719,20 @@ int rart_wgrad_reduce_f32(float* partial, int splits, int taps, int channels, in
 int rart_pack_conv_weight_bf16(const float* weight, const float* out_channel_scale, void* out, int n_out, int channels,
                                int r, int s, int n_taps, const int* tap_r, const int* tap_s, int transpose,
                                int rows_padded, rart_stream_t stream);
+/* Many table jobs in ONE launch: the adversarial-training step (cifar10/code/train.py:96-127: attack the CURRENT weights, then update
+ * them) re-packs every conv table of the train engine and re-folds every table of the attack engine after each optimizer step -- about
+ * 500 launches of 2-10 us kernels.  kind 0 = the job of rart_pack_conv_weight_bf16 (weight / scale / out and the geometry; <= 16 taps),
+ * kind 1 = the job of rart_pack_frag_bf16 (src16 -> out, rows x k).  jobs_device: an array of rart_pack_job in DEVICE memory, built once
+ * by the caller (every pointer in it must stay valid); blocks_per_job workgroups walk each job grid-strided. */
+typedef struct rart_pack_job {
+  int kind, n_out, channels, r, s, n_taps, transpose, rows_padded, rows, k;
+  int tap_r[16], tap_s[16];
+  const float* weight;
+  const float* out_channel_scale;
+  const void* src16;
+  void* out;
+} rart_pack_job;
+int rart_pack_jobs_bf16(const rart_pack_job* jobs_device, int n_jobs, int blocks_per_job, rart_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ SIGNATURES = {
     'rart_igemm_set_gemm256': (c_int, [c_int]),
     'rart_gemm256_supported': (c_int, [ctypes.c_longlong, c_int, c_int, c_int, c_int]),
     'rart_gemm_pair_bf16': (c_int, [c_void_p, c_void_p]),
+    'rart_pack_jobs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'rart_vit_add_pos_cls_pair': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_layernorm_pair': (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_int64, ctypes.c_int64, c_float, c_void_p]),
     'rart_layernorm_bwd_pair': (c_int, [c_void_p] * 9 + [c_int, c_int] + [ctypes.c_int64] * 4 + [c_float, c_void_p]),
@@ -194,6 +195,13 @@ class ConvDesc(ctypes.Structure):
                 ('src_z_outer', ctypes.c_int64), ('src_z_inner', ctypes.c_int64), ('wgt_z_outer', ctypes.c_int64),
                 ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64),
                 ('sign_out', c_void_p), ('dst_pair_off', ctypes.c_int64), ('res_pair_off', ctypes.c_int64)]
+
+
+class PackJob(ctypes.Structure):
+    """rart_pack_job (include/robustart_hip.h): one table job of rart_pack_jobs_bf16."""
+    _fields_ = [(n, ctypes.c_int32) for n in ('kind', 'n_out', 'channels', 'r', 's', 'n_taps', 'transpose', 'rows_padded', 'rows', 'k')] + \
+               [('tap_r', ctypes.c_int32 * 16), ('tap_s', ctypes.c_int32 * 16), ('weight', c_void_p), ('out_channel_scale', c_void_p),
+                ('src16', c_void_p), ('out', c_void_p)]
 
 
 class GemmPairDesc(ctypes.Structure):

@@ -389,6 +389,48 @@ __global__ __launch_bounds__(kBlock) void k_pack_weight(const float* __restrict_
   }
 }
 
+// Many small table jobs in ONE launch (blockIdx.y = job): the adversarial-training step re-packs every conv table of the train engine
+// and re-folds + re-packs every table of the attack engine after each optimizer step -- ~500 launches of 2-10 us kernels whose dispatch
+// gaps cost more than their work.  The job list lives in device memory (built once: the tensors are persistent).
+// kind 0 = k_pack_weight's job (fp32 [N][C][R][S] -> bf16 igemm table, optional per-row scale), kind 1 = the fragment re-order of
+// conv3x3_halo.hip's k_pack_frag (w [rows][k] row-major -> fragment-major 16-byte chunks).
+struct PackJobDev {
+  int kind, N, C, R, S, n_taps, transpose, rows_pad, rows, k;
+  int tap_r[16], tap_s[16];
+  const float* w;
+  const float* row_scale;
+  const uint16_t* src16;
+  uint16_t* out;
+};
+__global__ __launch_bounds__(kBlock) void k_pack_jobs(const PackJobDev* __restrict__ jobs) {
+  const PackJobDev& a = jobs[blockIdx.y];
+  if (a.kind == 0) {
+    const int inner = a.transpose ? a.N : a.C;
+    const size_t K = (size_t)a.n_taps * inner;
+    const size_t total = (size_t)a.rows_pad * K;
+    const int rows = a.transpose ? a.C : a.N;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+      const int row = (int)(i / K);
+      const size_t k = i % K;
+      const int ti = (int)(k / inner), in = (int)(k % inner);
+      float v = 0.f;
+      if (row < rows) {
+        const int n = a.transpose ? in : row, c = a.transpose ? row : in;
+        v = a.w[(((size_t)n * a.C + c) * a.R + a.tap_r[ti]) * a.S + a.tap_s[ti]];
+        if (a.row_scale) v *= a.row_scale[n];
+      }
+      a.out[i] = (uint16_t)f2bf(v);
+    }
+  } else {
+    const int chunks = a.rows * a.k / 8, nwn = a.rows / 32;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < chunks; i += gridDim.x * kBlock) {
+      const int l = i & 63, ks = (i >> 6) & 3, f = i >> 8, wn = f % nwn, st = f / nwn;
+      *reinterpret_cast<uint4*>(a.out + (size_t)i * 8) =
+          *reinterpret_cast<const uint4*>(a.src16 + (size_t)(wn * 32 + (l & 31)) * a.k + st * 64 + ks * 16 + (l >> 5) * 8);
+    }
+  }
+}
+
 inline unsigned grid_for(size_t n) {
   size_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -547,5 +589,17 @@ extern "C" int rart_pack_conv_weight_bf16(const float* weight, const float* out_
   hipLaunchKernelGGL(k_pack_weight, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, weight, out_channel_scale,
                      (uint16_t*)out, a);
   RART_CHECK_LAUNCH("rart_pack_conv_weight_bf16");
+  return RART_OK;
+}
+
+
+// The jobs of rart_pack_conv_weight_bf16 (kind 0) / rart_pack_frag_bf16 (kind 1) for MANY tables in one launch.  jobs: DEVICE array of
+// rart_pack_job (the caller builds it once -- every pointer in it must stay valid); blocks_per_job workgroups walk each job grid-strided.
+extern "C" int rart_pack_jobs_bf16(const rart_pack_job* jobs_device, int n_jobs, int blocks_per_job, rart_stream_t stream) {
+  static_assert(sizeof(rart_pack_job) == sizeof(PackJobDev), "rart_pack_job and its device mirror must have one layout");
+  RART_CHECK_ARG(jobs_device && n_jobs > 0 && n_jobs <= 65535 && blocks_per_job > 0 && blocks_per_job <= 4096, "rart_pack_jobs_bf16: bad arguments");
+  hipLaunchKernelGGL(k_pack_jobs, dim3((unsigned)blocks_per_job, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream,
+                     reinterpret_cast<const PackJobDev*>(jobs_device));
+  RART_CHECK_LAUNCH("rart_pack_jobs_bf16");
   return RART_OK;
 }

@@ -194,17 +194,32 @@ class ResNet50Engine:
         if not split:
             self._pack_frag_tables()
 
-    def _pack_frag_tables(self):
+    def _pack_frag_tables(self, record=None, sums=None):
         """MFMA-fragment-ordered copies of the 3x3 tables the LDS-resident kernels (conv3x3_halo.hip, bottleneck_fused.hip)
-        stream from L2: a fragment load then reads 1 KiB contiguous instead of touching 32 cache lines."""
+        stream from L2: a fragment load then reads 1 KiB contiguous instead of touching 32 cache lines.
+        record / sums (refold): instead of launching, append every (source table, fragment table, rows, k) job to `record` and
+        every (conv3 bias, shortcut bias, summed bias) triple to `sums` -- the allocations happen either way."""
         torch = _lib.require_gpu()
         sp = _lib.stream_ptr()
+        lib_pack = self.lib.rart_pack_frag_bf16
+
+        def pack(tab, dst, rows, k):
+            if record is not None:
+                record.append((tab, dst, rows, k))
+            else:
+                _lib.check(lib_pack(_lib.ptr(tab), _lib.ptr(dst), rows, k, sp))
+
+        def bias_sum(a, b, out):
+            if sums is not None:
+                sums.append((a, b, out))
+            else:
+                torch.add(a, b, out=out)
         for ca, cb, cc, ds in self.blocks:
             if cb.r == 3 and cb.stride == 1 and cb.cin == cb.cout and cb.cin in (64, 128, 256, 512):
                 for name, tab in (('w_fwd_frag', cb.w_fwd), ('w_bwd_frag', cb.bwd[0][2])):
                     if getattr(cb, name, None) is None:
                         setattr(cb, name, torch.empty(9 * cb.cin * cb.cin, dtype=torch.bfloat16, device=self.device))
-                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(cb, name)), cb.cin, 9 * cb.cin, sp))
+                    pack(tab, getattr(cb, name), cb.cin, 9 * cb.cin)
             if ds is None and cb.stride == 1 and (ca.cin, ca.cout, cc.cout) in ((1024, 256, 1024), (512, 128, 512), (2048, 512, 2048)):
                 # identity blocks of layer2 / layer3 / layer4 for the image-resident fused kernels: both 1x1 tables in fragment order
                 for c_, rows, k in ((ca, ca.cout, ca.cin), (cc, cc.cout, cc.cin)):
@@ -212,7 +227,7 @@ class ResNet50Engine:
                         r_, k_ = (rows, k) if name == 'w_fwd_frag' else (k, rows)
                         if getattr(c_, name, None) is None:
                             setattr(c_, name, torch.empty(rows * k, dtype=torch.bfloat16, device=self.device))
-                        _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(c_, name)), r_, k_, sp))
+                        pack(tab, getattr(c_, name), r_, k_)
             if (ds is not None and cb.stride == 2 and cb.r == 3 and ds.stride == 2 and ds.r == 1
                     and (ca.cin, ca.cout, cc.cout) in ((256, 128, 512), (512, 256, 1024))):
                 # stride-2 first block of layer2 / layer3 for the fused forward kernel (bottleneck_s2_fused.hip): all four tables in
@@ -221,10 +236,10 @@ class ResNet50Engine:
                                           (ds, 's2_wd', ds.cout, ds.cin)):
                     if getattr(c_, name, None) is None:
                         setattr(c_, name, torch.empty(rows * k, dtype=torch.bfloat16, device=self.device))
-                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(c_.w_fwd), _lib.ptr(getattr(c_, name)), rows, k, sp))
+                    pack(c_.w_fwd, getattr(c_, name), rows, k)
                 if getattr(ds, 'bias_sum', None) is None:
                     ds.bias_sum = torch.empty_like(cc.bias)
-                torch.add(cc.bias, ds.bias, out=ds.bias_sum)
+                bias_sum(cc.bias, ds.bias, ds.bias_sum)
                 # ... and the backward kernel's: transposed tables of conv3 / conv1 / the shortcut, and the four input-parity-class
                 # tables of the 3x3 / 2 (1 / 2 / 2 / 4 taps) packed one by one into a single buffer
                 cm = ca.cout
@@ -232,12 +247,12 @@ class ResNet50Engine:
                                                (ds, 's2_wdt', ds.bwd[0][2], ds.cin, ds.cout)):
                     if getattr(c_, name, None) is None:
                         setattr(c_, name, torch.empty(rows * k, dtype=torch.bfloat16, device=self.device))
-                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(getattr(c_, name)), rows, k, sp))
+                    pack(tab, getattr(c_, name), rows, k)
                 if getattr(cb, 's2_w2t', None) is None:
                     cb.s2_w2t = torch.empty(9 * cm * cm, dtype=torch.bfloat16, device=self.device)
                 off = 0
                 for (_, taps, tab) in cb.bwd:                  # parity classes (0,0) (0,1) (1,0) (1,1)
-                    _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(tab), _lib.ptr(cb.s2_w2t[off:]), cm, len(taps) * cm, sp))
+                    pack(tab, cb.s2_w2t[off:], cm, len(taps) * cm)
                     off += len(taps) * cm * cm
                 assert off == 9 * cm * cm
             if (ds is not None and ds.stride == 1 and ds.r == 1 and cb.stride == 1 and ca.cin == 64 and ca.cout == 64
@@ -246,8 +261,8 @@ class ResNet50Engine:
                 if getattr(ds, 'w_fwd_frag', None) is None:
                     ds.w_fwd_frag = torch.empty(ds.cout * ds.cin, dtype=torch.bfloat16, device=self.device)
                     ds.bias_sum = torch.empty_like(cc.bias)
-                _lib.check(self.lib.rart_pack_frag_bf16(_lib.ptr(ds.w_fwd), _lib.ptr(ds.w_fwd_frag), ds.cout, ds.cin, sp))
-                torch.add(cc.bias, ds.bias, out=ds.bias_sum)
+                pack(ds.w_fwd, ds.w_fwd_frag, ds.cout, ds.cin)
+                bias_sum(cc.bias, ds.bias, ds.bias_sum)
 
     @staticmethod
     def _stem_bwd_table(wb):
@@ -271,39 +286,47 @@ class ResNet50Engine:
 
     # ------------------------------------------------------------------ re-fold from the live parameters
     def refold(self, model):
-        """Re-derive every table from `model`'s CURRENT parameters and running statistics, on the GPU
-        (rart_pack_conv_weight_bf16 with the BatchNorm scale folded in): the adversarial-training loop attacks the
-        model it is training (cifar10/code/train.py:105-111), so the attack engine is refreshed every iteration."""
+        """Re-derive every table from `model`'s CURRENT parameters and running statistics, on the GPU: the adversarial-training
+        loop attacks the model it is training (cifar10/code/train.py:105-111), so the attack engine is refreshed every iteration.
+        Round 4: the ~480 launches this took (five torch elementwise kernels + two to five rart_pack_conv_weight_bf16 calls per
+        convolution, one rart_pack_frag_bf16 per fragment-ordered copy) are a handful now -- the BatchNorm fold runs on flat
+        concatenated vectors, every conv table is one job of ONE rart_pack_jobs_bf16 launch, every fragment re-order one job of a
+        second; the tables are bit-identical to the constructor's (tests/test_engine_gpu.py::test_refold_...)."""
         torch = _lib.require_gpu()
         if self.precision != 'bf16':
             raise NotImplementedError('refold() serves the adversarial-training loop, which attacks on the bf16 engine; build a '
                                       'new ResNet50Engine(model, precision=%r) from the updated weights instead' % self.precision)
         lib, sp = self.lib, _lib.stream_ptr()
         m = model
-
-        def fold(c, conv, bn):
-            w = conv.weight.detach()
-            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
-            scale = (bn.running_var.detach() + bn.eps).rsqrt() * bn.weight.detach()
-            c.bias.copy_(bn.bias.detach() - bn.running_mean.detach() * scale)
-            rs = [(r, s) for r in range(c.r) for s in range(c.s)]
-            _lib.check(lib.rart_pack_conv_weight_bf16(w.data_ptr(), scale.data_ptr(), c.w_fwd.data_ptr(), c.cout, c.cin, c.r,
-                                                      c.s, len(rs), _cints([a for a, _ in rs]), _cints([b for _, b in rs]), 0,
-                                                      c.w_fwd.shape[0], sp))
-            for parity, taps, tab in c.bwd:
-                if tab is None:
-                    continue
-                if parity is None:
-                    prs = rs
-                else:
-                    ph, pw = parity
-                    prs = [(r, s_) for r, s_ in rs if (ph + c.pad - r) % 2 == 0 and (pw + c.pad - s_) % 2 == 0]
-                _lib.check(lib.rart_pack_conv_weight_bf16(w.data_ptr(), scale.data_ptr(), tab.data_ptr(), c.cout, c.cin, c.r,
-                                                          c.s, len(prs), _cints([a for a, _ in prs]),
-                                                          _cints([b for _, b in prs]), 1, tab.shape[0], sp))
-            return scale
-
-        sc = fold(self.stem, m.conv1, m.bn1)
+        pairs = [(self.stem, m.conv1, m.bn1)]
+        bi = 0
+        for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
+            for blk in layer:
+                ca, cb, cc, ds = self.blocks[bi]
+                pairs += [(ca, blk.conv1, blk.bn1), (cb, blk.conv2, blk.bn2), (cc, blk.conv3, blk.bn3)]
+                if ds is not None:
+                    pairs.append((ds, blk.downsample[0], blk.downsample[1]))
+                bi += 1
+        st = getattr(self, '_refold_state', None)
+        key = tuple(conv.weight.data_ptr() for _, conv, _ in pairs)
+        if st is None or st['key'] != key:
+            st = self._build_refold_state(pairs, key)
+        # ---- BatchNorm fold on flat vectors: scale = gamma * rsqrt(var + eps), bias = beta - mean * scale
+        torch.cat([bn.running_var.detach() for _, _, bn in pairs], out=st['var'])
+        torch.cat([bn.weight.detach() for _, _, bn in pairs], out=st['gamma'])
+        torch.cat([bn.bias.detach() for _, _, bn in pairs], out=st['beta'])
+        torch.cat([bn.running_mean.detach() for _, _, bn in pairs], out=st['mean'])
+        torch.add(st['var'], st['eps'], out=st['scale'])
+        st['scale'].rsqrt_().mul_(st['gamma'])
+        torch.mul(st['mean'], st['scale'], out=st['tmp'])
+        torch.sub(st['beta'], st['tmp'], out=st['bias'])        # c.bias of every layer is a view into st['bias']
+        # ---- every conv table (forward + backward-to-input classes) in one launch, every fragment-ordered copy in a second
+        _lib.check(lib.rart_pack_jobs_bf16(_lib.ptr(st['pack_jobs']), st['n_pack'], 48, sp))
+        for w, scale, tab, c, trs, tr in st['big']:
+            _lib.check(lib.rart_pack_conv_weight_bf16(w.data_ptr(), scale.data_ptr(), tab.data_ptr(), c.cout, c.cin, c.r, c.s, len(trs),
+                                                      _cints([a for a, _ in trs]), _cints([b for _, b in trs]), tr, tab.shape[0], sp))
+        # stem extras (row-tap table, patches table, fused-backward table) and the classifier
+        sc = st['scale'][:64]
         wb = (m.conv1.weight.detach() * sc.view(-1, 1, 1, 1)).to(torch.bfloat16)          # [64][3][7][7]
         wrow = torch.zeros(64, 7, 8, 4, dtype=torch.bfloat16, device=self.device)
         wrow[:, :, :7, :3] = wb.permute(0, 2, 3, 1)
@@ -313,21 +336,74 @@ class ResNet50Engine:
         self.stem_wd.zero_()
         self.stem_wd[:147] = wb.permute(2, 3, 1, 0).reshape(147, 64)
         self.stem_wt.copy_(self._stem_bwd_table(wb.float()))
-        bi = 0
-        for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
-            for blk in layer:
-                ca, cb, cc, ds = self.blocks[bi]
-                fold(ca, blk.conv1, blk.bn1)
-                fold(cb, blk.conv2, blk.bn2)
-                fold(cc, blk.conv3, blk.bn3)
-                if ds is not None:
-                    fold(ds, blk.downsample[0], blk.downsample[1])
-                bi += 1
         wfb = m.fc.weight.detach().to(torch.bfloat16)
         self.fc_w[:self.n_classes] = wfb
         self.fc_wd[:, :self.n_classes] = wfb.t()
         self.fc_b.copy_(m.fc.bias.detach())
-        self._pack_frag_tables()
+        if st['n_frag']:
+            _lib.check(lib.rart_pack_jobs_bf16(_lib.ptr(st['frag_jobs']), st['n_frag'], 32, sp))
+        for cc_bias, ds_bias, out in st['bias_sums']:
+            torch.add(cc_bias, ds_bias, out=out)
+
+    def _build_refold_state(self, pairs, key):
+        """Persistent buffers and the two device job lists of `refold` (built once per model: every pointer in them is stable --
+        parameters live in the optimizer's arena, tables and flat vectors are allocated here or in the constructor)."""
+        torch = _lib.require_gpu()
+        dev = self.device
+        n_tot = sum(c.cout for c, _, _ in pairs)
+        eps = {float(bn.eps) for _, _, bn in pairs}
+        assert len(eps) == 1, 'refold folds every BatchNorm with one eps'
+        st = {'key': key, 'eps': eps.pop()}
+        for nm in ('var', 'gamma', 'beta', 'mean', 'scale', 'tmp', 'bias'):
+            st[nm] = torch.empty(n_tot, dtype=torch.float32, device=dev)
+        jobs, big, off = [], [], 0
+        for c, conv, bn in pairs:
+            w = conv.weight
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+            old = c.bias
+            c.bias = st['bias'][off:off + c.cout]           # a view: the flat fold writes every layer's bias at once
+            c.bias.copy_(old)
+            scale_ptr = st['scale'][off:off + c.cout].data_ptr()
+            rs = [(r, s_) for r in range(c.r) for s_ in range(c.s)]
+            todo = [(c.w_fwd, rs, 0)]
+            for parity, taps, tab in c.bwd:
+                if tab is not None:
+                    prs = rs if parity is None else [(r, s_) for r, s_ in rs if (parity[0] + c.pad - r) % 2 == 0 and (parity[1] + c.pad - s_) % 2 == 0]
+                    todo.append((tab, prs, 1))
+            for tab, trs, tr in todo:
+                if len(trs) <= 16:
+                    jobs.append(self._pack_job(w, scale_ptr, tab, c, trs, tr))
+                else:                                       # the 7 x 7 stem's generic tables (49 taps): single launches, as before
+                    big.append((w, st['scale'][off:off + c.cout], tab, c, trs, tr))
+            off += c.cout
+        frag, sums = [], []
+        self._pack_frag_tables(record=frag, sums=sums)
+        fj = []
+        for src, dst, rows, k in frag:
+            j = _lib.PackJob()
+            j.kind, j.rows, j.k, j.src16, j.out = 1, rows, k, src.data_ptr(), dst.data_ptr()
+            fj.append(j)
+        st['pack_jobs'], st['n_pack'] = self._upload_jobs(jobs), len(jobs)
+        st['frag_jobs'], st['n_frag'] = (self._upload_jobs(fj) if fj else None), len(fj)
+        st['bias_sums'], st['big'] = sums, big
+        st['_keep'] = (jobs, fj)
+        self._refold_state = st
+        return st
+
+    @staticmethod
+    def _pack_job(w, scale_ptr, tab, c, rs, transpose):
+        j = _lib.PackJob()
+        j.kind, j.n_out, j.channels, j.r, j.s, j.n_taps, j.transpose, j.rows_padded = 0, c.cout, c.cin, c.r, c.s, len(rs), transpose, tab.shape[0]
+        for i, (a, b) in enumerate(rs):
+            j.tap_r[i], j.tap_s[i] = a, b
+        j.weight, j.out_channel_scale, j.out = w.data_ptr(), scale_ptr, tab.data_ptr()
+        return j
+
+    def _upload_jobs(self, jobs):
+        torch = _lib.require_gpu()
+        arr = (_lib.PackJob * len(jobs))(*jobs)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        return host.to(self.device)
 
     # ------------------------------------------------------------------ buffers / launches
     def _get(self, name, shape, dtype=None):

@@ -100,8 +100,27 @@ class ResNet50TrainEngine:
     def repack(self):
         """fp32 master weights -> bf16 igemm tables; call after every optimizer step."""
         torch, sp = self.torch, _lib.stream_ptr()
-        for c in [self.stem] + [c for blk in self.blocks for c in blk if c is not None]:
-            if c is not self.stem:
+        convs = [c for blk in self.blocks for c in blk if c is not None]
+        key = tuple(c.conv.weight.data_ptr() for c in convs)
+        if all(str(c.conv.weight.dtype) == 'torch.float32' and len(c.all_rs) <= 16 for c in convs):
+            # every table of every convolution as one job of ONE launch (rart_pack_jobs_bf16; ~110 launches of 3-10 us kernels before):
+            # the job list is built once -- master weights (views into the optimizer's arena) and tables are persistent
+            if getattr(self, '_pack_key', None) != key:
+                jobs = []
+                for c in convs:
+                    for tab, rs, tr in [(c.w_fwd, c.all_rs, 0)] + [(tab, prs, 1) for _, _, prs, tab in c.bwd if tab is not None]:
+                        j = _lib.PackJob()
+                        j.kind, j.n_out, j.channels, j.r, j.s, j.n_taps, j.transpose, j.rows_padded = 0, c.cout, c.cin, c.r, c.s, len(rs), tr, tab.shape[0]
+                        for i, (a, b) in enumerate(rs):
+                            j.tap_r[i], j.tap_s[i] = a, b
+                        j.weight, j.out_channel_scale, j.out = c.conv.weight.data_ptr(), None, tab.data_ptr()
+                        jobs.append(j)
+                arr = (_lib.PackJob * len(jobs))(*jobs)
+                self._pack_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+                self._pack_n, self._pack_key = len(jobs), key
+            _lib.check(self.lib.rart_pack_jobs_bf16(_lib.ptr(self._pack_jobs), self._pack_n, 48, sp))
+        else:
+            for c in convs:
                 c.repack(self.lib, sp)
         # stem forward table: a "tap" = one filter row of 8 px x 4 ch on the padded hi/lo planes (engine.py)
         wb = self.model.conv1.weight.detach().float()

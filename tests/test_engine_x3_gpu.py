@@ -342,3 +342,28 @@ def test_x3_engine_new_kernel_matches_the_round3_igemm_pair_path(setup):
     # moves discontinuously with them -- the fp64 tests with the engine's own masks are the pin, this is a sanity bound
     cos = ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min().item()
     assert rel <= 0.15 and cos >= 0.98
+
+
+def test_x3_engine_b256_matches_small_batches_bit_for_bit(setup):
+    """The reference-precision ResNet-50 engine at the benchmark's B = 256: every 32nd image of a forward / forward + backward equals the
+    same image in a batch of 2 bit for bit (every tile of k_gemm_pair sums a row's K slices in the same order whatever the batch), and
+    the logits of those rows are within 1e-4 of the fp32 module -- the small-batch parity statements hold at the full size."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(256, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 1000, (256,), generator=g).cuda()
+    big = eng.logits(x, MEAN, STD).clone()
+    lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    lb, gb = lb.clone(), gb.clone()
+    assert torch.equal(big, lb)
+    for i in range(0, 256, 32):
+        xs, ys = x[i:i + 2].contiguous(), y[i:i + 2].contiguous()
+        small = eng.logits(xs, MEAN, STD)
+        assert torch.equal(small[0], big[i]) and torch.equal(small[1], big[i + 1]), i
+        ls, _, gs, _ = eng.forward_backward(xs, MEAN, STD, ys, 0)
+        assert torch.equal(ls[0], lb[i]) and torch.equal(gs[0], gb[i]) and torch.equal(gs[1], gb[i + 1]), i
+    mean = torch.tensor(MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(STD, device='cuda').view(1, 3, 1, 1)
+    rows = torch.arange(0, 256, 32, device='cuda')
+    ref = m((x[rows] - mean) / std)
+    assert (big[rows] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
