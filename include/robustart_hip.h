@@ -196,7 +196,8 @@ int rart_mim_step(float* x, float* momentum, const float* g, const float* x0, in
 /* APGD random start (Attacks/autoattack/autopgd_base.py:213-220,237):
  * x = clip(x0 + eps * t / (max|t| + 1e-12), 0, 1) for Linf, t ~ U(-1,1);
  * x = clip(x0 + eps * t / (|t|_2 + 1e-12), 0, 1) for L2, t ~ N(0,1).
- * norm: 0 = Linf, 1 = L2.  injected_t: NULL or the fp32 draws.  workspace: rart_attack_workspace_bytes(batch). */
+ * norm: 0 = Linf, 1 = L2, 2 = L1 (normal draws divided by their L1 norm: the random start of FAB's restarts, fab_base.py:133-166, which
+ * has the same x0 + r t / ||t|| form with r = eps / 2).  injected_t: NULL or the fp32 draws.  workspace: rart_attack_workspace_bytes(batch). */
 int rart_apgd_init(float* x, const float* x0, int batch, size_t n_per_sample, int norm, float eps,
                    uint64_t seed, uint64_t sample_offset, const int64_t* row_samples, const float* injected_t,
                    void* workspace, size_t workspace_bytes, rart_stream_t stream);
@@ -378,7 +379,7 @@ int rart_gemm256_supported(long long rows, int k, int n_cols, int src_ld, int ds
  * dst : pair planes [rows][ldc] (hi = bf16(v), lo = bf16(v - hi)), or fp32 [rows][ldc] in dst_hi with flag 2 (dst_lo unused).
  * res : optional residual PAIR indexed like dst, added in fp32.
  * 256- or 128-row tiles x 64 / 128 / 256-column tiles (chosen from the shape; tile_m / tile_n override).
- * flags: 1 ReLU; 2 fp32 output; 4 exact GELU; 64 GELU with the pre-activation kept (aux RECEIVES the pair u, dst = gelu(u_hi + u_lo));
+ * flags: 1 ReLU; 2 fp32 output; 4 exact GELU (of the value the pair of the pre-activation represents, as flag 64 computes it); 64 GELU with the pre-activation kept (aux RECEIVES the pair u, dst = gelu(u_hi + u_lo));
  *        8 GELU' (v *= gelu'(aux_hi + aux_lo), aux indexed like dst).
  * Row re-basing (0 = none): output row m of image m / rows_per_image reads source row img * src_rows_per_image + m % rows_per_image +
  * src_row_off and writes destination row img * dst_rows_per_image + m % rows_per_image + dst_row_off (ViT's class-token slot).

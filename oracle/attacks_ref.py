@@ -886,6 +886,117 @@ def fab_targeted_perturb(model_fn, x, y, eps, n_iter, n_target_classes=9, norm='
     return adv
 
 
+def fab_single_run(model_fn, x, y, eps, n_iter, norm='Linf', target_class=None, rand_t=None, alpha_max=0.1, eta=1.05, beta=0.9):
+    """FABAttack.attack_single_run (fab_base.py:84-270), general form: targeted (target_class = k-th most likely class) or UNTARGETED
+    (target_class None: df / dg of every class from the full Jacobian, fab_pt.py:77-100, and per step the class whose linearised
+    boundary is closest in the dual norm, fab_base.py:168-186); rand_t(shape) -> the draw `t` of a random start (use_rand_start,
+    fab_base.py:133-166: Linf 2 * rand - 1, L2 / L1 randn) or None."""
+    project = FAB_PROJECTIONS[norm]
+    x = x.detach().clone().float()
+    y_pred = model_fn(x).max(1)[1]
+    pred = y_pred == y
+    if pred.sum() == 0:
+        return x
+    pred = pred.nonzero().flatten()
+    targeted = target_class is not None
+    if targeted:
+        la_target2 = model_fn(x).sort(dim=-1)[1][:, -target_class][pred].clone()
+    im2, la2 = x[pred].clone(), y[pred].clone()
+    bs = im2.shape[0]
+    u1 = torch.arange(bs)
+    adv = im2.clone()
+    adv_c = x.clone()
+    res2 = 1e10 * torch.ones([bs])
+    x1 = im2.clone()
+    x0 = im2.clone().reshape([bs, -1])
+    if rand_t is not None:
+        t = rand_t(tuple(x1.shape)).float()
+        r = torch.min(res2, eps * torch.ones(res2.shape)).reshape(-1, 1, 1, 1)
+        tf = t.reshape(bs, -1)
+        if norm == 'Linf':
+            x1 = im2 + r * t / tf.abs().max(dim=1, keepdim=True)[0].reshape(-1, 1, 1, 1) * .5
+        elif norm == 'L2':
+            x1 = im2 + r * t / (tf ** 2).sum(dim=-1).sqrt().view(-1, 1, 1, 1) * .5
+        else:
+            x1 = im2 + r * t / tf.abs().sum(dim=-1).view(-1, 1, 1, 1) / 2
+        x1 = x1.clamp(0.0, 1.0)
+    for _ in range(n_iter):
+        im = x1.clone().requires_grad_()
+        with torch.enable_grad():
+            yy = model_fn(im)
+            if targeted:
+                diffy = -(yy[u1, la2] - yy[u1, la_target2])
+                g, = torch.autograd.grad(diffy.sum(), im)
+                df, dg = diffy.detach().unsqueeze(1), g.unsqueeze(1)
+            else:
+                g2 = torch.stack([torch.autograd.grad(yy[:, c].sum(), im, retain_graph=True)[0] for c in range(yy.shape[-1])], 1)
+                y2 = yy.detach()
+                df = y2 - y2[u1, la2].unsqueeze(1)
+                dg = g2 - g2[u1, la2].unsqueeze(1)
+                df[u1, la2] = 1e10
+        with torch.no_grad():
+            dgf = dg.reshape(bs, dg.shape[1], -1)
+            if norm == 'Linf':
+                dist1 = df.abs() / (1e-12 + dgf.abs().sum(dim=-1))
+            elif norm == 'L2':
+                dist1 = df.abs() / (1e-12 + (dgf ** 2).sum(dim=-1).sqrt())
+            else:
+                dist1 = df.abs() / (1e-12 + dgf.abs().max(dim=2)[0])
+            ind = dist1.min(dim=1)[1]
+            dg2 = dg[u1, ind]
+            b = -df[u1, ind] + (dg2 * x1).reshape(bs, -1).sum(dim=-1)
+            w = dg2.reshape([bs, -1])
+            d3 = project(torch.cat((x1.reshape([bs, -1]), x0), 0), torch.cat((w, w), 0), torch.cat((b, b), 0))
+            d1, d2 = d3[:bs].reshape(x1.shape), d3[-bs:].reshape(x1.shape)
+            a0 = _fab_row_norm(d3, norm).view(-1, 1, 1, 1)
+            a0 = torch.max(a0, 1e-8 * torch.ones_like(a0))
+            a1, a2 = a0[:bs], a0[-bs:]
+            alpha = torch.min(torch.max(a1 / (a1 + a2), torch.zeros_like(a1)), alpha_max * torch.ones_like(a1))
+            x1 = ((x1 + eta * d1) * (1 - alpha) + (im2 + d2 * eta) * alpha).clamp(0.0, 1.0)
+            is_adv = model_fn(x1).max(1)[1] != la2
+            if is_adv.sum() > 0:
+                ia = is_adv.nonzero().flatten()
+                t = _fab_row_norm(x1[ia] - im2[ia], norm)
+                better = (t < res2[ia]).float().view(-1, 1, 1, 1)
+                adv[ia] = x1[ia] * better + adv[ia] * (1 - better)
+                res2[ia] = t * (t < res2[ia]).float() + res2[ia] * (t >= res2[ia]).float()
+                x1[ia] = im2[ia] + (x1[ia] - im2[ia]) * beta
+    ind_succ = (res2 < 1e10).nonzero().flatten()
+    adv_c[pred[ind_succ]] = adv[ind_succ].clone()
+    return adv_c
+
+
+def fab_perturb(model_fn, x, y, eps, n_iter, n_restarts=1, norm='Linf', targeted=False, n_target_classes=9, start_draw=None):
+    """FABAttack.perturb (fab_base.py:272-336) with restarts: restart 0 starts at the clean point, every later one at a random point
+    (start_draw(norm, shape) -> t, drawn from the torch stream the caller re-seeded like perturb() does, fab_base.py:281).  Untargeted:
+    the `fab` stage of AutoAttack version 'plus' (autoattack.py:269-270); targeted with n_restarts > 1: its `fab-t` stage."""
+    adv = x.clone()
+    with torch.no_grad():
+        acc = model_fn(x).max(1)[1] == y
+    rounds = [None] if not targeted else list(range(2, n_target_classes + 2))
+    for target_class in rounds:
+        for counter in range(n_restarts):
+            ind = acc.nonzero().flatten()
+            if ind.numel() == 0:
+                continue
+            xs, ys = x[ind].clone(), y[ind].clone()
+            rt = (lambda shape: start_draw(norm, shape)) if counter > 0 else None
+            adv_curr = fab_single_run(model_fn, xs, ys, eps, n_iter, norm, target_class, rt)
+            with torch.no_grad():
+                acc_curr = model_fn(adv_curr).max(1)[1] == ys
+            res = _fab_row_norm(xs - adv_curr, norm)
+            acc_curr = torch.max(acc_curr, res > eps)
+            fooled = (acc_curr == 0).nonzero().flatten()
+            acc[ind[fooled]] = False
+            adv[ind[fooled]] = adv_curr[fooled].clone()
+    return adv
+
+
+def fab_start_draw(norm, shape):
+    """the `t` of FAB's random start from torch's global generator (fab_base.py:134, :143, :154)"""
+    return 2 * torch.rand(tuple(shape)) - 1 if norm == 'Linf' else torch.randn(tuple(shape))
+
+
 # ---------------------------------------------------------------------------------------
 # AutoAttack orchestrator, Linf (Attacks/autoattack/autoattack.py:90-211) -- pinned
 # ---------------------------------------------------------------------------------------
@@ -908,6 +1019,9 @@ class TorchStreamDraws:
 
     def randn(self, _index, shape):                      # APGD-L1 start (autopgd_base.py:223, :538)
         return torch.randn(tuple(shape))
+
+    def fab_start(self, norm, shape):                    # FAB restarts > 0 (fab_base.py:134, :143, :154)
+        return fab_start_draw(norm, shape)
 
     def square_init(self, n, c, w):
         return torch.sign(2 * torch.rand([n, c, 1, w]) - 1)

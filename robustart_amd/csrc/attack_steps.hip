@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_apgd_init_reduce(float* __restrict__
   for (size_t e = c.begin + threadIdx.x; e < c.end; e += kBlock) {
     const float t = inj ? inj[(size_t)b * nps + e]
                         : (NORM == 0 ? native_pm1(k0, k1, e, row_sample(rows, sbase, b)) : native_normal(k0, k1, e, row_sample(rows, sbase, b)));
-    acc = NORM == 0 ? fmaxf(acc, fabsf(t)) : acc + t * t;
+    acc = NORM == 0 ? fmaxf(acc, fabsf(t)) : (NORM == 1 ? acc + t * t : acc + fabsf(t));      // NORM 2: FAB's L1 start, sum |t|
   }
   const float r = NORM == 0 ? block_max(acc, sh) : block_sum(acc, sh);
   if (threadIdx.x == 0) part[(size_t)b * RCH + blockIdx.x] = r;
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(kBlock) void k_apgd_init_apply(float* __restrict__ 
                                                             uint32_t k0, uint32_t k1, uint32_t sbase,
                                                             const float* __restrict__ inj, const int64_t* __restrict__ rows) {
   const uint32_t b = blockIdx.y;
-  const float red = NORM == 0 ? max_partials(part + (size_t)b * RCH) : sqrtf(sum_partials(part + (size_t)b * RCH));
+  const float red = NORM == 0 ? max_partials(part + (size_t)b * RCH)
+                              : (NORM == 1 ? sqrtf(sum_partials(part + (size_t)b * RCH)) : sum_partials(part + (size_t)b * RCH));
   const float denom = red + 1e-12f;
   const size_t base = (size_t)b * nps;
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < nps; e += (size_t)gridDim.x * kBlock) {
@@ -1353,7 +1354,7 @@ int rart_apgd_init(float* x, const float* x0, int batch, size_t nps, int norm, f
                    uint64_t sample_offset, const int64_t* row_samples, const float* inj, void* ws, size_t ws_bytes,
                    rart_stream_t stream) {
   RART_CHECK_ARG(x && x0 && batch > 0 && nps > 0 && nps < (1ull << 29), "rart_apgd_init: bad arguments");
-  RART_CHECK_ARG(norm == 0 || norm == 1, "rart_apgd_init: norm must be 0 (Linf) or 1 (L2)");
+  RART_CHECK_ARG(norm >= 0 && norm <= 2, "rart_apgd_init: norm must be 0 (Linf), 1 (L2) or 2 (L1: normal draws divided by their L1 norm)");
   if (int e = need_ws("rart_apgd_init", ws, ws_bytes, (size_t)batch * RCH)) return e;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), sb = (uint32_t)sample_offset;
@@ -1362,9 +1363,13 @@ int rart_apgd_init(float* x, const float* x0, int batch, size_t nps, int norm, f
     hipLaunchKernelGGL(k_apgd_init_reduce<0>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj, row_samples);
     hipLaunchKernelGGL(k_apgd_init_apply<0>, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, part, nps, eps, k0,
                        k1, sb, inj, row_samples);
-  } else {
+  } else if (norm == 1) {
     hipLaunchKernelGGL(k_apgd_init_reduce<1>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj, row_samples);
     hipLaunchKernelGGL(k_apgd_init_apply<1>, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, part, nps, eps, k0,
+                       k1, sb, inj, row_samples);
+  } else {
+    hipLaunchKernelGGL(k_apgd_init_reduce<2>, dim3(RCH, batch), dim3(kBlock), 0, s, part, nps, k0, k1, sb, inj, row_samples);
+    hipLaunchKernelGGL(k_apgd_init_apply<2>, grid_rows(nps, batch), dim3(kBlock), 0, s, x, x0, part, nps, eps, k0,
                        k1, sb, inj, row_samples);
   }
   RART_CHECK_LAUNCH("rart_apgd_init");

@@ -352,7 +352,10 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += rv[j];
         }
-        if (flags & GP_GELU) {
+        if (flags & GP_GELU) {     // gelu of the value the PAIR of the pre-activation represents: the same result as GELU_KEEP's, so a forward-only
+          uint4 ph, pl;            // evaluation and the forward of a gradient evaluation agree bit for bit
+          gp_split8(v, ph, pl);
+          gp_join8(ph, pl, v);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = gp_gelu(v[j]);
         }

@@ -116,7 +116,7 @@ def apgd_init(x0, norm, eps, seed=None, sample_offset=0, injected_t=None):
     B = x0.shape[0]
     ws, nb = _ws(B, x0.device)
     off, rows = _rows(sample_offset)
-    _lib.check(_lib.load().rart_apgd_init(_lib.ptr(x), _lib.ptr(x0), B, x0[0].numel(), 0 if norm == 'Linf' else 1,
+    _lib.check(_lib.load().rart_apgd_init(_lib.ptr(x), _lib.ptr(x0), B, x0[0].numel(), {'Linf': 0, 'L2': 1, 'L1': 2}[norm],
                                           float(eps), _seed(seed), off, _lib.ptr(rows), _lib.ptr(injected_t),
                                           _lib.ptr(ws), nb, _lib.stream_ptr()))
     return x
@@ -804,8 +804,16 @@ def row_norm_diff(a, b, norm='Linf', out=None):
     return out
 
 
-def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9, norm='Linf'):
-    """FABAttack.attack_single_run, is_targeted, no random start, norm Linf / L2 / L1 (fab_base.py:84-270)."""
+_FAB_DUAL = {'Linf': 'L1', 'L2': 'L2', 'L1': 'Linf'}      # the norm of dg that measures the distance to a linearised boundary
+
+
+def _fab_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9, norm='Linf', start=None):
+    """FABAttack.attack_single_run, norm Linf / L2 / L1 (fab_base.py:84-270).  target_class k: targeted at the k-th most likely class;
+    None: UNTARGETED -- per step the class whose linearised boundary is closest in the dual norm (fab_base.py:168-186) among ALL classes
+    (fab_pt.py:77-100 builds the full Jacobian with one backward pass per class; here one gradient evaluation of z_c - z_y per class, the
+    running minimum and its gradient row kept by masked row selects, so memory stays O(batch) instead of O(batch x classes)).
+    start: None, or dict(seed, rows, t) for the random start of a restart (fab_base.py:133-166: x0 + min(res2, eps) t / ||t|| / 2 with
+    res2 = 1e10 at that point) -- rart_apgd_init's form with radius eps / 2; t = injected draws (parity) or None (counter generator)."""
     torch = _lib.require_gpu()
     lib, sp = _lib.load(), _lib.stream_ptr
     logits0 = prov.logits(x)
@@ -814,17 +822,46 @@ def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.
     idx = pred.nonzero().flatten()
     if idx.numel() == 0:
         return adv_c
-    la_t = logits0.sort(dim=-1)[1][:, -target_class][idx].contiguous()
+    targeted = target_class is not None
+    la_t = logits0.sort(dim=-1)[1][:, -target_class][idx].contiguous() if targeted else None
+    n_classes = logits0.shape[1]
     im2, la2 = x[idx].contiguous(), y[idx].contiguous()
     bs = im2.shape[0]
     nps = im2[0].numel()
     adv = im2.clone()
     res2 = torch.full((bs,), 1e10, dtype=torch.float32, device=x.device)
-    x1 = im2.clone()
+    if start is not None:
+        t = start.get('t')
+        if callable(t):
+            t = t(tuple(im2.shape))
+        if t is not None:
+            t = t.to(im2.device, torch.float32).contiguous()
+        rows = start['rows'][idx].contiguous() if start.get('rows') is not None else 0
+        x1 = apgd_init(im2, norm, 0.5 * float(eps), start.get('seed'), rows, t)
+    else:
+        x1 = im2.clone()
     dotb = torch.empty(bs, dtype=torch.float32, device=x.device)
     tbuf = torch.empty(bs, dtype=torch.float32, device=x.device)
+    if not targeted:
+        zeros = torch.zeros_like(im2)
+        gsel = torch.empty_like(im2)
+        gn = torch.empty(bs, dtype=torch.float32, device=x.device)
     for _ in range(int(n_iter)):
-        logits, df, g, _ = prov.logits_and_grad(x1, la2, LOSS_TARGETED_DIFF, la_t)       # fab_pt.py:102-117
+        if targeted:
+            logits, df, g, _ = prov.logits_and_grad(x1, la2, LOSS_TARGETED_DIFF, la_t)   # fab_pt.py:102-117
+        else:
+            best = torch.full((bs,), float('inf'), dtype=torch.float32, device=x.device)
+            df = torch.zeros(bs, dtype=torch.float32, device=x.device)
+            for c in range(n_classes):
+                cls = torch.full((bs,), c, dtype=la2.dtype, device=x.device)
+                _, dfc, gc, _ = prov.logits_and_grad(x1, la2, LOSS_TARGETED_DIFF, cls)   # z_c - z_y and its gradient: row c of df, dg
+                row_norm_diff(gc, zeros, _FAB_DUAL[norm], out=gn)
+                dist = torch.where(cls == la2, torch.full_like(best, float('inf')), dfc.abs() / (1e-12 + gn))
+                take = dist < best                                                     # first minimum wins, like dist1.min(dim=1)
+                best = torch.where(take, dist, best)
+                df = torch.where(take, dfc, df)
+                select_rows_(gsel, gc.contiguous(), take)
+            g = gsel
         _lib.check(lib.rart_row_dot(_lib.ptr(g), _lib.ptr(x1), _lib.ptr(dotb), bs, nps, sp()))
         b = (dotb - df).contiguous()                                                       # fab_base.py:170-171
         d1, a1 = fab_project(x1, g, b, norm)                                               # fab_base.py:174-203
@@ -845,6 +882,11 @@ def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.
     return adv_c
 
 
+def _fab_targeted_single_run(prov, x, y, target_class, eps, n_iter, alpha_max=0.1, eta=1.05, beta=0.9, norm='Linf'):
+    """FABAttack.attack_single_run, is_targeted, no random start (the `standard` configuration)."""
+    return _fab_single_run(prov, x, y, target_class, eps, n_iter, alpha_max, eta, beta, norm)
+
+
 def _fab_provider(prov, allow_bf16_fab):
     """The provider FAB runs on.  Measured (tests/test_outcome_gpu.py, fitted ResNet-50, eps 4/255): FAB-T leaves 34 % robust on the
     bf16 engine where the fp32 module and the reference-precision engine leave 5 % -- its projections linearise the boundary from the
@@ -862,39 +904,56 @@ def _fab_provider(prov, allow_bf16_fab):
     return prov.with_engine(eng)
 
 
-def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_classes=9, _prov=None, norm='Linf', allow_bf16_fab=False):
-    """FABAttack.perturb, targeted, norm Linf / L2 / L1, n_restarts 1 (fab_base.py:272-336).  FAB is deterministic without
-    random restarts, so there are no draws to inject.  A bf16 engine is replaced by the reference-precision engine of the same
-    module (`_fab_provider`)."""
+def fab_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_restarts=1, norm='Linf', targeted=False, n_target_classes=9, seed=None,
+                sample_offset=None, start_draws=None, _prov=None, allow_bf16_fab=False):
+    """FABAttack.perturb (fab_base.py:272-336), norm Linf / L2 / L1: targeted (one pass per target class 2 .. n_target_classes + 1) or
+    UNTARGETED (AutoAttack version 'plus', autoattack.py:269-275), each with n_restarts runs -- restart 0 from the clean point, the later
+    ones from a random point of radius eps / 2 (fab_base.py:133-166) drawn at every sample's global index (seed, restart, target class).
+    start_draws(norm, shape) (parity tests): the reference's torch draws instead.  A bf16 engine is replaced by the reference-precision
+    engine of the same module (`_fab_provider`).  The untargeted form costs one gradient evaluation per CLASS and step, as the
+    reference's Jacobian does: it is meant for small label spaces."""
     torch = _lib.require_gpu()
     if norm not in _FAB_NORM:
         raise ValueError('norm not supported')                                             # fab_base.py:164
     prov = _fab_provider(_prov or _Provider(model_fn, normalize_inside=False), allow_bf16_fab)
     x, y = _check_inputs(x, y)
+    rows = _row_tensor(_offset(sample_offset, x.shape[0]), x.shape[0], x.device) if n_restarts > 1 and start_draws is None else None
     adv = x.clone()
     acc = prov.logits(x).max(1)[1] == y
-    for target_class in range(2, n_target_classes + 2):
-        ind = acc.nonzero().flatten()
-        if ind.numel() == 0:
-            break
-        xs, ys = x[ind].contiguous(), y[ind].contiguous()
-        adv_curr = _fab_targeted_single_run(prov, xs, ys, target_class, eps, n_iter, norm=norm)
-        acc_curr = prov.logits(adv_curr).max(1)[1] == ys
-        res = row_norm_diff(xs, adv_curr, norm)                                            # fab_base.py:296-301
-        acc_curr = acc_curr | (res > eps)
-        fooled = (~acc_curr).nonzero().flatten()
-        acc[ind[fooled]] = False
-        adv[ind[fooled]] = adv_curr[fooled]
+    for ti, target_class in enumerate(list(range(2, n_target_classes + 2)) if targeted else [None]):
+        for counter in range(int(n_restarts)):
+            ind = acc.nonzero().flatten()
+            if ind.numel() == 0:
+                break
+            xs, ys = x[ind].contiguous(), y[ind].contiguous()
+            start = None
+            if counter > 0:
+                start = dict(seed=_seed(seed) + 31 * counter + 1009 * ti, rows=rows[ind] if rows is not None else None,
+                             t=(lambda shape: start_draws(norm, shape)) if start_draws is not None else None)
+            adv_curr = _fab_single_run(prov, xs, ys, target_class, eps, n_iter, norm=norm, start=start)
+            acc_curr = prov.logits(adv_curr).max(1)[1] == ys
+            res = row_norm_diff(xs, adv_curr, norm)                                        # fab_base.py:296-301
+            acc_curr = acc_curr | (res > eps)
+            fooled = (~acc_curr).nonzero().flatten()
+            acc[ind[fooled]] = False
+            adv[ind[fooled]] = adv_curr[fooled]
     return adv
+
+
+def fab_targeted_perturb(model_fn, x, y, eps=8 / 255, n_iter=100, n_target_classes=9, _prov=None, norm='Linf', allow_bf16_fab=False,
+                         n_restarts=1, seed=None, sample_offset=None, start_draws=None):
+    """FABAttack.perturb, targeted (the `fab-t` stage; n_restarts 1 in version 'standard', 5 in 'plus')."""
+    return fab_perturb(model_fn, x, y, eps, n_iter, n_restarts, norm, True, n_target_classes, seed, sample_offset, start_draws, _prov,
+                       allow_bf16_fab)
 
 
 def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None, _overrides=None, allow_bf16_fab=False):
     """attack.py:35-38 -> AutoAttack(model, norm, eps, version).run_standard_evaluation(x, y, bs=len(x))
     (autoattack.py:90-211).  `model` takes normalised input (NormalizeModel, autoattack.py:12-23).
-    standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); the
-    untargeted `fab` of version 'plus' (a 1000-class Jacobian per step, unusable on ImageNet in the reference too)
-    is reported as skipped (the result is then an upper bound on robust accuracy, never silently presented as the full
-    ensemble); apgd-ce / apgd-t / fab-t / square run for all three norms; version 'rand' = apgd-ce + apgd-dlr with the gradient
+    standard = [apgd-ce, apgd-t, fab-t, square]: all four run here for Linf (the whole `standard` ensemble); version 'plus' =
+    [apgd-ce, apgd-dlr, fab, square, apgd-t, fab-t] with 5 restarts of apgd AND of both fab stages (autoattack.py:269-275) runs in
+    full since round 4: the untargeted `fab` costs one gradient evaluation per class and step, like the reference's 1000-class
+    Jacobian (fab_pt.py:77-100) -- hours per ImageNet batch there and here; apgd-ce / apgd-t / fab-t / square run for all three norms; version 'rand' = apgd-ce + apgd-dlr with the gradient
     averaged over 20 passes (rart_eot_accumulate; Linf / L2).
     _overrides (parity tests only; the reference shrinks the same attributes, autoattack.py:253-267): dict with any of
     plan, apgd_iter, apgdt_iter, apgdt_classes, fab_iter, fab_classes, square_queries, and `draws` -- an object like
@@ -916,7 +975,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
     apgdt_classes, fab_iter, fab_classes = int(ov.get('apgdt_classes', 9)), int(ov.get('fab_iter', 100)), int(ov.get('fab_classes', 9))
     square_queries = int(ov.get('square_queries', 5000))
     draws = ov.get('draws')
-    skipped = [a for a in plan if a in ('fab',)]
+    skipped = []
+    fab_restarts = int(ov.get('fab_restarts', 5 if version == 'plus' else 1))      # autoattack.py:270: one FABAttack_PT object serves fab and fab-t
     if norm == 'L1' and eot_iter > 1:
         raise NotImplementedError("AutoAttack version 'rand' with norm 'L1': the EOT average is not wired into the L1 APGD loop")
     if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes
@@ -962,8 +1022,10 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
             elif attack == 'apgd-t':
                 adv_curr = apgd_targeted_perturb(None, x, y, norm, eps, apgdt_iter, apgdt_classes, sd, first, init_ts=ts,
                                                  _prov=prov)
-            elif attack == 'fab-t':
-                adv_curr = fab_targeted_perturb(None, x, y, eps, fab_iter, fab_classes, _prov=prov, norm=norm, allow_bf16_fab=allow_bf16_fab)
+            elif attack in ('fab', 'fab-t'):
+                adv_curr = fab_perturb(None, x, y, eps, fab_iter, fab_restarts, norm, attack == 'fab-t', fab_classes, sd, first,
+                                       start_draws=draws.fab_start if draws is not None else None, _prov=prov,
+                                       allow_bf16_fab=allow_bf16_fab)
             elif attack == 'square' and norm != 'Linf':
                 adv_curr = square_lp_perturb(None, x, y, norm, eps, square_queries, 0.8, False, sd, first, draws=draws, _prov=prov)
             elif attack == 'square':

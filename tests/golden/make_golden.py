@@ -248,8 +248,39 @@ def gen_square_lp():
     print('square_lp_ref.npz', len(out), 'entries')
 
 
+def gen_fab_plus():
+    """FABAttack_PT as AutoAttack version 'plus' configures it (autoattack.py:269-275: fab.n_restarts = 5 for BOTH the untargeted `fab` stage
+    and `fab-t`): the UNTARGETED attack (full Jacobian, fab_pt.py:77-100; the closest linearised class boundary, fab_base.py:168-186) and
+    random-start restarts (fab_base.py:133-166), shrunk to 2-3 restarts / 5 iterations on the 10-class tiny CNN, Linf / L2 / L1
+    -> fab_plus_ref.npz."""
+    net = make_tinynet()
+    model_fn = lambda z: net(normalize(z))  # noqa: E731
+    x = make_batch()
+    y = model_fn(x).max(1)[1]
+    out = {'x': x.numpy(), 'y': y.numpy()}
+    for norm, eps in (('Linf', 1.5 / 255), ('L2', 0.25), ('L1', 3.0)):        # radii at which some images survive the first restart
+        fab = FABAttack_PT(model_fn, n_restarts=3, n_iter=5, eps=eps, seed=0, norm=norm, verbose=False, device='cpu', targeted=False)
+        adv = fab.perturb(x.clone(), y.clone()).detach()
+        out[f'fab/{norm}/adv'] = adv.numpy()
+        print('fab (untargeted, 3 restarts)', norm, 'robust', int((model_fn(adv).max(1)[1] == y).sum()), 'of', len(x))
+        # one run without and one with the random start, every image's result (perturb() keeps only the fooled ones)
+        torch.random.manual_seed(0)
+        out[f'fab/{norm}/run0'] = fab.attack_single_run(x.clone(), y.clone(), use_rand_start=False, is_targeted=False).detach().numpy()
+        torch.random.manual_seed(0)
+        out[f'fab/{norm}/run1'] = fab.attack_single_run(x.clone(), y.clone(), use_rand_start=True, is_targeted=False).detach().numpy()
+        fabt = FABAttack_PT(model_fn, n_restarts=2, n_iter=5, eps=eps, seed=0, norm=norm, verbose=False, device='cpu', targeted=True,
+                            n_target_classes=2)
+        advt = fabt.perturb(x.clone(), y.clone()).detach()
+        out[f'fabt_restarts/{norm}/adv'] = advt.numpy()
+        print('fab-t (2 restarts x 2 classes)', norm, 'robust', int((model_fn(advt).max(1)[1] == y).sum()), 'of', len(x))
+    np.savez_compressed(os.path.join(HERE, 'fab_plus_ref.npz'), **out)
+    print('fab_plus_ref.npz', len(out), 'entries')
+
+
 if __name__ == '__main__':
-    if 'square_lp' in sys.argv[1:]:
+    if 'fab_plus' in sys.argv[1:]:
+        gen_fab_plus()
+    elif 'square_lp' in sys.argv[1:]:
         gen_square_lp()
     elif 'fab_l2_l1' in sys.argv[1:]:
         gen_fab_l2_l1()
@@ -264,3 +295,4 @@ if __name__ == '__main__':
         gen_apgd_l1()
         gen_fab_l2_l1()
         gen_square_lp()
+        gen_fab_plus()

@@ -253,6 +253,33 @@ def test_fab_l2_l1_projections_and_fab_t_match_reference():
         np.testing.assert_allclose(adv.numpy(), g[f'fabt/{norm}/adv'], atol=tol)
 
 
+FAB_PLUS_CASES = (('Linf', 1.5 / 255, 2e-6), ('L2', 0.25, 2e-6), ('L1', 3.0, 5e-5))
+
+
+def test_untargeted_fab_and_random_restarts_match_reference():
+    """The `fab` stage of AutoAttack version 'plus' (autoattack.py:269-275): FABAttack_PT UNTARGETED (full Jacobian, fab_pt.py:77-100; the
+    closest linearised class boundary per step, fab_base.py:168-186) and random-start restarts (fab_base.py:133-166) for both `fab` and
+    `fab-t`, restated and compared with the unmodified reference on the tiny CNN: a single run without and with the random start (every
+    image's result), perturb() with three restarts, and the targeted perturb() with two restarts per target class."""
+    g = np.load(os.path.join(GOLD, 'fab_plus_ref.npz'))
+    net = make_tinynet()
+    model_fn = lambda z: net(A.normalize(z))  # noqa: E731
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    for norm, eps, tol in FAB_PLUS_CASES:
+        run0 = A.fab_single_run(model_fn, x, y, eps, 5, norm)
+        np.testing.assert_allclose(run0.numpy(), g[f'fab/{norm}/run0'], atol=tol)
+        torch.random.manual_seed(0)
+        run1 = A.fab_single_run(model_fn, x, y, eps, 5, norm, rand_t=lambda shape: A.fab_start_draw(norm, shape))
+        np.testing.assert_allclose(run1.numpy(), g[f'fab/{norm}/run1'], atol=tol)
+        assert not np.allclose(run0.numpy(), run1.numpy())
+        torch.random.manual_seed(0)
+        adv = A.fab_perturb(model_fn, x, y, eps, 5, 3, norm, False, start_draw=A.fab_start_draw)
+        np.testing.assert_allclose(adv.numpy(), g[f'fab/{norm}/adv'], atol=tol)
+        torch.random.manual_seed(0)
+        advt = A.fab_perturb(model_fn, x, y, eps, 5, 2, norm, True, 2, start_draw=A.fab_start_draw)
+        np.testing.assert_allclose(advt.numpy(), g[f'fabt_restarts/{norm}/adv'], atol=tol)
+
+
 SQUARE_LP_CASES = (('L2', 0.5, 60), ('L2', 2.0, 25), ('L1', 12.0, 60), ('L1', 40.0, 25))
 
 
