@@ -435,6 +435,11 @@ int rart_vit_unpatchify_from_f32(const float* dpatches, float* grad, int n, int 
  * products, the soft-max in fp32 registers (timm Attention.forward; the reference runs it in fp32). */
 int rart_vit_attention_pair(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int n, int tokens, int heads, int head_dim,
                             rart_stream_t stream);
+/* Its backward (two launches, csrc/vit_pair.hip): dqkv pair [n*tokens][3*D] (dq | dk | dv) from the qkv pair, the forward's output pair, and
+ * the gradient pair of that output.  stats: scratch of n * heads * 32 * ceil(tokens / 32) * 4 floats (per query: max, 1 / sum, delta). */
+int rart_vit_attention_bwd_pair(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
+                                const void* dout_lo, void* dqkv_hi, void* dqkv_lo, float* stats, int n, int tokens, int heads, int head_dim,
+                                rart_stream_t stream);
 
 /* 3x3 stride-1 "same" convolution, channels in = channels out = 64, 128 or 256 (256: images of at most 224 positions, one
  * image per workgroup), bf16 NHWC, with the input halo tile resident in LDS (csrc/conv3x3_halo.hip): ResNet-50's layer1 /

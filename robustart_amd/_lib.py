@@ -113,6 +113,7 @@ SIGNATURES = {
     'rart_softmax_rows_pair': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'rart_softmax_bwd_rows_pair': (c_int, [c_void_p] * 5 + [ctypes.c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'rart_vit_attention_pair': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'rart_vit_attention_bwd_pair': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_void_p]),
     'rart_vit_unpatchify_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64, ctypes.POINTER(c_float), c_void_p]),
     'rart_engine_prep_input': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),

@@ -418,6 +418,291 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_pair(const uint16_t
     }
   }
 }
+
+// ---- fused attention BACKWARD on pairs: two kernels, one workgroup per (image, head) each -----------------------------------------------
+// dQ, dK, dV of softmax(Q K^T / sqrt(d)) V from the Q, K, V, O (the forward's output) and dO pairs.  The bf16 kernel (k_vit_attention_bwd,
+// csrc/vit_aux.hip) keeps Q, K, V, dO and two transposed copies in 158 KB of LDS; as pairs that is twice what a CU has, so the two phases
+// of that kernel are two launches here, each with HALF of the operands resident (129 KB):
+//   k_vit_attention_bwd_q_pair  (a wave owns 32 QUERIES; K, V pairs resident): S^T = K Q^T and dP^T = V dO^T land with lane = query, so max,
+//       1 / sum and delta = rowsum(dO * O) need one shuffle; dS (fp32, split into hi + lo) feeds straight back as the B operand of
+//       dQ^T = K^T dS^T, whose A operand K^T is gathered from the row-major K image with 2-byte reads in the accumulator's key order (a
+//       transposed copy would not fit); writes dQ and the per-query statistics (max, 1 / sum, delta);
+//   k_vit_attention_bwd_kv_pair (a wave owns 32 KEYS; Q, dO pairs resident): S = Q K^T and dP = dO V^T are recomputed with lane = key
+//       (statistics from LDS), P and dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS (A operands gathered from the row-major Q / dO
+//       images), accumulated in registers over the query tiles; writes dK and dV.
+// Every contraction is three MFMA products; the soft-max and its derivative are evaluated in fp32 registers.  Replaces, per layer, the
+// decomposition into five batched pair products with fp32 score-sized temporaries, two soft-max row kernels and ten transposes.
+__device__ __forceinline__ void patt_load_rows(uint16_t* s, const uint16_t* g, int T, int TP, int ld, int tid) {
+  for (int i = tid; i < TP * 8; i += kBlock) {                         // [t][72]: 16-byte chunks, coalesced
+    const int t = i >> 3, c = i & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < T) v = *reinterpret_cast<const uint4*>(g + (size_t)t * ld + c * 8);
+    *reinterpret_cast<uint4*>(s + t * PATT_LDK + c * 8) = v;
+  }
+}
+// A-operand fragment of the TRANSPOSE of a row-major [t][72] image: rows = channel d, k = the eight tokens t0 + {0,1,2,3,8,9,10,11}
+__device__ __forceinline__ bf16x8 patt_tr_frag(const uint16_t* s, int t0, int d) {
+  const uint16_t* p = s + t0 * PATT_LDK + d;
+  uint4 v;
+  v.x = (uint32_t)p[0] | ((uint32_t)p[PATT_LDK] << 16);
+  v.y = (uint32_t)p[2 * PATT_LDK] | ((uint32_t)p[3 * PATT_LDK] << 16);
+  v.z = (uint32_t)p[8 * PATT_LDK] | ((uint32_t)p[9 * PATT_LDK] << 16);
+  v.w = (uint32_t)p[10 * PATT_LDK] | ((uint32_t)p[11 * PATT_LDK] << 16);
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+__device__ __forceinline__ void patt_split8(const float* v, bf16x8& hi, bf16x8& lo) {
+  uint4 h, l;
+  split8(v, h, l);
+  hi = *reinterpret_cast<bf16x8*>(&h);
+  lo = *reinterpret_cast<bf16x8*>(&l);
+}
+#define RART_MFMA3(ACC, AH, AL, BH, BL)                                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, ACC, 0, 0, 0);    \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, ACC, 0, 0, 0);    \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, ACC, 0, 0, 0);
+
+template <int NKT>
+__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd_q_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+                                                                        const uint16_t* __restrict__ o_h, const uint16_t* __restrict__ o_l,
+                                                                        const uint16_t* __restrict__ do_h, const uint16_t* __restrict__ do_l,
+                                                                        uint16_t* __restrict__ dq_h, uint16_t* __restrict__ dq_l,
+                                                                        float4* __restrict__ stats, int T, int H, int ld, int D, float scale,
+                                                                        float scale_log2e) {
+  constexpr int TP = NKT * 32;
+  __shared__ __attribute__((aligned(16))) uint16_t sK[2][TP * PATT_LDK];
+  __shared__ __attribute__((aligned(16))) uint16_t sV[2][TP * PATT_LDK];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+  const size_t boff = (size_t)b * T * ld + h * PATT_HD, doff = (size_t)b * T * D + h * PATT_HD;
+  const uint16_t* const qb[2] = {qkv_h + boff, qkv_l + boff};
+  const uint16_t* const ob[2] = {o_h + doff, o_l + doff};
+  const uint16_t* const db[2] = {do_h + doff, do_l + doff};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    patt_load_rows(sK[p], qb[p] + D, T, TP, ld, tid);
+    patt_load_rows(sV[p], qb[p] + 2 * D, T, TP, ld, tid);
+  }
+  __syncthreads();
+  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
+    const int q = qt * 32 + l31;
+    bf16x8 bq[2][4], bdo[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        uint4 vq = make_uint4(0, 0, 0, 0), vd = make_uint4(0, 0, 0, 0);
+        if (q < T) {
+          vq = *reinterpret_cast<const uint4*>(qb[p] + (size_t)q * ld + kb * 16 + hh * 8);
+          vd = *reinterpret_cast<const uint4*>(db[p] + (size_t)q * D + kb * 16 + hh * 8);
+        }
+        bq[p][kb] = *reinterpret_cast<bf16x8*>(&vq);
+        bdo[p][kb] = *reinterpret_cast<bf16x8*>(&vd);
+      }
+    // delta_q = sum_d dO[q][d] O[q][d]: a lane sums its half of the channels, one shuffle adds the halves
+    float delta = 0.f;
+    if (q < T) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float ov[8], dv[8];
+        join8(*reinterpret_cast<const uint4*>(ob[0] + (size_t)q * D + hh * 32 + c * 8), *reinterpret_cast<const uint4*>(ob[1] + (size_t)q * D + hh * 32 + c * 8), ov);
+        join8(*reinterpret_cast<const uint4*>(db[0] + (size_t)q * D + hh * 32 + c * 8), *reinterpret_cast<const uint4*>(db[1] + (size_t)q * D + hh * 32 + c * 8), dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta = fmaf(ov[j], dv[j], delta);
+      }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sK[0][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sK[1][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        RART_MFMA3(sacc[kt], ah, al, bq[0][kb], bq[1][kb])
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= T) sacc[NKT - 1][r] = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64)) * scale_log2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], scale_log2e, -m));
+        sacc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (hh == 0) stats[(size_t)blockIdx.x * TP + q] = make_float4(m, inv, delta, 0.f);
+    const float sinv = scale * inv;
+    f32x16 dq[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[nt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sV[0][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sV[1][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        RART_MFMA3(dp, ah, al, bdo[0][kb], bdo[1][kb])
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        float dsv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsv[j] = sinv * sacc[kt][8 * kb2 + j] * (dp[8 * kb2 + j] - delta);
+        bf16x8 dsh, dsl;
+        patt_split8(dsv, dsh, dsl);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int t0 = kt * 32 + 16 * kb2 + 4 * hh, dch = nt * 32 + l31;
+          const bf16x8 ah = patt_tr_frag(sK[0], t0, dch), al = patt_tr_frag(sK[1], t0, dch);
+          RART_MFMA3(dq[nt], ah, al, dsh, dsl)
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one key tile at a time
+    }
+    // dq[nt][r] = dQ[query q][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]
+    if (q < T) {
+      const size_t ro = boff + (size_t)q * ld;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v[4] = {dq[nt][4 * g], dq[nt][4 * g + 1], dq[nt][4 * g + 2], dq[nt][4 * g + 3]};
+          uint2 vh, vl;
+          split4(v, vh, vl);
+          *reinterpret_cast<uint2*>(dq_h + ro + nt * 32 + 8 * g + 4 * hh) = vh;
+          *reinterpret_cast<uint2*>(dq_l + ro + nt * 32 + 8 * g + 4 * hh) = vl;
+        }
+    }
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd_kv_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+                                                                         const uint16_t* __restrict__ do_h, const uint16_t* __restrict__ do_l,
+                                                                         uint16_t* __restrict__ dq_h, uint16_t* __restrict__ dq_l,
+                                                                         const float4* __restrict__ stats, int T, int H, int ld, int D, float scale,
+                                                                         float scale_log2e) {
+  constexpr int TP = NKT * 32;
+  __shared__ __attribute__((aligned(16))) uint16_t sQ[2][TP * PATT_LDK];
+  __shared__ __attribute__((aligned(16))) uint16_t sdO[2][TP * PATT_LDK];
+  __shared__ __attribute__((aligned(16))) float4 sStat[TP];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+  const size_t boff = (size_t)b * T * ld + h * PATT_HD, doff = (size_t)b * T * D + h * PATT_HD;
+  const uint16_t* const qb[2] = {qkv_h + boff, qkv_l + boff};
+  const uint16_t* const db[2] = {do_h + doff, do_l + doff};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    patt_load_rows(sQ[p], qb[p], T, TP, ld, tid);
+    patt_load_rows(sdO[p], db[p], T, TP, D, tid);
+  }
+  for (int i = tid; i < TP; i += kBlock) sStat[i] = stats[(size_t)blockIdx.x * TP + i];
+  __syncthreads();
+  for (int kt = wave; kt < NKT; kt += kBlock / 64) {
+    const int key = kt * 32 + l31;
+    const bool key_ok = key < T;
+    bf16x8 bk[2][4], bv[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        uint4 vk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key_ok) {
+          vk = *reinterpret_cast<const uint4*>(qb[p] + (size_t)key * ld + D + kb * 16 + hh * 8);
+          vv = *reinterpret_cast<const uint4*>(qb[p] + (size_t)key * ld + 2 * D + kb * 16 + hh * 8);
+        }
+        bk[p][kb] = *reinterpret_cast<bf16x8*>(&vk);
+        bv[p][kb] = *reinterpret_cast<bf16x8*>(&vv);
+      }
+    // dV^T = dO^T . P and dK^T = Q^T . dS (operands swapped): lane = key, registers = channels
+    f32x16 dvv[2], dkk[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dvv[nt][r] = dkk[nt][r] = 0.f;
+#pragma unroll 1
+    for (int qt = 0; qt < NKT; ++qt) {
+      f32x16 sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int so = (qt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8;
+        const bf16x8 qh = *reinterpret_cast<const bf16x8*>(&sQ[0][so]), ql = *reinterpret_cast<const bf16x8*>(&sQ[1][so]);
+        const bf16x8 dh = *reinterpret_cast<const bf16x8*>(&sdO[0][so]), dl = *reinterpret_cast<const bf16x8*>(&sdO[1][so]);
+        RART_MFMA3(sa, qh, ql, bk[0][kb], bk[1][kb])
+        RART_MFMA3(dp, dh, dl, bv[0][kb], bv[1][kb])
+      }
+      // lane = key kt*32 + l31; register r = query qt*32 + (r&3) + 8*(r>>2) + 4*hh (queries past the sequence have zero Q / dO rows:
+      // whatever probability they get multiplies zeros)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 st = sStat[qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+        const float pv = key_ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], scale_log2e, -st.x)) * st.y : 0.f;
+        sa[r] = pv;
+        dp[r] = scale * pv * (dp[r] - st.z);
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        float pw[8], dw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pw[j] = sa[8 * kb2 + j];
+          dw[j] = dp[8 * kb2 + j];
+        }
+        bf16x8 pbh, pbl, dbh, dbl;
+        patt_split8(pw, pbh, pbl);
+        patt_split8(dw, dbh, dbl);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int t0 = qt * 32 + 16 * kb2 + 4 * hh, dch = nt * 32 + l31;
+          const bf16x8 oh = patt_tr_frag(sdO[0], t0, dch), ol = patt_tr_frag(sdO[1], t0, dch);
+          const bf16x8 qh = patt_tr_frag(sQ[0], t0, dch), ql = patt_tr_frag(sQ[1], t0, dch);
+          RART_MFMA3(dvv[nt], oh, ol, pbh, pbl)
+          RART_MFMA3(dkk[nt], qh, ql, dbh, dbl)
+        }
+      }
+    }
+    // dkk / dvv[nt][r] = dK / dV[key][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]: 8-byte runs of the lane's own key row
+    if (key_ok) {
+      const size_t ro = boff + (size_t)key * ld;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float vk[4] = {dkk[nt][4 * g], dkk[nt][4 * g + 1], dkk[nt][4 * g + 2], dkk[nt][4 * g + 3]};
+          const float vv[4] = {dvv[nt][4 * g], dvv[nt][4 * g + 1], dvv[nt][4 * g + 2], dvv[nt][4 * g + 3]};
+          uint2 kh, kl, vh, vl;
+          split4(vk, kh, kl);
+          split4(vv, vh, vl);
+          *reinterpret_cast<uint2*>(dq_h + ro + D + nt * 32 + 8 * g + 4 * hh) = kh;
+          *reinterpret_cast<uint2*>(dq_l + ro + D + nt * 32 + 8 * g + 4 * hh) = kl;
+          *reinterpret_cast<uint2*>(dq_h + ro + 2 * D + nt * 32 + 8 * g + 4 * hh) = vh;
+          *reinterpret_cast<uint2*>(dq_l + ro + 2 * D + nt * 32 + 8 * g + 4 * hh) = vl;
+        }
+    }
+  }
+}
+#undef RART_MFMA3
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
 }  // namespace
 
@@ -517,6 +802,40 @@ int rart_vit_attention_pair(const void* qkv_hi, const void* qkv_lo, void* out_hi
   }
 #undef RART_PATT_CASE
   RART_CHECK_LAUNCH("rart_vit_attention_pair");
+  return RART_OK;
+}
+
+int rart_vit_attention_bwd_pair(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
+                                const void* dout_lo, void* dqkv_hi, void* dqkv_lo, float* stats, int n, int tokens, int heads, int head_dim,
+                                rart_stream_t stream) {
+  RART_CHECK_ARG(qkv_hi && qkv_lo && out_hi && out_lo && dout_hi && dout_lo && dqkv_hi && dqkv_lo && stats && n > 0 && tokens > 0 && heads > 0,
+                 "rart_vit_attention_bwd_pair: bad arguments");
+  RART_CHECK_ARG(head_dim == 64, "rart_vit_attention_bwd_pair: head_dim must be 64 (ViT-B/16)");
+  RART_CHECK_ARG(tokens <= 224, "rart_vit_attention_bwd_pair: at most 224 tokens (197 for 224x224 / patch 16)");
+  const int D = heads * head_dim;
+  const float scale = 1.0f / sqrtf((float)head_dim), sl2e = scale * 1.4426950408889634f;
+  const dim3 grid((uint32_t)(n * heads));
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t *qh = (const uint16_t*)qkv_hi, *ql = (const uint16_t*)qkv_lo, *oh = (const uint16_t*)out_hi, *ol = (const uint16_t*)out_lo;
+  const uint16_t *dh = (const uint16_t*)dout_hi, *dl = (const uint16_t*)dout_lo;
+  uint16_t *gh = (uint16_t*)dqkv_hi, *gl = (uint16_t*)dqkv_lo;
+  float4* s4 = (float4*)stats;
+#define RART_PATTB_CASE(N)                                                                                                              \
+  hipLaunchKernelGGL(k_vit_attention_bwd_q_pair<N>, grid, dim3(kBlock), 0, st, qh, ql, oh, ol, dh, dl, gh, gl, s4, tokens, heads, 3 * D, D, \
+                     scale, sl2e);                                                                                                      \
+  hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair<N>, grid, dim3(kBlock), 0, st, qh, ql, dh, dl, gh, gl, (const float4*)s4, tokens, heads,  \
+                     3 * D, D, scale, sl2e);
+  switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
+    case 1: RART_PATTB_CASE(1) break;
+    case 2: RART_PATTB_CASE(2) break;
+    case 3: RART_PATTB_CASE(3) break;
+    case 4: RART_PATTB_CASE(4) break;
+    case 5: RART_PATTB_CASE(5) break;
+    case 6: RART_PATTB_CASE(6) break;
+    default: RART_PATTB_CASE(7) break;
+  }
+#undef RART_PATTB_CASE
+  RART_CHECK_LAUNCH("rart_vit_attention_bwd_pair");
   return RART_OK;
 }
 

@@ -448,7 +448,7 @@ class ViTEngine:
         for li, (L, XL) in enumerate(zip(self.layers, X['layers'])):
             qkv = self._get('x3_qkv%d' % li if keep else 'x3_qkv', (2, rows, 3 * D))
             xm = self._get('x3_xm%d' % li, (2, B, T, D)) if keep else x
-            att = self._get('x3_att', (2, B, T, D))
+            att = self._get('x3_att%d' % li if keep else 'x3_att', (2, B, T, D))     # the fused backward reads the output (delta)
             xo = self._get('x3_x%d' % (li + 1), (2, B, T, D)) if keep else x
             _lib.check(lib.rart_layernorm_pair(_lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(L['n1g']), _lib.ptr(L['n1b']), _lib.ptr(ln[0]),
                                                _lib.ptr(ln[1]), rows, D, D, D, 1e-6, sp))
@@ -467,7 +467,7 @@ class ViTEngine:
             if keep:
                 u = self._get('x3_u%d' % li, (2, B, T, L['hidden']))
                 self._gemm_pair(ln, XL['fc1_w'], hid, rows, L['hidden'], D, D, L['hidden'], bias=L['fc1_b'], flags=F_GELU_KEEP, aux=u)
-                saved.append((x, xm, qkv, u))
+                saved.append((x, xm, qkv, u, att))
             else:
                 self._gemm_pair(ln, XL['fc1_w'], hid, rows, L['hidden'], D, D, L['hidden'], bias=L['fc1_b'], flags=F_GELU)
             self._gemm_pair(hid, XL['fc2_w'], xo, rows, D, L['hidden'], L['hidden'], D, bias=L['fc2_b'], res=xm)
@@ -483,8 +483,9 @@ class ViTEngine:
 
     def _backward_x3(self, dl, std):
         """d(loss)/d(x01) from the fp32 loss gradient dl [B][classes]: the backward-to-input chain of `forward_backward` on pairs.
-        The attention backward is the decomposition into batched products (S = Q K^T recomputed, dP = dO V^T, dQ = dS K,
-        dK = dS^T Q, dV = P^T dO) with fp32 score-sized temporaries; GELU' runs in the fc2 dgrad epilogue."""
+        The attention backward is the two-launch fused pair kernel (csrc/vit_pair.hip) or, with `fused_attention_bwd` off (the
+        cross-check), the decomposition into batched products (S = Q K^T recomputed, dP = dO V^T, dQ = dS K, dK = dS^T Q,
+        dV = P^T dO) with fp32 score-sized temporaries; GELU' runs in the fc2 dgrad epilogue."""
         torch = _lib.require_gpu()
         lib, sp = self.lib, _lib.stream_ptr()
         saved, x_last, (B, Himg, Wimg, P, T) = self._saved
@@ -507,7 +508,7 @@ class ViTEngine:
         m_all = BH * t_pad
         for li in range(len(self.layers) - 1, -1, -1):
             L, XL = self.layers[li], X['layers'][li]
-            x_in, xm, qkv, u = saved[li]
+            x_in, xm, qkv, u, att = saved[li]
             dh = self._get('x3_g_hid', (2, rows, L['hidden']))
             self._gemm_pair(dx, XL['fc2_wd'], dh, rows, L['hidden'], D, D, L['hidden'], flags=F_GELU_BWD, aux=u)    # du = (dx W2) gelu'(u)
             dln = self._get('x3_g_ln', (2, rows, D))
@@ -518,29 +519,35 @@ class ViTEngine:
                                                    1e-6, sp))
             datt = self._get('x3_g_att', (2, rows, D))
             self._gemm_pair(dxm, XL['proj_wd'], datt, rows, D, D, D, D)
-            # ---- attention backward, batched over (image, head)
-            probs = self._scores_probs_x3(qkv, B, T)
-            dprobs = self._get('x3_dprobs', (BH, T, s_ld), torch.float32)
-            self._gemm_pair(datt, qkv, dprobs, T, s_ld, hd, D, s_ld, ldw=3 * D, flags=F_OUT_F32, w_rows=T, w_off=2 * D,
-                            batched=dict(n=BH, inner=H, a=(T * D, hd), w=(T * 3 * D, hd), c=(H * T * s_ld, T * s_ld)))       # dP = dO V^T
-            ds = self._get('x3_dscores', (2, BH, T, t_pad))
-            _lib.check(lib.rart_softmax_bwd_rows_pair(_lib.ptr(probs[0]), _lib.ptr(probs[1]), _lib.ptr(dprobs), _lib.ptr(ds[0]),
-                                                      _lib.ptr(ds[1]), BH * T, T, t_pad, s_ld, t_pad, scale, sp))
-            kt = self._transpose_heads_x3(qkv, 'x3_kt', B, T, 3 * D, D)
-            qt = self._transpose_heads_x3(qkv, 'x3_qt', B, T, 3 * D, 0)
-            dot = self._transpose_heads_x3(datt, 'x3_dot', B, T, D, 0)
-            hb = dict(n=BH, inner=H, a=(H * T * t_pad, T * t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * 3 * D, hd))
-            self._gemm_pair(ds, kt, dqkv, T, hd, t_pad, t_pad, 3 * D, ldw=t_pad, w_rows=hd, batched=hb)                   # dQ = dS K
-            # query-contiguous copies of dS and P: [t_pad (key)][BH * t_pad (image-head, query)]; queries past T are zero columns
-            ds_t = self._get('x3_ds_t', (2, t_pad, m_all))
-            p_t = self._get('x3_p_t', (2, t_pad, m_all))
-            for src_m, dst_m in ((ds, ds_t), (probs, p_t)):
-                for p in range(2):
-                    _lib.check(lib.rart_transpose_gather_bf16(_lib.ptr(src_m[p]), _lib.ptr(dst_m[p]), BH, T, 1, t_pad, t_pad, 1, 1, 1, 1,
-                                                              zero, zero, m_all, 0, 0, sp))
-            tb = dict(n=BH, inner=H, a=(H * t_pad, t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * 3 * D, hd))
-            self._gemm_pair(ds_t, qt, dqkv, T, hd, t_pad, m_all, 3 * D, ldw=t_pad, w_rows=hd, batched=tb, dst_off=D)      # dK = dS^T Q
-            self._gemm_pair(p_t, dot, dqkv, T, hd, t_pad, m_all, 3 * D, ldw=t_pad, w_rows=hd, batched=tb, dst_off=2 * D)  # dV = P^T dO
+            # ---- attention backward, per (image, head)
+            if self.fused_attention_bwd and hd == 64 and T <= 224:
+                stats = self._get('x3_att_stats', (BH, t_pad, 4), torch.float32)
+                _lib.check(lib.rart_vit_attention_bwd_pair(_lib.ptr(qkv[0]), _lib.ptr(qkv[1]), _lib.ptr(att[0]), _lib.ptr(att[1]),
+                                                           _lib.ptr(datt[0]), _lib.ptr(datt[1]), _lib.ptr(dqkv[0]), _lib.ptr(dqkv[1]),
+                                                           _lib.ptr(stats), B, T, H, hd, sp))
+            else:
+                probs = self._scores_probs_x3(qkv, B, T)
+                dprobs = self._get('x3_dprobs', (BH, T, s_ld), torch.float32)
+                self._gemm_pair(datt, qkv, dprobs, T, s_ld, hd, D, s_ld, ldw=3 * D, flags=F_OUT_F32, w_rows=T, w_off=2 * D,
+                                batched=dict(n=BH, inner=H, a=(T * D, hd), w=(T * 3 * D, hd), c=(H * T * s_ld, T * s_ld)))       # dP = dO V^T
+                ds = self._get('x3_dscores', (2, BH, T, t_pad))
+                _lib.check(lib.rart_softmax_bwd_rows_pair(_lib.ptr(probs[0]), _lib.ptr(probs[1]), _lib.ptr(dprobs), _lib.ptr(ds[0]),
+                                                          _lib.ptr(ds[1]), BH * T, T, t_pad, s_ld, t_pad, scale, sp))
+                kt = self._transpose_heads_x3(qkv, 'x3_kt', B, T, 3 * D, D)
+                qt = self._transpose_heads_x3(qkv, 'x3_qt', B, T, 3 * D, 0)
+                dot = self._transpose_heads_x3(datt, 'x3_dot', B, T, D, 0)
+                hb = dict(n=BH, inner=H, a=(H * T * t_pad, T * t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * 3 * D, hd))
+                self._gemm_pair(ds, kt, dqkv, T, hd, t_pad, t_pad, 3 * D, ldw=t_pad, w_rows=hd, batched=hb)                   # dQ = dS K
+                # query-contiguous copies of dS and P: [t_pad (key)][BH * t_pad (image-head, query)]; queries past T are zero columns
+                ds_t = self._get('x3_ds_t', (2, t_pad, m_all))
+                p_t = self._get('x3_p_t', (2, t_pad, m_all))
+                for src_m, dst_m in ((ds, ds_t), (probs, p_t)):
+                    for p in range(2):
+                        _lib.check(lib.rart_transpose_gather_bf16(_lib.ptr(src_m[p]), _lib.ptr(dst_m[p]), BH, T, 1, t_pad, t_pad, 1, 1, 1, 1,
+                                                                  zero, zero, m_all, 0, 0, sp))
+                tb = dict(n=BH, inner=H, a=(H * t_pad, t_pad), w=(H * hd * t_pad, hd * t_pad), c=(T * 3 * D, hd))
+                self._gemm_pair(ds_t, qt, dqkv, T, hd, t_pad, m_all, 3 * D, ldw=t_pad, w_rows=hd, batched=tb, dst_off=D)      # dK = dS^T Q
+                self._gemm_pair(p_t, dot, dqkv, T, hd, t_pad, m_all, 3 * D, ldw=t_pad, w_rows=hd, batched=tb, dst_off=2 * D)  # dV = P^T dO
             self._gemm_pair(dqkv, XL['qkv_wd'], dln, rows, D, 3 * D, 3 * D, D)
             _lib.check(lib.rart_layernorm_bwd_pair(_lib.ptr(dln[0]), _lib.ptr(dln[1]), _lib.ptr(x_in[0]), _lib.ptr(x_in[1]),
                                                    _lib.ptr(L['n1g']), _lib.ptr(dxm[0]), _lib.ptr(dxm[1]), _lib.ptr(dx[0]), _lib.ptr(dx[1]),

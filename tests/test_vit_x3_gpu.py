@@ -332,6 +332,57 @@ def test_fused_pair_attention_vs_fp64_every_key_tile_count(T):
     assert err <= 2.5e-5
 
 
+@pytest.mark.parametrize('T', [197, 33, 224, 64, 130])
+def test_fused_pair_attention_backward_vs_fp64_autograd(T):
+    """rart_vit_attention_bwd_pair (query-side launch: dQ + per-query statistics; key-side launch: dK, dV) against fp64 autograd of
+    soft-max attention on the values the pairs represent -- O is the fp64 forward's output rounded to a pair, as the engine hands it."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(100 + T)
+    B, H, hd = 2, 3, 64
+    D = H * hd
+    qkv = _split((torch.randn(B * T, 3 * D, generator=g) * 1.5).cuda())
+    dout = _split(torch.randn(B * T, D, generator=g).cuda())
+    q64 = _f64(qkv).requires_grad_(True)
+    qh = q64.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    o64 = (torch.softmax(qh[0] @ qh[1].transpose(-1, -2) / 8.0, -1) @ qh[2]).permute(0, 2, 1, 3).reshape(B * T, D)
+    (o64 * _f64(dout)).sum().backward()
+    out = _split(o64.detach().float())
+    dqkv = torch.full((2, B * T, 3 * D), float('nan'), dtype=torch.bfloat16, device='cuda')
+    stats = torch.empty(B * H * ((T + 31) // 32 * 32) * 4, dtype=torch.float32, device='cuda')
+    _lib.check(lib.rart_vit_attention_bwd_pair(_lib.ptr(qkv[0]), _lib.ptr(qkv[1]), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(dout[0]),
+                                               _lib.ptr(dout[1]), _lib.ptr(dqkv[0]), _lib.ptr(dqkv[1]), _lib.ptr(stats), B, T, H, hd,
+                                               _lib.stream_ptr()))
+    got, want = _f64(dqkv), q64.grad
+    assert torch.isfinite(got).all()
+    for name, lo in (('dQ', 0), ('dK', D), ('dV', 2 * D)):
+        w = want[:, lo:lo + D]
+        err = (got[:, lo:lo + D] - w).abs().max().item() / w.abs().max().item()
+        print('pair attention backward T=%d %s: max err %.2e of scale' % (T, name, err))
+        assert err <= 3e-5, (name, err)
+
+
+def test_vit_x3_fused_attention_backward_matches_the_unfused_path(setup):
+    """forward_backward with the fused pair attention backward against the same engine on the decomposition into batched pair
+    products: the same logits bit for bit (the forward is shared), the input gradient to summation-order noise."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(3, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    assert eng.fused_attention_bwd
+    la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    la, ga = la.clone(), ga.clone()
+    eng.fused_attention_bwd = False
+    try:
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.fused_attention_bwd = True
+    assert torch.equal(la, lb)
+    err = (ga - gb).abs().max().item() / gb.abs().max().item()
+    print('ViT x3 input gradient, fused vs unfused attention backward: %.2e of scale' % err)
+    assert err <= 5e-5
+
+
 def test_vit_x3_fused_attention_matches_the_unfused_path(setup):
     """The forward with the fused pair attention against the same engine on the decomposition into batched pair products (fp32 scores,
     soft-max rows, V transposes): same operands, other summation order."""
