@@ -595,6 +595,10 @@ int rart_engine_stem_col2im_f32(const float* patches, float* grad, int n, int h,
  * (autograd of attack.py:21-22 / autopgd_base.py:271-289 through conv1-bn1-relu-maxpool) */
 int rart_engine_stem_bwd_fused(const void* dpool, const void* argmax, const void* wtab, float* grad, int n, int h, int w,
                                const float* std_host, rart_stream_t stream);
+/* The reference-precision form (csrc/stem_pair.hip): pooled gradient and weight table as hi + lo planes of bf16, three MFMA products per
+ * fragment pair; replaces rart_engine_maxpool_bwd_pair -> rart_gemm_pair_bf16 (patches, fp32) -> rart_engine_stem_col2im_f32. */
+int rart_engine_stem_bwd_fused_pair(const void* dpool_hi, const void* dpool_lo, const void* argmax, const void* wtab_hi, const void* wtab_lo,
+                                    float* grad, int n, int h, int w, const float* std_host, rart_stream_t stream);
 /* The stem FORWARD as one persistent kernel: normalisation + hi/lo bf16 split (rart_engine_prep_input), 7x7/2 convolution
  * with the folded BatchNorm bias + ReLU (the K = 448 row-tap GEMM) and the 3x3/2 max pool (rart_engine_maxpool_keep) fused;
  * the 112 x 112 x 64 stem output never reaches HBM.  wgt: bf16 [64][wgt_row_stride], row n, column r*32 + s*4 + c =

@@ -125,6 +125,7 @@ SIGNATURES = {
     'rart_engine_stem_col2im': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_stem_fwd_fused': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                            c_int, c_void_p, c_void_p, c_void_p]),
+    'rart_engine_stem_bwd_fused_pair': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_stem_bwd_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_maxpool_pair': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'rart_engine_maxpool_bwd_pair': (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_void_p]),

@@ -152,6 +152,9 @@ class ResNet50Engine:
             self.stem_w = _bf16(torch.cat([wrow, wrow_l, wrow], 1)).to(dev)      # x_hi.w_hi, x_hi.w_lo, x_lo.w_hi row taps
             wpl = wl.permute(2, 3, 1, 0).reshape(147, 64)
             self.stem_wd = _bf16(_pad_rows(torch.cat([wp, wpl, wp], 1), _rows_mult(self.stem_patch_cols))).to(dev)
+            wt32 = self._stem_bwd_table(st.w_folded, dtype=torch.float32)           # fused pair stem backward (stem_pair.hip)
+            wt_hi = wt32.to(torch.bfloat16)
+            self.stem_wt_pair = torch.stack([wt_hi, (wt32 - wt_hi.float()).to(torch.bfloat16)]).contiguous().to(dev)
         self.fused_stem_bwd = True       # False: max-pool bwd -> patches GEMM -> col2im (kept as the cross-check)
         self.sign_bit_masks = True       # False: the backward reads the bf16 activations for their ReLU sign (cross-check)
         self.halo_conv3x3 = True         # False: layer1 / layer2 3x3 convs on the generic implicit GEMM (cross-check)
@@ -265,8 +268,8 @@ class ResNet50Engine:
                 bias_sum(cc.bias, ds.bias, ds.bias_sum)
 
     @staticmethod
-    def _stem_bwd_table(wb):
-        """bf16 [16][1024] table of rart_engine_stem_bwd_fused from the folded stem weights wb [64][3][7][7]:
+    def _stem_bwd_table(wb, dtype=None):
+        """bf16 (or `dtype`) [16][1024] table of rart_engine_stem_bwd_fused from the folded stem weights wb [64][3][7][7]:
         row (py*2+px)*3+c, column ((dp+1)*4+(dq+1))*64+k = W[k][c][py+3-2dp][px+3-2dq] (0 outside 0..6)."""
         import torch
         t = torch.zeros(16, 16, 64, dtype=wb.dtype, device=wb.device)
@@ -282,7 +285,7 @@ class ResNet50Engine:
                             continue
                         for c in range(3):
                             t[(py * 2 + px) * 3 + c, (dp + 1) * 4 + (dq + 1)] = wb[:, c, r, s_]
-        return t.reshape(16, 1024).to(torch.bfloat16).contiguous()
+        return t.reshape(16, 1024).to(dtype or torch.bfloat16).contiguous()
 
     # ------------------------------------------------------------------ re-fold from the live parameters
     def refold(self, model):
@@ -902,6 +905,12 @@ class ResNet50Engine:
             dz = dx
         grad = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
         stdf = (ctypes.c_float * 3)(*std)
+        if self.fused_stem_bwd:
+            # stem: max-pool backward + ReLU mask + transposed 7x7/2 conv to the fp32 image on pairs, one kernel (stem_pair.hip)
+            _lib.check(lib.rart_engine_stem_bwd_fused_pair(_lib.ptr(dz[0]), _lib.ptr(dz[1]), _lib.ptr(acts['p1_argmax']),
+                                                           _lib.ptr(self.stem_wt_pair[0]), _lib.ptr(self.stem_wt_pair[1]),
+                                                           _lib.ptr(grad), B, H, W, stdf, sp))
+            return grad
         h1, w1 = H // 2, W // 2
         dz1 = self._get('x3_g_y1', (2, B, h1, w1, 64))
         _lib.check(lib.rart_engine_maxpool_bwd_pair(_lib.ptr(acts['p1_argmax']), _lib.ptr(dz), self._lo(dz), _lib.ptr(dz1),

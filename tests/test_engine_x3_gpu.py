@@ -344,6 +344,33 @@ def test_x3_engine_new_kernel_matches_the_round3_igemm_pair_path(setup):
     assert rel <= 0.15 and cos >= 0.98
 
 
+@pytest.mark.parametrize('HW', [(96, 128), (224, 224), (32, 64)])
+def test_x3_fused_stem_backward_matches_the_three_launch_chain(setup, HW):
+    """rart_engine_stem_bwd_fused_pair (max-pool backward + ReLU mask + transposed 7x7/2 conv on pairs, one kernel) against the chain it
+    replaces (rart_engine_maxpool_bwd_pair -> patches GEMM with fp32 output -> rart_engine_stem_col2im_f32) inside the same
+    forward + backward: identical forward, identical decisions, so only the summation order of the last contraction differs.  Image
+    sizes with full, partial and single 16 x 16 tiles of the stem grid."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(3, 3, HW[0], HW[1], generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    assert eng.fused_stem_bwd
+    la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    la, ga = la.clone(), ga.clone()
+    eng.fused_stem_bwd = False
+    try:
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.fused_stem_bwd = True
+    assert torch.equal(la, lb)
+    assert torch.isfinite(ga).all()
+    a, b = ga.double().flatten(1), gb.double().flatten(1)
+    rel = ((a - b).norm(dim=1) / b.norm(dim=1)).max().item()
+    mx = (a - b).abs().max().item() / b.abs().max().item()
+    print('x3 fused stem backward vs chain %s: rel L2 %.2e, max %.2e of scale' % (HW, rel, mx))
+    assert rel <= 2e-6 and mx <= 2e-6
+
+
 def test_x3_engine_b256_matches_small_batches_bit_for_bit(setup):
     """The reference-precision ResNet-50 engine at the benchmark's B = 256: every 32nd image of a forward / forward + backward equals the
     same image in a batch of 2 bit for bit (every tile of k_gemm_pair sums a row's K slices in the same order whatever the batch), and
