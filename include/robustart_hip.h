@@ -411,6 +411,32 @@ typedef struct rart_gemm_pair_desc {
 } rart_gemm_pair_desc;
 int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stream);
 
+/* The second half of a ResNet Bottleneck of the reference-precision engine as ONE launch (csrc/conv_tail_pair.hip): 3x3 stride-1 pad-1
+ * convolution (c_mid -> c_mid channels, c_mid = 64 or 128) + point-wise step + the 1x1 expansion (c_mid -> 4 c_mid) + skip pair +
+ * point-wise step, on hi + lo planes of bf16 with three MFMA products per contraction; the c_mid-channel intermediate stays in registers.
+ *   forward  (Bottleneck.forward, conv2-bn2-relu-conv3-bn3-add-relu):  relu_mid = relu_out = 1, biases set, sign_* receive the 1-bit
+ *            (value > 0) tensors the backward masks with;
+ *   backward (autograd of attack.py:21-22 / autopgd_base.py:271-289 through conv1^T after conv2^T): tables transposed / taps flipped,
+ *            mask_mid / mask_out = those 1-bit tensors, res = the gradient arriving over the identity skip.
+ * w_*: the 3x3's table, row = output channel, k = tap * c_mid + c, row stride ldw elements.  t_*: the 1x1's [4 c_mid][c_mid] matrix
+ * in MFMA fragment order: element ((blk * (c_mid / 16) + s) * 64 + h * 32 + r) * 8 + e = T[blk * 32 + r][16 s + 8 h + e].
+ * 1-bit tensors: byte (position * channels + channel) / 8, bit channel % 8. */
+typedef struct rart_conv_tail_desc {
+  const void* a_hi;  const void* a_lo;       /* input pair [batch][h][w][c_mid] */
+  const void* w_hi;  const void* w_lo;
+  const void* t_hi;  const void* t_lo;
+  const float* bias_mid;                     /* [c_mid] or null */
+  const float* bias_out;                     /* [4 c_mid] or null */
+  const void* mask_mid;  const void* mask_out;
+  void* sign_mid;  void* sign_out;
+  const void* res_hi;  const void* res_lo;   /* skip pair [batch][h][w][4 c_mid] or null */
+  void* dst_hi;  void* dst_lo;               /* [batch][h][w][4 c_mid] */
+  int batch, h, w, c_mid, ldw, relu_mid, relu_out;
+  int tap_dy[9], tap_dx[9];                  /* source pixel of tap i = (y + tap_dy[i], x + tap_dx[i]); zero outside the image */
+} rart_conv_tail_desc;
+int rart_conv3x3_tail_pair_supported(int c_mid);
+int rart_conv3x3_tail_pair(const rart_conv_tail_desc* desc_host, rart_stream_t stream);
+
 /* Row / elementwise kernels of the reference-precision ViT-B/16 engine (csrc/vit_pair.hip): every tensor a pair of bf16 planes, the
  * arithmetic in fp32 as the fp32 module (timm ViT-B/16, RobustART/model/__init__.py:1 -> absent submodule) does it.
  * add_pos_cls: x[b][0][:] = cls_pos0, x[b][t][:] += pos[t].  layernorm: eps inside the root, biased variance; rows of dim <= 1024.

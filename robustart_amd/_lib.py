@@ -125,6 +125,8 @@ SIGNATURES = {
     'rart_engine_stem_col2im': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_stem_fwd_fused': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                            c_int, c_void_p, c_void_p, c_void_p]),
+    'rart_conv3x3_tail_pair_supported': (c_int, [c_int]),
+    'rart_conv3x3_tail_pair': (c_int, [c_void_p, c_void_p]),
     'rart_engine_stem_bwd_fused_pair': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_stem_bwd_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_maxpool_pair': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -216,6 +218,14 @@ class GemmPairDesc(ctypes.Structure):
                [('tap_dy', ctypes.c_int32 * 16), ('tap_dx', ctypes.c_int32 * 16)] + \
                [(n, ctypes.c_int32) for n in ('dst_h', 'dst_w', 'dst_sy', 'dst_sx', 'dst_oy', 'dst_ox')] + \
                [('mask_bits', c_void_p), ('sign_out', c_void_p), ('tile_n', ctypes.c_int32), ('tile_m', ctypes.c_int32)]
+
+
+class ConvTailDesc(ctypes.Structure):
+    """rart_conv_tail_desc (include/robustart_hip.h): 3x3 + 1x1 expansion of a Bottleneck on split-bf16 pairs, one launch."""
+    _fields_ = [(n, c_void_p) for n in ('a_hi', 'a_lo', 'w_hi', 'w_lo', 't_hi', 't_lo', 'bias_mid', 'bias_out', 'mask_mid', 'mask_out',
+                                        'sign_mid', 'sign_out', 'res_hi', 'res_lo', 'dst_hi', 'dst_lo')] + \
+               [(n, ctypes.c_int32) for n in ('batch', 'h', 'w', 'c_mid', 'ldw', 'relu_mid', 'relu_out')] + \
+               [('tap_dy', ctypes.c_int32 * 9), ('tap_dx', ctypes.c_int32 * 9)]
 
 
 _lib = None

@@ -168,6 +168,7 @@ class ResNet50Engine:
         self.fused_bottleneck_s2_bwd = True   # False: their backward-to-input as seven conv launches (cross-check)
         self.small_m_fc = True           # False: the classifier head and its backward on the implicit GEMM (cross-check)
         self.pair_tile = (0, 0)
+        self.fused_tail_pair = True      # reference-precision mode: 3x3 + 1x1 expansion of a Bottleneck as one launch (conv_tail_pair.hip); False: two launches (cross-check)
         self.pair_gemm_kernel = True     # reference-precision mode: False = the three products as 3 x the taps of the implicit GEMM (round 3; cross-check)
         self.blocks = []
         for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
@@ -196,6 +197,28 @@ class ResNet50Engine:
         self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
         if not split:
             self._pack_frag_tables()
+        else:
+            self._pack_tail_tables()
+
+    def _pack_tail_tables(self):
+        """Reference-precision mode: the 1x1 expansion tables of rart_conv3x3_tail_pair in MFMA fragment order, as [2 (hi, lo)][rows * k]:
+        element ((blk * (k / 16) + s) * 64 + h * 32 + r) * 8 + e = T[blk * 32 + r][16 s + 8 h + e].  `tail_fwd` on conv3 (rows = its
+        output channels), `tail_bwd` on conv1 of an identity block (rows = its INPUT channels: the transposed table of the backward)."""
+        torch = _lib.require_gpu()
+
+        def frag(tab, rows, k):          # tab: the [rows_padded][hi | lo | hi] table of _Conv(split=True)
+            out = []
+            for pl in range(2):
+                w = tab[:rows, pl * k:(pl + 1) * k]
+                out.append(w.reshape(rows // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1))
+            return torch.stack(out).contiguous()
+        for ca, cb, cc, ds in self.blocks:
+            if not (cb.r == 3 and cb.stride == 1 and cb.pad == 1 and cb.cin == cb.cout and self.lib.rart_conv3x3_tail_pair_supported(cb.cin)):
+                continue
+            if cc.cin == cb.cout and cc.cout == 4 * cb.cout and cc.r == 1 and cc.stride == 1:
+                cc.tail_fwd = frag(cc.w_fwd, cc.cout, cc.cin)
+            if ds is None and ca.cout == cb.cin and ca.cin == 4 * cb.cin and ca.r == 1 and ca.stride == 1:
+                ca.tail_bwd = frag(ca.bwd[0][2], ca.cin, ca.cout)
 
     def _pack_frag_tables(self, record=None, sums=None):
         """MFMA-fragment-ordered copies of the 3x3 tables the LDS-resident kernels (conv3x3_halo.hip, bottleneck_fused.hip)
@@ -508,6 +531,36 @@ class ResNet50Engine:
             self.profile.append((3 * 2.0 * batch * grid[0] * grid[1] * k_tot * n_cols, e0, e1, 'gemm_pair'))   # MFMA FLOPs issued
             return
         _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _tail(self, src, wgt, taps, tail, dst, batch, hw, c_mid, bias_mid=None, bias_out=None, res=None, mask_mid=None, mask_out=None,
+              sign_mid=None, sign_out=None, relu=False):
+        """3x3 (c_mid -> c_mid) + point-wise step + 1x1 expansion (c_mid -> 4 c_mid) + skip pair + point-wise step of the
+        reference-precision mode as ONE launch (csrc/conv_tail_pair.hip).  src / dst / res: pair tensors; wgt: the 3x3's
+        [rows][hi | lo | hi] table; tail: `_pack_tail_tables`' [2][...] fragment-ordered 1x1 table."""
+        k_tot = 9 * c_mid
+        assert src.shape[0] == 2 and wgt.shape[1] == 3 * k_tot and len(taps) == 9
+        d = _lib.ConvTailDesc()
+        d.a_hi, d.a_lo = src[0].data_ptr(), src[1].data_ptr()
+        d.w_hi, d.w_lo = wgt.data_ptr(), wgt.data_ptr() + 2 * k_tot
+        d.t_hi, d.t_lo = tail[0].data_ptr(), tail[1].data_ptr()
+        d.bias_mid, d.bias_out = _lib.ptr(bias_mid), _lib.ptr(bias_out)
+        d.mask_mid, d.mask_out, d.sign_mid, d.sign_out = _lib.ptr(mask_mid), _lib.ptr(mask_out), _lib.ptr(sign_mid), _lib.ptr(sign_out)
+        if res is not None:
+            d.res_hi, d.res_lo = res[0].data_ptr(), res[1].data_ptr()
+        d.dst_hi, d.dst_lo = dst[0].data_ptr(), dst[1].data_ptr()
+        d.batch, d.h, d.w, d.c_mid, d.ldw = batch, hw[0], hw[1], c_mid, 3 * k_tot
+        d.relu_mid = d.relu_out = 1 if relu else 0
+        for i, (dy, dx) in enumerate(taps):
+            d.tap_dy[i], d.tap_dx[i] = dy, dx
+        if self.profile is not None:
+            torch = _lib.require_gpu()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(self.lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
+            e1.record()
+            self.profile.append((3 * 2.0 * batch * hw[0] * hw[1] * (k_tot * c_mid + 4 * c_mid * c_mid), e0, e1, 'conv_tail_pair'))   # MFMA FLOPs issued
+            return
+        _lib.check(self.lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
 
     def _fc(self, a, w, out, m, n, k, bias=None):
         """The classifier head / its backward: rart_gemm_small_m_bf16 (one workgroup per 32 x 32 tile, waves split K) instead of the
@@ -846,20 +899,25 @@ class ResNet50Engine:
         x, xhw = p1, (h2, w2)
         for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
             ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
+            tail = self.fused_tail_pair and getattr(cc, 'tail_fwd', None) is not None and self._fits32(B, ohw, cc.cout)
             ya = self._get('x3_b%d_a' % bi, (2, B, xhw[0], xhw[1], ca.cout))
-            yb = self._get('x3_b%d_b' % bi, (2, B, ohw[0], ohw[1], cb.cout))
+            yb = None if tail else self._get('x3_b%d_b' % bi, (2, B, ohw[0], ohw[1], cb.cout))
             yc = self._get('x3_b%d_c' % bi, (2, B, ohw[0], ohw[1], cc.cout))
             sa = self._get('b%d_a_sign' % bi, (B, xhw[0], xhw[1], ca.cout // 8), torch.uint8) if keep else None
             sb = self._get('b%d_b_sign' % bi, (B, ohw[0], ohw[1], cb.cout // 8), torch.uint8) if keep else None
             sc = self._get('b%d_c_sign' % bi, (B, ohw[0], ohw[1], cc.cout // 8), torch.uint8) if keep else None
             self._conv_fwd(ca, x, xhw, ya, True, sign=sa, pair=True)
-            self._conv_fwd(cb, ya, xhw, yb, True, sign=sb, pair=True)
             if ds is not None:
                 sk = self._get('x3_b%d_ds' % bi, (2, B, ohw[0], ohw[1], cc.cout))
                 self._conv_fwd(ds, x, xhw, sk, False, pair=True)
             else:
                 sk = x
-            self._conv_fwd(cc, yb, ohw, yc, True, res=sk, sign=sc, pair=True)
+            if tail:         # conv2 + relu + conv3 + skip + relu in one launch: the 3x3's output never exists in HBM
+                self._tail(ya, cb.w_fwd, cb.fwd_taps, cc.tail_fwd, yc, B, ohw, cb.cout, bias_mid=cb.bias, bias_out=cc.bias, res=sk,
+                           sign_mid=sb, sign_out=sc, relu=True)
+            else:
+                self._conv_fwd(cb, ya, xhw, yb, True, sign=sb, pair=True)
+                self._conv_fwd(cc, yb, ohw, yc, True, res=sk, sign=sc, pair=True)
             acts['b%d' % bi] = (x, xhw, ya, yb, yc, ohw)
             acts['b%d_masks' % bi] = (xs, sa, sb)
             x, xhw, xs = yc, ohw, sc
@@ -892,11 +950,17 @@ class ResNet50Engine:
             ca, cb, cc, ds = self.blocks[bi]
             x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
             mx, ma, mb = acts['b%d_masks' % bi]
-            dzb = self._get('x3_g_b', tuple(yb.shape))
+            dzb = self._get('x3_g_b', (2, B, ohw[0], ohw[1], cb.cout))
             self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb, pair=True)
+            dx = self._get('x3_g_out_%d' % (bi - 1), tuple(x.shape))
+            if (self.fused_tail_pair and getattr(ca, 'tail_bwd', None) is not None and ma is not None and mx is not None
+                    and self._fits32(B, xhw, ca.cin)):
+                # conv2^T + mask + conv1^T + identity-skip gradient + mask in one launch
+                self._tail(dzb, cb.bwd[0][2], cb.bwd[0][1], ca.tail_bwd, dx, B, xhw, cb.cin, res=dz, mask_mid=ma, mask_out=mx)
+                dz = dx
+                continue
             dza = self._get('x3_g_a', tuple(ya.shape))
             self._conv_bwd(cb, dzb, ohw, dza, xhw, mask=ma, pair=True)
-            dx = self._get('x3_g_out_%d' % (bi - 1), tuple(x.shape))
             if ds is None:
                 self._conv_bwd(ca, dza, xhw, dx, xhw, res=dz, mask=mx, pair=True)            # identity skip
             else:

@@ -82,7 +82,18 @@ def wrapped_s2b(g_, ca, cb, cc, ds, m2, m1, m0, dx_, B_, xhw):
     e0.record(); r = orig_s2b(g_, ca, cb, cc, ds, m2, m1, m0, dx_, B_, xhw); e1.record()
     rows.append(((pout, ca.cin * 4 + 9 * cb.cin + cc.cin + ds.cin, cc.cout, 93), fl, by, e0, e1))   # taps column 93 = fused stride-2 block (backward)
     return r
+orig_tail = eng._tail
+def wrapped_tail(src, wgt, taps, tail, dst, batch, hw, c_mid, **kw):
+    M = batch * hw[0] * hw[1]
+    pair_b = 4      # bytes per element of a pair tensor
+    by = M * c_mid * pair_b + M * 4 * c_mid * pair_b * (2 if kw.get('res') is not None else 1) + (9 * c_mid * c_mid + 4 * c_mid * c_mid) * pair_b + \
+        sum(M * c * 0.125 for c, m_ in ((c_mid, kw.get('mask_mid')), (c_mid, kw.get('sign_mid')), (4 * c_mid, kw.get('mask_out')), (4 * c_mid, kw.get('sign_out'))) if m_ is not None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r = orig_tail(src, wgt, taps, tail, dst, batch, hw, c_mid, **kw); e1.record()
+    rows.append(((M, 9 * c_mid + 4 * c_mid, c_mid, 92), 2.0 * M * c_mid * (9 * c_mid + 4 * c_mid), by, e0, e1))   # taps column 92 = 3x3 + 1x1 expansion, one launch (fp32x)
+    return r
 for _ in range(2): eng.forward_backward(x, MEAN, STD, y, 0)
+eng._tail = wrapped_tail
 eng._bneck14 = wrapped_b14
 eng._bneck_s2_bwd = wrapped_s2b
 eng._bneck_s2 = wrapped_s2
@@ -94,6 +105,7 @@ rows.clear()
 eng.forward_backward(x, MEAN, STD, y, 0)
 torch.cuda.synchronize()
 eng._gemm = orig
+eng._tail = orig_tail
 eng._halo = orig_halo
 eng._bneck = orig_bneck
 eng._bneck14 = orig_b14
@@ -109,7 +121,7 @@ for key, (us, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     floor = max(fl / PEAK_F, by / PEAK_B) * 1e6
     tot += us; totf += floor
     print('%9d %6d %6d %4d %4d %9.1f %8.1f %8.1f %9.1f %6.3f' % (*key, cnt, us, fl / us / 1e6, by / us / 1e3, floor, floor / us))
-print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 / 95 = the fused Bottleneck kernels of layer1 / layer3 / layer2 / layer4: one row = 1x1 + 3x3 + 1x1; 94 / 93 = the fused stride-2 first blocks of layer2 / layer3, forward / backward)')
+print('(taps 99 = the LDS-resident 3x3 kernels, 98 / 97 / 96 / 95 = the fused Bottleneck kernels of layer1 / layer3 / layer2 / layer4: one row = 1x1 + 3x3 + 1x1; 94 / 93 = the fused stride-2 first blocks of layer2 / layer3, forward / backward; 92 = 3x3 + 1x1 expansion of the fp32x engine, one launch)')
 print('conv launches %d: measured %.1f us, roofline floor %.1f us, fraction of the per-layer floor %.3f' %
       (len(rows), tot, totf, totf / tot))
 for name, fn in (('fwd+bwd', lambda: eng.forward_backward(x, MEAN, STD, y, 0)), ('fwd', lambda: eng.logits(x, MEAN, STD))):

@@ -371,6 +371,103 @@ def test_x3_fused_stem_backward_matches_the_three_launch_chain(setup, HW):
     assert rel <= 2e-6 and mx <= 2e-6
 
 
+def _bits(t, channels):
+    """[P][channels / 8] uint8 -> [P][channels] of 0 / 1 (bit c % 8 of byte c / 8)"""
+    sh = torch.arange(8, device=t.device, dtype=torch.uint8)
+    return ((t.unsqueeze(-1) >> sh) & 1).reshape(t.shape[0], channels)
+
+
+@pytest.mark.parametrize('C,backward', [(64, False), (64, True), (128, False), (128, True)])
+def test_conv_tail_pair_kernel_vs_fp64(C, backward):
+    """rart_conv3x3_tail_pair (3x3 + point-wise step + 1x1 expansion + skip + point-wise step on pairs, one launch; the intermediate
+    stays in registers) against fp64 of the same pair operands with the intermediate rounded to a pair where the kernel rounds it.
+    Forward mode: biases, ReLU, both sign tensors out.  Backward mode: both 1-bit masks in, no bias.  M = 2 x 9 x 11 positions is not a
+    multiple of the 128-position tile; taps reach outside the image on every side."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C + backward)
+    B, H, W, N = 2, 9, 11, 4 * C
+    P = B * H * W
+    x = _split(torch.randn(B, H, W, C, generator=g).cuda())
+    w2 = (torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()             # [n][r][s][c]
+    w3 = (torch.randn(N, C, generator=g) * (1.0 / C) ** 0.5).cuda()
+    res = _split(torch.randn(B, H, W, N, generator=g).cuda())
+    b2, b3 = torch.randn(C, generator=g).cuda() * 0.3, torch.randn(N, generator=g).cuda() * 0.3
+    w2p, w3p = _split(w2.reshape(C, 9 * C)), _split(w3)
+    tab = torch.cat([w2p[0], w2p[1], w2p[0]], 1).contiguous()
+    tail = torch.stack([w3p[pl].reshape(N // 32, 32, C // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1) for pl in range(2)]).contiguous()
+    dst = torch.full((2, B, H, W, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+    d = _lib.ConvTailDesc()
+    d.a_hi, d.a_lo, d.w_hi, d.w_lo = x[0].data_ptr(), x[1].data_ptr(), tab.data_ptr(), tab.data_ptr() + 2 * 9 * C
+    d.t_hi, d.t_lo = tail[0].data_ptr(), tail[1].data_ptr()
+    d.res_hi, d.res_lo, d.dst_hi, d.dst_lo = res[0].data_ptr(), res[1].data_ptr(), dst[0].data_ptr(), dst[1].data_ptr()
+    d.batch, d.h, d.w, d.c_mid, d.ldw = B, H, W, C, 3 * 9 * C
+    for i in range(9):
+        d.tap_dy[i], d.tap_dx[i] = i // 3 - 1, i % 3 - 1
+    if backward:
+        mm = torch.randint(0, 256, (P, C // 8), generator=g, dtype=torch.uint8).cuda()
+        mo = torch.randint(0, 256, (P, N // 8), generator=g, dtype=torch.uint8).cuda()
+        d.mask_mid, d.mask_out = mm.data_ptr(), mo.data_ptr()
+    else:
+        sm = torch.full((P, C // 8), 0xAA, dtype=torch.uint8, device='cuda')
+        so = torch.full((P, N // 8), 0xAA, dtype=torch.uint8, device='cuda')
+        d.bias_mid, d.bias_out, d.sign_mid, d.sign_out = b2.data_ptr(), b3.data_ptr(), sm.data_ptr(), so.data_ptr()
+        d.relu_mid = d.relu_out = 1
+    _lib.check(lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    x64 = (x[0].double() + x[1].double()).permute(0, 3, 1, 2)
+    w64 = (w2p[0].double() + w2p[1].double()).reshape(C, 3, 3, C).permute(0, 3, 1, 2)
+    mid = torch.nn.functional.conv2d(x64, w64, padding=1).permute(0, 2, 3, 1).reshape(P, C)
+    if backward:
+        mid = mid * _bits(mm, C).double()
+    else:
+        mid = (mid + b2.double()).clamp_min(0)
+    mp = _split(mid.float())
+    out = (mp[0].double() + mp[1].double()) @ (w3p[0].double() + w3p[1].double()).t() + (res[0].double() + res[1].double()).reshape(P, N)
+    if backward:
+        out = out * _bits(mo, N).double()
+    else:
+        out = (out + b3.double()).clamp_min(0)
+    got = (dst[0].double() + dst[1].double()).reshape(P, N)
+    assert torch.isfinite(got).all()
+    err = (got - out).abs().max().item() / out.abs().max().item()
+    print('conv tail pair C=%d %s: max err %.2e of scale' % (C, 'backward' if backward else 'forward', err))
+    assert err <= 2e-5
+    if not backward:
+        assert torch.equal(_bits(so, N), (dst[0].reshape(P, N) > 0).to(torch.uint8))       # the sign tensor of the kernel's own output
+        clear = mid.abs() > 1e-3
+        assert torch.equal(_bits(sm, C)[clear], (mid > 0).to(torch.uint8)[clear])
+
+
+def test_x3_fused_tail_matches_the_two_launch_path(setup):
+    """The reference-precision forward + backward with conv2 + conv3 (forward) / conv2^T + conv1^T (backward) of layer1 / layer2 as one
+    launch each against the same engine on two launches of rart_gemm_pair_bf16: the same products in the same order with the
+    intermediate rounded to a pair at the same place."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(3, 3, 96, 128, generator=g).cuda()
+    y = torch.randint(0, 1000, (3,), generator=g).cuda()
+    assert eng.fused_tail_pair and getattr(eng.blocks[1][2], 'tail_fwd', None) is not None and getattr(eng.blocks[1][0], 'tail_bwd', None) is not None
+    la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    la, ga = la.clone(), ga.clone()
+    signs_a = {k: v.clone() for k, v in eng._buf.items() if k.endswith('_sign')}
+    eng.fused_tail_pair = False
+    try:
+        lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+    finally:
+        eng.fused_tail_pair = True
+    signs_b = {k: v for k, v in eng._buf.items() if k.endswith('_sign')}
+    le = (la - lb).abs().max().item() / lb.abs().max().item()
+    a, b = ga.double().flatten(1), gb.double().flatten(1)
+    rel = ((a - b).norm(dim=1) / b.norm(dim=1)).max().item()
+    same = sum(int(torch.equal(signs_a[k], signs_b[k])) for k in signs_a)
+    print('x3 fused tail vs two launches: logits %.2e of scale (bit-equal: %s), gradient rel L2 %.2e, sign tensors equal %d / %d'
+          % (le, torch.equal(la, lb), rel, same, len(signs_a)))
+    assert le <= 2e-5
+    cos = ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min().item()
+    assert rel <= 0.15 and cos >= 0.98          # ReLU decisions of near-zero pre-activations may flip (see the igemm cross-check above)
+
+
 def test_x3_engine_b256_matches_small_batches_bit_for_bit(setup):
     """The reference-precision ResNet-50 engine at the benchmark's B = 256: every 32nd image of a forward / forward + backward equals the
     same image in a batch of 2 bit for bit (every tile of k_gemm_pair sums a row's K slices in the same order whatever the batch), and
