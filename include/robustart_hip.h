@@ -433,6 +433,16 @@ typedef struct rart_conv_tail_desc {
   void* dst_hi;  void* dst_lo;               /* [batch][h][w][4 c_mid] */
   int batch, h, w, c_mid, ldw, relu_mid, relu_out;
   int tap_dy[9], tap_dx[9];                  /* source pixel of tap i = (y + tap_dy[i], x + tap_dx[i]); zero outside the image */
+  /* optional (n_hi != null): the NEIGHBOURING block's 1x1 reduction (4 c_mid -> c_mid) of the tile just produced -- forward: the next
+   * block's conv1 + bias + ReLU (+ sign tensor); backward: the previous block's conv3^T + mask.  n_*: its [c_mid][4 c_mid] matrix in
+   * fragment order by 64-wide K chunk: element (((chunk * (c_mid / 32) + blk) * 4 + s) * 64 + h * 32 + r) * 8 + e =
+   * N[blk * 32 + r][64 chunk + 16 s + 8 h + e].  dstn_*: [batch][h][w][c_mid]. */
+  const void* n_hi;  const void* n_lo;
+  const float* bias_next;
+  const void* mask_next;
+  void* sign_next;
+  void* dstn_hi;  void* dstn_lo;
+  int relu_next;
 } rart_conv_tail_desc;
 int rart_conv3x3_tail_pair_supported(int c_mid);
 int rart_conv3x3_tail_pair(const rart_conv_tail_desc* desc_host, rart_stream_t stream);

@@ -225,7 +225,8 @@ class ConvTailDesc(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ('a_hi', 'a_lo', 'w_hi', 'w_lo', 't_hi', 't_lo', 'bias_mid', 'bias_out', 'mask_mid', 'mask_out',
                                         'sign_mid', 'sign_out', 'res_hi', 'res_lo', 'dst_hi', 'dst_lo')] + \
                [(n, ctypes.c_int32) for n in ('batch', 'h', 'w', 'c_mid', 'ldw', 'relu_mid', 'relu_out')] + \
-               [('tap_dy', ctypes.c_int32 * 9), ('tap_dx', ctypes.c_int32 * 9)]
+               [('tap_dy', ctypes.c_int32 * 9), ('tap_dx', ctypes.c_int32 * 9)] + \
+               [(n, c_void_p) for n in ('n_hi', 'n_lo', 'bias_next', 'mask_next', 'sign_next', 'dstn_hi', 'dstn_lo')] + [('relu_next', ctypes.c_int32)]
 
 
 _lib = None

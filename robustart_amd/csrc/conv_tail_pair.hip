@@ -21,6 +21,12 @@
 // L2 in MFMA fragment order (1 KiB contiguous per fragment load), 64 output channels at a time; each 32 x 64 result is transposed
 // through the wave's private LDS region so that the skip loads and the stores are 128-byte row segments per plane.
 //
+// NEXT instances also run the 1x1 REDUCTION of the neighbouring block on the tile they just produced (a 1x1 convolution is
+// position-local): forward, conv1 + bias + ReLU of the NEXT block on `out`; backward, conv3^T + mask of the PREVIOUS block on dx.  Each
+// 64-channel chunk of the result goes back to the wave's LDS region as a pair of bf16 planes, is read as B-operand fragments and
+// multiplied into C more accumulators (table in fragment order from L2); the neighbour's own launch -- which re-read the whole
+// 4C-channel pair from HBM (822 MB per block of layer1 at B = 256) to produce a C-channel one -- disappears.
+//
 // Reference step: Bottleneck.forward of the public ResNet-50 (RobustART/model/__init__.py:1 -> absent submodule;
 // robustart_amd/model/resnet_torch.py) and its autograd inside every attack iteration, in fp32
 // (RobustART/noise/utils/adv/attack.py:20-23, Attacks/autoattack/autopgd_base.py:271-289).
@@ -33,6 +39,9 @@ namespace {
 constexpr int CT_TM = 128;                       // positions per workgroup
 constexpr int CT_LDE = 68;                       // epilogue staging row (floats): 64 columns + 4
 constexpr int CT_PLANE_A = CT_TM * 64;           // one position plane of a stage: 128 rows x 64 B
+constexpr int CT_NLD = 144;                      // NEXT: row stride (bytes) of a 32 x 64 bf16 plane of the chunk: ds_read_b128 conflict free
+constexpr int CT_WREG = 2 * 32 * CT_NLD;         // a wave's private LDS region (9 216 B >= the 32 x 68 fp32 staging)
+static_assert(CT_WREG >= 32 * CT_LDE * 4, "the staging must fit the wave's region");
 
 struct ConvTailDev {
   const uint16_t *a_hi, *a_lo, *w_hi, *w_lo, *t_hi, *t_lo;
@@ -44,6 +53,13 @@ struct ConvTailDev {
   int M, H, W, ldw, relu_mid, relu_out;
   int tap_dy[9], tap_dx[9];
   uint32_t w_magic, w_shift, h_magic, h_shift;
+  // NEXT instances: the neighbouring block's 1x1 reduction (4C -> C) of the tile
+  const uint16_t *n_hi, *n_lo;      // fragment order: ((chunk * (C / 32) + blk) * 4 + s) * 64 + lane
+  const float* bias_next;
+  const uint8_t* mask_next;
+  uint8_t* sign_next;
+  uint16_t *dstn_hi, *dstn_lo;
+  int relu_next;
 };
 __device__ __forceinline__ uint32_t ct_fastdiv(uint32_t n, uint32_t magic, uint32_t shift) { return (uint32_t)(((uint64_t)n * magic) >> shift); }
 
@@ -85,8 +101,43 @@ __device__ __forceinline__ uint32_t ct_sign_byte(const uint4& v) {
   return sb;
 }
 
-template <int C>
-__global__ __launch_bounds__(256, C == 64 ? 3 : 2) void k_conv3x3_tail_pair(const ConvTailDev d) {
+// Point-wise step of NJ accumulator blocks in registers (acc[j][r] = channel j*32 + (r&3) + 8*(r>>2) + 4h of the lane's position): ReLU
+// and / or a 1-bit mask (mw[j] = the 32 mask bits of block j), hi + lo split, then lanes l and l + 32 exchange halves so that lane half h
+// owns the whole 8-channel chunk 2s + h of the 16-channel group s = 2j + g/2: MFMA B-operand fragments / 16-byte row segments
+template <int NJ>
+__device__ __forceinline__ void ct_pointwise_frags(const f32x16* acc, const uint32_t* mw, bool relu, int h, uint4* fh, uint4* fl) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int ge = 0; ge < 4; ge += 2) {
+      uint32_t eh[2], el[2], oh[2], ol[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        float ve[2], vo[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ve[i] = acc[j][4 * ge + 2 * w + i];
+          vo[i] = acc[j][4 * ge + 4 + 2 * w + i];
+          if (relu) { ve[i] = fmaxf(ve[i], 0.f); vo[i] = fmaxf(vo[i], 0.f); }
+          if (!((mw[j] >> (8 * ge + 4 * h + 2 * w + i)) & 1u)) ve[i] = 0.f;
+          if (!((mw[j] >> (8 * ge + 8 + 4 * h + 2 * w + i)) & 1u)) vo[i] = 0.f;
+        }
+        eh[w] = ct_pack_bf16x2(ve[0], ve[1]);
+        el[w] = ct_pack_bf16x2(ve[0] - __uint_as_float(eh[w] << 16), ve[1] - __uint_as_float(eh[w] & 0xFFFF0000u));
+        oh[w] = ct_pack_bf16x2(vo[0], vo[1]);
+        ol[w] = ct_pack_bf16x2(vo[0] - __uint_as_float(oh[w] << 16), vo[1] - __uint_as_float(oh[w] & 0xFFFF0000u));
+        const auto sh = __builtin_amdgcn_permlane32_swap(eh[w], oh[w], false, false);
+        eh[w] = sh[0]; oh[w] = sh[1];
+        const auto sl = __builtin_amdgcn_permlane32_swap(el[w], ol[w], false, false);
+        el[w] = sl[0]; ol[w] = sl[1];
+      }
+      fh[j * 2 + ge / 2] = make_uint4(eh[0], eh[1], oh[0], oh[1]);
+      fl[j * 2 + ge / 2] = make_uint4(el[0], el[1], ol[0], ol[1]);
+    }
+}
+
+template <int C, bool NEXT>
+__global__ __launch_bounds__(256, (C == 64 && !NEXT) ? 3 : 2) void k_conv3x3_tail_pair(const ConvTailDev d) {
   constexpr int NJ = C / 32;                     // 32-channel blocks of the 3x3's output
   constexpr int KS = C / 16;                     // 16-deep K steps of the 1x1
   constexpr int NOUT = 4 * C, NC = NOUT / 64;    // the 1x1's output channels, in chunks of 64
@@ -94,7 +145,7 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : 2) void k_conv3x3_tail_pair(cons
   constexpr int KT = 9 << TPT_SHIFT;
   constexpr int PLANE_B = C * 64, STAGE = 2 * CT_PLANE_A + 2 * PLANE_B;
   constexpr int BQ = (C / 16) / 4;               // 1 KiB pieces of a weight plane per wave
-  static_assert(4 * 32 * CT_LDE * 4 <= 2 * STAGE, "epilogue staging must fit the tile buffers");
+  static_assert(4 * CT_WREG <= 2 * STAGE, "the waves' epilogue regions must fit the tile buffers");
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,43 +262,31 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : 2) void k_conv3x3_tail_pair(cons
 #pragma unroll
       for (int j = 0; j < NJ; ++j) mw[j] = mp[j];
     }
-    const bool relu = d.relu_mid != 0;
+    uint4 fh[KS], fl[KS];
+    ct_pointwise_frags<NJ>(acc, mw, d.relu_mid != 0, h, fh, fl);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int ge = 0; ge < 4; ge += 2) {
-        uint32_t eh[2], el[2], oh[2], ol[2];
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-          float ve[2], vo[2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            ve[i] = acc[j][4 * ge + 2 * w + i];
-            vo[i] = acc[j][4 * ge + 4 + 2 * w + i];
-            if (relu) { ve[i] = fmaxf(ve[i], 0.f); vo[i] = fmaxf(vo[i], 0.f); }
-            if (!((mw[j] >> (8 * ge + 4 * h + 2 * w + i)) & 1u)) ve[i] = 0.f;
-            if (!((mw[j] >> (8 * ge + 8 + 4 * h + 2 * w + i)) & 1u)) vo[i] = 0.f;
-          }
-          eh[w] = ct_pack_bf16x2(ve[0], ve[1]);
-          el[w] = ct_pack_bf16x2(ve[0] - __uint_as_float(eh[w] << 16), ve[1] - __uint_as_float(eh[w] & 0xFFFF0000u));
-          oh[w] = ct_pack_bf16x2(vo[0], vo[1]);
-          ol[w] = ct_pack_bf16x2(vo[0] - __uint_as_float(oh[w] << 16), vo[1] - __uint_as_float(oh[w] & 0xFFFF0000u));
-          const auto sh = __builtin_amdgcn_permlane32_swap(eh[w], oh[w], false, false);
-          eh[w] = sh[0]; oh[w] = sh[1];
-          const auto sl = __builtin_amdgcn_permlane32_swap(el[w], ol[w], false, false);
-          el[w] = sl[0]; ol[w] = sl[1];
-        }
-        const uint4 fh = make_uint4(eh[0], eh[1], oh[0], oh[1]), fl = make_uint4(el[0], el[1], ol[0], ol[1]);
-        const int s = j * 2 + ge / 2;
-        a2h[s] = __builtin_bit_cast(bf16x8, fh);
-        a2l[s] = __builtin_bit_cast(bf16x8, fl);
-        if (d.sign_mid && p_ok) d.sign_mid[(size_t)p * (C / 8) + 2 * s + h] = (uint8_t)ct_sign_byte(fh);
-      }
+    for (int s = 0; s < KS; ++s) {
+      a2h[s] = __builtin_bit_cast(bf16x8, fh[s]);
+      a2l[s] = __builtin_bit_cast(bf16x8, fl[s]);
+      if (d.sign_mid && p_ok) d.sign_mid[(size_t)p * (C / 8) + 2 * s + h] = (uint8_t)ct_sign_byte(fh[s]);
+    }
   }
 
   // ---- the 1x1, 64 output channels at a time: table fragments straight from L2, result transposed through the wave's LDS region
-  float* sE = reinterpret_cast<float*>(lds) + wave * 32 * CT_LDE;
+  uint8_t* const wreg = lds + wave * CT_WREG;                 // the wave's private region: fp32 staging, then (NEXT) the chunk as two bf16 planes
+  float* sE = reinterpret_cast<float*>(wreg);
   const int cw = lane & 7, rw = lane >> 3;
+  f32x16 accn[NEXT ? NJ : 1];                                 // NEXT: the neighbour's reduction, channel j*32 + (r&3) + 8*(r>>2) + 4h of position fr
+  if (NEXT) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias_next) bv = *reinterpret_cast<const float4*>(d.bias_next + j * 32 + 8 * g + 4 * h);
+        accn[j][4 * g] = bv.x; accn[j][4 * g + 1] = bv.y; accn[j][4 * g + 2] = bv.z; accn[j][4 * g + 3] = bv.w;
+      }
+  }
   const uint4* th_base = reinterpret_cast<const uint4*>(d.t_hi) + lane;
   const uint4* tl_base = reinterpret_cast<const uint4*>(d.t_lo) + lane;
   const bool relu_out = d.relu_out != 0;
@@ -275,12 +314,6 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : 2) void k_conv3x3_tail_pair(cons
     f32x16 acc2[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      uint4 th[KS], tl[KS];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        th[s] = th_base[((c * 2 + b) * KS + s) * 64];
-        tl[s] = tl_base[((c * 2 + b) * KS + s) * 64];
-      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -288,11 +321,20 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : 2) void k_conv3x3_tail_pair(cons
         acc2[b][4 * g] = bv.x; acc2[b][4 * g + 1] = bv.y; acc2[b][4 * g + 2] = bv.z; acc2[b][4 * g + 3] = bv.w;
       }
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, th[s]), wl = __builtin_bit_cast(bf16x8, tl[s]);
-        acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a2l[s], acc2[b], 0, 0, 0);
-        acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, a2h[s], acc2[b], 0, 0, 0);
-        acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a2h[s], acc2[b], 0, 0, 0);
+      for (int sg = 0; sg < KS; sg += 4) {          // four K steps of table fragments in flight (32 registers)
+        uint4 th[4], tl[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          th[s] = th_base[((c * 2 + b) * KS + sg + s) * 64];
+          tl[s] = tl_base[((c * 2 + b) * KS + sg + s) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 wh = __builtin_bit_cast(bf16x8, th[s]), wl = __builtin_bit_cast(bf16x8, tl[s]);
+          acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a2l[sg + s], acc2[b], 0, 0, 0);
+          acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, a2h[sg + s], acc2[b], 0, 0, 0);
+          acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a2h[sg + s], acc2[b], 0, 0, 0);
+        }
       }
     }
     // lane: position fr, channels b*32 + 8g + 4h + (0..3) -> one 16-byte LDS store each
@@ -305,12 +347,14 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : 2) void k_conv3x3_tail_pair(cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4 oph[4], opl[4];              // NEXT: the chunk's results as pairs (zeros for rows past M)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = q * 8 + rw;
       const float4 v0 = *reinterpret_cast<const float4*>(sE + r * CT_LDE + cw * 8);
       const float4 v1 = *reinterpret_cast<const float4*>(sE + r * CT_LDE + cw * 8 + 4);
       const int e = eo[q];
+      oph[q] = opl[q] = make_uint4(0, 0, 0, 0);
       if (e >= 0) {
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (d.res_hi) {
@@ -331,10 +375,70 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : 2) void k_conv3x3_tail_pair(cons
         *reinterpret_cast<uint4*>(d.dst_hi + e) = ph;
         *reinterpret_cast<uint4*>(d.dst_lo + e) = pl;
         if (d.sign_out) d.sign_out[e >> 3] = (uint8_t)ct_sign_byte(ph);
+        oph[q] = ph;
+        opl[q] = pl;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (NEXT) {
+      // the chunk as two [32 positions][64 channels] bf16 planes in the region the staging just left, then as B-operand fragments
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<uint4*>(wreg + (q * 8 + rw) * CT_NLD + cw * 16) = oph[q];
+        *reinterpret_cast<uint4*>(wreg + 32 * CT_NLD + (q * 8 + rw) * CT_NLD + cw * 16) = opl[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      bf16x8 xh[4], xl[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        xh[s] = *reinterpret_cast<const bf16x8*>(wreg + fr * CT_NLD + s * 32 + h * 16);
+        xl[s] = *reinterpret_cast<const bf16x8*>(wreg + 32 * CT_NLD + fr * CT_NLD + s * 32 + h * 16);
+      }
+      const uint4* nh_base = reinterpret_cast<const uint4*>(d.n_hi) + lane;
+      const uint4* nl_base = reinterpret_cast<const uint4*>(d.n_lo) + lane;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        uint4 nh[4], nl[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          nh[s] = nh_base[((c * NJ + j) * 4 + s) * 64];
+          nl[s] = nl_base[((c * NJ + j) * 4 + s) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 wh = __builtin_bit_cast(bf16x8, nh[s]), wl = __builtin_bit_cast(bf16x8, nl[s]);
+          accn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], accn[j], 0, 0, 0);
+          accn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], accn[j], 0, 0, 0);
+          accn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], accn[j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();       // the fragment reads are done before the next chunk's staging
+    }
+  }
+  if (NEXT) {
+    // ---- point-wise step of the neighbour's reduction and its stores: a lane owns 16-byte segments of its position's row
+    uint32_t mw[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) mw[j] = 0xFFFFFFFFu;
+    if (d.mask_next && p_ok) {
+      const uint32_t* mp = reinterpret_cast<const uint32_t*>(d.mask_next + (size_t)p * (C / 8));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) mw[j] = mp[j];
+    }
+    uint4 fh[KS], fl[KS];
+    ct_pointwise_frags<NJ>(accn, mw, d.relu_next != 0, h, fh, fl);
+    if (p_ok) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        *reinterpret_cast<uint4*>(d.dstn_hi + (size_t)p * C + 16 * s + 8 * h) = fh[s];
+        *reinterpret_cast<uint4*>(d.dstn_lo + (size_t)p * C + 16 * s + 8 * h) = fl[s];
+        if (d.sign_next) d.sign_next[(size_t)p * (C / 8) + 2 * s + h] = (uint8_t)ct_sign_byte(fh[s]);
+      }
+    }
   }
 }
 
@@ -368,11 +472,21 @@ extern "C" int rart_conv3x3_tail_pair(const rart_conv_tail_desc* t, rart_stream_
   d.dst_hi = (uint16_t*)t->dst_hi; d.dst_lo = (uint16_t*)t->dst_lo;
   d.M = (int)M; d.H = t->h; d.W = t->w; d.ldw = t->ldw; d.relu_mid = t->relu_mid; d.relu_out = t->relu_out;
   for (int i = 0; i < 9; ++i) { d.tap_dy[i] = t->tap_dy[i]; d.tap_dx[i] = t->tap_dx[i]; }
+  const bool next = t->n_hi != nullptr;
+  RART_CHECK_ARG(!next || (t->n_lo && t->dstn_hi && t->dstn_lo), "rart_conv3x3_tail_pair: the neighbour's reduction needs both table planes and its destination pair");
+  d.n_hi = (const uint16_t*)t->n_hi; d.n_lo = (const uint16_t*)t->n_lo; d.bias_next = t->bias_next; d.mask_next = (const uint8_t*)t->mask_next;
+  d.sign_next = (uint8_t*)t->sign_next; d.dstn_hi = (uint16_t*)t->dstn_hi; d.dstn_lo = (uint16_t*)t->dstn_lo; d.relu_next = t->relu_next;
   ct_magic((uint32_t)d.W, d.w_magic, d.w_shift);
   ct_magic((uint32_t)d.H, d.h_magic, d.h_shift);
   const dim3 grid((uint32_t)((M + CT_TM - 1) / CT_TM));
-  if (t->c_mid == 64) hipLaunchKernelGGL(k_conv3x3_tail_pair<64>, grid, dim3(256), 0, (hipStream_t)stream, d);
-  else hipLaunchKernelGGL(k_conv3x3_tail_pair<128>, grid, dim3(256), 0, (hipStream_t)stream, d);
+  hipStream_t st = (hipStream_t)stream;
+  if (t->c_mid == 64) {
+    if (next) hipLaunchKernelGGL((k_conv3x3_tail_pair<64, true>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((k_conv3x3_tail_pair<64, false>), grid, dim3(256), 0, st, d);
+  } else {
+    if (next) hipLaunchKernelGGL((k_conv3x3_tail_pair<128, true>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((k_conv3x3_tail_pair<128, false>), grid, dim3(256), 0, st, d);
+  }
   RART_CHECK_LAUNCH("rart_conv3x3_tail_pair");
   return RART_OK;
 }

@@ -168,6 +168,8 @@ class ResNet50Engine:
         self.fused_bottleneck_s2_bwd = True   # False: their backward-to-input as seven conv launches (cross-check)
         self.small_m_fc = True           # False: the classifier head and its backward on the implicit GEMM (cross-check)
         self.pair_tile = (0, 0)
+        self.fused_next_pair = True      # reference-precision mode: ... and the neighbouring block's 1x1 reduction in the same launch; False: its own launch (cross-check)
+        self.fused_next_channels = (64,)  # ... for these mid-channel counts (measured at B = 256: layer1 -0.35 ms per gradient evaluation; layer2's instance sits at 256 VGPRs and loses 0.6 ms)
         self.fused_tail_pair = True      # reference-precision mode: 3x3 + 1x1 expansion of a Bottleneck as one launch (conv_tail_pair.hip); False: two launches (cross-check)
         self.pair_gemm_kernel = True     # reference-precision mode: False = the three products as 3 x the taps of the implicit GEMM (round 3; cross-check)
         self.blocks = []
@@ -212,13 +214,26 @@ class ResNet50Engine:
                 w = tab[:rows, pl * k:(pl + 1) * k]
                 out.append(w.reshape(rows // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1))
             return torch.stack(out).contiguous()
-        for ca, cb, cc, ds in self.blocks:
+        def frag_next(tab, rows, k):     # the neighbour's reduction [rows = C][k = 4C], fragment order by 64-wide K chunk
+            out = []
+            for pl in range(2):
+                w = tab[:rows, pl * k:(pl + 1) * k]
+                out.append(w.reshape(rows // 32, 32, k // 64, 4, 2, 8).permute(2, 0, 3, 4, 1, 5).contiguous().view(-1))
+            return torch.stack(out).contiguous()
+        for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
             if not (cb.r == 3 and cb.stride == 1 and cb.pad == 1 and cb.cin == cb.cout and self.lib.rart_conv3x3_tail_pair_supported(cb.cin)):
                 continue
             if cc.cin == cb.cout and cc.cout == 4 * cb.cout and cc.r == 1 and cc.stride == 1:
                 cc.tail_fwd = frag(cc.w_fwd, cc.cout, cc.cin)
+                if bi + 1 < len(self.blocks):        # the next block's conv1 on this block's output tile
+                    na = self.blocks[bi + 1][0]
+                    if na.r == 1 and na.stride == 1 and na.cin == cc.cout and na.cout == cb.cout:
+                        na.next_fwd = frag_next(na.w_fwd, na.cout, na.cin)
             if ds is None and ca.cout == cb.cin and ca.cin == 4 * cb.cin and ca.r == 1 and ca.stride == 1:
                 ca.tail_bwd = frag(ca.bwd[0][2], ca.cin, ca.cout)
+                pc = self.blocks[bi - 1][2]          # the previous block's conv3^T on this block's input-gradient tile
+                if bi > 0 and pc.r == 1 and pc.stride == 1 and pc.cout == ca.cin and pc.cin == cb.cin:
+                    pc.next_bwd = frag_next(pc.bwd[0][2], pc.cin, pc.cout)
 
     def _pack_frag_tables(self, record=None, sums=None):
         """MFMA-fragment-ordered copies of the 3x3 tables the LDS-resident kernels (conv3x3_halo.hip, bottleneck_fused.hip)
@@ -533,10 +548,11 @@ class ResNet50Engine:
         _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
     def _tail(self, src, wgt, taps, tail, dst, batch, hw, c_mid, bias_mid=None, bias_out=None, res=None, mask_mid=None, mask_out=None,
-              sign_mid=None, sign_out=None, relu=False):
+              sign_mid=None, sign_out=None, relu=False, nxt=None):
         """3x3 (c_mid -> c_mid) + point-wise step + 1x1 expansion (c_mid -> 4 c_mid) + skip pair + point-wise step of the
         reference-precision mode as ONE launch (csrc/conv_tail_pair.hip).  src / dst / res: pair tensors; wgt: the 3x3's
-        [rows][hi | lo | hi] table; tail: `_pack_tail_tables`' [2][...] fragment-ordered 1x1 table."""
+        [rows][hi | lo | hi] table; tail: `_pack_tail_tables`' [2][...] fragment-ordered 1x1 table.  nxt: the neighbouring block's 1x1
+        reduction of the tile in the same launch -- dict(tab, dst, bias, mask, sign, relu)."""
         k_tot = 9 * c_mid
         assert src.shape[0] == 2 and wgt.shape[1] == 3 * k_tot and len(taps) == 9
         d = _lib.ConvTailDesc()
@@ -552,13 +568,19 @@ class ResNet50Engine:
         d.relu_mid = d.relu_out = 1 if relu else 0
         for i, (dy, dx) in enumerate(taps):
             d.tap_dy[i], d.tap_dx[i] = dy, dx
+        if nxt is not None:
+            d.n_hi, d.n_lo = nxt['tab'][0].data_ptr(), nxt['tab'][1].data_ptr()
+            d.dstn_hi, d.dstn_lo = nxt['dst'][0].data_ptr(), nxt['dst'][1].data_ptr()
+            d.bias_next, d.mask_next, d.sign_next = _lib.ptr(nxt.get('bias')), _lib.ptr(nxt.get('mask')), _lib.ptr(nxt.get('sign'))
+            d.relu_next = 1 if nxt.get('relu') else 0
         if self.profile is not None:
             torch = _lib.require_gpu()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             _lib.check(self.lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
             e1.record()
-            self.profile.append((3 * 2.0 * batch * hw[0] * hw[1] * (k_tot * c_mid + 4 * c_mid * c_mid), e0, e1, 'conv_tail_pair'))   # MFMA FLOPs issued
+            self.profile.append((3 * 2.0 * batch * hw[0] * hw[1] * (k_tot * c_mid + (8 if nxt is not None else 4) * c_mid * c_mid), e0, e1,
+                                 'conv_tail_pair'))   # MFMA FLOPs issued
             return
         _lib.check(self.lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
 
@@ -897,6 +919,7 @@ class ResNet50Engine:
                                                 _lib.ptr(xs), B, h1, w1, 64, sp))
         acts['p1_argmax'] = parg
         x, xhw = p1, (h2, w2)
+        pre_a = False            # this block's conv1 was already computed by the previous block's launch
         for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
             ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
             tail = self.fused_tail_pair and getattr(cc, 'tail_fwd', None) is not None and self._fits32(B, ohw, cc.cout)
@@ -906,15 +929,24 @@ class ResNet50Engine:
             sa = self._get('b%d_a_sign' % bi, (B, xhw[0], xhw[1], ca.cout // 8), torch.uint8) if keep else None
             sb = self._get('b%d_b_sign' % bi, (B, ohw[0], ohw[1], cb.cout // 8), torch.uint8) if keep else None
             sc = self._get('b%d_c_sign' % bi, (B, ohw[0], ohw[1], cc.cout // 8), torch.uint8) if keep else None
-            self._conv_fwd(ca, x, xhw, ya, True, sign=sa, pair=True)
+            if not pre_a:
+                self._conv_fwd(ca, x, xhw, ya, True, sign=sa, pair=True)
+            pre_a = False
             if ds is not None:
                 sk = self._get('x3_b%d_ds' % bi, (2, B, ohw[0], ohw[1], cc.cout))
                 self._conv_fwd(ds, x, xhw, sk, False, pair=True)
             else:
                 sk = x
             if tail:         # conv2 + relu + conv3 + skip + relu in one launch: the 3x3's output never exists in HBM
+                nxt = None
+                na = self.blocks[bi + 1][0] if bi + 1 < len(self.blocks) else None
+                if self.fused_next_pair and na is not None and getattr(na, 'next_fwd', None) is not None and cb.cout in self.fused_next_channels:
+                    # ... and the next block's conv1 + relu on the output tile: that block's own read of this output disappears
+                    nxt = dict(tab=na.next_fwd, bias=na.bias, relu=True, dst=self._get('x3_b%d_a' % (bi + 1), (2, B, ohw[0], ohw[1], na.cout)),
+                               sign=self._get('b%d_a_sign' % (bi + 1), (B, ohw[0], ohw[1], na.cout // 8), torch.uint8) if keep else None)
+                    pre_a = True
                 self._tail(ya, cb.w_fwd, cb.fwd_taps, cc.tail_fwd, yc, B, ohw, cb.cout, bias_mid=cb.bias, bias_out=cc.bias, res=sk,
-                           sign_mid=sb, sign_out=sc, relu=True)
+                           sign_mid=sb, sign_out=sc, relu=True, nxt=nxt)
             else:
                 self._conv_fwd(cb, ya, xhw, yb, True, sign=sb, pair=True)
                 self._conv_fwd(cc, yb, ohw, yc, True, res=sk, sign=sc, pair=True)
@@ -946,17 +978,29 @@ class ResNet50Engine:
         dz = self._get('x3_g_out_%d' % (len(self.blocks) - 1), tuple(xl.shape))
         _lib.check(lib.rart_engine_avgpool_bwd_pair(_lib.ptr(acts['last_sign']), _lib.ptr(dpool), self._lo(dpool), _lib.ptr(dz),
                                                     self._lo(dz), B, xlhw[0] * xlhw[1], self.fc_in, sp))
+        pre_b = False            # this block's conv3^T was already computed by the launch of the block above
         for bi in range(len(self.blocks) - 1, -1, -1):
             ca, cb, cc, ds = self.blocks[bi]
             x, xhw, ya, yb, yc, ohw = acts['b%d' % bi]
             mx, ma, mb = acts['b%d_masks' % bi]
-            dzb = self._get('x3_g_b', (2, B, ohw[0], ohw[1], cb.cout))
-            self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb, pair=True)
+            dzb = self._get('x3_g_b%d' % (bi & 1), (2, B, ohw[0], ohw[1], cb.cout))
+            if not pre_b:
+                self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb, pair=True)
+            pre_b = False
             dx = self._get('x3_g_out_%d' % (bi - 1), tuple(x.shape))
             if (self.fused_tail_pair and getattr(ca, 'tail_bwd', None) is not None and ma is not None and mx is not None
                     and self._fits32(B, xhw, ca.cin)):
                 # conv2^T + mask + conv1^T + identity-skip gradient + mask in one launch
-                self._tail(dzb, cb.bwd[0][2], cb.bwd[0][1], ca.tail_bwd, dx, B, xhw, cb.cin, res=dz, mask_mid=ma, mask_out=mx)
+                nxt = None
+                pc = self.blocks[bi - 1][2] if bi > 0 else None
+                if self.fused_next_pair and pc is not None and getattr(pc, 'next_bwd', None) is not None and cb.cin in self.fused_next_channels:
+                    # ... and the previous block's conv3^T + mask on the input-gradient tile
+                    nxt = dict(tab=pc.next_bwd, mask=acts['b%d_masks' % (bi - 1)][2],
+                               dst=self._get('x3_g_b%d' % ((bi - 1) & 1), (2, B, xhw[0], xhw[1], pc.cin)))
+                    pre_b = nxt['mask'] is not None
+                    if not pre_b:
+                        nxt = None
+                self._tail(dzb, cb.bwd[0][2], cb.bwd[0][1], ca.tail_bwd, dx, B, xhw, cb.cin, res=dz, mask_mid=ma, mask_out=mx, nxt=nxt)
                 dz = dx
                 continue
             dza = self._get('x3_g_a', tuple(ya.shape))

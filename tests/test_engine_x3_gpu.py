@@ -377,12 +377,14 @@ def _bits(t, channels):
     return ((t.unsqueeze(-1) >> sh) & 1).reshape(t.shape[0], channels)
 
 
-@pytest.mark.parametrize('C,backward', [(64, False), (64, True), (128, False), (128, True)])
-def test_conv_tail_pair_kernel_vs_fp64(C, backward):
+@pytest.mark.parametrize('C,backward,nxt', [(64, False, False), (64, True, False), (128, False, False), (128, True, False),
+                                            (64, False, True), (64, True, True), (128, False, True), (128, True, True)])
+def test_conv_tail_pair_kernel_vs_fp64(C, backward, nxt):
     """rart_conv3x3_tail_pair (3x3 + point-wise step + 1x1 expansion + skip + point-wise step on pairs, one launch; the intermediate
     stays in registers) against fp64 of the same pair operands with the intermediate rounded to a pair where the kernel rounds it.
     Forward mode: biases, ReLU, both sign tensors out.  Backward mode: both 1-bit masks in, no bias.  M = 2 x 9 x 11 positions is not a
-    multiple of the 128-position tile; taps reach outside the image on every side."""
+    multiple of the 128-position tile; taps reach outside the image on every side.  nxt: the neighbouring block's 1x1 reduction
+    (4C -> C) of the output tile in the same launch (forward: bias + ReLU + sign tensor; backward: mask)."""
     from robustart_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(C + backward)
@@ -413,6 +415,20 @@ def test_conv_tail_pair_kernel_vs_fp64(C, backward):
         so = torch.full((P, N // 8), 0xAA, dtype=torch.uint8, device='cuda')
         d.bias_mid, d.bias_out, d.sign_mid, d.sign_out = b2.data_ptr(), b3.data_ptr(), sm.data_ptr(), so.data_ptr()
         d.relu_mid = d.relu_out = 1
+    if nxt:
+        wn = (torch.randn(C, N, generator=g) * (1.0 / N) ** 0.5).cuda()
+        wnp = _split(wn)
+        ntab = torch.stack([wnp[pl].reshape(C // 32, 32, N // 64, 4, 2, 8).permute(2, 0, 3, 4, 1, 5).contiguous().view(-1)
+                            for pl in range(2)]).contiguous()
+        dn = torch.full((2, P, C), float('nan'), dtype=torch.bfloat16, device='cuda')
+        d.n_hi, d.n_lo, d.dstn_hi, d.dstn_lo = ntab[0].data_ptr(), ntab[1].data_ptr(), dn[0].data_ptr(), dn[1].data_ptr()
+        if backward:
+            mn = torch.randint(0, 256, (P, C // 8), generator=g, dtype=torch.uint8).cuda()
+            d.mask_next = mn.data_ptr()
+        else:
+            bn = torch.randn(C, generator=g).cuda() * 0.3
+            sn = torch.full((P, C // 8), 0xAA, dtype=torch.uint8, device='cuda')
+            d.bias_next, d.sign_next, d.relu_next = bn.data_ptr(), sn.data_ptr(), 1
     _lib.check(lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
     torch.cuda.synchronize()
     x64 = (x[0].double() + x[1].double()).permute(0, 3, 1, 2)
@@ -437,6 +453,17 @@ def test_conv_tail_pair_kernel_vs_fp64(C, backward):
         assert torch.equal(_bits(so, N), (dst[0].reshape(P, N) > 0).to(torch.uint8))       # the sign tensor of the kernel's own output
         clear = mid.abs() > 1e-3
         assert torch.equal(_bits(sm, C)[clear], (mid > 0).to(torch.uint8)[clear])
+    if nxt:
+        # the reduction multiplies the pair the kernel WROTE
+        nref = got @ (wnp[0].double() + wnp[1].double()).t()
+        nref = nref * _bits(mn, C).double() if backward else (nref + bn.double()).clamp_min(0)
+        ngot = dn[0].double() + dn[1].double()
+        assert torch.isfinite(ngot).all()
+        nerr = (ngot - nref).abs().max().item() / nref.abs().max().item()
+        print('   neighbour reduction: max err %.2e of scale' % nerr)
+        assert nerr <= 1e-5
+        if not backward:
+            assert torch.equal(_bits(sn, C), (dn[0] > 0).to(torch.uint8))
 
 
 def test_x3_fused_tail_matches_the_two_launch_path(setup):
@@ -451,6 +478,15 @@ def test_x3_fused_tail_matches_the_two_launch_path(setup):
     la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
     la, ga = la.clone(), ga.clone()
     signs_a = {k: v.clone() for k, v in eng._buf.items() if k.endswith('_sign')}
+    assert eng.fused_next_pair and getattr(eng.blocks[1][0], 'next_fwd', None) is not None and getattr(eng.blocks[0][2], 'next_bwd', None) is not None
+    eng.fused_next_pair = False          # the tail launches without the neighbour's reduction
+    try:
+        lc, _, gc, _ = eng.forward_backward(x, MEAN, STD, y, 0)
+        lc, gc = lc.clone(), gc.clone()
+    finally:
+        eng.fused_next_pair = True
+    print('x3 tail with vs without the neighbour reduction: logits bit-equal %s, gradient bit-equal %s' % (torch.equal(la, lc), torch.equal(ga, gc)))
+    assert (la - lc).abs().max().item() <= 2e-5 * lc.abs().max().item()
     eng.fused_tail_pair = False
     try:
         lb, _, gb, _ = eng.forward_backward(x, MEAN, STD, y, 0)
