@@ -631,6 +631,13 @@ int rart_engine_stem_col2im_f32(const float* patches, float* grad, int n, int h,
  * (autograd of attack.py:21-22 / autopgd_base.py:271-289 through conv1-bn1-relu-maxpool) */
 int rart_engine_stem_bwd_fused(const void* dpool, const void* argmax, const void* wtab, float* grad, int n, int h, int w,
                                const float* std_host, rart_stream_t stream);
+/* The reference-precision stem FORWARD as one persistent kernel (csrc/stem_pair.hip): normalisation + hi / lo split + 7x7/2 convolution
+ * (three MFMA products per K step) + bias + ReLU + hi / lo split + 3x3/2 max pool of the pair values; bit-identical to
+ * rart_engine_prep_input -> rart_gemm_pair_bf16 (7 row taps) -> rart_engine_maxpool_pair.  wgt_*: [64][224] bf16, column r * 32 + px * 4 + c
+ * (px < 7, c < 3; zero elsewhere).  p1_*: [n][h/4][w/4][64]; argmax_out / sign_out as rart_engine_maxpool_pair (may be null). */
+int rart_engine_stem_fwd_fused_pair(const void* src, int src_is_u8, const void* wgt_hi, const void* wgt_lo, const float* bias, void* p1_hi,
+                                    void* p1_lo, void* argmax_out, void* sign_out, int n, int h, int w, const float* mean_host,
+                                    const float* std_host, rart_stream_t stream);
 /* The reference-precision form (csrc/stem_pair.hip): pooled gradient and weight table as hi + lo planes of bf16, three MFMA products per
  * fragment pair; replaces rart_engine_maxpool_bwd_pair -> rart_gemm_pair_bf16 (patches, fp32) -> rart_engine_stem_col2im_f32. */
 int rart_engine_stem_bwd_fused_pair(const void* dpool_hi, const void* dpool_lo, const void* argmax, const void* wtab_hi, const void* wtab_lo,

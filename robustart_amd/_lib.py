@@ -127,6 +127,7 @@ SIGNATURES = {
                                            c_int, c_void_p, c_void_p, c_void_p]),
     'rart_conv3x3_tail_pair_supported': (c_int, [c_int]),
     'rart_conv3x3_tail_pair': (c_int, [c_void_p, c_void_p]),
+    'rart_engine_stem_fwd_fused_pair': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'rart_engine_stem_bwd_fused_pair': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_stem_bwd_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_maxpool_pair': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -215,3 +215,226 @@ extern "C" int rart_engine_stem_bwd_fused_pair(const void* dpool_hi, const void*
   RART_CHECK_LAUNCH("rart_engine_stem_bwd_fused_pair");
   return RART_OK;
 }
+
+// =====================================================================================================================
+// Fused stem FORWARD on pairs: input normalisation (hi + lo bf16 split) + 7x7/2 convolution (x_lo.w_hi + x_hi.w_lo + x_hi.w_hi per K
+// step, fp32 accumulation) + folded BatchNorm bias + ReLU + hi + lo split + 3x3/2 max pool of the pair VALUES in ONE persistent kernel.
+// Replaces rart_engine_prep_input -> rart_gemm_pair_bf16 (row taps, K = 224) -> rart_engine_maxpool_pair, which wrote and re-read the
+// padded hi / lo image and the 112 x 112 x 64 stem-output pair (2 x 411 MB per 256 images): 0.77 ms of a 10.1 ms forward.
+//
+// Same structure as k_stem_fwd_fused (csrc/stem_fused.hip): a workgroup loops over 8 x 8 tiles of POOLED positions; the 39 x 39 input
+// patch behind the 17 x 17 stem outputs the tile's windows touch is staged in LDS as two [39][40 px][4 ch] bf16 planes; the convolution
+// is the row-tap implicit GEMM (a tap = one filter row of 8 px x 4 ch) read straight from the patch, operands swapped so a lane owns 4
+// consecutive channels of one position.  What the pair changes: both weight planes are LDS resident (2 x 29.7 KB), and the stem-output
+// tile is kept as fp32 -- the value hi + lo of the pair the unfused chain would have written, so the pool's comparisons, argmax codes and
+// outputs are bit-identical to it -- 78.6 KB: one workgroup of 512 threads per CU (138 KB of LDS).
+// =====================================================================================================================
+namespace {
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int SP_PT = 8;                        // pooled tile side
+constexpr int SP_R = 2 * SP_PT + 1;             // stem-output region side (17)
+constexpr int SP_NPOS = SP_R * SP_R;            // 289
+constexpr int SP_PH = 2 * (SP_R - 1) + 7;       // patch rows (39)
+constexpr int SP_PW = 40;                       // patch row stride in pixels
+constexpr int SP_PLANE = SP_PH * SP_PW * 8;     // bytes per hi / lo plane (12 480)
+constexpr int SP_WROW = 464;                    // weight row stride in LDS (224 k x 2 B + 16 pad: conflict-free b128 reads)
+constexpr int SP_YROW = 272;                    // stem-output tile row stride: 64 fp32 + 16 B pad
+constexpr int SP_W_BYTES = 64 * SP_WROW;        // 29 696 per plane
+constexpr int SP_T_BYTES = SP_NPOS * SP_YROW;   // 78 608 (>= 2 * SP_PLANE: the tile aliases the patch)
+constexpr int SP_NT = 3;                        // 32-position M tiles per wave row (4 wave rows x 3 >= 10 tiles)
+static_assert(SP_T_BYTES >= 2 * SP_PLANE, "the stem-output tile must cover the patch it aliases");
+
+struct StemNormP { float mean[3], istd[3]; };
+// the normalisation must round exactly like k_prep_input (engine_aux.hip): multiply, subtract, multiply -- no contraction
+#pragma clang fp contract(off)
+
+template <bool SRC_U8>
+__global__ __launch_bounds__(512, 1) void k_stem_fwd_pair(const void* __restrict__ src, const uint16_t* __restrict__ w_h,
+                                                          const uint16_t* __restrict__ w_l, const float* __restrict__ bias,
+                                                          uint4* __restrict__ p1_h, uint4* __restrict__ p1_l, uint2* __restrict__ arg,
+                                                          uint8_t* __restrict__ sign, int n, int h, int w, StemNormP nm) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * SP_W_BYTES + SP_T_BYTES];
+  uint8_t* sW = lds;                            // [hi | lo][64][SP_WROW]
+  uint8_t* sP = lds + 2 * SP_W_BYTES;           // patch (hi plane, lo plane) / stem-output tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kq = lane >> 5;
+  const int oh = h >> 1, ow = w >> 1, oh2 = oh >> 1, ow2 = ow >> 1;
+  const int tiles_x = (ow2 + SP_PT - 1) / SP_PT, tiles_y = (oh2 + SP_PT - 1) / SP_PT;
+  const int n_tiles = n * tiles_y * tiles_x;
+
+  // weights: [64][224] per plane, once per workgroup
+  for (int i = tid; i < 2 * 64 * 28; i += 512) {
+    const int pl = i / (64 * 28), j = i - pl * (64 * 28), row = j / 28, ch = j - row * 28;
+    *reinterpret_cast<uint4*>(sW + pl * SP_W_BYTES + row * SP_WROW + ch * 16) =
+        *reinterpret_cast<const uint4*>((pl ? w_l : w_h) + (size_t)row * 224 + ch * 8);
+  }
+  uint32_t a_off[SP_NT];
+#pragma unroll
+  for (int i = 0; i < SP_NT; ++i) {
+    int p = (wm * SP_NT + i) * 32 + (lane & 31);
+    p = p < SP_NPOS ? p : SP_NPOS - 1;          // rows past the region recompute the last position; never stored
+    const int py = p / SP_R, px = p - py * SP_R;
+    a_off[i] = (uint32_t)(((2 * py) * SP_PW + 2 * px) * 8 + kq * 16);
+  }
+  const uint32_t w_off = (uint32_t)((wn * 32 + (lane & 31)) * SP_WROW + kq * 16);
+  float bz[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bz[r] = bias ? bias[wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq] : 0.f;
+
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int img = t / (tiles_y * tiles_x);
+    const int tr = t - img * (tiles_y * tiles_x);
+    const int q0y = (tr / tiles_x) * SP_PT, q0x = (tr % tiles_x) * SP_PT;
+    const int in_y0 = 4 * q0y - 5, in_x0 = 4 * q0x - 5;          // input pixel of patch (0, 0)
+    __syncthreads();                                               // previous tile's pool is done with the LDS tile
+    // ---- stage the patch: (x - mean) / std as hi + lo bf16, zeros outside the image and in the 4th channel
+    {
+      constexpr int U = (SP_PH * SP_PW + 511) / 512;               // 4
+      float v01[U][3];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = u * 512 + tid;
+        const int pr = i / SP_PW, pc = i - pr * SP_PW;
+        const int y = in_y0 + pr, x = in_x0 + pc;
+        ok[u] = i < SP_PH * SP_PW && (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w && pc < SP_PH;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          v01[u][c] = 0.f;
+          if (ok[u]) {
+            if (SRC_U8) v01[u][c] = (float)((const uint8_t*)src)[(((size_t)img * h + y) * w + x) * 3 + c];
+            else v01[u][c] = ((const float*)src)[(((size_t)img * 3 + c) * h + y) * w + x];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = u * 512 + tid;
+        if (i >= SP_PH * SP_PW) continue;
+        uint32_t hv[3] = {0, 0, 0}, lv[3] = {0, 0, 0};
+        if (ok[u]) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float x01 = SRC_U8 ? v01[u][c] * (1.0f / 255.0f) : v01[u][c];
+            const float v = (x01 - nm.mean[c]) * nm.istd[c];
+            hv[c] = sp_pack2(v, 0.f) & 0xFFFFu;
+            lv[c] = sp_pack2(v - __uint_as_float(hv[c] << 16), 0.f) & 0xFFFFu;
+          }
+        }
+        *reinterpret_cast<uint2*>(sP + i * 8) = make_uint2(hv[0] | (hv[1] << 16), hv[2]);
+        *reinterpret_cast<uint2*>(sP + SP_PLANE + i * 8) = make_uint2(lv[0] | (lv[1] << 16), lv[2]);
+      }
+    }
+    __syncthreads();
+    // ---- implicit GEMM: 7 row taps x 2 k-steps x 3 products, D^T accumulators (register -> channel, lane -> position)
+    f32x16 acc[SP_NT];
+#pragma unroll
+    for (int i = 0; i < SP_NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = bz[r];
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(sW + w_off + r * 64 + ks * 32);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sW + SP_W_BYTES + w_off + r * 64 + ks * 32);
+#pragma unroll
+        for (int i = 0; i < SP_NT; ++i) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sP + a_off[i] + r * (SP_PW * 8) + ks * 32);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(sP + a_off[i] + SP_PLANE + r * (SP_PW * 8) + ks * 32);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc[i], 0, 0, 0);
+        }
+      }
+    __syncthreads();                                               // every wave is done reading the patch
+    // ---- ReLU, the value of the hi + lo pair (what the unfused chain stores), into the LDS tile [position][64 ch] fp32
+#pragma unroll
+    for (int i = 0; i < SP_NT; ++i) {
+      const int p = (wm * SP_NT + i) * 32 + (lane & 31);
+      if (p < SP_NPOS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[i][4 * q + k], 0.f);
+          const uint32_t h0 = sp_pack2(v[0], v[1]), h1 = sp_pack2(v[2], v[3]);
+          const uint32_t l0 = sp_pack2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xFFFF0000u));
+          const uint32_t l1 = sp_pack2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xFFFF0000u));
+          *reinterpret_cast<float4*>(sP + p * SP_YROW + (wn * 32 + 8 * q + 4 * kq) * 4) =
+              make_float4(__uint_as_float(h0 << 16) + __uint_as_float(l0 << 16), __uint_as_float(h0 & 0xFFFF0000u) + __uint_as_float(l0 & 0xFFFF0000u),
+                          __uint_as_float(h1 << 16) + __uint_as_float(l1 << 16), __uint_as_float(h1 & 0xFFFF0000u) + __uint_as_float(l1 & 0xFFFF0000u));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3x3/2 max pool (pad 1) of the pair values: first maximum in scan order, code 15 when the maximum is <= 0
+    {
+      const int c = tid & 7, q = tid >> 3;          // 64 pooled positions x 8 channel groups = 512 threads
+      const int qy = q / SP_PT, qx = q - qy * SP_PT;
+      const int gy = q0y + qy, gx = q0x + qx;
+      if (gy < oh2 && gx < ow2) {
+        float m[8];
+        uint32_t code[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; code[j] = 0; }
+        for (int ky = 0; ky < 3; ++ky) {
+          const int y1 = 2 * gy - 1 + ky;
+          if ((unsigned)y1 >= (unsigned)oh) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int x1 = 2 * gx - 1 + kx;
+            if ((unsigned)x1 >= (unsigned)ow) continue;
+            const float* tp = reinterpret_cast<const float*>(sP + ((2 * qy + ky) * SP_R + 2 * qx + kx) * SP_YROW) + c * 8;
+            const float4 v0 = *reinterpret_cast<const float4*>(tp), v1 = *reinterpret_cast<const float4*>(tp + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (f[j] > m[j]) { m[j] = f[j]; code[j] = (uint32_t)(ky * 3 + kx); }
+          }
+        }
+        const size_t o = (((size_t)img * oh2 + gy) * ow2 + gx) * 8 + c;
+        uint32_t hv[4], lv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hv[k] = sp_pack2(m[2 * k], m[2 * k + 1]);
+          lv[k] = sp_pack2(m[2 * k] - __uint_as_float(hv[k] << 16), m[2 * k + 1] - __uint_as_float(hv[k] & 0xFFFF0000u));
+        }
+        p1_h[o] = make_uint4(hv[0], hv[1], hv[2], hv[3]);
+        p1_l[o] = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+        uint32_t sb = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (m[j] > 0.f) sb |= 1u << j; else code[j] = 15u;
+        }
+        if (sign) sign[o] = (uint8_t)sb;
+        if (arg) arg[o] = make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
+                                     code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24));
+      }
+    }
+  }
+}
+#pragma clang fp contract(fast)
+}  // namespace
+
+extern "C" int rart_engine_stem_fwd_fused_pair(const void* src, int src_is_u8, const void* wgt_hi, const void* wgt_lo, const float* bias,
+                                               void* p1_hi, void* p1_lo, void* argmax_out, void* sign_out, int n, int h, int w,
+                                               const float* mean_host, const float* std_host, rart_stream_t stream) {
+  RART_CHECK_ARG(src && wgt_hi && wgt_lo && p1_hi && p1_lo && n > 0 && h % 4 == 0 && w % 4 == 0 && h >= 4 && w >= 4,
+                 "rart_engine_stem_fwd_fused_pair: bad arguments (h, w multiples of 4)");
+  StemNormP nm;
+  for (int c = 0; c < 3; ++c) {
+    nm.mean[c] = mean_host ? mean_host[c] : 0.f;
+    nm.istd[c] = std_host ? 1.0f / std_host[c] : 1.f;
+  }
+  const long long tiles = (long long)n * ((h / 4 + SP_PT - 1) / SP_PT) * ((w / 4 + SP_PT - 1) / SP_PT);
+  const int grid = (int)(tiles < 256 ? tiles : 256);              // persistent: one workgroup per CU
+  if (src_is_u8)
+    hipLaunchKernelGGL(k_stem_fwd_pair<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, src, (const uint16_t*)wgt_hi,
+                       (const uint16_t*)wgt_lo, bias, (uint4*)p1_hi, (uint4*)p1_lo, (uint2*)argmax_out, (uint8_t*)sign_out, n, h, w, nm);
+  else
+    hipLaunchKernelGGL(k_stem_fwd_pair<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, src, (const uint16_t*)wgt_hi,
+                       (const uint16_t*)wgt_lo, bias, (uint4*)p1_hi, (uint4*)p1_lo, (uint2*)argmax_out, (uint8_t*)sign_out, n, h, w, nm);
+  RART_CHECK_LAUNCH("rart_engine_stem_fwd_fused_pair");
+  return RART_OK;
+}

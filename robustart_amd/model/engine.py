@@ -152,6 +152,7 @@ class ResNet50Engine:
             self.stem_w = _bf16(torch.cat([wrow, wrow_l, wrow], 1)).to(dev)      # x_hi.w_hi, x_hi.w_lo, x_lo.w_hi row taps
             wpl = wl.permute(2, 3, 1, 0).reshape(147, 64)
             self.stem_wd = _bf16(_pad_rows(torch.cat([wp, wpl, wp], 1), _rows_mult(self.stem_patch_cols))).to(dev)
+            self.stem_w_pair = _bf16(torch.stack([wrow, wrow_l])).contiguous().to(dev)   # fused pair stem forward (stem_pair.hip): [2][64][224]
             wt32 = self._stem_bwd_table(st.w_folded, dtype=torch.float32)           # fused pair stem backward (stem_pair.hip)
             wt_hi = wt32.to(torch.bfloat16)
             self.stem_wt_pair = torch.stack([wt_hi, (wt32 - wt_hi.float()).to(torch.bfloat16)]).contiguous().to(dev)
@@ -906,17 +907,23 @@ class ResNet50Engine:
         acts = {}
         h1, w1 = H // 2, W // 2
         h2, w2 = h1 // 2, w1 // 2
-        hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
-        _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]),
-                                              B, H, W, meanf, stdf, sp))
-        y1 = self._get('x3_y1', (2, B, h1, w1, 64))
-        self._gemm(hi, self.stem_w, y1, B, (h1, w1), (H + 8, W + 8), 4, 32, [(r, 0) for r in range(7)], 64, (h1, w1), 64,
-                   bias=self.stem.bias, flags=F_RELU, stride=(2, 2), pair=True)
         p1 = self._get('x3_p1', (2, B, h2, w2, 64))
         parg = self._get('p1_argmax', (B, h2, w2, 64), torch.uint8) if keep else None
         xs = self._get('p1_sign', (B, h2, w2, 8), torch.uint8) if keep else None
-        _lib.check(lib.rart_engine_maxpool_pair(_lib.ptr(y1), self._lo(y1), _lib.ptr(p1), self._lo(p1), _lib.ptr(parg),
-                                                _lib.ptr(xs), B, h1, w1, 64, sp))
+        if self.fused_stem_fwd:
+            # stem: normalise + split + 7x7/2 conv + bias + ReLU + max pool on pairs, one persistent kernel (stem_pair.hip)
+            _lib.check(lib.rart_engine_stem_fwd_fused_pair(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(self.stem_w_pair[0]),
+                                                           _lib.ptr(self.stem_w_pair[1]), _lib.ptr(self.stem.bias), _lib.ptr(p1[0]),
+                                                           _lib.ptr(p1[1]), _lib.ptr(parg), _lib.ptr(xs), B, H, W, meanf, stdf, sp))
+        else:
+            hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
+            _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]),
+                                                  B, H, W, meanf, stdf, sp))
+            y1 = self._get('x3_y1', (2, B, h1, w1, 64))
+            self._gemm(hi, self.stem_w, y1, B, (h1, w1), (H + 8, W + 8), 4, 32, [(r, 0) for r in range(7)], 64, (h1, w1), 64,
+                       bias=self.stem.bias, flags=F_RELU, stride=(2, 2), pair=True)
+            _lib.check(lib.rart_engine_maxpool_pair(_lib.ptr(y1), self._lo(y1), _lib.ptr(p1), self._lo(p1), _lib.ptr(parg),
+                                                    _lib.ptr(xs), B, h1, w1, 64, sp))
         acts['p1_argmax'] = parg
         x, xhw = p1, (h2, w2)
         pre_a = False            # this block's conv1 was already computed by the previous block's launch

@@ -127,7 +127,7 @@ def test_x3_u8_entry_and_batch_invariance(setup):
 
 def _x3_reference_backward_with_engine_masks(m, eng, acts, dl, std):
     """fp64 backward-to-input of the fp32 network `m` (BatchNorm folded in fp64) using the ENGINE's forward decisions -- its
-    1-bit ReLU sign tensors and its stem output for the max pool -- so that only the arithmetic of the backward chain is
+    1-bit ReLU sign tensors and the max pool's argmax codes -- so that only the arithmetic of the backward chain is
     compared: a ReLU that flips between two forwards that differ by 1e-5 changes the gradient discontinuously, which is a
     property of the network, not of the kernels."""
     import numpy as np
@@ -154,11 +154,17 @@ def _x3_reference_backward_with_engine_masks(m, eng, acts, dl, std):
             dz = (dgrad(ca, dza, xhw) + dz) * sign(mx)
         else:
             dz = (dgrad(ca, dza, xhw) + dgrad(ds, dz, xhw)) * sign(mx)
-    y1p = eng._buf['x3_y1']
-    y1 = (y1p[0].double() + y1p[1].double()).cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-    g1, = torch.autograd.grad(F.max_pool2d(y1, 3, 2, 1), y1, grad_outputs=dz)
-    dz1 = g1 * (y1.detach() > 0)
-    g = dgrad(eng.stem, dz1, (y1.shape[2] * 2, y1.shape[3] * 2))
+    # max-pool backward + stem ReLU from the engine's argmax codes (code k = window element (k / 3, k % 3); 15 = window maximum <= 0)
+    codes = acts['p1_argmax'].cpu().long().permute(0, 3, 1, 2)
+    h2, w2 = codes.shape[2], codes.shape[3]
+    dz1 = torch.zeros(B, codes.shape[1], 2 * h2, 2 * w2, dtype=dt)
+    for k in range(9):
+        ky, kx = divmod(k, 3)
+        ys, xs = 2 * torch.arange(h2) - 1 + ky, 2 * torch.arange(w2) - 1 + kx
+        oky, okx = ys >= 0, xs >= 0
+        sel = ((codes == k).to(dt) * dz)[:, :, oky][:, :, :, okx]
+        dz1[:, :, ys[oky][:, None], xs[okx][None, :]] += sel
+    g = dgrad(eng.stem, dz1, (dz1.shape[2] * 2, dz1.shape[3] * 2))
     return g / torch.tensor(std, dtype=dt).view(1, 3, 1, 1)
 
 
@@ -464,6 +470,34 @@ def test_conv_tail_pair_kernel_vs_fp64(C, backward, nxt):
         assert nerr <= 1e-5
         if not backward:
             assert torch.equal(_bits(sn, C), (dn[0] > 0).to(torch.uint8))
+
+
+@pytest.mark.parametrize('HW,u8', [((96, 128), False), ((224, 224), True), ((32, 64), False)])
+def test_x3_fused_stem_forward_is_bit_identical_to_the_three_launch_chain(setup, HW, u8):
+    """rart_engine_stem_fwd_fused_pair (normalise + split + 7x7/2 conv with three products per K step + bias + ReLU + split + max pool of
+    the pair values, one persistent kernel) against rart_engine_prep_input -> rart_gemm_pair_bf16 -> rart_engine_maxpool_pair: the pooled
+    pair, the argmax codes and the sign bits, bit for bit (same products in the same order, same rounding points); fp32 and uint8 input."""
+    m, eng = setup
+    g = torch.Generator().manual_seed(41)
+    if u8:
+        x = torch.randint(0, 256, (3, HW[0], HW[1], 3), generator=g, dtype=torch.uint8).cuda()
+        run = lambda: eng._forward(x, True, MEAN, STD, True)          # noqa: E731
+    else:
+        x = torch.rand(3, 3, HW[0], HW[1], generator=g).cuda()
+        run = lambda: eng._forward(x, False, MEAN, STD, True)         # noqa: E731
+    assert eng.fused_stem_fwd
+    la, _ = run()
+    a = [eng._buf[k].clone() for k in ('x3_p1', 'p1_argmax', 'p1_sign')]
+    la = la.clone()
+    eng.fused_stem_fwd = False
+    try:
+        lb, _ = run()
+    finally:
+        eng.fused_stem_fwd = True
+    b = [eng._buf[k] for k in ('x3_p1', 'p1_argmax', 'p1_sign')]
+    for name, u, v in zip(('p1 pair', 'argmax codes', 'sign bits'), a, b):
+        assert torch.equal(u, v), name
+    assert torch.equal(la, lb)
 
 
 def test_x3_fused_tail_matches_the_two_launch_path(setup):
