@@ -53,7 +53,7 @@ enum {
 /* ABI version of THIS header.  Bumped whenever a struct layout or a signature changes (round 3 -> 4: rart_conv_desc grew
  * its tap arrays from 16 to 32 entries and gained dst_pair_off / res_pair_off; several attack entries gained a per-row
  * sample-index pointer).  A caller compiled against another header must refuse to run: compare with rart_version(). */
-#define RART_ABI_VERSION 104
+#define RART_ABI_VERSION 105
 int rart_version(void);
 const char* rart_last_error_string(void);
 /* name of corruption id (static string), NULL if out of range */

@@ -13,7 +13,7 @@ c_void_p, c_int, c_size_t, c_u64, c_float = (ctypes.c_void_p, ctypes.c_int, ctyp
                                               ctypes.c_uint64, ctypes.c_float)
 c_double = ctypes.c_double
 
-ABI_VERSION = 104        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
+ABI_VERSION = 105        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
 
 # name -> (restype, argtypes); every symbol include/robustart_hip.h declares
 SIGNATURES = {
