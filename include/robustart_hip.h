@@ -760,6 +760,15 @@ int rart_bn_train_backward_bf16(const void* dy, const void* ymask, const void* z
 int rart_transpose_gather_bf16(const void* src, void* dst, int batch, int src_h, int src_w, int channels, int grid_h,
                                int grid_w, int sy, int sx, int n_taps, const int* tap_dy, const int* tap_dx,
                                long long rows_padded, int chunk, int rows_total, rart_stream_t stream);
+/* Weight gradient straight from the NHWC activations (csrc/wgrad_direct.hip): partial[z][t * channels + c][n] = sum over the positions m of
+ * K split z (chunk positions each) of x[pixel(m) + tap t][c] * dz[m][n], fp32, the layout rart_wgrad_reduce_f32 folds -- without the two
+ * rart_transpose_gather_bf16 passes: the position-major tiles are read out of LDS transposed (ds_read_b64_tr_b16).  x [batch][in_h][in_w]
+ * [channels], dz [batch][grid_h][grid_w][dz_cols] bf16; channels 64 or a multiple of 128, dz_cols a multiple of 64, 1..9 taps;
+ * chunk a multiple of 32 with splits * chunk >= batch * grid_h * grid_w; ld_n = dz_cols.  (loss.backward() of cls_solver.py:183-215) */
+int rart_wgrad_direct_supported(int channels, int dz_cols, int n_taps);
+int rart_wgrad_direct_bf16(const void* x, const void* dz, float* partial, int batch, int in_h, int in_w, int channels, int grid_h, int grid_w,
+                           int dz_cols, int stride_y, int stride_x, int n_taps, const int* tap_dy, const int* tap_dx, int splits, int chunk,
+                           int ld_n, rart_stream_t stream);
 /* grad[n][c][t] (torch conv weight layout, t = r*S + s) (+)= sum_z partial[z][t*channels_padded + c][n];
  * partial: fp32 [splits][taps*channels_padded][ld_n], the split-K output of rart_conv_igemm_bf16; it is scratch:
  * more than 16 splits are first folded 16:1 in place. */

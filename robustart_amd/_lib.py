@@ -125,6 +125,8 @@ SIGNATURES = {
     'rart_engine_stem_col2im': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rart_engine_stem_fwd_fused': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                            c_int, c_void_p, c_void_p, c_void_p]),
+    'rart_wgrad_direct_supported': (c_int, [c_int, c_int, c_int]),
+    'rart_wgrad_direct_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rart_conv3x3_tail_pair_supported': (c_int, [c_int]),
     'rart_conv3x3_tail_pair': (c_int, [c_void_p, c_void_p]),
     'rart_engine_stem_fwd_fused_pair': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -94,6 +94,7 @@ class ResNet50TrainEngine:
         self.fc_w = torch.zeros(self.fc_kpad, self.fc_in, dtype=torch.bfloat16, device=dev)      # [1024][2048]
         self.fc_wd = torch.zeros(self.fc_in, self.fc_kpad, dtype=torch.bfloat16, device=dev)     # [2048][1024]
         self._buf = {}
+        self.direct_wgrad = True       # False: transpose_gather (dz^T, im2col^T) + implicit GEMM on the copies (rounds 1-3; cross-check)
         self.repack()
 
     # ------------------------------------------------------------------ tables
@@ -234,6 +235,19 @@ class ResNet50TrainEngine:
         gh, gw = grid_hw
         M = B * gh * gw
         kp = len(taps) * x_c                                   # rows of the transposed im2col matrix
+        if self.direct_wgrad and c_valid is None and lib.rart_wgrad_direct_supported(x_c, n_pad_cols, len(taps)):
+            # straight from the NHWC activations (csrc/wgrad_direct.hip): no transposed copies, no materialised im2col
+            row_tiles = len(taps) * (x_c // 128) if x_c >= 128 else (len(taps) + 1) // 2
+            tiles = row_tiles * (n_pad_cols // (128 if n_pad_cols % 128 == 0 else 64))
+            splits = max(1, min(2048 // max(tiles, 1), M // 256 if M >= 512 else 1, 256))
+            chunk = ((M + splits - 1) // splits + 31) // 32 * 32
+            splits = (M + chunk - 1) // chunk
+            part = self._scratch('wg_part', splits * kp * n_pad_cols * 4)
+            _lib.check(lib.rart_wgrad_direct_bf16(x.data_ptr(), dz.data_ptr(), part.data_ptr(), B, x_hw[0], x_hw[1], x_c, gh, gw, n_pad_cols,
+                                                  stride, stride, len(taps), _ints([t[0] for t in taps]), _ints([t[1] for t in taps]),
+                                                  splits, chunk, n_pad_cols, sp))
+            _lib.check(lib.rart_wgrad_reduce_f32(part.data_ptr(), splits, len(taps), x_c, x_c, n_out, n_pad_cols, grad.data_ptr(), 0, sp))
+            return
         bn_tile = 128 if n_pad_cols > 64 else 64
         tiles = ((kp + 127) // 128) * ((n_pad_cols + bn_tile - 1) // bn_tile)
         splits = max(1, min(1024 // max(tiles, 1), M // 512 if M >= 1024 else 1, 256))

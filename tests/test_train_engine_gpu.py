@@ -141,16 +141,21 @@ def _tiny_resnet_inputs(B, S):
     return model, x01, y
 
 
-def test_wgrad_single_layers_match_torch():
-    """Weight gradient of single convs (3x3/1, 3x3/2, 1x1/1, 1x1/2): split-K GEMM path vs torch autograd."""
+@pytest.mark.parametrize('direct', [True, False])
+def test_wgrad_single_layers_match_torch(direct):
+    """Weight gradient of single convs (3x3/1, 3x3/2, 1x1/1, 1x1/2) vs torch autograd, on both paths: rart_wgrad_direct_bf16 (tiles
+    position-major in LDS, fragments through ds_read_b64_tr_b16; two taps per tile for 64 channels, 64- and 128-column tiles, position
+    counts that are not a multiple of the 32-position K step, several K splits) and the transpose_gather + implicit-GEMM path it replaces."""
     from robustart_amd.model.train_engine import ResNet50TrainEngine, _TConv
     model, _, _ = _tiny_resnet_inputs(2, 32)
     for p in model.parameters():
         p.grad = torch.zeros_like(p)
     eng = ResNet50TrainEngine(model)
+    eng.direct_wgrad = direct
     torch.manual_seed(5)
     for cin, cout, r, stride, H, B in [(64, 64, 3, 1, 16, 4), (128, 128, 3, 2, 16, 4), (256, 64, 1, 1, 8, 8),
-                                       (256, 512, 1, 2, 8, 8), (512, 2048, 1, 1, 4, 16)]:
+                                       (256, 512, 1, 2, 8, 8), (512, 2048, 1, 1, 4, 16), (64, 256, 1, 1, 10, 3), (64, 64, 1, 1, 10, 3),
+                                       (128, 128, 3, 1, 14, 5), (64, 64, 3, 1, 56, 6), (1024, 256, 1, 1, 14, 4), (256, 256, 3, 2, 14, 3)]:
         conv = torch.nn.Conv2d(cin, cout, r, stride=stride, padding=r // 2, bias=False).cuda()
         conv.weight.grad = torch.zeros_like(conv.weight)
         tc = _TConv(conv, None, torch.device('cuda'), torch)
@@ -160,7 +165,7 @@ def test_wgrad_single_layers_match_torch():
         eng._conv_wgrad(tc, dz, (oh, oh), x, (H, H))
         w = conv.weight.detach().clone().requires_grad_(True)
         F.conv2d(x.float().permute(0, 3, 1, 2), w, stride=stride, padding=r // 2).backward(dz.float().permute(0, 3, 1, 2))
-        assert _cos(conv.weight.grad, w.grad) > 0.99999
+        assert _cos(conv.weight.grad, w.grad) > 0.99999, (cin, cout, r, stride, H, B)
         torch.testing.assert_close(conv.weight.grad, w.grad, rtol=1e-3, atol=1e-3 * float(w.grad.abs().max()))
 
 
