@@ -94,6 +94,9 @@ class ResNet50TrainEngine:
         self.fc_w = torch.zeros(self.fc_kpad, self.fc_in, dtype=torch.bfloat16, device=dev)      # [1024][2048]
         self.fc_wd = torch.zeros(self.fc_in, self.fc_kpad, dtype=torch.bfloat16, device=dev)     # [2048][1024]
         self._buf = {}
+        # K splits of a weight-gradient launch: ~1 024 workgroups in all (measured at B = 256: 512 -> 58.1, 1 024 -> 55.1-55.8, 2 048 -> 56.3,
+        # 4 096 -> 57.5 ms per adv_train step: more splits fill the CUs, every split writes and re-reads an fp32 copy of the weight tensor)
+        self.wgrad_target_wgs, self.wgrad_min_chunk = 1024, 256
         self.direct_wgrad = True       # False: transpose_gather (dz^T, im2col^T) + implicit GEMM on the copies (rounds 1-3; cross-check)
         self.repack()
 
@@ -239,7 +242,7 @@ class ResNet50TrainEngine:
             # straight from the NHWC activations (csrc/wgrad_direct.hip): no transposed copies, no materialised im2col
             row_tiles = len(taps) * (x_c // 128) if x_c >= 128 else (len(taps) + 1) // 2
             tiles = row_tiles * (n_pad_cols // (128 if n_pad_cols % 128 == 0 else 64))
-            splits = max(1, min(2048 // max(tiles, 1), M // 256 if M >= 512 else 1, 256))
+            splits = max(1, min(self.wgrad_target_wgs // max(tiles, 1), M // self.wgrad_min_chunk if M >= 2 * self.wgrad_min_chunk else 1, 256))
             chunk = ((M + splits - 1) // splits + 31) // 32 * 32
             splits = (M + chunk - 1) // chunk
             part = self._scratch('wg_part', splits * kp * n_pad_cols * 4)
