@@ -739,15 +739,16 @@ int rart_label_smooth_ce_f32(const float* logits, const int64_t* labels, int bat
 size_t rart_bn_workspace_bytes(size_t rows, int channels);
 /* batch statistics of z, y = [relu](z*scale + shift [+ res]); running stats updated in place when non-NULL
  * (running_var with the unbiased variance); mean_out / invstd_out [channels] are kept for the backward;
- * scale_shift [2][channels] receives gamma*invstd and beta - mean*gamma*invstd. */
-int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, size_t rows, int channels, const float* gamma,
+ * scale_shift [2][channels] receives gamma*invstd and beta - mean*gamma*invstd.  sign_out (nullable): [rows][channels / 8] bytes,
+ * bit j of byte (row, c / 8) = (y[row][c] > 0): the backward's ReLU mask at 1/16 of y's bytes. */
+int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, void* sign_out, size_t rows, int channels, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, double momentum, double eps,
                                int relu, float* mean_out, float* invstd_out, float* scale_shift, void* workspace,
                                size_t workspace_bytes, rart_stream_t stream);
-/* g = dy * [ymask > 0] (ymask NULL: g = dy); dgamma = sum g*xhat, dbeta = sum g (written, or added when
- * accumulate != 0); dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); g_out (nullable) receives g.
- * coef: [3][channels] fp32 scratch. */
-int rart_bn_train_backward_bf16(const void* dy, const void* ymask, const void* z, void* dz, void* g_out, size_t rows,
+/* g = dy * [ymask > 0] (ymask NULL: g = dy; ymask_is_bits: ymask is the forward's sign_out instead of the bf16 activation);
+ * dgamma = sum g*xhat, dbeta = sum g (written, or added when accumulate != 0); dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));
+ * g_out (nullable) receives g.  coef: [3][channels] fp32 scratch. */
+int rart_bn_train_backward_bf16(const void* dy, const void* ymask, int ymask_is_bits, const void* z, void* dz, void* g_out, size_t rows,
                                 int channels, const float* gamma, const float* mean, const float* invstd, float* dgamma,
                                 float* dbeta, int accumulate, float* coef, void* workspace, size_t workspace_bytes,
                                 rart_stream_t stream);

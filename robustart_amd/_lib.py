@@ -170,10 +170,10 @@ SIGNATURES = {
     'rart_label_smooth_ce_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p,
                                          c_void_p]),
     'rart_bn_workspace_bytes': (c_size_t, [c_size_t, c_int]),
-    'rart_bn_train_forward_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p,
+    'rart_bn_train_forward_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_size_t, c_void_p]),
-    'rart_bn_train_backward_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p,
+    'rart_bn_train_backward_bf16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                             c_void_p]),
     'rart_transpose_gather_bf16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

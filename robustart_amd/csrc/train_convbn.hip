@@ -51,13 +51,19 @@ __device__ __forceinline__ void keep8(const uint4& v, bool* k) {
   }
 }
 
+// ... or from the 1-bit form (bit j of the byte = channel j of the group > 0), written by k_bn_apply
+__device__ __forceinline__ void keep8_bits(uint32_t byte, bool* k) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = (byte >> j) & 1u;
+}
+
 // ---- two-level column reductions over rows of a [M][C] bf16 matrix ------------------------------------------
 // MODE 0: a = sum z, b = sum z^2.   MODE 1: g = dy*[ymask>0]; a = sum g, b = sum g*xhat  (xhat from z, mean, invstd)
 // Block = 256 threads = (C/8 channel groups) x (2048/C row lanes); partial[chunk][0/1][C] fp32.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_colsum2(const uint4* __restrict__ z, const uint4* __restrict__ dy,
-                                                     const uint4* __restrict__ ymask, const float* __restrict__ mean,
-                                                     const float* __restrict__ invstd, size_t M, int C,
+                                                     const uint4* __restrict__ ymask, const uint8_t* __restrict__ ybits,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd, size_t M, int C,
                                                      size_t rows_per_chunk, float* __restrict__ partial) {
   __shared__ float sh[2][2048];
   const int c8n = C / 8;
@@ -86,10 +92,11 @@ __global__ __launch_bounds__(kBlock) void k_colsum2(const uint4* __restrict__ z,
       float gf[8];
       unpack8(dy[idx], gf);
       bool kp[8];
-      if (ymask) keep8(ymask[idx], kp);
+      if (ybits) keep8_bits(ybits[idx], kp);
+      else if (ymask) keep8(ymask[idx], kp);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float g = (!ymask || kp[j]) ? gf[j] : 0.f;
+        const float g = ((!ymask && !ybits) || kp[j]) ? gf[j] : 0.f;
         a[j] += g;
         b[j] = fmaf(g, (zf[j] - mu[j]) * is[j], b[j]);
       }
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
 // The grid stride (gridDim.x * 256 vectors) is a multiple of the channel-group count (a power of two <= 256), so a
 // thread meets the same 8 channels in every iteration: its per-channel constants are loaded once, outside the loop.
 __global__ __launch_bounds__(kBlock) void k_bn_apply(const uint4* __restrict__ z, const uint4* __restrict__ res,
-                                                     uint4* __restrict__ y, size_t n8, int c8n,
+                                                     uint4* __restrict__ y, uint8_t* __restrict__ sign, size_t n8, int c8n,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      int relu) {
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -208,11 +215,21 @@ __global__ __launch_bounds__(kBlock) void k_bn_apply(const uint4* __restrict__ z
       if (relu) v = fmaxf(v, 0.f);
       zf[j] = v;
     }
-    y[i] = pack8(zf);
+    const uint4 o = pack8(zf);
+    y[i] = o;
+    if (sign) {             // (stored value > 0), one byte per 8 channels: the backward's ReLU mask at 1/16 of y's bytes
+      bool kp[8];
+      keep8(o, kp);
+      uint32_t sb = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sb |= (kp[j] ? 1u : 0u) << j;
+      sign[i] = (uint8_t)sb;
+    }
   }
 }
 
 __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(const uint4* __restrict__ dy, const uint4* __restrict__ ymask,
+                                                         const uint8_t* __restrict__ ybits,
                                                          const uint4* __restrict__ z, uint4* __restrict__ dz,
                                                          uint4* __restrict__ g_out, size_t n8, int c8n, int C,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -234,10 +251,11 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(const uint4* __restrict
     unpack8(dy[i], gf);
     unpack8(z[i], zf);
     bool kp[8];
-    if (ymask) keep8(ymask[i], kp);
+    if (ybits) keep8_bits(ybits[i], kp);
+    else if (ymask) keep8(ymask[i], kp);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float g = (!ymask || kp[j]) ? gf[j] : 0.f;
+      const float g = ((!ymask && !ybits) || kp[j]) ? gf[j] : 0.f;
       gf[j] = g;
       const float xh = (zf[j] - mu[j]) * is[j];
       zf[j] = sg[j] * (g - k1[j] - xh * k2[j]);
@@ -456,7 +474,7 @@ extern "C" size_t rart_bn_workspace_bytes(size_t rows, int channels) {
   return (size_t)chunks * 2 * channels * sizeof(float);
 }
 
-extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, size_t rows, int channels,
+extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, void* sign_out, size_t rows, int channels,
                                           const float* gamma, const float* beta, float* running_mean, float* running_var,
                                           double momentum, double eps, int relu, float* mean_out, float* invstd_out,
                                           float* scale_shift /* [2][channels] */, void* workspace, size_t workspace_bytes,
@@ -473,7 +491,7 @@ extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* 
   size_t rpc;
   const int chunks = chunks_for(rows, channels, &rpc);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_colsum2<0>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
+  hipLaunchKernelGGL(k_colsum2<0>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr, nullptr,
                      rows, channels, rpc, (float*)workspace);
   hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + 15) / 16), dim3(256), 0, st, (const float*)workspace, chunks,
                      channels, 1.0 / (double)rows, (double)rows / (double)(rows - 1), gamma, beta, (float)eps,
@@ -481,12 +499,12 @@ extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* 
                      scale_shift + channels);
   const size_t n8 = rows * (size_t)(channels / 8);
   hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n8)), dim3(kBlock), 0, st, (const uint4*)z, (const uint4*)res, (uint4*)y,
-                     n8, channels / 8, scale_shift, scale_shift + channels, relu);
+                     (uint8_t*)sign_out, n8, channels / 8, scale_shift, scale_shift + channels, relu);
   RART_CHECK_LAUNCH("rart_bn_train_forward_bf16");
   return RART_OK;
 }
 
-extern "C" int rart_bn_train_backward_bf16(const void* dy, const void* ymask, const void* z, void* dz, void* g_out,
+extern "C" int rart_bn_train_backward_bf16(const void* dy, const void* ymask, int ymask_is_bits, const void* z, void* dz, void* g_out,
                                            size_t rows, int channels, const float* gamma, const float* mean,
                                            const float* invstd, float* dgamma, float* dbeta, int accumulate,
                                            float* coef /* [3][channels] scratch */, void* workspace,
@@ -503,13 +521,15 @@ extern "C" int rart_bn_train_backward_bf16(const void* dy, const void* ymask, co
   size_t rpc;
   const int chunks = chunks_for(rows, channels, &rpc);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_colsum2<1>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, (const uint4*)dy,
-                     (const uint4*)ymask, mean, invstd, rows, channels, rpc, (float*)workspace);
+  const uint4* ym = ymask_is_bits ? nullptr : (const uint4*)ymask;
+  const uint8_t* yb = ymask_is_bits ? (const uint8_t*)ymask : nullptr;
+  hipLaunchKernelGGL(k_colsum2<1>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, (const uint4*)dy, ym, yb, mean, invstd, rows,
+                     channels, rpc, (float*)workspace);
   hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((channels + 15) / 16), dim3(256), 0, st, (const float*)workspace, chunks,
                      channels, 1.0 / (double)rows, gamma, invstd, dgamma, dbeta, accumulate, coef);
   const size_t n8 = rows * (size_t)(channels / 8);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n8)), dim3(kBlock), 0, st, (const uint4*)dy, (const uint4*)ymask,
-                     (const uint4*)z, (uint4*)dz, (uint4*)g_out, n8, channels / 8, channels, mean, invstd, coef);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n8)), dim3(kBlock), 0, st, (const uint4*)dy, ym, yb, (const uint4*)z, (uint4*)dz,
+                     (uint4*)g_out, n8, channels / 8, channels, mean, invstd, coef);
   RART_CHECK_LAUNCH("rart_bn_train_backward_bf16");
   return RART_OK;
 }

@@ -97,6 +97,8 @@ class ResNet50TrainEngine:
         # K splits of a weight-gradient launch: ~1 024 workgroups in all (measured at B = 256: 512 -> 58.1, 1 024 -> 55.1-55.8, 2 048 -> 56.3,
         # 4 096 -> 57.5 ms per adv_train step: more splits fill the CUs, every split writes and re-reads an fp32 copy of the weight tensor)
         self.wgrad_target_wgs, self.wgrad_min_chunk = 1024, 256
+        self.bit_masks = True          # False: the BatchNorm backward reads the bf16 activation for its ReLU mask (rounds 1-3; cross-check)
+        self._ysign = {}
         self.direct_wgrad = True       # False: transpose_gather (dz^T, im2col^T) + implicit GEMM on the copies (rounds 1-3; cross-check)
         self.repack()
 
@@ -209,8 +211,12 @@ class ResNet50TrainEngine:
         need = lib.rart_bn_workspace_bytes(rows, c.cout)
         ws = self._scratch('bn_ws', need)
         mom = bn.momentum if bn.momentum is not None else 0.1
+        sign = None
+        if relu and self.bit_masks:      # 1 bit per element of (y > 0): what the backward reads instead of y (1/16 of its bytes)
+            sign = self._get('sgn_%x' % y.data_ptr(), (rows, c.cout // 8), self.torch.uint8)
+            self._ysign[y.data_ptr()] = sign
         _lib.check(lib.rart_bn_train_forward_bf16(
-            z.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(), rows, c.cout, bn.weight.data_ptr(),
+            z.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(), _lib.ptr(sign), rows, c.cout, bn.weight.data_ptr(),
             bn.bias.data_ptr(), bn.running_mean.data_ptr() if bn.track_running_stats else None,
             bn.running_var.data_ptr() if bn.track_running_stats else None, mom, bn.eps, 1 if relu else 0,
             c.mean.data_ptr(), c.invstd.data_ptr(), c.scale_shift.data_ptr(), ws.data_ptr(), need, _lib.stream_ptr()))
@@ -222,8 +228,11 @@ class ResNet50TrainEngine:
         need = lib.rart_bn_workspace_bytes(rows, c.cout)
         ws = self._scratch('bn_ws', need)
         coef = self._get('bn_coef', (3, 2048), self.torch.float32)
+        bits = self._ysign.get(ymask.data_ptr()) if (ymask is not None and self.bit_masks) else None
         _lib.check(lib.rart_bn_train_backward_bf16(
-            dy.data_ptr(), ymask.data_ptr() if ymask is not None else None, z.data_ptr(), dz.data_ptr(),
+            dy.data_ptr(),
+            bits.data_ptr() if bits is not None else (ymask.data_ptr() if ymask is not None else None), 1 if bits is not None else 0,
+            z.data_ptr(), dz.data_ptr(),
             g_out.data_ptr() if g_out is not None else None, rows, c.cout, bn.weight.data_ptr(), c.mean.data_ptr(),
             c.invstd.data_ptr(), bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), 0, coef.data_ptr(), ws.data_ptr(),
             need, _lib.stream_ptr()))

@@ -39,7 +39,8 @@ def test_bn_train_forward_and_backward_kernels(rows, C, relu, with_res):
     mean, invstd, ss = (torch.empty(C, device='cuda'), torch.empty(C, device='cuda'), torch.empty(2, C, device='cuda'))
     need = lib.rart_bn_workspace_bytes(rows, C)
     ws = torch.empty(need, dtype=torch.uint8, device='cuda')
-    L.check(lib.rart_bn_train_forward_bf16(z.data_ptr(), res.data_ptr() if with_res else None, y.data_ptr(), rows, C,
+    sign = torch.full((rows, C // 8), 0xAA, dtype=torch.uint8, device='cuda')
+    L.check(lib.rart_bn_train_forward_bf16(z.data_ptr(), res.data_ptr() if with_res else None, y.data_ptr(), sign.data_ptr(), rows, C,
                                            gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, relu,
                                            mean.data_ptr(), invstd.data_ptr(), ss.data_ptr(), ws.data_ptr(), need,
                                            L.stream_ptr()))
@@ -60,10 +61,19 @@ def test_bn_train_forward_and_backward_kernels(rows, C, relu, with_res):
     dy = torch.randn(rows, C, device='cuda').to(torch.bfloat16)
     dz, g = torch.empty_like(z), torch.empty_like(z)
     dgam, dbet, coef = torch.empty(C, device='cuda'), torch.empty(C, device='cuda'), torch.empty(3, C, device='cuda')
-    L.check(lib.rart_bn_train_backward_bf16(dy.data_ptr(), y.data_ptr() if relu else None, z.data_ptr(), dz.data_ptr(),
+    # the sign tensor is the 1-bit form of (y > 0)
+    sh = torch.arange(8, device='cuda', dtype=torch.uint8)
+    assert torch.equal(((sign.unsqueeze(-1) >> sh) & 1).reshape(rows, C), (y > 0).to(torch.uint8))
+    L.check(lib.rart_bn_train_backward_bf16(dy.data_ptr(), y.data_ptr() if relu else None, 0, z.data_ptr(), dz.data_ptr(),
                                             g.data_ptr(), rows, C, gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                             dgam.data_ptr(), dbet.data_ptr(), 0, coef.data_ptr(), ws.data_ptr(), need,
                                             L.stream_ptr()))
+    if relu:      # the same backward with the mask read as bits: bit-identical results
+        dz2, g2, dgam2, dbet2 = torch.empty_like(z), torch.empty_like(z), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        L.check(lib.rart_bn_train_backward_bf16(dy.data_ptr(), sign.data_ptr(), 1, z.data_ptr(), dz2.data_ptr(), g2.data_ptr(), rows, C,
+                                                gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dgam2.data_ptr(), dbet2.data_ptr(), 0,
+                                                coef.data_ptr(), ws.data_ptr(), need, L.stream_ptr()))
+        assert torch.equal(dz, dz2) and torch.equal(g, g2) and torch.equal(dgam, dgam2) and torch.equal(dbet, dbet2)
     gmask = dy.float() * ((y.float() > 0).float() if relu else 1.0)
     torch.testing.assert_close(g.float(), gmask, rtol=0, atol=0)
     # torch: BatchNorm backward for upstream gradient gmask
