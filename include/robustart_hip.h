@@ -351,6 +351,11 @@ typedef struct rart_conv_desc {
    * with flag 2 the output is plain fp32 and no residual / mask is applied.  Reference arithmetic: fp32 everywhere
    * (adv/attack.py:20-23, autopgd_base.py:271-289); this mode reproduces it to ~1e-5 of the logit scale. */
   int64_t dst_pair_off, res_pair_off;
+  /* train-mode forward (nullable): per 128-row tile of the output, the column sums and sums of squares of the bf16 values as stored,
+   * fp32 [ceil(rows / 128)][2][n_cols] -- the batch statistics of the BatchNorm that follows (rart_bn_train_forward_bf16's
+   * stats_partial), from the accumulators instead of a pass over the tensor.  Plain bf16 convolution only: no bias / residual / mask /
+   * flags, unbatched. */
+  float* bn_stats_out;
 } rart_conv_desc;
 
 int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
@@ -740,11 +745,13 @@ size_t rart_bn_workspace_bytes(size_t rows, int channels);
 /* batch statistics of z, y = [relu](z*scale + shift [+ res]); running stats updated in place when non-NULL
  * (running_var with the unbiased variance); mean_out / invstd_out [channels] are kept for the backward;
  * scale_shift [2][channels] receives gamma*invstd and beta - mean*gamma*invstd.  sign_out (nullable): [rows][channels / 8] bytes,
- * bit j of byte (row, c / 8) = (y[row][c] > 0): the backward's ReLU mask at 1/16 of y's bytes. */
+ * bit j of byte (row, c / 8) = (y[row][c] > 0): the backward's ReLU mask at 1/16 of y's bytes.  stats_partial (nullable):
+ * [stats_chunks][2][channels] fp32 column sums / sums of squares of z from the producing convolution (rart_conv_desc.bn_stats_out)
+ * -- then no statistics pass reads z. */
 int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, void* sign_out, size_t rows, int channels, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, double momentum, double eps,
-                               int relu, float* mean_out, float* invstd_out, float* scale_shift, void* workspace,
-                               size_t workspace_bytes, rart_stream_t stream);
+                               int relu, float* mean_out, float* invstd_out, float* scale_shift, const float* stats_partial,
+                               int stats_chunks, void* workspace, size_t workspace_bytes, rart_stream_t stream);
 /* g = dy * [ymask > 0] (ymask NULL: g = dy; ymask_is_bits: ymask is the forward's sign_out instead of the bf16 activation);
  * dgamma = sum g*xhat, dbeta = sum g (written, or added when accumulate != 0); dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));
  * g_out (nullable) receives g.  coef: [3][channels] fp32 scratch. */

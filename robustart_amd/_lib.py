@@ -171,7 +171,7 @@ SIGNATURES = {
                                          c_void_p]),
     'rart_bn_workspace_bytes': (c_size_t, [c_size_t, c_int]),
     'rart_bn_train_forward_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                            c_size_t, c_void_p]),
     'rart_bn_train_backward_bf16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
@@ -201,7 +201,7 @@ class ConvDesc(ctypes.Structure):
                 ('reserved_', ctypes.c_int32),
                 ('src_z_outer', ctypes.c_int64), ('src_z_inner', ctypes.c_int64), ('wgt_z_outer', ctypes.c_int64),
                 ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64),
-                ('sign_out', c_void_p), ('dst_pair_off', ctypes.c_int64), ('res_pair_off', ctypes.c_int64)]
+                ('sign_out', c_void_p), ('dst_pair_off', ctypes.c_int64), ('res_pair_off', ctypes.c_int64), ('bn_stats_out', c_void_p)]
 
 
 class PackJob(ctypes.Structure):

@@ -59,6 +59,9 @@ struct RartConvDescDev {
   // split-bf16 ("bf16x3") tensors: a value is the pair hi + lo of two bf16 planes; the lo plane of dst / res sits this many
   // ELEMENTS after the hi plane (PAIR kernel instances only; src planes are reached through tap_src_off)
   long long dst_pair_off, res_pair_off;
+  // train-mode forward: per row tile, the column sums and sums of squares of the bf16 OUTPUT ([m_tiles][2][n_cols] fp32): the batch
+  // statistics BatchNorm needs, taken from the accumulators instead of a pass over the stored tensor (plain bf16 conv only)
+  float* stats_out;
 };
 
 namespace {
@@ -388,6 +391,36 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 #undef RART_STORE_TILE
 #undef RART_COMPUTE
 
+  // ---- BatchNorm batch statistics of the tile (train-mode forward): sum and sum of squares of the values AS STORED (bf16, round to
+  //      nearest even) per column; rows past M hold exact zeros (no bias on this path).  lane = column of a 32 x 32 MFMA tile, the 16
+  //      registers x 2 passes are 32 of the wave's 64 rows, the other lane half holds the other 32: one shuffle; the two row waves of a
+  //      column meet in LDS after the epilogue (fixed order: deterministic).
+  constexpr int STAT_OFF = 4 * 32 * (BN / 2 + 4) * 4;
+  static_assert(STAT_OFF + 4 * BN * 4 <= kLdsBytes, "the statistics slots must fit behind the epilogue staging");
+  float* const sStat = reinterpret_cast<float*>(lds_raw + STAT_OFF);           // [wm][sum | sumsq][BN]
+  if (!PAIR && d.stats_out) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float cs = 0.f, cq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t pk = pack_bf16x2(acc[i][j][r], acc[i][j][r + 1]);
+          const float a = __uint_as_float(pk << 16), b = __uint_as_float(pk & 0xFFFF0000u);
+          cs += a + b;
+          cq = fmaf(a, a, cq);
+          cq = fmaf(b, b, cq);
+        }
+      cs += __shfl_xor(cs, 32, 64);
+      cq += __shfl_xor(cq, 32, 64);
+      if (lane < 32) {
+        sStat[(wm * 2 + 0) * BN + wn * WN + j * 32 + lane] = cs;
+        sStat[(wm * 2 + 1) * BN + wn * WN + j * 32 + lane] = cq;
+      }
+    }
+  }
+
   // ---- epilogue: each wave transposes its own 64 x WN sub-tile through a private LDS region, 32 rows at a
   //      time, so the four waves drain concurrently and no block barrier sits between MFMAs and stores (the K
   //      loop's last barrier already fenced the tile buffers).  fp32 staging -> bias / residual / ReLU mask /
@@ -535,6 +568,14 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+  if (!PAIR && d.stats_out) {          // block-uniform
+    __syncthreads();
+    if (tid < BN && n0 + tid < d.n_cols) {
+      float* o = d.stats_out + (size_t)m_tile * 2 * d.n_cols + n0 + tid;
+      o[0] = sStat[(0 * 2 + 0) * BN + tid] + sStat[(1 * 2 + 0) * BN + tid];
+      o[d.n_cols] = sStat[(0 * 2 + 1) * BN + tid] + sStat[(1 * 2 + 1) * BN + tid];
+    }
   }
 }
 
@@ -792,7 +833,10 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   d.src_zo = h->src_z_outer; d.src_zi = h->src_z_inner; d.wgt_zo = h->wgt_z_outer; d.wgt_zi = h->wgt_z_inner;
   d.dst_zo = h->dst_z_outer; d.dst_zi = h->dst_z_inner;
   d.sign_out = (uint8_t*)h->sign_out;
+  d.stats_out = h->bn_stats_out;
   const bool pair = (h->flags & F_PAIR) != 0;
+  RART_CHECK_ARG(!d.stats_out || (!pair && !d.bias && !d.res && !d.mask && !d.sign_out && h->n_batched <= 1 && d.flags == 0),
+                 "rart_conv_igemm_bf16: bn_stats_out serves a plain bf16 convolution (no bias / residual / mask / flags, unbatched)");
   d.dst_pair_off = h->dst_pair_off; d.res_pair_off = h->res_pair_off;
   RART_CHECK_ARG(!pair || (nz == 1 && !(d.flags & (F_GELU | F_GELU_BWD)) && (!d.mask || (d.flags & F_MASK_BITS)) &&
                            ((d.flags & F_OUT_F32) ? (!d.res && !d.mask) : (d.dst_pair_off > 0 && d.dst_pair_off % 8 == 0)) &&

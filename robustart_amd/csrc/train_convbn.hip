@@ -474,11 +474,26 @@ extern "C" size_t rart_bn_workspace_bytes(size_t rows, int channels) {
   return (size_t)chunks * 2 * channels * sizeof(float);
 }
 
+// [chunks][2][C] -> [ceil(chunks / 16)][2][C]: groups of 16 partial rows summed in fixed order (the convolution's per-tile statistics of a
+// large layer are thousands of rows; the finaliser walks at most 2 048)
+__global__ __launch_bounds__(kBlock) void k_stats_fold(const float* __restrict__ in, float* __restrict__ out, int chunks, int C2) {
+  const int groups = (chunks + 15) / 16;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)groups * C2; i += (size_t)gridDim.x * kBlock) {
+    const int gidx = (int)(i / C2);
+    const int e = (int)(i - (size_t)gidx * C2);
+    const int cnt = chunks - gidx * 16 < 16 ? chunks - gidx * 16 : 16;
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < cnt; ++k) s += in[((size_t)gidx * 16 + k) * C2 + e];
+    out[i] = s;
+  }
+}
+
 extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* y, void* sign_out, size_t rows, int channels,
                                           const float* gamma, const float* beta, float* running_mean, float* running_var,
                                           double momentum, double eps, int relu, float* mean_out, float* invstd_out,
-                                          float* scale_shift /* [2][channels] */, void* workspace, size_t workspace_bytes,
-                                          rart_stream_t stream) {
+                                          float* scale_shift /* [2][channels] */, const float* stats_partial, int stats_chunks,
+                                          void* workspace, size_t workspace_bytes, rart_stream_t stream) {
   RART_CHECK_ARG(z && y && gamma && beta && mean_out && invstd_out && scale_shift && rows > 1,
                  "rart_bn_train_forward_bf16: null pointer or fewer than 2 rows");
   RART_CHECK_ARG(channels >= 8 && channels % 8 == 0 && channels <= 2048 && 2048 % channels == 0,
@@ -491,9 +506,26 @@ extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* 
   size_t rpc;
   const int chunks = chunks_for(rows, channels, &rpc);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_colsum2<0>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     rows, channels, rpc, (float*)workspace);
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + 15) / 16), dim3(256), 0, st, (const float*)workspace, chunks,
+  const float* part = (const float*)workspace;
+  int n_part = chunks;
+  if (stats_partial) {        // the producing convolution's per-tile sums (rart_conv_desc.bn_stats_out): no pass over z
+    RART_CHECK_ARG(stats_chunks >= 1, "rart_bn_train_forward_bf16: stats_chunks must be >= 1");
+    part = stats_partial;
+    n_part = stats_chunks;
+    if (n_part > 2048) {
+      const int groups = (n_part + 15) / 16;
+      RART_CHECK_ARG((size_t)groups * 2 * channels * sizeof(float) <= workspace_bytes,
+                     "rart_bn_train_forward_bf16: workspace too small for the folded statistics");
+      hipLaunchKernelGGL(k_stats_fold, dim3(grid_for((size_t)groups * 2 * channels)), dim3(kBlock), 0, st, stats_partial,
+                         (float*)workspace, n_part, 2 * channels);
+      part = (const float*)workspace;
+      n_part = groups;
+    }
+  } else {
+    hipLaunchKernelGGL(k_colsum2<0>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       rows, channels, rpc, (float*)workspace);
+  }
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + 15) / 16), dim3(256), 0, st, part, n_part,
                      channels, 1.0 / (double)rows, (double)rows / (double)(rows - 1), gamma, beta, (float)eps,
                      (float)momentum, running_mean, running_var, mean_out, invstd_out, scale_shift,
                      scale_shift + channels);

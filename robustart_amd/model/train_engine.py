@@ -97,6 +97,7 @@ class ResNet50TrainEngine:
         # K splits of a weight-gradient launch: ~1 024 workgroups in all (measured at B = 256: 512 -> 58.1, 1 024 -> 55.1-55.8, 2 048 -> 56.3,
         # 4 096 -> 57.5 ms per adv_train step: more splits fill the CUs, every split writes and re-reads an fp32 copy of the weight tensor)
         self.wgrad_target_wgs, self.wgrad_min_chunk = 1024, 256
+        self.conv_bn_stats = True      # False: every BatchNorm takes its own statistics pass over the conv output (rounds 1-3; cross-check)
         self.bit_masks = True          # False: the BatchNorm backward reads the bf16 activation for its ReLU mask (rounds 1-3; cross-check)
         self._ysign = {}
         self.direct_wgrad = True       # False: transpose_gather (dz^T, im2col^T) + implicit GEMM on the copies (rounds 1-3; cross-check)
@@ -161,8 +162,9 @@ class ResNet50TrainEngine:
         return t
 
     def _gemm(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, res=None,
-              flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0), tap_src_off=None, bias=None, batched=None):
+              flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0), tap_src_off=None, bias=None, batched=None, stats_out=None):
         d = _lib.ConvDesc()
+        d.bn_stats_out = stats_out.data_ptr() if stats_out is not None else None
         d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
         d.bias = bias.data_ptr() if bias is not None else None
         d.res = res.data_ptr() if res is not None else None
@@ -188,11 +190,18 @@ class ResNet50TrainEngine:
             d.wgt_row_stride = batched['wgt_row_stride']
         _lib.check(self.lib.rart_conv_igemm_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
-    def _conv_fwd(self, c, x, xhw, out):
+    def _conv_fwd(self, c, x, xhw, out, stats_name='bn_stats'):
+        """-> (partial statistics buffer, row tiles) of the output for the BatchNorm that follows (the igemm's epilogue sums the
+        columns of its 128-row tiles), or None with `conv_bn_stats` off (the BatchNorm then takes its own pass over the output)."""
         B = x.shape[0]
         oh, ow = xhw[0] // c.stride, xhw[1] // c.stride
+        stats = None
+        if self.conv_bn_stats:
+            tiles = (B * oh * ow + 127) // 128
+            stats = (self._scratch(stats_name, tiles * 2 * c.cout * 4), tiles)
         self._gemm(x, c.w_fwd, out, B, (oh, ow), xhw, c.cin, c.cin, c.fwd_taps, c.cout, (oh, ow), c.cout,
-                   stride=(c.stride, c.stride))
+                   stride=(c.stride, c.stride), stats_out=stats[0] if stats else None)
+        return stats
 
     def _conv_dgrad(self, c, dz, dz_hw, dx, dx_hw, res=None):
         B = dz.shape[0]
@@ -206,7 +215,7 @@ class ResNet50TrainEngine:
                 self._gemm(dz, w, dx, B, (dx_hw[0] // 2, dx_hw[1] // 2), dz_hw, c.cout, c.cout, taps, c.cin, dx_hw,
                            c.cin, res=res, dst_stride=(2, 2), dst_off=(ph, pw))
 
-    def _bn_fwd(self, c, z, y, rows, relu, res=None):
+    def _bn_fwd(self, c, z, y, rows, relu, res=None, stats=None):
         lib, bn = self.lib, c.bn
         need = lib.rart_bn_workspace_bytes(rows, c.cout)
         ws = self._scratch('bn_ws', need)
@@ -219,7 +228,8 @@ class ResNet50TrainEngine:
             z.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(), _lib.ptr(sign), rows, c.cout, bn.weight.data_ptr(),
             bn.bias.data_ptr(), bn.running_mean.data_ptr() if bn.track_running_stats else None,
             bn.running_var.data_ptr() if bn.track_running_stats else None, mom, bn.eps, 1 if relu else 0,
-            c.mean.data_ptr(), c.invstd.data_ptr(), c.scale_shift.data_ptr(), ws.data_ptr(), need, _lib.stream_ptr()))
+            c.mean.data_ptr(), c.invstd.data_ptr(), c.scale_shift.data_ptr(), stats[0].data_ptr() if stats else None,
+            stats[1] if stats else 0, ws.data_ptr(), need, _lib.stream_ptr()))
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
 
@@ -306,9 +316,13 @@ class ResNet50TrainEngine:
         z1 = self._get('z1', (B, h1, w1, 64))
         y1 = self._get('y1', (B, h1, w1, 64))
         lo_off = (hi[1].data_ptr() - hi[0].data_ptr()) // 2
+        st = None
+        if self.conv_bn_stats:
+            tiles = (B * h1 * w1 + 127) // 128
+            st = (self._scratch('bn_stats', tiles * 2 * 64 * 4), tiles)
         self._gemm(hi[0], self.stem_w, z1, B, (h1, w1), (H + 8, W + 8), 4, 32, [(r, 0) for r in range(7)] * 2, 64, (h1, w1),
-                   64, stride=(2, 2), tap_src_off=[0] * 7 + [lo_off] * 7)
-        self._bn_fwd(self.stem, z1, y1, B * h1 * w1, True)
+                   64, stride=(2, 2), tap_src_off=[0] * 7 + [lo_off] * 7, stats_out=st[0] if st else None)
+        self._bn_fwd(self.stem, z1, y1, B * h1 * w1, True, stats=st)
         h2, w2 = h1 // 2, w1 // 2
         p1 = self._get('p1', (B, h2, w2, 64))
         parg = self._get('p1_argmax', (B, h2, w2, 64), torch.uint8)
@@ -323,21 +337,21 @@ class ResNet50TrainEngine:
             yb = self._get('b%d_yb' % bi, (B, ohw[0], ohw[1], cb.cout))
             zc = self._get('b%d_zc' % bi, (B, ohw[0], ohw[1], cc.cout))
             out = self._get('b%d_out' % bi, (B, ohw[0], ohw[1], cc.cout))
-            self._conv_fwd(ca, x, xhw, za)
-            self._bn_fwd(ca, za, ya, B * xhw[0] * xhw[1], True)
-            self._conv_fwd(cb, ya, xhw, zb)
+            st = self._conv_fwd(ca, x, xhw, za)
+            self._bn_fwd(ca, za, ya, B * xhw[0] * xhw[1], True, stats=st)
+            st = self._conv_fwd(cb, ya, xhw, zb)
             rows_o = B * ohw[0] * ohw[1]
-            self._bn_fwd(cb, zb, yb, rows_o, True)
-            self._conv_fwd(cc, yb, ohw, zc)
+            self._bn_fwd(cb, zb, yb, rows_o, True, stats=st)
+            st_c = self._conv_fwd(cc, yb, ohw, zc)
             zd = None
             if ds is not None:
                 zd = self._get('b%d_zd' % bi, (B, ohw[0], ohw[1], cc.cout))
                 sk = self._get('b%d_sk' % bi, (B, ohw[0], ohw[1], cc.cout))
-                self._conv_fwd(ds, x, xhw, zd)
-                self._bn_fwd(ds, zd, sk, rows_o, False)
+                st = self._conv_fwd(ds, x, xhw, zd, stats_name='bn_stats_ds')
+                self._bn_fwd(ds, zd, sk, rows_o, False, stats=st)
             else:
                 sk = x
-            self._bn_fwd(cc, zc, out, rows_o, True, res=sk)
+            self._bn_fwd(cc, zc, out, rows_o, True, res=sk, stats=st_c)
             acts['b%d' % bi] = (x, xhw, za, ya, zb, yb, zc, zd, out, ohw)
             x, xhw = out, ohw
         pooled = self._get('pooled', (B, self.fc_in))

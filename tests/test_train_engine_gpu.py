@@ -42,7 +42,7 @@ def test_bn_train_forward_and_backward_kernels(rows, C, relu, with_res):
     sign = torch.full((rows, C // 8), 0xAA, dtype=torch.uint8, device='cuda')
     L.check(lib.rart_bn_train_forward_bf16(z.data_ptr(), res.data_ptr() if with_res else None, y.data_ptr(), sign.data_ptr(), rows, C,
                                            gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, relu,
-                                           mean.data_ptr(), invstd.data_ptr(), ss.data_ptr(), ws.data_ptr(), need,
+                                           mean.data_ptr(), invstd.data_ptr(), ss.data_ptr(), None, 0, ws.data_ptr(), need,
                                            L.stream_ptr()))
     # torch reference on the same bf16-rounded z
     zt = z.float().requires_grad_(True)
@@ -83,6 +83,44 @@ def test_bn_train_forward_and_backward_kernels(rows, C, relu, with_res):
     torch.testing.assert_close(dgam, gt.grad, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(dbet, bt.grad, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(dz.float(), zt.grad, rtol=2e-2, atol=2e-2 * float(zt.grad.abs().max()))
+
+
+@pytest.mark.parametrize('cin,cout,r,stride,H,B', [(64, 64, 3, 1, 16, 4), (64, 256, 1, 1, 10, 3), (256, 128, 1, 1, 28, 9), (128, 128, 3, 2, 16, 4),
+                                                   (1024, 2048, 1, 2, 4, 16)])
+def test_conv_epilogue_batchnorm_statistics(cin, cout, r, stride, H, B):
+    """rart_conv_desc.bn_stats_out: the igemm's per-tile column sums / sums of squares of the bf16 output equal the sums of the stored
+    tensor (fp32 order noise), for 64- and 128-column tiles, shallow and deep K pipelines and a ragged last row tile; fed to
+    rart_bn_train_forward_bf16 as stats_partial they give the statistics of its own pass over z."""
+    from robustart_amd.model.train_engine import ResNet50TrainEngine, _TConv
+    L, lib = _L()
+    model, _, _ = _tiny_resnet_inputs(2, 32)
+    eng = ResNet50TrainEngine(model)
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, r, stride=stride, padding=r // 2, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(cout).cuda()
+    tc = _TConv(conv, bn, torch.device('cuda'), torch)
+    tc.repack(lib, L.stream_ptr())
+    x = torch.randn(B, H, H, cin, device='cuda').to(torch.bfloat16)
+    oh = H // stride
+    z = torch.empty(B, oh, oh, cout, dtype=torch.bfloat16, device='cuda')
+    assert eng.conv_bn_stats
+    st = eng._conv_fwd(tc, x, (H, H), z)
+    rows = B * oh * oh
+    part = st[0][:st[1] * 2 * cout * 4].view(torch.float32).view(st[1], 2, cout)
+    zf = z.float().view(rows, cout)
+    s_ref, q_ref = zf.double().sum(0), (zf.double() ** 2).sum(0)
+    assert (part[:, 0].double().sum(0) - s_ref).abs().max().item() <= 1e-4 * (zf.abs().double().sum(0).max().item() + 1)
+    assert (part[:, 1].double().sum(0) - q_ref).abs().max().item() <= 1e-5 * q_ref.max().item()
+    outs = []
+    for use in (st, None):
+        y = torch.empty_like(z)
+        tc.bn.running_mean.zero_(); tc.bn.running_var.fill_(1)
+        eng._bn_fwd(tc, z, y, rows, True, stats=use)
+        outs.append((y.clone(), tc.mean.clone(), tc.invstd.clone(), tc.bn.running_var.clone()))
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-6)
+    assert (outs[0][0].float() - outs[1][0].float()).abs().max().item() <= 2e-2
 
 
 @pytest.mark.parametrize('B,H,C,r,stride', [(3, 8, 64, 3, 1), (2, 12, 128, 3, 2), (5, 7, 256, 1, 1), (2, 8, 512, 1, 2)])
