@@ -306,24 +306,38 @@ class ResNet50Engine:
                 pack(ds.w_fwd, ds.w_fwd_frag, ds.cout, ds.cin)
                 bias_sum(cc.bias, ds.bias, ds.bias_sum)
 
+    _stem_bwd_index = {}
+
     @staticmethod
     def _stem_bwd_table(wb, dtype=None):
         """bf16 (or `dtype`) [16][1024] table of rart_engine_stem_bwd_fused from the folded stem weights wb [64][3][7][7]:
-        row (py*2+px)*3+c, column ((dp+1)*4+(dq+1))*64+k = W[k][c][py+3-2dp][px+3-2dq] (0 outside 0..6)."""
+        row (py*2+px)*3+c, column ((dp+1)*4+(dq+1))*64+k = W[k][c][py+3-2dp][px+3-2dq] (0 outside 0..6).  One gather + one scatter
+        through index tensors built once per device (the adversarial-training loop calls this every step: 147 slice assignments
+        were 147 tiny launches)."""
         import torch
-        t = torch.zeros(16, 16, 64, dtype=wb.dtype, device=wb.device)
-        for py in range(2):
-            for px in range(2):
-                for dp in range(-1, 3):
-                    r = py + 3 - 2 * dp
-                    if not 0 <= r <= 6:
-                        continue
-                    for dq in range(-1, 3):
-                        s_ = px + 3 - 2 * dq
-                        if not 0 <= s_ <= 6:
+        key = str(wb.device)
+        idx = ResNet50Engine._stem_bwd_index.get(key)
+        if idx is None:
+            src, dst = [], []
+            for py in range(2):
+                for px in range(2):
+                    for dp in range(-1, 3):
+                        r = py + 3 - 2 * dp
+                        if not 0 <= r <= 6:
                             continue
-                        for c in range(3):
-                            t[(py * 2 + px) * 3 + c, (dp + 1) * 4 + (dq + 1)] = wb[:, c, r, s_]
+                        for dq in range(-1, 3):
+                            s_ = px + 3 - 2 * dq
+                            if not 0 <= s_ <= 6:
+                                continue
+                            for c in range(3):
+                                row, blk = (py * 2 + px) * 3 + c, (dp + 1) * 4 + (dq + 1)
+                                for k in range(64):
+                                    dst.append(row * 1024 + blk * 64 + k)
+                                    src.append(((k * 3 + c) * 7 + r) * 7 + s_)
+            idx = (torch.tensor(src, dtype=torch.long, device=wb.device), torch.tensor(dst, dtype=torch.long, device=wb.device))
+            ResNet50Engine._stem_bwd_index[key] = idx
+        t = torch.zeros(16 * 1024, dtype=wb.dtype, device=wb.device)
+        t[idx[1]] = wb.reshape(-1)[idx[0]]
         return t.reshape(16, 1024).to(dtype or torch.bfloat16).contiguous()
 
     # ------------------------------------------------------------------ re-fold from the live parameters

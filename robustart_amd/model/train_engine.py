@@ -17,6 +17,7 @@ train/arena.py); `on_grad_ready(param)` lets the arena launch a bucket's all-red
 exists, so the exchange overlaps the rest of the backward pass.
 """
 import ctypes
+import os as _os
 
 from .. import _lib
 from .engine import F_OUT_F32, _rows_mult
@@ -94,13 +95,16 @@ class ResNet50TrainEngine:
         self.fc_w = torch.zeros(self.fc_kpad, self.fc_in, dtype=torch.bfloat16, device=dev)      # [1024][2048]
         self.fc_wd = torch.zeros(self.fc_in, self.fc_kpad, dtype=torch.bfloat16, device=dev)     # [2048][1024]
         self._buf = {}
+        _fl = dict(kv.split('=') for kv in _os.environ.get('RART_TRAIN_FLAGS', '').split(',') if '=' in kv)   # A/B switches for profiling
         # K splits of a weight-gradient launch: ~1 024 workgroups in all (measured at B = 256: 512 -> 58.1, 1 024 -> 55.1-55.8, 2 048 -> 56.3,
-        # 4 096 -> 57.5 ms per adv_train step: more splits fill the CUs, every split writes and re-reads an fp32 copy of the weight tensor)
+        # 4 096 -> 57.5 ms per adv_train step: more splits fill the CUs, every split writes and re-reads an fp32 copy of the weight tensor);
+        # up to 1 024 splits of >= 256 positions each (a cap of 256 left layer1's one- and two-tile 1x1 layers at 256-512 workgroups: +0.6 ms)
         self.wgrad_target_wgs, self.wgrad_min_chunk = 1024, 256
-        self.conv_bn_stats = True      # False: every BatchNorm takes its own statistics pass over the conv output (rounds 1-3; cross-check)
-        self.bit_masks = True          # False: the BatchNorm backward reads the bf16 activation for its ReLU mask (rounds 1-3; cross-check)
+        self._nbt_pending = None
+        self.conv_bn_stats = _fl.get('stats', '1') == '1'      # False: every BatchNorm takes its own statistics pass over the conv output (rounds 1-3; cross-check)
+        self.bit_masks = _fl.get('bits', '1') == '1'          # False: the BatchNorm backward reads the bf16 activation for its ReLU mask (rounds 1-3; cross-check)
         self._ysign = {}
-        self.direct_wgrad = True       # False: transpose_gather (dz^T, im2col^T) + implicit GEMM on the copies (rounds 1-3; cross-check)
+        self.direct_wgrad = _fl.get('direct', '1') == '1'       # False: transpose_gather (dz^T, im2col^T) + implicit GEMM on the copies (rounds 1-3; cross-check)
         self.repack()
 
     # ------------------------------------------------------------------ tables
@@ -231,7 +235,10 @@ class ResNet50TrainEngine:
             c.mean.data_ptr(), c.invstd.data_ptr(), c.scale_shift.data_ptr(), stats[0].data_ptr() if stats else None,
             stats[1] if stats else 0, ws.data_ptr(), need, _lib.stream_ptr()))
         if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            if self._nbt_pending is not None:
+                self._nbt_pending.append(bn.num_batches_tracked)      # one multi-tensor add at the end of forward() instead of 53 launches
+            else:
+                bn.num_batches_tracked += 1
 
     def _bn_bwd(self, c, dy, ymask, z, dz, rows, g_out=None):
         lib, bn = self.lib, c.bn
@@ -261,7 +268,8 @@ class ResNet50TrainEngine:
             # straight from the NHWC activations (csrc/wgrad_direct.hip): no transposed copies, no materialised im2col
             row_tiles = len(taps) * (x_c // 128) if x_c >= 128 else (len(taps) + 1) // 2
             tiles = row_tiles * (n_pad_cols // (128 if n_pad_cols % 128 == 0 else 64))
-            splits = max(1, min(self.wgrad_target_wgs // max(tiles, 1), M // self.wgrad_min_chunk if M >= 2 * self.wgrad_min_chunk else 1, 256))
+            splits = max(1, min(self.wgrad_target_wgs // max(tiles, 1), M // self.wgrad_min_chunk if M >= 2 * self.wgrad_min_chunk else 1,
+                                1024))
             chunk = ((M + splits - 1) // splits + 31) // 32 * 32
             splits = (M + chunk - 1) // chunk
             part = self._scratch('wg_part', splits * kp * n_pad_cols * 4)
@@ -309,6 +317,7 @@ class ResNet50TrainEngine:
             src = src.detach().float().contiguous()
             B, H, W = src.shape[0], src.shape[2], src.shape[3]
         assert H % 32 == 0 and W % 32 == 0
+        self._nbt_pending = []
         hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
         _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]), B, H, W,
                                               (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), sp))
@@ -361,6 +370,9 @@ class ResNet50TrainEngine:
                    self.n_classes, bias=self.model.fc.bias.detach(), flags=F_OUT_F32)
         acts['last'], acts['pooled'] = (x, xhw), pooled
         self.acts = acts
+        pending, self._nbt_pending = self._nbt_pending, None
+        if pending:
+            torch._foreach_add_(pending, 1)
         return logits
 
     # ------------------------------------------------------------------ backward to every parameter
