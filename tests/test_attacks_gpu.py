@@ -105,6 +105,31 @@ def test_select_rows_and_logit_losses():
             assert torch.equal(pred.cpu().long(), z.argmax(1))
 
 
+def test_ce_gradient_of_saturated_rows_sums_to_zero():
+    """Rows whose softmax is saturated (1 - p_y between 1e-9 and 1e-5, logits around 20-30): d(CE)/dz must keep dl_y = -(sum of the
+    others) -- lse = log(s) + max formed first loses log(s) below the ulp of the maximum and the input gradient of a network with a
+    common-mode logit Jacobian flips its sign (found on the fitted ResNet-50 of test_outcome_gpu.py).  Against fp64."""
+    from robustart_amd.noise import adv
+    g = torch.Generator().manual_seed(9)
+    C, B = 1000, 64
+    z = torch.randn(B, C, generator=g) * 2.0
+    y = torch.randint(0, C, (B,), generator=g)
+    margin = torch.linspace(12.0, 24.0, B)                # 1 - p_y from ~1e-3 down to ~1e-9 (1 000 classes)
+    z[torch.arange(B), y] = z.max(1)[0] + margin
+    z = z + 20.0                                          # logits at the scale where an fp32 ulp is 2e-6
+    loss, dl, pred = adv.logit_loss(z.cuda(), y.cuda(), 0, None, 1.0)
+    z64 = z.double().requires_grad_(True)
+    l64 = torch.nn.functional.cross_entropy(z64, y, reduction='none')
+    g64, = torch.autograd.grad(l64.sum(), z64)
+    dl = dl.cpu().double()
+    assert (dl.sum(1).abs() <= 1e-6 * dl.abs().sum(1)).all()                     # the gradient has no common-mode component
+    rel = (dl - g64).abs().max(1)[0] / g64.abs().max(1)[0]
+    print('CE gradient of saturated rows vs fp64: max relative error %.2e; loss %.2e' % (rel.max().item(), ((loss.cpu().double() - l64.detach()).abs() / l64.detach()).max().item()))
+    assert rel.max().item() <= 1e-5
+    assert ((loss.cpu().double() - l64.detach()).abs() <= 1e-5 * l64.detach()).all()
+    assert torch.equal(pred.cpu().long(), y)
+
+
 def _gold_model():
     g = np.load(os.path.join(GOLD, 'attacks_ref.npz'))
     net = make_tinynet({k[4:]: g[k] for k in g.files if k.startswith('net/')})
