@@ -508,14 +508,14 @@ extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* 
   hipStream_t st = (hipStream_t)stream;
   const float* part = (const float*)workspace;
   int n_part = chunks;
-  if (stats_partial) {        // the producing convolution's per-tile sums (rart_conv_desc.bn_stats_out): no pass over z
-    RART_CHECK_ARG(stats_chunks >= 1, "rart_bn_train_forward_bf16: stats_chunks must be >= 1");
+  RART_CHECK_ARG(!stats_partial || stats_chunks >= 1, "rart_bn_train_forward_bf16: stats_chunks must be >= 1");
+  // more than 2 048 x 16 tiles (batch > ~330 at the stem's 112 x 112 grid): the folded sums would not fit the workspace -- own pass instead
+  const bool use_partial = stats_partial && (stats_chunks <= 2048 || (size_t)((stats_chunks + 15) / 16) * 2 * channels * sizeof(float) <= workspace_bytes);
+  if (use_partial) {          // the producing convolution's per-tile sums (rart_conv_desc.bn_stats_out): no pass over z
     part = stats_partial;
     n_part = stats_chunks;
     if (n_part > 2048) {
       const int groups = (n_part + 15) / 16;
-      RART_CHECK_ARG((size_t)groups * 2 * channels * sizeof(float) <= workspace_bytes,
-                     "rart_bn_train_forward_bf16: workspace too small for the folded statistics");
       hipLaunchKernelGGL(k_stats_fold, dim3(grid_for((size_t)groups * 2 * channels)), dim3(kBlock), 0, st, stats_partial,
                          (float*)workspace, n_part, 2 * channels);
       part = (const float*)workspace;
