@@ -42,8 +42,8 @@ __device__ __attribute__((aligned(16))) const uint32_t g_wg_zero16[4] = {0u, 0u,
 // transposed fragment: 8 consecutive K (positions k0 .. k0 + 7) of column `col0 + (lane & 15)` of a [32][ROWB bytes] tile
 template <int ROWB>
 __device__ __forceinline__ bf16x8 wg_frag(const uint8_t* tile, int k0, int col0, int a) {
-  constexpr int XS = ROWB == 256 ? 0 : 1;          // swizzle key: (row >> XS) & (ROWB == 256 ? 3 : 1)
-  constexpr int XM = ROWB == 256 ? 3 : 1;
+  constexpr int XS = ROWB >= 256 ? 0 : 1;          // swizzle key: (row >> XS) & (ROWB >= 256 ? 3 : 1)
+  constexpr int XM = ROWB >= 256 ? 3 : 1;
   s16x4 v[2];
 #pragma unroll
   for (int rd = 0; rd < 2; ++rd) {
@@ -57,44 +57,45 @@ __device__ __forceinline__ bf16x8 wg_frag(const uint8_t* tile, int k0, int col0,
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int TN>
-__global__ __launch_bounds__(256, 2) void k_wgrad_direct(const WgradDev d) {
-  constexpr int WN = TN / 64, WM = 4 / WN, RW = 128 / WM, MI = RW / 32;
-  constexpr int ROWA = 256, ROWB = TN * 2;
+template <int TN, int TMR>
+__global__ __launch_bounds__(TMR * 2, 2) void k_wgrad_direct(const WgradDev d) {
+  constexpr int NW = TMR / 32;                      // waves: 4 (128 rows) / 8 (256 rows)
+  constexpr int WN = TN / 64, WM = NW / WN, RW = TMR / WM, MI = RW / 32;
+  constexpr int ROWA = TMR * 2, ROWB = TN * 2;      // bytes of a position's row in the x / dz tile
   constexpr int A_BYTES = 32 * ROWA, B_BYTES = 32 * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int BI = B_BYTES / 1024 / 4;            // 1 KiB wave-loads of the dz tile per wave (2 / 1)
+  constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;     // 1 KiB wave-loads per tile
+  constexpr int AI = A_PIECES / NW, BI = (B_PIECES + NW - 1) / NW;       // ... per wave (2; 2 / 1)
+  constexpr int CPRA = ROWA / 16, RPLA = 64 / CPRA;                       // 16-byte chunks per x row; rows per wave-load
+  constexpr int CPRB = ROWB / 16, RPLB = 64 / CPRB;
+  static_assert(AI == 2, "two x pieces per wave");
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
   const int rt = blockIdx.x, n0 = blockIdx.y * TN, z = blockIdx.z;
-  // the 128 rows of this tile: one tap x 128 channels, or (C == 64) two taps x 64 channels
-  const int per_tap = d.C >= 128 ? d.C / 128 : 1;
-  const int t0 = d.C >= 128 ? rt / per_tap : 2 * rt;
-  const int c0 = d.C >= 128 ? (rt - t0 * per_tap) * 128 : 0;
+  // the TMR rows of this tile: one tap x TMR channels, or (C < TMR) TMR / C taps x C channels
+  const int per_tap = d.C >= TMR ? d.C / TMR : 1;
+  const int tpt = d.C >= TMR ? 1 : TMR / d.C;       // taps per tile
+  const int t0 = d.C >= TMR ? rt / per_tap : rt * tpt;
+  const int c0 = d.C >= TMR ? (rt - t0 * per_tap) * TMR : 0;
+  const int cpt = (d.C >= TMR ? TMR : d.C) / 8;     // 16-byte chunks of one tap inside a tile row
   const int m_begin = z * d.chunk, m_end = min(m_begin + d.chunk, d.M);
   const int steps = (m_end - m_begin + 31) / 32;
 
-  // ---- loader: wave w brings 1 KiB pieces 2w, 2w + 1 of the x tile (4 rows of 256 B each) and BI pieces of the dz tile
-  const int a_chunk = lane & 15, a_rl = lane >> 4;
-  int a_tap[2], a_coff[2];                          // per piece: the lane's tap (C == 64: by chunk half) and channel offset of its LOGICAL chunk
-  int a_row[2];
+  // ---- loader: wave w brings 1 KiB pieces AI*w .. of the x tile (RPLA rows each) and BI pieces of the dz tile; the lane's LDS slot holds
+  //      the row's chunk (slot ^ 4 (row & 3))
+  int a_tap[AI], a_coff[AI], a_row[AI];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    a_row[q] = 4 * (2 * wave + q) + a_rl;
-    const int logical = a_chunk ^ (4 * (a_row[q] & 3));
-    if (d.C >= 128) { a_tap[q] = t0; a_coff[q] = c0 + logical * 8; }
-    else { a_tap[q] = t0 + (logical >> 3); a_coff[q] = (logical & 7) * 8; }
+  for (int q = 0; q < AI; ++q) {
+    a_row[q] = RPLA * (AI * wave + q) + lane / CPRA;
+    const int logical = (lane % CPRA) ^ (4 * (a_row[q] & 3));
+    a_tap[q] = t0 + logical / cpt;
+    a_coff[q] = c0 + (logical % cpt) * 8;
   }
   int b_row[BI], b_coff[BI];
 #pragma unroll
   for (int q = 0; q < BI; ++q) {
-    if (TN == 128) {
-      b_row[q] = 4 * (BI * wave + q) + (lane >> 4);
-      b_coff[q] = ((lane & 15) ^ (4 * (b_row[q] & 3))) * 8;
-    } else {
-      b_row[q] = 8 * (BI * wave + q) + (lane >> 3);
-      b_coff[q] = ((lane & 7) ^ (4 * ((b_row[q] >> 1) & 1))) * 8;
-    }
+    b_row[q] = RPLB * (BI * wave + q) + lane / CPRB;
+    b_coff[q] = ((lane % CPRB) ^ (4 * (ROWB >= 256 ? (b_row[q] & 3) : ((b_row[q] >> 1) & 1)))) * 8;
   }
   const char* const zsrc = reinterpret_cast<const char*>(g_wg_zero16);
 #define RART_WG_DL(SRC, DST)                                                                                    \
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_direct(const WgradDev d) {
   {                                                                                                             \
     uint8_t* const st_ = lds + (BUF)*STAGE;                                                                     \
     const int mb_ = m_begin + (STEP)*32;                                                                        \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
+    _Pragma("unroll") for (int q = 0; q < AI; ++q) {                                                            \
       const int m_ = mb_ + a_row[q];                                                                            \
       const char* src_ = zsrc;                                                                                  \
       if (m_ < m_end && a_tap[q] < d.n_taps) {                                                                  \
@@ -116,13 +117,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_direct(const WgradDev d) {
         if ((unsigned)iy_ < (unsigned)d.ih && (unsigned)ix_ < (unsigned)d.iw)                                   \
           src_ = reinterpret_cast<const char*>(d.x + ((size_t)(im_ * d.ih + iy_) * d.iw + ix_) * d.C + a_coff[q]); \
       }                                                                                                         \
-      RART_WG_DL(src_, st_ + (2 * wave + q) * 1024)                                                              \
+      RART_WG_DL(src_, st_ + (AI * wave + q) * 1024)                                                             \
     }                                                                                                           \
     _Pragma("unroll") for (int q = 0; q < BI; ++q) {                                                            \
-      const int m_ = mb_ + b_row[q];                                                                            \
-      const char* src_ = zsrc;                                                                                  \
-      if (m_ < m_end && n0 + b_coff[q] < d.ldz) src_ = reinterpret_cast<const char*>(d.dz + (size_t)m_ * d.ldz + n0 + b_coff[q]); \
-      RART_WG_DL(src_, st_ + A_BYTES + (BI * wave + q) * 1024)                                                   \
+      if (BI * wave + q < B_PIECES) {                                                                           \
+        const int m_ = mb_ + b_row[q];                                                                          \
+        const char* src_ = zsrc;                                                                                \
+        if (m_ < m_end && n0 + b_coff[q] < d.ldz) src_ = reinterpret_cast<const char*>(d.dz + (size_t)m_ * d.ldz + n0 + b_coff[q]); \
+        RART_WG_DL(src_, st_ + A_BYTES + (BI * wave + q) * 1024)                                                 \
+      }                                                                                                         \
     }                                                                                                           \
   }
   f32x16 acc[MI][2];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_direct(const WgradDev d) {
 #undef RART_WG_DL
   // ---- fp32 partial sums: acc[i][j][r] = row wm*RW + i*32 + (r&3) + 8*(r>>2) + 4h, column wn*64 + j*32 + (lane & 31)
   const int fr = lane & 31, h = lane >> 5;
-  const int row_base = (d.C >= 128 ? t0 * d.C + c0 : t0 * 64);
+  const int row_base = t0 * d.C + c0;
   float* const pz = d.part + (size_t)z * d.kp * d.ld_n;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -212,13 +215,15 @@ extern "C" int rart_wgrad_direct_bf16(const void* x, const void* dz, float* part
   d.M = (int)M; d.chunk = chunk;
   wg_magic((uint32_t)grid_w, d.gw_magic, d.gw_shift);
   wg_magic((uint32_t)grid_h, d.gh_magic, d.gh_shift);
-  const int row_tiles = channels >= 128 ? n_taps * (channels / 128) : (n_taps + 1) / 2;
+  // Tile height: the kernel is written for TMR = 128 or 256 rows.  256-row tiles (8 waves, 0.375 KB of LDS traffic per MFMA instead of 0.5,
+  // half the split-K partials at equal workgroup count) were measured on every conv shape of ResNet-50 at B = 256 and LOSE: 7.04 vs 6.14 ms of
+  // weight gradients per step (adv_train 4.82 vs 4.90 k images/s): three 8-wave workgroups per CU hide the K step's load latency worse than
+  // five 4-wave ones.  128 rows it is.
+  constexpr int tmr = 128;
+  const int row_tiles = channels >= tmr ? n_taps * (channels / tmr) : (n_taps + tmr / channels - 1) / (tmr / channels);
   hipStream_t st = (hipStream_t)stream;
-  if (dz_cols % 128 == 0) {
-    hipLaunchKernelGGL(k_wgrad_direct<128>, dim3(row_tiles, dz_cols / 128, splits), dim3(256), 0, st, d);
-  } else {
-    hipLaunchKernelGGL(k_wgrad_direct<64>, dim3(row_tiles, dz_cols / 64, splits), dim3(256), 0, st, d);
-  }
+  if (dz_cols % 128 == 0) hipLaunchKernelGGL((k_wgrad_direct<128, 128>), dim3(row_tiles, dz_cols / 128, splits), dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((k_wgrad_direct<64, 128>), dim3(row_tiles, dz_cols / 64, splits), dim3(256), 0, st, d);
   RART_CHECK_LAUNCH("rart_wgrad_direct_bf16");
   return RART_OK;
 }

@@ -266,7 +266,8 @@ class ResNet50TrainEngine:
         kp = len(taps) * x_c                                   # rows of the transposed im2col matrix
         if self.direct_wgrad and c_valid is None and lib.rart_wgrad_direct_supported(x_c, n_pad_cols, len(taps)):
             # straight from the NHWC activations (csrc/wgrad_direct.hip): no transposed copies, no materialised im2col
-            row_tiles = len(taps) * (x_c // 128) if x_c >= 128 else (len(taps) + 1) // 2
+            tmr = 128                # the library's tile height (csrc/wgrad_direct.hip: 256-row tiles measured slower)
+            row_tiles = len(taps) * (x_c // tmr) if x_c >= tmr else (len(taps) + tmr // x_c - 1) // (tmr // x_c)
             tiles = row_tiles * (n_pad_cols // (128 if n_pad_cols % 128 == 0 else 64))
             splits = max(1, min(self.wgrad_target_wgs // max(tiles, 1), M // self.wgrad_min_chunk if M >= 2 * self.wgrad_min_chunk else 1,
                                 1024))
