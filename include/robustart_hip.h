@@ -332,7 +332,9 @@ typedef struct rart_conv_desc {
   int32_t n_cols;
   int32_t dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox, dst_pix_stride;
   int32_t flags;          /* 1 = ReLU, 2 = fp32 output, 4 = exact GELU, 8 = GELU' of `mask`, 16 = `mask` is a 1-bit tensor,
-                           * 32 = split-bf16 tensors (dst_pair_off / res_pair_off below) */
+                           * 32 = split-bf16 tensors (dst_pair_off / res_pair_off below), 64 = GELU with the pre-activation kept,
+                           * 128 = the 1-bit `mask` (with 16) applies to the RESIDUAL instead of the result: dst = acc + res . [mask]
+                           * (train engine: the skip gradient d_out . [out > 0] without materialising it) */
   /* batched problems (attention: one GEMM per (image, head)): problem z in [0, n_batched) splits into
    * zo = z / z_inner, zi = z % z_inner; zo*_z_outer + zi*_z_inner elements are added to src / wgt / dst (res and
    * mask follow dst).  n_batched <= 1 = a single problem.  wgt_row_stride: elements between consecutive weight

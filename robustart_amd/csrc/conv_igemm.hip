@@ -67,7 +67,7 @@ struct RartConvDescDev {
 namespace {
 constexpr int BM = 128;
 constexpr int kThreads = 256;
-enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8, F_MASK_BITS = 16, F_PAIR = 32, F_GELU_KEEP = 64 };
+enum { F_RELU = 1, F_OUT_F32 = 2, F_GELU = 4, F_GELU_BWD = 8, F_MASK_BITS = 16, F_PAIR = 32, F_GELU_KEEP = 64, F_MASK_RES = 128 };
 
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
@@ -489,10 +489,12 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
               v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u) + __uint_as_float(rlw[j] & 0xFFFF0000u);
             }
           } else {
+            const bool mres = d.flags & F_MASK_RES;     // the 1-bit mask applies to the RESIDUAL (train engine: the skip gradient g = d_out . [out > 0])
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              v[2 * j] += __uint_as_float(rw[j] << 16);
-              v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
+              const uint32_t rj = mres ? (rw[j] & halves_from_bits(mw[0], j)) : rw[j];
+              v[2 * j] += __uint_as_float(rj << 16);
+              v[2 * j + 1] += __uint_as_float(rj & 0xFFFF0000u);
             }
           }
         }
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-            if (p_mask && !(d.flags & F_GELU_BWD)) o[j] &= mask_bits ? halves_from_bits(mw[0], j) : positive_lanes_i16(mw[j]);
+            if (p_mask && !(d.flags & (F_GELU_BWD | F_MASK_RES))) o[j] &= mask_bits ? halves_from_bits(mw[0], j) : positive_lanes_i16(mw[j]);
             if (relu) o[j] = relu_bf16x2(o[j]);
           }
           if (p_sign) {
@@ -842,6 +844,8 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
                            ((d.flags & F_OUT_F32) ? (!d.res && !d.mask) : (d.dst_pair_off > 0 && d.dst_pair_off % 8 == 0)) &&
                            (!d.res || (d.res_pair_off > 0 && d.res_pair_off % 8 == 0))),
                  "rart_conv_igemm_bf16: split-bf16 (flag 32) needs an unbatched problem, 1-bit masks and 16-byte aligned lo planes");
+  RART_CHECK_ARG(!(d.flags & F_MASK_RES) || (!pair && d.res && d.mask && (d.flags & F_MASK_BITS) && !(d.flags & F_OUT_F32)),
+                 "rart_conv_igemm_bf16: flag 128 (mask on the residual) needs a residual, a 1-bit mask (flag 16) and bf16 output");
   RART_CHECK_ARG(!(d.sign_out || (d.flags & F_MASK_BITS)) || (nz == 1 && !(d.flags & (F_OUT_F32 | F_GELU_BWD))),
                  "rart_conv_igemm_bf16: sign_out / bit masks need a single bf16-output problem");
   {

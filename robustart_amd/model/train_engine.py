@@ -101,6 +101,7 @@ class ResNet50TrainEngine:
         # up to 1 024 splits of >= 256 positions each (a cap of 256 left layer1's one- and two-tile 1x1 layers at 256-512 workgroups: +0.6 ms)
         self.wgrad_target_wgs, self.wgrad_min_chunk = 1024, 256
         self._nbt_pending = None
+        self.masked_skip = _fl.get('skip', '1') == '1'        # False: the BatchNorm backward writes the masked skip gradient as a tensor (cross-check)
         self.conv_bn_stats = _fl.get('stats', '1') == '1'      # False: every BatchNorm takes its own statistics pass over the conv output (rounds 1-3; cross-check)
         self.bit_masks = _fl.get('bits', '1') == '1'          # False: the BatchNorm backward reads the bf16 activation for its ReLU mask (rounds 1-3; cross-check)
         self._ysign = {}
@@ -166,13 +167,14 @@ class ResNet50TrainEngine:
         return t
 
     def _gemm(self, src, wgt, dst, batch, grid, src_hw, src_pix, k_per_tap, taps, n_cols, dst_hw, dst_pix, res=None,
-              flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0), tap_src_off=None, bias=None, batched=None, stats_out=None):
+              flags=0, stride=(1, 1), dst_stride=(1, 1), dst_off=(0, 0), tap_src_off=None, bias=None, batched=None, stats_out=None,
+              mask_bits=None):
         d = _lib.ConvDesc()
         d.bn_stats_out = stats_out.data_ptr() if stats_out is not None else None
         d.src, d.wgt, d.dst = src.data_ptr(), wgt.data_ptr(), dst.data_ptr()
         d.bias = bias.data_ptr() if bias is not None else None
         d.res = res.data_ptr() if res is not None else None
-        d.mask = None
+        d.mask = mask_bits.data_ptr() if mask_bits is not None else None
         d.batch, d.grid_h, d.grid_w = batch, grid[0], grid[1]
         d.src_h, d.src_w, d.src_pix_stride = src_hw[0], src_hw[1], src_pix
         d.k_per_tap, d.n_taps = k_per_tap, len(taps)
@@ -207,11 +209,14 @@ class ResNet50TrainEngine:
                    stride=(c.stride, c.stride), stats_out=stats[0] if stats else None)
         return stats
 
-    def _conv_dgrad(self, c, dz, dz_hw, dx, dx_hw, res=None):
+    def _conv_dgrad(self, c, dz, dz_hw, dx, dx_hw, res=None, res_mask_bits=None):
+        """dx = conv^T(dz) [+ res]; res_mask_bits: the residual is masked by that 1-bit tensor in the epilogue (dx = conv^T(dz) + res . [bit]):
+        the skip gradient d_out . [out > 0] without a tensor of its own."""
         B = dz.shape[0]
         for parity, taps, rs, w in c.bwd:
             if parity is None:
-                self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res)
+                self._gemm(dz, w, dx, B, dx_hw, dz_hw, c.cout, c.cout, taps, c.cin, dx_hw, c.cin, res=res, mask_bits=res_mask_bits,
+                           flags=(16 | 128) if res_mask_bits is not None else 0)
             else:
                 ph, pw = parity
                 if not taps:
@@ -404,7 +409,8 @@ class ResNet50TrainEngine:
             x, xhw, za, ya, zb, yb, zc, zd, out, ohw = acts['b%d' % bi]
             rows_o, rows_i = B * ohw[0] * ohw[1], B * xhw[0] * xhw[1]
             dzc = self._get('g_zc', tuple(zc.shape))
-            g = self._get('g_skip', tuple(zc.shape))
+            skip_bits = self._ysign.get(out.data_ptr()) if (self.bit_masks and self.masked_skip and ds is None) else None
+            g = None if skip_bits is not None else self._get('g_skip', tuple(zc.shape))
             self._bn_bwd(cc, d_out, out, zc, dzc, rows_o, g_out=g)
             self._conv_wgrad(cc, dzc, ohw, yb, ohw)
             dyb = self._get('g_yb', tuple(yb.shape))
@@ -420,7 +426,10 @@ class ResNet50TrainEngine:
             self._bn_bwd(ca, dya, ya, za, dza, rows_i)
             self._conv_wgrad(ca, dza, xhw, x, xhw)
             dx = self._get('g_x_%d' % (bi % 2), tuple(x.shape))
-            if ds is None:
+            if ds is None and skip_bits is not None:
+                # the identity skip's gradient d_out . [out > 0] is formed in the dgrad epilogue from d_out and the sign bits of `out`
+                self._conv_dgrad(ca, dza, xhw, dx, xhw, res=d_out, res_mask_bits=skip_bits)
+            elif ds is None:
                 self._conv_dgrad(ca, dza, xhw, dx, xhw, res=g)
             else:
                 self._conv_dgrad(ca, dza, xhw, dx, xhw)

@@ -21,5 +21,5 @@ python $R/scratch/r4/time_square.py > /dev/null 2>&1; cp $R/gpurun_out/r04_squar
 rocprofv3 --kernel-trace --stats -d /tmp/prof_adv -o a -- python $R/bench.py --workload adv_train --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python $R/profiles/summarize_rocpd.py $(find /tmp/prof_adv -name "*.db" | head -1) $O/r04_adv_train_kernel_stats.csv > /dev/null
 python $R/scratch/r4/time_wgrad.py 2>/dev/null > $O/r04_wgrad_per_layer.txt
-for f in "" "stats=0" "bits=0" "direct=0" "stats=0,bits=0,direct=0"; do echo "[$f] $(RART_TRAIN_FLAGS=$f python $R/bench.py --workload adv_train --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1)"; done > $O/r04_adv_train_switches.txt
+for f in "" "skip=0" "stats=0" "bits=0" "direct=0" "skip=0,stats=0,bits=0,direct=0"; do echo "[$f] $(RART_TRAIN_FLAGS=$f python $R/bench.py --workload adv_train --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1)"; done > $O/r04_adv_train_switches.txt
 ls -la $O
