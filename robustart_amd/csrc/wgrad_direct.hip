@@ -58,7 +58,7 @@ __device__ __forceinline__ bf16x8 wg_frag(const uint8_t* tile, int k0, int col0,
 }
 
 template <int TN, int TMR>
-__global__ __launch_bounds__(TMR * 2, 2) void k_wgrad_direct(const WgradDev d) {
+__global__ __launch_bounds__(TMR * 2, TMR == 128 ? 5 : 2) void k_wgrad_direct(const WgradDev d) {
   constexpr int NW = TMR / 32;                      // waves: 4 (128 rows) / 8 (256 rows)
   constexpr int WN = TN / 64, WM = NW / WN, RW = TMR / WM, MI = RW / 32;
   constexpr int ROWA = TMR * 2, ROWB = TN * 2;      // bytes of a position's row in the x / dz tile

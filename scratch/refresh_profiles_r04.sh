@@ -21,5 +21,7 @@ python $R/scratch/r4/time_square.py > /dev/null 2>&1; cp $R/gpurun_out/r04_squar
 rocprofv3 --kernel-trace --stats -d /tmp/prof_adv -o a -- python $R/bench.py --workload adv_train --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python $R/profiles/summarize_rocpd.py $(find /tmp/prof_adv -name "*.db" | head -1) $O/r04_adv_train_kernel_stats.csv > /dev/null
 python $R/scratch/r4/time_wgrad.py 2>/dev/null > $O/r04_wgrad_per_layer.txt
+for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --kernel-trace --pmc $c -d /tmp/prof_adv_$c -o a -- python $R/bench.py --workload adv_train --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; done
+python $R/profiles/summarize_pmc.py $(find /tmp/prof_adv_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/prof_adv_WRITE_SIZE -name "*.db" | head -1) $O/r04_adv_train_pmc_traffic.json > /dev/null
 for f in "" "skip=0" "stats=0" "bits=0" "direct=0" "skip=0,stats=0,bits=0,direct=0"; do echo "[$f] $(RART_TRAIN_FLAGS=$f python $R/bench.py --workload adv_train --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1)"; done > $O/r04_adv_train_switches.txt
 ls -la $O
