@@ -64,8 +64,8 @@ __device__ __forceinline__ void pool_bwd_class(uint4* sDz1, const uint4* sDp, co
           const int qx = (px >> 1) + ib;
           const uint32_t mine = (ky * 3 + (uint32_t)(px - (2 * qx - 1))) * 0x01010101u;
           const int lp = (qy - qy0) * PT + (qx - qx0);      // out-of-grid windows hold code 15 / zeros
-          const uint2 cd = sArg[lp * 8 + c];
-          const uint4 dv = sDp[lp * 8 + c];
+          const uint2 cd = sArg[c * NPOOL + lp];            // chunk-major: the lanes of a wave walk consecutive windows
+          const uint4 dv = sDp[c * NPOOL + lp];
           const uint32_t cw[2] = {cd.x, cd.y};
           const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd_fused(const uint4* __restri
   // one LDS object (a second one makes hipcc wait vmcnt(0) before LDS reads): dz1 tile | raw pooled tile (later: out tile)
   __shared__ __attribute__((aligned(16))) uint8_t lds[8 * NPOS_PAD * 16 + NPOOL * 192];
   uint4* sDz1 = reinterpret_cast<uint4*>(lds);                          // [8][NPOS_PAD]
-  uint4* sDp = reinterpret_cast<uint4*>(lds + 8 * NPOS_PAD * 16);       // [NPOOL][8]  pooled gradient, 8 channels / 16 B
-  uint2* sArg = reinterpret_cast<uint2*>(lds + 8 * NPOS_PAD * 16 + NPOOL * 128);   // [NPOOL][8]  argmax codes, 8 / 8 B
+  uint4* sDp = reinterpret_cast<uint4*>(lds + 8 * NPOS_PAD * 16);       // [8][NPOOL]  pooled gradient, 8 channels / 16 B (chunk-major)
+  uint2* sArg = reinterpret_cast<uint2*>(lds + 8 * NPOS_PAD * 16 + NPOOL * 128);   // [8][NPOOL]  argmax codes, 8 / 8 B
   float* sOut = reinterpret_cast<float*>(lds + 8 * NPOS_PAD * 16);      // [3][OT][OLD] (aliases the raw tile)
   static_assert(3 * OT * OLD * 4 <= NPOOL * 192, "output tile must fit the raw pooled tile");
 
@@ -118,11 +118,12 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd_fused(const uint4* __restri
     if (v < 8) {
       uint4 val = make_uint4(0, 0, 0, 0);
       if (ok) val = dpool[base * 8 + v];
-      sDp[pos * 8 + v] = val;
+      sDp[v * NPOOL + pos] = val;
     } else {
       uint4 val = make_uint4(0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu);
       if (ok) val = reinterpret_cast<const uint4*>(arg)[base * 4 + (v - 8)];
-      reinterpret_cast<uint4*>(sArg)[pos * 4 + (v - 8)] = val;
+      sArg[(2 * (v - 8)) * NPOOL + pos] = make_uint2(val.x, val.y);
+      sArg[(2 * (v - 8) + 1) * NPOOL + pos] = make_uint2(val.z, val.w);
     }
   }
   __syncthreads();

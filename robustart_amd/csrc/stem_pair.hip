@@ -63,8 +63,8 @@ __device__ __forceinline__ void pool_bwd_class_pair(uint4* sDz1, const uint4* sD
           const int qx = (px >> 1) + ib;
           const uint32_t mine = (ky * 3 + (uint32_t)(px - (2 * qx - 1))) * 0x01010101u;
           const int lp = (qy - qy0) * PT + (qx - qx0);      // out-of-grid windows hold code 15 / zeros
-          const uint2 cd = sArg[lp * 4 + c];
-          const uint4 dh = sDp[lp * 4 + c], dl = sDp[NPOOL * 4 + lp * 4 + c];
+          const uint2 cd = sArg[c * NPOOL + lp];            // chunk-major: the lanes of a wave walk consecutive windows
+          const uint4 dh = sDp[c * NPOOL + lp], dl = sDp[(4 + c) * NPOOL + lp];
           const uint32_t cw[2] = {cd.x, cd.y};
           const uint32_t hw_[4] = {dh.x, dh.y, dh.z, dh.w}, lw_[4] = {dl.x, dl.y, dl.z, dl.w};
 #pragma unroll
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd_pair(const uint4* __restric
                                                           int h, int w, Istd3p istd) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[DZ_BYTES + DP_BYTES + ARG_BYTES];
   uint4* sDz1 = reinterpret_cast<uint4*>(lds);                                     // [2][4][NPOS_PAD]
-  uint4* sDp = reinterpret_cast<uint4*>(lds + DZ_BYTES);                           // [2][NPOOL][4]
-  uint2* sArg = reinterpret_cast<uint2*>(lds + DZ_BYTES + DP_BYTES);               // [NPOOL][4]
+  uint4* sDp = reinterpret_cast<uint4*>(lds + DZ_BYTES);                           // [2][4][NPOOL] (chunk-major)
+  uint2* sArg = reinterpret_cast<uint2*>(lds + DZ_BYTES + DP_BYTES);               // [4][NPOOL]
   float* sOut = reinterpret_cast<float*>(lds + DZ_BYTES);                          // [3][OT][OLD] (aliases the raw tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,11 +134,12 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd_pair(const uint4* __restric
         const int pl = v >> 2, c = v & 3;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (ok) val = (pl ? dpool_l : dpool_h)[base * 8 + half * 4 + c];
-        sDp[pl * NPOOL * 4 + pos * 4 + c] = val;
+        sDp[(pl * 4 + c) * NPOOL + pos] = val;
       } else {
         uint4 val = make_uint4(0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu);
         if (ok) val = arg[base * 4 + half * 2 + (v - 8)];
-        reinterpret_cast<uint4*>(sArg)[pos * 2 + (v - 8)] = val;
+        sArg[(2 * (v - 8)) * NPOOL + pos] = make_uint2(val.x, val.y);
+        sArg[(2 * (v - 8) + 1) * NPOOL + pos] = make_uint2(val.z, val.w);
       }
     }
     __syncthreads();
