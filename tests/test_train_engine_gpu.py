@@ -86,7 +86,7 @@ def test_bn_train_forward_and_backward_kernels(rows, C, relu, with_res):
 
 
 @pytest.mark.parametrize('cin,cout,r,stride,H,B', [(64, 64, 3, 1, 16, 4), (64, 256, 1, 1, 10, 3), (256, 128, 1, 1, 28, 9), (128, 128, 3, 2, 16, 4),
-                                                   (1024, 2048, 1, 2, 4, 16)])
+                                                   (1024, 2048, 1, 2, 4, 16), (64, 256, 1, 1, 56, 96)])     # the last: 2 352 row tiles -> the folded finaliser
 def test_conv_epilogue_batchnorm_statistics(cin, cout, r, stride, H, B):
     """rart_conv_desc.bn_stats_out: the igemm's per-tile column sums / sums of squares of the bf16 output equal the sums of the stored
     tensor (fp32 order noise), for 64- and 128-column tiles, shallow and deep K pipelines and a ragged last row tile; fed to
@@ -215,6 +215,26 @@ def test_wgrad_single_layers_match_torch(direct):
         F.conv2d(x.float().permute(0, 3, 1, 2), w, stride=stride, padding=r // 2).backward(dz.float().permute(0, 3, 1, 2))
         assert _cos(conv.weight.grad, w.grad) > 0.99999, (cin, cout, r, stride, H, B)
         torch.testing.assert_close(conv.weight.grad, w.grad, rtol=1e-3, atol=1e-3 * float(w.grad.abs().max()))
+
+
+def test_wgrad_direct_at_the_benchmark_size():
+    """rart_wgrad_direct_bf16 at B = 256 on layer1's 3x3 (802 816 positions, 1 020 K splits, two taps per tile) and layer3's 1x1
+    (1 024 -> 256): against torch's fp32 weight gradient of the same bf16 tensors."""
+    from robustart_amd.model.train_engine import ResNet50TrainEngine, _TConv
+    model, _, _ = _tiny_resnet_inputs(2, 32)
+    eng = ResNet50TrainEngine(model)
+    assert eng.direct_wgrad
+    torch.manual_seed(7)
+    for cin, cout, r, H in ((64, 64, 3, 56), (1024, 256, 1, 14)):
+        conv = torch.nn.Conv2d(cin, cout, r, padding=r // 2, bias=False).cuda()
+        conv.weight.grad = torch.zeros_like(conv.weight)
+        tc = _TConv(conv, None, torch.device('cuda'), torch)
+        x = torch.randn(256, H, H, cin, device='cuda').to(torch.bfloat16)
+        dz = torch.randn(256, H, H, cout, device='cuda').to(torch.bfloat16)
+        eng._conv_wgrad(tc, dz, (H, H), x, (H, H))
+        want = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), conv.weight.shape, dz.float().permute(0, 3, 1, 2), padding=r // 2)
+        assert _cos(conv.weight.grad, want) > 0.999999, (cin, cout, r)
+        torch.testing.assert_close(conv.weight.grad, want, rtol=2e-3, atol=2e-3 * float(want.abs().max()))
 
 
 def _rb(t):
