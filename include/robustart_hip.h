@@ -773,7 +773,8 @@ int rart_transpose_gather_bf16(const void* src, void* dst, int batch, int src_h,
 /* Weight gradient straight from the NHWC activations (csrc/wgrad_direct.hip): partial[z][t * channels + c][n] = sum over the positions m of
  * K split z (chunk positions each) of x[pixel(m) + tap t][c] * dz[m][n], fp32, the layout rart_wgrad_reduce_f32 folds -- without the two
  * rart_transpose_gather_bf16 passes: the position-major tiles are read out of LDS transposed (ds_read_b64_tr_b16).  x [batch][in_h][in_w]
- * [channels], dz [batch][grid_h][grid_w][dz_cols] bf16; channels 64 or a multiple of 128, dz_cols a multiple of 64, 1..9 taps;
+ * [channels], dz [batch][grid_h][grid_w][dz_cols] bf16; channels 64 or a multiple of 128, dz_cols a multiple of 64, 1..9 taps -- or
+ * channels 4 (the stem's padded plane: 32 taps x 4 channels per tile, 4-byte direct loads), dz_cols 64, 1..49 taps;
  * chunk a multiple of 32 with splits * chunk >= batch * grid_h * grid_w; ld_n = dz_cols.  (loss.backward() of cls_solver.py:183-215) */
 int rart_wgrad_direct_supported(int channels, int dz_cols, int n_taps);
 int rart_wgrad_direct_bf16(const void* x, const void* dz, float* partial, int batch, int in_h, int in_w, int channels, int grid_h, int grid_w,

@@ -32,7 +32,7 @@ struct WgradDev {
   float* part;            // [splits][kp][ld_n]
   int C, ldz, ld_n, kp, n_valid;
   int ih, iw, gh, gw, sy, sx, n_taps;
-  int tap_dy[9], tap_dx[9];
+  int tap_dy[49], tap_dx[49];
   int M, chunk;           // positions, positions per K split (a multiple of 32)
   uint32_t gw_magic, gw_shift, gh_magic, gh_shift;
 };
@@ -57,7 +57,9 @@ __device__ __forceinline__ bf16x8 wg_frag(const uint8_t* tile, int k0, int col0,
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int TN, int TMR>
+// STEM: x has 4 channels per pixel (the padded hi plane of the 7x7/2 stem, 3 valid): a tile row = 32 taps x 4 channels, every 8-byte piece of
+// it from another pixel -- the x tile is loaded with 4-byte direct loads, one wave-load per position row
+template <int TN, int TMR, bool STEM>
 __global__ __launch_bounds__(TMR * 2, TMR == 128 ? 5 : 2) void k_wgrad_direct(const WgradDev d) {
   constexpr int NW = TMR / 32;                      // waves: 4 (128 rows) / 8 (256 rows)
   constexpr int WN = TN / 64, WM = NW / WN, RW = TMR / WM, MI = RW / 32;
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(TMR * 2, TMR == 128 ? 5 : 2) void k_wgrad_direct(co
   const int tpt = d.C >= TMR ? 1 : TMR / d.C;       // taps per tile
   const int t0 = d.C >= TMR ? rt / per_tap : rt * tpt;
   const int c0 = d.C >= TMR ? (rt - t0 * per_tap) * TMR : 0;
-  const int cpt = (d.C >= TMR ? TMR : d.C) / 8;     // 16-byte chunks of one tap inside a tile row
+  const int t0s = rt * (TMR / 4);                   // STEM: 32 taps per 128-row tile
+  const int cpt = STEM ? 1 : (d.C >= TMR ? TMR : d.C) / 8;     // 16-byte chunks of one tap inside a tile row
   const int m_begin = z * d.chunk, m_end = min(m_begin + d.chunk, d.M);
   const int steps = (m_end - m_begin + 31) / 32;
 
@@ -105,6 +108,26 @@ __global__ __launch_bounds__(TMR * 2, TMR == 128 ? 5 : 2) void k_wgrad_direct(co
   {                                                                                                             \
     uint8_t* const st_ = lds + (BUF)*STAGE;                                                                     \
     const int mb_ = m_begin + (STEP)*32;                                                                        \
+    if (STEM) {                                                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 32 / NW; ++q) {                                                     \
+        const int row_ = (32 / NW) * wave + q;                                                                  \
+        const int m_ = mb_ + row_;                                                                              \
+        const int ld_ = ((((lane >> 2) ^ (4 * (row_ & 3))) << 2) | (lane & 3));       /* logical dword of the lane's slot */ \
+        const int tap_ = t0s + (ld_ >> 1);                                                                       \
+        const char* src_ = zsrc;                                                                                \
+        if (m_ < m_end && tap_ < d.n_taps) {                                                                    \
+          const uint32_t t_ = wg_fastdiv((uint32_t)m_, d.gw_magic, d.gw_shift);                                 \
+          const int ox_ = (int)((uint32_t)m_ - t_ * (uint32_t)d.gw);                                            \
+          const int im_ = (int)wg_fastdiv(t_, d.gh_magic, d.gh_shift);                                          \
+          const int oy_ = (int)(t_ - (uint32_t)im_ * (uint32_t)d.gh);                                           \
+          const int iy_ = oy_ * d.sy + d.tap_dy[tap_], ix_ = ox_ * d.sx + d.tap_dx[tap_];                       \
+          if ((unsigned)iy_ < (unsigned)d.ih && (unsigned)ix_ < (unsigned)d.iw)                                 \
+            src_ = reinterpret_cast<const char*>(d.x + ((size_t)(im_ * d.ih + iy_) * d.iw + ix_) * 4 + (ld_ & 1) * 2); \
+        }                                                                                                       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_),                 \
+                                         (__attribute__((address_space(3))) void*)(st_ + row_ * ROWA), 4, 0, 0); \
+      }                                                                                                         \
+    } else                                                                                                      \
     _Pragma("unroll") for (int q = 0; q < AI; ++q) {                                                            \
       const int m_ = mb_ + a_row[q];                                                                            \
       const char* src_ = zsrc;                                                                                  \
@@ -166,7 +189,7 @@ __global__ __launch_bounds__(TMR * 2, TMR == 128 ? 5 : 2) void k_wgrad_direct(co
 #undef RART_WG_DL
   // ---- fp32 partial sums: acc[i][j][r] = row wm*RW + i*32 + (r&3) + 8*(r>>2) + 4h, column wn*64 + j*32 + (lane & 31)
   const int fr = lane & 31, h = lane >> 5;
-  const int row_base = t0 * d.C + c0;
+  const int row_base = STEM ? t0s * 4 : t0 * d.C + c0;
   float* const pz = d.part + (size_t)z * d.kp * d.ld_n;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -191,6 +214,7 @@ void wg_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividend
 }  // namespace
 
 extern "C" int rart_wgrad_direct_supported(int channels, int n_cols, int n_taps) {
+  if (channels == 4) return (n_cols == 64 && n_taps >= 1 && n_taps <= 49) ? 1 : 0;          // the stem: 4-channel pixels (3 valid), 64 filters
   return ((channels == 64 || (channels >= 128 && channels % 128 == 0)) && n_cols % 64 == 0 && n_cols >= 64 && n_taps >= 1 && n_taps <= 9) ? 1 : 0;
 }
 
@@ -200,7 +224,7 @@ extern "C" int rart_wgrad_direct_bf16(const void* x, const void* dz, float* part
   RART_CHECK_ARG(x && dz && partial && batch > 0 && in_h > 0 && in_w > 0 && grid_h > 0 && grid_w > 0 && tap_dy && tap_dx,
                  "rart_wgrad_direct_bf16: bad arguments");
   RART_CHECK_ARG(rart_wgrad_direct_supported(channels, dz_cols, n_taps),
-                 "rart_wgrad_direct_bf16: channels must be 64 or a multiple of 128, dz_cols a multiple of 64, 1..9 taps");
+                 "rart_wgrad_direct_bf16: channels must be 64 or a multiple of 128 (dz_cols a multiple of 64, 1..9 taps), or 4 (dz_cols 64, 1..49 taps)");
   const long long M = (long long)batch * grid_h * grid_w;
   RART_CHECK_ARG(M < (1ll << 31) && (long long)batch * in_h * in_w * channels < (1ll << 31) && M * dz_cols < (1ll << 31),
                  "rart_wgrad_direct_bf16: tensors must stay below 2^31 elements");
@@ -211,7 +235,7 @@ extern "C" int rart_wgrad_direct_bf16(const void* x, const void* dz, float* part
   d.x = (const uint16_t*)x; d.dz = (const uint16_t*)dz; d.part = partial;
   d.C = channels; d.ldz = dz_cols; d.ld_n = ld_n; d.kp = n_taps * channels; d.n_valid = ld_n;
   d.ih = in_h; d.iw = in_w; d.gh = grid_h; d.gw = grid_w; d.sy = stride_y; d.sx = stride_x; d.n_taps = n_taps;
-  for (int i = 0; i < 9; ++i) { d.tap_dy[i] = i < n_taps ? tap_dy[i] : 0; d.tap_dx[i] = i < n_taps ? tap_dx[i] : 0; }
+  for (int i = 0; i < 49; ++i) { d.tap_dy[i] = i < n_taps ? tap_dy[i] : 0; d.tap_dx[i] = i < n_taps ? tap_dx[i] : 0; }
   d.M = (int)M; d.chunk = chunk;
   wg_magic((uint32_t)grid_w, d.gw_magic, d.gw_shift);
   wg_magic((uint32_t)grid_h, d.gh_magic, d.gh_shift);
@@ -220,10 +244,15 @@ extern "C" int rart_wgrad_direct_bf16(const void* x, const void* dz, float* part
   // weight gradients per step (adv_train 4.82 vs 4.90 k images/s): three 8-wave workgroups per CU hide the K step's load latency worse than
   // five 4-wave ones.  128 rows it is.
   constexpr int tmr = 128;
-  const int row_tiles = channels >= tmr ? n_taps * (channels / tmr) : (n_taps + tmr / channels - 1) / (tmr / channels);
   hipStream_t st = (hipStream_t)stream;
-  if (dz_cols % 128 == 0) hipLaunchKernelGGL((k_wgrad_direct<128, 128>), dim3(row_tiles, dz_cols / 128, splits), dim3(256), 0, st, d);
-  else hipLaunchKernelGGL((k_wgrad_direct<64, 128>), dim3(row_tiles, dz_cols / 64, splits), dim3(256), 0, st, d);
+  if (channels == 4) {
+    hipLaunchKernelGGL((k_wgrad_direct<64, 128, true>), dim3((n_taps + 31) / 32, 1, splits), dim3(256), 0, st, d);
+    RART_CHECK_LAUNCH("rart_wgrad_direct_bf16");
+    return RART_OK;
+  }
+  const int row_tiles = channels >= tmr ? n_taps * (channels / tmr) : (n_taps + tmr / channels - 1) / (tmr / channels);
+  if (dz_cols % 128 == 0) hipLaunchKernelGGL((k_wgrad_direct<128, 128, false>), dim3(row_tiles, dz_cols / 128, splits), dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((k_wgrad_direct<64, 128, false>), dim3(row_tiles, dz_cols / 64, splits), dim3(256), 0, st, d);
   RART_CHECK_LAUNCH("rart_wgrad_direct_bf16");
   return RART_OK;
 }

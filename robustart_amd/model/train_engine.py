@@ -269,10 +269,13 @@ class ResNet50TrainEngine:
         gh, gw = grid_hw
         M = B * gh * gw
         kp = len(taps) * x_c                                   # rows of the transposed im2col matrix
-        if self.direct_wgrad and c_valid is None and lib.rart_wgrad_direct_supported(x_c, n_pad_cols, len(taps)):
+        if self.direct_wgrad and (c_valid is None or x_c == 4) and lib.rart_wgrad_direct_supported(x_c, n_pad_cols, len(taps)):
             # straight from the NHWC activations (csrc/wgrad_direct.hip): no transposed copies, no materialised im2col
             tmr = 128                # the library's tile height (csrc/wgrad_direct.hip: 256-row tiles measured slower)
-            row_tiles = len(taps) * (x_c // tmr) if x_c >= tmr else (len(taps) + tmr // x_c - 1) // (tmr // x_c)
+            if x_c == 4:             # the stem's padded hi plane: 32 taps x 4 channels per tile
+                row_tiles = (len(taps) + 31) // 32
+            else:
+                row_tiles = len(taps) * (x_c // tmr) if x_c >= tmr else (len(taps) + tmr // x_c - 1) // (tmr // x_c)
             tiles = row_tiles * (n_pad_cols // (128 if n_pad_cols % 128 == 0 else 64))
             splits = max(1, min(self.wgrad_target_wgs // max(tiles, 1), M // self.wgrad_min_chunk if M >= 2 * self.wgrad_min_chunk else 1,
                                 1024))
@@ -282,7 +285,8 @@ class ResNet50TrainEngine:
             _lib.check(lib.rart_wgrad_direct_bf16(x.data_ptr(), dz.data_ptr(), part.data_ptr(), B, x_hw[0], x_hw[1], x_c, gh, gw, n_pad_cols,
                                                   stride, stride, len(taps), _ints([t[0] for t in taps]), _ints([t[1] for t in taps]),
                                                   splits, chunk, n_pad_cols, sp))
-            _lib.check(lib.rart_wgrad_reduce_f32(part.data_ptr(), splits, len(taps), x_c, x_c, n_out, n_pad_cols, grad.data_ptr(), 0, sp))
+            _lib.check(lib.rart_wgrad_reduce_f32(part.data_ptr(), splits, len(taps), c_valid if c_valid is not None else x_c, x_c, n_out,
+                                                 n_pad_cols, grad.data_ptr(), 0, sp))
             return
         bn_tile = 128 if n_pad_cols > 64 else 64
         tiles = ((kp + 127) // 128) * ((n_pad_cols + bn_tile - 1) // bn_tile)

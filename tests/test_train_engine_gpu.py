@@ -217,6 +217,28 @@ def test_wgrad_single_layers_match_torch(direct):
         torch.testing.assert_close(conv.weight.grad, w.grad, rtol=1e-3, atol=1e-3 * float(w.grad.abs().max()))
 
 
+def test_stem_wgrad_direct_matches_the_transposing_path_and_torch():
+    """The stem's weight gradient (7x7 / 2, 49 taps on the 4-channel padded plane, 3 valid channels) on rart_wgrad_direct_bf16's
+    4-channel form against the transpose_gather path and torch, through a full engine step at 64 x 64 and 96 x 128 inputs."""
+    from robustart_amd.model.train_engine import ResNet50TrainEngine
+    for S_ in ((64, 64), (96, 128)):
+        model, _, _ = _tiny_resnet_inputs(2, 32)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        eng = ResNet50TrainEngine(model)
+        g = torch.Generator().manual_seed(3)
+        x01 = torch.rand(3, 3, S_[0], S_[1], generator=g).cuda()
+        dl = (torch.randn(3, 1000, generator=g) * 1e-2).cuda()
+        grads = []
+        for direct in (True, False):
+            eng.direct_wgrad = direct
+            eng.forward(x01, False, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+            eng.backward(dl)
+            grads.append(model.conv1.weight.grad.clone())
+        assert _cos(grads[0], grads[1]) > 0.99999
+        torch.testing.assert_close(grads[0], grads[1], rtol=2e-3, atol=2e-3 * float(grads[1].abs().max()))
+
+
 def test_wgrad_direct_at_the_benchmark_size():
     """rart_wgrad_direct_bf16 at B = 256 on layer1's 3x3 (802 816 positions, 1 020 K splits, two taps per tile) and layer3's 1x1
     (1 024 -> 256): against torch's fp32 weight gradient of the same bf16 tensors."""
