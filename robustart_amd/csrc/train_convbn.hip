@@ -15,6 +15,7 @@
 // Reference arithmetic: torch.nn.BatchNorm2d / conv2d autograd (the reference trains with PyTorch:
 // cifar10/code/train.py:96-127; model RobustART/model/__init__.py:1 -> public ResNet-50).
 #include "rart_common.h"
+#include <cstdlib>
 
 namespace {
 constexpr int kBlock = 256;
@@ -119,25 +120,28 @@ __global__ __launch_bounds__(kBlock) void k_colsum2(const uint4* __restrict__ z,
   }
 }
 
-// Finalisers: 16 channels x 16 chunk lanes per 256-thread block (a single thread walking 2048 partials is a
-// 2048-deep chain of dependent-latency loads, ~0.5 ms per layer); fixed summation order -> deterministic.
-__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int chunks, int C, int c, int lane16,
-                                                double (*sh)[16][16], double& s, double& q) {
+// Finalisers: FIN_CH channels x FIN_LANES chunk lanes per 256-thread block; fixed summation order -> deterministic.  A single thread walking
+// 2 048 partials was a 2 048-deep chain of dependent-latency loads (~0.5 ms per layer); 16 lanes per channel still left 128 loads per lane in
+// 32 dependent batches -- 14.5 us per launch, 106 launches per training step; 64 lanes per channel (4 channels per block, C / 4 blocks) leave
+// eight batches.
+constexpr int FIN_LANES = 64, FIN_CH = 256 / FIN_LANES;
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int chunks, int C, int c, int lane,
+                                                double (*sh)[FIN_LANES][FIN_CH], double& s, double& q) {
   double a = 0.0, b = 0.0;
   if (c < C) {
 #pragma unroll 4
-    for (int k = lane16; k < chunks; k += 16) {
+    for (int k = lane; k < chunks; k += FIN_LANES) {
       a += (double)partial[((size_t)k * 2 + 0) * C + c];
       b += (double)partial[((size_t)k * 2 + 1) * C + c];
     }
   }
-  const int cl = threadIdx.x & 15;
-  sh[0][lane16][cl] = a;
-  sh[1][lane16][cl] = b;
+  const int cl = threadIdx.x % FIN_CH;
+  sh[0][lane][cl] = a;
+  sh[1][lane][cl] = b;
   __syncthreads();
   s = q = 0.0;
-  if (lane16 == 0) {
-    for (int k = 0; k < 16; ++k) {
+  if (lane == 0) {
+    for (int k = 0; k < FIN_LANES; ++k) {
       s += sh[0][k][cl];
       q += sh[1][k][cl];
     }
@@ -150,8 +154,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                          float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  __shared__ double sh[2][16][16];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  __shared__ double sh[2][FIN_LANES][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), lane16 = threadIdx.x / FIN_CH;
   double s, q;
   reduce_partials(partial, chunks, C, c, lane16, sh, s, q);
   if (lane16 != 0 || c >= C) return;
@@ -173,8 +177,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                                          float* __restrict__ coef /* [3][C]: k1, k2, gamma*invstd */) {
-  __shared__ double sh[2][16][16];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  __shared__ double sh[2][FIN_LANES][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), lane16 = threadIdx.x / FIN_CH;
   double s, q;
   reduce_partials(partial, chunks, C, c, lane16, sh, s, q);
   if (lane16 != 0 || c >= C) return;
@@ -456,9 +460,9 @@ inline unsigned grid_for(size_t n) {
   return (unsigned)b;
 }
 inline int chunks_for(size_t M, int C, size_t* rows_per_chunk) {
-  // ~2048 workgroups (8 per CU), each at least four passes of its row lanes
+  // ~1024 workgroups (4 per CU), each at least four passes of its row lanes
   const size_t rows_par = (size_t)(kBlock / (C / 8));
-  size_t chunks = 2048;
+  size_t chunks = 1024;      // (2 048 measured 0.35 ms per adv_train step slower: the finalisers read every partial row)
   size_t rpc = (M + chunks - 1) / chunks;
   if (rpc < rows_par * 4) rpc = rows_par * 4;
   chunks = (M + rpc - 1) / rpc;
@@ -474,17 +478,17 @@ extern "C" size_t rart_bn_workspace_bytes(size_t rows, int channels) {
   return (size_t)chunks * 2 * channels * sizeof(float);
 }
 
-// [chunks][2][C] -> [ceil(chunks / 16)][2][C]: groups of 16 partial rows summed in fixed order (the convolution's per-tile statistics of a
-// large layer are thousands of rows; the finaliser walks at most 2 048)
-__global__ __launch_bounds__(kBlock) void k_stats_fold(const float* __restrict__ in, float* __restrict__ out, int chunks, int C2) {
-  const int groups = (chunks + 15) / 16;
+// [chunks][2][C] -> [ceil(chunks / fold)][2][C]: groups of `fold` partial rows summed in fixed order (the convolution's per-tile statistics
+// of a large layer are thousands of rows; the finaliser walks at most 1 024)
+__global__ __launch_bounds__(kBlock) void k_stats_fold(const float* __restrict__ in, float* __restrict__ out, int chunks, int C2, int fold) {
+  const int groups = (chunks + fold - 1) / fold;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)groups * C2; i += (size_t)gridDim.x * kBlock) {
     const int gidx = (int)(i / C2);
     const int e = (int)(i - (size_t)gidx * C2);
-    const int cnt = chunks - gidx * 16 < 16 ? chunks - gidx * 16 : 16;
+    const int cnt = chunks - gidx * fold < fold ? chunks - gidx * fold : fold;
     float s = 0.f;
 #pragma unroll 4
-    for (int k = 0; k < cnt; ++k) s += in[((size_t)gidx * 16 + k) * C2 + e];
+    for (int k = 0; k < cnt; ++k) s += in[((size_t)gidx * fold + k) * C2 + e];
     out[i] = s;
   }
 }
@@ -509,15 +513,18 @@ extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* 
   const float* part = (const float*)workspace;
   int n_part = chunks;
   RART_CHECK_ARG(!stats_partial || stats_chunks >= 1, "rart_bn_train_forward_bf16: stats_chunks must be >= 1");
-  // more than 2 048 x 16 tiles (batch > ~330 at the stem's 112 x 112 grid): the folded sums would not fit the workspace -- own pass instead
-  const bool use_partial = stats_partial && (stats_chunks <= 2048 || (size_t)((stats_chunks + 15) / 16) * 2 * channels * sizeof(float) <= workspace_bytes);
+  // more tiles than the finaliser should walk: fold them `fold`:1 into the workspace first (as many slots as it holds, at most 1 024)
+  const size_t slots = workspace_bytes / ((size_t)2 * channels * sizeof(float));
+  const int keep = (int)(slots < 1024 ? slots : 1024);
+  const bool use_partial = stats_partial && (stats_chunks <= 1024 || keep >= 64);
   if (use_partial) {          // the producing convolution's per-tile sums (rart_conv_desc.bn_stats_out): no pass over z
     part = stats_partial;
     n_part = stats_chunks;
-    if (n_part > 2048) {
-      const int groups = (n_part + 15) / 16;
+    if (n_part > 1024) {
+      const int fold = (n_part + keep - 1) / keep;
+      const int groups = (n_part + fold - 1) / fold;
       hipLaunchKernelGGL(k_stats_fold, dim3(grid_for((size_t)groups * 2 * channels)), dim3(kBlock), 0, st, stats_partial,
-                         (float*)workspace, n_part, 2 * channels);
+                         (float*)workspace, n_part, 2 * channels, fold);
       part = (const float*)workspace;
       n_part = groups;
     }
@@ -525,7 +532,7 @@ extern "C" int rart_bn_train_forward_bf16(const void* z, const void* res, void* 
     hipLaunchKernelGGL(k_colsum2<0>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr, nullptr,
                        rows, channels, rpc, (float*)workspace);
   }
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + 15) / 16), dim3(256), 0, st, part, n_part,
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((channels + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, part, n_part,
                      channels, 1.0 / (double)rows, (double)rows / (double)(rows - 1), gamma, beta, (float)eps,
                      (float)momentum, running_mean, running_var, mean_out, invstd_out, scale_shift,
                      scale_shift + channels);
@@ -557,7 +564,7 @@ extern "C" int rart_bn_train_backward_bf16(const void* dy, const void* ymask, in
   const uint8_t* yb = ymask_is_bits ? (const uint8_t*)ymask : nullptr;
   hipLaunchKernelGGL(k_colsum2<1>, dim3(chunks), dim3(kBlock), 0, st, (const uint4*)z, (const uint4*)dy, ym, yb, mean, invstd, rows,
                      channels, rpc, (float*)workspace);
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((channels + 15) / 16), dim3(256), 0, st, (const float*)workspace, chunks,
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((channels + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, (const float*)workspace, chunks,
                      channels, 1.0 / (double)rows, gamma, invstd, dgamma, dbeta, accumulate, coef);
   const size_t n8 = rows * (size_t)(channels / 8);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n8)), dim3(kBlock), 0, st, (const uint4*)dy, ym, yb, (const uint4*)z, (uint4*)dz,
