@@ -12,7 +12,7 @@ torch.manual_seed(20260927)
 d = tempfile.mkdtemp()
 cfg = {'model': {'type': 'resnet50_official', 'kwargs': {'num_classes': 1000}},
        'data': {'read_from': 'structured', 'fake_size': 4096, 'batch_size': 64, 'input_size': 224},
-       'label_smooth': 0.0, 'max_iter': 400, 'ema': {'enable': True, 'kwargs': {'decay': 0.9}},
+       'label_smooth': 0.1, 'max_iter': 400, 'ema': {'enable': True, 'kwargs': {'decay': 0.9}},
        'lr_scheduler': {'kwargs': {'base_lr': 0.02, 'warmup_lr': 0.08, 'warmup_steps': 10}},
        'saver': {'save_dir': d, 'print_freq': 100}}
 a = _Args()

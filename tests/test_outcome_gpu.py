@@ -32,7 +32,7 @@ class _Args:
 
 @pytest.fixture(scope='module')
 def fitted(tmp_path_factory):
-    """ResNet-50 fitted for 400 SGD-Nesterov steps (HIP train engine, batch 64) on StructuredFakeImageNet, saved and
+    """ResNet-50 fitted for 400 SGD-Nesterov steps (HIP train engine, batch 64, label smoothing 0.1) on StructuredFakeImageNet, saved and
     re-loaded through the solver's checkpoint path (saver.pretrain.path)."""
     from robustart_amd.train import cls_solver as S
     rank, world, device = S.init_dist()
@@ -40,12 +40,15 @@ def fitted(tmp_path_factory):
     d = str(tmp_path_factory.mktemp('ckpt'))
     cfg = {'model': {'type': 'resnet50_official', 'kwargs': {'num_classes': 1000}},
            'data': {'read_from': 'structured', 'fake_size': 4096, 'batch_size': 64, 'input_size': 224},
-           'label_smooth': 0.0, 'max_iter': 400, 'ema': {'enable': True, 'kwargs': {'decay': 0.9}},
+           'label_smooth': 0.1, 'max_iter': 400, 'ema': {'enable': True, 'kwargs': {'decay': 0.9}},
            'lr_scheduler': {'kwargs': {'base_lr': 0.02, 'warmup_lr': 0.08, 'warmup_steps': 10}},
            'saver': {'save_dir': d, 'print_freq': 50}}
     a = _Args()
     loss, model = S.train(cfg, a, rank, world, device)
-    assert loss < 1.0, 'the structured set must be learnable (final loss %.3f)' % loss
+    # label smoothing 0.1 over 1 000 classes has a floor of 1.02 (the reference's recipe: label_smooth 0.1 in 128 of its 134 configs;
+    # round 4 moved the fixture to it -- without smoothing the network saturates, BatchNorm variances of the conv3 layers collapse to
+    # 6e-3 and the fit becomes a lottery for every precision statement made on it)
+    assert loss < 1.6, 'the structured set must be learnable (final loss %.3f)' % loss
     path = os.path.join(d, 'ckpt.pth.tar')
     assert os.path.exists(path)
     ck = torch.load(path, map_location='cpu', weights_only=False)
