@@ -166,3 +166,36 @@ def test_square_eta_pattern_host_side():
             assert (e[:s // 2] > 0).all() and (e[s // 2:] < 0).all()
             if s % 2 == 1:
                 assert torch.allclose(e, e.flip(1), atol=1e-7)       # (odd sides: the rectangles are centred)
+
+
+def test_round4_host_side_predicates_and_tables():
+    """Host-only pieces of the round-4 entries (no GPU): which shapes the direct weight-gradient and the fused pair tail kernels accept, the
+    descriptor validation of rart_conv3x3_tail_pair / rart_wgrad_direct_bf16, and the vectorised stem-backward table of the eval engine
+    against its definition."""
+    import torch
+    from robustart_amd import _lib
+    from robustart_amd.model.engine import ResNet50Engine
+    lib = _lib.load()
+    assert lib.rart_wgrad_direct_supported(64, 64, 9) == 1 and lib.rart_wgrad_direct_supported(1024, 256, 1) == 1
+    assert lib.rart_wgrad_direct_supported(4, 64, 49) == 1            # the stem: 4-channel pixels, 49 taps
+    assert lib.rart_wgrad_direct_supported(4, 128, 49) == 0 and lib.rart_wgrad_direct_supported(64, 64, 49) == 0
+    assert lib.rart_wgrad_direct_supported(96, 64, 1) == 0 and lib.rart_wgrad_direct_supported(64, 1000, 1) == 0
+    assert lib.rart_conv3x3_tail_pair_supported(64) == 1 and lib.rart_conv3x3_tail_pair_supported(128) == 1
+    assert lib.rart_conv3x3_tail_pair_supported(256) == 0
+    d = _lib.ConvTailDesc()
+    assert lib.rart_conv3x3_tail_pair(ctypes.byref(d), None) == 1 and b'null operand plane' in lib.rart_last_error_string()
+    assert lib.rart_wgrad_direct_bf16(None, None, None, 1, 8, 8, 64, 8, 8, 64, 1, 1, 1, None, None, 1, 64, 64, None) == 1
+    # the stem-backward table: row (py*2+px)*3+c, column ((dp+1)*4+(dq+1))*64+k = W[k][c][py+3-2dp][px+3-2dq], zero where a tap leaves 0..6
+    wb = torch.randn(64, 3, 7, 7)
+    t = torch.zeros(16, 16, 64)
+    for py in range(2):
+        for px in range(2):
+            for dp in range(-1, 3):
+                for dq in range(-1, 3):
+                    r, s_ = py + 3 - 2 * dp, px + 3 - 2 * dq
+                    if 0 <= r <= 6 and 0 <= s_ <= 6:
+                        for c in range(3):
+                            t[(py * 2 + px) * 3 + c, (dp + 1) * 4 + (dq + 1)] = wb[:, c, r, s_]
+    got = ResNet50Engine._stem_bwd_table(wb, dtype=torch.float32)
+    assert torch.equal(got, t.reshape(16, 1024))
+    assert ResNet50Engine._stem_bwd_table(wb).dtype == torch.bfloat16
