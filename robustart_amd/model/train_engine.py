@@ -231,7 +231,7 @@ class ResNet50TrainEngine:
         mom = bn.momentum if bn.momentum is not None else 0.1
         sign = None
         if relu and self.bit_masks:      # 1 bit per element of (y > 0): what the backward reads instead of y (1/16 of its bytes)
-            sign = self._get('sgn_%x' % y.data_ptr(), (rows, c.cout // 8), self.torch.uint8)
+            sign = self._get('sgn_%x' % id(c), (rows, c.cout // 8), self.torch.uint8)      # one per conv + BatchNorm (stable name: no growth when batch sizes alternate)
             self._ysign[y.data_ptr()] = sign
         _lib.check(lib.rart_bn_train_forward_bf16(
             z.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(), _lib.ptr(sign), rows, c.cout, bn.weight.data_ptr(),
@@ -328,6 +328,7 @@ class ResNet50TrainEngine:
             B, H, W = src.shape[0], src.shape[2], src.shape[3]
         assert H % 32 == 0 and W % 32 == 0
         self._nbt_pending = []
+        self._ysign = {}               # activation pointer -> its sign tensor, for this forward's backward only
         hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
         _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]), B, H, W,
                                               (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), sp))
