@@ -95,7 +95,7 @@ class ResNet50TrainEngine:
         self.fc_w = torch.zeros(self.fc_kpad, self.fc_in, dtype=torch.bfloat16, device=dev)      # [1024][2048]
         self.fc_wd = torch.zeros(self.fc_in, self.fc_kpad, dtype=torch.bfloat16, device=dev)     # [2048][1024]
         self._buf = {}
-        _fl = dict(kv.split('=') for kv in _os.environ.get('RART_TRAIN_FLAGS', '').split(',') if '=' in kv)   # A/B switches for profiling
+        _fl = dict(kv.split('=', 1) for kv in _os.environ.get('RART_TRAIN_FLAGS', '').split(',') if '=' in kv)   # A/B switches for profiling
         # K splits of a weight-gradient launch: ~1 024 workgroups in all (measured at B = 256: 512 -> 58.1, 1 024 -> 55.1-55.8, 2 048 -> 56.3,
         # 4 096 -> 57.5 ms per adv_train step: more splits fill the CUs, every split writes and re-reads an fp32 copy of the weight tensor);
         # up to 1 024 splits of >= 256 positions each (a cap of 256 left layer1's one- and two-tile 1x1 layers at 256-512 workgroups: +0.6 ms)
@@ -114,7 +114,8 @@ class ResNet50TrainEngine:
         torch, sp = self.torch, _lib.stream_ptr()
         convs = [c for blk in self.blocks for c in blk if c is not None]
         key = tuple(c.conv.weight.data_ptr() for c in convs)
-        if all(str(c.conv.weight.dtype) == 'torch.float32' and len(c.all_rs) <= 16 for c in convs):
+        if all(str(c.conv.weight.dtype) == 'torch.float32' and c.conv.weight.is_contiguous() and len(c.all_rs) <= 16 for c in convs):
+            # (k_pack_jobs indexes a master weight as dense [N][C][R][S]: a non-contiguous / channels_last one takes the per-conv path)
             # every table of every convolution as one job of ONE launch (rart_pack_jobs_bf16; ~110 launches of 3-10 us kernels before):
             # the job list is built once -- master weights (views into the optimizer's arena) and tables are persistent
             if getattr(self, '_pack_key', None) != key:

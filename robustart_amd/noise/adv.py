@@ -57,7 +57,7 @@ def attack_init_linf(x0, eps, clip=True, seed=None, sample_offset=0, injected_u=
     B = x0.shape[0]
     nps = x0[0].numel()
     lo, hi = (0.0, 1.0) if clip else (1.0, 0.0)
-    off, rows = _rows(sample_offset)
+    off, rows = _rows(sample_offset, x0)
     _lib.check(_lib.load().rart_attack_init_linf(_lib.ptr(x), _lib.ptr(x0), B, nps, float(eps), lo, hi,
                                                  _seed(seed), off, _lib.ptr(rows), _lib.ptr(injected_u), _lib.stream_ptr()))
     return x
@@ -94,7 +94,7 @@ def random_start_l1(x0, eps, seed=None, sample_offset=0, init_signed_exp=None, i
     if init_signed_exp is not None:
         init_signed_exp = init_signed_exp.to(x0.device, torch.float32).contiguous()
         init_radius = init_radius.to(x0.device, torch.float32).contiguous()
-    off, rows = _rows(sample_offset)
+    off, rows = _rows(sample_offset, x0)
     _lib.check(_lib.load().rart_random_start_l1(_lib.ptr(x), _lib.ptr(x0), B, x0[0].numel(), float(eps), _seed(seed),
                                                 off, _lib.ptr(rows), _lib.ptr(init_signed_exp), _lib.ptr(init_radius),
                                                 _lib.ptr(ws), nb, _lib.stream_ptr()))
@@ -115,7 +115,7 @@ def apgd_init(x0, norm, eps, seed=None, sample_offset=0, injected_t=None):
     x = torch.empty_like(x0)
     B = x0.shape[0]
     ws, nb = _ws(B, x0.device)
-    off, rows = _rows(sample_offset)
+    off, rows = _rows(sample_offset, x0)
     _lib.check(_lib.load().rart_apgd_init(_lib.ptr(x), _lib.ptr(x0), B, x0[0].numel(), {'Linf': 0, 'L2': 1, 'L1': 2}[norm],
                                           float(eps), _seed(seed), off, _lib.ptr(rows), _lib.ptr(injected_t),
                                           _lib.ptr(ws), nb, _lib.stream_ptr()))
@@ -143,14 +143,29 @@ def _seed(seed):
     return _rng.current_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-def _rows(sample_offset):
+def _rows(sample_offset, like=None):
     """sample_offset as the C-ABI takes it: (contiguous offset, per-row index tensor or None).  An int means rows
     sample_offset .. sample_offset + B - 1; an int64 tensor [B] names every row's GLOBAL sample index (the still-robust subsets
-    inside AutoAttack: a sample's draws must not depend on which other samples survived)."""
+    inside AutoAttack: a sample's draws must not depend on which other samples survived).  `like` is the tensor the kernel
+    writes: the index tensor is moved to ITS device (the kernel dereferences it as `const int64_t*`; a host tensor would hand it a
+    host pointer) and must hold one index per row, each in [0, 2^32) -- the counter generator keys a sample by a 32-bit word."""
     torch = _lib.require_gpu()
     if torch.is_tensor(sample_offset):
-        return 0, sample_offset.to(torch.int64).contiguous()
-    return int(sample_offset), None
+        rows = sample_offset.to(dtype=torch.int64)
+        if like is not None:
+            if rows.dim() != 1 or rows.shape[0] != like.shape[0]:
+                raise ValueError('sample_offset tensor must hold one global sample index per row: got shape %s for %d rows'
+                                 % (tuple(rows.shape), like.shape[0]))
+            rows = rows.to(device=like.device)
+        if rows.numel():
+            lo, hi = rows.aminmax()
+            if int(lo) < 0 or int(hi) >= 1 << 32:
+                raise ValueError('sample indices must lie in [0, 2^32): got [%d, %d]' % (int(lo), int(hi)))
+        return 0, rows.contiguous()
+    off = int(sample_offset)
+    if off < 0:
+        raise ValueError('sample_offset must be >= 0, got %d' % off)
+    return off, None
 
 
 def _row_tensor(sample_offset, n, device):
@@ -452,7 +467,7 @@ def _row_count_diff(a, b):
 def _normal_rows(out, seed, sample_offset, stream_id):
     """standard normals [B][...] of the counter generator for a contiguous offset or a per-row index tensor"""
     lib = _lib.load()
-    off, rows = _rows(sample_offset)
+    off, rows = _rows(sample_offset, out)
     if rows is None:
         _lib.check(lib.rart_rng_normal_f32(_lib.ptr(out), out.shape[0], out[0].numel(), seed, off, stream_id, _lib.stream_ptr()))
     else:
@@ -981,6 +996,17 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
         raise NotImplementedError("AutoAttack version 'rand' with norm 'L1': the EOT average is not wired into the L1 APGD loop")
     if norm == 'L1':       # autoattack.py:258-262: larger-eps schedule, 5 restarts, 5 target classes
         n_restarts, apgdt_classes = int(ov.get('apgd_restarts', 5)), int(ov.get('apgdt_classes', 5))
+    fab_prov = None
+    if any(a in ('fab', 'fab-t') for a in plan):
+        # resolve FAB's provider BEFORE any stage runs: a bare bf16 engine is refused here, not after the APGD stages of a long
+        # evaluation have already been paid for, and building the reference-precision engine of the module (a second set of tables
+        # and activation buffers) is announced instead of happening silently inside the fab stage
+        fab_prov = _fab_provider(prov, allow_bf16_fab)
+        if fab_prov is not prov:
+            import logging
+            logging.getLogger('robustart_amd').info(
+                "autoattack_linf: the model runs on a bf16 engine; the fab / fab-t stages use the reference-precision ('fp32x') "
+                "engine folded from the same module (built once, cached on the EngineModel)")
     if skipped:
         warnings.warn('autoattack_linf: %s not implemented on this build yet -- running %s only; robust accuracy '
                       'is an upper bound of the full ensemble' % (skipped, [a for a in plan if a not in skipped]),
@@ -1024,8 +1050,8 @@ def autoattack_linf(input, label, model, norm, eps, version, verbose, seed=None,
                                                  _prov=prov)
             elif attack in ('fab', 'fab-t'):
                 adv_curr = fab_perturb(None, x, y, eps, fab_iter, fab_restarts, norm, attack == 'fab-t', fab_classes, sd, first,
-                                       start_draws=draws.fab_start if draws is not None else None, _prov=prov,
-                                       allow_bf16_fab=allow_bf16_fab)
+                                       start_draws=draws.fab_start if draws is not None else None, _prov=fab_prov,
+                                       allow_bf16_fab=True)         # (already resolved above)
             elif attack == 'square' and norm != 'Linf':
                 adv_curr = square_lp_perturb(None, x, y, norm, eps, square_queries, 0.8, False, sd, first, draws=draws, _prov=prov)
             elif attack == 'square':

@@ -245,10 +245,16 @@ def load_checkpoint_file(path):
                            'TRUSTED legacy checkpoint' % (path, e)) from e
 
 
-def load_pretrain(model, path, prefer='model', strict=True):
+def load_pretrain(model, path, prefer='model', strict=True, ignore_model=()):
     """`saver.pretrain.path` / --recover: load a checkpoint written by this solver or by the reference's
-    (torch.save of {'model': state_dict, 'ema': {...}, ...} or a bare state_dict; DistributedDataParallel's 'module.'
-    prefix stripped).  prefer = 'ema' picks the EMA weights when the file has them."""
+    (torch.save of {'model': state_dict, 'ema': {...}, ...} or a bare state_dict such as timm's
+    jx_vit_base_p16_224-80ecf9dd.pth, exprs/nips_benchmark/new_adv_train/vit_base/config.yaml:78-79; DistributedDataParallel's
+    'module.' prefix stripped).  prefer = 'ema' picks the EMA weights when the file has them.
+    `ignore_model` = `saver.pretrain.ignore.model` (same file :80-87, exp/imagenet_c_loop_mini/config_vit_base.yaml:106-118): keys
+    (with or without 'module.') popped from the checkpoint before loading -- fine-tuning with another number of classes; the
+    model keeps its own initialisation for them and every OTHER key still has to match when strict.
+    A ViT checkpoint in the key layout rounds 1-4 of this repository wrote (`patch_embed.weight`, `blocks.N.fc1.*`) is renamed to
+    timm's layout, which the module tree now carries."""
     ck = load_checkpoint_file(path)
     sd = ck
     if isinstance(ck, dict):
@@ -258,21 +264,44 @@ def load_pretrain(model, path, prefer='model', strict=True):
                 break
     if isinstance(sd, dict) and 'ema_state_dict' in sd:          # reference EMA wrapper
         sd = sd['ema_state_dict']
-    sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
-    missing, unexpected = model.load_state_dict(sd, strict=strict)
-    if missing or unexpected:                       # only reachable with strict=False
+    strip = lambda k: k[7:] if k.startswith('module.') else k    # noqa: E731
+    sd = {strip(k): v for k, v in sd.items()}
+    from ..model.vit_torch import VisionTransformer, legacy_vit_keys
+    if isinstance(model, VisionTransformer):
+        sd = legacy_vit_keys(sd)
+    dropped = []
+    for k in ignore_model or ():
+        k = strip(str(k))
+        if isinstance(model, VisionTransformer):
+            k = next(iter(legacy_vit_keys({k: None})))
+        if k in sd:
+            del sd[k]
+            dropped.append(k)
+        else:
+            raise KeyError('saver.pretrain.ignore.model: %r is not a key of %s' % (k, path))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if k not in dropped]
+    if strict and (missing or unexpected):
+        raise RuntimeError('load_pretrain(%s): missing keys %s, unexpected keys %s' % (path, list(missing), list(unexpected)))
+    if missing or unexpected:
         import warnings
         warnings.warn('load_pretrain(%s): missing keys %s, unexpected keys %s' % (path, list(missing), list(unexpected)),
                       RuntimeWarning)
+    load_pretrain.last_ignored = dropped
     return ck if isinstance(ck, dict) else {}
 
 
-def save_checkpoint(path, model, ema_state=None, optimizer_state=None, step=0, extra=None):
-    """The reference solver's checkpoint shape: {'model', 'ema', 'optimizer', 'last_iter'} (state dicts on the CPU)."""
+def save_checkpoint(path, model, ema_state=None, optimizer_state=None, step=0, extra=None, legacy_vit_keys=False):
+    """The reference solver's checkpoint shape: {'model', 'ema', 'optimizer', 'last_iter'} (state dicts on the CPU).
+    legacy_vit_keys (`saver.legacy_vit_keys: True`): write a ViT's parameters under the names rounds 1-4 of this repository used
+    instead of timm's (for tools that read those files)."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    ck = {'model': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'last_iter': int(step)}
+    ren = (lambda d: d)
+    if legacy_vit_keys:
+        from ..model.vit_torch import timm_to_legacy_keys as ren
+    ck = {'model': ren({k: v.detach().cpu() for k, v in model.state_dict().items()}), 'last_iter': int(step)}
     if ema_state is not None:
-        ck['ema'] = {k: v.detach().cpu() for k, v in ema_state.items()}
+        ck['ema'] = ren({k: v.detach().cpu() for k, v in ema_state.items()})
     if optimizer_state is not None:
         ck['optimizer'] = optimizer_state
     if extra:
@@ -370,7 +399,8 @@ def build_model(cfg, args=None):
     path = getattr(args, 'recover', None) or pre.get('path')
     build_model.last_checkpoint = None
     if path:
-        ck = load_pretrain(model, path, prefer='ema' if pre.get('use_ema', False) else 'model')
+        ck = load_pretrain(model, path, prefer='ema' if pre.get('use_ema', False) else 'model',
+                           ignore_model=((pre.get('ignore') or {}).get('model')) or ())
         # `saver.pretrain.ignore.key: [optimizer, last_iter]` (pgd_adv_train/resnet50/config.yaml:67-70): fine-tuning from a
         # checkpoint instead of resuming it
         drop = set(((pre.get('ignore') or {}).get('key')) or [])
@@ -604,7 +634,8 @@ def train(cfg, args, rank, world, device):
         if save_dir and rank == 0:
             ost = opt.state_dict() if use_hip_opt else {'torch': opt.state_dict()}
             name = 'ckpt_%d.pth.tar' % step if scfg.get('save_many', False) and step != max_iter else 'ckpt.pth.tar'
-            save_checkpoint(os.path.join(save_dir, name), model, ema_state(), ost, step)
+            save_checkpoint(os.path.join(save_dir, name), model, ema_state(), ost, step,
+                            legacy_vit_keys=bool(scfg.get('legacy_vit_keys', False)))
 
     for it in range(start_iter, max_iter):
         lr = cosine_lr(it, max_iter, base_lr, warmup_lr, warmup_steps, min_lr)
@@ -624,7 +655,10 @@ def train(cfg, args, rank, world, device):
                 attack_model.rart_refold(model)
             x01 = A.pgd_linf(x01.contiguous(), labels, attack_model, parse_eps(adv['eps']),
                              float(adv.get('rel_stepsize', 3 / 40)), int(adv.get('steps', 3)), seed=it,
-                             sample_offset=sel[0])
+                             # every row draws its random start at ITS dataset index (sel is a strided slice of the epoch's
+                             # permutation, not a contiguous range): no two images of an iteration share a field, and the
+                             # draws do not depend on the world size
+                             sample_offset=torch.as_tensor([int(i) for i in sel], dtype=torch.int64, device=device))
         model.train()
         if train_engine is not None:
             # train-mode forward (batch statistics), label-smoothed CE, backward to every parameter: all HIP

@@ -265,3 +265,83 @@ def test_missing_checkpoint_file_raises_oserror_not_a_pickle_message(tmp_path):
     from robustart_amd.train import cls_solver as S
     with pytest.raises(OSError):
         S.load_checkpoint_file(str(tmp_path / 'nope.pth.tar'))
+
+
+def _timm_vit_b16_state_dict(num_classes=1000, seed=0):
+    """A state dict with the 152 key names and shapes of timm's jx_vit_base_p16_224-80ecf9dd.pth -- the file the reference's
+    ViT configs point saver.pretrain.path at (exprs/nips_benchmark/new_adv_train/vit_base/config.yaml:78-79).  Names and shapes
+    are written out here, NOT taken from the repository's module, so the test notices if the module drifts from timm's layout."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.02      # noqa: E731
+    sd = {'cls_token': r(1, 1, 768), 'pos_embed': r(1, 197, 768),
+          'patch_embed.proj.weight': r(768, 3, 16, 16), 'patch_embed.proj.bias': r(768)}
+    for i in range(12):
+        b = 'blocks.%d.' % i
+        sd.update({b + 'norm1.weight': r(768), b + 'norm1.bias': r(768),
+                   b + 'attn.qkv.weight': r(2304, 768), b + 'attn.qkv.bias': r(2304),
+                   b + 'attn.proj.weight': r(768, 768), b + 'attn.proj.bias': r(768),
+                   b + 'norm2.weight': r(768), b + 'norm2.bias': r(768),
+                   b + 'mlp.fc1.weight': r(3072, 768), b + 'mlp.fc1.bias': r(3072),
+                   b + 'mlp.fc2.weight': r(768, 3072), b + 'mlp.fc2.bias': r(768)})
+    sd.update({'norm.weight': r(768), 'norm.bias': r(768), 'head.weight': r(num_classes, 768), 'head.bias': r(num_classes)})
+    assert len(sd) == 152
+    return sd
+
+
+def test_vit_loads_a_timm_layout_checkpoint_strictly_and_honours_ignore_model(tmp_path):
+    """`get_model({'type': 'vit_base'})` must take timm's published checkpoint with strict=True, and
+    `saver.pretrain.ignore.model` (vit_base/config.yaml:80-87, config_vit_base.yaml:106-118) pops the listed keys first."""
+    sd = _timm_vit_b16_state_dict()
+    bare = str(tmp_path / 'jx_vit_base_p16_224.pth')
+    torch.save(sd, bare)                                              # timm ships a BARE state dict
+    cfg = {'model': {'type': 'vit_base', 'kwargs': {'num_classes': 1000}}, 'saver': {'pretrain': {'path': bare}}}
+    m = S.build_model(cfg)
+    got = m.state_dict()
+    assert list(got) == list(sd)                                      # same names, same order as timm's module tree
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    x = torch.rand(1, 3, 224, 224)
+    with torch.no_grad():
+        assert torch.isfinite(m(x)).all()
+    # the same file under DistributedDataParallel's prefix inside the solver's checkpoint shape
+    wrapped = str(tmp_path / 'ckpt.pth.tar')
+    torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'last_iter': 7}, wrapped)
+    cfg['saver']['pretrain']['path'] = wrapped
+    m2 = S.build_model(cfg)
+    assert torch.equal(m2.blocks[3].mlp.fc1.weight, sd['blocks.3.mlp.fc1.weight'])
+    # a checkpoint written by rounds 1-4 of this repository (patch_embed.weight, blocks.N.fc1.*) still loads
+    from robustart_amd.model.vit_torch import timm_to_legacy_keys
+    legacy = str(tmp_path / 'legacy.pth')
+    old = timm_to_legacy_keys(sd)
+    assert 'patch_embed.weight' in old and 'blocks.0.fc1.weight' in old and 'blocks.0.mlp.fc1.weight' not in old
+    torch.save({'model': old}, legacy)
+    cfg['saver']['pretrain']['path'] = legacy
+    m3 = S.build_model(cfg)
+    assert torch.equal(m3.patch_embed.proj.weight, sd['patch_embed.proj.weight'])
+    # fine-tuning with another label space: head popped from the checkpoint, everything else strict
+    cfg10 = {'model': {'type': 'vit_base', 'kwargs': {'num_classes': 10}},
+             'saver': {'pretrain': {'path': bare, 'ignore': {'model': ['module.head.weight', 'module.head.bias']}}}}
+    torch.manual_seed(3)
+    m10 = S.build_model(cfg10)
+    assert S.load_pretrain.last_ignored == ['head.weight', 'head.bias']
+    assert m10.head.weight.shape == (10, 768) and torch.equal(m10.norm.weight, sd['norm.weight'])
+    # without the ignore list the 1000-class head does not fit a 10-class model: strict loading refuses
+    cfg10['saver']['pretrain'].pop('ignore')
+    with pytest.raises(RuntimeError):
+        S.build_model(cfg10)
+    # a key that is not in the file is a configuration error, not a silent no-op
+    cfg10['saver']['pretrain']['ignore'] = {'model': ['module.fc.weight']}
+    with pytest.raises(KeyError, match='fc.weight'):
+        S.build_model(cfg10)
+    # a missing key is still refused when strict
+    short = dict(sd)
+    del short['blocks.11.mlp.fc2.bias']
+    p = str(tmp_path / 'short.pth')
+    torch.save(short, p)
+    with pytest.raises(RuntimeError, match='missing keys'):
+        S.load_pretrain(m, p)
+    # save side: timm's names by default, the old names behind the flag
+    out = S.save_checkpoint(str(tmp_path / 'o' / 'a.pth'), m)
+    assert 'patch_embed.proj.weight' in torch.load(out, weights_only=True)['model']
+    out = S.save_checkpoint(str(tmp_path / 'o' / 'b.pth'), m, legacy_vit_keys=True)
+    assert 'patch_embed.weight' in torch.load(out, weights_only=True)['model']
