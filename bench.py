@@ -13,6 +13,12 @@ images per step = 6*B.  Inputs are resident in HBM before the timed region.  Wea
 rank processes its own B images (global sample indices keep the noise field rank-invariant); the
 only collective is the 3-scalar metric all-reduce after the timed region.
 
+The TOP-LEVEL value / ms_per_step / dtype / roofline are those of the tolerance-meeting path: the reference-precision
+engine (`--precision bf16x3`, the default: logits within 1e-4 of the fp32 network, which is what the reference computes,
+noise/utils/adv/attack.py:20-23).  The bf16 engine's figure for the same step follows as `fast_mode` with its stated
+error; BASELINE configs 4 and 5 (ViT-B/16 x ImageNet-C, ResNet-50 adversarial training) follow as `secondary`, three
+steps each; the oracle on the host cores as `cpu_baseline`.
+
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
@@ -43,15 +49,18 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-reference-precision', action='store_true',
-                    help="skip the second block: the same step on the reference-precision ('bf16x3') engine")
+    ap.add_argument('--precision', choices=['bf16x3', 'bf16'], default='bf16x3',
+                    help="engine of the timed step: 'bf16x3' = the reference-precision engine (hi + lo bf16 pairs, three MFMA products per "
+                         "contraction, logits within 1e-4 of the fp32 network; default) or 'bf16' (fast mode, ~3e-3)")
+    ap.add_argument('--no-fast-mode', '--no-reference-precision', dest='no_other_engine', action='store_true',
+                    help='skip the block that repeats the step on the OTHER engine (fast_mode under bf16x3, reference_precision under bf16)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` block (adv_train and vit_inc, three steps each)')
+    ap.add_argument('--secondary-steps', type=int, default=3)
     ap.add_argument('--cpu-sample', type=int, default=64, help='images of the bounded model leg of the CPU baseline')
     ap.add_argument('--cpu-sweep', action='store_true', help='only run the CPU 14 corruptions x 5 severities sweep (BASELINE.md 3b)')
     ap.add_argument('--workload', choices=['headline', 'vit_inc', 'vit_pgd', 'adv_train'], default='headline',
                     help="'headline' = the BASELINE.json metric (default); 'vit_inc' = BASELINE config 4: ViT-B/16 evaluated "
                          "on all 15 ImageNet-C corruptions x 5 severities generated on the GPU (frost on synthetic textures)")
-    ap.add_argument('--model-path', choices=['hip', 'scaffold'], default='hip',
-                    help="'hip' = hand-written engine (product); 'scaffold' = PyTorch-ROCm/MIOpen, for comparison only")
     ap.add_argument('--one-stream', action='store_true', help='run the two halves of a step back to back on one stream (A/B)')
     ap.add_argument('--spawn-check', action='store_true',
                     help='launch-path self test (no GPU work): every rank joins a gloo group, rank 0 prints one JSON line '
@@ -115,60 +124,31 @@ def build_workload(B, device, rank):
 
 
 class HipEngine:
-    """The product path: hand-written bf16 MFMA implicit-GEMM engine (robustart_amd/model/engine.py).
+    """The product path: the hand-written MFMA engine (robustart_amd/model/engine.py), in either precision.
     Two engine instances (own activation buffers, same folded weights) let the step run its two independent halves on two
     HIP streams: the corrupted evaluations (HBM-bound layer1 / layer2 most of the time) overlap the PGD chain's
     MFMA-bound deep layers and fill each other's grid tails."""
-    name = 'hip-igemm-bf16'
     MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
-    def __init__(self, model, device, two_streams=True, precision='bf16'):
+    def __init__(self, model, device, two_streams=True, precision='bf16x3'):
         from robustart_amd.model.engine import ResNet50Engine, EngineModel
         self.precision = precision
-        if precision != 'bf16':
-            self.name = 'hip-igemm-' + precision
+        self.name = 'hip-igemm-' + precision
         self.eng = ResNet50Engine(model, device, precision)
         self.f_model = EngineModel(None, takes_normalized=False, mean=self.MEAN, std=self.STD, engine=self.eng)
         n_side = int(os.environ.get('RART_BENCH_SIDE_STREAMS', '1')) if two_streams else 0
         self.eval_engs = [ResNet50Engine(model, device, precision) for _ in range(n_side)] or [self.eng]
         self.sides = [torch.cuda.Stream(device=device) for _ in range(n_side)]
-        self.side = self.sides[0] if self.sides else None
 
-    def logits_from_u8(self, u8, norm_buf, k=0):
+    def logits_from_u8(self, u8, k=0):
         return self.eval_engs[k % len(self.eval_engs)].logits_from_u8(u8, self.MEAN, self.STD)
 
 
-class Scaffold:
-    """Model path used until the hand-written HIP engine covers ResNet-50: bf16 channels_last
-    ResNet-50 on PyTorch-ROCm (MIOpen/hipBLASLt).  Reported as such in `config.model_path`."""
-    name = 'torch-rocm-bf16-scaffold'
-
-    def __init__(self, model, device):
-        self.m = model.to(device).to(torch.bfloat16).to(memory_format=torch.channels_last)
-        self.mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
-        self.std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
-
-    def logits_from_u8(self, u8, norm_buf):
-        from robustart_amd import _lib
-        B = u8.shape[0]
-        _lib.check(_lib.load().rart_u8_to_normalized(_lib.ptr(u8), _lib.ptr(norm_buf), B, H, W, 1, 1, _lib.stream_ptr()))
-        with torch.no_grad():     # (B,H,W,3) bf16 = channels_last storage of an NCHW view
-            return self.m(norm_buf.permute(0, 3, 1, 2)).float()
-
-    def f_model(self, x01):
-        xn = ((x01 - self.mean) / self.std).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        return self.m(xn)
-
-
-def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
-    from robustart_amd import _lib
+def one_step(images, labels, path, step_idx, rank, B):
     from robustart_amd.noise import imagenet_c as C, adv
-    lib = _lib.load()
-    correct = 0
     base = (step_idx * 1_000_003 + rank * B)          # global sample index of this rank's first image
-    side = getattr(path, 'side', None)
     main = torch.cuda.current_stream()
-    sides = getattr(path, 'sides', None) or [main]
+    sides = path.sides or [main]
     for sd in sides:
         if sd is not main:
             sd.wait_stream(main)                       # the previous step's consumers of the scratch buffers are done
@@ -183,8 +163,7 @@ def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
     for sev in range(1, 6):
         k = (sev - 1) % len(sides)
         with torch.cuda.stream(sides[k]):
-            buf = bufs[sev - 1]
-            logits = path.logits_from_u8(buf, norm_buf, k) if isinstance(path, HipEngine) else path.logits_from_u8(buf, norm_buf)
+            logits = path.logits_from_u8(bufs[sev - 1], k)
             _, _, pred = adv.logit_loss(logits, labels, 0, None, 1.0, want_grad=False)
             parts.append((pred.long() == labels).sum())
     x01 = C.to_unit_nchw(images, one_step.extra.setdefault(('x01', images.shape), torch.empty(B, 3, H, W, device=images.device)))
@@ -196,8 +175,7 @@ def one_step(images, labels, path, scratch_u8, norm_buf, step_idx, rank, B):
     for sd in sides:
         if sd is not main:
             main.wait_stream(sd)                       # join: the step is complete when every stream's part is
-    correct = sum(parts)
-    return correct, correct_adv
+    return sum(parts), correct_adv
 
 
 one_step.extra = {}
@@ -281,11 +259,62 @@ def measure_gaussian_roofline(B, device, launches=40, npairs=9):
     return avg, bracket, copy_s
 
 
+def gaussian_noise_block(B, device):
+    """`hbm_roofline_gaussian_noise`: the corruption half's kernel against the HBM roof.  achieved / frac = the bytes the launch MOVES
+    (source read once + five severity outputs = 6 x 38.5 MB) / its duration / 8 TB/s -- a physical roofline fraction, always < 1.  The
+    throughput figure "five corrupted batches per launch, each worth the 2 x 150 528 B per image of a single-severity pass" is NOT a
+    roofline fraction (the launch avoids 4 of those 10 byte-units) and is reported under `launch_equivalent` with its own names.  The
+    single-severity launch -- what AddNoise.add_noise(batch, severity=s) issues -- follows with the same definition."""
+    avg, bracket, copy_s = measure_gaussian_roofline(B, device)
+    ex = dict(getattr(measure_gaussian_roofline, 'extra', {}) or {})
+    algo = BYTES_PER_IMAGE * B
+    single = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, one severity, B=%d, u8 NHWC in/out)' % B,
+              'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
+              'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': pmc_traffic('k_normal_noise_mfmaI'),
+              'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s '
+                              '(FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run' % getattr(pmc_traffic, 'source', '?'),
+              'avg_launch_us': avg * 1e6, 'per_launch_event_bracket_us': bracket * 1e6,
+              'timing': 'two events on the launch stream around 40 back-to-back launches / 40 (median of 3 passes); '
+                        'per_launch_event_bracket_us = every launch between its own event pair (adds the event records)',
+              'algorithmic_bytes_per_launch': algo,
+              'device_copy_same_bytes': {'avg_launch_us': copy_s * 1e6, 'achieved': algo / copy_s / 1e9, 'unit': 'GB/s',
+                                         'frac_of_peak': algo / copy_s / HBM_PEAK, 'kernel_vs_copy': copy_s / avg,
+                                         'note': 'torch Tensor.copy_ over the same 9 rotating buffer pairs: the read+write '
+                                                 'rate this part sustains at this size'}}
+    # the same kernel on a 4x larger launch (B = 1024 by default, 3 rotating pairs = 925 MB): how much of the B = 256 gap to the peak is
+    # launch ramp / tail of a 18 us kernel rather than the steady-state rate
+    if os.environ.get('RART_BENCH_NO_4X') != '1':        # (the PMC passes set this: their per-kernel averages must hold B = 256 launches only)
+        avg4, _, copy4 = measure_gaussian_roofline(4 * B, device, launches=12, npairs=3)
+        single['at_4x_batch'] = {'batch': 4 * B, 'avg_launch_us': avg4 * 1e6, 'achieved': 4 * algo / avg4 / 1e9,
+                                 'unit': 'GB/s', 'frac': 4 * algo / avg4 / HBM_PEAK,
+                                 'device_copy_frac_of_peak': 4 * algo / copy4 / HBM_PEAK}
+    if 'multi_launch_s' not in ex:
+        return single
+    t5 = ex['multi_launch_s']
+    moved = (1 + 5) * ELEMS * B
+    return {'kernel': 'k_normal_noise_mfma_multi<0> (gaussian_noise, severities 1..5 of B=%d u8 NHWC images in one launch, one field per severity: '
+                      'the launch the bench step issues)' % B,
+            'bound': 'hbm', 'achieved': moved / t5 / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': moved / t5 / HBM_PEAK,
+            'basis': 'bytes the launch moves (the source once + five outputs) / its duration',
+            'avg_launch_us': t5 * 1e6, 'algorithmic_bytes_per_launch': moved, 'bytes_moved_per_launch': moved,
+            'traffic': pmc_traffic('k_normal_noise_mfma_multi'),
+            'launch_equivalent': {'launch_equivalent_us': t5 / 5 * 1e6, 'corrupted_images_per_s': 5 * B / t5,
+                                  'throughput_equivalent_gb_per_s': 5 * algo / t5 / 1e9, 'throughput_equivalent_frac': 5 * algo / t5 / HBM_PEAK,
+                                  'single_severity_bytes_x5': 5 * algo,
+                                  'note': 'NOT a roofline fraction: 5 x the algorithmic bytes of a single-severity pass (2 x 150528 B per image) / '
+                                          'the duration of the five-severity launch, which moves only 6/10 of those bytes -- the speed-up of '
+                                          'reading the source once, for comparison with SURVEY 8(d)\'s per-severity 13.8 us target'},
+            'timing': 'two events on the launch stream around 40 back-to-back launches / 40 (median of 3 passes), %d MB of rotating buffers' % ex['multi_buffers_mb'],
+            'single_severity_launch_one_stream': single,
+            'single_severity_launches_two_streams': {'avg_launch_us': ex['two_streams_s'] * 1e6, 'achieved': algo / ex['two_streams_s'] / 1e9,
+                                                     'unit': 'GB/s', 'frac': algo / ex['two_streams_s'] / HBM_PEAK}}
+
+
 def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r04_pmc_traffic.json, else r03 / r02; produced by profiles/summarize_pmc.py); None if absent."""
+    (profiles/r05_pmc_traffic.json, else r04 / r03 / r02; produced by profiles/summarize_pmc.py); None if absent."""
     try:
-        path = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_pmc_traffic.json' % r) for r in (4, 3, 2)) if os.path.exists(q)), None)
+        path = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_pmc_traffic.json' % r) for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
         pmc_traffic.source = os.path.basename(path)
         with open(path) as f:
             d = json.load(f)
@@ -310,19 +339,28 @@ KERNEL_NAMES = {
     'bottleneck_s2': 'k_bottleneck_s2 (stride-2 first blocks of layer2 / layer3, forward: 1x1 + 3x3/2 + 1x1 + projection in one launch)',
     'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd (the same blocks, backward-to-input in one launch)',
     'fc_small_m': 'k_gemm_small_m (classifier head and its backward: one 32 x 32 tile per workgroup, waves split K)',
-    'gemm_pair': 'k_gemm_pair (split-bf16 GEMM / implicit-GEMM convolution of the reference-precision engines)'}
+    'gemm_pair': 'k_gemm_pair<TM, TN, conv> (split-bf16 implicit-GEMM convolution of the reference-precision engine: four operand planes '
+                 'staged once per K step, three MFMAs per fragment pair)',
+    'conv_tail_pair': 'k_conv3x3_tail_pair<C, NEXT> (reference-precision 3x3 + 1x1 expansion [+ the neighbouring block\'s 1x1 reduction] in one launch)',
+    'conv_tail256_pair': 'k_conv3x3_tail256_pair (reference-precision 3x3 + 1x1 expansion of layer3 / layer4 in one launch)',
+    'stem_pair': 'k_stem_fwd_pair / k_stem_bwd_pair (reference-precision stem: normalise + 7x7/2 + ReLU + max pool, and its backward, one launch each)'}
 PMC_KEYS = {'bottleneck': 'k_bottleneck56', 'bottleneck14': 'k_bottleneck14', 'bottleneck28': 'k_bottleneck28', 'bottleneck7': 'k_bottleneck7',
-            'bottleneck_s2': '15k_bottleneck_s2I', 'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd', 'halo3x3': 'k_conv3x3', 'igemm': 'igemm'}
+            'bottleneck_s2': '15k_bottleneck_s2I', 'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd', 'halo3x3': 'k_conv3x3', 'igemm': 'igemm',
+            'gemm_pair': 'k_gemm_pairI', 'conv_tail_pair': 'k_conv3x3_tail_pairI', 'conv_tail256_pair': 'k_conv3x3_tail256_pair',
+            'stem_pair': 'k_stem_'}
 
 
-def measure_igemm_roofline(path, images, labels):
+def measure_engine_roofline(path, images, labels):
     """`roofline` = the kernel family with the LARGEST share of one PGD gradient evaluation (forward + backward-to-input at B = 256,
-    every launch timed with events on the launch stream).  Since round 2's fusions that is k_bottleneck56 (layer1), not the implicit
-    GEMM.  A fused block is priced against its BINDING roof -- max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s), where the algorithmic
-    bytes are x in + out + weight tables + 1-bit sign tensors, each once (the residual re-read and the halo rows are implementation
-    traffic: they show up in `traffic`, the PMC bytes per launch, and in `overfetch` = traffic / algorithmic bytes) -- with the MFMA
-    fraction beside it.  Every other family follows under `other_mfma_kernels`, the total under `all_conv_launches`."""
+    every launch timed with events on the launch stream) of the engine the step ran on.  A family is priced against its BINDING roof --
+    max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s), where the algorithmic bytes are every operand once (x in + out + weight tables
+    + 1-bit sign tensors; the residual re-read and the halo rows are implementation traffic: they show up in `traffic`, the PMC bytes per
+    launch, and in `overfetch` = traffic / algorithmic bytes) -- with the MFMA fraction beside it.  On the reference-precision engine the
+    FLOPs are the bf16 MFMA FLOPs ISSUED (three per algorithmic product; `achieved_fp32_equivalent` = a third of it) and the bytes are
+    those of the hi + lo pair tensors (4 B per element).  Every other family follows under `other_mfma_kernels`, the total under
+    `all_conv_launches`."""
     eng = path.eng
+    x3 = path.precision != 'bf16'
     x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
     eng.forward_backward(x01, path.MEAN, path.STD, labels, 0)          # warm
     eng.profile = []
@@ -345,6 +383,8 @@ def measure_igemm_roofline(path, images, labels):
     def block(kind, f):
         o = {'achieved': f['flops'] / f['s'] / 1e12, 'unit': 'TFLOP/s', 'frac': f['flops'] / f['s'] / MFMA_BF16_PEAK,
              'avg_launch_us': f['s'] / f['n'] * 1e6, 'launches': f['n'], 'share_of_gradient_evaluation': f['s'] / tot_s}
+        if x3:
+            o['achieved_fp32_equivalent'] = o['achieved'] / 3.0
         if f['has_bytes']:
             floor = max(f['flops'] / MFMA_BF16_PEAK, f['bytes'] / HBM_PEAK)
             o['algorithmic_bytes_per_launch'] = f['bytes'] / f['n']
@@ -359,8 +399,8 @@ def measure_igemm_roofline(path, images, labels):
         return o
     dom = max(fam, key=lambda k: fam[k]['s'])
     d = block(dom, fam[dom])
-    out = {'kernel': '%s, %d launches of one gradient evaluation (ResNet-50 forward + backward-to-input, B=%d)'
-                     % (KERNEL_NAMES.get(dom, dom), fam[dom]['n'], images.shape[0]),
+    out = {'kernel': '%s, %d launches of one gradient evaluation (ResNet-50 forward + backward-to-input, B=%d, engine precision %s)'
+                     % (KERNEL_NAMES.get(dom, dom), fam[dom]['n'], images.shape[0], path.precision),
            'selection': 'the kernel family with the largest share of the gradient evaluation (%.0f %% of the kernel time)' % (100 * fam[dom]['s'] / tot_s),
            'bound': d.get('binding_roof', 'mfma')}
     if d.get('binding_roof') == 'hbm':
@@ -370,12 +410,17 @@ def measure_igemm_roofline(path, images, labels):
         out.update({'achieved': d['achieved'], 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': d['frac']})
         if 'hbm_algorithmic' in d:
             out['hbm_algorithmic'] = d['hbm_algorithmic']
+    if x3:
+        out['achieved_fp32_equivalent'] = d['achieved_fp32_equivalent']
+        out['note'] = ('achieved counts the bf16 MFMA FLOPs actually issued (3 per algorithmic product); the fp32-equivalent rate is a third of it '
+                       '(the fp32 MFMA peak of this part is %.1f TFLOP/s)' % (MFMA_F32_PEAK / 1e12))
     out.update({'traffic': d.get('traffic'), 'overfetch': d.get('overfetch'),
                 'algorithmic_bytes_per_launch': d.get('algorithmic_bytes_per_launch'),
                 'algorithmic_flops_per_launch': fam[dom]['flops'] / fam[dom]['n'],
                 'avg_launch_us': d['avg_launch_us'], 'launches': fam[dom]['n'], 'share_of_gradient_evaluation': d['share_of_gradient_evaluation'],
-                'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s (rocprofv3 FETCH_SIZE x2 (gfx950 correction) + '
-                                'WRITE_SIZE, KiB units), not re-measured in this run' % getattr(pmc_traffic, 'source', '?')})
+                'traffic_note': 'HBM bytes per launch (launch-weighted mean over the family\'s template instances) from the committed PMC pass '
+                                'profiles/%s (rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB units), not re-measured in this run'
+                                % getattr(pmc_traffic, 'source', '?')})
     out['other_mfma_kernels'] = {'%s, %d launches' % (KERNEL_NAMES.get(k, k), f['n']): block(k, f) for k, f in sorted(fam.items()) if k != dom}
     out['all_conv_launches'] = {'achieved': tot_f / tot_s / 1e12, 'unit': 'TFLOP/s', 'frac': tot_f / tot_s / MFMA_BF16_PEAK,
                                 'seconds_per_fwd_bwd': tot_s, 'launches': len(prof)}
@@ -384,45 +429,33 @@ def measure_igemm_roofline(path, images, labels):
 
 MFMA_F32_PEAK = 157.3e12               # v_mfma_f32_32x32x2_f32, the rate fp32 operands would get
 
+ARITHMETIC = {
+    'bf16x3': 'activations / gradients / weights as hi + lo bf16 pairs (16 significand bits), x.w = lo.hi + hi.lo + hi.hi on '
+              'v_mfma_f32_32x32x16_bf16 with fp32 accumulation (rart_gemm_pair_bf16 and the fused pair kernels: the four operand planes of a '
+              'K step staged once in LDS, three MFMAs per fragment pair); logits within 1e-4 of the fp32 network, PGD / AutoAttack outcomes '
+              'identical to the fp32 module (tests/test_engine_x3_gpu.py, tests/test_outcome_gpu.py, profiles/r04_outcome_x3_vs_fp32.json)',
+    'bf16': 'activations / gradients / weights stored as bf16, fp32 MFMA accumulation: logits ~2.6e-3 (median) from the fp32 network, PGD-7 '
+            'per-image outcome agreement 99.5 %, gradient sign agreement 97.4 % (profiles/r04_outcome_bf16_vs_fp32.json) -- narrower than the '
+            'reference\'s fp32 arithmetic and outside the north star\'s 1e-4; offered as a fast mode, never as the headline'}
 
-def measure_reference_precision(model, device, images, labels, scratch, norm_buf, rank, B, steps, two_streams):
-    """The SAME step on the reference-precision engine (precision 'bf16x3': hi + lo bf16 pairs, three MFMA products per
-    contraction, fp32 accumulate -- logits within ~1e-5 of the fp32 network where the bf16 headline is ~3e-3; the
-    reference's arithmetic is fp32, adv/attack.py:20-23).  One warm-up step, `steps` timed steps, then one gradient
-    evaluation timed launch by launch for the roofline block."""
-    path = HipEngine(model, device, two_streams=two_streams, precision='bf16x3')
-    one_step(images, labels, path, scratch, norm_buf, 0, rank, B)
+
+def measure_other_engine(model, device, images, labels, rank, B, steps, two_streams, precision):
+    """The SAME step on the other engine: `fast_mode` (bf16) beside the reference-precision headline, or `reference_precision` when the
+    step was run with --precision bf16.  One warm-up step, `steps` timed steps, then the roofline block of that engine."""
+    path = HipEngine(model, device, two_streams=two_streams, precision=precision)
+    one_step(images, labels, path, 0, rank, B)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        acc = one_step(images, labels, path, scratch, norm_buf, 1 + i, rank, B)
+        acc = one_step(images, labels, path, 1 + i, rank, B)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    eng = path.eng
-    x01 = images.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
-    eng.profile = []
-    eng.forward_backward(x01, path.MEAN, path.STD, labels, 0)
-    torch.cuda.synchronize()
-    prof, eng.profile = eng.profile, None
-    secs = sum(a.elapsed_time(b) for _, a, b, _ in prof) * 1e-3
-    issued = sum(f for f, _, _, _ in prof)               # MFMA FLOPs issued: three bf16 products per algorithmic product
-    algo = issued / 3.0
     step_flops = (5 + 15) * B * FLOP_FWD
-    return {'value': 6 * B * steps / dt, 'unit': 'images/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'dtype': 'bf16x3',
-            'arithmetic': 'activations / gradients / weights as hi + lo bf16 pairs (16 significand bits), x.w = lo.hi + hi.lo + hi.hi '
-                          'on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (rart_gemm_pair_bf16: the four operand planes of a K step staged '
-                          'once in LDS, three MFMAs per fragment pair); logits within 1e-4 of the fp32 network '
-                          '(tests/test_engine_x3_gpu.py, tests/test_outcome_gpu.py)',
-            'model_path': path.name, 'correct_corrupted': int(acc[0]), 'correct_adv': int(acc[1]),
+    return {'value': 6 * B * steps / dt, 'unit': 'images/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'dtype': precision,
+            'arithmetic': ARITHMETIC[precision], 'model_path': path.name, 'correct_corrupted': int(acc[0]), 'correct_adv': int(acc[1]),
             'step_algorithmic': {'achieved': step_flops * steps / dt / 1e12, 'unit': 'TFLOP/s',
-                                 'vs_fp32_mfma_peak': step_flops * steps / dt / MFMA_F32_PEAK,
-                                 'note': 'fp32-equivalent FLOPs of the step / time; 157.3 TFLOP/s is what fp32 MFMA operands peak at'},
-            'roofline': {'kernel': 'k_gemm_pair<TM, TN, conv> (every contraction of the ResNet-50 forward + backward-to-input, B=%d, %d launches)' % (B, len(prof)),
-                         'bound': 'mfma', 'achieved': issued / secs / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                         'frac': issued / secs / MFMA_BF16_PEAK, 'traffic': None,
-                         'achieved_fp32_equivalent': algo / secs / 1e12, 'avg_launch_us': secs / len(prof) * 1e6,
-                         'kernel_seconds_per_fwd_bwd': secs,
-                         'note': 'achieved counts the bf16 MFMA FLOPs actually issued (3 per algorithmic product)'}}
+                                 'note': 'algorithmic FLOPs of the step (20 forward-equivalents) / time'},
+            'roofline': measure_engine_roofline(path, images, labels)}
 
 
 def _cpu_model_name():
@@ -629,7 +662,7 @@ def run_vit_inc(args, device, rank, world, dist):
            'config': {'workload': 'BASELINE config 4 (secondary): 75 corrupted batches of %d per step -> ViT-B/16 eval' % B,
                       'corruptions': len(ids), 'frost_textures': 'synthetic (6 random uint8 photographs, cropped on the device)',
                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'streams': n_q}}
-    if not args.no_reference_precision:
+    if not args.no_other_engine:
         del engs
         torch.cuda.empty_cache()
         engs = [ViTEngine(model, device, precision='fp32x') for _ in range(n_q)]
@@ -643,8 +676,9 @@ def run_vit_inc(args, device, rank, world, dist):
             'step_algorithmic': {'achieved': n_img * rsteps * 35.1e9 / rdt / 1e12, 'unit': 'TFLOP/s',
                                  'vs_fp32_mfma_peak': n_img * rsteps * 35.1e9 / rdt / MFMA_F32_PEAK,
                                  'note': 'fp32-equivalent FLOPs (35.1 GFLOP per ViT-B/16 forward) / time; 157.3 TFLOP/s is what fp32 MFMA operands peak at'}}
-    if rank == 0:
-        print(json.dumps(out))
+    del engs
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_vit_pgd(args, device, rank, world, dist):
@@ -680,16 +714,15 @@ def run_vit_pgd(args, device, rank, world, dist):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        flops = 15 * 35.1e9 * B * world                       # (2k + 1) F, F(ViT-B/16) = 35.1 GFLOP
-        print(json.dumps({'metric': 'attacked images/sec/node (ViT-B/16, PGD-Linf-7 eval)', 'value': B * world * args.steps / dt,
+    flops = 15 * 35.1e9 * B * world                       # (2k + 1) F, F(ViT-B/16) = 35.1 GFLOP
+    return ({'metric': 'attacked images/sec/node (ViT-B/16, PGD-Linf-7 eval)', 'value': B * world * args.steps / dt,
                           'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                           'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
                           'step_mfma': {'achieved': flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
                                         'note': '15 forward-equivalents per image'},
                           'config': {'workload': 'secondary: PGD-Linf-7 eps 2/255 + final forward, ViT-B/16, batch 256 per GPU',
-                                     'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
+                                     'global_batch': B * world, 'parallelism': 'dp%d' % world}})
 
 
 def run_adv_train(args, device, rank, world, dist):
@@ -741,18 +774,44 @@ def run_adv_train(args, device, rank, world, dist):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        flops = (3 * 2 + 3) * FLOP_FWD * B * world          # PGD-3: 3 x (fwd + bwd-to-input); train step: fwd + 2 x bwd
-        print(json.dumps({'metric': 'adversarially trained images/sec/node (ResNet-50, cls_solver step, PGD-3 inner loop)',
+    flops = (3 * 2 + 3) * FLOP_FWD * B * world          # PGD-3: 3 x (fwd + bwd-to-input); train step: fwd + 2 x bwd
+    final_loss = float(loss_rows.mean())
+    del eng, attack, opt, arena, model
+    torch.cuda.empty_cache()
+    return ({'metric': 'adversarially trained images/sec/node (ResNet-50, cls_solver step, PGD-3 inner loop)',
                           'value': B * world * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-                          'final_loss': float(loss_rows.mean()),
+                          'final_loss': final_loss,
                           'step_mfma': {'achieved': flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
                                         'note': '9 forward-equivalents per image (SURVEY.md 8d)'},
                           'config': {'workload': 'BASELINE config 5 (secondary): PGD-Linf-3 eps 4/255 on the eval engine + '
                                                  'train-mode fwd/bwd + SGD-Nesterov/EMA, batch 256 per GPU',
-                                     'global_batch': B * world, 'parallelism': 'dp%d' % world}}))
+                                     'global_batch': B * world, 'parallelism': 'dp%d' % world}})
+
+
+def measure_secondary(args, device, B):
+    """`secondary`: BASELINE configs 4 and 5 timed by the same process right after the headline (one rank, `--secondary-steps` steps each
+    after one warm-up step): ResNet-50 adversarial training (cls_solver step, PGD-3 inner loop, bf16 as config 5 names it) and the ViT-B/16
+    ImageNet-C sweep (15 corruptions x 5 severities generated on the GPU) on the bf16 engine and on the reference-precision engine."""
+    import types
+    a = types.SimpleNamespace(steps=max(1, args.secondary_steps), warmup=1, batch=B, one_stream=args.one_stream, no_other_engine=False)
+    out = {'note': 'one warm-up + %d timed steps each, batch %d, run after the headline inside the same process' % (a.steps, B)}
+    t0 = time.time()
+    r = run_adv_train(a, device, 0, 1, None)
+    out['adv_train'] = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'final_loss', 'step_mfma', 'config')}
+    r = run_vit_inc(a, device, 0, 1, None)
+    out['vit_inc'] = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config')}
+    rp = r['reference_precision']
+    out['vit_inc_reference_precision'] = {k: rp[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'step_algorithmic')}
+    out['seconds'] = time.time() - t0
+    return out
+
+
+def _diag(rank, **kv):
+    """Per-rank launch diagnostics on STDERR (stdout carries the one JSON line): communicator creation, barrier, all-reduce and step
+    times separately, so that the first real N-rank run is cheap to debug (exprs/exp/imagenet_c_loop_mini/eval.sh:21-23 launch shape)."""
+    print('[bench rank %d] %s' % (rank, json.dumps(kv)), file=sys.stderr, flush=True)
 
 
 def main():
@@ -776,15 +835,36 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
+    comm = {}
     if world > 1 or os.environ.get('RART_FORCE_DIST') == '1':     # (forced: a one-rank RCCL group, tests/test_rccl_gpu.py)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        t0 = time.perf_counter()
         dist.init_process_group('nccl', device_id=device)       # "nccl" == RCCL on ROCm
+        comm['init_process_group_s'] = time.perf_counter() - t0
+        # the first collective creates the RCCL communicator (ring / tree setup over xGMI): timed apart from every later one
+        t0 = time.perf_counter()
+        warm = torch.ones(1, device=device)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        comm['first_all_reduce_s'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        dist.barrier()
+        torch.cuda.synchronize()
+        comm['barrier_s'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        comm['all_reduce_s'] = time.perf_counter() - t0
+        _diag(rank, phase='communicator', world=world, local_rank=local, device=torch.cuda.get_device_name(local),
+              ipc_mode_legacy=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), **comm)
     if args.workload in ('vit_inc', 'vit_pgd', 'adv_train'):
-        {'vit_inc': run_vit_inc, 'vit_pgd': run_vit_pgd, 'adv_train': run_adv_train}[args.workload](args, device, rank, world, dist)
+        out = {'vit_inc': run_vit_inc, 'vit_pgd': run_vit_pgd, 'adv_train': run_adv_train}[args.workload](args, device, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -792,31 +872,37 @@ def main():
     images, labels, model = build_workload(B, device, rank)
     import copy
     model_cpu = copy.deepcopy(model) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    path = HipEngine(model, device, two_streams=not args.one_stream) if args.model_path == 'hip' else Scaffold(model, device)
-    scratch = torch.empty_like(images)
-    norm_buf = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=device)
+    path = HipEngine(model, device, two_streams=not args.one_stream, precision=args.precision)
 
     for i in range(args.warmup):
-        one_step(images, labels, path, scratch, norm_buf, i, rank, B)
+        one_step(images, labels, path, i, rank, B)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    tb = time.perf_counter()
     barrier()
     t0 = time.perf_counter()
     acc = None
     for i in range(args.steps):
-        acc = one_step(images, labels, path, scratch, norm_buf, args.warmup + i, rank, B)
+        acc = one_step(images, labels, path, args.warmup + i, rank, B)
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
+        ta = time.perf_counter()
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt_max = float(t.item())
         stats = torch.stack([acc[0], acc[1], torch.tensor(B, device=device), torch.tensor(rank + 1, device=device)]).to(torch.int64)
         dist.all_reduce(stats)                                   # the eval metric exchange + a rank checksum
+        torch.cuda.synchronize()
+        _diag(rank, phase='timed_region', steps=args.steps, opening_barrier_s=t0 - tb, own_steps_s=t_local, with_closing_barrier_s=dt,
+              max_over_ranks_s=dt_max, metric_all_reduce_s=time.perf_counter() - ta, ms_per_step_own=t_local / args.steps * 1e3)
+        dt = dt_max
     imgs_per_step = 6 * B * world
     value = imgs_per_step * args.steps / dt
 
@@ -824,12 +910,12 @@ def main():
         'metric': 'corrupted+attacked images/sec/node (ResNet-50, PGD-7 + IN-C x5)',
         'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': 'per step and GPU: gaussian_noise sev 1..5 on 256 u8 224x224 images -> normalise -> '
                                'ResNet-50 eval (1280 img) + PGD-Linf-7 eps 2/255 ResNet-50 eval (256 img)',
                    'global_batch': B * world, 'images_per_step': imgs_per_step,
                    'model_path': path.name, 'parallelism': 'dp%d' % world,
-                   'streams': 1 + len(getattr(path, 'sides', None) or [])},
+                   'streams': 1 + len(path.sides), 'arithmetic': ARITHMETIC[args.precision]},
     }
     if dist is not None:
         # evidence in the driver's SCALE record that the collective really spanned N ranks: world size as torch.distributed saw
@@ -838,64 +924,27 @@ def main():
         out['rccl_rank_sum'] = int(stats[3].item())
         out['rccl_rank_sum_expected'] = world * (world + 1) // 2
         out['images_per_step_all_ranks'] = int(stats[2].item()) * 6
+        out['rank0_communicator'] = comm
     if rank == 0:
+        step_flops = (5 + 15) * B * world * FLOP_FWD
+        out['step_algorithmic'] = {'achieved': step_flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
+                                   'note': 'whole-step algorithmic FLOPs (20 forward-equivalents per image batch) / step time'
+                                           + ('; against the %.1f TFLOP/s fp32 MFMA peak of the arithmetic the reference uses: %.2f x'
+                                              % (MFMA_F32_PEAK / 1e12, step_flops * args.steps / dt / MFMA_F32_PEAK / world)
+                                              if args.precision != 'bf16' else '')}
         if world == 1:
-            avg, bracket, copy_s = measure_gaussian_roofline(B, device)
-            ex_first = dict(getattr(measure_gaussian_roofline, 'extra', {}) or {})
-            algo = BYTES_PER_IMAGE * B
-            out['roofline'] = {'kernel': 'k_normal_noise_mfma<0> (gaussian_noise, B=256, u8 NHWC in/out)',
-                               'bound': 'hbm', 'achieved': algo / avg / 1e9, 'peak': HBM_PEAK / 1e9,
-                               'unit': 'GB/s', 'frac': algo / avg / HBM_PEAK, 'traffic': pmc_traffic('k_normal_noise_mfmaI'),
-                               'traffic_note': 'HBM bytes per launch from the committed PMC pass profiles/%s '
-                                               '(FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run' % getattr(pmc_traffic, 'source', '?'),
-                               'avg_launch_us': avg * 1e6, 'per_launch_event_bracket_us': bracket * 1e6,
-                               'timing': 'two events on the launch stream around 40 back-to-back launches / 40 (median of 3 passes); '
-                                         'per_launch_event_bracket_us = every launch between its own event pair (adds the event records)',
-                               'algorithmic_bytes_per_launch': algo,
-                               'device_copy_same_bytes': {'avg_launch_us': copy_s * 1e6, 'achieved': algo / copy_s / 1e9, 'unit': 'GB/s',
-                                                          'frac_of_peak': algo / copy_s / HBM_PEAK,
-                                                          'kernel_vs_copy': copy_s / avg,
-                                                          'note': 'torch Tensor.copy_ over the same 9 rotating buffer pairs: the read+write '
-                                                                  'rate this part sustains at this size'}}
-            # the same kernel on a 4x larger launch (B = 1024 by default, 3 rotating pairs = 925 MB): how much of the B = 256 gap to the peak is
-            # launch ramp / tail of a 18 us kernel rather than the steady-state rate
-            if os.environ.get('RART_BENCH_NO_4X') != '1':        # (the PMC passes set this: their per-kernel averages must hold B = 256 launches only)
-                avg4, _, copy4 = measure_gaussian_roofline(4 * B, device, launches=12, npairs=3)
-                out['roofline']['at_4x_batch'] = {'batch': 4 * B, 'avg_launch_us': avg4 * 1e6, 'achieved': 4 * algo / avg4 / 1e9,
-                                                  'unit': 'GB/s', 'frac': 4 * algo / avg4 / HBM_PEAK,
-                                                  'device_copy_frac_of_peak': 4 * algo / copy4 / HBM_PEAK}
-            single = out.pop('roofline')
-            ex = ex_first
-            if 'multi_launch_s' in ex:
-                # headline of this block: the launch the WORKLOAD issues -- five severities of the resident batch in one launch --
-                # per launch-equivalent (1 / 5 of its duration) against the algorithmic 2 x 38.5 MB of one severity; beside it the same
-                # duration against the bytes the launch really moves (6 x 38.5 MB), the single-severity launch (one stream: round 3's
-                # figure) and the single-severity launches alternating over two streams
-                t5 = ex['multi_launch_s']
-                moved = (1 + 5) * ELEMS * B
-                blk = {'kernel': 'k_normal_noise_mfma_multi<0> (gaussian_noise, severities 1..5 of B=%d u8 NHWC images in one launch, one field per severity)' % B,
-                       'bound': 'hbm', 'achieved': 5 * algo / t5 / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': 5 * algo / t5 / HBM_PEAK,
-                       'basis': 'per launch-equivalent: 5 x the algorithmic bytes of one severity (2 x 150528 B per image) / the duration of the '
-                                'five-severity launch; the launch itself moves 6/10 of those bytes (the source is read once)',
-                       'avg_launch_us': t5 * 1e6, 'launch_equivalent_us': t5 / 5 * 1e6, 'algorithmic_bytes_per_launch': 5 * algo,
-                       'bytes_moved_per_launch': moved,
-                       'against_bytes_moved': {'achieved': moved / t5 / 1e9, 'unit': 'GB/s', 'frac': moved / t5 / HBM_PEAK},
-                       'traffic': pmc_traffic('k_normal_noise_mfma_multi'),
-                       'timing': 'two events on the launch stream around 40 back-to-back launches / 40 (median of 3 passes), %d MB of rotating buffers' % ex['multi_buffers_mb'],
-                       'single_severity_launch_one_stream': single,
-                       'single_severity_launches_two_streams': {'avg_launch_us': ex['two_streams_s'] * 1e6, 'achieved': algo / ex['two_streams_s'] / 1e9,
-                                                                'unit': 'GB/s', 'frac': algo / ex['two_streams_s'] / HBM_PEAK}}
-                out['hbm_roofline_gaussian_noise'] = blk
-            else:
-                out['hbm_roofline_gaussian_noise'] = single
-            step_flops = (5 + 15) * B * FLOP_FWD
-            out['step_mfma'] = {'achieved': step_flops * args.steps / dt / 1e12, 'unit': 'TFLOP/s',
-                                'note': 'whole-step algorithmic FLOPs (20 forward-equivalents) / step time'}
-            if isinstance(path, HipEngine):
-                out['roofline'] = measure_igemm_roofline(path, images, labels)
-                if not args.no_reference_precision:
-                    out['reference_precision'] = measure_reference_precision(
-                        model, device, images, labels, scratch, norm_buf, rank, B, max(2, min(args.steps, 5)), not args.one_stream)
+            out['roofline'] = measure_engine_roofline(path, images, labels)
+            out['hbm_roofline_gaussian_noise'] = gaussian_noise_block(B, device)
+            other = 'bf16' if args.precision != 'bf16' else 'bf16x3'
+            if not args.no_other_engine:
+                del path
+                torch.cuda.empty_cache()
+                out['fast_mode' if other == 'bf16' else 'reference_precision'] = measure_other_engine(
+                    model, device, images, labels, rank, B, max(2, min(args.steps, 5)), not args.one_stream, other)
+            if not args.no_secondary:
+                one_step.extra.clear()
+                torch.cuda.empty_cache()
+                out['secondary'] = measure_secondary(args, device, B)
             if model_cpu is not None:
                 out['cpu_baseline'] = cpu_baseline(args.cpu_sample, model_cpu)
         print(json.dumps(out))

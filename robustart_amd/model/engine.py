@@ -558,7 +558,12 @@ class ResNet50Engine:
             e0.record()
             _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
             e1.record()
-            self.profile.append((3 * 2.0 * batch * grid[0] * grid[1] * k_tot * n_cols, e0, e1, 'gemm_pair'))   # MFMA FLOPs issued
+            # MFMA FLOPs issued; algorithmic bytes = every operand once: source pair pixels (4 B per element), destination pair (or fp32),
+            # residual pair, both weight planes, 1 bit per destination element for a mask / sign tensor
+            rows = batch * grid[0] * grid[1]
+            nbytes = 4.0 * batch * src_hw[0] * src_hw[1] * k_per_tap + 4.0 * rows * n_cols * (2 if res is not None else 1) + 4.0 * k_tot * n_cols \
+                + rows * n_cols / 8.0 * ((mask is not None) + (sign_out is not None))
+            self.profile.append((3 * 2.0 * rows * k_tot * n_cols, e0, e1, 'gemm_pair', nbytes))
             return
         _lib.check(self.lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
 
@@ -594,10 +599,28 @@ class ResNet50Engine:
             e0.record()
             _lib.check(self.lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
             e1.record()
-            self.profile.append((3 * 2.0 * batch * hw[0] * hw[1] * (k_tot * c_mid + (8 if nxt is not None else 4) * c_mid * c_mid), e0, e1,
-                                 'conv_tail_pair'))   # MFMA FLOPs issued
+            px = batch * hw[0] * hw[1]
+            nbytes = 4.0 * px * c_mid * (1 + 4 + (4 if res is not None else 0) + (1 if nxt is not None else 0)) \
+                + 4.0 * c_mid * c_mid * (9 + 4 + (4 if nxt is not None else 0))
+            self.profile.append((3 * 2.0 * px * (k_tot * c_mid + (8 if nxt is not None else 4) * c_mid * c_mid), e0, e1,
+                                 'conv_tail_pair', nbytes))   # MFMA FLOPs issued, algorithmic bytes (every operand once)
             return
         _lib.check(self.lib.rart_conv3x3_tail_pair(ctypes.byref(d), _lib.stream_ptr()))
+
+    def _prof_begin(self):
+        if self.profile is None:
+            return None
+        torch = _lib.require_gpu()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def _prof_end(self, e0, flops, kind, nbytes=None):
+        if e0 is None:
+            return
+        e1 = _lib.require_gpu().cuda.Event(enable_timing=True)
+        e1.record()
+        self.profile.append((flops, e0, e1, kind, nbytes))
 
     def _fc(self, a, w, out, m, n, k, bias=None):
         """The classifier head / its backward: rart_gemm_small_m_bf16 (one workgroup per 32 x 32 tile, waves split K) instead of the
@@ -926,9 +949,12 @@ class ResNet50Engine:
         xs = self._get('p1_sign', (B, h2, w2, 8), torch.uint8) if keep else None
         if self.fused_stem_fwd:
             # stem: normalise + split + 7x7/2 conv + bias + ReLU + max pool on pairs, one persistent kernel (stem_pair.hip)
+            ev = self._prof_begin()
             _lib.check(lib.rart_engine_stem_fwd_fused_pair(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(self.stem_w_pair[0]),
                                                            _lib.ptr(self.stem_w_pair[1]), _lib.ptr(self.stem.bias), _lib.ptr(p1[0]),
                                                            _lib.ptr(p1[1]), _lib.ptr(parg), _lib.ptr(xs), B, H, W, meanf, stdf, sp))
+            # issued: 3 products x (7 row taps x 32 = 224-deep K) x 64 channels per stem output; bytes: the image once + the pooled pair
+            self._prof_end(ev, 3 * 2.0 * B * h1 * w1 * 224 * 64, 'stem_pair', B * H * W * 3 * (1 if src_is_u8 else 4) + 4.0 * B * h2 * w2 * 64)
         else:
             hi = self._get('in_hi', (2, B, H + 8, W + 8, 4))
             _lib.check(lib.rart_engine_prep_input(_lib.ptr(src), 1 if src_is_u8 else 0, _lib.ptr(hi[0]), _lib.ptr(hi[1]),
@@ -1036,9 +1062,13 @@ class ResNet50Engine:
         stdf = (ctypes.c_float * 3)(*std)
         if self.fused_stem_bwd:
             # stem: max-pool backward + ReLU mask + transposed 7x7/2 conv to the fp32 image on pairs, one kernel (stem_pair.hip)
+            ev = self._prof_begin()
             _lib.check(lib.rart_engine_stem_bwd_fused_pair(_lib.ptr(dz[0]), _lib.ptr(dz[1]), _lib.ptr(acts['p1_argmax']),
                                                            _lib.ptr(self.stem_wt_pair[0]), _lib.ptr(self.stem_wt_pair[1]),
                                                            _lib.ptr(grad), B, H, W, stdf, sp))
+            # issued: M = stem-output positions, K = 16 taps x 64 channels, N = 16 (4 pixel parities x 3 colours, padded); bytes: pooled
+            # gradient pair + argmax codes + the fp32 image gradient
+            self._prof_end(ev, 3 * 2.0 * B * (H // 2) * (W // 2) * 16 * 64 * 16, 'stem_pair', 4.0 * B * (H // 4) * (W // 4) * 64 * 1.25 + 4.0 * B * H * W * 3)
             return grad
         h1, w1 = H // 2, W // 2
         dz1 = self._get('x3_g_y1', (2, B, h1, w1, 64))

@@ -18,6 +18,7 @@ The arithmetic is torch.optim.SGD / AdamW (exprs/nips_benchmark/pgd_adv_train/re
 new_adv_train/vit_base/config.yaml:11-38); the kernels are pinned to it through oracle/train_ref.py.
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -102,14 +103,43 @@ class ParamArena:
         this step (unused branches) are reduced here so every rank issues the same collectives.  Returns the
         factor the optimizer must fold into the gradients (1 / world_size)."""
         if self.exchange:
+            late = 0
             for b, (lo, hi, cnt) in enumerate(self.buckets):
                 if self._pending[b] != cnt:
                     self._handles.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                    late += 1
+            ev = None
+            if self.flat_g.is_cuda:
+                # Work.wait() of an RCCL collective makes the compute stream wait for the communication stream without blocking the
+                # host: the stall the exchange really costs is the time between these two events on the compute stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            t0 = time.perf_counter()
             for h in self._handles:
                 h.wait()
+            host_wait = time.perf_counter() - t0
+            if ev is not None:
+                ev[1].record()
+            self._last_exchange = dict(buckets=len(self.buckets), launched_during_backward=len(self.buckets) - late, launched_after_backward=late,
+                                       bytes=4 * int(self.flat_g.numel()), bucket_bytes=[4 * (hi - lo) for lo, hi, _ in self.buckets],
+                                       host_wait_s=host_wait, world=self.world, _events=ev)
             self._handles = []
             self._pending = [0] * len(self.buckets)
         return 1.0 / self.world
+
+    def exchange_stats(self):
+        """What the last finish_grad_exchange() did -- bucket count and bytes, how many buckets started during backward (overlapped) and how
+        many after it, the host-side wait and the stall of the compute stream behind the collectives (synchronises on the closing event:
+        call it at logging frequency, not every step).  None when there is no exchange."""
+        st = getattr(self, '_last_exchange', None)
+        if st is None:
+            return None
+        st = dict(st)
+        ev = st.pop('_events')
+        if ev is not None:
+            ev[1].synchronize()
+            st['stream_wait_s'] = ev[0].elapsed_time(ev[1]) * 1e-3
+        return st
 
     def repoint_grads(self):
         """autograd replaces `.grad` when it was None; keep the arena views (call after zero_grad(set_to_none=True))."""

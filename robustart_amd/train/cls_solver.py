@@ -23,6 +23,7 @@ import argparse
 import json
 import math
 import os
+import sys
 import time
 
 import torch
@@ -699,8 +700,17 @@ def train(cfg, args, rank, world, device):
                     if k in ema_buffers:
                         ema_buffers[k].mul_(decay).add_(v.detach(), alpha=1 - decay)
         loss_v = float(loss.detach())
-        if rank == 0 and (it % int(scfg.get('print_freq', 10)) == 0 or it == max_iter - 1):
-            print(json.dumps({'iter': it, 'loss': loss_v, 'lr': lr}))
+        if it % int(scfg.get('print_freq', 10)) == 0 or it == max_iter - 1:
+            xs = arena.exchange_stats()
+            if xs is not None:
+                # every rank, on stderr: the gradient exchange of this step -- buckets, bytes, how many all-reduces started during backward,
+                # and how long the compute stream stalled behind them (a first N-rank run is debugged from these lines)
+                print('[cls_solver rank %d] %s' % (rank, json.dumps(dict(iter=it, grad_exchange=xs))), file=sys.stderr, flush=True)
+            if rank == 0:
+                rec = {'iter': it, 'loss': loss_v, 'lr': lr}
+                if xs is not None:
+                    rec['grad_exchange'] = {k: xs[k] for k in ('buckets', 'bytes', 'launched_during_backward', 'stream_wait_s', 'host_wait_s') if k in xs}
+                print(json.dumps(rec))
         if save_freq and (it + 1) % save_freq == 0 and it + 1 < max_iter:
             save(it + 1)                                     # an interrupted run resumes from here with --recover
     # checkpoint (rank 0): model, EMA (parameters from the optimizer's arena + the EMA'd buffers), optimizer, last iteration

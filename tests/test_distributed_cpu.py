@@ -72,6 +72,7 @@ def _run(world):
         assert p.returncode == 0, e[-2000:]
         line = [ln for ln in o.splitlines() if ln.startswith('RESULT ')][-1]
         outs.append(json.loads(line[7:]))
+        outs[-1]['grad_exchange_log'] = [json.loads(ln.split('] ', 1)[1]) for ln in e.splitlines() if ln.startswith('[cls_solver rank ')]
     return outs
 
 
@@ -90,6 +91,14 @@ def test_world2_matches_world1_and_syncs_gradients():
     # the training exchange: after 3 steps all ranks hold identical parameters
     assert all(o['params_identical_across_ranks'] for o in two)
     assert all(o['loss'] == o['loss'] for o in two)          # finite
+    # every rank logs its gradient exchange (stderr): 4 buckets (bucket_mb 0 = one per parameter) of 4 x (108 + 4 + 4000 + 1000) bytes, all
+    # started by the backward hooks; the one-process run has nothing to exchange and logs nothing
+    assert one['grad_exchange_log'] == []
+    for o in two:
+        assert [q['iter'] for q in o['grad_exchange_log']] == [0, 2]
+        gx = o['grad_exchange_log'][-1]['grad_exchange']
+        assert gx['world'] == 2 and gx['buckets'] == 4 and gx['bytes'] == 4 * (108 + 4 + 4000 + 1000)
+        assert gx['launched_during_backward'] == 4 and gx['launched_after_backward'] == 0 and gx['host_wait_s'] >= 0
 
 
 def test_shard_indices_cover_ragged_and_empty():

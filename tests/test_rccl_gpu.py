@@ -33,14 +33,27 @@ def _torchrun(args, timeout=900):
 
 def test_bench_headline_under_a_one_rank_rccl_group():
     r = _torchrun([os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline',
-                   '--no-reference-precision'])
+                   '--no-fast-mode', '--no-secondary'])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     # the process group existed and the all-reduce over it returned what one rank contributes
     assert d['world_size_seen'] == 1 and d['rccl_rank_sum'] == 1 == d['rccl_rank_sum_expected']
-    assert d['images_per_step_all_ranks'] == 6 * 64 and d['n_gpus'] == 1 and d['value'] > 0
+    assert d['images_per_step_all_ranks'] == 6 * 64 and d['n_gpus'] == 1 and d['value'] > 0 and d['dtype'] == 'bf16x3'
+    # per-rank diagnostics on stderr -- communicator creation, barrier and all-reduce apart from the step time
+    diag = {}
+    for ln in r.stderr.splitlines():
+        if ln.startswith('[bench rank 0] '):
+            q = json.loads(ln[len('[bench rank 0] '):])
+            diag[q['phase']] = q
+    c, t = diag['communicator'], diag['timed_region']
+    for k in ('init_process_group_s', 'first_all_reduce_s', 'barrier_s', 'all_reduce_s'):
+        assert c[k] >= 0 and d['rank0_communicator'][k] == c[k], k
+    assert c['world'] == 1 and c['ipc_mode_legacy'] == '0'
+    for k in ('opening_barrier_s', 'own_steps_s', 'with_closing_barrier_s', 'max_over_ranks_s', 'metric_all_reduce_s'):
+        assert t[k] >= 0, k
+    assert t['own_steps_s'] <= t['with_closing_barrier_s'] <= t['max_over_ranks_s'] + 1e-9
 
 
 def test_cls_solver_adv_train_steps_under_a_one_rank_rccl_group(tmp_path):
@@ -62,6 +75,12 @@ saver: {print_freq: 1}
     assert r.returncode == 0, r.stderr[-3000:]
     recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith('{"iter"')]
     assert [q['iter'] for q in recs] == [0, 1] and all(q['loss'] == q['loss'] and q['loss'] > 0 for q in recs)
+    # bucket count / bytes / wait time of the gradient exchange, per step, in the record and per rank on stderr
+    for q in recs:
+        gx = q['grad_exchange']
+        assert gx['buckets'] >= 2 and gx['bytes'] == 4 * 25557032 and 0 <= gx['launched_during_backward'] <= gx['buckets']
+        assert gx['stream_wait_s'] >= 0 and gx['host_wait_s'] >= 0
+    assert sum(1 for ln in r.stderr.splitlines() if ln.startswith('[cls_solver rank 0] ')) == 2
     r = _torchrun(['-m', 'robustart_amd.train.cls_solver', '--config', str(cfg), '--evaluate'])
     assert r.returncode == 0, r.stderr[-3000:]
     res = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
