@@ -277,6 +277,178 @@ size_t filter2d_lds(int ksz) {
   return (256 + (size_t)ksz * ksz + (size_t)(F2_TH + 2 * r) * (F2_TW + 2 * r) * 3) * sizeof(double);
 }
 
+// ---- defocus_blur on the matrix cores (round 5) --------------------------------------------------------------------
+// k_filter2d above is bound by the fp64 vector rate (289 taps x 3 channels x (mul + add) per pixel: 2.2 ms per 256-image batch).  The filter's
+// REAL value needs no fp64: the inputs are 8-bit integers and the 17 x 17 weights are fp32 values, so with W = round(w 2^F) (32-bit
+// fixed point, exact for severities 2-4 whose weights span 31 bits) T = sum W p is an exact integer and the reference's result is
+// floor(T / 2^F) -- unless T / 2^F lies within `band` (the fixed-point error bound + 1e-9 for the reference's own fp64 rounding) of
+// an integer, where the ORDER of the reference's fp64 additions decides (flat regions: every tap of a saturated neighbourhood lands on
+// p (1 +- 1e-16)).  So:
+//   * fast path, every pixel: T on v_mfma_i32_16x16x64_i8.  W is split into four signed base-256 digits, the pixels go in as q = p - 128
+//     (a constant 128 sum W is added back).  One MFMA = 16 output columns (M) x 16 output rows (N) x two kernel rows of a 32-pixel window
+//     (K = 2 x 32): the A operand is the banded (Toeplitz) weight matrix of a row pair and a digit -- 9 pairs x 4 digits = 36 fragments,
+//     resident in 144 VGPRs for the whole workgroup -- the B operand one ds_read_b128 per lane from the channel-planar tile in LDS,
+//     reused by the four digit MFMAs.  Only the CONSISTENCY of the (lane >> 4, byte) -> k mapping between A and B is relied upon.
+//   * flagged 16 x 16 tiles (any output within `band` of an integer, T != 0): recomputed by the whole workgroup in fp64, tap by tap in
+//     the reference's order from the same LDS tile -- bit-identical to k_filter2d.  Random images flag nothing; flat regions pay the old rate.
+// Output identical to k_filter2d's on every input (tests/test_corruptions_gpu.py::test_defocus_fast_path_equals_the_ordered_fp64_kernel).
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+constexpr int FI_TH = 32, FI_RH = FI_TH + 17, FI_RS = 240, FI_STEPS = 9, FI_XT = 14;     // 224 = 7 strips x 32 rows = 14 column tiles x 16
+constexpr int FI_PLANES = 3 * FI_RH * FI_RS;                      // 35 280 B: q = p - 128, [channel][row][x + 8]
+constexpr int FI_OUT = FI_TH * 224 * 3;                           // 21 504 B: the strip's output, NHWC
+constexpr int FI_TILES = 3 * 2 * FI_XT;                           // 84 tile-channels per strip
+constexpr size_t FI_LDS = FI_PLANES + FI_OUT + 256 * sizeof(double) + (FI_TILES + 4) * sizeof(int);
+struct FilterI8Meta {
+  int F;
+  long long corr, band;
+};
+
+__global__ __launch_bounds__(kBlock, 2) void k_filter2d_i8(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           const uint4* __restrict__ frags, const double* __restrict__ kern,
+                                                           FilterI8Meta meta) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fi_lds[];
+  uint8_t* const sP = fi_lds;
+  uint8_t* const sO = fi_lds + FI_PLANES;
+  double* const lut = reinterpret_cast<double*>(fi_lds + FI_PLANES + FI_OUT);
+  int* const sList = reinterpret_cast<int*>(lut + 256);           // [0] = count, [1 ..] = flagged tile-channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int y0 = blockIdx.x * FI_TH;
+  const size_t img = blockIdx.y;
+  // the 36 weight fragments of this lane (same for every tile): requested first, consumed after the staging
+  i32x4 A[FI_STEPS][4];
+#pragma unroll
+  for (int j = 0; j < FI_STEPS; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A[j][k] = __builtin_bit_cast(i32x4, frags[(j * 4 + k) * 64 + lane]);
+  lut[tid] = (double)tid / 255.0;
+  if (tid == 0) sList[0] = 0;
+  // ---- stage rows y0 - 8 .. y0 + 40 (reflect-101) as three byte planes
+  const uint8_t* base = in + img * (size_t)(224 * 224 * 3);
+  for (int i = tid; i < FI_RH * 42; i += kBlock) {
+    const int ry = i / 42, cx = i - ry * 42;
+    const int yy = reflect101(y0 - 8 + ry, 224);
+    const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)yy * 672 + cx * 16);
+    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+    int e = cx * 16, px = e / 3, c = e - px * 3;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      sP[(c * FI_RH + ry) * FI_RS + px + 8] = (uint8_t)(((wv[b >> 2] >> (8 * (b & 3))) & 0xFFu) ^ 0x80u);
+      if (++c == 3) { c = 0; ++px; }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * FI_RH * 16; i += kBlock) {               // x halos: x = -8 .. -1 <- p[-x], x = 224 .. 231 <- p[446 - x]
+    const int row = i >> 4, k = i & 15;
+    uint8_t* r = sP + row * FI_RS;
+    if (k < 8) r[k] = r[8 + (8 - k)];
+    else r[8 + 224 + (k - 8)] = r[8 + 222 - (k - 8)];
+  }
+  __syncthreads();
+  // ---- fast path: tile-channel tc = (channel, row block, column tile); lane = (n = output row of the block, g = K group)
+  const int n = lane & 15, g = lane >> 4;
+  const long long one = 1ll << meta.F;
+  for (int tc = wave; tc < FI_TILES; tc += 4) {
+    const int c = tc % 3, rest = tc / 3, blk = rest / FI_XT, xt = rest - blk * FI_XT;
+    const uint8_t* pb = sP + (c * FI_RH + blk * 16 + n + (g >> 1)) * FI_RS + xt * 16 + 16 * (g & 1);
+    i32x4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = (i32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < FI_STEPS; ++j) {
+      const i32x4 B = *reinterpret_cast<const i32x4*>(pb + 2 * j * FI_RS);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[j][k], B, acc[k], 0, 0, 0);
+    }
+    bool flag = false;
+    uint8_t* o = sO + ((blk * 16 + n) * 224 + xt * 16 + 4 * g) * 3 + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long T = (long long)acc[0][r] + (long long)acc[1][r] * 256ll + (long long)acc[2][r] * 65536ll +
+                          (long long)acc[3][r] * 16777216ll + meta.corr;
+      const long long fl = T >> meta.F, fr = T - (fl << meta.F);
+      flag |= T != 0 && (fr < meta.band || fr > one - meta.band);
+      o[3 * r] = (uint8_t)(T <= 0 ? 0 : (fl > 255 ? 255 : fl));
+    }
+    if (__ballot(flag) != 0ull && lane == 0) sList[1 + atomicAdd(&sList[0], 1)] = tc;
+  }
+  __syncthreads();
+  // ---- flagged tiles: the reference's fp64 sum, row-major tap order, multiply then add (k_filter2d's arithmetic), one output per thread
+  const int nflag = sList[0];
+  for (int i = 0; i < nflag; ++i) {
+    const int tc = sList[1 + i];
+    const int c = tc % 3, rest = tc / 3, blk = rest / FI_XT, xt = rest - blk * FI_XT;
+    const int ty = tid >> 4, tx = tid & 15;
+    const uint8_t* pb = sP + (c * FI_RH + blk * 16 + ty) * FI_RS + xt * 16 + tx;
+    double acc = 0.0;
+    for (int a = 0; a < 17; ++a) {
+      const uint8_t* row = pb + a * FI_RS;
+      const double* kr = kern + a * 17;
+#pragma unroll
+      for (int b = 0; b < 17; ++b) {
+        const double t = lut[row[b] ^ 0x80u] * kr[b];
+        acc += t;
+      }
+    }
+    const double cl = acc < 0.0 ? 0.0 : (acc > 1.0 ? 1.0 : acc);
+    sO[((blk * 16 + ty) * 224 + xt * 16 + tx) * 3 + c] = (uint8_t)(uint32_t)(cl * 255.0);
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(out + img * (size_t)(224 * 224 * 3) + (size_t)y0 * 672);
+  const uint4* so4 = reinterpret_cast<const uint4*>(sO);
+  for (int i = tid; i < FI_OUT / 16; i += kBlock) dst[i] = so4[i];
+}
+
+// Host side of the fast path: the fixed-point weights, their four signed base-256 digits as MFMA A-operand fragments
+// (fragment (pair j, digit k), lane (m = lane & 15, g = lane >> 4), byte i: kernel row 2 j + (g >> 1), window column 16 (g & 1) + i ->
+// tap b = column - m), the constant 128 sum W and the ambiguity band.
+struct FilterI8Host {
+  std::vector<uint8_t> frags;        // [FI_STEPS][4][64][16]
+  FilterI8Meta meta;
+  bool ok = false;
+};
+FilterI8Host make_filter_i8(const std::vector<double>& kern, int ksz) {
+  FilterI8Host h;
+  if (ksz != 17) return h;
+  double wmax = 0.0;
+  for (double v : kern) {
+    if (v < 0.0) return h;                       // the digit split below assumes non-negative weights (every disk is)
+    wmax = v > wmax ? v : wmax;
+  }
+  if (!(wmax > 0.0)) return h;
+  int ex;
+  frexp(wmax, &ex);                              // wmax = f 2^ex, f in [0.5, 1)
+  const int F = 30 - ex;                         // W <= 2^30
+  if (F < 8 || F > 46) return h;
+  std::vector<long long> W(kern.size());
+  long long sumW = 0;
+  double dq = 0.0;
+  for (size_t i = 0; i < kern.size(); ++i) {
+    W[i] = llrint(ldexp(kern[i], F));
+    sumW += W[i];
+    dq += fabs(ldexp((double)W[i], -F) - kern[i]);
+  }
+  h.frags.assign((size_t)FI_STEPS * 4 * 64 * 16, 0);
+  for (int j = 0; j < FI_STEPS; ++j)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = lane & 15, g = lane >> 4, a = 2 * j + (g >> 1);
+      for (int i = 0; i < 16; ++i) {
+        const int b = 16 * (g & 1) + i - m;
+        long long w = (a < 17 && b >= 0 && b < 17) ? W[(size_t)a * 17 + b] : 0;
+        for (int k = 0; k < 4; ++k) {
+          const long long lo = ((w + 128) & 255) - 128;     // signed digit in [-128, 127]
+          h.frags[(((size_t)(j * 4 + k) * 64 + lane) * 16) + i] = (uint8_t)(int8_t)lo;
+          w = (w - lo) / 256;
+        }
+        if (w != 0) return h;                                // does not fit four digits
+      }
+    }
+  h.meta.F = F;
+  h.meta.corr = 128 * sumW;
+  h.meta.band = (long long)ceil(ldexp(255.0 * dq + 1e-9, F)) + 1;
+  h.ok = true;
+  return h;
+}
+
 // ---- motion_blur (ImageMagick) -----------------------------------------------------------------
 struct MotionTab {
   int offx[41], offy[41];
@@ -465,7 +637,7 @@ size_t rart_ws_stencil(int id, int /*severity*/, int n, int h, int w) {
   switch (id) {
     case RART_GAUSSIAN_BLUR: return tmp;
     case RART_GLASS_BLUR: return tmp + rart_align_up((size_t)n * h * w * 3, 256);
-    case RART_DEFOCUS_BLUR: return rart_align_up(21 * 21 * sizeof(double), 256);
+    case RART_DEFOCUS_BLUR: return rart_align_up(21 * 21 * sizeof(double), 4096) + rart_align_up((size_t)FI_STEPS * 4 * 64 * 16, 256);
     case RART_MOTION_BLUR: return rart_motion_tab_bytes(n);
   }
   return 0;
@@ -505,6 +677,24 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
         return RART_ERR_HIP;
       }
       RART_CHECK_ARG(a.n <= 65535, "defocus_blur: at most 65535 images per call");
+      {
+        // the matrix-core path (17 x 17 disks = severities 1-4, 224 x 224 images, 16-byte aligned batches); everything else: k_filter2d
+        static FilterI8Host fast[5];
+        static bool fast_made[5] = {false, false, false, false, false};
+        if (!fast_made[s]) { fast[s] = make_filter_i8(disks[s], ksz[s]); fast_made[s] = true; }
+        const bool use_fast = fast[s].ok && a.h == 224 && a.w == 224 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.out & 15) == 0 &&
+                              getenv("RART_DEFOCUS_FP64") == nullptr;
+        if (use_fast && rart_raise_dynamic_lds((const void*)k_filter2d_i8, FI_LDS, "defocus_blur (matrix-core path)")) {
+          uint8_t* ftab = (uint8_t*)a.workspace + rart_align_up(21 * 21 * sizeof(double), 4096);
+          if (hipMemcpyAsync(ftab, fast[s].frags.data(), fast[s].frags.size(), hipMemcpyHostToDevice, a.stream) != hipSuccess) {
+            rart_set_error("defocus_blur: fragment table upload failed");
+            return RART_ERR_HIP;
+          }
+          hipLaunchKernelGGL(k_filter2d_i8, dim3(224 / FI_TH, a.n), dim3(kBlock), FI_LDS, a.stream, a.in, a.out, (const uint4*)ftab,
+                             (const double*)a.workspace, fast[s].meta);
+          break;
+        }
+      }
       const size_t lds = filter2d_lds(ksz[s]);
       if (!rart_raise_dynamic_lds((const void*)k_filter2d<17>, filter2d_lds(21), "defocus_blur") ||
           !rart_raise_dynamic_lds((const void*)k_filter2d<21>, filter2d_lds(21), "defocus_blur"))

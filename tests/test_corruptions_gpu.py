@@ -115,6 +115,39 @@ def test_hip_matches_reference_golden_crops_pinned_modulo_shim(name, sev):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize('sev', [1, 2, 3, 4, 5])
+def test_defocus_fast_path_equals_the_ordered_fp64_kernel(sev):
+    """Round 5: defocus_blur's 17 x 17 disks run as an exact fixed-point filter on the i8 matrix cores; outputs whose real value lies
+    within the stated band of an integer (flat / saturated regions: the ORDER of the reference's fp64 additions decides them) are
+    recomputed tap by tap in fp64.  The result must equal the ordered fp64 kernel (RART_DEFOCUS_FP64=1: round 2-4's k_filter2d, itself
+    bit-identical to the oracle's arithmetic) on EVERY input -- random texture, saturated and black regions, ramps, constant images --
+    and the oracle within the stated tolerance (here: exactly, the oracle sums in the same order)."""
+    import os
+    rs = np.random.RandomState(100 + sev)
+    imgs = [rs.randint(0, 256, (224, 224, 3)).astype(np.uint8)]
+    flat = np.full((224, 224, 3), 255, np.uint8)
+    flat[40:120, 30:170] = rs.randint(0, 256, (80, 140, 3))
+    flat[150:] = 0
+    flat[:24] = 77
+    flat[:, 200:] = (3, 200, 128)
+    imgs.append(flat)
+    yy, xx = np.mgrid[0:224, 0:224]
+    imgs.append(np.stack([(yy + xx) // 2, np.clip(xx, 0, 255), np.clip(255 - yy, 0, 255)], -1).astype(np.uint8))
+    imgs += [np.full((224, 224, 3), v, np.uint8) for v in (0, 1, 127, 254, 255)]
+    lowc = rs.randint(120, 124, (224, 224, 3)).astype(np.uint8)             # low contrast: many near-integer sums
+    imgs.append(lowc)
+    batch = np.stack(imgs)
+    fast = _run('defocus_blur', batch, sev)
+    os.environ['RART_DEFOCUS_FP64'] = '1'
+    try:
+        slow = _run('defocus_blur', batch, sev)
+    finally:
+        del os.environ['RART_DEFOCUS_FP64']
+    np.testing.assert_array_equal(fast, slow)
+    want = np.stack([np.asarray(O.corrupt('defocus_blur', im, sev)).astype(np.uint8) for im in imgs[:3]])
+    np.testing.assert_array_equal(fast[:3], want)
+
+
 @pytest.mark.parametrize('name', [n for n in NAMES if n != 'frost'])
 def test_native_mode_deterministic_and_shard_invariant(name):
     sev = 4
