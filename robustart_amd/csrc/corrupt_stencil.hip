@@ -449,6 +449,215 @@ FilterI8Host make_filter_i8(const std::vector<double>& kern, int ksz) {
   return h;
 }
 
+// ---- gaussian_blur / glass_blur's two blurs on the matrix cores (round 5) ------------------------------------------------
+// The same idea as k_filter2d_i8, for the SEPARABLE filter: W_a = round(w_a 2^31) in four signed base-256 digits, q = p - 128.
+//   pass 1 (along H): U'[y][x] = sum_a W_a q[y + a - r][x] -- an exact integer, |U'| < 2^38.1 -- as one 16 x 16 x 64 i8 MFMA per digit:
+//          M = 16 output rows (A = the banded weight matrix over a 64-row window), N = 16 columns, B from the TRANSPOSED tile [c][x][row];
+//   U' is split into five signed digits (carry-propagated in 32-bit from the four accumulators) and written to five byte planes [row][x + r];
+//   pass 2 (along W): T = sum_b W_b U'[y][x + b - r] + 128 (sum W)^2: digit pairs (dw, du) with dw + du >= 3 (14 MFMAs; the six dropped pairs
+//          are below 2^-24.8 of an output step and part of the band), M = 16 output columns (the SAME A fragments), N = 16 rows.
+//   out = floor(T / 2^62) unless T / 2^62 is within `band` of an integer: those 16 x 16 tiles are recomputed by the workgroup in fp64 in
+//   scipy's order (pass 1 into a scratch tile, pass 2 from it) -- k_gauss_fused's arithmetic, bit for bit.
+// 16 + 2 r <= 64 covers every radius of gaussian_blur (4 .. 24) and glass_blur (3 .. 6).  18 MFMAs per 256 outputs and channel.
+constexpr int GI_TH = 16, GI_WR = 64, GI_RSU = 272, GI_THREADS = 448, GI_XT = 14;
+constexpr int GI_PT = 3 * 224 * GI_WR;                 // 43 008 B: q transposed, [channel][x][window row]
+constexpr int GI_U = 5 * GI_TH * GI_RSU;               // 21 760 B: the five digit planes of U' of ONE channel (then the fallback's fp64 scratch)
+constexpr int GI_OUT = GI_TH * 224 * 3;                // 10 752 B
+constexpr size_t GI_LDS = GI_PT + GI_U + GI_OUT + 256 * sizeof(double) + (3 * GI_XT + 4) * sizeof(int);
+static_assert(GI_U >= GI_TH * GI_WR * (int)sizeof(double), "the fallback's pass-1 scratch lives in the digit planes");
+struct GaussI8Meta {
+  long long corr, band;      // 128 (sum W)^2 >> 24; ambiguity band, both in units of 2^-38 of an output step
+};
+
+template <int FINISH>
+__global__ __launch_bounds__(GI_THREADS, 2) void k_gauss_i8(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                            const uint4* __restrict__ frags, GaussW gw, GaussI8Meta meta) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t gi_lds[];
+  uint8_t* const sPT = gi_lds;
+  int8_t* const sU = reinterpret_cast<int8_t*>(gi_lds + GI_PT);
+  uint8_t* const sO = gi_lds + GI_PT + GI_U;
+  double* const lut = reinterpret_cast<double*>(gi_lds + GI_PT + GI_U + GI_OUT);
+  int* const sList = reinterpret_cast<int*>(lut + 256);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = gw.radius, nrow = GI_TH + 2 * r;
+  const int y0 = blockIdx.x * GI_TH;
+  const size_t img = blockIdx.y;
+  i32x4 A[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) A[k] = __builtin_bit_cast(i32x4, frags[k * 64 + lane]);
+  if (tid < 256) lut[tid] = (double)tid / 255.0;
+  if (tid == 0) sList[0] = 0;
+  // ---- stage window rows y0 - r .. y0 + 15 + r (mode 'nearest') transposed: sPT[(c * 224 + x) * 64 + window row]
+  const uint8_t* base = in + img * (size_t)(224 * 224 * 3);
+  for (int i = tid; i < nrow * 42; i += GI_THREADS) {
+    const int k = i / 42, cx = i - k * 42;
+    int yy = y0 - r + k;
+    yy = yy < 0 ? 0 : (yy > 223 ? 223 : yy);
+    const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)yy * 672 + cx * 16);
+    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+    int e = cx * 16, px = e / 3, c = e - px * 3;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      sPT[(c * 224 + px) * GI_WR + k] = (uint8_t)(((wv[b >> 2] >> (8 * (b & 3))) & 0xFFu) ^ 0x80u);
+      if (++c == 3) { c = 0; ++px; }
+    }
+  }
+  __syncthreads();
+  const int n = lane & 15, g = lane >> 4;
+  for (int c = 0; c < 3; ++c) {
+    // ---- pass 1: column tile xt of channel c -> five digit planes
+    for (int xt = wave; xt < GI_XT; xt += GI_THREADS / 64) {
+      const i32x4 B = *reinterpret_cast<const i32x4*>(sPT + (c * 224 + xt * 16 + n) * GI_WR + 16 * g);
+      i32x4 acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, (i32x4){0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                 // lane: column xt*16 + n, rows 4g + q
+        int8_t* u = sU + (4 * g + q) * GI_RSU + r + xt * 16 + n;
+        int t = acc[0][q];
+        int d = (int)(int8_t)t;
+        u[0] = (int8_t)d;
+        t = acc[1][q] + ((t - d) >> 8);
+        d = (int)(int8_t)t;
+        u[GI_TH * GI_RSU] = (int8_t)d;
+        t = acc[2][q] + ((t - d) >> 8);
+        d = (int)(int8_t)t;
+        u[2 * GI_TH * GI_RSU] = (int8_t)d;
+        t = acc[3][q] + ((t - d) >> 8);
+        d = (int)(int8_t)t;
+        u[3 * GI_TH * GI_RSU] = (int8_t)d;
+        u[4 * GI_TH * GI_RSU] = (int8_t)((t - d) >> 8);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 5 * GI_TH * (GI_RSU - 224); i += GI_THREADS) {       // 'nearest' along W: both halos <- the edge columns
+      const int row = i / (GI_RSU - 224), k = i - row * (GI_RSU - 224);
+      int8_t* u = sU + row * GI_RSU;
+      if (k < r) u[k] = u[r];
+      else u[224 + k] = u[r + 223];
+    }
+    __syncthreads();
+    // ---- pass 2: lane = (n = row, g = K group); result lane: row n, columns xt*16 + 4g + q
+    for (int xt = wave; xt < GI_XT; xt += GI_THREADS / 64) {
+      i32x4 Bu[5];
+#pragma unroll
+      for (int du = 0; du < 5; ++du) Bu[du] = *reinterpret_cast<const i32x4*>(sU + (du * GI_TH + n) * GI_RSU + xt * 16 + 16 * g);
+      i32x4 acc[5];
+#pragma unroll
+      for (int s = 0; s < 5; ++s) acc[s] = (i32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+        for (int du = 0; du < 5; ++du)
+          if (dw + du >= 3) acc[dw + du - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[dw], Bu[du], acc[dw + du - 3], 0, 0, 0);
+      bool flag = false;
+      uint8_t* o = sO + (n * 224 + xt * 16 + 4 * g) * 3 + c;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long T = (long long)acc[0][q] + (long long)acc[1][q] * 256ll + (long long)acc[2][q] * 65536ll +
+                            (long long)acc[3][q] * 16777216ll + (long long)acc[4][q] * 4294967296ll + meta.corr;
+        const long long fl = T >> 38, fr = T - (fl << 38);
+        flag |= fr < meta.band || fr > (1ll << 38) - meta.band;
+        o[3 * q] = (uint8_t)(fl < 0 ? 0 : (fl > 255 ? 255 : fl));
+      }
+      if (__ballot(flag) != 0ull && lane == 0) sList[1 + atomicAdd(&sList[0], 1)] = c * GI_XT + xt;
+    }
+    __syncthreads();
+  }
+  // ---- flagged tiles: scipy's two passes in fp64 (k_gauss_fused's arithmetic: centre tap, then symmetric pairs added before weighting)
+  const int nflag = sList[0];
+  double* const P1 = reinterpret_cast<double*>(sU);              // [16][64]
+  const int ncol = 16 + 2 * r;
+  for (int i = 0; i < nflag; ++i) {
+    const int tc = sList[1 + i], c = tc / GI_XT, xt = tc - c * GI_XT;
+    for (int j = tid; j < GI_TH * ncol; j += GI_THREADS) {
+      const int ty = j / ncol, jx = j - ty * ncol;
+      int xx = xt * 16 - r + jx;
+      xx = xx < 0 ? 0 : (xx > 223 ? 223 : xx);
+      const uint8_t* col = sPT + (c * 224 + xx) * GI_WR + ty + r;
+      double tmp = lut[col[0] ^ 0x80u] * gw.w[r];
+      for (int jj = -r; jj < 0; ++jj) {
+        const double pair = lut[col[jj] ^ 0x80u] + lut[col[-jj] ^ 0x80u];
+        tmp += pair * gw.w[jj + r];
+      }
+      P1[ty * GI_WR + jx] = tmp;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int ty = tid >> 4, tx = tid & 15;
+      const double* row = P1 + ty * GI_WR + tx + r;
+      double tmp = row[0] * gw.w[r];
+      for (int jj = -r; jj < 0; ++jj) {
+        const double pair = row[jj] + row[-jj];
+        tmp += pair * gw.w[jj + r];
+      }
+      uint8_t o;
+      if (FINISH == 1) {
+        o = (uint8_t)(uint32_t)(tmp * 255.0);
+      } else {
+        const double cl = tmp < 0.0 ? 0.0 : (tmp > 1.0 ? 1.0 : tmp);
+        o = (uint8_t)(uint32_t)(cl * 255.0);
+      }
+      sO[(ty * 224 + xt * 16 + tx) * 3 + c] = o;
+    }
+    __syncthreads();
+  }
+  uint4* dst = reinterpret_cast<uint4*>(out + img * (size_t)(224 * 224 * 3) + (size_t)y0 * 672);
+  const uint4* so4 = reinterpret_cast<const uint4*>(sO);
+  for (int i = tid; i < GI_OUT / 16; i += GI_THREADS) dst[i] = so4[i];
+}
+
+struct GaussI8Host {
+  double sigma = -1.0;
+  std::vector<uint8_t> frags;        // [4 digits][64 lanes][16]
+  GaussI8Meta meta;
+  bool ok = false;
+};
+GaussI8Host make_gauss_i8(const GaussW& gw, double sigma) {
+  GaussI8Host h;
+  h.sigma = sigma;
+  const int r = gw.radius, nt = 2 * r + 1;
+  if (16 + 2 * r > GI_WR) return h;
+  long long W[2 * MAXR + 1];
+  __int128 sumW = 0;
+  double errw = 0.0;
+  for (int i = 0; i < nt; ++i) {
+    W[i] = llrint(ldexp(gw.w[i], 31));
+    sumW += W[i];
+    errw += fabs(ldexp((double)W[i], -31) - gw.w[i]);
+  }
+  h.frags.assign(4 * 64 * 16, 0);
+  for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, g = lane >> 4;
+    for (int i = 0; i < 16; ++i) {
+      const int t = 16 * g + i - m;
+      long long w = (t >= 0 && t < nt) ? W[t] : 0;
+      for (int k = 0; k < 4; ++k) {
+        const long long lo = ((w + 128) & 255) - 128;
+        h.frags[((size_t)k * 64 + lane) * 16 + i] = (uint8_t)(int8_t)lo;
+        w = (w - lo) / 256;
+      }
+      if (w != 0) return h;            // a weight >= 0.996 (sigma < 0.3): not a blur this library issues
+    }
+  }
+  const __int128 corr = (__int128)128 * sumW * sumW;
+  h.meta.corr = (long long)(corr >> 24);
+  const double bq = 255.0 * (2.0 * errw + errw * errw) + 1e-9;
+  const long long dropped = ((long long)nt * 16384ll * (1ll + 2ll * 256ll + 3ll * 65536ll)) >> 24;
+  h.meta.band = (long long)ceil(ldexp(bq, 38)) + dropped + 8;
+  h.ok = true;
+  return h;
+}
+const GaussI8Host& gauss_i8_for(const GaussW& gw, double sigma) {
+  static GaussI8Host cache[16];
+  static int used = 0;
+  for (int i = 0; i < used; ++i)
+    if (cache[i].sigma == sigma) return cache[i];
+  const int slot = used < 16 ? used++ : 15;
+  cache[slot] = make_gauss_i8(gw, sigma);
+  return cache[slot];
+}
+
 // ---- motion_blur (ImageMagick) -----------------------------------------------------------------
 struct MotionTab {
   int offx[41], offy[41];
@@ -601,7 +810,17 @@ const double kMotion[5][2] = {{10, 3}, {15, 5}, {15, 8}, {15, 12}, {20, 15}};
 
 template <int FINISH>
 void gauss_u8_to_u8(const uint8_t* in, uint8_t* out, double* tmp, int n, int h, int w, const GaussW& g,
-                    hipStream_t s) {
+                    hipStream_t s, double sigma = 0.0, void* frag_ws = nullptr) {
+  if (frag_ws && h == 224 && w == 224 && n <= 65535 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+      getenv("RART_GAUSS_FP64") == nullptr) {
+    // the matrix-core path (exact fixed point + ordered-fp64 recompute of ambiguous tiles); anything else: the fp64 kernels below
+    const GaussI8Host& f = gauss_i8_for(g, sigma);
+    if (f.ok && rart_raise_dynamic_lds((const void*)k_gauss_i8<FINISH>, GI_LDS, "gaussian filter (matrix-core path)") &&
+        hipMemcpyAsync(frag_ws, f.frags.data(), f.frags.size(), hipMemcpyHostToDevice, s) == hipSuccess) {
+      hipLaunchKernelGGL((k_gauss_i8<FINISH>), dim3(224 / GI_TH, n), dim3(GI_THREADS), GI_LDS, s, in, out, (const uint4*)frag_ws, g, f.meta);
+      return;
+    }
+  }
   if (g.radius <= GF_RMAX && n <= 65535) {
     const size_t lds = gauss_fused_lds(g.radius);
     if (rart_raise_dynamic_lds((const void*)k_gauss_fused<FINISH>, lds, "gaussian filter")) {
@@ -635,8 +854,8 @@ size_t rart_motion_tab_bytes(int n) { return rart_align_up((size_t)n * sizeof(Mo
 size_t rart_ws_stencil(int id, int /*severity*/, int n, int h, int w) {
   const size_t tmp = rart_align_up((size_t)n * h * w * 3 * sizeof(double), 256);
   switch (id) {
-    case RART_GAUSSIAN_BLUR: return tmp;
-    case RART_GLASS_BLUR: return tmp + rart_align_up((size_t)n * h * w * 3, 256);
+    case RART_GAUSSIAN_BLUR: return tmp + 4096;                                              // + the weight fragments of k_gauss_i8
+    case RART_GLASS_BLUR: return tmp + rart_align_up((size_t)n * h * w * 3, 256) + 4096;
     case RART_DEFOCUS_BLUR: return rart_align_up(21 * 21 * sizeof(double), 4096) + rart_align_up((size_t)FI_STEPS * 4 * 64 * 16, 256);
     case RART_MOTION_BLUR: return rart_motion_tab_bytes(n);
   }
@@ -649,7 +868,8 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
   switch (id) {
     case RART_GAUSSIAN_BLUR: {
       const GaussW g = make_gauss(kGaussBlurSigma[s], 4.0);
-      gauss_u8_to_u8<2>(a.in, a.out, (double*)a.workspace, a.n, a.h, a.w, g, a.stream);
+      void* fr = (uint8_t*)a.workspace + rart_align_up((size_t)a.n * a.h * a.w * 3 * sizeof(double), 256);
+      gauss_u8_to_u8<2>(a.in, a.out, (double*)a.workspace, a.n, a.h, a.w, g, a.stream, kGaussBlurSigma[s], fr);
       break;
     }
     case RART_GLASS_BLUR: {
@@ -657,12 +877,13 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
       const GaussW g = make_gauss(kGlass[s][0], 4.0);
       double* tmp = (double*)a.workspace;
       uint8_t* mid = (uint8_t*)a.workspace + rart_align_up((size_t)a.n * a.h * a.w * 3 * sizeof(double), 256);
-      gauss_u8_to_u8<1>(a.in, mid, tmp, a.n, a.h, a.w, g, a.stream);
+      void* fr = mid + rart_align_up((size_t)a.n * a.h * a.w * 3, 256);
+      gauss_u8_to_u8<1>(a.in, mid, tmp, a.n, a.h, a.w, g, a.stream, kGlass[s][0], fr);
       if (!rart_raise_dynamic_lds((const void*)k_glass_shuffle, 224 * 224 * 3, "glass_blur")) return RART_ERR_HIP;
       hipLaunchKernelGGL(k_glass_shuffle, dim3(a.n), dim3(kGlassThreads), 224 * 224 * 3, a.stream, mid,
                          (int)kGlass[s][1], (int)kGlass[s][2], (const int8_t*)inj0, (uint32_t)a.seed,
                          (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
-      gauss_u8_to_u8<2>(mid, a.out, tmp, a.n, a.h, a.w, g, a.stream);
+      gauss_u8_to_u8<2>(mid, a.out, tmp, a.n, a.h, a.w, g, a.stream, kGlass[s][0], fr);
       break;
     }
     case RART_DEFOCUS_BLUR: {

@@ -30,6 +30,24 @@ def _run(name, batch_u8, sev, draws=None, seed=0, offset=0):
     return dev.cpu().numpy()
 
 
+def _hard_images(seed):
+    """random texture, saturated / black / constant regions, ramps, constant images, low contrast: the inputs on which an order-free
+    evaluation of a filter and the reference's ordered fp64 sums can disagree by the last bit"""
+    rs = np.random.RandomState(seed)
+    imgs = [rs.randint(0, 256, (224, 224, 3)).astype(np.uint8)]
+    flat = np.full((224, 224, 3), 255, np.uint8)
+    flat[40:120, 30:170] = rs.randint(0, 256, (80, 140, 3))
+    flat[150:] = 0
+    flat[:24] = 77
+    flat[:, 200:] = (3, 200, 128)
+    imgs.append(flat)
+    yy, xx = np.mgrid[0:224, 0:224]
+    imgs.append(np.stack([(yy + xx) // 2, np.clip(xx, 0, 255), np.clip(255 - yy, 0, 255)], -1).astype(np.uint8))
+    imgs += [np.full((224, 224, 3), v, np.uint8) for v in (0, 1, 127, 254, 255)]
+    imgs.append(rs.randint(120, 124, (224, 224, 3)).astype(np.uint8))
+    return imgs
+
+
 def _oracle_batch(name, batch, sev, seed):
     rs = np.random.RandomState(seed)
     per = [O.draw(name, batch[i], sev, rs) for i in range(batch.shape[0])]
@@ -123,19 +141,7 @@ def test_defocus_fast_path_equals_the_ordered_fp64_kernel(sev):
     bit-identical to the oracle's arithmetic) on EVERY input -- random texture, saturated and black regions, ramps, constant images --
     and the oracle within the stated tolerance (here: exactly, the oracle sums in the same order)."""
     import os
-    rs = np.random.RandomState(100 + sev)
-    imgs = [rs.randint(0, 256, (224, 224, 3)).astype(np.uint8)]
-    flat = np.full((224, 224, 3), 255, np.uint8)
-    flat[40:120, 30:170] = rs.randint(0, 256, (80, 140, 3))
-    flat[150:] = 0
-    flat[:24] = 77
-    flat[:, 200:] = (3, 200, 128)
-    imgs.append(flat)
-    yy, xx = np.mgrid[0:224, 0:224]
-    imgs.append(np.stack([(yy + xx) // 2, np.clip(xx, 0, 255), np.clip(255 - yy, 0, 255)], -1).astype(np.uint8))
-    imgs += [np.full((224, 224, 3), v, np.uint8) for v in (0, 1, 127, 254, 255)]
-    lowc = rs.randint(120, 124, (224, 224, 3)).astype(np.uint8)             # low contrast: many near-integer sums
-    imgs.append(lowc)
+    imgs = _hard_images(100 + sev)
     batch = np.stack(imgs)
     fast = _run('defocus_blur', batch, sev)
     os.environ['RART_DEFOCUS_FP64'] = '1'
@@ -146,6 +152,48 @@ def test_defocus_fast_path_equals_the_ordered_fp64_kernel(sev):
     np.testing.assert_array_equal(fast, slow)
     want = np.stack([np.asarray(O.corrupt('defocus_blur', im, sev)).astype(np.uint8) for im in imgs[:3]])
     np.testing.assert_array_equal(fast[:3], want)
+
+
+@pytest.mark.parametrize('sev', [1, 2, 3, 4, 5])
+def test_zoom_blur_table_kernel_equals_the_direct_kernel(sev):
+    """Round 5: zoom_blur with the source coordinates of every (zoom factor, row / column) tabulated once and the taps fetched as 8-byte
+    loads (k_zoom_blur_tab) == the per-pixel kernel of rounds 1-4 (RART_ZOOM_DIRECT=1), which is bit-exact against the oracle."""
+    import os
+    batch = np.stack(_hard_images(300 + sev)[:4])
+    fast = _run('zoom_blur', batch, sev)
+    os.environ['RART_ZOOM_DIRECT'] = '1'
+    try:
+        slow = _run('zoom_blur', batch, sev)
+    finally:
+        del os.environ['RART_ZOOM_DIRECT']
+    np.testing.assert_array_equal(fast, slow)
+    np.testing.assert_array_equal(fast[0], np.asarray(O.corrupt('zoom_blur', batch[0], sev)).astype(np.uint8))
+
+
+@pytest.mark.parametrize('name', ['gaussian_blur', 'glass_blur'])
+@pytest.mark.parametrize('sev', [1, 2, 3, 4, 5])
+def test_gaussian_fast_path_equals_the_ordered_fp64_kernels(name, sev):
+    """Round 5: the separable Gaussian of gaussian_blur (radius 4 .. 24) and of glass_blur's two blurs runs as an exact fixed-point
+    filter on the i8 matrix cores (k_gauss_i8); 16 x 16 tiles holding a value within the stated band of an integer are recomputed in
+    scipy's fp64 order.  Equal to the fp64 kernels (RART_GAUSS_FP64=1: k_gauss_fused / k_gauss_pass, bit-identical to the oracle's
+    arithmetic) on every input, and to the oracle itself."""
+    import os
+    imgs = _hard_images(200 + sev)
+    batch = np.stack(imgs)
+    fast = _run(name, batch, sev, None, 5, 70)
+    os.environ['RART_GAUSS_FP64'] = '1'
+    try:
+        slow = _run(name, batch, sev, None, 5, 70)
+    finally:
+        del os.environ['RART_GAUSS_FP64']
+    np.testing.assert_array_equal(fast, slow)
+    if name == 'gaussian_blur':
+        # against the oracle (scipy itself): the random image exactly up to the stated tolerance; the flat regions within 1 LSB only --
+        # there the floor of p (1 +- 1e-16) is decided by the last bit of the 1-D weights, and numpy's SIMD exp / pairwise sum (the
+        # oracle's, the reference's) and libm's exp / sequential sum (the library's host code) differ in that bit for sigma 2, 3, 4, 6
+        want = np.stack([np.asarray(O.corrupt(name, im, sev)).astype(np.uint8) for im in imgs[:3]])
+        diff = np.abs(fast[:3].astype(int) - want.astype(int))
+        assert diff.max() <= 1 and (diff[0] != 0).mean() <= 1e-5, (diff.max(), (diff[0] != 0).mean())
 
 
 @pytest.mark.parametrize('name', [n for n in NAMES if n != 'frost'])
