@@ -209,9 +209,17 @@ __global__ __launch_bounds__(kBlock) void k_field_gauss(const TIN* __restrict__ 
 //   AXIS 1 (along w): ext[line][pos], a thread owns position tid of each of the FL_N rows (adjacent lanes, adjacent addresses);
 //   AXIS 0 (along h): ext[pos][line], lane -> (line = tid & 7, pos = tid >> 3 + 32 k): 64 contiguous bytes per position.
 constexpr int FL_N = 8;
-template <int AXIS, bool REFLECT, typename TIN, typename TOUT>
+// GEN (round 5, elastic_transform's native fields): the staged values are drawn here -- U(-1, 1) of the counter generator at the element's
+// own index, exactly k_uniform_field's expression -- instead of being written to HBM by a launch of their own and read back (2 x 34 us + a
+// 103 MB round trip per field at B = 256); the reflected extension re-draws the element it mirrors.
+struct FieldGen {
+  uint32_t k0, k1, sample_base;
+  int stream_id;
+};
+template <int AXIS, bool REFLECT, typename TIN, typename TOUT, bool GEN = false>
 __global__ __launch_bounds__(kBlock) void k_field_gauss_lds(const TIN* __restrict__ src, TOUT* __restrict__ dst, int h, int w,
-                                                            const double* __restrict__ wts, int radius, double post_scale) {
+                                                            const double* __restrict__ wts, int radius, double post_scale,
+                                                            FieldGen gen = FieldGen{0, 0, 0, 0}) {
   extern __shared__ __attribute__((aligned(16))) double fl_s[];
   const int len = AXIS == 0 ? h : w, other = AXIS == 0 ? w : h;
   const int ext = len + 2 * radius;
@@ -234,7 +242,11 @@ __global__ __launch_bounds__(kBlock) void k_field_gauss_lds(const TIN* __restric
       p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
     }
     double v = 0.0;
-    if (l0 + line < other) v = (double)src[ibase + (AXIS == 0 ? (size_t)p * w + (l0 + line) : (size_t)(l0 + line) * w + p)];
+    if (l0 + line < other) {
+      const size_t el = AXIS == 0 ? (size_t)p * w + (l0 + line) : (size_t)(l0 + line) * w + p;
+      if (GEN) v = -1.0 + 2.0 * u53(threefry2x32(gen.k0, gen.k1, rart_ctr0((uint32_t)el, gen.stream_id), gen.sample_base + (uint32_t)img));
+      else v = (double)src[ibase + el];
+    }
     e[AXIS == 0 ? q * FL_N + line : line * extp + q] = v;
   }
   __syncthreads();
@@ -630,6 +642,15 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
       hipLaunchKernelGGL(k_warp_affine, img_grid(a.n), dim3(kBlock), 0, st, a.in, warped, inv);
       for (int which = 0; which < 2; ++which) {
         const double* fsrc = (const double*)inj(1 + which);
+        const size_t gen_lds = (size_t)(((radius + 2) & ~1) + (size_t)FL_N * (HW + 2 * radius)) * sizeof(double);
+        if (!fsrc && gen_lds <= 150 * 1024 && getenv("RART_ELASTIC_FIELD_KERNEL") == nullptr &&
+            rart_raise_dynamic_lds((const void*)k_field_gauss_lds<0, true, double, double, true>, gen_lds, "gaussian field filter")) {
+          // native fields: drawn inside the first pass's staging loop (no field tensor of their own)
+          hipLaunchKernelGGL((k_field_gauss_lds<0, true, double, double, true>), dim3((unsigned)(a.n * ((HW + FL_N - 1) / FL_N))), dim3(kBlock),
+                             gen_lds, st, (const double*)nullptr, f1, HW, HW, (const double*)wdev, radius, 1.0, FieldGen{k0, k1, sb, 11 + which});
+          launch_field_gauss<1, true, double, float>((const double*)f1, which == 0 ? dx : dy, a.n, HW, HW, (const double*)wdev, radius, c[0], st);
+          continue;
+        }
         if (!fsrc) {
           hipLaunchKernelGGL(k_uniform_field, img_grid(a.n), dim3(kBlock), 0, st, f0, k0, k1, sb, 11 + which);
           fsrc = f0;
