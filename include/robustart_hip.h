@@ -52,8 +52,9 @@ enum {
 
 /* ABI version of THIS header.  Bumped whenever a struct layout or a signature changes (round 3 -> 4: rart_conv_desc grew
  * its tap arrays from 16 to 32 entries and gained dst_pair_off / res_pair_off; several attack entries gained a per-row
- * sample-index pointer).  A caller compiled against another header must refuse to run: compare with rart_version(). */
-#define RART_ABI_VERSION 105
+ * sample-index pointer; round 4 -> 5: rart_stencil_fixed_point_info added).  A caller compiled against another header must refuse to run:
+ * compare with rart_version(). */
+#define RART_ABI_VERSION 106
 int rart_version(void);
 const char* rart_last_error_string(void);
 /* name of corruption id (static string), NULL if out of range */
@@ -101,6 +102,24 @@ int rart_corrupt_u8(const uint8_t* in, uint8_t* out, int n, int h, int w,
  * buffers and the matrix-core generator selected (callers then issue ns rart_corrupt_u8 calls). */
 int rart_noise_multi_u8(const uint8_t* in, uint8_t* const* outs, int ns, int n, int h, int w, int corruption_id, const int* severities,
                         const uint64_t* seeds, uint64_t sample_offset, rart_stream_t stream);
+
+/* Host-only introspection of the fixed-point tables behind the matrix-core stencil paths (round 5; no GPU needed: the "-m 'not gpu'"
+ * tests check the tables against the oracle's weights).  defocus_blur severities 1-4 (corruptions.py:187-198: 17 x 17 disk) run as an
+ * exact 2-D integer filter, gaussian_blur (corruptions.py:162-166) and glass_blur's two blurs (corruptions.py:169-184) as an exact
+ * separable one: W = round(w 2^frac_bits) split into four signed base-256 digits laid out as v_mfma_i32_16x16x64_i8 A-operand
+ * fragments -- fragment (step j, digit d), lane (m = lane & 15, g = lane >> 4), byte i:
+ *   kind 1 (2-D):       kernel row 2 j + (g >> 1), window column 16 (g & 1) + i, tap b = column - m      (n_steps = 9)
+ *   kind 2 (separable): tap t = 16 g + i - m of the 1-D kernel                                            (n_steps = 1)
+ * An output whose fixed-point value lies within `band` units (of 2^-out_frac_bits of an output step) of an integer is recomputed in the
+ * reference's fp64 order.  blur_index: 0 for defocus_blur / gaussian_blur; glass_blur has one sigma, index 0.
+ * frags: NULL or a HOST buffer of n_steps * 4 * 64 * 16 bytes.  Returns RART_ERR_UNSUPPORTED (kind 0) where the fp64 kernels run. */
+typedef struct rart_fixed_point_info {
+  int kind, ksize, n_steps, frac_bits, out_frac_bits;
+  long long corr, band;
+  double max_abs_weight_error;      /* max |W / 2^frac_bits - w| over the taps */
+  double sum_abs_weight_error;
+} rart_fixed_point_info;
+int rart_stencil_fixed_point_info(int corruption_id, int severity, rart_fixed_point_info* info, unsigned char* frags, size_t frags_bytes);
 
 /* ImageNet-S resize operators (imagenet_s_gen.py:19-34,127-166): Pillow's Image.resize((resize_w, resize_h), filter) on
  * uint8 NHWC images followed by a crop, bit-exact with Pillow (Resample.c 22-bit fixed point; Geometry.c for

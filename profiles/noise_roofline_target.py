@@ -14,7 +14,7 @@ out = {'avg_launch_us': avg * 1e6, 'per_launch_event_bracket_us': bracket * 1e6,
        'frac_of_8TBps': 2 * 256 * 150528 / avg / 8e12}
 if 'multi_launch_s' in ex:
     out['five_severity_launch_us'] = ex['multi_launch_s'] * 1e6
-    out['five_severity_frac_per_launch_equivalent'] = 5 * 2 * 256 * 150528 / ex['multi_launch_s'] / 8e12
+    out['five_severity_throughput_equivalent_frac_NOT_a_roofline_fraction'] = 5 * 2 * 256 * 150528 / ex['multi_launch_s'] / 8e12
     out['five_severity_frac_of_bytes_moved'] = 6 * 256 * 150528 / ex['multi_launch_s'] / 8e12
     out['two_streams_launch_us'] = ex['two_streams_s'] * 1e6
 print(json.dumps(out))

@@ -13,7 +13,7 @@ c_void_p, c_int, c_size_t, c_u64, c_float = (ctypes.c_void_p, ctypes.c_int, ctyp
                                               ctypes.c_uint64, ctypes.c_float)
 c_double = ctypes.c_double
 
-ABI_VERSION = 105        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
+ABI_VERSION = 106        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
 
 # name -> (restype, argtypes); every symbol include/robustart_hip.h declares
 SIGNATURES = {
@@ -23,6 +23,7 @@ SIGNATURES = {
     'rart_corrupt_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'rart_corrupt_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_u64, c_u64,
                                 ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
+    'rart_stencil_fixed_point_info': (c_int, [c_int, c_int, c_void_p, c_void_p, c_size_t]),
     'rart_noise_multi_u8': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
                                     ctypes.POINTER(c_u64), c_u64, c_void_p]),
     'rart_pil_resize_workspace_bytes': (c_size_t, [c_int] * 10),
@@ -202,6 +203,13 @@ class ConvDesc(ctypes.Structure):
                 ('src_z_outer', ctypes.c_int64), ('src_z_inner', ctypes.c_int64), ('wgt_z_outer', ctypes.c_int64),
                 ('wgt_z_inner', ctypes.c_int64), ('dst_z_outer', ctypes.c_int64), ('dst_z_inner', ctypes.c_int64),
                 ('sign_out', c_void_p), ('dst_pair_off', ctypes.c_int64), ('res_pair_off', ctypes.c_int64), ('bn_stats_out', c_void_p)]
+
+
+class FixedPointInfo(ctypes.Structure):
+    """rart_fixed_point_info (include/robustart_hip.h): the fixed-point table of a matrix-core stencil path."""
+    _fields_ = [(n, ctypes.c_int32) for n in ('kind', 'ksize', 'n_steps', 'frac_bits', 'out_frac_bits')] + \
+               [('corr', ctypes.c_longlong), ('band', ctypes.c_longlong), ('max_abs_weight_error', ctypes.c_double),
+                ('sum_abs_weight_error', ctypes.c_double)]
 
 
 class PackJob(ctypes.Structure):

@@ -7,6 +7,7 @@
 // taps along the angle, edge virtual pixels, 8-bit requantisation).
 #include "rart_common.h"
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -850,6 +851,51 @@ int rart_motion_blur_gray(const uint8_t* in, uint8_t* out, int n, int h, int w, 
   return RART_OK;
 }
 size_t rart_motion_tab_bytes(int n) { return rart_align_up((size_t)n * sizeof(MotionTab), 256); }
+
+extern "C" int rart_stencil_fixed_point_info(int corruption_id, int severity, rart_fixed_point_info* info, unsigned char* frags,
+                                             size_t frags_bytes) {
+  RART_CHECK_ARG(info != nullptr, "rart_stencil_fixed_point_info: null info");
+  RART_CHECK_ARG(severity >= 1 && severity <= 5, "rart_stencil_fixed_point_info: severity %d outside 1..5", severity);
+  memset(info, 0, sizeof(*info));
+  const int s = severity - 1;
+  const std::vector<uint8_t>* fr = nullptr;
+  FilterI8Host f2;
+  GaussI8Host f1;
+  if (corruption_id == RART_DEFOCUS_BLUR) {
+    int ksz = 0;
+    const std::vector<double> disk = make_disk((int)kDefocus[s][0], kDefocus[s][1], &ksz);
+    f2 = make_filter_i8(disk, ksz);
+    if (!f2.ok) return RART_ERR_UNSUPPORTED;
+    info->kind = 1; info->ksize = ksz; info->n_steps = FI_STEPS; info->frac_bits = f2.meta.F; info->out_frac_bits = f2.meta.F;
+    info->corr = f2.meta.corr; info->band = f2.meta.band;
+    for (double v : disk) {
+      const double e = fabs(ldexp((double)llrint(ldexp(v, f2.meta.F)), -f2.meta.F) - v);
+      info->max_abs_weight_error = e > info->max_abs_weight_error ? e : info->max_abs_weight_error;
+      info->sum_abs_weight_error += e;
+    }
+    fr = &f2.frags;
+  } else if (corruption_id == RART_GAUSSIAN_BLUR || corruption_id == RART_GLASS_BLUR) {
+    const double sigma = corruption_id == RART_GAUSSIAN_BLUR ? kGaussBlurSigma[s] : kGlass[s][0];
+    const GaussW g = make_gauss(sigma, 4.0);
+    f1 = make_gauss_i8(g, sigma);
+    if (!f1.ok) return RART_ERR_UNSUPPORTED;
+    info->kind = 2; info->ksize = 2 * g.radius + 1; info->n_steps = 1; info->frac_bits = 31; info->out_frac_bits = 38;
+    info->corr = f1.meta.corr; info->band = f1.meta.band;
+    for (int i = 0; i <= 2 * g.radius; ++i) {
+      const double e = fabs(ldexp((double)llrint(ldexp(g.w[i], 31)), -31) - g.w[i]);
+      info->max_abs_weight_error = e > info->max_abs_weight_error ? e : info->max_abs_weight_error;
+      info->sum_abs_weight_error += e;
+    }
+    fr = &f1.frags;
+  } else {
+    return RART_ERR_UNSUPPORTED;
+  }
+  if (frags) {
+    RART_CHECK_ARG(frags_bytes >= fr->size(), "rart_stencil_fixed_point_info: fragment buffer of %zu bytes required", fr->size());
+    memcpy(frags, fr->data(), fr->size());
+  }
+  return RART_OK;
+}
 
 size_t rart_ws_stencil(int id, int /*severity*/, int n, int h, int w) {
   const size_t tmp = rart_align_up((size_t)n * h * w * 3 * sizeof(double), 256);
