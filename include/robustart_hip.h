@@ -406,7 +406,9 @@ int rart_gemm256_supported(long long rows, int k, int n_cols, int src_ld, int ds
  * res : optional residual PAIR indexed like dst, added in fp32.
  * 256- or 128-row tiles x 64 / 128 / 256-column tiles (chosen from the shape; tile_m / tile_n override).
  * flags: 1 ReLU; 2 fp32 output; 4 exact GELU (of the value the pair of the pre-activation represents, as flag 64 computes it); 64 GELU with the pre-activation kept (aux RECEIVES the pair u, dst = gelu(u_hi + u_lo));
- *        8 GELU' (v *= gelu'(aux_hi + aux_lo), aux indexed like dst).
+ *        8 GELU' (v *= gelu'(aux_hi + aux_lo), aux indexed like dst);
+ *        16 (round 5) the weight table is INTERLEAVED: a row holds, per 32-deep K step, the 32 hi elements followed by the 32 lo elements
+ *        (ldw >= 2 K, w_lo = w_hi + 32 elements): one 128-byte line per row and step instead of two half lines K apart.
  * Row re-basing (0 = none): output row m of image m / rows_per_image reads source row img * src_rows_per_image + m % rows_per_image +
  * src_row_off and writes destination row img * dst_rows_per_image + m % rows_per_image + dst_row_off (ViT's class-token slot).
  * Batched (n_batched > 1, blockIdx.y = z -> zo = z / z_inner, zi = z % z_inner): element offsets zo * *_z_outer + zi * *_z_inner are

@@ -32,7 +32,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
-enum { GP_OUT_F32 = 2, GP_GELU = 4, GP_GELU_BWD = 8, GP_GELU_KEEP = 64, GP_RELU = 1 };
+enum { GP_OUT_F32 = 2, GP_GELU = 4, GP_GELU_BWD = 8, GP_GELU_KEEP = 64, GP_RELU = 1, GP_W_INTERLEAVED = 16 };
 constexpr int GP_BK = 32;
 constexpr int GP_LDE = 68;                         // epilogue staging row (floats): 64 columns + 4
 
@@ -184,6 +184,9 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
     }
   }
   const char* const zsrc = reinterpret_cast<const char*>(g_pair_zero16);
+  // GP_W_INTERLEAVED: the weight table holds, per row and K step, the 64 bytes of the hi plane followed by the 64 bytes of the lo plane
+  // (one 128-byte line per row and step; w_lo = w_hi + 32 elements) instead of two planes K apart
+  const int w_step = (d.flags & GP_W_INTERLEAVED) ? 128 : 64;
 #define RART_GP_DL(SRC, DST)                                                                                    \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                        \
                                    (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
       }                                                                                                         \
     }                                                                                                           \
     {                                                                                                           \
-      const size_t ko_ = (size_t)kt_ * 64;                                                                      \
+      const size_t ko_ = (size_t)kt_ * w_step;                                                                  \
       _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                                          \
         if (wave + NW * q < B_PIECES) {                                                                         \
           RART_GP_DL(bsrc_h[q] ? bsrc_h[q] + ko_ : zsrc, st_ + 2 * GP_PLANE_A + (wave + NW * q) * 1024)          \
@@ -470,7 +473,8 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   RART_CHECK_ARG((h->res_hi == nullptr) == (h->res_lo == nullptr), "rart_gemm_pair_bf16: the residual is a pair: both planes or none");
   RART_CHECK_ARG(!(h->flags & (GP_GELU_KEEP | GP_GELU_BWD)) || (h->aux_hi && h->aux_lo),
                  "rart_gemm_pair_bf16: GELU_KEEP / GELU_BWD need the pre-activation pair (aux)");
-  RART_CHECK_ARG(!(h->flags & ~(GP_OUT_F32 | GP_GELU | GP_GELU_BWD | GP_GELU_KEEP | GP_RELU)), "rart_gemm_pair_bf16: unknown flag");
+  RART_CHECK_ARG(!(h->flags & ~(GP_OUT_F32 | GP_GELU | GP_GELU_BWD | GP_GELU_KEEP | GP_RELU | GP_W_INTERLEAVED)), "rart_gemm_pair_bf16: unknown flag");
+  RART_CHECK_ARG(!(h->flags & GP_W_INTERLEAVED) || h->ldw >= 2 * d.K, "rart_gemm_pair_bf16: an interleaved weight table has rows of 2 K elements");
   {
     const int g = (h->flags & GP_GELU ? 1 : 0) + (h->flags & GP_GELU_BWD ? 1 : 0) + (h->flags & GP_GELU_KEEP ? 1 : 0);
     RART_CHECK_ARG(g <= 1 && !((h->flags & GP_GELU_KEEP) && out_f32), "rart_gemm_pair_bf16: at most one GELU mode; GELU_KEEP writes pairs");

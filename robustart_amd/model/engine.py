@@ -14,6 +14,7 @@ backward), rart_engine_* (stem input prep, pools, col2im), rart_logit_loss.  bf1
 accumulation; the fp32 pixels enter the stem as a hi+lo bf16 pair so eps-sized perturbations are kept.
 """
 import ctypes
+import os as _os
 
 from .. import _lib
 
@@ -198,6 +199,10 @@ class ResNet50Engine:
             self.fc_wd = _bf16(torch.cat([wt, wtl, wt], 1)).to(dev)       # [2048][3 * 1024]
         self._buf = {}
         self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
+        # round 5: the pair GEMM's weight tables with the hi and the lo slice of a 32-deep K step side by side (one 128-byte line per row and
+        # step instead of two half lines K apart): 2-5 % per K-deep launch (profiles/r05_pair_knockouts.txt); RART_PAIR_WIL=0 = two planes
+        self.pair_w_interleaved = _os.environ.get('RART_PAIR_WIL', '1') == '1'
+        self._w_il = {}
         if not split:
             self._pack_frag_tables()
         else:
@@ -532,6 +537,16 @@ class ResNet50Engine:
         d = _lib.GemmPairDesc()
         d.a_hi, d.a_lo = src[0].data_ptr(), src[1].data_ptr()
         d.w_hi, d.w_lo = wgt.data_ptr(), wgt.data_ptr() + 2 * k_tot
+        ldw, wflag = 3 * k_tot, 0
+        if self.pair_w_interleaved:
+            # per row and 32-deep K step: the hi slice then the lo slice (one 128-byte line per row and step instead of two half lines)
+            il = self._w_il.get(wgt.data_ptr())
+            if il is None:
+                import torch
+                rows = wgt.shape[0]
+                il = torch.stack([wgt[:, :k_tot].reshape(rows, k_tot // 32, 32), wgt[:, k_tot:2 * k_tot].reshape(rows, k_tot // 32, 32)], 2)
+                il = self._w_il[wgt.data_ptr()] = il.reshape(rows, 2 * k_tot).contiguous()
+            d.w_hi, d.w_lo, ldw, wflag = il.data_ptr(), il.data_ptr() + 64, 2 * k_tot, 16
         d.bias = bias.data_ptr() if bias is not None else None
         if res is not None:
             d.res_hi, d.res_lo = res[0].data_ptr(), res[1].data_ptr()
@@ -539,8 +554,8 @@ class ResNet50Engine:
             d.dst_hi = dst.data_ptr()
         else:
             d.dst_hi, d.dst_lo = dst[0].data_ptr(), dst[1].data_ptr()
-        d.N, d.lda, d.ldw, d.ldc, d.w_rows = n_cols, src_pix, 3 * k_tot, dst_pix, wgt.shape[0]
-        d.flags = flags & (F_RELU | F_OUT_F32)
+        d.N, d.lda, d.ldw, d.ldc, d.w_rows = n_cols, src_pix, ldw, dst_pix, wgt.shape[0]
+        d.flags = (flags & (F_RELU | F_OUT_F32)) | wflag
         d.conv, d.batch, d.grid_h, d.grid_w = 1, batch, grid[0], grid[1]
         d.src_h, d.src_w, d.sy, d.sx = src_hw[0], src_hw[1], stride[0], stride[1]
         d.k_per_tap, d.n_taps = k_per_tap, len(taps)
