@@ -43,6 +43,9 @@ class ViTEngine:
         m = model
         self.D, self.H, self.ps = m.embed_dim, m.num_heads, m.patch_size
         self.hd = self.D // self.H
+        import os as _os
+        self.pair_w_interleaved = _os.environ.get('RART_PAIR_WIL', '1') == '1'     # see engine.py: weight tables interleaved per K step
+        self._w_il = {}
         self.refold(model)
         self._buf = {}
         self.fused_attention = True
@@ -117,7 +120,14 @@ class ViTEngine:
             r = (w.shape[0] + 255) // 256 * 256
             if r != w.shape[0]:
                 w = torch.cat([w, torch.zeros(r - w.shape[0], w.shape[1], device=dev)], 0)
-            return _pair(w.contiguous())
+            t = _pair(w.contiguous())
+            if self.pair_w_interleaved and t.shape[2] % 32 == 0:
+                # round 5: per row and 32-deep K step the hi slice then the lo slice (rart_gemm_pair_bf16 flag 16: one 128-byte line per
+                # row and step); kept beside the planes, keyed by their address
+                rows, k = t.shape[1], t.shape[2]
+                self._w_il[t.data_ptr()] = torch.stack([t[0].reshape(rows, k // 32, 32), t[1].reshape(rows, k // 32, 32)], 2).reshape(rows, 2 * k).contiguous()
+            return t
+        self._w_il = {}
         pe = m.patch_embed.weight.detach().reshape(self.D, -1)
         self.x3 = dict(pe_w=tab(pe), pe_wd=tab(pe.t()), head_w=tab(m.head.weight), head_wd=tab(m.head.weight.t(), self.head_kpad),
                        layers=[dict(qkv_w=tab(b.attn.qkv.weight), proj_w=tab(b.attn.proj.weight), fc1_w=tab(b.fc1.weight),
@@ -372,6 +382,10 @@ class ViTEngine:
         if aux is not None:
             d.aux_hi, d.aux_lo = aux[0].data_ptr() + dst_off * es, aux[1].data_ptr() + dst_off * es
         d.M, d.N, d.K, d.lda, d.ldw, d.ldc = M, N, K, lda, (ldw or K), ldc
+        il = self._w_il.get(w.data_ptr()) if (w_off == 0 and ldw is None and not batched) else None
+        if il is not None and il.shape[1] == 2 * K:
+            d.w_hi, d.w_lo, d.ldw = il.data_ptr(), il.data_ptr() + 64, 2 * K
+            flags |= 16
         d.w_rows = w_rows if w_rows is not None else w.shape[-2]
         d.rows_per_image, d.src_rows_per_image, d.src_row_off = rows_per_image, src_rows_per_image, src_row_off
         d.dst_rows_per_image, d.dst_row_off = dst_rows_per_image, dst_row_off

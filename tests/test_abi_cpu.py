@@ -199,3 +199,73 @@ def test_round4_host_side_predicates_and_tables():
     got = ResNet50Engine._stem_bwd_table(wb, dtype=torch.float32)
     assert torch.equal(got, t.reshape(16, 1024))
     assert ResNet50Engine._stem_bwd_table(wb).dtype == torch.bfloat16
+
+
+def _signed_digits_to_int(frag_bytes, n_steps):
+    """fragment table [step][digit][lane][16] of int8 digits -> integer weights per (step, lane, byte)"""
+    import numpy as np
+    d = np.frombuffer(frag_bytes, dtype=np.int8).reshape(n_steps, 4, 64, 16).astype(np.int64)
+    return d[:, 0] + d[:, 1] * 256 + d[:, 2] * 65536 + d[:, 3] * 16777216
+
+
+def test_fixed_point_tables_of_the_matrix_core_stencils_match_the_oracle_weights():
+    """Round 5 host logic, no GPU: defocus_blur / gaussian_blur / glass_blur run as exact fixed-point filters on the i8 matrix cores.
+    rart_stencil_fixed_point_info hands out the tables the kernels consume; here they are decoded with the documented lane mapping
+    (include/robustart_hip.h) and compared with the oracle's weights: W / 2^frac_bits reproduces every tap to the stated error, taps
+    outside the kernel are zero, the ambiguity band covers the accumulated quantisation error of a whole output, and the 21 x 21 disk of
+    defocus severity 5 stays on the fp64 kernel."""
+    import ctypes
+    import numpy as np
+    from robustart_amd import _lib
+    from oracle import corruptions_np as O
+    lib = _lib.load()
+    names = O.CORRUPTION_NAMES
+    for name in ('defocus_blur', 'gaussian_blur', 'glass_blur'):
+        for sev in range(1, 6):
+            info = _lib.FixedPointInfo()
+            buf = (ctypes.c_ubyte * (9 * 4 * 64 * 16))()
+            rc = lib.rart_stencil_fixed_point_info(names.index(name), sev, ctypes.byref(info), buf, len(buf))
+            if name == 'defocus_blur' and sev == 5:
+                assert rc == 2 and info.kind == 0                   # RART_ERR_UNSUPPORTED: radius 10 -> 21 x 21
+                continue
+            assert rc == 0, (name, sev)
+            W = _signed_digits_to_int(bytes(buf)[:info.n_steps * 4 * 64 * 16], info.n_steps)        # [step][lane][byte]
+            lane = np.arange(64)
+            m, g = lane & 15, lane >> 4
+            if name == 'defocus_blur':
+                r, alias = O.PARAMS['defocus_blur'][sev - 1]
+                k = O.disk_kernel(r, alias).astype(np.float64)
+                assert info.kind == 1 and info.ksize == 17 == k.shape[0] and info.n_steps == 9 and info.out_frac_bits == info.frac_bits
+                F = info.frac_bits
+                want = np.zeros((9, 64, 16), np.int64)
+                for j in range(9):
+                    for i in range(16):
+                        a = 2 * j + (g >> 1)
+                        b = 16 * (g & 1) + i - m
+                        ok = (a < 17) & (b >= 0) & (b < 17)
+                        want[j, ok, i] = np.rint(k[a[ok], b[ok]] * 2.0 ** F).astype(np.int64)
+                np.testing.assert_array_equal(W, want)
+                err = np.abs(np.rint(k * 2.0 ** F) / 2.0 ** F - k)
+                assert err.max() <= 2.0 ** -(F + 1) and info.max_abs_weight_error == pytest.approx(err.max(), abs=1e-30)
+                assert info.corr == 128 * int(np.rint(k * 2.0 ** F).sum())
+                assert info.band >= 255.0 * err.sum() * 2.0 ** F                     # the band covers the worst-case quantisation error
+                assert info.band < 2.0 ** F * 1e-4                                   # ... and stays a 1e-4 sliver of an output step
+            else:
+                sigma = O.PARAMS['gaussian_blur'][sev - 1] if name == 'gaussian_blur' else O.PARAMS['glass_blur'][sev - 1][0]
+                radius = int(4.0 * sigma + 0.5)
+                w = O.gaussian_kernel1d(sigma, radius)
+                assert info.kind == 2 and info.ksize == 2 * radius + 1 and info.n_steps == 1 and (info.frac_bits, info.out_frac_bits) == (31, 38)
+                want = np.zeros((64, 16), np.int64)
+                for i in range(16):
+                    t = 16 * g + i - m
+                    ok = (t >= 0) & (t <= 2 * radius)
+                    want[ok, i] = np.rint(w[t[ok]] * 2.0 ** 31).astype(np.int64)
+                # the library's weights come from libm's exp and a sequential sum, numpy's from its own exp and a pairwise sum: equal to
+                # a few ulp, i.e. to one unit of 2^-31 at most
+                assert np.abs(W[0] - want).max() <= 1
+                assert (W[0][want == 0] == 0).all()
+                assert info.max_abs_weight_error <= 2.0 ** -32 and info.band * 2.0 ** -38 < 1e-5
+                assert info.band * 2.0 ** -38 >= 255.0 * 2 * info.sum_abs_weight_error
+    bad = _lib.FixedPointInfo()
+    assert lib.rart_stencil_fixed_point_info(names.index('zoom_blur'), 3, ctypes.byref(bad), None, 0) == 2
+    assert lib.rart_stencil_fixed_point_info(names.index('gaussian_blur'), 9, ctypes.byref(bad), None, 0) == 1      # RART_ERR_INVALID
