@@ -28,70 +28,9 @@
 // sign bits in the epilogue; column tiles of 64 / 128 / 256 so that the 64- and 128-channel layers do not pad their MFMA work.
 #include "rart_common.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+#include "rart_gemm_pair_dev.h"
 
 namespace {
-enum { GP_OUT_F32 = 2, GP_GELU = 4, GP_GELU_BWD = 8, GP_GELU_KEEP = 64, GP_RELU = 1, GP_W_INTERLEAVED = 16 };
-constexpr int GP_BK = 32;
-constexpr int GP_LDE = 68;                         // epilogue staging row (floats): 64 columns + 4
-
-struct GemmPairDev {
-  const uint16_t *a_hi, *a_lo, *w_hi, *w_lo;
-  const float* bias;
-  const uint16_t *res_hi, *res_lo;
-  uint16_t *dst_hi, *dst_lo;
-  uint16_t *aux_hi, *aux_lo;
-  int M, N, K, lda, ldw, ldc, w_rows;
-  int rpi, src_rpi, src_off, dst_rpi, dst_off, map_rows;
-  int flags, z_inner;
-  long long a_zo, a_zi, w_zo, w_zi, c_zo, c_zi;
-  // CONV instances: row grid, source / destination geometry, taps (k_per_tap / 32 a power of two: tap = kt >> tpt_shift)
-  int grid_h, grid_w, src_h, src_w, sy, sx, n_taps, tpt_shift;
-  int tap_dy[16], tap_dx[16];
-  int dst_h, dst_w, dst_sy, dst_sx, dst_oy, dst_ox;
-  uint32_t gw_magic, gw_shift, gh_magic, gh_shift;      // exact division by multiply-shift for dividends < 2^31
-  const uint8_t* mask_bits;                              // 1 bit per destination element (byte (off + col) / 8): v = 0 where clear
-  uint8_t* sign_out;                                     // receives (output hi plane > 0), same indexing
-};
-__device__ __forceinline__ uint32_t gp_fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
-  return (uint32_t)(((uint64_t)n * magic) >> shift);
-}
-
-__device__ __attribute__((aligned(16))) const uint32_t g_pair_zero16[4] = {0u, 0u, 0u, 0u};   // source of rows past M / N
-
-__device__ __forceinline__ uint32_t gp_pack_bf16x2(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
-  typedef __attribute__((ext_vector_type(2))) float f2_t;
-  typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
-  f2_t f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2_t));
-}
-// exact (erf) GELU, timm's nn.GELU default; libm's erff (~1 ulp): this path is the reference-precision one
-__device__ __forceinline__ float gp_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
-// d/du [u * Phi(u)] = Phi(u) + u * phi(u)
-__device__ __forceinline__ float gp_gelu_grad(float u) {
-  return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
-}
-__device__ __forceinline__ void gp_split8(const float* v, uint4& hi, uint4& lo) {
-  uint32_t h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    h[j] = gp_pack_bf16x2(v[2 * j], v[2 * j + 1]);
-    l[j] = gp_pack_bf16x2(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xFFFF0000u));
-  }
-  hi = make_uint4(h[0], h[1], h[2], h[3]);
-  lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-// hi + lo is exact in fp32 (two 8-bit significands, lo below half an ulp of hi)
-__device__ __forceinline__ void gp_join8(const uint4& hi, const uint4& lo, float* v) {
-  const uint32_t h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    v[2 * j] = __uint_as_float(h[j] << 16) + __uint_as_float(l[j] << 16);
-    v[2 * j + 1] = __uint_as_float(h[j] & 0xFFFF0000u) + __uint_as_float(l[j] & 0xFFFF0000u);
-  }
-}
-
 // TM x TN: the tile (rows 256 / 128, columns 256 / 128 / 64), TM / 32 waves (8 / 4) in a (NW / WN) x WN grid, WN = TN / 64; a wave owns
 // (TM / WM) rows x 64 columns.  The 256-row tiles are for the K-deep, MFMA-bound products (one workgroup per CU, 48 MFMAs per wave between
 // two barriers at TN = 256); the 128-row tiles (48-96 KB of LDS: two or three workgroups per CU whose load / multiply / store phases
@@ -274,145 +213,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
   }
 #undef RART_GP_ISSUE
 #undef RART_GP_DL
-  // ---- epilogue: per wave, 32 rows x 64 columns at a time through LDS -> 128-byte row segments per plane; residual / mask / GELU
-  //      operands of a pass are requested before its transposition
-  float* sE = reinterpret_cast<float*>(lds) + wave * 32 * GP_LDE;
-  uint32_t* const row_dst = reinterpret_cast<uint32_t*>(lds + GP_STAGING);      // CONV: destination element offset of tile row r, ~0 past M
-  if (CONV) {
-    if (tid < TM) {
-      const uint32_t m = (uint32_t)(m0 + tid);
-      uint32_t off = 0xFFFFFFFFu;
-      if (m < (uint32_t)d.M) {
-        const uint32_t t = gp_fastdiv(m, d.gw_magic, d.gw_shift);
-        const int ox = (int)(m - t * (uint32_t)d.grid_w);
-        const int n = (int)gp_fastdiv(t, d.gh_magic, d.gh_shift);
-        const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
-        off = (uint32_t)(((n * d.dst_h + (oy * d.dst_sy + d.dst_oy)) * d.dst_w + (ox * d.dst_sx + d.dst_ox)) * d.ldc);
-      }
-      row_dst[tid] = off;
-    }
-    __syncthreads();
-  }
-  const int cw = lane & 7, rw = lane >> 3;
-  const int col = n0 + wn * 64 + cw * 8;
-  const bool col_ok = col < d.N;
-  const int flags = d.flags;
-  const bool out_f32 = flags & GP_OUT_F32;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    long long eo[4];
-    uint4 rh[4], rl[4], uh[4], ul[4];
-    uint32_t mb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rt = wm * RW + i * 32 + q * 8 + rw;       // row inside the tile
-      const int m = m0 + rt;
-      eo[q] = -1;
-      rh[q] = rl[q] = uh[q] = ul[q] = make_uint4(0, 0, 0, 0);
-      mb[q] = 0xFFu;
-      if (m < d.M && col_ok) {
-        long long e;
-        if (CONV) {
-          e = (long long)row_dst[rt] + col;
-        } else {
-          long long drow = m;
-          if (d.map_rows) {
-            const int img = m / d.rpi;
-            drow = (long long)img * d.dst_rpi + (m - img * d.rpi);
-          }
-          e = c_off + (drow + d.dst_off) * d.ldc + col;
-        }
-        eo[q] = e;
-        if (d.res_hi) {
-          rh[q] = *reinterpret_cast<const uint4*>(d.res_hi + e);
-          rl[q] = *reinterpret_cast<const uint4*>(d.res_lo + e);
-        }
-        if (flags & GP_GELU_BWD) {
-          uh[q] = *reinterpret_cast<const uint4*>(d.aux_hi + e);
-          ul[q] = *reinterpret_cast<const uint4*>(d.aux_lo + e);
-        }
-        if (CONV && d.mask_bits) mb[q] = d.mask_bits[e >> 3];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sE[((r & 3) + 8 * (r >> 2) + 4 * h) * GP_LDE + j * 32 + fr] = acc[i][j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = q * 8 + rw;
-      const float4 v0 = *reinterpret_cast<const float4*>(sE + r * GP_LDE + cw * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(sE + r * GP_LDE + cw * 8 + 4);
-      const long long e = eo[q];
-      if (e >= 0) {
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        if (d.res_hi) {
-          float rv[8];
-          gp_join8(rh[q], rl[q], rv);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += rv[j];
-        }
-        if (flags & GP_GELU) {     // gelu of the value the PAIR of the pre-activation represents: the same result as GELU_KEEP's, so a forward-only
-          uint4 ph, pl;            // evaluation and the forward of a gradient evaluation agree bit for bit
-          gp_split8(v, ph, pl);
-          gp_join8(ph, pl, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gp_gelu(v[j]);
-        }
-        if (flags & GP_GELU_KEEP) {
-          // two outputs: the pre-activation pair u goes to `aux` (the backward's GELU' operand); dst receives gelu of the value the
-          // pair REPRESENTS, so forward and backward see the same u
-          uint4 ph, pl;
-          gp_split8(v, ph, pl);
-          *reinterpret_cast<uint4*>(d.aux_hi + e) = ph;
-          *reinterpret_cast<uint4*>(d.aux_lo + e) = pl;
-          gp_join8(ph, pl, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gp_gelu(v[j]);
-        }
-        if (flags & GP_GELU_BWD) {
-          float u[8];
-          gp_join8(uh[q], ul[q], u);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= gp_gelu_grad(u[j]);
-        }
-        if (CONV) {      // 1-bit ReLU mask of the destination (backward-to-input): bit k of the byte = column col + k
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (!((mb[q] >> j) & 1u)) v[j] = 0.f;
-        }
-        if (flags & GP_RELU) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        if (out_f32) {
-          float* o = reinterpret_cast<float*>(d.dst_hi) + e;
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          uint4 ph, pl;
-          gp_split8(v, ph, pl);
-          *reinterpret_cast<uint4*>(d.dst_hi + e) = ph;
-          *reinterpret_cast<uint4*>(d.dst_lo + e) = pl;
-          if (CONV && d.sign_out) {     // (hi plane > 0): a bf16 is > 0 exactly when its bits, read as int16, are > 0
-            const uint32_t hw[4] = {ph.x, ph.y, ph.z, ph.w};
-            uint32_t sb = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              sb |= ((short)(hw[j] & 0xFFFFu) > 0 ? 1u : 0u) << (2 * j);
-              sb |= ((short)(hw[j] >> 16) > 0 ? 1u : 0u) << (2 * j + 1);
-            }
-            d.sign_out[e >> 3] = (uint8_t)sb;
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
+  gp_epilogue<TM, TN, CONV, MI>(d, lds, acc, m0, n0, c_off);
 }
 
 void gp_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividends < 2^31
