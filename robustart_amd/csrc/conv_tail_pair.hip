@@ -184,6 +184,20 @@ __global__ __launch_bounds__(256, (C == 64 && !NEXT) ? 3 : 2) void k_conv3x3_tai
     bsrc_l[q] = reinterpret_cast<const char*>(d.w_lo + e);
   }
   const char* const zsrc = reinterpret_cast<const char*>(g_tail_zero16);
+  // round 5 (as in k_gemm_pair): what does not depend on the K step is formed once per lane -- the address of the row's pixel at tap (0, 0),
+  // one in-bounds bit per tap -- and the byte offset of tap t sits in lane t of `tapreg`
+  const char* abase[2];
+  uint32_t okmask[2] = {0u, 0u};
+  const int tapreg = lane < 9 ? (d.tap_dy[lane] * d.W + d.tap_dx[lane]) * (C * 2) : 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    abase[q] = reinterpret_cast<const char*>(d.a_hi) + (long long)(a_img[q] + a_y[q] * d.W + a_x[q]) * (C * 2) + a_cs[q];
+    for (int t = 0; t < 9; ++t) {
+      const int iy = a_y[q] + d.tap_dy[t], ix = a_x[q] + d.tap_dx[t];
+      if (a_ok[q] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) okmask[q] |= 1u << t;
+    }
+  }
+  const long long lo_delta = reinterpret_cast<const char*>(d.a_lo) - reinterpret_cast<const char*>(d.a_hi);
 #define RART_CT_DL(SRC, DST)                                                                                    \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                        \
                                    (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);
@@ -192,14 +206,12 @@ __global__ __launch_bounds__(256, (C == 64 && !NEXT) ? 3 : 2) void k_conv3x3_tai
     uint8_t* const st_ = lds + (BUF)*STAGE;                                                                     \
     const int kt_ = (KT_);                                                                                      \
     const int tap_ = kt_ >> TPT_SHIFT;                                                                          \
-    const int kcb_ = (kt_ - (tap_ << TPT_SHIFT)) * 64;                                                          \
-    const int dy_ = d.tap_dy[tap_], dx_ = d.tap_dx[tap_];                                                       \
+    const long long so_ = (long long)(__builtin_amdgcn_readlane(tapreg, tap_) + (kt_ - (tap_ << TPT_SHIFT)) * 64); \
     _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
-      const int iy_ = a_y[q] + dy_, ix_ = a_x[q] + dx_;                                                         \
-      const bool ok_ = a_ok[q] && (unsigned)iy_ < (unsigned)d.H && (unsigned)ix_ < (unsigned)d.W;               \
-      const long long bo_ = (long long)(a_img[q] + iy_ * d.W + ix_) * (C * 2) + kcb_ + a_cs[q];                 \
-      RART_CT_DL(ok_ ? reinterpret_cast<const char*>(d.a_hi) + bo_ : zsrc, st_ + (wave + 4 * q) * 1024)          \
-      RART_CT_DL(ok_ ? reinterpret_cast<const char*>(d.a_lo) + bo_ : zsrc, st_ + CT_PLANE_A + (wave + 4 * q) * 1024) \
+      const bool ok_ = (okmask[q] >> tap_) & 1u;                                                                \
+      const char* const ph_ = abase[q] + so_;                                                                   \
+      RART_CT_DL(ok_ ? ph_ : zsrc, st_ + (wave + 4 * q) * 1024)                                                 \
+      RART_CT_DL(ok_ ? ph_ + lo_delta : zsrc, st_ + CT_PLANE_A + (wave + 4 * q) * 1024)                         \
     }                                                                                                           \
     _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                                            \
       RART_CT_DL(bsrc_h[q] + (size_t)kt_ * 64, st_ + 2 * CT_PLANE_A + (wave + 4 * q) * 1024)                     \

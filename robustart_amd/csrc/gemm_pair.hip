@@ -110,6 +110,25 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
       asrc_l[q] = reinterpret_cast<const char*>(a_lo + e);
     }
   }
+  // CONV, round 5 (scratch/r5/time_pair_ts.py: the issue block of a K step took ~2 000 of its ~5 700 cycles, most of it the per-step
+  // address arithmetic of the eight loads -- tap table reads, 64-bit multiply-adds, bounds compares): everything that does not depend on
+  // the step is formed ONCE per lane -- the address of the row's pixel at tap (0, 0), one in-bounds bit per tap -- and the byte offset
+  // of tap t sits in lane t of `tapreg`, so a step is a v_readlane, two 64-bit adds and a select per row piece.
+  const char* abase[2] = {nullptr, nullptr};
+  uint32_t okmask[2] = {0u, 0u};
+  int tapreg = 0;
+  if (CONV) {
+    if (lane < d.n_taps) tapreg = (d.tap_dy[lane] * d.src_w + d.tap_dx[lane]) * d.lda * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      abase[q] = reinterpret_cast<const char*>(a_hi) + (long long)(a_img[q] + a_by[q] * d.src_w + a_bx[q]) * d.lda * 2 + a_cs[q];
+      for (int t = 0; t < d.n_taps; ++t) {
+        const int iy = a_by[q] + d.tap_dy[t], ix = a_bx[q] + d.tap_dx[t];
+        if (a_ok[q] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w) okmask[q] |= 1u << t;
+      }
+    }
+  }
+  const long long lo_delta = reinterpret_cast<const char*>(a_lo) - reinterpret_cast<const char*>(a_hi);
 #pragma unroll
   for (int q = 0; q < BQ; ++q) {
     const int r = 16 * (wave + NW * q) + (lane >> 2);
@@ -135,14 +154,12 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
     const int kt_ = (KT);                                                                                       \
     if (CONV) {                                                                                                 \
       const int tap_ = kt_ >> d.tpt_shift;                                                                      \
-      const int kcb_ = (kt_ - (tap_ << d.tpt_shift)) * 64;                                                      \
-      const int dy_ = d.tap_dy[tap_], dx_ = d.tap_dx[tap_];                                                     \
+      const long long so_ = (long long)(__builtin_amdgcn_readlane(tapreg, tap_) + (kt_ - (tap_ << d.tpt_shift)) * 64); \
       _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
-        const int iy_ = a_by[q] + dy_, ix_ = a_bx[q] + dx_;                                                     \
-        const bool ok_ = a_ok[q] && (unsigned)iy_ < (unsigned)d.src_h && (unsigned)ix_ < (unsigned)d.src_w;     \
-        const long long bo_ = (long long)(a_img[q] + iy_ * d.src_w + ix_) * d.lda * 2 + kcb_ + a_cs[q];         \
-        RART_GP_DL(ok_ ? reinterpret_cast<const char*>(a_hi) + bo_ : zsrc, st_ + (wave + NW * q) * 1024)         \
-        RART_GP_DL(ok_ ? reinterpret_cast<const char*>(a_lo) + bo_ : zsrc, st_ + GP_PLANE_A + (wave + NW * q) * 1024) \
+        const bool ok_ = (okmask[q] >> tap_) & 1u;                                                              \
+        const char* const ph_ = abase[q] + so_;                                                                 \
+        RART_GP_DL(ok_ ? ph_ : zsrc, st_ + (wave + NW * q) * 1024)                                              \
+        RART_GP_DL(ok_ ? ph_ + lo_delta : zsrc, st_ + GP_PLANE_A + (wave + NW * q) * 1024)                      \
       }                                                                                                         \
     } else {                                                                                                    \
       const size_t ko_ = (size_t)kt_ * 64;                                                                      \
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
     {                                                                                                           \
       const size_t ko_ = (size_t)kt_ * w_step;                                                                  \
       _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                                          \
-        if (wave + NW * q < B_PIECES) {                                                                         \
+        if (NW * q + NW <= B_PIECES || wave + NW * q < B_PIECES) {   /* (first half: compile time, no branch) */  \
           RART_GP_DL(bsrc_h[q] ? bsrc_h[q] + ko_ : zsrc, st_ + 2 * GP_PLANE_A + (wave + NW * q) * 1024)          \
           RART_GP_DL(bsrc_l[q] ? bsrc_l[q] + ko_ : zsrc, st_ + 2 * GP_PLANE_A + PLANE_B + (wave + NW * q) * 1024) \
         }                                                                                                       \
