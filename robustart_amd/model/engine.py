@@ -199,9 +199,11 @@ class ResNet50Engine:
             self.fc_wd = _bf16(torch.cat([wt, wtl, wt], 1)).to(dev)       # [2048][3 * 1024]
         self._buf = {}
         self.profile = None      # set to a list to record (flops, start_event, end_event) per GEMM launch
-        # round 5: the pair GEMM's weight tables with the hi and the lo slice of a 32-deep K step side by side (one 128-byte line per row and
-        # step instead of two half lines K apart): 2-5 % per K-deep launch (profiles/r05_pair_knockouts.txt); RART_PAIR_WIL=0 = two planes
-        self.pair_w_interleaved = _os.environ.get('RART_PAIR_WIL', '1') == '1'
+        # round 5 experiment, OFF by default: the pair GEMM's weight tables with the hi and the lo slice of a 32-deep K step side by side (one
+        # 128-byte line per row and step instead of two half lines K apart).  2-5 % per K-deep launch when a shape is replayed back to back
+        # (profiles/r05_pair_knockouts.txt), nothing on the whole gradient evaluation (20.61 vs 20.63 ms) and +0.9 % on the forward
+        # (scratch/r5/ab_engine_x3.py): the isolated replay keeps the tables hot in L2, the network does not.  RART_PAIR_WIL=1 turns it on.
+        self.pair_w_interleaved = _os.environ.get('RART_PAIR_WIL', '0') == '1'
         self._w_il = {}
         if not split:
             self._pack_frag_tables()

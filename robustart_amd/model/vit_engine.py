@@ -44,7 +44,7 @@ class ViTEngine:
         self.D, self.H, self.ps = m.embed_dim, m.num_heads, m.patch_size
         self.hd = self.D // self.H
         import os as _os
-        self.pair_w_interleaved = _os.environ.get('RART_PAIR_WIL', '1') == '1'     # see engine.py: weight tables interleaved per K step
+        self.pair_w_interleaved = _os.environ.get('RART_PAIR_WIL', '0') == '1'     # see engine.py: weight tables interleaved per K step
         self._w_il = {}
         self.refold(model)
         self._buf = {}
