@@ -151,6 +151,12 @@ size_t gauss_fused_lds(int r) {
 // time t row index a (h = 224-d-a) handles column index b = t - a*S.  Operations issued in the same time step are >= S columns
 // apart (no conflict) and every earlier-in-scan conflicting operation has a strictly smaller time ((a'-a)*S + (b'-b) >= S - d).
 // One workgroup per image, image resident in LDS.
+// Round 5 tried to take work out of the chain (scratch/r5/glass_offsets_prepass.patch, all variants bit-identical, us per 256 images at
+// severity 3 for the whole corruption; this kernel: 1 197): the (dx, dy) draws by a parallel pre-pass, the chain only copying, two waves
+// and a barrier per step 1 322; one wave per image, no barrier, four row slots per lane 1 637; the same with the four slots' reads
+// issued before their writes 1 972.  A time step is bound by its dependent chain (offset -> LDS read -> LDS write) and by instruction
+// issue per row slot, not by the Threefry call or the barrier: more lanes per step is what helps, and 128 threads x <= 2 rows is where
+// the 222 rows run out.
 constexpr int kGlassThreads = 128;
 
 __global__ __launch_bounds__(kGlassThreads) void k_glass_shuffle(uint8_t* __restrict__ img_all, int delta, int iters,
