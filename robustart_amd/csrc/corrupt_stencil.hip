@@ -155,9 +155,9 @@ size_t gauss_fused_lds(int r) {
 // severity 3 for the whole corruption; this kernel: 1 197): the (dx, dy) draws by a parallel pre-pass, the chain only copying, two waves
 // and a barrier per step 1 322; one wave per image, no barrier, four row slots per lane 1 637; the same with the four slots' reads
 // issued before their writes 1 972.  A time step is bound by its dependent chain (offset -> LDS read -> LDS write) and by instruction
-// issue per row slot, not by the Threefry call or the barrier: more lanes per step is what helps, and 128 threads x <= 2 rows is where
+// issue per row slot, not by the Threefry call or the barrier: more lanes per step is what helps (256 threads, one row each: 1 154), and that is where
 // the 222 rows run out.
-constexpr int kGlassThreads = 128;
+constexpr int kGlassThreads = 256;
 
 __global__ __launch_bounds__(kGlassThreads) void k_glass_shuffle(uint8_t* __restrict__ img_all, int delta, int iters,
                                                                  const int8_t* __restrict__ inj, uint32_t k0,
