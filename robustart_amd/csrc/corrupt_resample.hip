@@ -306,9 +306,11 @@ __global__ __launch_bounds__(kBlock) void k_zoom_blur(const uint8_t* __restrict_
 // workgroup barrier inside the (row, zoom) loop.  Measured on the way (us per 256 images, severity 3; all bit-identical): rounds 1-4's
 // per-pixel kernel 620-780; per-pixel gathers with the tables 465; one L row per workgroup with two __syncthreads per (row, zoom) 574;
 // this version 454; the same with a bank-replicated 64 KiB LUT 676 (occupancy); L in registers fetched by cross-lane reads with the
-// zoom loop's loads free to move: 444 VGPRs or spills.  The kernel is bound by the dependent chain table entry -> row bytes -> LUT per
-// (row, zoom) at 12 waves per CU, not by arithmetic (~55 VALU operations per pixel and zoom).  The per-column tables live in registers
-// (the zoom loop is unrolled over the 16 possible factors).
+// zoom loop's loads free to move: 444 VGPRs or spills; this version with the strip's source rows staged in LDS (no global load inside the
+// loop) 459.  The last one settles what binds it: instruction issue -- 440 us are ~94 issue slots per wave and (row, zoom), of which 24
+// are the arithmetic the reference prescribes (18 fp64 operations, 3 casts, 3 fp32 adds) and 12 the LUT reads; the rest is byte
+// extraction, LUT / L address arithmetic and wave fences.  The per-column tables live in registers (the zoom loop is unrolled over the 16
+// possible factors).
 constexpr int ZB_ROWS = 8, ZB_WCOLS = 56;
 
 __global__ void k_zoom_table(double* __restrict__ tt, uint32_t* __restrict__ ii, int h, ZoomParams zp) {
