@@ -306,11 +306,11 @@ __global__ __launch_bounds__(kBlock) void k_zoom_blur(const uint8_t* __restrict_
 // workgroup barrier inside the (row, zoom) loop.  Measured on the way (us per 256 images, severity 3; all bit-identical): rounds 1-4's
 // per-pixel kernel 620-780; per-pixel gathers with the tables 465; one L row per workgroup with two __syncthreads per (row, zoom) 574;
 // this version 454; the same with a bank-replicated 64 KiB LUT 676 (occupancy); L in registers fetched by cross-lane reads with the
-// zoom loop's loads free to move: 444 VGPRs or spills; this version with the strip's source rows staged in LDS (no global load inside the
-// loop) 459.  The last one settles what binds it: instruction issue -- 440 us are ~94 issue slots per wave and (row, zoom), of which 24
-// are the arithmetic the reference prescribes (18 fp64 operations, 3 casts, 3 fp32 adds) and 12 the LUT reads; the rest is byte
-// extraction, LUT / L address arithmetic and wave fences.  The per-column tables live in registers (the zoom loop is unrolled over the 16
-// possible factors).
+// zoom loop's loads free to move: 444 VGPRs or spills; this version with the strip's source rows staged in LDS, i.e. no global load
+// inside the loop: 459 (not kept).  The last one settles what binds the kernel: instruction issue -- 440 us are ~94 issue slots per wave
+// and (row, zoom), of which 24 are the arithmetic the reference prescribes (18 fp64 operations, 3 casts, 3 fp32 adds) and 12 the LUT
+// reads; the rest is byte extraction, LUT / L address arithmetic and the wave fences.  The per-column tables live in registers (the zoom
+// loop is unrolled over the 16 possible factors).
 constexpr int ZB_ROWS = 8, ZB_WCOLS = 56;
 
 __global__ void k_zoom_table(double* __restrict__ tt, uint32_t* __restrict__ ii, int h, ZoomParams zp) {
@@ -325,19 +325,11 @@ __global__ void k_zoom_table(double* __restrict__ tt, uint32_t* __restrict__ ii,
   ii[z * 224 + o] = (uint32_t)i0 | ((uint32_t)i1 << 16);
 }
 
-struct ZoomStrips {            // source rows a strip of ZB_ROWS output rows reads, over every zoom factor (host-computed, one row of slack)
-  uint8_t lo[224 / ZB_ROWS], cnt[224 / ZB_ROWS];
-};
-constexpr int ZB_MAXSRC = 48;  // rows of the widest strip this kernel accepts (8 + 2 + the spread of the crops' offsets)
-
 __global__ __launch_bounds__(kBlock) void k_zoom_blur_rows(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                            const double* __restrict__ g_tt, const uint32_t* __restrict__ g_ii,
-                                                           ZoomParams zp, ZoomStrips zs) {
+                                                           ZoomParams zp) {
   __shared__ double lut[256];
   __shared__ double Lw[4][2][64 * 3];
-  __shared__ double ytt[ZB_ROWS * 16];
-  __shared__ uint32_t yii[ZB_ROWS * 16];
-  __shared__ __attribute__((aligned(16))) uint8_t srows[ZB_MAXSRC * 672 + 16];    // the strip's source rows: every tap of the loop reads LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool col = lane < ZB_WCOLS;
@@ -354,19 +346,9 @@ __global__ __launch_bounds__(kBlock) void k_zoom_blur_rows(const uint8_t* __rest
       xir[z] = g_ii[z * 224 + xo];
     }
   }
+  __syncthreads();
   const uint8_t* img = in + (size_t)blockIdx.y * (224 * 224 * 3);
   uint8_t* dst = out + (size_t)blockIdx.y * (224 * 224 * 3);
-  const int r_lo = zs.lo[blockIdx.x], r_cnt = zs.cnt[blockIdx.x];
-  for (int i = tid; i < r_cnt * 42; i += kBlock)
-    reinterpret_cast<uint4*>(srows)[i] = reinterpret_cast<const uint4*>(img + (size_t)r_lo * 672)[i];
-  if (tid < ZB_ROWS * 16) {
-    const int rr = tid >> 4, z = tid & 15;
-    if (z < zp.count) {
-      ytt[tid] = g_tt[z * 224 + blockIdx.x * ZB_ROWS + rr];
-      yii[tid] = g_ii[z * 224 + blockIdx.x * ZB_ROWS + rr];
-    }
-  }
-  __syncthreads();
   const float denom = (float)(zp.count + 1);
   for (int row = 0; row < ZB_ROWS; ++row) {
     const int yo = blockIdx.x * ZB_ROWS + row;
@@ -375,20 +357,21 @@ __global__ __launch_bounds__(kBlock) void k_zoom_blur_rows(const uint8_t* __rest
     for (int z = 0; z < 16; ++z) {
       if (z < zp.count) {
         const int top = zp.top[z], ch = zp.ch[z];
-        const uint32_t yi = yii[row * 16 + z];
-        const double ty = ytt[row * 16 + z], omty = 1.0 - ty;
+        const uint32_t yi = g_ii[z * 224 + yo];
+        const double ty = g_tt[z * 224 + yo], omty = 1.0 - ty;
         const int y0 = (int)(yi & 0xFFFFu), y1 = (int)(yi >> 16);
         const int x0 = (int)(xir[z] & 0xFFFFu), x1 = (int)(xir[z] >> 16);
         const int xs0 = __builtin_amdgcn_readfirstlane(x0);           // first source column this wave reads
         double* Lb = Lw[wave][z & 1];
         const int xs = xs0 + lane;                                     // L phase: lane -> source column (<= 57 of them are read)
         if (xs < ch) {
-          // the 3 bytes of source pixel (top + xs) of both rows from the strip's rows in LDS: two aligned dwords and a funnel shift each
-          const int bo = (top + xs) * 3, o0 = (top + y0 - r_lo) * 672 + bo, o1 = (top + y1 - r_lo) * 672 + bo;
-          const uint32_t* w0 = reinterpret_cast<const uint32_t*>(srows + (o0 & ~3));
-          const uint32_t* w1 = reinterpret_cast<const uint32_t*>(srows + (o1 & ~3));
-          const uint32_t u0 = (uint32_t)((((uint64_t)w0[1] << 32) | w0[0]) >> (8 * (o0 & 3)));
-          const uint32_t u1 = (uint32_t)((((uint64_t)w1[1] << 32) | w1[0]) >> (8 * (o1 & 3)));
+          // the 3 bytes of source pixel (top + xs) of both rows as one 4-byte load each that never leaves the image row (672 bytes)
+          const int bo = (top + xs) * 3, ba = bo > 668 ? 668 : bo, sh = (bo - ba) * 8;
+          uint32_t u0, u1;
+          __builtin_memcpy(&u0, img + (size_t)(top + y0) * 672 + ba, 4);
+          __builtin_memcpy(&u1, img + (size_t)(top + y1) * 672 + ba, 4);
+          u0 >>= sh;
+          u1 >>= sh;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const double a0 = lut[(u0 >> (8 * c)) & 0xFFu], a1 = lut[(u1 >> (8 * c)) & 0xFFu];
@@ -499,34 +482,11 @@ int rart_launch_resample(int id, const RartCorruptArgs& a) {
     if (a.h == 224 && a.w == 224 && a.n <= 65535 && a.workspace && getenv("RART_ZOOM_DIRECT") == nullptr) {
       double* tt = (double*)a.workspace;
       uint32_t* ii = (uint32_t*)(tt + 16 * 224);
-      // source rows of every strip of ZB_ROWS output rows over all zoom factors: k_zoom_table's expressions on the host, one row of slack
-      ZoomStrips zs;
-      bool fits = true;
-      for (int sidx = 0; sidx < 224 / ZB_ROWS; ++sidx) {
-        int lo = 223, hi = 0;
-        for (int z = 0; z < zp.count; ++z)
-          for (int o = sidx * ZB_ROWS; o < (sidx + 1) * ZB_ROWS; ++o) {
-            const int ch = zp.ch[z], on = zp.out_n[z];
-            const double sc = on > 1 ? (double)((long long)(o + zp.trim[z]) * (ch - 1)) / (double)(on - 1) : 0.0;
-            int i0 = (int)floor(sc);
-            i0 = i0 < 0 ? 0 : (i0 > ch - 1 ? ch - 1 : i0);
-            const int i1 = i0 + 1 < ch ? i0 + 1 : ch - 1;
-            lo = zp.top[z] + i0 < lo ? zp.top[z] + i0 : lo;
-            hi = zp.top[z] + i1 > hi ? zp.top[z] + i1 : hi;
-          }
-        lo = lo > 0 ? lo - 1 : 0;
-        hi = hi < 223 ? hi + 1 : 223;
-        zs.lo[sidx] = (uint8_t)lo;
-        zs.cnt[sidx] = (uint8_t)(hi - lo + 1);
-        fits = fits && hi - lo + 1 <= ZB_MAXSRC;
-      }
-      if (fits && ((uintptr_t)a.in & 15) == 0) {
-        hipLaunchKernelGGL(k_zoom_table, dim3(zp.count), dim3(256), 0, a.stream, tt, ii, a.h, zp);
-        hipLaunchKernelGGL(k_zoom_blur_rows, dim3(224 / ZB_ROWS, a.n), dim3(kBlock), 0, a.stream, a.in, a.out, (const double*)tt,
-                           (const uint32_t*)ii, zp, zs);
-        RART_CHECK_LAUNCH("zoom_blur");
-        return RART_OK;
-      }
+      hipLaunchKernelGGL(k_zoom_table, dim3(zp.count), dim3(256), 0, a.stream, tt, ii, a.h, zp);
+      hipLaunchKernelGGL(k_zoom_blur_rows, dim3(224 / ZB_ROWS, a.n), dim3(kBlock), 0, a.stream, a.in, a.out, (const double*)tt,
+                         (const uint32_t*)ii, zp);
+      RART_CHECK_LAUNCH("zoom_blur");
+      return RART_OK;
     }
     hipLaunchKernelGGL(k_zoom_blur, dim3(rart_grid_for((size_t)a.n * a.h * a.w, kBlock, 256 * 16)), dim3(kBlock), 0,
                        a.stream, a.in, a.out, a.n, a.h, a.w, zp);
