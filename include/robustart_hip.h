@@ -104,11 +104,12 @@ int rart_noise_multi_u8(const uint8_t* in, uint8_t* const* outs, int ns, int n, 
                         const uint64_t* seeds, uint64_t sample_offset, rart_stream_t stream);
 
 /* Host-only introspection of the fixed-point tables behind the matrix-core stencil paths (round 5; no GPU needed: the "-m 'not gpu'"
- * tests check the tables against the oracle's weights).  defocus_blur severities 1-4 (corruptions.py:187-198: 17 x 17 disk) run as an
+ * tests check the tables against the oracle's weights).  defocus_blur (corruptions.py:187-198: 17 x 17 disks, 21 x 21 at severity 5) runs as an
  * exact 2-D integer filter, gaussian_blur (corruptions.py:162-166) and glass_blur's two blurs (corruptions.py:169-184) as an exact
  * separable one: W = round(w 2^frac_bits) split into four signed base-256 digits laid out as v_mfma_i32_16x16x64_i8 A-operand
  * fragments -- fragment (step j, digit d), lane (m = lane & 15, g = lane >> 4), byte i:
- *   kind 1 (2-D):       kernel row 2 j + (g >> 1), window column 16 (g & 1) + i, tap b = column - m      (n_steps = 9)
+ *   kind 1 (2-D):       kernel row 2 j + (g >> 1), window column 16 (g & 1) + i, tap b = column - m; rows m >= 33 - ksize are zero
+ *                       (n_steps = (ksize + 1) / 2: 9 for 17 x 17, 11 for 21 x 21 whose row blocks hold 12 outputs)
  *   kind 2 (separable): tap t = 16 g + i - m of the 1-D kernel                                            (n_steps = 1)
  * An output whose fixed-point value lies within `band` units (of 2^-out_frac_bits of an output step) of an integer is recomputed in the
  * reference's fp64 order.  blur_index: 0 for defocus_blur / gaussian_blur; glass_blur has one sigma, index 0.

@@ -300,81 +300,99 @@ size_t filter2d_lds(int ksz) {
 //     the reference's order from the same LDS tile -- bit-identical to k_filter2d.  Random images flag nothing; flat regions pay the old rate.
 // Output identical to k_filter2d's on every input (tests/test_corruptions_gpu.py::test_defocus_fast_path_equals_the_ordered_fp64_kernel).
 typedef __attribute__((ext_vector_type(4))) int i32x4;
-constexpr int FI_TH = 32, FI_RH = FI_TH + 17, FI_RS = 240, FI_STEPS = 9, FI_XT = 14;     // 224 = 7 strips x 32 rows = 14 column tiles x 16
-constexpr int FI_PLANES = 3 * FI_RH * FI_RS;                      // 35 280 B: q = p - 128, [channel][row][x + 8]
-constexpr int FI_OUT = FI_TH * 224 * 3;                           // 21 504 B: the strip's output, NHWC
-constexpr int FI_TILES = 3 * 2 * FI_XT;                           // 84 tile-channels per strip
-constexpr size_t FI_LDS = FI_PLANES + FI_OUT + 256 * sizeof(double) + (FI_TILES + 4) * sizeof(int);
+typedef int i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+// KSZ x KSZ kernel, MOUT outputs per MFMA row block (MOUT + KSZ - 1 = 32 = the window two kernel rows share one K = 64 step over):
+// 17 x 17 -> 16 outputs (14 column tiles, 9 row pairs, 16-byte aligned window reads); 21 x 21 (severity 5) -> 12 outputs (19 column tiles,
+// 11 row pairs, the window starts every 12 bytes: 4-byte aligned reads, rows 4 of 16 of the result block unused).
+template <int KSZ, int MOUT>
+struct FiCfg {
+  static constexpr int R = KSZ / 2, TH = 32, RH = TH + KSZ, STEPS = (KSZ + 1) / 2, XT = (224 + MOUT - 1) / MOUT;
+  static constexpr int RS = MOUT == 16 ? 240 : 252;                  // bytes per staged row: x = -R .. ; 4 x odd for the 4-byte reads
+  static constexpr int PLANES = 3 * RH * RS, PLANES_PAD = (PLANES + 15) / 16 * 16;
+  static constexpr int OUT = TH * 224 * 3, TILES = 3 * 2 * XT;
+  static constexpr size_t LDS = PLANES_PAD + OUT + 256 * sizeof(double) + (TILES + 4) * sizeof(int);
+  static_assert(MOUT + KSZ - 1 == 32, "two kernel rows of a 32-pixel window per K = 64 step");
+  static_assert((XT - 1) * MOUT + 31 + 1 <= RS, "the last column tile's window stays inside the staged row");
+};
+constexpr int FI_TH = 32, FI_STEPS = 9;                               // (17 x 17: what rart_stencil_fixed_point_info reports)
 struct FilterI8Meta {
   int F;
   long long corr, band;
 };
 
+template <int KSZ, int MOUT>
 __global__ __launch_bounds__(kBlock, 2) void k_filter2d_i8(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                            const uint4* __restrict__ frags, const double* __restrict__ kern,
                                                            FilterI8Meta meta) {
+  using C = FiCfg<KSZ, MOUT>;
   extern __shared__ __attribute__((aligned(16))) uint8_t fi_lds[];
   uint8_t* const sP = fi_lds;
-  uint8_t* const sO = fi_lds + FI_PLANES;
-  double* const lut = reinterpret_cast<double*>(fi_lds + FI_PLANES + FI_OUT);
+  uint8_t* const sO = fi_lds + C::PLANES_PAD;
+  double* const lut = reinterpret_cast<double*>(fi_lds + C::PLANES_PAD + C::OUT);
   int* const sList = reinterpret_cast<int*>(lut + 256);           // [0] = count, [1 ..] = flagged tile-channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int y0 = blockIdx.x * FI_TH;
+  const int y0 = blockIdx.x * C::TH;
   const size_t img = blockIdx.y;
-  // the 36 weight fragments of this lane (same for every tile): requested first, consumed after the staging
-  i32x4 A[FI_STEPS][4];
+  // the weight fragments of this lane (same for every tile): requested first, consumed after the staging
+  i32x4 A[C::STEPS][4];
 #pragma unroll
-  for (int j = 0; j < FI_STEPS; ++j)
+  for (int j = 0; j < C::STEPS; ++j)
 #pragma unroll
     for (int k = 0; k < 4; ++k) A[j][k] = __builtin_bit_cast(i32x4, frags[(j * 4 + k) * 64 + lane]);
   lut[tid] = (double)tid / 255.0;
   if (tid == 0) sList[0] = 0;
-  // ---- stage rows y0 - 8 .. y0 + 40 (reflect-101) as three byte planes
+  // ---- stage rows y0 - R .. y0 + TH + R (reflect-101) as three byte planes, x = -R at byte 0 of a row
   const uint8_t* base = in + img * (size_t)(224 * 224 * 3);
-  for (int i = tid; i < FI_RH * 42; i += kBlock) {
+  for (int i = tid; i < C::RH * 42; i += kBlock) {
     const int ry = i / 42, cx = i - ry * 42;
-    const int yy = reflect101(y0 - 8 + ry, 224);
+    const int yy = reflect101(y0 - C::R + ry, 224);
     const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)yy * 672 + cx * 16);
     const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
     int e = cx * 16, px = e / 3, c = e - px * 3;
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
-      sP[(c * FI_RH + ry) * FI_RS + px + 8] = (uint8_t)(((wv[b >> 2] >> (8 * (b & 3))) & 0xFFu) ^ 0x80u);
+      sP[(c * C::RH + ry) * C::RS + px + C::R] = (uint8_t)(((wv[b >> 2] >> (8 * (b & 3))) & 0xFFu) ^ 0x80u);
       if (++c == 3) { c = 0; ++px; }
     }
   }
   __syncthreads();
-  for (int i = tid; i < 3 * FI_RH * 16; i += kBlock) {               // x halos: x = -8 .. -1 <- p[-x], x = 224 .. 231 <- p[446 - x]
-    const int row = i >> 4, k = i & 15;
-    uint8_t* r = sP + row * FI_RS;
-    if (k < 8) r[k] = r[8 + (8 - k)];
-    else r[8 + 224 + (k - 8)] = r[8 + 222 - (k - 8)];
+  constexpr int HALO = C::RS - 224;                                  // R bytes left of x = 0, the rest right of x = 223
+  for (int i = tid; i < 3 * C::RH * HALO; i += kBlock) {             // x = -k <- p[k]; x = 223 + k <- p[223 - k]
+    const int row = i / HALO, k = i - row * HALO;
+    uint8_t* r = sP + row * C::RS;
+    if (k < C::R) r[k] = r[C::R + (C::R - k)];
+    else r[C::R + 224 + (k - C::R)] = r[C::R + 222 - (k - C::R)];
   }
   __syncthreads();
   // ---- fast path: tile-channel tc = (channel, row block, column tile); lane = (n = output row of the block, g = K group)
   const int n = lane & 15, g = lane >> 4;
   const long long one = 1ll << meta.F;
-  for (int tc = wave; tc < FI_TILES; tc += 4) {
-    const int c = tc % 3, rest = tc / 3, blk = rest / FI_XT, xt = rest - blk * FI_XT;
-    const uint8_t* pb = sP + (c * FI_RH + blk * 16 + n + (g >> 1)) * FI_RS + xt * 16 + 16 * (g & 1);
+  for (int tc = wave; tc < C::TILES; tc += 4) {
+    const int c = tc % 3, rest = tc / 3, blk = rest / C::XT, xt = rest - blk * C::XT;
+    const uint8_t* pb = sP + (c * C::RH + blk * 16 + n + (g >> 1)) * C::RS + xt * MOUT + 16 * (g & 1);
     i32x4 acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = (i32x4){0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < FI_STEPS; ++j) {
-      const i32x4 B = *reinterpret_cast<const i32x4*>(pb + 2 * j * FI_RS);
+    for (int j = 0; j < C::STEPS; ++j) {
+      i32x4 B;
+      if (MOUT == 16) B = *reinterpret_cast<const i32x4*>(pb + 2 * j * C::RS);
+      else B = *reinterpret_cast<const i32x4_a4*>(pb + 2 * j * C::RS);
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[j][k], B, acc[k], 0, 0, 0);
     }
     bool flag = false;
-    uint8_t* o = sO + ((blk * 16 + n) * 224 + xt * 16 + 4 * g) * 3 + c;
+    const int xo = xt * MOUT + 4 * g;
+    uint8_t* o = sO + ((blk * 16 + n) * 224 + xo) * 3 + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const long long T = (long long)acc[0][r] + (long long)acc[1][r] * 256ll + (long long)acc[2][r] * 65536ll +
-                          (long long)acc[3][r] * 16777216ll + meta.corr;
-      const long long fl = T >> meta.F, fr = T - (fl << meta.F);
-      flag |= T != 0 && (fr < meta.band || fr > one - meta.band);
-      o[3 * r] = (uint8_t)(T <= 0 ? 0 : (fl > 255 ? 255 : fl));
+      if (4 * g + r < MOUT && xo + r < 224) {                          // (MOUT = 12: the fourth row group of the block is unused)
+        const long long T = (long long)acc[0][r] + (long long)acc[1][r] * 256ll + (long long)acc[2][r] * 65536ll +
+                            (long long)acc[3][r] * 16777216ll + meta.corr;
+        const long long fl = T >> meta.F, fr = T - (fl << meta.F);
+        flag |= T != 0 && (fr < meta.band || fr > one - meta.band);
+        o[3 * r] = (uint8_t)(T <= 0 ? 0 : (fl > 255 ? 255 : fl));
+      }
     }
     if (__ballot(flag) != 0ull && lane == 0) sList[1 + atomicAdd(&sList[0], 1)] = tc;
   }
@@ -383,39 +401,43 @@ __global__ __launch_bounds__(kBlock, 2) void k_filter2d_i8(const uint8_t* __rest
   const int nflag = sList[0];
   for (int i = 0; i < nflag; ++i) {
     const int tc = sList[1 + i];
-    const int c = tc % 3, rest = tc / 3, blk = rest / FI_XT, xt = rest - blk * FI_XT;
+    const int c = tc % 3, rest = tc / 3, blk = rest / C::XT, xt = rest - blk * C::XT;
     const int ty = tid >> 4, tx = tid & 15;
-    const uint8_t* pb = sP + (c * FI_RH + blk * 16 + ty) * FI_RS + xt * 16 + tx;
-    double acc = 0.0;
-    for (int a = 0; a < 17; ++a) {
-      const uint8_t* row = pb + a * FI_RS;
-      const double* kr = kern + a * 17;
+    if (tx < MOUT && xt * MOUT + tx < 224) {
+      const uint8_t* pb = sP + (c * C::RH + blk * 16 + ty) * C::RS + xt * MOUT + tx;
+      double acc = 0.0;
+      for (int a = 0; a < KSZ; ++a) {
+        const uint8_t* row = pb + a * C::RS;
+        const double* kr = kern + a * KSZ;
 #pragma unroll
-      for (int b = 0; b < 17; ++b) {
-        const double t = lut[row[b] ^ 0x80u] * kr[b];
-        acc += t;
+        for (int b = 0; b < KSZ; ++b) {
+          const double t = lut[row[b] ^ 0x80u] * kr[b];
+          acc += t;
+        }
       }
+      const double cl = acc < 0.0 ? 0.0 : (acc > 1.0 ? 1.0 : acc);
+      sO[((blk * 16 + ty) * 224 + xt * MOUT + tx) * 3 + c] = (uint8_t)(uint32_t)(cl * 255.0);
     }
-    const double cl = acc < 0.0 ? 0.0 : (acc > 1.0 ? 1.0 : acc);
-    sO[((blk * 16 + ty) * 224 + xt * 16 + tx) * 3 + c] = (uint8_t)(uint32_t)(cl * 255.0);
   }
   __syncthreads();
   uint4* dst = reinterpret_cast<uint4*>(out + img * (size_t)(224 * 224 * 3) + (size_t)y0 * 672);
   const uint4* so4 = reinterpret_cast<const uint4*>(sO);
-  for (int i = tid; i < FI_OUT / 16; i += kBlock) dst[i] = so4[i];
+  for (int i = tid; i < C::OUT / 16; i += kBlock) dst[i] = so4[i];
 }
 
 // Host side of the fast path: the fixed-point weights, their four signed base-256 digits as MFMA A-operand fragments
 // (fragment (pair j, digit k), lane (m = lane & 15, g = lane >> 4), byte i: kernel row 2 j + (g >> 1), window column 16 (g & 1) + i ->
 // tap b = column - m), the constant 128 sum W and the ambiguity band.
 struct FilterI8Host {
-  std::vector<uint8_t> frags;        // [FI_STEPS][4][64][16]
+  std::vector<uint8_t> frags;        // [steps][4][64][16]
   FilterI8Meta meta;
+  int steps = 0, mout = 0;
   bool ok = false;
 };
 FilterI8Host make_filter_i8(const std::vector<double>& kern, int ksz) {
   FilterI8Host h;
-  if (ksz != 17) return h;
+  if (ksz != 17 && ksz != 21) return h;
+  const int mout = 33 - ksz, steps = (ksz + 1) / 2;
   double wmax = 0.0;
   for (double v : kern) {
     if (v < 0.0) return h;                       // the digit split below assumes non-negative weights (every disk is)
@@ -434,13 +456,13 @@ FilterI8Host make_filter_i8(const std::vector<double>& kern, int ksz) {
     sumW += W[i];
     dq += fabs(ldexp((double)W[i], -F) - kern[i]);
   }
-  h.frags.assign((size_t)FI_STEPS * 4 * 64 * 16, 0);
-  for (int j = 0; j < FI_STEPS; ++j)
+  h.frags.assign((size_t)steps * 4 * 64 * 16, 0);
+  for (int j = 0; j < steps; ++j)
     for (int lane = 0; lane < 64; ++lane) {
       const int m = lane & 15, g = lane >> 4, a = 2 * j + (g >> 1);
       for (int i = 0; i < 16; ++i) {
         const int b = 16 * (g & 1) + i - m;
-        long long w = (a < 17 && b >= 0 && b < 17) ? W[(size_t)a * 17 + b] : 0;
+        long long w = (m < mout && a < ksz && b >= 0 && b < ksz) ? W[(size_t)a * ksz + b] : 0;
         for (int k = 0; k < 4; ++k) {
           const long long lo = ((w + 128) & 255) - 128;     // signed digit in [-128, 127]
           h.frags[(((size_t)(j * 4 + k) * 64 + lane) * 16) + i] = (uint8_t)(int8_t)lo;
@@ -452,6 +474,8 @@ FilterI8Host make_filter_i8(const std::vector<double>& kern, int ksz) {
   h.meta.F = F;
   h.meta.corr = 128 * sumW;
   h.meta.band = (long long)ceil(ldexp(255.0 * dq + 1e-9, F)) + 1;
+  h.steps = steps;
+  h.mout = mout;
   h.ok = true;
   return h;
 }
@@ -872,7 +896,7 @@ extern "C" int rart_stencil_fixed_point_info(int corruption_id, int severity, ra
     const std::vector<double> disk = make_disk((int)kDefocus[s][0], kDefocus[s][1], &ksz);
     f2 = make_filter_i8(disk, ksz);
     if (!f2.ok) return RART_ERR_UNSUPPORTED;
-    info->kind = 1; info->ksize = ksz; info->n_steps = FI_STEPS; info->frac_bits = f2.meta.F; info->out_frac_bits = f2.meta.F;
+    info->kind = 1; info->ksize = ksz; info->n_steps = f2.steps; info->frac_bits = f2.meta.F; info->out_frac_bits = f2.meta.F;
     info->corr = f2.meta.corr; info->band = f2.meta.band;
     for (double v : disk) {
       const double e = fabs(ldexp((double)llrint(ldexp(v, f2.meta.F)), -f2.meta.F) - v);
@@ -908,7 +932,7 @@ size_t rart_ws_stencil(int id, int /*severity*/, int n, int h, int w) {
   switch (id) {
     case RART_GAUSSIAN_BLUR: return tmp + 4096;                                              // + the weight fragments of k_gauss_i8
     case RART_GLASS_BLUR: return tmp + rart_align_up((size_t)n * h * w * 3, 256) + 4096;
-    case RART_DEFOCUS_BLUR: return rart_align_up(21 * 21 * sizeof(double), 4096) + rart_align_up((size_t)FI_STEPS * 4 * 64 * 16, 256);
+    case RART_DEFOCUS_BLUR: return rart_align_up(21 * 21 * sizeof(double), 4096) + rart_align_up((size_t)11 * 4 * 64 * 16, 256);
     case RART_MOTION_BLUR: return rart_motion_tab_bytes(n);
   }
   return 0;
@@ -957,14 +981,20 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
         if (!fast_made[s]) { fast[s] = make_filter_i8(disks[s], ksz[s]); fast_made[s] = true; }
         const bool use_fast = fast[s].ok && a.h == 224 && a.w == 224 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.out & 15) == 0 &&
                               getenv("RART_DEFOCUS_FP64") == nullptr;
-        if (use_fast && rart_raise_dynamic_lds((const void*)k_filter2d_i8, FI_LDS, "defocus_blur (matrix-core path)")) {
+        const void* kfn = ksz[s] == 17 ? (const void*)k_filter2d_i8<17, 16> : (const void*)k_filter2d_i8<21, 12>;
+        const size_t flds = ksz[s] == 17 ? FiCfg<17, 16>::LDS : FiCfg<21, 12>::LDS;
+        if (use_fast && rart_raise_dynamic_lds(kfn, flds, "defocus_blur (matrix-core path)")) {
           uint8_t* ftab = (uint8_t*)a.workspace + rart_align_up(21 * 21 * sizeof(double), 4096);
           if (hipMemcpyAsync(ftab, fast[s].frags.data(), fast[s].frags.size(), hipMemcpyHostToDevice, a.stream) != hipSuccess) {
             rart_set_error("defocus_blur: fragment table upload failed");
             return RART_ERR_HIP;
           }
-          hipLaunchKernelGGL(k_filter2d_i8, dim3(224 / FI_TH, a.n), dim3(kBlock), FI_LDS, a.stream, a.in, a.out, (const uint4*)ftab,
-                             (const double*)a.workspace, fast[s].meta);
+          if (ksz[s] == 17)
+            hipLaunchKernelGGL((k_filter2d_i8<17, 16>), dim3(224 / FI_TH, a.n), dim3(kBlock), flds, a.stream, a.in, a.out, (const uint4*)ftab,
+                               (const double*)a.workspace, fast[s].meta);
+          else
+            hipLaunchKernelGGL((k_filter2d_i8<21, 12>), dim3(224 / FI_TH, a.n), dim3(kBlock), flds, a.stream, a.in, a.out, (const uint4*)ftab,
+                               (const double*)a.workspace, fast[s].meta);
           break;
         }
       }

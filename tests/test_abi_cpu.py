@@ -212,8 +212,7 @@ def test_fixed_point_tables_of_the_matrix_core_stencils_match_the_oracle_weights
     """Round 5 host logic, no GPU: defocus_blur / gaussian_blur / glass_blur run as exact fixed-point filters on the i8 matrix cores.
     rart_stencil_fixed_point_info hands out the tables the kernels consume; here they are decoded with the documented lane mapping
     (include/robustart_hip.h) and compared with the oracle's weights: W / 2^frac_bits reproduces every tap to the stated error, taps
-    outside the kernel are zero, the ambiguity band covers the accumulated quantisation error of a whole output, and the 21 x 21 disk of
-    defocus severity 5 stays on the fp64 kernel."""
+    outside the kernel are zero and the ambiguity band covers the accumulated quantisation error of a whole output."""
     import ctypes
     import numpy as np
     from robustart_amd import _lib
@@ -223,11 +222,8 @@ def test_fixed_point_tables_of_the_matrix_core_stencils_match_the_oracle_weights
     for name in ('defocus_blur', 'gaussian_blur', 'glass_blur'):
         for sev in range(1, 6):
             info = _lib.FixedPointInfo()
-            buf = (ctypes.c_ubyte * (9 * 4 * 64 * 16))()
+            buf = (ctypes.c_ubyte * (11 * 4 * 64 * 16))()
             rc = lib.rart_stencil_fixed_point_info(names.index(name), sev, ctypes.byref(info), buf, len(buf))
-            if name == 'defocus_blur' and sev == 5:
-                assert rc == 2 and info.kind == 0                   # RART_ERR_UNSUPPORTED: radius 10 -> 21 x 21
-                continue
             assert rc == 0, (name, sev)
             W = _signed_digits_to_int(bytes(buf)[:info.n_steps * 4 * 64 * 16], info.n_steps)        # [step][lane][byte]
             lane = np.arange(64)
@@ -235,14 +231,16 @@ def test_fixed_point_tables_of_the_matrix_core_stencils_match_the_oracle_weights
             if name == 'defocus_blur':
                 r, alias = O.PARAMS['defocus_blur'][sev - 1]
                 k = O.disk_kernel(r, alias).astype(np.float64)
-                assert info.kind == 1 and info.ksize == 17 == k.shape[0] and info.n_steps == 9 and info.out_frac_bits == info.frac_bits
+                ksz = 21 if sev == 5 else 17                       # radius 10 -> 21 x 21 (12 outputs per row block), else 17 x 17 (16)
+                mout, steps = 33 - ksz, (ksz + 1) // 2
+                assert info.kind == 1 and info.ksize == ksz == k.shape[0] and info.n_steps == steps and info.out_frac_bits == info.frac_bits
                 F = info.frac_bits
-                want = np.zeros((9, 64, 16), np.int64)
-                for j in range(9):
+                want = np.zeros((steps, 64, 16), np.int64)
+                for j in range(steps):
                     for i in range(16):
                         a = 2 * j + (g >> 1)
                         b = 16 * (g & 1) + i - m
-                        ok = (a < 17) & (b >= 0) & (b < 17)
+                        ok = (m < mout) & (a < ksz) & (b >= 0) & (b < ksz)
                         want[j, ok, i] = np.rint(k[a[ok], b[ok]] * 2.0 ** F).astype(np.int64)
                 np.testing.assert_array_equal(W, want)
                 err = np.abs(np.rint(k * 2.0 ** F) / 2.0 ** F - k)
