@@ -274,6 +274,75 @@ __global__ __launch_bounds__(kBlock) void k_field_gauss_lds(const TIN* __restric
   }
 }
 
+// ---- the field filter as a dense matrix product on the fp64 matrix cores (round 5) ---------------------------------------------------
+// elastic_transform's severity 1 filters its two 224 x 224 displacement fields with sigma = 170.8 px: radius 512, 1 025 taps per output and
+// pass over a signal of 224 samples that `mode='reflect'` wraps four and a half times -- 10.1 ms per 256-image batch, 29 % of a sweep over all
+// 19 corruptions x 5 severities (scratch/r5/sweep_all_severities.py).  Along one axis the filter IS a 224 x 224 matrix: out = M in with
+// M[l][p] = sum of the weights w[j] whose tap l + j reflects onto p.  Both passes become fp64 GEMMs against that one matrix,
+// Y = M X (axis 0) and Z = Y M^T (axis 1), 224 instead of 1 025 x 1.5 operations per output, on v_mfma_f64_16x16x4_f64 (the data operand from
+// an LDS slab laid out so that its reads are conflict free, the matrix operand in fragment order straight from L2, 56 fragments = 112 VGPRs
+// per 16-row block).  NOT the reference's summation order: the fp64 results differ from scipy's in the last bits (~1e-16 relative), which
+// survives the cast of the displacement to fp32 for ~1e-9 of its elements; the corrupted images stay inside elastic_transform's stated
+// tolerance (<= 1 LSB on <= 1e-4 of the pixels; measured: identical on the test batches,
+// test_elastic_dense_field_filter_matches_the_ordered_kernels).  Used when the kernel is longer than the signal (2 radius + 1 > 224:
+// severity 1); RART_ELASTIC_ORDERED=1 keeps the ordered kernels.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int FD_THREADS = 448, FD_SLAB = 32, FD_GROUP = 2;  // 7 waves; a slab = 32 columns (pass 0) / 32 rows (pass 1); fields per workgroup
+constexpr int FD_LDX = 48;                                   // pass 0: row stride of the [224][32] slab in doubles (96 dwords: K groups 32 banks apart)
+constexpr int FD_LDY = 226;                                  // pass 1: row stride of the [32][224] slab in doubles (452 dwords = 4 mod 64)
+
+// AXIS 0: Y[f][l][c] = sum_p M[l][p] X[f][p][c]            (TOUT double, post_scale 1)
+// AXIS 1: Z[f][r][c] = post_scale * sum_p Y[f][r][p] M[c][p]   (TOUT float)
+// grid (7 slabs x 2 halves, ceil(n / FD_GROUP)): wave w of half h owns the 16 output rows (AXIS 0) / columns (AXIS 1) of block 7 h + w and keeps
+// that block's 56 matrix fragments in registers for every field of its group; the data slab goes through LDS once per field.
+template <int AXIS, typename TOUT>
+__global__ __launch_bounds__(FD_THREADS) void k_field_dense(const double* __restrict__ src, TOUT* __restrict__ dst,
+                                                            const double* __restrict__ mfrag, double post_scale, int n) {
+  extern __shared__ __attribute__((aligned(16))) double fd_s[];     // AXIS 0: [224][FD_LDX]; AXIS 1: [32][FD_LDY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = (int)blockIdx.x >> 1, blk = ((int)blockIdx.x & 1) * 7 + wave;
+  const int j = lane & 15, kk = lane >> 4;
+  double m[56];
+#pragma unroll
+  for (int s = 0; s < 56; ++s) m[s] = mfrag[((size_t)blk * 56 + s) * 64 + lane];      // M[blk * 16 + j][4 s + kk]
+  const int f_end = min(n, ((int)blockIdx.y + 1) * FD_GROUP);
+  for (int f = (int)blockIdx.y * FD_GROUP; f < f_end; ++f) {
+    const size_t fbase = (size_t)f * HW * HW;
+    if (AXIS == 0) {
+      for (int i = tid; i < HW * FD_SLAB; i += FD_THREADS) fd_s[(i >> 5) * FD_LDX + (i & 31)] = src[fbase + (size_t)(i >> 5) * HW + slab * FD_SLAB + (i & 31)];
+    } else {
+      for (int i = tid; i < FD_SLAB * HW; i += FD_THREADS) {
+        const int rr = i / HW;
+        fd_s[rr * FD_LDY + (i - rr * HW)] = src[fbase + (size_t)slab * FD_SLAB * HW + i];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      const double* lp = AXIS == 0 ? fd_s + kk * FD_LDX + t * 16 + j : fd_s + (t * 16 + j) * FD_LDY + kk;
+#pragma unroll
+      for (int s = 0; s < 56; ++s) {
+        // v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]; D[row = (lane >> 4) + 4 reg][col = lane & 15]
+        if (AXIS == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[s], lp[4 * s * FD_LDX], acc, 0, 0, 0);
+        else           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[4 * s], m[s], acc, 0, 0, 0);
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (AXIS == 0) {
+          dst[fbase + (size_t)(blk * 16 + kk + 4 * q) * HW + slab * FD_SLAB + t * 16 + j] = (TOUT)acc[q];
+        } else {
+          double v = acc[q];
+          if (post_scale != 1.0) v = v * post_scale;
+          dst[fbase + (size_t)(slab * FD_SLAB + t * 16 + kk + 4 * q) * HW + blk * 16 + j] = (TOUT)v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // scipy gaussian_filter1d along AXIS of n fields [h][w]: the LDS-resident kernel whenever its lines fit, else the global-memory walk
 template <int AXIS, bool REFLECT, typename TIN, typename TOUT>
 static int launch_field_gauss(const TIN* src, TOUT* dst, int n, int h, int w, const double* wts, int radius, double post_scale,
@@ -526,6 +595,27 @@ std::vector<double> gauss_weights(double sigma, double truncate, int* radius) {
   return w;
 }
 
+// the folded filter matrix of `mode='reflect'` in MFMA fragment order: frag[(block * 56 + s) * 64 + lane] = M[block * 16 + (lane & 15)][4 s + (lane >> 4)]
+const std::vector<double>& cached_dense_matrix(int slot, const std::vector<double>& w, int radius) {
+  static std::vector<double> tabs[16];
+  if (tabs[slot].empty()) {
+    std::vector<long double> M((size_t)HW * HW, 0.0L);
+    for (int l = 0; l < HW; ++l)
+      for (int jx = -radius; jx <= radius; ++jx) {
+        int p = (l + jx) % (2 * HW);
+        if (p < 0) p += 2 * HW;
+        if (p >= HW) p = 2 * HW - 1 - p;
+        M[(size_t)l * HW + p] += (long double)w[jx + radius];
+      }
+    tabs[slot].resize((size_t)(HW / 16) * 56 * 64);
+    for (int blk = 0; blk < HW / 16; ++blk)
+      for (int sidx = 0; sidx < 56; ++sidx)
+        for (int lane = 0; lane < 64; ++lane)
+          tabs[slot][((size_t)blk * 56 + sidx) * 64 + lane] = (double)M[(size_t)(blk * 16 + (lane & 15)) * HW + 4 * sidx + (lane >> 4)];
+  }
+  return tabs[slot];
+}
+
 const double kFog[5][2] = {{1.5, 2}, {2., 2}, {2.5, 1.7}, {2.5, 1.5}, {3., 1.4}};
 const double kSnow[5][7] = {{0.1, 0.3, 3, 0.5, 10, 4, 0.8}, {0.2, 0.3, 2, 0.5, 12, 4, 0.7}, {0.55, 0.3, 4, 0.9, 12, 8, 0.7},
                             {0.55, 0.3, 4.5, 0.85, 12, 8, 0.65}, {0.55, 0.3, 2.5, 0.85, 12, 12, 0.55}};
@@ -558,7 +648,7 @@ size_t rart_ws_composite(int id, int /*severity*/, int n, int h, int w) {
     case RART_SNOW: return field + 2 * A256((size_t)n * HW * HW) + rart_motion_tab_bytes(n);
     case RART_ELASTIC_TRANSFORM:
       return A256((size_t)n * 6 * sizeof(double)) + A256((size_t)n * HW * HW * 3 * sizeof(float)) + 2 * field +
-             2 * A256((size_t)n * HW * HW * sizeof(float)) + A256(1025 * sizeof(double));
+             2 * A256((size_t)n * HW * HW * sizeof(float)) + A256(1025 * sizeof(double)) + A256((size_t)(HW / 16) * 56 * 64 * sizeof(double));
     case RART_SPATTER: return 2 * field + 2 * A256((size_t)n * HW * HW * sizeof(float)) + 2 * A256(64 * sizeof(double));
   }
   return 0;
@@ -640,7 +730,29 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
       }
       hipLaunchKernelGGL(k_elastic_affine, dim3(a.n), dim3(1), 0, st, inv, (const float*)inj(0), (float)c[2], k0, k1, sb);
       hipLaunchKernelGGL(k_warp_affine, img_grid(a.n), dim3(kBlock), 0, st, a.in, warped, inv);
-      for (int which = 0; which < 2; ++which) {
+      // the kernel is longer than the signal (severity 1): both passes as fp64 matrix products against the folded filter matrix
+      bool dense = 2 * radius + 1 > HW && getenv("RART_ELASTIC_ORDERED") == nullptr;
+      double* mdev = wdev + A256(1025 * sizeof(double)) / sizeof(double);
+      const size_t lds0 = (size_t)HW * FD_LDX * sizeof(double), lds1 = (size_t)FD_SLAB * FD_LDY * sizeof(double);
+      if (dense) {
+        const std::vector<double>& mf = cached_dense_matrix(s, wt, radius);
+        dense = hipMemcpyAsync(mdev, mf.data(), mf.size() * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
+                rart_raise_dynamic_lds((const void*)k_field_dense<0, double>, lds0, "elastic field filter (dense)") &&
+                rart_raise_dynamic_lds((const void*)k_field_dense<1, float>, lds1, "elastic field filter (dense)");
+      }
+      for (int which = 0; which < 2 && dense; ++which) {
+        const double* fsrc = (const double*)inj(1 + which);
+        if (!fsrc) {
+          hipLaunchKernelGGL(k_uniform_field, img_grid(a.n), dim3(kBlock), 0, st, f0, k0, k1, sb, 11 + which);
+          fsrc = f0;
+        }
+        const dim3 grid(2 * (HW / FD_SLAB), (unsigned)((a.n + FD_GROUP - 1) / FD_GROUP));
+        hipLaunchKernelGGL((k_field_dense<0, double>), grid, dim3(FD_THREADS), lds0, st, fsrc, f1, (const double*)mdev, 1.0, a.n);
+        hipLaunchKernelGGL((k_field_dense<1, float>), grid, dim3(FD_THREADS), lds1, st, (const double*)f1, which == 0 ? dx : dy,
+                           (const double*)mdev, c[0], a.n);
+      }
+      const bool dense_done = dense;
+      for (int which = 0; which < 2 && !dense_done; ++which) {
         const double* fsrc = (const double*)inj(1 + which);
         const size_t gen_lds = (size_t)(((radius + 2) & ~1) + (size_t)FL_N * (HW + 2 * radius)) * sizeof(double);
         if (!fsrc && gen_lds <= 150 * 1024 && getenv("RART_ELASTIC_FIELD_KERNEL") == nullptr &&

@@ -170,6 +170,30 @@ def test_zoom_blur_table_kernel_equals_the_direct_kernel(sev):
     np.testing.assert_array_equal(fast[0], np.asarray(O.corrupt('zoom_blur', batch[0], sev)).astype(np.uint8))
 
 
+@pytest.mark.parametrize('injected', [False, True])
+def test_elastic_dense_field_filter_matches_the_ordered_kernels(injected):
+    """Round 5: elastic_transform severity 1 (sigma 170.8 px: 1 025 taps over a 224-sample signal) filters its displacement fields as two fp64
+    matrix products against the folded reflect-filter matrix (k_field_dense, v_mfma_f64_16x16x4_f64).  Its summation order is not scipy's, so the
+    claim is the corruption's stated tolerance, checked against the ordered kernels (RART_ELASTIC_ORDERED=1) on native draws and against them +
+    the oracle on injected fields."""
+    import os
+    batch = np.stack(_hard_images(410)[:4]) if not injected else make_batch_u8(2, seed=411)
+    draws = None
+    if injected:
+        want, draws = _oracle_batch('elastic_transform', batch, 1, case_seed('elastic_transform', 1))
+    fast = _run('elastic_transform', batch, 1, draws, 5, 70)
+    os.environ['RART_ELASTIC_ORDERED'] = '1'
+    try:
+        slow = _run('elastic_transform', batch, 1, draws, 5, 70)
+    finally:
+        del os.environ['RART_ELASTIC_ORDERED']
+    max_lsb, max_frac = TOLERANT_INJECTED['elastic_transform']
+    for ref in ([slow, want] if injected else [slow]):
+        diff = np.abs(fast.astype(int) - ref.astype(int))
+        print('elastic dense vs %s: max diff %d, fraction %.3g' % ('ordered' if ref is slow else 'oracle', diff.max(), (diff != 0).mean()))
+        assert diff.max() <= max_lsb and (diff != 0).mean() <= max_frac
+
+
 @pytest.mark.parametrize('name', ['gaussian_blur', 'glass_blur'])
 @pytest.mark.parametrize('sev', [1, 2, 3, 4, 5])
 def test_gaussian_fast_path_equals_the_ordered_fp64_kernels(name, sev):
