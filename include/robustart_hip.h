@@ -54,7 +54,7 @@ enum {
  * its tap arrays from 16 to 32 entries and gained dst_pair_off / res_pair_off; several attack entries gained a per-row
  * sample-index pointer; round 4 -> 5: rart_stencil_fixed_point_info added).  A caller compiled against another header must refuse to run:
  * compare with rart_version(). */
-#define RART_ABI_VERSION 106
+#define RART_ABI_VERSION 107
 int rart_version(void);
 const char* rart_last_error_string(void);
 /* name of corruption id (static string), NULL if out of range */
@@ -102,6 +102,16 @@ int rart_corrupt_u8(const uint8_t* in, uint8_t* out, int n, int h, int w,
  * buffers and the matrix-core generator selected (callers then issue ns rart_corrupt_u8 calls). */
 int rart_noise_multi_u8(const uint8_t* in, uint8_t* const* outs, int ns, int n, int h, int w, int corruption_id, const int* severities,
                         const uint64_t* seeds, uint64_t sample_offset, rart_stream_t stream);
+
+/* frost from device-resident photographs (round 5).  The reference (imagenet_c/corruptions.py:249-266) opens one of its frost photographs
+ * per image -- randint(5) over a six-entry list -- crops 224 x 224 at a random origin and blends; the photographs are not in its repository, so
+ * the caller registers them (robustart_amd.noise.imagenet_c.set_frost_textures) and they live on the device as one stack
+ * uint8 [k_tex][sh][sw][3] (each padded to the common size; dims_host: host int[2 k_tex] = height, width of each).  The texture index and the
+ * crop origin of image i are the counter generator's uniforms of streams 8, 9, 10 at sample sample_offset + i, drawn in the kernel, which reads
+ * the crop in place: bit-identical to rart_corrupt_u8(RART_FROST) with those crops injected, without the gather (n x 150 528 B written and
+ * read back).  h = w = 224 only, as the reference.  in == out allowed. */
+int rart_frost_textures_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int severity, const uint8_t* stack, int k_tex, int sh, int sw,
+                           const int* dims_host, uint64_t seed, uint64_t sample_offset, rart_stream_t stream);
 
 /* Host-only introspection of the fixed-point tables behind the matrix-core stencil paths (round 5; no GPU needed: the "-m 'not gpu'"
  * tests check the tables against the oracle's weights).  defocus_blur (corruptions.py:187-198: 17 x 17 disks, 21 x 21 at severity 5) runs as an

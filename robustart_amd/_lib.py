@@ -13,7 +13,7 @@ c_void_p, c_int, c_size_t, c_u64, c_float = (ctypes.c_void_p, ctypes.c_int, ctyp
                                               ctypes.c_uint64, ctypes.c_float)
 c_double = ctypes.c_double
 
-ABI_VERSION = 106        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
+ABI_VERSION = 107        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
 
 # name -> (restype, argtypes); every symbol include/robustart_hip.h declares
 SIGNATURES = {
@@ -26,6 +26,8 @@ SIGNATURES = {
     'rart_stencil_fixed_point_info': (c_int, [c_int, c_int, c_void_p, c_void_p, c_size_t]),
     'rart_noise_multi_u8': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
                                     ctypes.POINTER(c_u64), c_u64, c_void_p]),
+    'rart_frost_textures_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int),
+                                       c_u64, c_u64, c_void_p]),
     'rart_pil_resize_workspace_bytes': (c_size_t, [c_int] * 10),
     'rart_pil_resize_u8': (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     'rart_cv_resize_workspace_bytes': (c_size_t, [c_int] * 10),

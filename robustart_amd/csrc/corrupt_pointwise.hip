@@ -681,6 +681,43 @@ __global__ __launch_bounds__(kBlock) void k_frost_blend(const uint8_t* __restric
   }
 }
 
+
+// frost with the photographs resident on the device (round 5): the crop of image i is drawn AND read here -- texture index
+// floor(u_8 * min(5, k)) (corruptions.py:250: randint(5) over the six-entry list), crop origin floor(u_9 * (height - 224)),
+// floor(u_10 * (width - 224)) (corruptions.py:259), u_s = the counter generator's uniform of stream s at element 0 of the sample --
+// the draws robustart_amd/noise/imagenet_c.py made on the host (rng.host_uniform_many) before gathering the n crops with a torch
+// index expression (211 us + nine small launches + an upload per 256 images; the blend itself is 50 us).  grid (147, n): a thread blends 4 bytes.
+struct FrostTex {
+  int k_draw, sh, sw;
+  int th[8], tw[8];
+};
+__global__ __launch_bounds__(kBlock) void k_frost_textures(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           const uint8_t* __restrict__ stack, FrostTex t, double a, double b,
+                                                           uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  const uint32_t sample = sample_base + blockIdx.y;
+  auto u53 = [&](int stream) {
+    const uint2 w = threefry2x32(k0, k1, rart_ctr0(0u, stream), sample);
+    return ((double)(w.x >> 5) * 67108864.0 + (double)(w.y >> 6)) / 9007199254740992.0;
+  };
+  const int idx = (int)(u53(8) * (double)t.k_draw);
+  const int xs = (int)(u53(9) * (double)(t.th[idx] - 224)), ys = (int)(u53(10) * (double)(t.tw[idx] - 224));
+  const int q = blockIdx.x * kBlock + threadIdx.x;                   // dword of the image: 168 per row
+  const int row = q / 168, cb = (q - row * 168) * 4;
+  const size_t o = (size_t)blockIdx.y * (224 * 672) + (size_t)q * 4;
+  const uint8_t* tp = stack + (((size_t)idx * t.sh + (xs + row)) * t.sw + ys) * 3 + cb;
+  const uint32_t pin = *(const uint32_t*)(in + o);
+  uint32_t r = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double ax = a * (double)((pin >> (8 * j)) & 255u);
+    const double bt = b * (double)tp[j];
+    double v = ax + bt;
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    r |= (uint32_t)v << (8 * j);
+  }
+  *(uint32_t*)(out + o) = r;
+}
+
 }  // namespace
 #pragma clang fp contract(fast)
 
@@ -912,5 +949,32 @@ extern "C" int rart_noise_multi_u8(const uint8_t* in, uint8_t* const* outs, int 
     hipLaunchKernelGGL(k_normal_noise_mfma_multi<1>, g, dim3(kBlock), 0, (hipStream_t)stream, (const uint4*)in, m, cps, total,
                        (uint32_t)sample_offset, cmagic, cshift);
   RART_CHECK_LAUNCH("rart_noise_multi_u8");
+  return RART_OK;
+}
+
+// frost from device-resident photographs: stack = uint8 [k_tex][sh][sw][3] (every photograph padded to a common sh x sw), dims_host = host int[2 k_tex]
+// (height, width of each); the per-image texture index and crop origin are the counter generator's (streams 8, 9, 10).  Bit-identical to
+// rart_corrupt_u8(RART_FROST) with those crops injected.
+extern "C" int rart_frost_textures_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int severity, const uint8_t* stack, int k_tex,
+                                      int sh, int sw, const int* dims_host, uint64_t seed, uint64_t sample_offset, rart_stream_t stream) {
+  RART_CHECK_ARG(in && out && stack && dims_host && n > 0 && n <= 65535, "rart_frost_textures_u8: bad arguments");
+  RART_CHECK_ARG(h == 224 && w == 224, "frost: reference hard-codes 224x224 (corruptions.py:259-260)");
+  RART_CHECK_ARG(severity >= 1 && severity <= 5, "rart_frost_textures_u8: severity must be 1..5");
+  RART_CHECK_ARG(k_tex >= 1 && k_tex <= 8, "rart_frost_textures_u8: 1..8 photographs");
+  RART_CHECK_ARG(!(reinterpret_cast<uintptr_t>(in) & 3) && !(reinterpret_cast<uintptr_t>(out) & 3), "rart_frost_textures_u8: 4-byte aligned batches");
+  FrostTex t;
+  t.k_draw = k_tex < 5 ? k_tex : 5;
+  t.sh = sh;
+  t.sw = sw;
+  for (int i = 0; i < 8; ++i) {
+    t.th[i] = i < k_tex ? dims_host[2 * i] : 224;
+    t.tw[i] = i < k_tex ? dims_host[2 * i + 1] : 224;
+    RART_CHECK_ARG(t.th[i] >= 224 && t.tw[i] >= 224 && (i >= k_tex || (t.th[i] <= sh && t.tw[i] <= sw)),
+                   "rart_frost_textures_u8: every photograph must be at least 224 x 224 and fit the stack");
+  }
+  static const double fr[5][2] = {{1, 0.4}, {0.8, 0.6}, {0.7, 0.7}, {0.65, 0.7}, {0.6, 0.75}};
+  hipLaunchKernelGGL(k_frost_textures, dim3(224 * 168 / kBlock, n), dim3(kBlock), 0, (hipStream_t)stream, in, out, stack, t, fr[severity - 1][0],
+                     fr[severity - 1][1], (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset);
+  RART_CHECK_LAUNCH("rart_frost_textures_u8");
   return RART_OK;
 }

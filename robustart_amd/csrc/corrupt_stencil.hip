@@ -6,6 +6,7 @@
 // cv2.GaussianBlur on the aliased disk (fp32); ImageMagick MotionBlurImage (one-sided gaussian
 // taps along the angle, edge virtual pixels, 8-bit requantisation).
 #include "rart_common.h"
+#include <type_traits>
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -692,6 +693,7 @@ const GaussI8Host& gauss_i8_for(const GaussW& gw, double sigma) {
 // ---- motion_blur (ImageMagick) -----------------------------------------------------------------
 struct MotionTab {
   int offx[41], offy[41];
+  int ext[4];                 // min / max of offx, min / max of offy over the taps (both ranges contain 0: tap 0 is the pixel itself)
 };
 
 // one block per image: offsets from the angle (injected or drawn from host-mirrored stream 8)
@@ -713,6 +715,27 @@ __global__ void k_motion_offsets(MotionTab* __restrict__ tab, const double* __re
     const double hyp = hypot(px, py);
     tab[img].offx[i] = (int)ceil((double)i * py / hyp - 0.5);
     tab[img].offy[i] = (int)ceil((double)i * px / hyp - 0.5);
+  }
+  if (blockDim.x == 64) {     // (both launches use one wave per image) the extents of the offsets, for the LDS-tiled kernel's halo
+    int ox = 0, oy = 0;
+    if (i < width) {
+      const double a = ang * (M_PI / 180.0);
+      const double px = (double)width * sin(a), py = (double)width * cos(a);
+      const double hyp = hypot(px, py);
+      ox = (int)ceil((double)i * py / hyp - 0.5);
+      oy = (int)ceil((double)i * px / hyp - 0.5);
+    }
+    int mnx = ox, mxx = ox, mny = oy, mxy = oy;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      mnx = min(mnx, __shfl_xor(mnx, d, 64));
+      mxx = max(mxx, __shfl_xor(mxx, d, 64));
+      mny = min(mny, __shfl_xor(mny, d, 64));
+      mxy = max(mxy, __shfl_xor(mxy, d, 64));
+    }
+    if (i == 0) {
+      tab[img].ext[0] = mnx; tab[img].ext[1] = mxx; tab[img].ext[2] = mny; tab[img].ext[3] = mxy;
+    }
   }
 }
 
@@ -760,6 +783,82 @@ __global__ __launch_bounds__(kBlock) void k_motion_blur(const uint8_t* __restric
       dst[p * CH + c] = (uint8_t)(uint32_t)v;
     }
   }
+}
+
+// Round 5: the same sum from an LDS tile.  k_motion_blur reads every tap of every channel as a byte from global memory (31 taps x 3 at
+// severity 3: 1.2 G byte loads per 256 images, 441 us); here a workgroup stages its 32 x 32 output tile + the halo the image's offsets reach
+// (edge clamp applied while staging, RGB packed into one dword per pixel) and a tap is one ds_read_b32 per pixel.  Same terms, same order,
+// same fp64 operations: bit-identical (test_motion_blur_tile_kernel_equals_the_direct_kernel).  RART_MOTION_DIRECT=1 keeps the old kernel.
+constexpr int MB_T = 32, MB_HALO = 40, MB_P = MB_T + MB_HALO;
+template <int CH>
+__global__ __launch_bounds__(kBlock) void k_motion_blur_tile(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int h, int w,
+                                                             const MotionTab* __restrict__ tab, MotionK mk) {
+  typedef typename std::conditional<CH == 3, uint32_t, uint8_t>::type PX;
+  __shared__ PX tile[MB_P * MB_P];
+  __shared__ int s_off[41];
+  const int img = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = blockIdx.x * MB_T, y0 = blockIdx.y * MB_T;
+  const MotionTab* mt = tab + img;
+  const int mnx = mt->ext[0], mxx = mt->ext[1], mny = mt->ext[2], mxy = mt->ext[3];
+  const int pitch = MB_T + mxx - mnx, rows = MB_T + mxy - mny;
+  if (tid < mk.width) s_off[tid] = mt->offy[tid] * pitch + mt->offx[tid];
+  const uint8_t* src = in + (size_t)img * h * w * CH;
+  for (int r = wave; r < rows; r += kBlock / 64) {
+    int gy = y0 + mny + r;
+    gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+    for (int c = lane; c < pitch; c += 64) {
+      int gx = x0 + mnx + c;
+      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+      const uint8_t* sp = src + ((size_t)gy * w + gx) * CH;
+      if (CH == 3) tile[r * pitch + c] = (PX)((uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16));
+      else tile[r * pitch + c] = (PX)sp[0];
+    }
+  }
+  __syncthreads();
+  constexpr int NP = MB_T * MB_T / kBlock;          // 4 pixels per thread: rows ly, ly + 8, ...
+  const int lx = tid & (MB_T - 1), ly = tid >> 5;
+  const int base = (ly - mny) * pitch + (lx - mnx);
+  double acc[NP][CH];
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[j][c] = 0.0;
+  for (int t = 0; t < mk.width; ++t) {
+    const int o = base + s_off[t];
+    const double kt = mk.k[t];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t px = (uint32_t)tile[o + j * (kBlock / MB_T) * pitch];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const double term = kt * (double)((px >> (8 * c)) & 255u);
+        acc[j][c] += term;
+      }
+    }
+  }
+  uint8_t* dst = out + (size_t)img * h * w * CH;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int yo = y0 + ly + j * (kBlock / MB_T), xo = x0 + lx;
+    if (yo < h && xo < w) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        double v = floor(acc[j][c] + 0.5);
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+        dst[((size_t)yo * w + xo) * CH + c] = (uint8_t)(uint32_t)v;
+      }
+    }
+  }
+}
+
+template <int CH>
+void launch_motion_blur(const uint8_t* in, uint8_t* out, int n, int h, int w, const MotionTab* tab, const MotionK& mk, hipStream_t s) {
+  if (mk.width - 1 <= MB_HALO && n <= 65535 && getenv("RART_MOTION_DIRECT") == nullptr) {
+    hipLaunchKernelGGL(k_motion_blur_tile<CH>, dim3((w + MB_T - 1) / MB_T, (h + MB_T - 1) / MB_T, n), dim3(kBlock), 0, s, in, out, h, w, tab, mk);
+    return;
+  }
+  const uint32_t gx = (uint32_t)(((size_t)h * w + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_motion_blur<CH>, dim3(gx, n), dim3(kBlock), 0, s, in, out, n, h, w, tab, mk);
 }
 
 MotionK make_motion_kernel(double radius, double sigma) {
@@ -876,8 +975,7 @@ int rart_motion_blur_gray(const uint8_t* in, uint8_t* out, int n, int h, int w, 
   MotionTab* tab = (MotionTab*)tab_ws;
   hipLaunchKernelGGL(k_motion_offsets, dim3(n), dim3(64), 0, s, tab, angles_dev, mk.width, lo, hi, (uint32_t)seed,
                      (uint32_t)(seed >> 32), (uint32_t)sample_offset);
-  uint32_t gx = (uint32_t)(((size_t)h * w + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(k_motion_blur<1>, dim3(gx, n), dim3(kBlock), 0, s, in, out, n, h, w, tab, mk);
+  launch_motion_blur<1>(in, out, n, h, w, tab, mk, s);
   return RART_OK;
 }
 size_t rart_motion_tab_bytes(int n) { return rart_align_up((size_t)n * sizeof(MotionTab), 256); }
@@ -1018,9 +1116,7 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
       MotionTab* tab = (MotionTab*)a.workspace;
       hipLaunchKernelGGL(k_motion_offsets, dim3(a.n), dim3(64), 0, a.stream, tab, (const double*)inj0, mk.width,
                          -45.0, 45.0, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
-      uint32_t gx = (uint32_t)(((size_t)a.h * a.w + kBlock - 1) / kBlock);
-      hipLaunchKernelGGL(k_motion_blur<3>, dim3(gx, a.n), dim3(kBlock), 0, a.stream, a.in, a.out, a.n, a.h, a.w, tab,
-                         mk);
+      launch_motion_blur<3>(a.in, a.out, a.n, a.h, a.w, tab, mk, a.stream);
       break;
     }
     default:

@@ -170,6 +170,39 @@ def test_zoom_blur_table_kernel_equals_the_direct_kernel(sev):
     np.testing.assert_array_equal(fast[0], np.asarray(O.corrupt('zoom_blur', batch[0], sev)).astype(np.uint8))
 
 
+@pytest.mark.parametrize('name', ['motion_blur', 'snow'])
+@pytest.mark.parametrize('sev', [1, 2, 3, 4, 5])
+def test_motion_blur_tile_kernel_equals_the_direct_kernel(name, sev):
+    """Round 5: ImageMagick's motion blur (motion_blur's RGB image, snow's 1-channel layer) from an LDS tile with the halo the image's own
+    offsets reach (k_motion_blur_tile) == the per-tap global-memory kernel of rounds 1-4 (RART_MOTION_DIRECT=1): same terms, same order."""
+    import os
+    batch = np.stack(_hard_images(500 + sev)[:5])
+    fast = _run(name, batch, sev, None, 9, 33)
+    os.environ['RART_MOTION_DIRECT'] = '1'
+    try:
+        slow = _run(name, batch, sev, None, 9, 33)
+    finally:
+        del os.environ['RART_MOTION_DIRECT']
+    np.testing.assert_array_equal(fast, slow)
+
+
+def test_frost_in_kernel_crops_equal_injected_crops():
+    """Round 5: rart_frost_textures_u8 (texture index, crop origin and crop read inside the blend kernel) == the crops gathered by the host
+    path's torch index expression and injected into rart_corrupt_u8."""
+    from robustart_amd.noise import imagenet_c as C
+    rs = np.random.RandomState(6)
+    C.set_frost_textures([rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in ((300, 340), (224, 400), (512, 512), (225, 225), (330, 250), (280, 280))])
+    try:
+        batch = make_batch_u8(9, seed=33)
+        for sev in (1, 3, 5):
+            native = _run('frost', batch, sev, None, 77, 1000)
+            draws = C._host_draws('frost', 9, sev, 77, 1000, torch.device('cuda'))
+            injected = _run('frost', batch, sev, draws, 77, 1000)
+            np.testing.assert_array_equal(native, injected)
+    finally:
+        C.set_frost_textures([])
+
+
 @pytest.mark.parametrize('injected', [False, True])
 def test_elastic_dense_field_filter_matches_the_ordered_kernels(injected):
     """Round 5: elastic_transform severity 1 (sigma 170.8 px: 1 025 taps over a 224-sample signal) filters its displacement fields as two fp64
