@@ -204,6 +204,92 @@ __global__ __launch_bounds__(kGlassThreads) void k_glass_shuffle(uint8_t* __rest
   for (int i = threadIdx.x; i < HW * HW * 3 / 16; i += kGlassThreads) o4[i] = l4[i];
 }
 
+// Round 5, second half: the ITERATIONS of the chain overlap, and the draws leave the chain.  Operation (it, a, b) conflicts with
+// (it', a', b') only when both index differences are <= d, whatever the iterations, so with time(it, a, b) = it * Toff + a * S + b,
+// Toff = d * S + d + 1, every conflicting pair that the reference executes in the order X, Y has time(Y) - time(X) >= 1 (same iteration: as
+// above; later iteration: Toff - d * S - d): a valid schedule with 256 lanes PER ITERATION in flight and T + (iters - 1) * Toff barriers
+// instead of iters * T (severity 3: 895 instead of 2 631).  A step of the kernel above is one wave per SIMD executing ~85 dependent
+// instructions (Threefry, address, LDS read, LDS write, loop control: ~700 cycles); here a parallel pre-pass (k_glass_offsets) writes the
+// (dx, dy) of every (step, lane) as one byte, [step / 16][lane][16], so that a lane fetches sixteen steps with one 16-byte load a block ahead
+// and a step is: extract, address, three byte reads, three byte writes, barrier (scratch/r5/glass_ko.hip: 167 us per 256 images at severity 3,
+// of which 45 us are the LDS accesses and 80 us the barriers; the old kernel: 815 us).  Same operations in an order the dependencies allow:
+// bit-identical (test_glass_shuffle_overlapped_iterations_equal_the_serial_kernel); RART_GLASS_SERIAL=1 keeps the kernel above.
+struct GlassSched {
+  int delta, iters, N, S, Toff, T, nthr;      // T = (N - 1) S + N + (iters - 1) Toff steps; nthr = 256 iters lanes
+};
+__global__ __launch_bounds__(256) void k_glass_offsets(uint4* __restrict__ tab_all, GlassSched g, const int8_t* __restrict__ inj,
+                                                       uint32_t k0, uint32_t k1, uint32_t sample_base) {
+  const int T16 = (g.T + 15) & ~15;
+  const int e = blockIdx.x * 256 + threadIdx.x;           // (block of 16 steps, lane), lane fastest: one 16-byte store per thread
+  if (e >= (T16 >> 4) * g.nthr) return;
+  const int blk = e / g.nthr, lane = e - blk * g.nthr;
+  const int it = lane >> 8, a = lane & 255;
+  const int bb = blk * 16 - it * g.Toff - a * g.S;         // column of the block's first step
+  if (a >= g.N || bb + 15 < 0 || bb >= g.N) return;        // never read
+  const int8_t* dr = inj ? inj + (size_t)blockIdx.y * g.iters * g.N * g.N * 2 : nullptr;
+  uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int b = bb + j;
+    if (b >= 0 && b < g.N) {
+      const size_t di = ((size_t)it * g.N + a) * g.N + b;
+      int dx, dy;
+      if (dr) {
+        dx = dr[di * 2];
+        dy = dr[di * 2 + 1];
+      } else {
+        const uint2 wv = threefry2x32(k0, k1, rart_ctr0((uint32_t)di, 4), sample_base + blockIdx.y);
+        dx = (int)__umulhi(wv.x, (uint32_t)(2 * g.delta)) - g.delta;  // randint(-d, d): upper bound exclusive
+        dy = (int)__umulhi(wv.y, (uint32_t)(2 * g.delta)) - g.delta;
+      }
+      w[j >> 2] |= (uint32_t)((dx + g.delta) | ((dy + g.delta) << 4)) << (8 * (j & 3));
+    }
+  }
+  tab_all[(size_t)blockIdx.y * (T16 >> 4) * g.nthr + e] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(768) void k_glass_shuffle_overlap(uint8_t* __restrict__ img_all, const uint8_t* __restrict__ tab_all,
+                                                               GlassSched g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // 224*224*3
+  constexpr int HW = 224;
+  const int nthr = g.nthr, tid = threadIdx.x;
+  uint8_t* gi = img_all + (size_t)blockIdx.x * HW * HW * 3;
+  const uint4* g4 = reinterpret_cast<const uint4*>(gi);
+  uint4* l4 = reinterpret_cast<uint4*>(lds);
+  for (int i = tid; i < HW * HW * 3 / 16; i += nthr) l4[i] = g4[i];
+  const int T16 = (g.T + 15) & ~15;
+  const uint4* tab = reinterpret_cast<const uint4*>(tab_all + (size_t)blockIdx.x * T16 * nthr) + tid;
+  const int it = tid >> 8, a = tid & 255;
+  const bool row_ok = a < g.N;
+  const int b0 = -it * g.Toff - a * g.S;                   // this lane's column at step 0
+  // the lane's pixel at column b: lds + ((HW - d - a) * HW + (HW - d - b)) * 3; the neighbour adds (dy * HW + dx) * 3, dy = (o >> 4) - d, dx = (o & 15) - d
+  const int pbase = ((HW - g.delta - a) * HW + (HW - g.delta)) * 3;
+  const int nbase = -(g.delta * HW + g.delta) * 3;
+  auto wanted = [&](int t0) { return row_ok && b0 + t0 + 15 >= 0 && b0 + t0 < g.N; };
+  uint4 nxt = make_uint4(0, 0, 0, 0);
+  if (wanted(0)) nxt = tab[0];
+  __syncthreads();
+  for (int t0 = 0; t0 < T16; t0 += 16) {
+    const uint4 cur = nxt;
+    if (t0 + 16 < T16 && wanted(t0 + 16)) nxt = tab[(size_t)((t0 >> 4) + 1) * nthr];
+    const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int b = b0 + t0 + j;
+      if (row_ok && b >= 0 && b < g.N) {
+        const uint32_t o = (cw[j >> 2] >> (8 * (j & 3))) & 255u;
+        uint8_t* p = lds + pbase - 3 * b;
+        const uint8_t* q = p + nbase + (int)(o >> 4) * (HW * 3) + (int)(o & 15u) * 3;
+        const uint8_t q0 = q[0], q1 = q[1], q2 = q[2];
+        p[0] = q0; p[1] = q1; p[2] = q2;
+      }
+      __syncthreads();
+    }
+  }
+  uint4* o4 = reinterpret_cast<uint4*>(gi);
+  for (int i = tid; i < HW * HW * 3 / 16; i += nthr) o4[i] = l4[i];
+}
+
 // ---- defocus_blur ---------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
@@ -1053,10 +1139,23 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
       uint8_t* mid = (uint8_t*)a.workspace + rart_align_up((size_t)a.n * a.h * a.w * 3 * sizeof(double), 256);
       void* fr = mid + rart_align_up((size_t)a.n * a.h * a.w * 3, 256);
       gauss_u8_to_u8<1>(a.in, mid, tmp, a.n, a.h, a.w, g, a.stream, kGlass[s][0], fr);
-      if (!rart_raise_dynamic_lds((const void*)k_glass_shuffle, 224 * 224 * 3, "glass_blur")) return RART_ERR_HIP;
-      hipLaunchKernelGGL(k_glass_shuffle, dim3(a.n), dim3(kGlassThreads), 224 * 224 * 3, a.stream, mid,
-                         (int)kGlass[s][1], (int)kGlass[s][2], (const int8_t*)inj0, (uint32_t)a.seed,
-                         (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
+      if (!rart_raise_dynamic_lds((const void*)k_glass_shuffle, 224 * 224 * 3, "glass_blur") ||
+          !rart_raise_dynamic_lds((const void*)k_glass_shuffle_overlap, 224 * 224 * 3, "glass_blur"))
+        return RART_ERR_HIP;
+      GlassSched gs;
+      gs.delta = (int)kGlass[s][1]; gs.iters = (int)kGlass[s][2];
+      gs.N = 224 - 2 * gs.delta; gs.S = gs.delta + 1; gs.Toff = gs.delta * gs.S + gs.delta + 1;
+      gs.T = (gs.N - 1) * gs.S + gs.N + (gs.iters - 1) * gs.Toff; gs.nthr = 256 * gs.iters;
+      const size_t tab_img = (size_t)((gs.T + 15) & ~15) * gs.nthr;           // bytes of the offset table per image: lives in `tmp` (free between the two blurs)
+      if (gs.iters <= 3 && tab_img <= (size_t)a.h * a.w * 3 * sizeof(double) && a.n <= 65535 && getenv("RART_GLASS_SERIAL") == nullptr) {
+        hipLaunchKernelGGL(k_glass_offsets, dim3((unsigned)((tab_img / 16 + 255) / 256), a.n), dim3(256), 0, a.stream, (uint4*)tmp, gs,
+                           (const int8_t*)inj0, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
+        hipLaunchKernelGGL(k_glass_shuffle_overlap, dim3(a.n), dim3(gs.nthr), 224 * 224 * 3, a.stream, mid, (const uint8_t*)tmp, gs);
+      } else {
+        hipLaunchKernelGGL(k_glass_shuffle, dim3(a.n), dim3(kGlassThreads), 224 * 224 * 3, a.stream, mid,
+                           (int)kGlass[s][1], (int)kGlass[s][2], (const int8_t*)inj0, (uint32_t)a.seed,
+                           (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
+      }
       gauss_u8_to_u8<2>(mid, a.out, tmp, a.n, a.h, a.w, g, a.stream, kGlass[s][0], fr);
       break;
     }

@@ -170,6 +170,22 @@ def test_zoom_blur_table_kernel_equals_the_direct_kernel(sev):
     np.testing.assert_array_equal(fast[0], np.asarray(O.corrupt('zoom_blur', batch[0], sev)).astype(np.uint8))
 
 
+@pytest.mark.parametrize('sev', [1, 2, 3, 4, 5])
+def test_glass_shuffle_overlapped_iterations_equal_the_serial_kernel(sev):
+    """Round 5: glass_blur's copy chain with its iterations in flight together (k_glass_shuffle_overlap: time = it * Toff + a * S + b, a
+    schedule every dependency of the reference's scan order allows) == the kernel that drains the image between iterations
+    (RART_GLASS_SERIAL=1), on native draws; the injected draws of test_injected_within_stated_tolerance pin it to the oracle."""
+    import os
+    batch = np.stack(_hard_images(600 + sev)[:3] + [make_batch_u8(1, seed=600 + sev)[0]])
+    fast = _run('glass_blur', batch, sev, None, 21, 90)
+    os.environ['RART_GLASS_SERIAL'] = '1'
+    try:
+        slow = _run('glass_blur', batch, sev, None, 21, 90)
+    finally:
+        del os.environ['RART_GLASS_SERIAL']
+    np.testing.assert_array_equal(fast, slow)
+
+
 @pytest.mark.parametrize('name', ['motion_blur', 'snow'])
 @pytest.mark.parametrize('sev', [1, 2, 3, 4, 5])
 def test_motion_blur_tile_kernel_equals_the_direct_kernel(name, sev):
