@@ -29,11 +29,12 @@ __device__ __forceinline__ double u53(uint2 w) {
 // =====================================================================================
 constexpr int MAPN = 256;
 constexpr int PLASMA_DRAWS = 65535;
+constexpr int PLASMA_T = 1024;            // 16 waves per image (round 5; 4 until then: 274 us per 256 images, the last two levels are 80 % of the draws)
 
-__global__ __launch_bounds__(kBlock) void k_plasma(double* __restrict__ maps, double* __restrict__ minmax,
+__global__ __launch_bounds__(PLASMA_T) void k_plasma(double* __restrict__ maps, double* __restrict__ minmax,
                                                    const double* __restrict__ inj, double wibbledecay, uint32_t k0,
                                                    uint32_t k1, uint32_t sample_base) {
-  __shared__ double red[kBlock];
+  __shared__ double red[PLASMA_T];
   double* M = maps + (size_t)blockIdx.x * MAPN * MAPN;
   const double* dr = inj ? inj + (size_t)blockIdx.x * PLASMA_DRAWS : nullptr;
   const uint32_t sample = sample_base + blockIdx.x;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_plasma(double* __restrict__ maps, do
   for (int step = MAPN; step >= 2; step >>= 1) {
     const int m = MAPN / step, half = step / 2;
     // fillsquares
-    for (int e = threadIdx.x; e < m * m; e += kBlock) {
+    for (int e = threadIdx.x; e < m * m; e += PLASMA_T) {
       const int i = e / m, j = e % m, i1 = (i + 1) % m, j1 = (j + 1) % m;
       const double a = M[(i * step) * MAPN + j * step] + M[(i1 * step) * MAPN + j * step];
       const double b = M[(i * step) * MAPN + j1 * step] + M[(i1 * step) * MAPN + j1 * step];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_plasma(double* __restrict__ maps, do
     }
     __syncthreads();
     // filldiamonds (two independent sets)
-    for (int e = threadIdx.x; e < m * m; e += kBlock) {
+    for (int e = threadIdx.x; e < m * m; e += PLASMA_T) {
       const int i = e / m, j = e % m, i1 = (i + 1) % m, j1 = (j + 1) % m, im = (i + m - 1) % m, jm = (j + m - 1) % m;
       const double dr_ij = M[(half + i * step) * MAPN + half + j * step];
       const double ul_ij = M[(i * step) * MAPN + j * step];
@@ -80,20 +81,20 @@ __global__ __launch_bounds__(kBlock) void k_plasma(double* __restrict__ maps, do
   }
   // min, then max of (M - min)
   double mn = INFINITY;
-  for (int e = threadIdx.x; e < MAPN * MAPN; e += kBlock) mn = fmin(mn, M[e]);
+  for (int e = threadIdx.x; e < MAPN * MAPN; e += PLASMA_T) mn = fmin(mn, M[e]);
   red[threadIdx.x] = mn;
   __syncthreads();
-  for (int s = kBlock / 2; s > 0; s >>= 1) {
+  for (int s = PLASMA_T / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
   mn = red[0];
   __syncthreads();
   double mx = -INFINITY;
-  for (int e = threadIdx.x; e < MAPN * MAPN; e += kBlock) mx = fmax(mx, M[e] - mn);
+  for (int e = threadIdx.x; e < MAPN * MAPN; e += PLASMA_T) mx = fmax(mx, M[e] - mn);
   red[threadIdx.x] = mx;
   __syncthreads();
-  for (int s = kBlock / 2; s > 0; s >>= 1) {
+  for (int s = PLASMA_T / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
@@ -673,7 +674,7 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
         rart_set_error("fog: memset failed");
         return RART_ERR_HIP;
       }
-      hipLaunchKernelGGL(k_plasma, dim3(a.n), dim3(kBlock), 0, st, maps, minmax, (const double*)inj(0), kFog[s][1], k0,
+      hipLaunchKernelGGL(k_plasma, dim3(a.n), dim3(PLASMA_T), 0, st, maps, minmax, (const double*)inj(0), kFog[s][1], k0,
                          k1, sb);
       hipLaunchKernelGGL(k_image_max, dim3(8, a.n), dim3(kBlock), 0, st, a.in, imax, (uint32_t)(HW * HW * 3));
       hipLaunchKernelGGL(k_fog_blend, img_grid(a.n), dim3(kBlock), 0, st, a.in, a.out, maps, minmax, imax, kFog[s][0]);
