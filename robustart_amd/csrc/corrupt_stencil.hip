@@ -220,12 +220,17 @@ struct GlassSched {
 __global__ __launch_bounds__(256) void k_glass_offsets(uint4* __restrict__ tab_all, GlassSched g, const int8_t* __restrict__ inj,
                                                        uint32_t k0, uint32_t k1, uint32_t sample_base) {
   const int T16 = (g.T + 15) & ~15;
-  const int e = blockIdx.x * 256 + threadIdx.x;           // (block of 16 steps, lane), lane fastest: one 16-byte store per thread
-  if (e >= (T16 >> 4) * g.nthr) return;
-  const int blk = e / g.nthr, lane = e - blk * g.nthr;
+  // thread = (k-th 16-step block that overlaps the lane's window of N steps, lane), lane fastest: one 16-byte store per thread, and every
+  // thread of a wave has work (dealing ALL blocks of a lane left a wave 53 % active: its 64 windows are 3 S steps apart)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int nblk = (g.N + 15) / 16 + 1;                    // a window of N steps touches at most this many aligned blocks
+  if (e >= nblk * g.nthr) return;
+  const int k = e / g.nthr, lane = e - k * g.nthr;
   const int it = lane >> 8, a = lane & 255;
-  const int bb = blk * 16 - it * g.Toff - a * g.S;         // column of the block's first step
-  if (a >= g.N || bb + 15 < 0 || bb >= g.N) return;        // never read
+  const int t_first = it * g.Toff + a * g.S;               // the step of the lane's column 0
+  const int blk = (t_first >> 4) + k;
+  const int bb = blk * 16 - t_first;                       // column of the block's first step
+  if (a >= g.N || bb >= g.N || blk >= (T16 >> 4)) return;  // never read
   const int8_t* dr = inj ? inj + (size_t)blockIdx.y * g.iters * g.N * g.N * 2 : nullptr;
   uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void k_glass_offsets(uint4* __restrict__ tab_a
       w[j >> 2] |= (uint32_t)((dx + g.delta) | ((dy + g.delta) << 4)) << (8 * (j & 3));
     }
   }
-  tab_all[(size_t)blockIdx.y * (T16 >> 4) * g.nthr + e] = make_uint4(w[0], w[1], w[2], w[3]);
+  tab_all[(size_t)blockIdx.y * (T16 >> 4) * g.nthr + (size_t)blk * g.nthr + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 __global__ __launch_bounds__(768) void k_glass_shuffle_overlap(uint8_t* __restrict__ img_all, const uint8_t* __restrict__ tab_all,
@@ -1148,7 +1153,7 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
       gs.T = (gs.N - 1) * gs.S + gs.N + (gs.iters - 1) * gs.Toff; gs.nthr = 256 * gs.iters;
       const size_t tab_img = (size_t)((gs.T + 15) & ~15) * gs.nthr;           // bytes of the offset table per image: lives in `tmp` (free between the two blurs)
       if (gs.iters <= 3 && tab_img <= (size_t)a.h * a.w * 3 * sizeof(double) && a.n <= 65535 && getenv("RART_GLASS_SERIAL") == nullptr) {
-        hipLaunchKernelGGL(k_glass_offsets, dim3((unsigned)((tab_img / 16 + 255) / 256), a.n), dim3(256), 0, a.stream, (uint4*)tmp, gs,
+        hipLaunchKernelGGL(k_glass_offsets, dim3((unsigned)((((gs.N + 15) / 16 + 1) * gs.nthr + 255) / 256), a.n), dim3(256), 0, a.stream, (uint4*)tmp, gs,
                            (const int8_t*)inj0, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)a.sample_offset);
         hipLaunchKernelGGL(k_glass_shuffle_overlap, dim3(a.n), dim3(gs.nthr), 224 * 224 * 3, a.stream, mid, (const uint8_t*)tmp, gs);
       } else {
