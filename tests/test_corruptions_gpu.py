@@ -359,6 +359,49 @@ def test_odd_sizes_and_single_pixel_rows():
         assert out.shape == batch.shape
 
 
+@pytest.mark.parametrize('n', [1, 3, 5])
+def test_round5_kernels_on_odd_batch_counts(n):
+    """The kernels of round 5's second half deal images or image pairs to workgroups: single images and odd counts against their serial /
+    ordered forms (elastic's dense field filter groups two fields per workgroup; glass, spatter, fog, frost, motion: one image per workgroup / grid row)."""
+    import os
+    from robustart_amd.noise import imagenet_c as C
+    batch = make_batch_u8(n, seed=700 + n)
+    for name, sev, switch in (('elastic_transform', 1, 'RART_ELASTIC_ORDERED'), ('glass_blur', 3, 'RART_GLASS_SERIAL'),
+                              ('motion_blur', 5, 'RART_MOTION_DIRECT'), ('snow', 2, 'RART_MOTION_DIRECT')):
+        fast = _run(name, batch, sev, None, 3, 17)
+        os.environ[switch] = '1'
+        try:
+            slow = _run(name, batch, sev, None, 3, 17)
+        finally:
+            del os.environ[switch]
+        diff = np.abs(fast.astype(int) - slow.astype(int))
+        if name == 'elastic_transform':
+            assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
+        else:
+            np.testing.assert_array_equal(fast, slow, err_msg=name)
+    for name in ('spatter', 'fog'):
+        want, draws = _oracle_batch(name, batch, 2, case_seed(name, 2))
+        got = _run(name, batch, 2, draws)
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert diff.max() <= TOLERANT_INJECTED.get(name, (0, 0))[0], name
+
+
+def test_motion_blur_tile_kernel_on_other_image_sizes():
+    """motion_blur takes any image size (the reference's wand call does): partial 32 x 32 tiles and images smaller than a tile + its halo."""
+    import os
+    rs = np.random.RandomState(8)
+    for (h, w) in ((200, 180), (33, 70), (17, 9)):
+        batch = rs.randint(0, 256, (3, h, w, 3)).astype(np.uint8)
+        for sev in (1, 5):
+            fast = _run('motion_blur', batch, sev, None, 4, 2)
+            os.environ['RART_MOTION_DIRECT'] = '1'
+            try:
+                slow = _run('motion_blur', batch, sev, None, 4, 2)
+            finally:
+                del os.environ['RART_MOTION_DIRECT']
+            np.testing.assert_array_equal(fast, slow, err_msg=str((h, w, sev)))
+
+
 # ---- native RNG ---------------------------------------------------------------------------
 
 def _native_normals(n, elems, seed, offset):
