@@ -285,39 +285,64 @@ __global__ __launch_bounds__(kBlock) void k_field_gauss_lds(const TIN* __restric
 // per 16-row block).  NOT the reference's summation order: the fp64 results differ from scipy's in the last bits (~1e-16 relative), which
 // survives the cast of the displacement to fp32 for ~1e-9 of its elements; the corrupted images stay inside elastic_transform's stated
 // tolerance (<= 1 LSB on <= 1e-4 of the pixels; measured: identical on the test batches,
-// test_elastic_dense_field_filter_matches_the_ordered_kernels).  Used when the kernel is longer than the signal (2 radius + 1 > 224:
-// severity 1); RART_ELASTIC_ORDERED=1 keeps the ordered kernels.
+// test_elastic_dense_field_filter_matches_the_ordered_kernels).  Used when the kernel is longer than half the signal (4 radius + 2 > 224:
+// severity 1, and severity 2 -- sigma 19.5 px, 119 taps -- whose matrix is banded: the zero K steps are skipped); RART_ELASTIC_ORDERED=1
+// keeps the ordered kernels.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-constexpr int FD_THREADS = 448, FD_SLAB = 32, FD_GROUP = 2;  // 7 waves; a slab = 32 columns (pass 0) / 32 rows (pass 1); fields per workgroup
+constexpr int FD_THREADS = 448, FD_SLAB = 32, FD_GROUPS = 18; // 7 waves; a slab = 32 columns (pass 0) / 32 rows (pass 1); 14 x 18 = 252 persistent workgroups
 constexpr int FD_LDX = 48;                                   // pass 0: row stride of the [224][32] slab in doubles (96 dwords: K groups 32 banks apart)
 constexpr int FD_LDY = 226;                                  // pass 1: row stride of the [32][224] slab in doubles (452 dwords = 4 mod 64)
+constexpr int FD_PF = HW * FD_SLAB / FD_THREADS;             // 16 slab elements per thread
 
 // AXIS 0: Y[f][l][c] = sum_p M[l][p] X[f][p][c]            (TOUT double, post_scale 1)
 // AXIS 1: Z[f][r][c] = post_scale * sum_p Y[f][r][p] M[c][p]   (TOUT float)
-// grid (7 slabs x 2 halves, ceil(n / FD_GROUP)): wave w of half h owns the 16 output rows (AXIS 0) / columns (AXIS 1) of block 7 h + w and keeps
-// that block's 56 matrix fragments in registers for every field of its group; the data slab goes through LDS once per field.
+// grid (7 slabs x 2 halves, min(n, FD_GROUPS)), persistent: wave w of half h owns the 16 output rows (AXIS 0) / columns (AXIS 1) of block
+// 7 h + w and keeps that block's 56 matrix fragments in registers for EVERY field the workgroup walks (f = group, group + groups, ...); the data
+// slab goes through LDS once per field, the next field's slab already in flight into registers while this one is multiplied.  (First version: a
+// workgroup per two fields, slab staged and fragments re-read in the open: 201 / 188 us per 256 fields = 29 TFLOP/s.)
 template <int AXIS, typename TOUT>
 __global__ __launch_bounds__(FD_THREADS) void k_field_dense(const double* __restrict__ src, TOUT* __restrict__ dst,
-                                                            const double* __restrict__ mfrag, double post_scale, int n) {
+                                                            const double* __restrict__ mfrag, double post_scale, int n, int radius) {
   extern __shared__ __attribute__((aligned(16))) double fd_s[];     // AXIS 0: [224][FD_LDX]; AXIS 1: [32][FD_LDY]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slab = (int)blockIdx.x >> 1, blk = ((int)blockIdx.x & 1) * 7 + wave;
   const int j = lane & 15, kk = lane >> 4;
+  // element e = tid + FD_THREADS * q of a slab: where it comes from (offset inside the field) and where it goes in LDS
+  int goff[FD_PF], loff[FD_PF];
+#pragma unroll
+  for (int q = 0; q < FD_PF; ++q) {
+    const int e = tid + FD_THREADS * q;
+    if (AXIS == 0) {
+      goff[q] = (e >> 5) * HW + slab * FD_SLAB + (e & 31);
+      loff[q] = (e >> 5) * FD_LDX + (e & 31);
+    } else {
+      const int rr = e / HW;
+      goff[q] = slab * FD_SLAB * HW + e;
+      loff[q] = rr * FD_LDY + (e - rr * HW);
+    }
+  }
+  double pf[FD_PF];
+  int f = blockIdx.y;
+  if (f < n) {
+#pragma unroll
+    for (int q = 0; q < FD_PF; ++q) pf[q] = src[(size_t)f * HW * HW + goff[q]];
+  }
+  // rows 16 blk .. 16 blk + 15 of M are zero outside columns [16 blk - radius, 16 blk + 15 + radius] (taps past an edge fold back INTO that range):
+  // K steps outside it multiply by exact zeros and are skipped (severity 2: 34 of 56 steps per block)
+  const int ublk = __builtin_amdgcn_readfirstlane(blk);
+  const int s_lo = max(0, 16 * ublk - radius) >> 2, s_hi = (min(HW - 1, 16 * ublk + 15 + radius) >> 2) + 1;
   double m[56];
 #pragma unroll
-  for (int s = 0; s < 56; ++s) m[s] = mfrag[((size_t)blk * 56 + s) * 64 + lane];      // M[blk * 16 + j][4 s + kk]
-  const int f_end = min(n, ((int)blockIdx.y + 1) * FD_GROUP);
-  for (int f = (int)blockIdx.y * FD_GROUP; f < f_end; ++f) {
+  for (int s = 0; s < 56; ++s) m[s] = (s >= s_lo && s < s_hi) ? mfrag[((size_t)blk * 56 + s) * 64 + lane] : 0.0;      // M[blk * 16 + j][4 s + kk]
+  for (; f < n; f += gridDim.y) {
     const size_t fbase = (size_t)f * HW * HW;
-    if (AXIS == 0) {
-      for (int i = tid; i < HW * FD_SLAB; i += FD_THREADS) fd_s[(i >> 5) * FD_LDX + (i & 31)] = src[fbase + (size_t)(i >> 5) * HW + slab * FD_SLAB + (i & 31)];
-    } else {
-      for (int i = tid; i < FD_SLAB * HW; i += FD_THREADS) {
-        const int rr = i / HW;
-        fd_s[rr * FD_LDY + (i - rr * HW)] = src[fbase + (size_t)slab * FD_SLAB * HW + i];
-      }
-    }
+#pragma unroll
+    for (int q = 0; q < FD_PF; ++q) fd_s[loff[q]] = pf[q];
     __syncthreads();
+    if (f + (int)gridDim.y < n) {
+#pragma unroll
+      for (int q = 0; q < FD_PF; ++q) pf[q] = src[(size_t)(f + gridDim.y) * HW * HW + goff[q]];
+    }
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {
       f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -325,8 +350,10 @@ __global__ __launch_bounds__(FD_THREADS) void k_field_dense(const double* __rest
 #pragma unroll
       for (int s = 0; s < 56; ++s) {
         // v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]; D[row = (lane >> 4) + 4 reg][col = lane & 15]
-        if (AXIS == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[s], lp[4 * s * FD_LDX], acc, 0, 0, 0);
-        else           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[4 * s], m[s], acc, 0, 0, 0);
+        if (s >= s_lo && s < s_hi) {
+          if (AXIS == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[s], lp[4 * s * FD_LDX], acc, 0, 0, 0);
+          else           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[4 * s], m[s], acc, 0, 0, 0);
+        }
         if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -731,8 +758,8 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
       }
       hipLaunchKernelGGL(k_elastic_affine, dim3(a.n), dim3(1), 0, st, inv, (const float*)inj(0), (float)c[2], k0, k1, sb);
       hipLaunchKernelGGL(k_warp_affine, img_grid(a.n), dim3(kBlock), 0, st, a.in, warped, inv);
-      // the kernel is longer than the signal (severity 1): both passes as fp64 matrix products against the folded filter matrix
-      bool dense = 2 * radius + 1 > HW && getenv("RART_ELASTIC_ORDERED") == nullptr;
+      // the kernel is longer than half the signal (severities 1 and 2): both passes as fp64 matrix products against the folded filter matrix
+      bool dense = 4 * radius + 2 > HW && getenv("RART_ELASTIC_ORDERED") == nullptr;          // severities 1 (radius 512) and 2 (radius 59)
       double* mdev = wdev + A256(1025 * sizeof(double)) / sizeof(double);
       const size_t lds0 = (size_t)HW * FD_LDX * sizeof(double), lds1 = (size_t)FD_SLAB * FD_LDY * sizeof(double);
       if (dense) {
@@ -747,10 +774,10 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
           hipLaunchKernelGGL(k_uniform_field, img_grid(a.n), dim3(kBlock), 0, st, f0, k0, k1, sb, 11 + which);
           fsrc = f0;
         }
-        const dim3 grid(2 * (HW / FD_SLAB), (unsigned)((a.n + FD_GROUP - 1) / FD_GROUP));
-        hipLaunchKernelGGL((k_field_dense<0, double>), grid, dim3(FD_THREADS), lds0, st, fsrc, f1, (const double*)mdev, 1.0, a.n);
+        const dim3 grid(2 * (HW / FD_SLAB), (unsigned)(a.n < FD_GROUPS ? a.n : FD_GROUPS));
+        hipLaunchKernelGGL((k_field_dense<0, double>), grid, dim3(FD_THREADS), lds0, st, fsrc, f1, (const double*)mdev, 1.0, a.n, radius);
         hipLaunchKernelGGL((k_field_dense<1, float>), grid, dim3(FD_THREADS), lds1, st, (const double*)f1, which == 0 ? dx : dy,
-                           (const double*)mdev, c[0], a.n);
+                           (const double*)mdev, c[0], a.n, radius);
       }
       const bool dense_done = dense;
       for (int which = 0; which < 2 && !dense_done; ++which) {

@@ -219,9 +219,10 @@ def test_frost_in_kernel_crops_equal_injected_crops():
         C.set_frost_textures([])
 
 
+@pytest.mark.parametrize('sev', [1, 2])
 @pytest.mark.parametrize('injected', [False, True])
-def test_elastic_dense_field_filter_matches_the_ordered_kernels(injected):
-    """Round 5: elastic_transform severity 1 (sigma 170.8 px: 1 025 taps over a 224-sample signal) filters its displacement fields as two fp64
+def test_elastic_dense_field_filter_matches_the_ordered_kernels(injected, sev):
+    """Round 5: elastic_transform severities 1 (sigma 170.8 px: 1 025 taps over a 224-sample signal) and 2 (sigma 19.5 px: 119 taps, banded matrix) filter its displacement fields as two fp64
     matrix products against the folded reflect-filter matrix (k_field_dense, v_mfma_f64_16x16x4_f64).  Its summation order is not scipy's, so the
     claim is the corruption's stated tolerance, checked against the ordered kernels (RART_ELASTIC_ORDERED=1) on native draws and against them +
     the oracle on injected fields."""
@@ -229,11 +230,11 @@ def test_elastic_dense_field_filter_matches_the_ordered_kernels(injected):
     batch = np.stack(_hard_images(410)[:4]) if not injected else make_batch_u8(2, seed=411)
     draws = None
     if injected:
-        want, draws = _oracle_batch('elastic_transform', batch, 1, case_seed('elastic_transform', 1))
-    fast = _run('elastic_transform', batch, 1, draws, 5, 70)
+        want, draws = _oracle_batch('elastic_transform', batch, sev, case_seed('elastic_transform', sev))
+    fast = _run('elastic_transform', batch, sev, draws, 5, 70)
     os.environ['RART_ELASTIC_ORDERED'] = '1'
     try:
-        slow = _run('elastic_transform', batch, 1, draws, 5, 70)
+        slow = _run('elastic_transform', batch, sev, draws, 5, 70)
     finally:
         del os.environ['RART_ELASTIC_ORDERED']
     max_lsb, max_frac = TOLERANT_INJECTED['elastic_transform']
