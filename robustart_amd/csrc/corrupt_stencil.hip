@@ -1029,9 +1029,114 @@ const double kGlass[5][3] = {{0.7, 1, 2}, {0.9, 2, 1}, {1, 2, 3}, {1.1, 3, 2}, {
 const double kDefocus[5][2] = {{3, 0.1}, {4, 0.5}, {6, 0.5}, {8, 0.5}, {10, 0.5}};
 const double kMotion[5][2] = {{10, 3}, {15, 5}, {15, 8}, {15, 12}, {20, 15}};
 
+// ---- the small Gaussians (radius 3, 4, 6: both blurs of glass_blur at every severity, gaussian_blur severity 1) -- round 5 ---------------------
+// k_gauss_i8 costs 166-186 us per 256 images whatever the radius (the digit split and the 18 MFMAs do not shrink with it); k_gauss_fused re-reads
+// every tap of every output from LDS (300 us at radius 4).  Here the ordered fp64 sums run from REGISTER windows: pass 1 (along H) is one
+// thread per column element sliding down 12 + 2 R rows (one coalesced byte load per row, the 2 R + 1 window in registers, compile-time ring), pass 2
+// (along W) one thread per run of 4 pixels and channel by channel a 4 + 2 R window read once from the LDS row -- 3 reads per output instead of
+// 2 R + 1.  The same operations in the same order as k_gauss_pass / k_gauss_fused (scipy's symmetric correlate1d): bit-identical to them and hence to
+// k_gauss_i8 (test_gaussian_fast_path_equals_the_ordered_fp64_kernels covers all three).  RART_GAUSS_SMALL_OFF=1 disables.
+constexpr int GS_TH = 12, GS_THREADS = 704, GS_TILES = (224 + GS_TH - 1) / GS_TH;
+template <int R, int FINISH>
+__global__ __launch_bounds__(GS_THREADS) void k_gauss_small(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, GaussW g) {
+  constexpr int HW = 224, RWD = (HW + 2 * R) * 3;            // an LDS row: R halo pixels on each side
+  __shared__ double lut[256];
+  __shared__ double p1[GS_TH * RWD];
+  const int tid = threadIdx.x;
+  if (tid < 256) lut[tid] = (double)tid / 255.0;
+  __syncthreads();
+  const int y0 = blockIdx.x * GS_TH;
+  const uint8_t* img = src + (size_t)blockIdx.y * HW * HW * 3;
+  if (tid < HW * 3) {
+    // pass 1, axis 0: element tid of a row; win[k] = in(y + k - R), mode='nearest'
+    const int px = tid / 3;
+    double win[2 * R + 1];
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) {
+      int yy = y0 - R + k;
+      yy = yy < 0 ? 0 : (yy > HW - 1 ? HW - 1 : yy);
+      win[k + 1] = lut[img[(size_t)yy * (HW * 3) + tid]];
+    }
+#pragma unroll
+    for (int ty = 0; ty < GS_TH; ++ty) {
+#pragma unroll
+      for (int k = 0; k < 2 * R; ++k) win[k] = win[k + 1];
+      int yy = y0 + ty + R;
+      yy = yy < 0 ? 0 : (yy > HW - 1 ? HW - 1 : yy);
+      win[2 * R] = lut[img[(size_t)yy * (HW * 3) + tid]];
+      double tmp = win[R] * g.w[R];
+#pragma unroll
+      for (int jj = -R; jj < 0; ++jj) {
+        const double pair = win[R + jj] + win[R - jj];
+        tmp += pair * g.w[jj + R];
+      }
+      double* row = p1 + ty * RWD;
+      row[R * 3 + tid] = tmp;
+      if (px == 0) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) row[k * 3 + tid] = tmp;                       // columns -R .. -1 = column 0 (tid = its channel)
+      }
+      if (px == HW - 1) {
+#pragma unroll
+        for (int k = 1; k <= R; ++k) row[(R + k) * 3 + tid] = tmp;                // columns 224 .. 223 + R = column 223
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < GS_TH * (HW / 4)) {
+    // pass 2, axis 1: row ty, pixels 4 run .. 4 run + 3, channel by channel
+    const int ty = tid / (HW / 4), run = tid - ty * (HW / 4);
+    const int yy = y0 + ty;
+    if (yy < HW) {
+      const double* row = p1 + ty * RWD + (4 * run) * 3;                           // element of pixel (4 run - R)
+      uint32_t ob[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double win[4 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * R; ++k) win[k] = row[k * 3 + c];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          double tmp = win[o + R] * g.w[R];
+#pragma unroll
+          for (int jj = -R; jj < 0; ++jj) {
+            const double pair = win[o + R + jj] + win[o + R - jj];
+            tmp += pair * g.w[jj + R];
+          }
+          uint32_t b;
+          if (FINISH == 1) {
+            b = (uint32_t)(uint8_t)(uint32_t)(tmp * 255.0);
+          } else {
+            const double cl = tmp < 0.0 ? 0.0 : (tmp > 1.0 ? 1.0 : tmp);
+            b = (uint32_t)(uint8_t)(uint32_t)(cl * 255.0);
+          }
+          const int byte = o * 3 + c;                                              // byte of the 12-byte run
+          ob[byte >> 2] |= b << (8 * (byte & 3));
+        }
+      }
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * HW * HW * 3 + ((size_t)yy * HW + 4 * run) * 3);
+      o32[0] = ob[0]; o32[1] = ob[1]; o32[2] = ob[2];
+    }
+  }
+}
+
+template <int FINISH>
+bool launch_gauss_small(const uint8_t* in, uint8_t* out, int n, const GaussW& g, hipStream_t s) {
+  const dim3 grid(GS_TILES, (unsigned)n), blk(GS_THREADS);
+  switch (g.radius) {
+    case 3: hipLaunchKernelGGL((k_gauss_small<3, FINISH>), grid, blk, 0, s, in, out, g); return true;
+    case 4: hipLaunchKernelGGL((k_gauss_small<4, FINISH>), grid, blk, 0, s, in, out, g); return true;
+    case 6: hipLaunchKernelGGL((k_gauss_small<6, FINISH>), grid, blk, 0, s, in, out, g); return true;
+  }
+  return false;
+}
+
 template <int FINISH>
 void gauss_u8_to_u8(const uint8_t* in, uint8_t* out, double* tmp, int n, int h, int w, const GaussW& g,
                     hipStream_t s, double sigma = 0.0, void* frag_ws = nullptr) {
+  if (FINISH != 0 && h == 224 && w == 224 && n <= 65535 && ((uintptr_t)out & 3) == 0 && getenv("RART_GAUSS_FP64") == nullptr &&
+      getenv("RART_GAUSS_SMALL_OFF") == nullptr && launch_gauss_small<FINISH>(in, out, n, g, s))
+    return;
   if (frag_ws && h == 224 && w == 224 && n <= 65535 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
       getenv("RART_GAUSS_FP64") == nullptr) {
     // the matrix-core path (exact fixed point + ordered-fp64 recompute of ambiguous tiles); anything else: the fp64 kernels below
