@@ -1029,7 +1029,7 @@ const double kGlass[5][3] = {{0.7, 1, 2}, {0.9, 2, 1}, {1, 2, 3}, {1.1, 3, 2}, {
 const double kDefocus[5][2] = {{3, 0.1}, {4, 0.5}, {6, 0.5}, {8, 0.5}, {10, 0.5}};
 const double kMotion[5][2] = {{10, 3}, {15, 5}, {15, 8}, {15, 12}, {20, 15}};
 
-// ---- the small Gaussians (radius 3, 4, 6: both blurs of glass_blur at every severity, gaussian_blur severity 1) -- round 5 ---------------------
+// ---- the small Gaussians (radius 3, 4, 6, 8: both blurs of glass_blur at every severity, gaussian_blur severities 1-2) -- round 5 ---------------------
 // k_gauss_i8 costs 166-186 us per 256 images whatever the radius (the digit split and the 18 MFMAs do not shrink with it); k_gauss_fused re-reads
 // every tap of every output from LDS (300 us at radius 4).  Here the ordered fp64 sums run from REGISTER windows: pass 1 (along H) is one
 // thread per column element sliding down 12 + 2 R rows (one coalesced byte load per row, the 2 R + 1 window in registers, compile-time ring), pass 2
@@ -1127,6 +1127,7 @@ bool launch_gauss_small(const uint8_t* in, uint8_t* out, int n, const GaussW& g,
     case 3: hipLaunchKernelGGL((k_gauss_small<3, FINISH>), grid, blk, 0, s, in, out, g); return true;
     case 4: hipLaunchKernelGGL((k_gauss_small<4, FINISH>), grid, blk, 0, s, in, out, g); return true;
     case 6: hipLaunchKernelGGL((k_gauss_small<6, FINISH>), grid, blk, 0, s, in, out, g); return true;
+    case 8: hipLaunchKernelGGL((k_gauss_small<8, FINISH>), grid, blk, 0, s, in, out, g); return true;
   }
   return false;
 }
