@@ -30,6 +30,9 @@ __device__ __forceinline__ double u53(uint2 w) {
 constexpr int MAPN = 256;
 constexpr int PLASMA_DRAWS = 65535;
 constexpr int PLASMA_T = 1024;            // 16 waves per image (round 5; 4 until then: 274 us per 256 images, the last two levels are 80 % of the draws)
+// (Round 5 also ran the last two levels as grid-wide launches, one thread per element, + a min / max reduction kernel: 34 + 47 + 84 + 20 = 185 us
+//  against 196 for this kernel -- the levels are bound by the strided fp64 map traffic through L2 (134 MB of maps per 256 images, every line of it
+//  read and half of it written by the last level), not by the one workgroup's latency.  Not kept: eight launches for 6 %.)
 
 __global__ __launch_bounds__(PLASMA_T) void k_plasma(double* __restrict__ maps, double* __restrict__ minmax,
                                                    const double* __restrict__ inj, double wibbledecay, uint32_t k0,
