@@ -109,7 +109,7 @@ int rart_noise_multi_u8(const uint8_t* in, uint8_t* const* outs, int ns, int n, 
  * uint8 [k_tex][sh][sw][3] (each padded to the common size; dims_host: host int[2 k_tex] = height, width of each).  The texture index and the
  * crop origin of image i are the counter generator's uniforms of streams 8, 9, 10 at sample sample_offset + i, drawn in the kernel, which reads
  * the crop in place: bit-identical to rart_corrupt_u8(RART_FROST) with those crops injected, without the gather (n x 150 528 B written and
- * read back).  h = w = 224 only, as the reference.  in == out allowed. */
+ * read back).  h = w = 224 only, as the reference; in / out 16-byte aligned.  in == out allowed. */
 int rart_frost_textures_u8(const uint8_t* in, uint8_t* out, int n, int h, int w, int severity, const uint8_t* stack, int k_tex, int sh, int sw,
                            const int* dims_host, uint64_t seed, uint64_t sample_offset, rart_stream_t stream);
 

@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_frost_blend(const uint8_t* __restric
 // floor(u_8 * min(5, k)) (corruptions.py:250: randint(5) over the six-entry list), crop origin floor(u_9 * (height - 224)),
 // floor(u_10 * (width - 224)) (corruptions.py:259), u_s = the counter generator's uniform of stream s at element 0 of the sample --
 // the draws robustart_amd/noise/imagenet_c.py made on the host (rng.host_uniform_many) before gathering the n crops with a torch
-// index expression (211 us + nine small launches + an upload per 256 images; the blend itself is 50 us).  grid (147, n): a thread blends 4 bytes.
+// index expression (211 us + nine small launches + an upload per 256 images; the blend itself is 50 us).  grid (37, n): a thread blends 16 bytes.
 struct FrostTex {
   int k_draw, sh, sw;
   int th[8], tw[8];
@@ -701,21 +701,23 @@ __global__ __launch_bounds__(kBlock) void k_frost_textures(const uint8_t* __rest
   };
   const int idx = (int)(u53(8) * (double)t.k_draw);
   const int xs = (int)(u53(9) * (double)(t.th[idx] - 224)), ys = (int)(u53(10) * (double)(t.tw[idx] - 224));
-  const int q = blockIdx.x * kBlock + threadIdx.x;                   // dword of the image: 168 per row
-  const int row = q / 168, cb = (q - row * 168) * 4;
-  const size_t o = (size_t)blockIdx.y * (224 * 672) + (size_t)q * 4;
+  const int q = blockIdx.x * kBlock + threadIdx.x;                   // 16-byte piece of the image: 42 per row
+  if (q >= 224 * 42) return;
+  const int row = q / 42, cb = (q - row * 42) * 16;
+  const size_t o = (size_t)blockIdx.y * (224 * 672) + (size_t)q * 16;
   const uint8_t* tp = stack + (((size_t)idx * t.sh + (xs + row)) * t.sw + ys) * 3 + cb;
-  const uint32_t pin = *(const uint32_t*)(in + o);
-  uint32_t r = 0;
+  const uint4 pin4 = *(const uint4*)(in + o);
+  const uint32_t pin[4] = {pin4.x, pin4.y, pin4.z, pin4.w};
+  uint32_t r[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const double ax = a * (double)((pin >> (8 * j)) & 255u);
+  for (int j = 0; j < 16; ++j) {
+    const double ax = a * (double)((pin[j >> 2] >> (8 * (j & 3))) & 255u);
     const double bt = b * (double)tp[j];
     double v = ax + bt;
     v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
-    r |= (uint32_t)v << (8 * j);
+    r[j >> 2] |= (uint32_t)v << (8 * (j & 3));
   }
-  *(uint32_t*)(out + o) = r;
+  *(uint4*)(out + o) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
 }  // namespace
@@ -961,7 +963,7 @@ extern "C" int rart_frost_textures_u8(const uint8_t* in, uint8_t* out, int n, in
   RART_CHECK_ARG(h == 224 && w == 224, "frost: reference hard-codes 224x224 (corruptions.py:259-260)");
   RART_CHECK_ARG(severity >= 1 && severity <= 5, "rart_frost_textures_u8: severity must be 1..5");
   RART_CHECK_ARG(k_tex >= 1 && k_tex <= 8, "rart_frost_textures_u8: 1..8 photographs");
-  RART_CHECK_ARG(!(reinterpret_cast<uintptr_t>(in) & 3) && !(reinterpret_cast<uintptr_t>(out) & 3), "rart_frost_textures_u8: 4-byte aligned batches");
+  RART_CHECK_ARG(!(reinterpret_cast<uintptr_t>(in) & 15) && !(reinterpret_cast<uintptr_t>(out) & 15), "rart_frost_textures_u8: 16-byte aligned batches");
   FrostTex t;
   t.k_draw = k_tex < 5 ? k_tex : 5;
   t.sh = sh;
@@ -973,7 +975,7 @@ extern "C" int rart_frost_textures_u8(const uint8_t* in, uint8_t* out, int n, in
                    "rart_frost_textures_u8: every photograph must be at least 224 x 224 and fit the stack");
   }
   static const double fr[5][2] = {{1, 0.4}, {0.8, 0.6}, {0.7, 0.7}, {0.65, 0.7}, {0.6, 0.75}};
-  hipLaunchKernelGGL(k_frost_textures, dim3(224 * 168 / kBlock, n), dim3(kBlock), 0, (hipStream_t)stream, in, out, stack, t, fr[severity - 1][0],
+  hipLaunchKernelGGL(k_frost_textures, dim3((224 * 42 + kBlock - 1) / kBlock, n), dim3(kBlock), 0, (hipStream_t)stream, in, out, stack, t, fr[severity - 1][0],
                      fr[severity - 1][1], (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset);
   RART_CHECK_LAUNCH("rart_frost_textures_u8");
   return RART_OK;

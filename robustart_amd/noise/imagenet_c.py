@@ -122,7 +122,8 @@ def corrupt_batch_(batch, corruption_id, severity, seed=None, sample_offset=None
         seed = _rng.current_seed()
     if sample_offset is None:
         sample_offset = _rng.next_offset(n)
-    if draws is None and name == 'frost' and (h, w) == (224, 224) and 1 <= len(_frost_textures) <= 8 and n <= 65535:
+    if draws is None and name == 'frost' and (h, w) == (224, 224) and 1 <= len(_frost_textures) <= 8 and n <= 65535 \
+            and batch.data_ptr() % 16 == 0 and (out is None or out.data_ptr() % 16 == 0):
         # the photographs are resident on the device: texture index, crop origin and crop read happen in the blend kernel
         stack = _frost_stack(torch, batch.device)
         dims = (ctypes.c_int * (2 * len(_frost_textures)))(*[int(v) for t in _frost_textures for v in t.shape[:2]])
