@@ -132,6 +132,9 @@ __global__ __launch_bounds__(kBlock) void k_fog_blend(const uint8_t* __restrict_
                                                       const double* __restrict__ maps,
                                                       const double* __restrict__ minmax,
                                                       const uint32_t* __restrict__ imax, double c0) {
+  __shared__ double lut[256];                    // b / 255.0: the same division, once per workgroup instead of three times per pixel (round 5)
+  lut[threadIdx.x] = (double)threadIdx.x / 255.0;
+  __syncthreads();
   const int img = blockIdx.y;
   const double mn = minmax[img * 2], mxm = minmax[img * 2 + 1];
   const double max_val = (double)imax[img] / 255.0;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_fog_blend(const uint8_t* __restrict_
     const double add = c0 * pl;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double v = (double)in[base + p * 3 + c] / 255.0 + add;
+      const double v = lut[in[base + p * 3 + c]] + add;
       const double num = v * max_val;
       double r = num / (max_val + c0);
       r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
@@ -441,19 +444,23 @@ __global__ __launch_bounds__(kBlock) void k_snow_layer_u8(const double* __restri
 
 __global__ __launch_bounds__(kBlock) void k_snow_blend(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                        const uint8_t* __restrict__ layer_u8, float c6, float omc6) {
+  __shared__ double lutd[256];                   // b / 255.0 and b / 255.0f: the same divisions, once per workgroup (round 5)
+  __shared__ float lutf[256];
+  lutd[threadIdx.x] = (double)threadIdx.x / 255.0;
+  lutf[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  __syncthreads();
   const int img = blockIdx.y;
   const size_t base = (size_t)img * HW * HW * 3;
   const uint8_t* L = layer_u8 + (size_t)img * HW * HW;
   for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < HW * HW; p += gridDim.x * kBlock) {
     const int y = p / HW, x = p % HW;
-    const float r = (float)in[base + p * 3] / 255.0f, g = (float)in[base + p * 3 + 1] / 255.0f,
-                b = (float)in[base + p * 3 + 2] / 255.0f;
+    const float r = lutf[in[base + p * 3]], g = lutf[in[base + p * 3 + 1]], b = lutf[in[base + p * 3 + 2]];
     const float g0 = 0.299f * r, g1 = 0.587f * g, g2 = 0.114f * b;
     const float gray = (g0 + g1) + g2;
     const float gg = gray * 1.5f;
     const float lift = gg + 0.5f;
-    const double s1 = (double)L[p] / 255.0;
-    const double s2 = (double)L[(HW - 1 - y) * HW + (HW - 1 - x)] / 255.0;  // np.rot90(k=2)
+    const double s1 = lutd[L[p]];
+    const double s2 = lutd[L[(HW - 1 - y) * HW + (HW - 1 - x)]];  // np.rot90(k=2)
     const float px[3] = {r, g, b};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
