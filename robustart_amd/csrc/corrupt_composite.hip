@@ -647,6 +647,7 @@ std::vector<double> gauss_weights(double sigma, double truncate, int* radius) {
 // the folded filter matrix of `mode='reflect'` in MFMA fragment order: frag[(block * 56 + s) * 64 + lane] = M[block * 16 + (lane & 15)][4 s + (lane >> 4)]
 const std::vector<double>& cached_dense_matrix(int slot, const std::vector<double>& w, int radius) {
   static std::vector<double> tabs[16];
+  std::lock_guard<std::mutex> lk(rart_host_table_mutex());
   if (tabs[slot].empty()) {
     std::vector<long double> M((size_t)HW * HW, 0.0L);
     for (int l = 0; l < HW; ++l)
@@ -681,6 +682,7 @@ size_t A256(size_t v) { return rart_align_up(v, 256); }
 const std::vector<double>& cached_weights(int slot, double sigma, double truncate, int* radius) {
   static std::vector<double> tabs[16];
   static int radii[16];
+  std::lock_guard<std::mutex> lk(rart_host_table_mutex());
   if (tabs[slot].empty()) tabs[slot] = gauss_weights(sigma, truncate, &radii[slot]);
   *radius = radii[slot];
   return tabs[slot];

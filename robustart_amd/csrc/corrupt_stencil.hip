@@ -774,6 +774,7 @@ GaussI8Host make_gauss_i8(const GaussW& gw, double sigma) {
 const GaussI8Host& gauss_i8_for(const GaussW& gw, double sigma) {
   static GaussI8Host cache[16];
   static int used = 0;
+  std::lock_guard<std::mutex> lk(rart_host_table_mutex());
   for (int i = 0; i < used; ++i)
     if (cache[i].sigma == sigma) return cache[i];
   const int slot = used < 16 ? used++ : 15;
@@ -1275,7 +1276,10 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
       // async upload below never reads freed host memory
       static std::vector<double> disks[5];
       static int ksz[5];
-      if (disks[s].empty()) disks[s] = make_disk((int)kDefocus[s][0], kDefocus[s][1], &ksz[s]);
+      {
+        std::lock_guard<std::mutex> lk(rart_host_table_mutex());
+        if (disks[s].empty()) disks[s] = make_disk((int)kDefocus[s][0], kDefocus[s][1], &ksz[s]);
+      }
       if (hipMemcpyAsync(a.workspace, disks[s].data(), disks[s].size() * sizeof(double), hipMemcpyHostToDevice,
                          a.stream) != hipSuccess) {
         rart_set_error("defocus_blur: kernel upload failed");
@@ -1286,7 +1290,10 @@ int rart_launch_stencil(int id, const RartCorruptArgs& a) {
         // the matrix-core path (17 x 17 disks = severities 1-4, 224 x 224 images, 16-byte aligned batches); everything else: k_filter2d
         static FilterI8Host fast[5];
         static bool fast_made[5] = {false, false, false, false, false};
-        if (!fast_made[s]) { fast[s] = make_filter_i8(disks[s], ksz[s]); fast_made[s] = true; }
+        {
+          std::lock_guard<std::mutex> lk(rart_host_table_mutex());
+          if (!fast_made[s]) { fast[s] = make_filter_i8(disks[s], ksz[s]); fast_made[s] = true; }
+        }
         const bool use_fast = fast[s].ok && a.h == 224 && a.w == 224 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.out & 15) == 0 &&
                               getenv("RART_DEFOCUS_FP64") == nullptr;
         const void* kfn = ksz[s] == 17 ? (const void*)k_filter2d_i8<17, 16> : (const void*)k_filter2d_i8<21, 12>;

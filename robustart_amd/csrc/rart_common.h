@@ -4,6 +4,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/robustart_hip.h"
+#include <mutex>
+// The lazily built process-lifetime host tables (gaussian weights, disks, fixed-point fragments, the folded filter matrix) are shared by every
+// thread that calls the library (ctypes releases the GIL: a loader thread and the main thread can be inside it together): one lock around
+// their construction.
+inline std::mutex& rart_host_table_mutex() {
+  static std::mutex mu;
+  return mu;
+}
 
 #define RART_VERSION RART_ABI_VERSION
 

@@ -403,6 +403,40 @@ def test_motion_blur_tile_kernel_on_other_image_sizes():
             np.testing.assert_array_equal(fast, slow, err_msg=str((h, w, sev)))
 
 
+def test_two_host_threads_on_two_streams_give_the_sequential_results():
+    """ctypes releases the GIL, so a loader thread and the main thread can be inside the library together: per-stream scratch buffers, a
+    thread-local error string and one lock around the lazily built host tables.  Two threads, each on its own stream, against the same calls
+    made one after the other."""
+    import threading
+    from robustart_amd.noise import imagenet_c as C
+    jobs = [('elastic_transform', 1), ('defocus_blur', 3), ('gaussian_blur', 4), ('spatter', 2), ('glass_blur', 1), ('motion_blur', 2),
+            ('defocus_blur', 5), ('elastic_transform', 2), ('zoom_blur', 3), ('fog', 2)]
+    batch = make_batch_u8(3, seed=900)
+    want = [_run(n, batch, s, None, 12, 5) for n, s in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for i in range(k, len(jobs), 2):
+                    dev = torch.from_numpy(batch.copy()).cuda()
+                    C.corrupt_batch_(dev, _cid(jobs[i][0]), jobs[i][1], seed=12, sample_offset=5)
+                    st.synchronize()
+                    got[i] = dev.cpu().numpy()
+        except Exception as e:          # surfaced below
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for (n, s), g, w in zip(jobs, got, want):
+        np.testing.assert_array_equal(g, w, err_msg='%s %d' % (n, s))
+
+
 # ---- native RNG ---------------------------------------------------------------------------
 
 def _native_normals(n, elems, seed, offset):
