@@ -70,6 +70,7 @@ struct AxisTable {
 const AxisTable& linear_family_table(int ssize, int dsize, int interp, bool is_x) {
   // cached for the process lifetime: the asynchronous upload reads the host vector after this call returns
   static std::map<std::tuple<int, int, int, bool>, AxisTable> cache;
+  std::lock_guard<std::mutex> lk(rart_host_table_mutex());      // (loader threads: see rart_common.h)
   const auto key = std::make_tuple(ssize, dsize, interp, is_x);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -113,6 +114,7 @@ struct AreaTable {
 };
 const AreaTable& area_table(int ssize, int dsize) {
   static std::map<std::pair<int, int>, AreaTable> cache;
+  std::lock_guard<std::mutex> lk(rart_host_table_mutex());      // (loader threads: see rart_common.h)
   const auto key = std::make_pair(ssize, dsize);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;

@@ -54,6 +54,7 @@ struct CoeffTable {
 };
 const CoeffTable& coeff_table(int in_size, int out_size, int f) {
   static std::map<std::tuple<int, int, int>, CoeffTable> cache;
+  std::lock_guard<std::mutex> lk(rart_host_table_mutex());      // (loader threads: see rart_common.h)
   auto key = std::make_tuple(in_size, out_size, f);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
