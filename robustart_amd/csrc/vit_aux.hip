@@ -223,6 +223,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // round
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2_t));
 }
 
+// Round 5 measured the launch alone (scratch/r5/time_attention.py, B = 256: 122 us = 2.5 TB/s on q, k, v, out, 250 TFLOP/s; the interleaved
+// [token][3 x 768] layout costs nothing: every head as its own image 121 us) and one variant: a wave per query tile (7 waves instead of 4 walking 7
+// tiles in two rounds) with the Q fragments requested before the K / V staging -- 134 us at the 128 VGPRs two resident workgroups allow (18 spilled).
+// The CU is idle ~70 % of the launch: two resident workgroups alternate between a 75 KB staging phase and ~3 us of matrix + soft-max work; the next
+// step is a persistent workgroup that stages (image, head) i + 1 while it multiplies i.
 template <int NKT>
 __global__ __launch_bounds__(kBlock, 2) void k_vit_attention(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ att,
                                                              int T, int H, int ld, int D, float scale_log2e) {
