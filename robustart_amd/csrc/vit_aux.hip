@@ -223,56 +223,75 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // round
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2_t));
 }
 
-// Round 5 measured the launch alone (scratch/r5/time_attention.py, B = 256: 122 us = 2.5 TB/s on q, k, v, out, 250 TFLOP/s; the interleaved
-// [token][3 x 768] layout costs nothing: every head as its own image 121 us) and one variant: a wave per query tile (7 waves instead of 4 walking 7
-// tiles in two rounds) with the Q fragments requested before the K / V staging -- 134 us at the 128 VGPRs two resident workgroups allow (18 spilled).
-// The CU is idle ~70 % of the launch: two resident workgroups alternate between a 75 KB staging phase and ~3 us of matrix + soft-max work; the next
-// step is a persistent workgroup that stages (image, head) i + 1 while it multiplies i.
+// Round 5 measured the launch alone (scratch/r5/time_attention.py, B = 256, 12 heads, 197 tokens).  One workgroup of 4 waves per (image, head), two
+// resident per CU: 122 us = 2.5 TB/s on q, k, v, out, 250 TFLOP/s -- the CU idle ~70 % of the launch between 75 KB staging phases; the interleaved
+// [token][3 x 768] layout costs nothing (every head as its own image: 121 us).  A wave per query tile with the Q fragments requested before the
+// staging, still one workgroup per item: 134 us (128 VGPRs for two resident workgroups: 18 spilled).  This kernel -- persistent, the next item's
+// K / V / Q in flight into registers under the current item's work -- 98.7 us = 3.1 TB/s, 309 TFLOP/s; what is left is the soft-max's
+// 112 v_exp_f32 per lane and tile (quarter rate) on 7 waves over 4 SIMDs.
 template <int NKT>
-__global__ __launch_bounds__(kBlock, 2) void k_vit_attention(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ att,
-                                                             int T, int H, int ld, int D, float scale_log2e) {
+__global__ __launch_bounds__(NKT * 64) void k_vit_attention(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ att,
+                                                            int T, int H, int ld, int D, float scale_log2e, int items) {
+  // Persistent (round 5): a workgroup of NKT waves -- one 32-query tile each -- walks (image, head) items blockIdx.x, + gridDim.x, ...; the K, V
+  // and Q pieces of the NEXT item are requested into registers (12 x 16 bytes per thread) before this item is multiplied and committed to LDS
+  // after it, so the 75 KB staging of an item is in flight under the matrix + soft-max work of its predecessor.
   constexpr int TP = NKT * 32, LDV = TP + 4;     // 228-element rows: conflict-free 8-byte reads across 32 lanes
+  constexpr int NT = NKT * 64;                   // = TP * 8 / 4 K chunks per thread = (TP / 4) * 8 V items: four + one per thread
   __shared__ __attribute__((aligned(16))) uint16_t sK[TP * ATT_LDK];
   __shared__ __attribute__((aligned(16))) uint16_t sVt[ATT_HD * LDV];
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
-  const uint16_t* base = qkv + (size_t)b * T * ld + h * ATT_HD;
-  for (int i = tid; i < TP * 8; i += kBlock) {                       // K rows: 16-byte chunks, coalesced
-    const int t = i >> 3, c = i & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0);
-    if (t < T) kv = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + c * 8);
-    *reinterpret_cast<uint4*>(sK + t * ATT_LDK + c * 8) = kv;
-  }
-  // V transposed: a thread takes 8 channels of FOUR consecutive tokens and writes eight 8-byte runs (one per channel); consecutive
-  // lanes take consecutive token quads, so a wave's writes to a channel row are contiguous (conflict free)
-  for (int i = tid; i < (TP / 4) * 8; i += kBlock) {
-    const int tq = i % (TP / 4), c = i / (TP / 4);
-    uint32_t w[4][4];
+  const int q = wave * 32 + l31;
+  const int vtq = tid % (TP / 4), vc = tid / (TP / 4);
+  uint4 kr[4], vr4[4], qr[4];
+  auto issue = [&](int item) {
+    const int b = item / H, h = item - b * H;
+    const uint16_t* base = qkv + (size_t)b * T * ld + h * ATT_HD;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      uint4 vv = make_uint4(0, 0, 0, 0);
-      if (tq * 4 + u < T) vv = *reinterpret_cast<const uint4*>(base + (size_t)(tq * 4 + u) * ld + 2 * D + c * 8);
-      w[u][0] = vv.x; w[u][1] = vv.y; w[u][2] = vv.z; w[u][3] = vv.w;
+    for (int j = 0; j < 4; ++j) {                                     // K rows: 16-byte chunks, coalesced
+      const int i = tid + NT * j, t = i >> 3, c = i & 7;
+      kr[j] = make_uint4(0, 0, 0, 0);
+      if (t < T) kr[j] = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + c * 8);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint16_t* row = sVt + (c * 8 + 2 * j) * LDV + tq * 4;
-      *reinterpret_cast<uint2*>(row) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x05040100u),
-                                                  __builtin_amdgcn_perm(w[3][j], w[2][j], 0x05040100u));
-      *reinterpret_cast<uint2*>(row + LDV) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x07060302u),
-                                                        __builtin_amdgcn_perm(w[3][j], w[2][j], 0x07060302u));
+    for (int u = 0; u < 4; ++u) {                                     // V: 8 channels of four consecutive tokens
+      vr4[u] = make_uint4(0, 0, 0, 0);
+      if (vtq * 4 + u < T) vr4[u] = *reinterpret_cast<const uint4*>(base + (size_t)(vtq * 4 + u) * ld + 2 * D + vc * 8);
     }
-  }
-  __syncthreads();
-  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
-    const int q = qt * 32 + l31;
-    bf16x8 bq[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < T) v = *reinterpret_cast<const uint4*>(base + (size_t)q * ld + kb * 16 + hh * 8);
-      bq[kb] = *reinterpret_cast<bf16x8*>(&v);
+      qr[kb] = make_uint4(0, 0, 0, 0);
+      if (q < T) qr[kb] = *reinterpret_cast<const uint4*>(base + (size_t)q * ld + kb * 16 + hh * 8);
     }
+  };
+  int item = blockIdx.x;
+  if (item < items) issue(item);
+  while (item < items) {
+    // commit the staged item: K rows, V transposed (a thread writes eight 8-byte runs, one per channel; consecutive lanes take consecutive
+    // token quads, so a wave's writes to a channel row are contiguous: conflict free)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + NT * j, t = i >> 3, c = i & 7;
+      *reinterpret_cast<uint4*>(sK + t * ATT_LDK + c * 8) = kr[j];
+    }
+    {
+      const uint32_t w[4][4] = {{vr4[0].x, vr4[0].y, vr4[0].z, vr4[0].w}, {vr4[1].x, vr4[1].y, vr4[1].z, vr4[1].w},
+                                {vr4[2].x, vr4[2].y, vr4[2].z, vr4[2].w}, {vr4[3].x, vr4[3].y, vr4[3].z, vr4[3].w}};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint16_t* row = sVt + (vc * 8 + 2 * j) * LDV + vtq * 4;
+        *reinterpret_cast<uint2*>(row) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x05040100u),
+                                                    __builtin_amdgcn_perm(w[3][j], w[2][j], 0x05040100u));
+        *reinterpret_cast<uint2*>(row + LDV) = make_uint2(__builtin_amdgcn_perm(w[1][j], w[0][j], 0x07060302u),
+                                                          __builtin_amdgcn_perm(w[3][j], w[2][j], 0x07060302u));
+      }
+    }
+    bf16x8 bq[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) bq[kb] = *reinterpret_cast<bf16x8*>(&qr[kb]);
+    const int b = item / H, h = item - b * H;
+    __syncthreads();
+    const int next = item + (int)gridDim.x;
+    if (next < items) issue(next);
     f32x16 sacc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -345,6 +364,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_vit_attention(const uint16_t* __r
           *reinterpret_cast<uint2*>(orow + nt * 32 + 8 * g + 4 * hh) =
               make_uint2(pack_bf16x2(o[nt][4 * g] * inv, o[nt][4 * g + 1] * inv), pack_bf16x2(o[nt][4 * g + 2] * inv, o[nt][4 * g + 3] * inv));
     }
+    __syncthreads();                                // every wave is done with this item's K / V before the next one is committed
+    item = next;
   }
 }
 // ---- fused attention backward (head_dim 64, tokens <= NKT*32), one workgroup per (image, head) ----------------------
@@ -687,14 +708,21 @@ int rart_vit_attention(const void* qkv, void* out, int n, int tokens, int heads,
   RART_CHECK_ARG(tokens <= 224, "rart_vit_attention: at most 224 tokens (197 for 224x224 / patch 16)");
   const int D = heads * head_dim;
   const float scale_log2e = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
-  const dim3 grid((uint32_t)(n * heads));
+  const int items = n * heads;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  const dim3 grid((uint32_t)(items < n_cu ? items : n_cu));          // one persistent workgroup per CU (61 KB of LDS, up to 7 waves)
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* q = (const uint16_t*)qkv;
   uint16_t* o = (uint16_t*)out;
-#define RART_ATT_CASE(N) case N: hipLaunchKernelGGL(k_vit_attention<N>, grid, dim3(kBlock), 0, st, q, o, tokens, heads, 3 * D, D, scale_log2e); break;
+#define RART_ATT_CASE(N) case N: hipLaunchKernelGGL(k_vit_attention<N>, grid, dim3(N * 64), 0, st, q, o, tokens, heads, 3 * D, D, scale_log2e, items); break;
   switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
     RART_ATT_CASE(1) RART_ATT_CASE(2) RART_ATT_CASE(3) RART_ATT_CASE(4) RART_ATT_CASE(5) RART_ATT_CASE(6)
-    default: hipLaunchKernelGGL(k_vit_attention<7>, grid, dim3(kBlock), 0, st, q, o, tokens, heads, 3 * D, D, scale_log2e); break;
+    default: hipLaunchKernelGGL(k_vit_attention<7>, grid, dim3(7 * 64), 0, st, q, o, tokens, heads, 3 * D, D, scale_log2e, items); break;
   }
 #undef RART_ATT_CASE
   RART_CHECK_LAUNCH("rart_vit_attention");
