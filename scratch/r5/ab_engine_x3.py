@@ -1,6 +1,7 @@
 """Round 5: A/B of two builds of the library on the reference-precision ResNet-50 engine at B = 256: forward and forward + backward-to-input,
 alternating the builds in child processes so that box-to-box and warm-up effects cancel.
-    gpurun -- python scratch/r5/ab_engine_x3.py scratch/r5/ko/lib_OLD.so product [rounds]"""
+    gpurun -- python scratch/r5/ab_engine_x3.py scratch/r5/ko/lib_OLD.so product [rounds]
+    gpurun -- python scratch/r5/ab_engine_x3.py product product:RART_PAIR_WFRAG=1 [rounds]        (a switch instead of a second build)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -31,7 +32,10 @@ rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
-        o = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', l], capture_output=True, text=True, timeout=600)
+        env = dict(os.environ)
+        for kv in l.split(':')[1:]:                       # 'product:RART_PAIR_WFRAG=1' = the product library with a switch set
+            env[kv.split('=', 1)[0]] = kv.split('=', 1)[1]
+        o = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', l.split(':')[0]], capture_output=True, text=True, timeout=600, env=env)
         res[l].append(json.loads([ln for ln in o.stdout.splitlines() if ln.startswith('{')][-1]))
         print(l, res[l][-1], flush=True)
 for l in libs:
