@@ -391,7 +391,7 @@ struct RartBneckS2BwdDesc {
 
 template <int CIN, int CM, int COUT, int HIN>
 __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2_bwd(const RartBneckS2BwdDesc d) {
-  constexpr int NW = CM / 32, NT = NW * 64;
+  constexpr int NW = CM / 32;
   constexpr int NPL = CM / 8;                            // planes of the d_a1 / d_a2 images
   constexpr int PL1 = 256 * 16;                          // d_a1 image plane: 4 classes x 64 slots, unpadded
   constexpr int PL2 = 64 * 16;                           // d_a2 plane: 8 x 8 grid slots

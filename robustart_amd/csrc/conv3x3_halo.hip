@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_halo(const RartHaloDesc d) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cf::WAVES_N, wn = wave % Cf::WAVES_N;
   const uint32_t W = (uint32_t)d.w, W2 = W + 2u;
-  const uint32_t G = (uint32_t)d.rows_total * W;
   // consecutive runs of positions share halo rows: keep neighbours on one XCD (its L2 serves the overlap)
   uint32_t blk;
   {

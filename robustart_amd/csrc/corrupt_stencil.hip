@@ -406,7 +406,7 @@ struct FiCfg {
   static_assert(MOUT + KSZ - 1 == 32, "two kernel rows of a 32-pixel window per K = 64 step");
   static_assert((XT - 1) * MOUT + 31 + 1 <= RS, "the last column tile's window stays inside the staged row");
 };
-constexpr int FI_TH = 32, FI_STEPS = 9;                               // (17 x 17: what rart_stencil_fixed_point_info reports)
+constexpr int FI_TH = 32;
 struct FilterI8Meta {
   int F;
   long long corr, band;

@@ -37,7 +37,7 @@ namespace {
 // overlap) for the short-K, HBM-bound 1x1 layers and the small-M layers of ResNet-50 whose 256-row tiling would not fill 256 CUs.
 template <int TM, int TN, bool CONV>
 __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
-  constexpr int NW = TM / 32, NT = TM * 2;
+  constexpr int NW = TM / 32;
   constexpr int WN = (TN / 64 < NW) ? TN / 64 : NW, WM = NW / WN, RW = TM / WM, MI = RW / 32, NJ = TN / (32 * WN);
   static_assert(NJ == 2, "a wave owns 64 columns");
   constexpr int GP_PLANE_A = TM * GP_BK * 2;                        // one A plane of a stage: TM rows x 64 B

@@ -25,7 +25,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 namespace {
 constexpr int T = 16;                     // positions per tile side
 constexpr int HT = T + 3;                 // halo tile side (dp, dq in -1..2)
-constexpr int NPOS = HT * HT;             // 361
 constexpr int NPOS_PAD = 368;             // multiple of 16: chunk planes start on a 256-byte bank row
 constexpr int PT = T / 2 + 3;             // pooled positions per side that reach the halo tile (11)
 constexpr int NPOOL = PT * PT;            // 121
