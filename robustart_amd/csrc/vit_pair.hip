@@ -285,8 +285,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int PATT_HD = 64, PATT_LDK = PATT_HD + 8;
 
 // (Round 5: the persistent form of k_vit_attention -- next item's K / V / Q of both planes prefetched into registers -- does not fit here: 112 score
-//  registers + 32 output + 64-96 of prefetch exceed the 256 a 7-wave workgroup has (98-132 VGPRs spilled); a split commit, K after S = K Q^T and V at the
-//  item boundary, would fit and is the next step for this kernel, 5 % of a reference-precision ViT-B/16 gradient evaluation.)
+//  registers + 32 output + 64-96 of prefetch exceed the 256 a 7-wave workgroup has (98-132 VGPRs spilled); a split commit -- K after S = K Q^T, V at the
+//  item boundary, the next Q into the registers the current Q released -- was written too and spilled 162: the allocator keeps the staged planes and the
+//  score registers apart for the whole item.  What is left for this kernel (5 % of a reference-precision ViT-B/16 gradient evaluation) is a prefetch
+//  through LDS, i.e. K / V tiles small enough for two buffers.)
 template <int NKT>
 __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
                                                                   uint16_t* __restrict__ att_h, uint16_t* __restrict__ att_l, int T, int H,
