@@ -54,7 +54,7 @@ enum {
  * its tap arrays from 16 to 32 entries and gained dst_pair_off / res_pair_off; several attack entries gained a per-row
  * sample-index pointer; round 4 -> 5: rart_stencil_fixed_point_info added).  A caller compiled against another header must refuse to run:
  * compare with rart_version(). */
-#define RART_ABI_VERSION 107
+#define RART_ABI_VERSION 108
 int rart_version(void);
 const char* rart_last_error_string(void);
 /* name of corruption id (static string), NULL if out of range */
@@ -449,6 +449,11 @@ typedef struct rart_gemm_pair_desc {
   int tile_m;               /* 0 = automatic (256; 128 for short-K or small convolutions); 128 / 256 force a row tile */
 } rart_gemm_pair_desc;
 int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stream);
+/* Schedule of the 256-row tiles with 128 / 256 columns (round 6, csrc/gemm_pair_pp.hip): 1 (default; RART_PAIR_SCHEDULE in the environment
+ * sets the initial value) = ping-pong -- the two halves of the workgroup alternate memory and matrix phases, counted vmcnt, no drain in the
+ * steady state; 0 = the two-stage loop of round 4 everywhere.  Outputs are bit-identical under both (same products, same order). */
+int rart_gemm_pair_set_schedule(int mode);
+int rart_gemm_pair_get_schedule(void);
 
 /* The second half of a ResNet Bottleneck of the reference-precision engine as ONE launch (csrc/conv_tail_pair.hip): 3x3 stride-1 pad-1
  * convolution (c_mid -> c_mid channels, c_mid = 64 or 128) + point-wise step + the 1x1 expansion (c_mid -> 4 c_mid) + skip pair +

@@ -27,6 +27,7 @@
 // ResNet-50 (forward taps, flipped taps, the parity classes of a stride-2 backward, the stem's row taps) -- with 1-bit ReLU masks and
 // sign bits in the epilogue; column tiles of 64 / 128 / 256 so that the 64- and 128-channel layers do not pad their MFMA work.
 #include "rart_common.h"
+#include <stdlib.h>
 
 #include "rart_gemm_pair_dev.h"
 
@@ -233,6 +234,18 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
   gp_epilogue<TM, TN, CONV, MI>(d, lds, acc, m0, n0, c_off);
 }
 
+// 1 (default): the 256-row tiles with 128 / 256 columns run the ping-pong schedule of csrc/gemm_pair_pp.hip (bit-identical outputs); 0: this
+// file's two-stage loop everywhere (the A/B switch of tests/test_engine_x3_gpu.py and scratch/r6/).  RART_PAIR_SCHEDULE in the environment
+// sets the initial value.
+int g_pair_schedule = -1;
+int gp_schedule() {
+  if (g_pair_schedule < 0) {
+    const char* e = getenv("RART_PAIR_SCHEDULE");
+    g_pair_schedule = e ? atoi(e) : 1;
+  }
+  return g_pair_schedule;
+}
+
 void gp_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividends < 2^31
   uint32_t l = 0;
   while ((1ull << l) < dv) ++l;
@@ -240,6 +253,15 @@ void gp_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividend
   mg = (uint32_t)(((1ull << sh) + dv - 1) / dv);
 }
 }  // namespace
+
+bool rart_gemm_pair_pp_launch(const void* dev_desc, int tn, bool conv, unsigned grid_x, unsigned grid_y, hipStream_t st);   // gemm_pair_pp.hip
+
+extern "C" int rart_gemm_pair_set_schedule(int mode) {
+  RART_CHECK_ARG(mode == 0 || mode == 1, "rart_gemm_pair_set_schedule: mode must be 0 (two-stage loop) or 1 (ping-pong)");
+  g_pair_schedule = mode;
+  return RART_OK;
+}
+extern "C" int rart_gemm_pair_get_schedule(void) { return gp_schedule(); }
 
 extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t stream) {
   RART_CHECK_ARG(h != nullptr, "rart_gemm_pair_bf16: null descriptor");
@@ -320,7 +342,12 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   // that leaves fewer than 128 workgroups (layer4: 256 x 128), K-deep narrow layers (N <= 128) 128 x N.  tile_m / tile_n override.
   int tn = d.N <= 64 ? 64 : (d.N <= 128 ? 128 : 256), tm = 256;
   if (conv) {
-    if (d.K <= 256) { tm = 256; tn = 64; }
+    if (gp_schedule() == 1 && d.N >= 256 && d.K >= 256) {
+      // round 6 (scratch/r6/time_pair_pp.py --tiles, profiles/r06_pair_pp.json): with the ping-pong schedule the 256-row tiles win wherever
+      // the layer is at least 256 wide and 256 deep -- 256 x 256 unless that leaves fewer than 128 workgroups (layer4: 256 x 128)
+      tm = 256;
+      tn = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256) < 128 ? 128 : 256;
+    } else if (d.K <= 256) { tm = 256; tn = 64; }
     else if (d.K < 1024 || d.N <= 128) { tm = 128; tn = d.N <= 64 ? 64 : 128; }
     else if ((long long)((d.M + 255) / 256) * ((d.N + 255) / 256) < 128) { tm = 256; tn = 128; }
     if (d.M <= 256) { tm = 128; tn = 64; }
@@ -333,6 +360,10 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   RART_CHECK_ARG(blocks < (1ll << 31), "rart_gemm_pair_bf16: grid too large");
   const dim3 grid((uint32_t)blocks, nz);
   hipStream_t st = (hipStream_t)stream;
+  if (tm == 256 && tn >= 128 && gp_schedule() == 1 && rart_gemm_pair_pp_launch(&d, tn, conv, grid.x, grid.y, st)) {
+    RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (ping-pong)");
+    return RART_OK;
+  }
 #define RART_GP_LAUNCH(TM_, TN_, CONV_) hipLaunchKernelGGL((k_gemm_pair<TM_, TN_, CONV_>), grid, dim3(TM_ * 2), 0, st, d)
 #define RART_GP_BY_TN(TM_, CONV_)                                          \
   do {                                                                     \

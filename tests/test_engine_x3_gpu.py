@@ -561,3 +561,86 @@ def test_x3_engine_b256_matches_small_batches_bit_for_bit(setup):
     rows = torch.arange(0, 256, 32, device='cuda')
     ref = m((x[rows] - mean) / std)
     assert (big[rows] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def _pair_schedule_case(lib, _lib, conv, M, K, N, tile_n, batched, seed):
+    """One rart_gemm_pair_bf16 problem with every epilogue operand (bias, residual pair, ReLU; conv: sign bits), 256-row tiles forced."""
+    g = torch.Generator().manual_seed(seed)
+    nz = 3 if batched else 1
+    d = _lib.GemmPairDesc()
+    keep = []
+    if conv:
+        B, Hh, Ww, C = conv
+        assert K == 9 * C and M == B * Hh * Ww
+        xp = _split(torch.randn(B, Hh, Ww, C, generator=g).cuda())
+        w = (torch.randn(N, 9 * C, generator=g) * 0.05).cuda()
+    else:
+        xp = _split(torch.randn(nz, M, K, generator=g).cuda())
+        w = (torch.randn(nz, N, K, generator=g) * 0.05).cuda()
+    wh = w.to(torch.bfloat16)
+    wl = (w - wh.float()).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    rp = _split(torch.randn(nz, M, N, generator=g).cuda())
+    out = torch.full((2, nz, M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+    sign = torch.zeros(M, N // 8, dtype=torch.uint8, device='cuda')
+    keep += [xp, wh, wl, bias, rp, out, sign]
+    d.a_hi, d.a_lo, d.w_hi, d.w_lo = xp[0].data_ptr(), xp[1].data_ptr(), wh.data_ptr(), wl.data_ptr()
+    d.bias, d.res_hi, d.res_lo, d.dst_hi, d.dst_lo = bias.data_ptr(), rp[0].data_ptr(), rp[1].data_ptr(), out[0].data_ptr(), out[1].data_ptr()
+    d.N, d.ldw, d.ldc, d.w_rows, d.flags, d.tile_n, d.tile_m = N, K, N, N, 1, tile_n, 256
+    if conv:
+        d.sign_out = sign.data_ptr()
+        d.lda = C
+        d.conv, d.batch, d.grid_h, d.grid_w, d.src_h, d.src_w, d.sy, d.sx, d.k_per_tap, d.n_taps = 1, B, Hh, Ww, Hh, Ww, 1, 1, C, 9
+        for i, (dy, dx) in enumerate([(r - 1, s - 1) for r in range(3) for s in range(3)]):
+            d.tap_dy[i], d.tap_dx[i] = dy, dx
+        d.dst_h, d.dst_w, d.dst_sy, d.dst_sx = Hh, Ww, 1, 1
+    else:
+        d.M, d.K, d.lda = M, K, K
+        if batched:
+            d.n_batched, d.z_inner = nz, 1
+            d.a_z_outer, d.w_z_outer, d.c_z_outer = M * K, N * K, M * N
+    return d, out, sign, keep
+
+
+@pytest.mark.parametrize('conv,M,K,N,tile_n,batched', [
+    (None, 700, 32, 256, 256, False),            # one K step: prologue only
+    (None, 513, 64, 128, 128, False),            # two K steps: the refill of group 0's first M0 and nothing else
+    (None, 1000, 96, 384, 256, False),           # three K steps, a half-empty column tile
+    (None, 4103, 1024, 256, 256, False),         # 32 K steps, >= 16 row tiles (the XCD remap), ragged last tile
+    (None, 777, 160, 256, 128, True),            # batched over blockIdx.y, five K steps, 128-column tiles
+    ((5, 20, 20, 64), 2000, 576, 256, 256, False),      # 3x3 gather, 18 K steps, zero padding through the zero page
+    ((3, 12, 10, 32), 360, 288, 128, 128, False),       # 32-channel taps (one K step per tap)
+    ((4, 33, 32, 128), 4224, 1152, 512, 256, False),    # 36 K steps, two column tiles, 17 row tiles
+])
+def test_pair_gemm_pingpong_schedule_is_bit_identical(conv, M, K, N, tile_n, batched):
+    """Round 6: the ping-pong schedule of the 256-row tiles (csrc/gemm_pair_pp.hip: the two halves of the workgroup alternate memory and
+    matrix phases, counted vmcnt, raw barriers) issues the same products in the same order as round 4's two-stage loop: the outputs must be
+    equal BIT FOR BIT -- and stay so over repeated launches beside a bandwidth hog on another stream (a missing wait shows as a rare wrong
+    tile, not as a wrong kernel)."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    d, out, sign, keep = _pair_schedule_case(lib, _lib, conv, M, K, N, tile_n, batched, seed=11)
+    old = lib.rart_gemm_pair_get_schedule()
+    try:
+        _lib.check(lib.rart_gemm_pair_set_schedule(0))
+        _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        want, want_sign = out.view(torch.int16).clone(), sign.clone()
+        assert torch.isfinite(out.float()).all()
+        _lib.check(lib.rart_gemm_pair_set_schedule(1))
+        hog_stream = torch.cuda.Stream()
+        hog = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+        for rep in range(6):
+            out.fill_(float('nan'))
+            sign.zero_()
+            if rep >= 2:
+                with torch.cuda.stream(hog_stream):
+                    for _ in range(4):
+                        hog.add_(1.0)
+            _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16), want), 'ping-pong schedule differs from the two-stage loop (repetition %d)' % rep
+            assert torch.equal(sign, want_sign)
+    finally:
+        lib.rart_gemm_pair_set_schedule(old)
+    assert lib.rart_gemm_pair_set_schedule(2) != 0
