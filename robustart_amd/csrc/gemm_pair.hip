@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "rart_gemm_pair_dev.h"
+#include "rart_lds_dma.h"
 
 namespace {
 // TM x TN: the tile (rows 256 / 128, columns 256 / 128 / 64), TM / 32 waves (8 / 4) in a (NW / WN) x WN grid, WN = TN / 64; a wave owns
@@ -75,106 +76,87 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
   const int m0 = m_tile * TM, n0 = n_tile * TN;
 
   // ---- loader: a plane goes to LDS in 1 KiB pieces (16 rows x 64 B); wave w brings pieces w and w + 8; lane -> row (lane >> 2),
-  //      LDS chunk (lane & 3) <- the row's chunk (lane & 3) ^ ((row >> 2) & 3)
-  const char* asrc_h[2];            // plain GEMM: per-lane source rows (nullptr past M)
-  const char* asrc_l[2];
-  int a_by[2], a_bx[2], a_img[2], a_cs[2];      // CONV: pixel of the row, byte offset of the lane's chunk inside a K slice
-  bool a_ok[2];
-  const char* bsrc_h[BQ];
-  const char* bsrc_l[BQ];
+  //      LDS chunk (lane & 3) <- the row's chunk (lane & 3) ^ ((row >> 2) & 3).
+  //      Round 6 (rart_lds_dma.h): the loads are buffer_load ... lds -- a lane's byte offset inside its plane is ONE constant (avoff /
+  //      wvoff; RART_DMA_OOR for rows past M / past the table: the resource's range check zero-fills them, no zero page), the K step and
+  //      the tap move the SCALAR offset; with taps the resource base is shifted down by the most negative tap offset and a pixel
+  //      outside the image for tap t (bit t of `nok`) gets its offset ORed with RART_DMA_OOR: two vector instructions per piece and
+  //      step where round 5's form had ~15 (which competed with the co-resident workgroups' MFMAs for the vector issue).
+  uint32_t avoff[2], nok[2] = {0u, 0u};
+  int tapreg = 0, tap_min = 0;
+  const bool one_tap = !CONV || d.n_taps == 1;
+  if (CONV) {
+    for (int t = 0; t < d.n_taps; ++t) tap_min = min(tap_min, (d.tap_dy[t] * d.src_w + d.tap_dx[t]) * d.lda * 2);
+    if (lane < d.n_taps) tapreg = (d.tap_dy[lane] * d.src_w + d.tap_dx[lane]) * d.lda * 2 - tap_min;
+  }
+  const uint32_t tap0 = CONV ? (uint32_t)__builtin_amdgcn_readfirstlane((d.tap_dy[0] * d.src_w + d.tap_dx[0]) * d.lda * 2 - tap_min) : 0u;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int r = 16 * (wave + NW * q) + (lane >> 2);
     const int csrc = (lane & 3) ^ ((r >> 2) & 3);
     const int m = m0 + r;
-    asrc_h[q] = asrc_l[q] = nullptr;
-    a_by[q] = a_bx[q] = a_img[q] = 0;
-    a_cs[q] = csrc * 16;
-    a_ok[q] = m < d.M;
+    const bool ok = m < d.M;
     if (CONV) {
-      const uint32_t mm = a_ok[q] ? (uint32_t)m : 0u;
+      const uint32_t mm = ok ? (uint32_t)m : 0u;
       const uint32_t t = gp_fastdiv(mm, d.gw_magic, d.gw_shift);
       const int ox = (int)(mm - t * (uint32_t)d.grid_w);
       const int n = (int)gp_fastdiv(t, d.gh_magic, d.gh_shift);
       const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
-      a_by[q] = oy * d.sy;
-      a_bx[q] = ox * d.sx;
-      a_img[q] = n * d.src_h * d.src_w;
-    } else if (a_ok[q]) {
+      const int by = oy * d.sy, bx = ox * d.sx;
+      avoff[q] = (uint32_t)((n * d.src_h * d.src_w + by * d.src_w + bx) * d.lda * 2 + csrc * 16);
+      for (int t2 = 0; t2 < d.n_taps; ++t2) {
+        const int iy = by + d.tap_dy[t2], ix = bx + d.tap_dx[t2];
+        if (!(ok && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w)) nok[q] |= 1u << t2;
+      }
+      if (one_tap && (nok[q] & 1u)) avoff[q] = RART_DMA_OOR;
+    } else {
       long long srow = m;
       if (d.map_rows) {
         const int img = m / d.rpi;
         srow = (long long)img * d.src_rpi + (m - img * d.rpi);
       }
-      const long long e = (srow + d.src_off) * d.lda + csrc * 8;
-      asrc_h[q] = reinterpret_cast<const char*>(a_hi + e);
-      asrc_l[q] = reinterpret_cast<const char*>(a_lo + e);
+      avoff[q] = ok ? (uint32_t)(((srow + d.src_off) * d.lda + csrc * 8) * 2) : RART_DMA_OOR;
     }
   }
-  // CONV, round 5 (scratch/r5/time_pair_ts.py: the issue block of a K step took ~2 000 of its ~5 700 cycles, most of it the per-step
-  // address arithmetic of the eight loads -- tap table reads, 64-bit multiply-adds, bounds compares): everything that does not depend on
-  // the step is formed ONCE per lane -- the address of the row's pixel at tap (0, 0), one in-bounds bit per tap -- and the byte offset
-  // of tap t sits in lane t of `tapreg`, so a step is a v_readlane, two 64-bit adds and a select per row piece.
-  const char* abase[2] = {nullptr, nullptr};
-  uint32_t okmask[2] = {0u, 0u};
-  int tapreg = 0;
-  if (CONV) {
-    if (lane < d.n_taps) tapreg = (d.tap_dy[lane] * d.src_w + d.tap_dx[lane]) * d.lda * 2;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      abase[q] = reinterpret_cast<const char*>(a_hi) + (long long)(a_img[q] + a_by[q] * d.src_w + a_bx[q]) * d.lda * 2 + a_cs[q];
-      for (int t = 0; t < d.n_taps; ++t) {
-        const int iy = a_by[q] + d.tap_dy[t], ix = a_bx[q] + d.tap_dx[t];
-        if (a_ok[q] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w) okmask[q] |= 1u << t;
-      }
-    }
-  }
-  const long long lo_delta = reinterpret_cast<const char*>(a_lo) - reinterpret_cast<const char*>(a_hi);
+  uint32_t wvoff[BQ];
 #pragma unroll
   for (int q = 0; q < BQ; ++q) {
     const int r = 16 * (wave + NW * q) + (lane >> 2);
     const int csrc = (lane & 3) ^ ((r >> 2) & 3);
     const int n = n0 + r;
-    bsrc_h[q] = bsrc_l[q] = nullptr;
-    if (r < TN && n < d.w_rows) {
-      const long long e = (long long)n * d.ldw + csrc * 8;
-      bsrc_h[q] = reinterpret_cast<const char*>(w_hi + e);
-      bsrc_l[q] = reinterpret_cast<const char*>(w_lo + e);
-    }
+    wvoff[q] = (r < TN && n < d.w_rows) ? (uint32_t)((n * d.ldw + csrc * 8) * 2) : RART_DMA_OOR;
   }
-  const char* const zsrc = reinterpret_cast<const char*>(g_pair_zero16);
+  const rart_srd_t srd_ah = rart_dma_srd(reinterpret_cast<const char*>(a_hi) + tap_min), srd_al = rart_dma_srd(reinterpret_cast<const char*>(a_lo) + tap_min);
+  const rart_srd_t srd_wh = rart_dma_srd(w_hi), srd_wl = rart_dma_srd(w_lo);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
   // GP_W_INTERLEAVED: the weight table holds, per row and K step, the 64 bytes of the hi plane followed by the 64 bytes of the lo plane
   // (one 128-byte line per row and step; w_lo = w_hi + 32 elements) instead of two planes K apart
   const int w_step = (d.flags & GP_W_INTERLEAVED) ? 128 : 64;
-#define RART_GP_DL(SRC, DST)                                                                                    \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                        \
-                                   (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);
 #define RART_GP_ISSUE(KT, BUF)                                                                                  \
   {                                                                                                             \
-    uint8_t* const st_ = lds + (BUF)*STAGE;                                                                     \
+    const uint32_t st_ = lds_base + (BUF)*STAGE;                                                                \
     const int kt_ = (KT);                                                                                       \
-    if (CONV) {                                                                                                 \
-      const int tap_ = kt_ >> d.tpt_shift;                                                                      \
-      const long long so_ = (long long)(__builtin_amdgcn_readlane(tapreg, tap_) + (kt_ - (tap_ << d.tpt_shift)) * 64); \
+    if (one_tap) {                                                                                              \
+      const uint32_t so_ = tap0 + (uint32_t)kt_ * 64u;                                                          \
       _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
-        const bool ok_ = (okmask[q] >> tap_) & 1u;                                                              \
-        const char* const ph_ = abase[q] + so_;                                                                 \
-        RART_GP_DL(ok_ ? ph_ : zsrc, st_ + (wave + NW * q) * 1024)                                              \
-        RART_GP_DL(ok_ ? ph_ + lo_delta : zsrc, st_ + GP_PLANE_A + (wave + NW * q) * 1024)                      \
+        rart_dma_load16(avoff[q], srd_ah, so_, st_ + (wave + NW * q) * 1024);                                   \
+        rart_dma_load16(avoff[q], srd_al, so_, st_ + GP_PLANE_A + (wave + NW * q) * 1024);                      \
       }                                                                                                         \
     } else {                                                                                                    \
-      const size_t ko_ = (size_t)kt_ * 64;                                                                      \
+      const int tap_ = kt_ >> d.tpt_shift;                                                                      \
+      const uint32_t so_ = (uint32_t)(__builtin_amdgcn_readlane(tapreg, tap_) + (kt_ - (tap_ << d.tpt_shift)) * 64); \
       _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
-        RART_GP_DL(asrc_h[q] ? asrc_h[q] + ko_ : zsrc, st_ + (wave + NW * q) * 1024)                             \
-        RART_GP_DL(asrc_l[q] ? asrc_l[q] + ko_ : zsrc, st_ + GP_PLANE_A + (wave + NW * q) * 1024)                \
+        const uint32_t vo_ = avoff[q] | ((uint32_t)__builtin_amdgcn_sbfe(nok[q], tap_, 1) & RART_DMA_OOR);      \
+        rart_dma_load16(vo_, srd_ah, so_, st_ + (wave + NW * q) * 1024);                                        \
+        rart_dma_load16(vo_, srd_al, so_, st_ + GP_PLANE_A + (wave + NW * q) * 1024);                           \
       }                                                                                                         \
     }                                                                                                           \
     {                                                                                                           \
-      const size_t ko_ = (size_t)kt_ * w_step;                                                                  \
+      const uint32_t so_ = (uint32_t)(kt_ * w_step);                                                            \
       _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                                          \
         if (NW * q + NW <= B_PIECES || wave + NW * q < B_PIECES) {   /* (first half: compile time, no branch) */  \
-          RART_GP_DL(bsrc_h[q] ? bsrc_h[q] + ko_ : zsrc, st_ + 2 * GP_PLANE_A + (wave + NW * q) * 1024)          \
-          RART_GP_DL(bsrc_l[q] ? bsrc_l[q] + ko_ : zsrc, st_ + 2 * GP_PLANE_A + PLANE_B + (wave + NW * q) * 1024) \
+          rart_dma_load16(wvoff[q], srd_wh, so_, st_ + 2 * GP_PLANE_A + (wave + NW * q) * 1024);                \
+          rart_dma_load16(wvoff[q], srd_wl, so_, st_ + 2 * GP_PLANE_A + PLANE_B + (wave + NW * q) * 1024);      \
         }                                                                                                       \
       }                                                                                                         \
     }                                                                                                           \
@@ -196,7 +178,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
   }
   const int KT = d.K / GP_BK;
   RART_GP_ISSUE(0, 0)
-  __builtin_amdgcn_s_waitcnt(0);
+  rart_dma_wait<0>();
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
@@ -226,11 +208,10 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    __builtin_amdgcn_s_waitcnt(0);          // the next stage has landed in LDS
+    rart_dma_wait<0>();                     // the next stage has landed in LDS
     __syncthreads();
   }
 #undef RART_GP_ISSUE
-#undef RART_GP_DL
   gp_epilogue<TM, TN, CONV, MI>(d, lds, acc, m0, n0, c_off);
 }
 
@@ -279,8 +260,9 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
                    "rart_gemm_pair_bf16 (conv): no batching / row re-basing in conv mode");
     const long long M = (long long)h->batch * h->grid_h * h->grid_w;
     RART_CHECK_ARG(M < (1ll << 31), "rart_gemm_pair_bf16 (conv): row grid must stay below 2^31 rows");
-    RART_CHECK_ARG((long long)h->batch * h->src_h * h->src_w * h->lda < (1ll << 31) && (long long)h->batch * h->dst_h * h->dst_w * h->ldc < (1ll << 31),
-                   "rart_gemm_pair_bf16 (conv): tensors must stay below 2^31 elements (split the batch)");
+    RART_CHECK_ARG((long long)h->batch * h->src_h * h->src_w * h->lda < (1ll << 30) && (long long)h->batch * h->dst_h * h->dst_w * h->ldc < (1ll << 31),
+                   "rart_gemm_pair_bf16 (conv): a source plane must stay below 2 GiB (32-bit byte offsets of the stage loads) and the destination "
+                   "below 2^31 elements (split the batch)");
     RART_CHECK_ARG(h->lda % 8 == 0 || h->lda == 4, "rart_gemm_pair_bf16 (conv): source pixels must keep 16-byte alignment of the K chunks");
     d.M = (int)M;
     d.K = h->k_per_tap * h->n_taps;
@@ -308,6 +290,12 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   RART_CHECK_ARG(d.K > 0 && d.K % GP_BK == 0, "rart_gemm_pair_bf16: K must be a positive multiple of 32");
   RART_CHECK_ARG(h->ldw % 8 == 0 && h->ldc % 8 == 0 && h->ldw >= d.K && h->ldc >= d.N,
                  "rart_gemm_pair_bf16: leading dimensions must cover the row and keep 16-byte alignment");
+  RART_CHECK_ARG((long long)(h->w_rows > 0 ? h->w_rows : h->N) * h->ldw < (1ll << 30), "rart_gemm_pair_bf16: a weight plane must stay below 2 GiB");
+  if (!conv) {
+    const long long imgs = (h->rows_per_image > 0 && h->rows_per_image < d.M) ? (d.M + h->rows_per_image - 1) / h->rows_per_image : 1;
+    const long long src_rows = imgs > 1 ? imgs * (h->src_rows_per_image > 0 ? h->src_rows_per_image : h->rows_per_image) : d.M;
+    RART_CHECK_ARG((src_rows + h->src_row_off) * h->lda < (1ll << 30), "rart_gemm_pair_bf16: a source plane must stay below 2 GiB (per batched problem)");
+  }
   const bool out_f32 = (h->flags & GP_OUT_F32) != 0;
   RART_CHECK_ARG(out_f32 || h->dst_lo, "rart_gemm_pair_bf16: a pair destination needs its lo plane");
   RART_CHECK_ARG((h->res_hi == nullptr) == (h->res_lo == nullptr), "rart_gemm_pair_bf16: the residual is a pair: both planes or none");

@@ -29,29 +29,16 @@
 #include <stdlib.h>
 
 #include "rart_gemm_pair_dev.h"
+#include "rart_lds_dma.h"
 
 namespace {
 
-typedef unsigned int pp_srd_t __attribute__((ext_vector_type(4)));   // buffer resource: base lo, base hi (16 bits; stride 0), num_records, flags
-
-// One 1 KiB LDS-DMA piece through a buffer resource: lane l's 16 bytes at srd.base + voff + soff land at lds_addr + 16 l (M0 = the LDS base
-// of the DMA, written in the same statement); a lane whose voff + soff lies beyond num_records receives ZEROS (scratch/r6/bl_test.hip printed
-// both rules on the MI355X).  The address is one constant VGPR + two scalars: the issue path of a K step has NO vector instruction.
-__device__ __forceinline__ void pp_bload(uint32_t voff, pp_srd_t srd, uint32_t soff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ pp_srd_t pp_make_srd(const void* base) {
-  const unsigned long long b = (unsigned long long)base;
-  pp_srd_t r = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xFFFFu)),
-                0x7FFFFFFFu, 0x00020000u};        // readfirstlane: the words must be PROVABLY wave-uniform to sit in SGPRs (guide T20)
-  return r;
-}
-constexpr uint32_t PP_OOR = 0x80000000u;              // a byte offset no tensor reaches (the host checks the planes stay below 2 GiB)
-
+typedef rart_srd_t pp_srd_t;
+__device__ __forceinline__ void pp_bload(uint32_t voff, pp_srd_t srd, uint32_t soff, uint32_t lds_addr) { rart_dma_load16(voff, srd, soff, lds_addr); }
+__device__ __forceinline__ pp_srd_t pp_make_srd(const void* base) { return rart_dma_srd(base); }
+constexpr uint32_t PP_OOR = RART_DMA_OOR;
 template <int N>
-__device__ __forceinline__ void pp_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
-}
+__device__ __forceinline__ void pp_vmcnt() { rart_dma_wait<N>(); }
 __device__ __forceinline__ void pp_slot_end() {      // phase boundary: nothing crosses it in either direction
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();

@@ -35,8 +35,6 @@ __device__ __forceinline__ uint32_t gp_fastdiv(uint32_t n, uint32_t magic, uint3
   return (uint32_t)(((uint64_t)n * magic) >> shift);
 }
 
-__device__ __attribute__((aligned(16))) const uint32_t g_pair_zero16[4] = {0u, 0u, 0u, 0u};   // source of rows past M / N
-
 __device__ __forceinline__ uint32_t gp_pack_bf16x2(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
   typedef __attribute__((ext_vector_type(2))) float f2_t;
   typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
