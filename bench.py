@@ -312,9 +312,9 @@ def gaussian_noise_block(B, device):
 
 def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r05_pmc_traffic.json, else r04 / r03 / r02; produced by profiles/summarize_pmc.py); None if absent."""
+    (profiles/r06_pmc_traffic.json, else r05 / r04 / ...; produced by profiles/summarize_pmc.py); None if absent."""
     try:
-        path = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_pmc_traffic.json' % r) for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
+        path = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_pmc_traffic.json' % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), None)
         pmc_traffic.source = os.path.basename(path)
         with open(path) as f:
             d = json.load(f)
@@ -339,14 +339,15 @@ KERNEL_NAMES = {
     'bottleneck_s2': 'k_bottleneck_s2 (stride-2 first blocks of layer2 / layer3, forward: 1x1 + 3x3/2 + 1x1 + projection in one launch)',
     'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd (the same blocks, backward-to-input in one launch)',
     'fc_small_m': 'k_gemm_small_m (classifier head and its backward: one 32 x 32 tile per workgroup, waves split K)',
-    'gemm_pair': 'k_gemm_pair<TM, TN, conv> (split-bf16 implicit-GEMM convolution of the reference-precision engine: four operand planes '
-                 'staged once per K step, three MFMAs per fragment pair)',
+    'gemm_pair': 'k_gemm_pair<TM, TN, conv> / k_gemm_pair_pp<TN, conv> (split-bf16 implicit-GEMM convolution of the reference-precision engine: '
+                 'four operand planes staged once per K step, three MFMAs per fragment pair; the 256-row tiles of layers at least 256 wide '
+                 'and deep on the ping-pong schedule of round 6, csrc/gemm_pair_pp.hip)',
     'conv_tail_pair': 'k_conv3x3_tail_pair<C, NEXT> (reference-precision 3x3 + 1x1 expansion [+ the neighbouring block\'s 1x1 reduction] in one launch)',
     'conv_tail256_pair': 'k_conv3x3_tail256_pair (reference-precision 3x3 + 1x1 expansion of layer3 / layer4 in one launch)',
     'stem_pair': 'k_stem_fwd_pair / k_stem_bwd_pair (reference-precision stem: normalise + 7x7/2 + ReLU + max pool, and its backward, one launch each)'}
 PMC_KEYS = {'bottleneck': 'k_bottleneck56', 'bottleneck14': 'k_bottleneck14', 'bottleneck28': 'k_bottleneck28', 'bottleneck7': 'k_bottleneck7',
             'bottleneck_s2': '15k_bottleneck_s2I', 'bottleneck_s2_bwd': 'k_bottleneck_s2_bwd', 'halo3x3': 'k_conv3x3', 'igemm': 'igemm',
-            'gemm_pair': 'k_gemm_pairI', 'conv_tail_pair': 'k_conv3x3_tail_pairI', 'conv_tail256_pair': 'k_conv3x3_tail256_pair',
+            'gemm_pair': 'k_gemm_pair', 'conv_tail_pair': 'k_conv3x3_tail_pairI', 'conv_tail256_pair': 'k_conv3x3_tail256_pair',
             'stem_pair': 'k_stem_'}
 
 
@@ -416,7 +417,8 @@ def measure_engine_roofline(path, images, labels):
                        '(the fp32 MFMA peak of this part is %.1f TFLOP/s)' % (MFMA_F32_PEAK / 1e12))
     out.update({'traffic': d.get('traffic'), 'overfetch': d.get('overfetch'),
                 'algorithmic_bytes_per_launch': d.get('algorithmic_bytes_per_launch'),
-                'algorithmic_flops_per_launch': fam[dom]['flops'] / fam[dom]['n'],
+                'issued_flops_per_launch': fam[dom]['flops'] / fam[dom]['n'],
+                'algorithmic_flops_per_launch': fam[dom]['flops'] / fam[dom]['n'] / (3.0 if x3 else 1.0),
                 'avg_launch_us': d['avg_launch_us'], 'launches': fam[dom]['n'], 'share_of_gradient_evaluation': d['share_of_gradient_evaluation'],
                 'traffic_note': 'HBM bytes per launch (launch-weighted mean over the family\'s template instances) from the committed PMC pass '
                                 'profiles/%s (rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB units), not re-measured in this run'

@@ -14,6 +14,7 @@ provider:
 foolbox's PyTorchModel; `model` (mim_linf / autoattack_linf / pgd_l1) takes NORMALISED input
 and the ImageNet mean/std are applied here (imfgsm_attack.py:14-23, autoattack.py:17-20).
 """
+import os
 import warnings
 
 import numpy as np
@@ -152,15 +153,19 @@ def _rows(sample_offset, like=None):
     torch = _lib.require_gpu()
     if torch.is_tensor(sample_offset):
         rows = sample_offset.to(dtype=torch.int64)
-        if like is not None:
-            if rows.dim() != 1 or rows.shape[0] != like.shape[0]:
-                raise ValueError('sample_offset tensor must hold one global sample index per row: got shape %s for %d rows'
-                                 % (tuple(rows.shape), like.shape[0]))
-            rows = rows.to(device=like.device)
-        if rows.numel():
+        if like is not None and (rows.dim() != 1 or rows.shape[0] != like.shape[0]):
+            raise ValueError('sample_offset tensor must hold one global sample index per row: got shape %s for %d rows'
+                             % (tuple(rows.shape), like.shape[0]))
+        # The range is checked where the values are HOST data (a CPU tensor, before its upload).  A device tensor is taken as it is: reading
+        # its extrema back would block the host on the device once per attack call -- once per adversarial-training iteration and once per
+        # AutoAttack sub-attack (no hidden device syncs on the path).  Whoever builds a device index tensor checks it at the
+        # source (EpochSampler.batch_rows, AutoAttack's arange-derived subsets); RART_CHECK_ROWS=1 restores the blocking check for debugging.
+        if rows.numel() and (rows.device.type == 'cpu' or os.environ.get('RART_CHECK_ROWS') == '1'):
             lo, hi = rows.aminmax()
             if int(lo) < 0 or int(hi) >= 1 << 32:
                 raise ValueError('sample indices must lie in [0, 2^32): got [%d, %d]' % (int(lo), int(hi)))
+        if like is not None:
+            rows = rows.to(device=like.device)
         return 0, rows.contiguous()
     off = int(sample_offset)
     if off < 0:

@@ -353,6 +353,22 @@ class EpochSampler:
         k = int(it) % self.per_epoch
         return [int(v) for v in self._order(epoch)[k * self.bs:(k + 1) * self.bs]], epoch
 
+    def batch_rows(self, it, device):
+        """The same indices as an int64 tensor on `device`, a VIEW of this rank's share of the epoch's permutation, which is uploaded ONCE per
+        epoch (the attack kernels read it as every row's global sample index: round 5 built a tensor from a Python list per step).  The
+        range [0, 2^32) the counter generator needs is checked here, on the host, once per epoch -- the attack entry does not look at a
+        device tensor's values (that was a blocking device-to-host copy per iteration)."""
+        import torch
+        epoch = self.epoch_of(it)
+        mine = self._order(epoch)
+        if getattr(self, '_dev_epoch', None) != (epoch, str(device)):
+            if len(mine) and (int(mine.min()) < 0 or int(mine.max()) >= 1 << 32):
+                raise ValueError('sample indices must lie in [0, 2^32)')
+            self._dev = torch.as_tensor(mine, dtype=torch.int64).to(device)
+            self._dev_epoch = (epoch, str(device))
+        k = int(it) % self.per_epoch
+        return self._dev[k * self.bs:(k + 1) * self.bs]
+
 
 def cosine_lr(step, total, base_lr, warmup_lr, warmup_steps, min_lr=0.0):
     """lr_scheduler.type CosineEpoch with linear warm-up (config.yaml:21-29)."""
@@ -606,10 +622,20 @@ def train(cfg, args, rank, world, device):
             opt.load_state_dict(ost['torch'])
         if ema_on and resume.get('ema') is not None:
             esd = {(k[7:] if k.startswith('module.') else k): v for k, v in resume['ema'].items()}
+            from ..model.vit_torch import VisionTransformer, legacy_vit_keys
+            if isinstance(model, VisionTransformer):
+                # a ViT checkpoint written by rounds 1-4 names patch_embed.{weight,bias} and blocks.N.fc{1,2}.*: load_pretrain renames the
+                # MODEL's dict only, so without this the 50 renamed tensors kept the freshly loaded live weights as their average while the
+                # moments and last_iter continued
+                esd = legacy_vit_keys(esd)
+            absent = [nm for nm in arena.names if nm not in esd]
+            if absent:
+                raise RuntimeError("resume: the checkpoint's 'ema' dict lacks %d of the model's %d parameters (first: %s); the average of "
+                                   "those tensors cannot continue -- drop it with saver.pretrain.ignore.key: ['ema'] to restart the average "
+                                   "from the loaded weights" % (len(absent), len(arena.names), absent[:3]))
             for nm, p_, o in zip(arena.names, arena.params, arena.offsets):
-                if nm in esd:
-                    tgt = opt.ema if use_hip_opt else ema
-                    tgt[o:o + p_.numel()].copy_(esd[nm].reshape(-1).to(tgt.device))
+                tgt = opt.ema if use_hip_opt else ema
+                tgt[o:o + p_.numel()].copy_(esd[nm].reshape(-1).to(tgt.device))
             for k in ema_buffers:
                 if k in esd:
                     ema_buffers[k].copy_(esd[k].to(ema_buffers[k].device))
@@ -659,7 +685,7 @@ def train(cfg, args, rank, world, device):
                              # every row draws its random start at ITS dataset index (sel is a strided slice of the epoch's
                              # permutation, not a contiguous range): no two images of an iteration share a field, and the
                              # draws do not depend on the world size
-                             sample_offset=torch.as_tensor([int(i) for i in sel], dtype=torch.int64, device=device))
+                             sample_offset=sampler.batch_rows(it, device))
         model.train()
         if train_engine is not None:
             # train-mode forward (batch statistics), label-smoothed CE, backward to every parameter: all HIP

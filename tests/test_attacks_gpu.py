@@ -688,3 +688,39 @@ def test_autoattack_plus_runs_all_six_stages():
                                  _overrides=dict(apgd_iter=3, apgdt_iter=2, apgdt_classes=2, fab_iter=2, fab_classes=2, fab_restarts=2,
                                                  square_queries=10))
     assert (xa - x).abs().max().item() <= 2 / 255 + 1e-6 and xa.min().item() >= 0 and xa.max().item() <= 1
+
+
+def test_attack_entry_with_a_device_index_tensor_never_blocks_the_host():
+    """VERDICT r5 item 5 / SURVEY 8(b) "no hidden device syncs": pgd_linf through the HIP engine with every row's GLOBAL sample index in a
+    DEVICE tensor -- what an adversarial-training iteration passes (EpochSampler.batch_rows) and what AutoAttack's sub-attacks pass -- must
+    not read that tensor back: the whole attack runs under torch.cuda.set_sync_debug_mode('error'), which turns any blocking
+    device-to-host copy into an exception.  The draws equal those of the contiguous-offset form; a HOST tensor is still range-checked
+    (before its upload, where the check is free)."""
+    from robustart_amd.noise import adv
+    from robustart_amd.model import get_model
+    from robustart_amd.model.engine import EngineModel
+    from robustart_amd.model.resnet_torch import randomize_bn_stats
+    from robustart_amd.train.cls_solver import EpochSampler
+    torch.manual_seed(0)
+    f = EngineModel(randomize_bn_stats(get_model({'type': 'resnet50_official'})).eval(), takes_normalized=False)
+    x = _rand((4, 3, 64, 64), 2).cuda()
+    y = torch.randint(0, 1000, (4,)).cuda()
+    sampler = EpochSampler(64, 4, 0, 1, seed=3)
+    rows = sampler.batch_rows(5, x.device)                         # a view of the epoch's permutation, uploaded once per epoch
+    assert rows.is_cuda and rows.tolist() == sampler.batch(5)[0] and sampler.batch_rows(6, x.device).data_ptr() != rows.data_ptr()
+    assert sampler.batch_rows(5, x.device).data_ptr() == rows.data_ptr()                       # no second upload inside an epoch
+    want = adv.pgd_linf(x, y, f, 2 / 255, 3 / 40, 2, seed=9, sample_offset=rows)                # warm-up: allocations, table packing
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        got = adv.pgd_linf(x, y, f, 2 / 255, 3 / 40, 2, seed=9, sample_offset=rows)
+        start = adv.attack_init_linf(x, 2 / 255, True, 9, rows)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert torch.equal(got, want)
+    ref = torch.cat([adv.attack_init_linf(x[i:i + 1].contiguous(), 2 / 255, True, 9, int(rows[i])) for i in range(4)])
+    assert torch.equal(start, ref)
+    with pytest.raises(ValueError, match=r'\[0, 2\^32\)'):
+        adv.attack_init_linf(x, 2 / 255, True, 9, torch.tensor([0, 1, 2, 1 << 32]))
+    with pytest.raises(ValueError, match='one global sample index per row'):
+        adv.attack_init_linf(x, 2 / 255, True, 9, rows[:3])

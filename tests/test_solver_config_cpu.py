@@ -345,3 +345,56 @@ def test_vit_loads_a_timm_layout_checkpoint_strictly_and_honours_ignore_model(tm
     assert 'patch_embed.proj.weight' in torch.load(out, weights_only=True)['model']
     out = S.save_checkpoint(str(tmp_path / 'o' / 'b.pth'), m, legacy_vit_keys=True)
     assert 'patch_embed.weight' in torch.load(out, weights_only=True)['model']
+
+
+def test_resume_of_a_legacy_named_vit_checkpoint_continues_the_whole_ema(tmp_path):
+    """a ViT checkpoint written by rounds 1-4 (patch_embed.weight, blocks.N.fc{1,2}.*) must resume with its WHOLE EMA: the renamed
+    tensors used to keep the freshly loaded live weights as their average while the moments and last_iter continued, silently.  Here the
+    checkpoint of iteration 2 is rewritten with the old names ('model' and 'ema'), resumed, and must end bit-identical to the uninterrupted
+    run; an 'ema' dict that lacks a parameter is refused with a message that names the way out."""
+    import robustart_amd.model as M
+    from robustart_amd.model.vit_torch import VisionTransformer, timm_to_legacy_keys
+
+    def tiny_vit(**kw):
+        torch.manual_seed(0)
+        return VisionTransformer(img_size=32, patch_size=16, num_classes=1000, embed_dim=32, depth=2, num_heads=2)
+    M._REGISTRY['tiny_vit_cfg_test'] = tiny_vit
+    dev = torch.device('cpu')
+    over = {'model.type': 'tiny_vit_cfg_test', 'data.batch_size': 4, 'data.input_size': 32, 'lr_scheduler.kwargs.max_epoch': 2,
+            'lr_scheduler.kwargs.warmup_epoch': 1, 'lr_scheduler.kwargs.base_lr': 0.01, 'lr_scheduler.kwargs.warmup_lr': 0.02,
+            'ema.kwargs.decay': 0.5, 'saver.val_freq': 2}
+
+    def config(save_dir, **saver):
+        cfg = reference_shaped_config(**over)
+        cfg['data']['fake_size'] = 8                                   # 2 iterations per epoch -> 4 iterations
+        cfg['bf16'] = False
+        cfg['saver'].update(save_dir=save_dir, **saver)
+        return cfg
+    full_dir, part_dir = str(tmp_path / 'full'), str(tmp_path / 'part')
+    S.train(config(full_dir), _Args(), 0, 1, dev)
+    ck_full = torch.load(os.path.join(full_dir, 'ckpt.pth.tar'), weights_only=True)
+    assert ck_full['last_iter'] == 4 and 'blocks.0.mlp.fc1.weight' in ck_full['ema']
+    S.train(config(part_dir, save_many=True), _Args(), 0, 1, dev)
+    mid = os.path.join(part_dir, 'ckpt_2.pth.tar')
+    ck = torch.load(mid, weights_only=True)
+    live, avg = ck['model']['blocks.0.mlp.fc1.weight'], ck['ema']['blocks.0.mlp.fc1.weight']
+    assert not torch.equal(live, avg)                                  # otherwise a dropped average would go unnoticed
+    ck['model'], ck['ema'] = timm_to_legacy_keys(ck['model']), timm_to_legacy_keys(ck['ema'])
+    assert 'blocks.0.fc1.weight' in ck['ema'] and 'blocks.0.mlp.fc1.weight' not in ck['ema']
+    legacy = str(tmp_path / 'legacy_2.pth.tar')
+    torch.save(ck, legacy)
+    a = _Args()
+    a.recover = legacy
+    S.train(config(str(tmp_path / 'resumed')), a, 0, 1, dev)
+    assert S.train.start_iter == 2
+    ck_res = torch.load(os.path.join(str(tmp_path / 'resumed'), 'ckpt.pth.tar'), weights_only=True)
+    for k in ck_full['ema']:
+        assert torch.equal(ck_full['ema'][k], ck_res['ema'][k]), k
+    for k in ck_full['model']:
+        assert torch.equal(ck_full['model'][k], ck_res['model'][k]), k
+    del ck['ema']['blocks.1.fc2.bias']
+    short = str(tmp_path / 'short_2.pth.tar')
+    torch.save(ck, short)
+    a.recover = short
+    with pytest.raises(RuntimeError, match="lacks 1 of the model's"):
+        S.train(config(str(tmp_path / 'refused')), a, 0, 1, dev)
