@@ -179,6 +179,11 @@ def one_step(images, labels, path, step_idx, rank, B):
 
 
 one_step.extra = {}
+# Round 6, measured and not kept (one box, alternating runs): the same step as N independent chains, each over a contiguous 1 / N of the batch on
+# its own stream and engine, so that every stream carries the same mix of work for the whole step (the form above overlaps its two streams
+# only while the five evaluations last, a quarter of the step): N = 2 / 3 / 4 gave 184.0 / 184.2 / 184.2 ms per step against 183.5-184.1 for
+# this form and 191.7 on one stream -- the step is bound by what its kernels need from the chip, not by gaps between them.
+
 
 
 def measure_gaussian_roofline(B, device, launches=40, npairs=9):
