@@ -451,7 +451,10 @@ typedef struct rart_gemm_pair_desc {
 int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stream);
 /* Schedule of the 256-row tiles with 128 / 256 columns (round 6, csrc/gemm_pair_pp.hip): 1 (default; RART_PAIR_SCHEDULE in the environment
  * sets the initial value) = ping-pong -- the two halves of the workgroup alternate memory and matrix phases, counted vmcnt, no drain in the
- * steady state; 0 = the two-stage loop of round 4 everywhere.  Outputs are bit-identical under both (same products, same order). */
+ * steady state; 2 (opt-in: measured slower than 1, see the kernel's header) = ping-pong, and one-tap problems (1x1 convolutions, plain
+ * products without row re-basing / batching / GELU) with at least two 256 x 128 tiles per CU on the PERSISTENT kernel, which writes a tile
+ * out under the next tile's K loop; 0 = the two-stage loop of round 4 everywhere.  Outputs are bit-identical under all three (same
+ * products, same order, same point-wise code). */
 int rart_gemm_pair_set_schedule(int mode);
 int rart_gemm_pair_get_schedule(void);
 

@@ -215,8 +215,9 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
   gp_epilogue<TM, TN, CONV, MI>(d, lds, acc, m0, n0, c_off);
 }
 
-// 1 (default): the 256-row tiles with 128 / 256 columns run the ping-pong schedule of csrc/gemm_pair_pp.hip (bit-identical outputs); 0: this
-// file's two-stage loop everywhere (the A/B switch of tests/test_engine_x3_gpu.py and scratch/r6/).  RART_PAIR_SCHEDULE in the environment
+// 1 (default): the 256-row tiles with 128 / 256 columns run the ping-pong schedule of csrc/gemm_pair_pp.hip; 2 (opt-in, measured slower): as 1,
+// and one-tap problems with at least two 256 x 128 tiles per CU on the PERSISTENT kernel with the deferred epilogue; 0: this file's two-stage loop everywhere (the
+// A/B switch of tests/test_engine_x3_gpu.py and scratch/r6/).  Bit-identical outputs under all three.  RART_PAIR_SCHEDULE in the environment
 // sets the initial value.
 int g_pair_schedule = -1;
 int gp_schedule() {
@@ -236,9 +237,23 @@ void gp_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividend
 }  // namespace
 
 bool rart_gemm_pair_pp_launch(const void* dev_desc, int tn, bool conv, unsigned grid_x, unsigned grid_y, hipStream_t st);   // gemm_pair_pp.hip
+void rart_gemm_pair_ps_launch(const void* dev_desc, bool conv, unsigned wgs, hipStream_t st);
+
+namespace {
+int gp_cu_count() {      // compute units of the current device (the persistent kernel's grid), per device
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
+}  // namespace
 
 extern "C" int rart_gemm_pair_set_schedule(int mode) {
-  RART_CHECK_ARG(mode == 0 || mode == 1, "rart_gemm_pair_set_schedule: mode must be 0 (two-stage loop) or 1 (ping-pong)");
+  RART_CHECK_ARG(mode >= 0 && mode <= 2, "rart_gemm_pair_set_schedule: mode must be 0 (two-stage loop), 1 (ping-pong) or 2 (ping-pong + persistent)");
   g_pair_schedule = mode;
   return RART_OK;
 }
@@ -330,7 +345,7 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   // that leaves fewer than 128 workgroups (layer4: 256 x 128), K-deep narrow layers (N <= 128) 128 x N.  tile_m / tile_n override.
   int tn = d.N <= 64 ? 64 : (d.N <= 128 ? 128 : 256), tm = 256;
   if (conv) {
-    if (gp_schedule() == 1 && d.N >= 256 && d.K >= 256) {
+    if (gp_schedule() >= 1 && d.N >= 256 && d.K >= 256) {
       // round 6 (scratch/r6/time_pair_pp.py --tiles, profiles/r06_pair_pp.json): with the ping-pong schedule the 256-row tiles win wherever
       // the layer is at least 256 wide and 256 deep -- 256 x 256 unless that leaves fewer than 128 workgroups (layer4: 256 x 128)
       tm = 256;
@@ -348,7 +363,19 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   RART_CHECK_ARG(blocks < (1ll << 31), "rart_gemm_pair_bf16: grid too large");
   const dim3 grid((uint32_t)blocks, nz);
   hipStream_t st = (hipStream_t)stream;
-  if (tm == 256 && tn >= 128 && gp_schedule() == 1 && rart_gemm_pair_pp_launch(&d, tn, conv, grid.x, grid.y, st)) {
+  // the persistent kernel (256 x 128 tiles, deferred epilogue): one tap, no GELU epilogue, no row re-basing / batching, at least two tiles per
+  // CU and a K loop with room for the 12 micro-steps of a tile's epilogue
+  if (gp_schedule() == 2 && tm == 256 && tn >= 128 && h->tile_n == 0 && h->tile_m == 0 && nz == 1 && !d.map_rows && d.src_off == 0 &&
+      (conv ? d.n_taps == 1 : true) && !(h->flags & (GP_GELU | GP_GELU_BWD | GP_GELU_KEEP)) && d.K / GP_BK >= 6) {
+    const int cus = gp_cu_count();
+    const long long tiles = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128);
+    if (tiles >= 2ll * cus) {
+      rart_gemm_pair_ps_launch(&d, conv, (unsigned)cus, st);
+      RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (persistent)");
+      return RART_OK;
+    }
+  }
+  if (tm == 256 && tn >= 128 && gp_schedule() >= 1 && rart_gemm_pair_pp_launch(&d, tn, conv, grid.x, grid.y, st)) {
     RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (ping-pong)");
     return RART_OK;
   }

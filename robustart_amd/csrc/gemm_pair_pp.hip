@@ -332,6 +332,313 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
 #endif
 }
 
+// ---- PERSISTENT form (round 6; opt-in: rart_gemm_pair_set_schedule(2)): 256 x 128 tiles, one workgroup per CU walks a contiguous run of
+//      tiles (consecutive column tiles of one row tile: the A rows stay in its L1 / L2), the ping-pong K loop above runs THROUGH the tile
+//      boundaries (the refills of the last two K steps fetch the next tile's first stages, the counted waits never drain), and the epilogue of
+//      tile t is DEFERRED: its accumulators move to a second register set and are written out in 12 micro-steps that ride in the phases of
+//      tile t + 1's K loop -- the skip-pair loads and the hi / lo stores of the wide 1x1 layers (50176 x 256 -> 1024 and its like: 0.5 MB
+//      per 256 x 256 of output against 8 K steps of matrix work) are 57 % of those launches and run with every CU's matrix pipes idle and
+//      every CU storing at once.
+//      A micro-step = a third of a 16-row half pass: (0) request the skip / mask operands of rows 0-7, write 16 accumulator registers per
+//      column block to the wave's staging; (1) rows 0-7: read back transposed, point-wise tail (gp_finish_segment, the same code as
+//      gp_epilogue: identical bits), stores, request rows 8-15; (2) rows 8-15.  The loads and stores of the micro-steps are ordinary
+//      compiler-counted memory operations beside the inline-asm LDS-DMA: gfx950 completes vector memory operations in issue order, so a
+//      counted `vmcnt(N)` of either kind can only wait for MORE than it needs when operations of the other kind sit behind its target --
+//      never less (N <= the operations issued after the target).
+//      One-tap problems without a GELU epilogue only (1x1 convolutions of any stride, plain products without row re-basing / batching).
+//      MEASURED (scratch/r6/time_ps.py, profiles/r06_persistent.txt): bit-identical on every shape and on the whole engine, and SLOWER than the
+//      256 x 256 ping-pong tiles it replaces -- 193 vs 176 us on 50176 x 256 -> 1024 (micro-steps in all four phases; 226 with them in the
+//      memory phases only; 216 with the operands requested two micro-steps ahead: 255 VGPRs), 207 vs 166 us on 50176 x 1024 -> 512, the
+//      gradient evaluation 20.4 vs 19.9 ms: a 128-column tile stages 1.5 x the bytes per MFMA (its K loop is bound by the texture-address
+//      unit, ~1 800 cycles per K step for 1 536 of matrix work), and a micro-step's VALU work beside the partner's MFMAs costs what the
+//      overlap gains.  A 256-column tile cannot hold two accumulator sets (2 x 128 registers).  Kept behind the switch, off by default.
+template <bool CONV>
+__global__ __launch_bounds__(512, 1) void k_gemm_pair_ps(const GemmPairDev d) {
+  constexpr int TM = 256, TN = 128, NW = 8, WN = 2, RW = 64, MI = 2;
+  constexpr int PLANE_A = TM * 64, PLANE_B = TN * 64, STAGE = 2 * PLANE_A + 2 * PLANE_B;
+  constexpr int WQ = 2, WH = 1, NB = WH + 2;
+  constexpr int VM_ALPHA = 3 * NB, VM_BETA = 2 + NB, VM_GAMMA = 2 + NB;
+  constexpr int PS_STG = 16 * GP_LDE * 4;                    // a wave's staging region: 16 rows x 68 floats
+  constexpr int OFF_STG = 2 * STAGE, OFF_TAB = OFF_STG + NW * PS_STG;
+  constexpr int NMS = 12;                                    // micro-steps of a tile's epilogue: 4 half passes x 3
+  __shared__ __attribute__((aligned(16))) uint8_t lds[OFF_TAB + 3 * TM * 4];
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+  const int g = wave >> 2, w4 = wave & 3, og = 1 - g;
+  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M + TM - 1) / TM, T = n_tiles * m_tiles;
+  const int G = gridDim.x, base_n = T / G, rem_n = T % G;
+  const int first = blockIdx.x * base_n + min((int)blockIdx.x, rem_n), count = base_n + ((int)blockIdx.x < rem_n ? 1 : 0);
+  if (count == 0) return;
+  const int KT = d.K / GP_BK;
+  const int flags = d.flags;
+  const bool out_f32 = flags & GP_OUT_F32;
+
+  // ---- loader (k_gemm_pair_pp's, TN = 128, one tap): piece rows, per-tile lane offsets
+  int pr[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int hh = q == 0 ? og : g;
+    pr[q] = (2 * og + (w4 >> 1)) * 64 + hh * 32 + (w4 & 1) * 16;
+  }
+  const uint32_t tap0 = CONV ? (uint32_t)__builtin_amdgcn_readfirstlane((d.tap_dy[0] * d.src_w + d.tap_dx[0]) * d.lda * 2) : 0u;
+  // byte offsets of this lane's two A pieces and two W pieces for tile t_
+#define RART_PS_ADDR(t_, AV, WV)                                                                                 \
+  {                                                                                                              \
+    const int mt_ = (t_) / n_tiles, nt_ = (t_) - mt_ * n_tiles;                                                  \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                              \
+      const int r = pr[q] + (lane >> 2);                                                                         \
+      const int csrc = (lane & 3) ^ ((r >> 2) & 3);                                                              \
+      const int m = mt_ * TM + r;                                                                                \
+      const bool ok = m < d.M;                                                                                   \
+      if (CONV) {                                                                                                \
+        const uint32_t mm = ok ? (uint32_t)m : 0u;                                                               \
+        const uint32_t tq = gp_fastdiv(mm, d.gw_magic, d.gw_shift);                                              \
+        const int ox = (int)(mm - tq * (uint32_t)d.grid_w);                                                      \
+        const int n = (int)gp_fastdiv(tq, d.gh_magic, d.gh_shift);                                               \
+        const int oy = (int)(tq - (uint32_t)n * (uint32_t)d.grid_h);                                             \
+        const int by = oy * d.sy, bx = ox * d.sx;                                                                \
+        const int iy = by + d.tap_dy[0], ix = bx + d.tap_dx[0];                                                  \
+        AV[q] = (ok && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w)                     \
+                    ? (uint32_t)((n * d.src_h * d.src_w + by * d.src_w + bx) * d.lda * 2 + csrc * 16) : PP_OOR;  \
+      } else {                                                                                                   \
+        AV[q] = ok ? (uint32_t)((((long long)m + d.src_off) * d.lda + csrc * 8) * 2) : PP_OOR;                   \
+      }                                                                                                          \
+    }                                                                                                            \
+    _Pragma("unroll") for (int q = 0; q < WQ; ++q) {                                                             \
+      const int r = 16 * (w4 + 4 * q) + (lane >> 2);                                                             \
+      const int csrc = (lane & 3) ^ ((r >> 2) & 3);                                                              \
+      const int n = nt_ * TN + r;                                                                                \
+      WV[q] = n < d.w_rows ? (uint32_t)((n * d.ldw + csrc * 8) * 2) : PP_OOR;                                    \
+    }                                                                                                            \
+  }
+  uint32_t av[2], wv[WQ], avn[2] = {PP_OOR, PP_OOR}, wvn[WQ] = {PP_OOR, PP_OOR};
+  RART_PS_ADDR(first, av, wv)
+  const pp_srd_t srd_ah = pp_make_srd(d.a_hi), srd_al = pp_make_srd(d.a_lo);
+  const pp_srd_t srd_w = pp_make_srd(g ? d.w_lo : d.w_hi);
+  const int w_step = (d.flags & GP_W_INTERLEAVED) ? 128 : 64;
+  const uint32_t w_dst = lds_base + 2 * PLANE_A + g * PLANE_B + w4 * 1024;
+  // stage S_ of the CURRENT tile's numbering (S_ >= KT: stage S_ - KT of the next tile, if there is one) -> buffer (par + S_) & 1
+#define RART_PS_ISSUE_A(Q, S_)                                                                                   \
+  {                                                                                                              \
+    const int s_ = (S_);                                                                                         \
+    const uint32_t dst_ = lds_base + ((par + s_) & 1) * STAGE + pr[Q] * 64;                                      \
+    if (s_ < KT) {                                                                                               \
+      const uint32_t so_ = tap0 + (uint32_t)s_ * 64u;                                                            \
+      pp_bload(av[Q], srd_ah, so_, dst_);                                                                        \
+      pp_bload(av[Q], srd_al, so_, dst_ + PLANE_A);                                                              \
+    } else if (has_next) {                                                                                       \
+      const uint32_t so_ = tap0 + (uint32_t)(s_ - KT) * 64u;                                                     \
+      pp_bload(avn[Q], srd_ah, so_, dst_);                                                                       \
+      pp_bload(avn[Q], srd_al, so_, dst_ + PLANE_A);                                                             \
+    }                                                                                                            \
+  }
+#define RART_PS_ISSUE_W(S_, Q0, Q1)                                                                              \
+  {                                                                                                              \
+    const int s_ = (S_);                                                                                         \
+    const uint32_t dst_ = w_dst + ((par + s_) & 1) * STAGE;                                                      \
+    if (s_ < KT) {                                                                                               \
+      _Pragma("unroll") for (int q = (Q0); q < (Q1); ++q) pp_bload(wv[q], srd_w, (uint32_t)(s_ * w_step), dst_ + q * 4096); \
+    } else if (has_next) {                                                                                       \
+      _Pragma("unroll") for (int q = (Q0); q < (Q1); ++q) pp_bload(wvn[q], srd_w, (uint32_t)((s_ - KT) * w_step), dst_ + q * 4096); \
+    }                                                                                                            \
+  }
+  const int fr = lane & 31, h = lane >> 5;
+  uint32_t xo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) xo[ks] = (uint32_t)(fr * 64 + (((2 * ks + h) ^ ((fr >> 2) & 3)) << 4));
+  f32x16 acc[MI][2], accp[MI][2];
+  int par = 0;
+  bool has_next = count > 1;
+  if (has_next) RART_PS_ADDR(first + 1, avn, wvn)
+
+  // ---- deferred epilogue state: the previous tile (n0p, its row table tabp), the next micro-step esp (NMS = nothing pending)
+  int esp = NMS, n0p = 0, tabp = 0;
+  float* const sE = reinterpret_cast<float*>(lds + OFF_STG + wave * PS_STG);
+  const int cw = lane & 7, rw = lane >> 3;
+  uint4 erh = make_uint4(0, 0, 0, 0), erl = erh;
+  uint32_t emb = 0xFFu;
+  long long ee = -1;
+  // request the operands of rows Q_ * 8 + rw of half pass HP_ of the pending tile
+#define RART_PS_EP_LOAD(HP_, Q_)                                                                                 \
+  {                                                                                                              \
+    const int rt_ = wm * RW + ((HP_) >> 1) * 32 + ((HP_)&1) * 16 + (Q_)*8 + rw;                                  \
+    const uint32_t off_ = reinterpret_cast<const uint32_t*>(lds + OFF_TAB)[tabp * TM + rt_];                     \
+    const int col_ = n0p + wn * 64 + cw * 8;                                                                     \
+    ee = (off_ != 0xFFFFFFFFu && col_ < d.N) ? (long long)off_ + col_ : -1;                                      \
+    erh = erl = make_uint4(0, 0, 0, 0);                                                                          \
+    emb = 0xFFu;                                                                                                 \
+    if (ee >= 0) {                                                                                               \
+      if (d.res_hi) {                                                                                            \
+        erh = *reinterpret_cast<const uint4*>(d.res_hi + ee);                                                    \
+        erl = *reinterpret_cast<const uint4*>(d.res_lo + ee);                                                    \
+      }                                                                                                          \
+      if (CONV && d.mask_bits) emb = d.mask_bits[ee >> 3];                                                       \
+    }                                                                                                            \
+  }
+#define RART_PS_EP_PUT(I_, H_)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int rr = 0; rr < 8; ++rr) {               \
+    const int r_ = (H_)*8 + rr;      /* a constant after unrolling: the register index stays static */            \
+    sE[((r_ & 3) + 8 * ((r_ >> 2) & 1) + 4 * h) * GP_LDE + j * 32 + fr] = accp[I_][j][r_];                       \
+  }
+  // one micro-step of the pending epilogue (nothing when none is pending)
+#define RART_PS_EP_STEP()                                                                                        \
+  if (esp < NMS) {                                                                                               \
+    const int hp_ = esp / 3, ph_ = esp - 3 * hp_;                                                                \
+    if (ph_ == 0) {                                                                                              \
+      RART_PS_EP_LOAD(hp_, 0)                                                                                    \
+      if (hp_ == 0) { RART_PS_EP_PUT(0, 0) } else if (hp_ == 1) { RART_PS_EP_PUT(0, 1) }                         \
+      else if (hp_ == 2) { RART_PS_EP_PUT(1, 0) } else { RART_PS_EP_PUT(1, 1) }                                  \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                     \
+      __builtin_amdgcn_wave_barrier();                                                                           \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                     \
+    } else {                                                                                                     \
+      const int r_ = (ph_ - 1) * 8 + rw;                                                                         \
+      const float4 v0 = *reinterpret_cast<const float4*>(sE + r_ * GP_LDE + cw * 8);                             \
+      const float4 v1 = *reinterpret_cast<const float4*>(sE + r_ * GP_LDE + cw * 8 + 4);                         \
+      if (ee >= 0) {                                                                                             \
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};                                           \
+        gp_finish_segment<CONV, false>(d, flags, out_f32, ee, v, erh, erl, erh, erl, emb);                       \
+      }                                                                                                          \
+      if (ph_ == 1) {                                                                                            \
+        RART_PS_EP_LOAD(hp_, 1)                                                                                  \
+      } else {                                                                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                   \
+        __builtin_amdgcn_wave_barrier();      /* the reads of this half pass are done before the next one's writes */ \
+      }                                                                                                          \
+    }                                                                                                            \
+    ++esp;                                                                                                       \
+  }
+
+  // ---- prologue: stage 0 whole, stage 1 except what the first M0 phases issue (the balanced form of k_gemm_pair_pp)
+  RART_PS_ISSUE_W(0, 0, WQ)
+  RART_PS_ISSUE_A(0, 0)
+  RART_PS_ISSUE_A(1, 0)
+  if (KT > 1 || has_next) {
+    RART_PS_ISSUE_W(1, 0, WH)
+    RART_PS_ISSUE_A(1, 1)
+    if (g) RART_PS_ISSUE_A(0, 1)
+  }
+  pp_vmcnt<0>();
+  __syncthreads();
+  if (g) pp_slot_end();
+
+  bf16x8 ah[2], al[2], bh[2][2], bl[2][2];
+  for (int s = 0; s < count; ++s) {
+    const int t = first + s, mt = t / n_tiles, m0 = mt * TM, n0 = (t - mt * n_tiles) * TN;
+    // the row table of this tile (destination element offset of tile row r, ~0 past M); three tables: the one overwritten here belonged to
+    // tile s - 3, whose deferred epilogue ended a whole tile ago
+    if (tid < TM) {
+      const uint32_t m = (uint32_t)(m0 + tid);
+      uint32_t off = 0xFFFFFFFFu;
+      if (m < (uint32_t)d.M) {
+        if (CONV) {
+          const uint32_t tq = gp_fastdiv(m, d.gw_magic, d.gw_shift);
+          const int ox = (int)(m - tq * (uint32_t)d.grid_w);
+          const int n = (int)gp_fastdiv(tq, d.gh_magic, d.gh_shift);
+          const int oy = (int)(tq - (uint32_t)n * (uint32_t)d.grid_h);
+          off = (uint32_t)(((n * d.dst_h + (oy * d.dst_sy + d.dst_oy)) * d.dst_w + (ox * d.dst_sx + d.dst_ox)) * d.ldc);
+        } else {
+          off = (uint32_t)((m + (uint32_t)d.dst_off) * (uint32_t)d.ldc);
+        }
+      }
+      reinterpret_cast<uint32_t*>(lds + OFF_TAB)[(s % 3) * TM + tid] = off;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int bc = n0 + wn * 64 + j * 32 + fr;
+      const float bv = (d.bias && bc < d.N) ? d.bias[bc] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+      const uint8_t* const Ah = lds + ((par + kt) & 1) * STAGE + (wm * RW) * 64;
+      const uint8_t* const Bh = lds + ((par + kt) & 1) * STAGE + 2 * PLANE_A + (wn * 64) * 64;
+      const int tail = !has_next && kt + 2 >= KT;
+      // ---- M0
+      RART_PS_ISSUE_W(kt + 1, WH, WQ)
+      RART_PS_ISSUE_A(0, kt + 1 + g)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bh[j][ks] = *reinterpret_cast<const bf16x8*>(Bh + j * 32 * 64 + xo[ks]);
+          bl[j][ks] = *reinterpret_cast<const bf16x8*>(Bh + PLANE_B + j * 32 * 64 + xo[ks]);
+        }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        ah[ks] = *reinterpret_cast<const bf16x8*>(Ah + xo[ks]);
+        al[ks] = *reinterpret_cast<const bf16x8*>(Ah + PLANE_A + xo[ks]);
+      }
+      RART_PS_EP_STEP()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_slot_end();
+      // ---- C0 (a micro-step after the MFMAs too: all eight waves advance their epilogue every slot)
+#define RART_PS_MFMA(I_)                                                                                         \
+  __builtin_amdgcn_s_setprio(1);                                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j) {              \
+    acc[I_][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[j][ks], acc[I_][j], 0, 0, 0);               \
+    acc[I_][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[j][ks], acc[I_][j], 0, 0, 0);               \
+    acc[I_][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[j][ks], acc[I_][j], 0, 0, 0);               \
+  }                                                                                                              \
+  __builtin_amdgcn_s_setprio(0);
+      RART_PS_MFMA(0)
+      RART_PS_EP_STEP()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_slot_end();
+      // ---- M1
+      RART_PS_ISSUE_W(kt + 2, 0, WH)
+      RART_PS_ISSUE_A(1, kt + 2)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        ah[ks] = *reinterpret_cast<const bf16x8*>(Ah + 32 * 64 + xo[ks]);
+        al[ks] = *reinterpret_cast<const bf16x8*>(Ah + PLANE_A + 32 * 64 + xo[ks]);
+      }
+      RART_PS_EP_STEP()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (tail) pp_vmcnt<0>();
+      else if (g) pp_vmcnt<VM_GAMMA>();
+      else pp_vmcnt<VM_ALPHA>();
+      pp_slot_end();
+      // ---- C1
+      RART_PS_MFMA(1)
+      RART_PS_EP_STEP()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!g) {
+        if (tail) pp_vmcnt<0>(); else pp_vmcnt<VM_BETA>();
+      }
+      pp_slot_end();
+    }
+#undef RART_PS_MFMA
+    // ---- tile boundary: what is left of the previous tile's epilogue, then this tile's accumulators become the pending ones
+    while (esp < NMS) { RART_PS_EP_STEP() }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
+    esp = 0; n0p = n0; tabp = s % 3;
+    par = (par + KT) & 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) av[q] = avn[q];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) wv[q] = wvn[q];
+    has_next = s + 2 < count;
+    if (has_next) RART_PS_ADDR(first + s + 2, avn, wvn)
+  }
+  if (!g) pp_slot_end();
+  pp_vmcnt<0>();
+  __syncthreads();
+  while (esp < NMS) { RART_PS_EP_STEP() }
+#undef RART_PS_EP_STEP
+#undef RART_PS_EP_PUT
+#undef RART_PS_EP_LOAD
+#undef RART_PS_ISSUE_W
+#undef RART_PS_ISSUE_A
+#undef RART_PS_ADDR
+}
+
 #ifndef RART_PP_DEFAULT_OPT
 #define RART_PP_DEFAULT_OPT 1
 #endif
@@ -362,6 +669,13 @@ __attribute__((visibility("hidden"))) bool rart_gemm_pair_pp_launch(const void* 
 #else
   return pp_launch_opt<RART_PP_DEFAULT_OPT>(d, tn, conv, grid, st);
 #endif
+}
+
+// The persistent form: grid = `wgs` workgroups (one per CU), each walking T / wgs tiles of 256 x 128.
+__attribute__((visibility("hidden"))) void rart_gemm_pair_ps_launch(const void* dev_desc, bool conv, unsigned wgs, hipStream_t st) {
+  const GemmPairDev& d = *static_cast<const GemmPairDev*>(dev_desc);
+  if (conv) hipLaunchKernelGGL((k_gemm_pair_ps<true>), dim3(wgs), dim3(512), 0, st, d);
+  else hipLaunchKernelGGL((k_gemm_pair_ps<false>), dim3(wgs), dim3(512), 0, st, d);
 }
 
 #ifdef RART_PP_STAMPS

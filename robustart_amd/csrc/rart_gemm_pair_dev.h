@@ -68,6 +68,73 @@ __device__ __forceinline__ void gp_join8(const uint4& hi, const uint4& lo, float
 }
 
 
+// The point-wise tail of one 8-column row segment (element offset e, CONV or plain): v = the fp32 accumulator values of the segment; residual
+// pair, GELU forms, 1-bit mask, ReLU, then hi / lo (two 16-byte stores) or fp32, and the sign byte.  Shared by gp_epilogue and the
+// persistent kernel's deferred epilogue (csrc/gemm_pair_pp.hip) so that both produce the same bits.
+template <bool CONV, bool GELU = true>
+__device__ __forceinline__ void gp_finish_segment(const GemmPairDev& d, int flags, bool out_f32, long long e, float (&v)[8], const uint4& rh_q,
+                                            const uint4& rl_q, const uint4& uh_q, const uint4& ul_q, uint32_t mb_q) {
+  if (d.res_hi) {
+    float rv[8];
+    gp_join8(rh_q, rl_q, rv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += rv[j];
+  }
+  if (GELU && (flags & GP_GELU)) {     // gelu of the value the PAIR of the pre-activation represents: the same result as GELU_KEEP's, so a forward-only
+    uint4 ph, pl;            // evaluation and the forward of a gradient evaluation agree bit for bit
+    gp_split8(v, ph, pl);
+    gp_join8(ph, pl, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gp_gelu(v[j]);
+  }
+  if (GELU && (flags & GP_GELU_KEEP)) {
+    // two outputs: the pre-activation pair u goes to `aux` (the backward's GELU' operand); dst receives gelu of the value the
+    // pair REPRESENTS, so forward and backward see the same u
+    uint4 ph, pl;
+    gp_split8(v, ph, pl);
+    *reinterpret_cast<uint4*>(d.aux_hi + e) = ph;
+    *reinterpret_cast<uint4*>(d.aux_lo + e) = pl;
+    gp_join8(ph, pl, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gp_gelu(v[j]);
+  }
+  if (GELU && (flags & GP_GELU_BWD)) {
+    float u[8];
+    gp_join8(uh_q, ul_q, u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= gp_gelu_grad(u[j]);
+  }
+  if (CONV) {      // 1-bit ReLU mask of the destination (backward-to-input): bit k of the byte = column col + k
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!((mb_q >> j) & 1u)) v[j] = 0.f;
+  }
+  if (flags & GP_RELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+  }
+  if (out_f32) {
+    float* o = reinterpret_cast<float*>(d.dst_hi) + e;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 ph, pl;
+    gp_split8(v, ph, pl);
+    *reinterpret_cast<uint4*>(d.dst_hi + e) = ph;
+    *reinterpret_cast<uint4*>(d.dst_lo + e) = pl;
+    if (CONV && d.sign_out) {     // (hi plane > 0): a bf16 is > 0 exactly when its bits, read as int16, are > 0
+      const uint32_t hw[4] = {ph.x, ph.y, ph.z, ph.w};
+      uint32_t sb = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sb |= ((short)(hw[j] & 0xFFFFu) > 0 ? 1u : 0u) << (2 * j);
+        sb |= ((short)(hw[j] >> 16) > 0 ? 1u : 0u) << (2 * j + 1);
+      }
+      d.sign_out[e >> 3] = (uint8_t)sb;
+    }
+  }
+}
+
 // Epilogue of a TM x TN tile whose accumulators acc[MI][2] follow k_gemm_pair's wave layout (wave = (wm, wn), a wave owns RW rows x 64
 // columns).  `lds` is the workgroup's tile buffer (free after the K loop).  Must be called by every thread of the workgroup.
 template <int TM, int TN, bool CONV, int MI>
@@ -154,65 +221,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmPairDev& d, uint8_t* lds, 
       const long long e = eo[q];
       if (e >= 0) {
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        if (d.res_hi) {
-          float rv[8];
-          gp_join8(rh[q], rl[q], rv);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += rv[j];
-        }
-        if (flags & GP_GELU) {     // gelu of the value the PAIR of the pre-activation represents: the same result as GELU_KEEP's, so a forward-only
-          uint4 ph, pl;            // evaluation and the forward of a gradient evaluation agree bit for bit
-          gp_split8(v, ph, pl);
-          gp_join8(ph, pl, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gp_gelu(v[j]);
-        }
-        if (flags & GP_GELU_KEEP) {
-          // two outputs: the pre-activation pair u goes to `aux` (the backward's GELU' operand); dst receives gelu of the value the
-          // pair REPRESENTS, so forward and backward see the same u
-          uint4 ph, pl;
-          gp_split8(v, ph, pl);
-          *reinterpret_cast<uint4*>(d.aux_hi + e) = ph;
-          *reinterpret_cast<uint4*>(d.aux_lo + e) = pl;
-          gp_join8(ph, pl, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gp_gelu(v[j]);
-        }
-        if (flags & GP_GELU_BWD) {
-          float u[8];
-          gp_join8(uh[q], ul[q], u);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= gp_gelu_grad(u[j]);
-        }
-        if (CONV) {      // 1-bit ReLU mask of the destination (backward-to-input): bit k of the byte = column col + k
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (!((mb[q] >> j) & 1u)) v[j] = 0.f;
-        }
-        if (flags & GP_RELU) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        if (out_f32) {
-          float* o = reinterpret_cast<float*>(d.dst_hi) + e;
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          uint4 ph, pl;
-          gp_split8(v, ph, pl);
-          *reinterpret_cast<uint4*>(d.dst_hi + e) = ph;
-          *reinterpret_cast<uint4*>(d.dst_lo + e) = pl;
-          if (CONV && d.sign_out) {     // (hi plane > 0): a bf16 is > 0 exactly when its bits, read as int16, are > 0
-            const uint32_t hw[4] = {ph.x, ph.y, ph.z, ph.w};
-            uint32_t sb = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              sb |= ((short)(hw[j] & 0xFFFFu) > 0 ? 1u : 0u) << (2 * j);
-              sb |= ((short)(hw[j] >> 16) > 0 ? 1u : 0u) << (2 * j + 1);
-            }
-            d.sign_out[e >> 3] = (uint8_t)sb;
-          }
-        }
+        gp_finish_segment<CONV>(d, flags, out_f32, e, v, rh[q], rl[q], uh[q], ul[q], mb[q]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -54,7 +54,7 @@ out = {'shapes': {}, 'engine': {}}
 calls = record(True)
 print('%d distinct launch shapes in the fused-tail engine' % len(calls), flush=True)
 tiles = [(0, 0)] + ([(256, 256), (256, 128)] if '--tiles' in sys.argv else [])
-tot = {0: 0.0, 1: 0.0}
+tot = {0: 0.0, 1: 0.0, 2: 0.0}
 for key, (cnt, a) in sorted(calls.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1][0]):
     dst = a[2]
     row = {'count': cnt}
@@ -63,40 +63,42 @@ for key, (cnt, a) in sorted(calls.items(), key=lambda kv: -kv[0][0] * kv[0][1] *
         lib.rart_gemm_pair_set_schedule(0)
         eng._gemm_pair(*a); torch.cuda.synchronize()
         want = dst.clone()
-        lib.rart_gemm_pair_set_schedule(1)
+        lib.rart_gemm_pair_set_schedule(2)
         dst.zero_()
         eng._gemm_pair(*a); torch.cuda.synchronize()
         same = bool(torch.equal(dst.view(torch.int16) if dst.dtype == torch.bfloat16 else dst.view(torch.int32),
                                 want.view(torch.int16) if want.dtype == torch.bfloat16 else want.view(torch.int32)))
-        ts = {0: [], 1: []}
+        ts = {0: [], 1: [], 2: []}
         for _ in range(3):
-            for s in (0, 1):
+            for s in (0, 1, 2):
                 lib.rart_gemm_pair_set_schedule(s)
                 ts[s].append(t_ms(lambda: eng._gemm_pair(*a)) * 1e3)
         name = 'auto' if tile == (0, 0) else '%dx%d' % tile
-        row[name] = {'two_stage_us': round(min(ts[0]), 1), 'pingpong_us': round(min(ts[1]), 1), 'bit_identical': same}
+        row[name] = {'two_stage_us': round(min(ts[0]), 1), 'pingpong_us': round(min(ts[1]), 1), 'persistent_us': round(min(ts[2]), 1),
+                     'bit_identical': same}
         if tile == (0, 0):
-            tot[0] += min(ts[0]) * cnt
-            tot[1] += min(ts[1]) * cnt
+            for q in (0, 1, 2):
+                tot[q] += min(ts[q]) * cnt
     eng.pair_tile = (0, 0)
     out['shapes']['%d_%d_%d_%d_%s' % (key[0], key[1], key[2], key[3], 'res' if key[4] else 'nores')] = row
     print(key, row, flush=True)
-print('sum over the launches of a gradient evaluation: two-stage %.1f us, ping-pong %.1f us' % (tot[0], tot[1]), flush=True)
-out['sum_us'] = {'two_stage': round(tot[0], 1), 'pingpong': round(tot[1], 1)}
+print('sum over the launches of a gradient evaluation: two-stage %.1f us, ping-pong %.1f us, + persistent %.1f us' % (tot[0], tot[1], tot[2]), flush=True)
+out['sum_us'] = {'two_stage': round(tot[0], 1), 'pingpong': round(tot[1], 1), 'persistent': round(tot[2], 1)}
 eng.fused_tail_pair = True
 for rnd in range(3):
-    for s in (0, 1):
+    for s in (0, 1, 2):
         lib.rart_gemm_pair_set_schedule(s)
         fb = t_ms(lambda: eng.forward_backward(x, MEAN, STD, y, 0), 5)
         f = t_ms(lambda: eng.logits(x, MEAN, STD), 5)
-        out['engine'].setdefault('pingpong' if s else 'two_stage', []).append({'fwd_ms': round(f, 3), 'fwd_bwd_ms': round(fb, 3)})
-        print('schedule', s, out['engine']['pingpong' if s else 'two_stage'][-1], flush=True)
+        nm = ('two_stage', 'pingpong', 'persistent')[s]
+        out['engine'].setdefault(nm, []).append({'fwd_ms': round(f, 3), 'fwd_bwd_ms': round(fb, 3)})
+        print('schedule', s, out['engine'][nm][-1], flush=True)
 # the whole engine under both schedules: logits and input gradient must be equal bit for bit
 lib.rart_gemm_pair_set_schedule(0)
-l0, _, g0, _ = eng.forward_backward(x[:64], MEAN, STD, y[:64], 0)
+l0, _, g0, _ = eng.forward_backward(x, MEAN, STD, y, 0)
 l0, g0 = l0.clone(), g0.clone()
-lib.rart_gemm_pair_set_schedule(1)
-l1, _, g1, _ = eng.forward_backward(x[:64], MEAN, STD, y[:64], 0)
+lib.rart_gemm_pair_set_schedule(2)
+l1, _, g1, _ = eng.forward_backward(x, MEAN, STD, y, 0)
 out['engine']['bit_identical_logits'] = bool(torch.equal(l0, l1))
 out['engine']['bit_identical_gradient'] = bool(torch.equal(g0, g1))
 print('engine bit-identical:', out['engine']['bit_identical_logits'], out['engine']['bit_identical_gradient'])

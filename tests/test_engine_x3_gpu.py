@@ -643,4 +643,84 @@ def test_pair_gemm_pingpong_schedule_is_bit_identical(conv, M, K, N, tile_n, bat
             assert torch.equal(sign, want_sign)
     finally:
         lib.rart_gemm_pair_set_schedule(old)
-    assert lib.rart_gemm_pair_set_schedule(2) != 0
+    assert lib.rart_gemm_pair_set_schedule(3) != 0
+
+
+def _pair_ps_case(_lib, conv, M, K, N, flags_relu, with_res, with_mask, seed):
+    """A one-tap problem large enough for the persistent kernel (>= 2 x 256 tiles of 256 x 128), automatic tiles."""
+    g = torch.Generator().manual_seed(seed)
+    d = _lib.GemmPairDesc()
+    if conv:
+        B, Hh, Ww, stride = conv
+        C = K
+        xp = _split(torch.randn(B, Hh * stride, Ww * stride, C, generator=g).cuda())
+        assert M == B * Hh * Ww
+    else:
+        xp = _split(torch.randn(M, K, generator=g).cuda())
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    wh = w.to(torch.bfloat16)
+    wl = (w - wh.float()).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    rp = _split(torch.randn(M, N, generator=g).cuda())
+    out = torch.full((2, M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+    sign = torch.zeros(M, N // 8, dtype=torch.uint8, device='cuda')
+    bits = (torch.rand(M, N // 8, generator=g) * 256).to(torch.uint8).cuda()
+    d.a_hi, d.a_lo, d.w_hi, d.w_lo = xp[0].data_ptr(), xp[1].data_ptr(), wh.data_ptr(), wl.data_ptr()
+    d.bias, d.dst_hi, d.dst_lo = bias.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
+    if with_res:
+        d.res_hi, d.res_lo = rp[0].data_ptr(), rp[1].data_ptr()
+    d.N, d.ldw, d.ldc, d.w_rows, d.flags = N, K, N, N, (1 if flags_relu else 0)
+    if conv:
+        d.lda = C
+        d.conv, d.batch, d.grid_h, d.grid_w, d.src_h, d.src_w, d.sy, d.sx, d.k_per_tap, d.n_taps = 1, B, Hh, Ww, Hh * stride, Ww * stride, stride, stride, C, 1
+        d.tap_dy[0], d.tap_dx[0] = 0, 0
+        d.dst_h, d.dst_w, d.dst_sy, d.dst_sx = Hh, Ww, 1, 1
+        if with_mask:
+            d.mask_bits = bits.data_ptr()
+        else:
+            d.sign_out = sign.data_ptr()
+    else:
+        d.M, d.K, d.lda = M, K, K
+    return d, out, sign, [xp, wh, wl, bias, rp, bits]
+
+
+@pytest.mark.parametrize('conv,M,K,N,relu,res,mask', [
+    (None, 10317, 192, 1792, False, True, False),          # six K steps: exactly the 12 micro-steps; ragged last row tile; 41 x 14 tiles
+    (None, 10240, 544, 1664, True, False, False),          # 17 K steps (odd: the stage-buffer parity flips per tile), 13 column tiles
+    ((8, 56, 56, 1), 25088, 256, 768, True, True, False),  # the layer shape: 1x1, skip pair, ReLU, sign bits
+    ((8, 28, 28, 2), 6272, 256, 2816, False, True, True),  # stride 2 with a 1-bit mask, 25 x 22 tiles
+    (None, 131072 + 5, 256, 136, False, True, False),      # N = 136: a column tile with 8 valid columns
+])
+def test_pair_gemm_persistent_kernel_is_bit_identical(conv, M, K, N, relu, res, mask):
+    """Round 6: the PERSISTENT form of the ping-pong GEMM (256 x 128 tiles, a workgroup per CU walks a run of tiles, the epilogue of a tile is
+    deferred into the memory phases of the next tile's K loop) against round 4's two-stage loop with its ordinary epilogue: equal BIT FOR
+    BIT, repeatedly, beside a bandwidth hog (the deferred epilogue mixes compiler-counted loads / stores with inline-asm LDS-DMA; a wrong
+    wait shows as a rare wrong tile)."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    d, out, sign, keep = _pair_ps_case(_lib, conv, M, K, N, relu, res, mask, seed=21)
+    old = lib.rart_gemm_pair_get_schedule()
+    try:
+        _lib.check(lib.rart_gemm_pair_set_schedule(0))
+        _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        want, want_sign = out.view(torch.int16).clone(), sign.clone()
+        assert torch.isfinite(out.float()).all()
+        _lib.check(lib.rart_gemm_pair_set_schedule(2))
+        hog_stream = torch.cuda.Stream()
+        hog = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+        for rep in range(6):
+            out.fill_(float('nan'))
+            sign.zero_()
+            if rep >= 2:
+                with torch.cuda.stream(hog_stream):
+                    for _ in range(4):
+                        hog.add_(1.0)
+            _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            bad = (out.view(torch.int16) != want).any(0)
+            assert not bad.any(), 'persistent kernel differs from the two-stage loop (repetition %d): %d elements, first rows %s' % (
+                rep, int(bad.sum()), bad.any(1).nonzero().flatten()[:8].tolist())
+            assert torch.equal(sign, want_sign)
+    finally:
+        lib.rart_gemm_pair_set_schedule(old)
