@@ -767,20 +767,30 @@ def run_adv_train(args, device, rank, world, dist):
         return loss_rows
     for i in range(args.warmup):
         step(i)
+    tb = time.perf_counter()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss_rows = step(args.warmup + i)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    with_barrier = dt
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the same per-rank diagnostics as the headline workload, plus what the gradient exchange of the last step did:
+        # the first real 8-GPU run of config 5 reads communicator / barrier / exchange times apart from the step time
+        _diag(rank, phase='timed_region', opening_barrier_s=t0 - tb, own_steps_s=own, with_closing_barrier_s=with_barrier, max_over_ranks_s=dt)
+        xs = arena.exchange_stats()
+        if xs is not None:
+            _diag(rank, phase='grad_exchange', **{k: v for k, v in xs.items() if isinstance(v, (int, float))})
     flops = (3 * 2 + 3) * FLOP_FWD * B * world          # PGD-3: 3 x (fwd + bwd-to-input); train step: fwd + 2 x bwd
     final_loss = float(loss_rows.mean())
     del eng, attack, opt, arena, model

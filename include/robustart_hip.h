@@ -74,7 +74,8 @@ const char* rart_corruption_name(int corruption_id);
  *   gaussian_noise, speckle_noise : [0] double noise[n][h][w][3]   (np.random.normal(scale=c))
  *   shot_noise                    : [0] int32  counts[n][h][w][3]  (np.random.poisson)
  *   impulse_noise                 : [0] uint8  code[n][h][w][3]    (0 keep, 1 salt, 2 pepper)
- *   glass_blur                    : [0] int8   dxdy[n][iters][224-2d][224-2d][2]
+ *   glass_blur                    : [0] int8   dxdy[n][iters][224-2d][224-2d][2]   (every value in [-d, d): numpy's randint(-d, d);
+ *                                       the overlapped copy chain packs dx + d, dy + d into nibbles -- the Python entry refuses others)
  *   motion_blur                   : [0] double angle[n]
  *   snow                          : [0] double layer[n][224][224]  [1] double angle[n]
  *   frost                         : [0] uint8  texture_crop[n][224][224][3]  (REQUIRED always: the
@@ -82,6 +83,12 @@ const char* rart_corruption_name(int corruption_id);
  *   fog                           : [0] double uniform[n][65535]   (plasma_fractal draws, call order)
  *   elastic_transform             : [0] float  jitter[n][3][2]  [1] double field_x[n][224][224]
  *                                   [2] double field_y[n][224][224]
+ *                                   (severities 1-2: the field filter runs as fp64 matrix products against the folded reflect-filter
+ *                                   matrix, resident on the device after the first call -- not scipy's summation order: the fields
+ *                                   differ in the last bits, the images stay within the corruption's stated tolerance (<= 1 LSB on <= 1e-4
+ *                                   of the pixels) and are NOT guaranteed bit-identical to the ordered kernels; RART_ELASTIC_ORDERED=1 in the
+ *                                   environment selects the ordered, bit-exact kernels.  The first severity-1 / 2 call per device
+ *                                   allocates: keep it outside stream capture)
  *   spatter                       : [0] double layer[n][224][224]
  *   others                        : ignored
  * workspace: rart_corrupt_workspace_bytes(...) bytes, 256-byte aligned.

@@ -666,6 +666,26 @@ const std::vector<double>& cached_dense_matrix(int slot, const std::vector<doubl
   return tabs[slot];
 }
 
+// The same matrix RESIDENT on the current device: allocated and uploaded once per (device, slot), for the life of the process (401 KB per
+// severity).  Round 5 copied it from pageable host memory with hipMemcpyAsync on every call -- a host stall per call, and not capturable in
+// a hipGraph.  The first call per device must not run under stream capture (it allocates and copies synchronously).
+const double* cached_dense_matrix_dev(int slot, const std::vector<double>& host) {
+  static const double* dev_tabs[64][16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(rart_host_table_mutex());
+  if (!dev_tabs[dev][slot]) {
+    double* p = nullptr;
+    if (hipMalloc((void**)&p, host.size() * sizeof(double)) != hipSuccess) return nullptr;
+    if (hipMemcpy(p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    dev_tabs[dev][slot] = p;
+  }
+  return dev_tabs[dev][slot];
+}
+
 const double kFog[5][2] = {{1.5, 2}, {2., 2}, {2.5, 1.7}, {2.5, 1.5}, {3., 1.4}};
 const double kSnow[5][7] = {{0.1, 0.3, 3, 0.5, 10, 4, 0.8}, {0.2, 0.3, 2, 0.5, 12, 4, 0.7}, {0.55, 0.3, 4, 0.9, 12, 8, 0.7},
                             {0.55, 0.3, 4.5, 0.85, 12, 8, 0.65}, {0.55, 0.3, 2.5, 0.85, 12, 12, 0.55}};
@@ -783,11 +803,11 @@ int rart_launch_composite(int id, const RartCorruptArgs& a) {
       hipLaunchKernelGGL(k_warp_affine, img_grid(a.n), dim3(kBlock), 0, st, a.in, warped, inv);
       // the kernel is longer than half the signal (severities 1 and 2): both passes as fp64 matrix products against the folded filter matrix
       bool dense = 4 * radius + 2 > HW && getenv("RART_ELASTIC_ORDERED") == nullptr;          // severities 1 (radius 512) and 2 (radius 59)
-      double* mdev = wdev + A256(1025 * sizeof(double)) / sizeof(double);
+      const double* mdev = nullptr;
       const size_t lds0 = (size_t)HW * FD_LDX * sizeof(double), lds1 = (size_t)FD_SLAB * FD_LDY * sizeof(double);
       if (dense) {
-        const std::vector<double>& mf = cached_dense_matrix(s, wt, radius);
-        dense = hipMemcpyAsync(mdev, mf.data(), mf.size() * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
+        mdev = cached_dense_matrix_dev(s, cached_dense_matrix(s, wt, radius));          // resident on the device, uploaded once
+        dense = mdev != nullptr &&
                 rart_raise_dynamic_lds((const void*)k_field_dense<0, double>, lds0, "elastic field filter (dense)") &&
                 rart_raise_dynamic_lds((const void*)k_field_dense<1, float>, lds1, "elastic field filter (dense)");
       }

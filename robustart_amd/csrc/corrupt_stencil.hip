@@ -6,6 +6,8 @@
 // cv2.GaussianBlur on the aliased disk (fp32); ImageMagick MotionBlurImage (one-sided gaussian
 // taps along the angle, edge virtual pixels, 8-bit requantisation).
 #include "rart_common.h"
+#include <map>
+#include <utility>
 #include <type_traits>
 #include <math.h>
 #include <string.h>
@@ -771,15 +773,15 @@ GaussI8Host make_gauss_i8(const GaussW& gw, double sigma) {
   h.ok = true;
   return h;
 }
+// Process-lifetime table per (sigma, radius), NEVER evicted (std::map nodes do not move): the reference handed out stays valid while another
+// thread inserts, and the fragments behind an in-flight hipMemcpyAsync are never overwritten (the 16-slot array reused slot 15).
 const GaussI8Host& gauss_i8_for(const GaussW& gw, double sigma) {
-  static GaussI8Host cache[16];
-  static int used = 0;
+  static std::map<std::pair<double, int>, GaussI8Host> cache;
   std::lock_guard<std::mutex> lk(rart_host_table_mutex());
-  for (int i = 0; i < used; ++i)
-    if (cache[i].sigma == sigma) return cache[i];
-  const int slot = used < 16 ? used++ : 15;
-  cache[slot] = make_gauss_i8(gw, sigma);
-  return cache[slot];
+  const auto key = std::make_pair(sigma, gw.radius);
+  auto it = cache.find(key);
+  if (it == cache.end()) it = cache.emplace(key, make_gauss_i8(gw, sigma)).first;
+  return it->second;
 }
 
 // ---- motion_blur (ImageMagick) -----------------------------------------------------------------

@@ -151,6 +151,13 @@ def corrupt_batch_(batch, corruption_id, severity, seed=None, sample_offset=None
                 # per-image list of arrays (fog: the successive np.random.uniform results) -> [n][flat]
                 v = np.stack([np.concatenate([np.asarray(q).ravel() for q in per]) for per in v])
             a = np.ascontiguousarray(np.asarray(v), dtype=dt)
+            if name == 'glass_blur' and key == 'dxdy' and a.size:
+                # the overlapped copy chain packs dx + delta and dy + delta into nibbles and its schedule is proved for |dx|, |dy| <= delta
+                # (tests/test_schedules_cpu.py): numpy's randint(-delta, delta) of the reference never leaves [-delta, delta), an injected
+                # array that does is refused here, on the host, instead of silently addressing the wrong pixel
+                delta = (1, 2, 2, 3, 4)[severity - 1]
+                if int(a.min()) < -delta or int(a.max()) >= delta:
+                    raise ValueError('glass_blur draws must lie in [-%d, %d) at severity %d, got [%d, %d]' % (delta, delta, severity, int(a.min()), int(a.max())))
             t = torch.from_numpy(a.reshape(-1).view(np.uint8) if a.dtype != np.uint8 else a.reshape(-1)).cuda()
             keep.append(t)
             arrs.append(t.data_ptr())

@@ -56,6 +56,33 @@ def test_bench_headline_under_a_one_rank_rccl_group():
     assert t['own_steps_s'] <= t['with_closing_barrier_s'] <= t['max_over_ranks_s'] + 1e-9
 
 
+def test_bench_adv_train_workload_under_a_one_rank_rccl_group():
+    """`bench.py --workload adv_train` (BASELINE config 5) prints the same per-rank diagnostics as the headline workload --
+    communicator creation, barriers, step time -- plus the gradient exchange of the last step, so the first real 8-GPU run of config 5 is
+    as cheap to read as config 3's."""
+    r = _torchrun([os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--workload', 'adv_train', '--steps', '2', '--warmup', '1', '--batch', '32',
+                   '--no-cpu-baseline'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['dtype'] == 'bf16' and d['final_loss'] == d['final_loss']
+    diag = {}
+    for ln in r.stderr.splitlines():
+        if ln.startswith('[bench rank 0] '):
+            q = json.loads(ln[len('[bench rank 0] '):])
+            diag[q['phase']] = q
+    c, t, gx = diag['communicator'], diag['timed_region'], diag['grad_exchange']
+    for k in ('init_process_group_s', 'first_all_reduce_s', 'barrier_s', 'all_reduce_s'):
+        assert c[k] >= 0, k
+    assert c['world'] == 1 and c['ipc_mode_legacy'] == '0'
+    for k in ('opening_barrier_s', 'own_steps_s', 'with_closing_barrier_s', 'max_over_ranks_s'):
+        assert t[k] >= 0, k
+    assert t['own_steps_s'] <= t['with_closing_barrier_s'] <= t['max_over_ranks_s'] + 1e-9
+    assert gx['buckets'] >= 2 and gx['bytes'] == 4 * 25557032 and 0 <= gx['launched_during_backward'] <= gx['buckets']
+    assert gx['stream_wait_s'] >= 0 and gx['host_wait_s'] >= 0
+
+
 def test_cls_solver_adv_train_steps_under_a_one_rank_rccl_group(tmp_path):
     """Two adversarial-training iterations of cls_solver (HIP train engine, bucketed all_reduce of the gradient arena overlapped with
     backward, optimizer + EMA kernels) and a clean evaluation (metric all-reduce) in a one-rank RCCL group."""
