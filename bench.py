@@ -227,6 +227,14 @@ def measure_gaussian_roofline(B, device, launches=40, npairs=9):
     # read + write stream of this size sustains on this part, next to the 8 TB/s spec the fraction is quoted against
     copy_s = timed(lambda i: dst[i % npairs].copy_(src[i % npairs]))
     measure_gaussian_roofline.extra = extra = {}
+    # and a PLAIN HIP copy kernel of the same bytes (rart_copy_calibration): in the noise kernel's own geometry (one wave per 1 KiB, 16 B per
+    # lane) and as the fastest plain copy found at this size (grid-stride, 1 024 workgroups) -- the ceiling a kernel that does nothing but move
+    # the launch's bytes reaches at B = 256
+    from robustart_amd import _lib
+    lib, nbytes = _lib.load(), src[0].numel()
+    for variant, key in ((0, 'plain_copy_same_geometry_s'), (1, 'plain_copy_grid_stride_s')):
+        extra[key] = timed(lambda i, v=variant: _lib.check(lib.rart_copy_calibration(src[i % npairs].data_ptr(), dst[i % npairs].data_ptr(),
+                                                                                      nbytes, v, _lib.stream_ptr())))
     if launches >= 20:
         # (a) the same single-severity launches alternating over TWO streams: the tail of one launch overlaps the ramp of the next
         #     (the five severities of the workload are independent); time = main-stream events around the fork / join
@@ -286,6 +294,15 @@ def gaussian_noise_block(B, device):
                                          'frac_of_peak': algo / copy_s / HBM_PEAK, 'kernel_vs_copy': copy_s / avg,
                                          'note': 'torch Tensor.copy_ over the same 9 rotating buffer pairs: the read+write '
                                                  'rate this part sustains at this size'}}
+    if 'plain_copy_same_geometry_s' in ex:
+        cg, cs = ex['plain_copy_same_geometry_s'], ex['plain_copy_grid_stride_s']
+        single['plain_copy_kernel'] = {
+            'same_geometry': {'avg_launch_us': cg * 1e6, 'frac_of_peak': algo / cg / HBM_PEAK, 'kernel_vs_copy': cg / avg},
+            'grid_stride_1024_workgroups': {'avg_launch_us': cs * 1e6, 'frac_of_peak': algo / cs / HBM_PEAK, 'kernel_vs_copy': cs / avg},
+            'note': 'rart_copy_calibration: a hand-written HIP kernel that only copies the launch\'s bytes (16 B per lane), in the noise '
+                    'kernel\'s launch geometry and as the fastest plain copy of this size; SQ counters of the noise kernels beside it: '
+                    'profiles/r06_noise_counters.csv (single severity: 52 % of wave cycles waiting on memory, 32 % issue stalls; five '
+                    'severities: 64 % issue stalls = VALU-bound)'}
     # the same kernel on a 4x larger launch (B = 1024 by default, 3 rotating pairs = 925 MB): how much of the B = 256 gap to the peak is
     # launch ramp / tail of a 18 us kernel rather than the steady-state rate
     if os.environ.get('RART_BENCH_NO_4X') != '1':        # (the PMC passes set this: their per-kernel averages must hold B = 256 launches only)

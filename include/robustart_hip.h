@@ -54,7 +54,7 @@ enum {
  * its tap arrays from 16 to 32 entries and gained dst_pair_off / res_pair_off; several attack entries gained a per-row
  * sample-index pointer; round 4 -> 5: rart_stencil_fixed_point_info added).  A caller compiled against another header must refuse to run:
  * compare with rart_version(). */
-#define RART_ABI_VERSION 108
+#define RART_ABI_VERSION 109
 int rart_version(void);
 const char* rart_last_error_string(void);
 /* name of corruption id (static string), NULL if out of range */
@@ -181,6 +181,10 @@ int rart_rng_normal_f32(float* out, int n_samples, size_t elems_per_sample,
  * whole number of 1 KiB chunks; 0 = Threefry + Box-Muller everywhere.  rart_rng_noise_field_f32 replays the
  * N(0,1) field those two corruptions use under the current setting. */
 int rart_set_normal_generator(int kind);
+/* Measurement aid of bench.py (hbm_roofline_gaussian_noise): a plain device copy of `bytes` (multiple of 16, 16-byte aligned buffers) --
+ * variant 0: one 16-byte vector per lane, one wave per 1 KiB, the noise kernels' launch geometry; variant 1: a grid-stride loop over 1 024
+ * workgroups.  What a kernel that only moves a launch's bytes reaches at that size is the ceiling the noise kernels are read against. */
+int rart_copy_calibration(const void* in, void* out, size_t bytes, int variant, rart_stream_t stream);
 int rart_get_normal_generator(void);
 int rart_rng_noise_field_f32(float* out, int n_samples, size_t elems_per_sample, uint64_t seed,
                              uint64_t sample_offset, rart_stream_t stream);

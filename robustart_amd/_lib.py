@@ -13,7 +13,7 @@ c_void_p, c_int, c_size_t, c_u64, c_float = (ctypes.c_void_p, ctypes.c_int, ctyp
                                               ctypes.c_uint64, ctypes.c_float)
 c_double = ctypes.c_double
 
-ABI_VERSION = 108        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
+ABI_VERSION = 109        # == RART_ABI_VERSION of include/robustart_hip.h; load() refuses a library built from another header
 
 # name -> (restype, argtypes); every symbol include/robustart_hip.h declares
 SIGNATURES = {
@@ -109,6 +109,7 @@ SIGNATURES = {
     'rart_igemm_set_gemm256': (c_int, [c_int]),
     'rart_gemm256_supported': (c_int, [ctypes.c_longlong, c_int, c_int, c_int, c_int]),
     'rart_gemm_pair_bf16': (c_int, [c_void_p, c_void_p]),
+    'rart_copy_calibration': (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p]),
     'rart_gemm_pair_set_schedule': (c_int, [c_int]),
     'rart_gemm_pair_get_schedule': (c_int, []),
     'rart_pack_jobs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),

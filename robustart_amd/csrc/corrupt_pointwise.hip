@@ -732,6 +732,32 @@ __global__ __launch_bounds__(kBlock) void k_frost_textures(const uint8_t* __rest
 // 1 = matrix-core CLT generator for gaussian/speckle noise when a sample is a whole number of 1 KiB chunks
 // (default), 0 = Threefry + Box-Muller everywhere.  The generator is part of the (seed -> field) definition.
 static int g_normal_generator = 1;
+// ---- calibration (bench.py's hbm_roofline_gaussian_noise block): a PLAIN copy of n bytes in k_normal_noise_mfma's own geometry -- one wave
+//      per 1 KiB chunk, 16 bytes per lane (variant 0) -- and as a grid-stride loop over 1 024 workgroups (variant 1, the fastest plain copy
+//      of 77 MB measured on this part: scratch/r6/copy_probe.hip).  What a kernel that does NOTHING but move the launch's bytes reaches at
+//      this size is the ceiling the noise kernel is read against.
+namespace {
+__global__ __launch_bounds__(256) void k_copy_calib_chunk(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_copy_calib_stride(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+}  // namespace
+extern "C" int rart_copy_calibration(const void* in, void* out, size_t bytes, int variant, rart_stream_t stream) {
+  RART_CHECK_ARG(in && out && bytes % 16 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                 "rart_copy_calibration: 16-byte aligned buffers of a multiple of 16 bytes");
+  RART_CHECK_ARG(variant == 0 || variant == 1, "rart_copy_calibration: variant must be 0 (one vector per lane) or 1 (grid-stride)");
+  const size_t n16 = bytes / 16;
+  if (n16 == 0) return RART_OK;
+  RART_CHECK_ARG((n16 + 255) / 256 < (1ull << 31), "rart_copy_calibration: buffer too large");
+  if (variant == 0) hipLaunchKernelGGL(k_copy_calib_chunk, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, n16);
+  else hipLaunchKernelGGL(k_copy_calib_stride, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, n16);
+  RART_CHECK_LAUNCH("rart_copy_calibration");
+  return RART_OK;
+}
+
 extern "C" int rart_set_normal_generator(int kind) {
   if (kind != 0 && kind != 1) {
     rart_set_error("rart_set_normal_generator: kind must be 0 (Box-Muller) or 1 (matrix-core CLT)");
