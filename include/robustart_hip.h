@@ -406,7 +406,9 @@ int rart_conv_igemm_bf16(const rart_conv_desc* desc_host, rart_stream_t stream);
  * (default 1024); others the x32 pipeline with loads two K steps ahead. */
 int rart_igemm_set_bk64_min_k(long long k);
 /* Tuning knob: plain row-major products (one tap, unit strides, no batching, flags within GELU / GELU') with at least 512 tiles of
- * 256 x 256 run on the 8-wave 256 x 256 x 64 kernel with direct-to-LDS tiles (the transformer layers); 0 disables it. */
+ * 256 x 256 run on the 8-wave 256 x 256 x 64 kernel with direct-to-LDS tiles (the transformer layers): 2 (default) = on the ping-pong
+ * schedule of round 6 (k_gemm256_pp: the two halves of the workgroup alternate memory and matrix phases, counted vmcnt, vector-free
+ * buffer_load ... lds issue), 1 = on round 2's two-stage loop (bit-identical outputs), 0 disables the kernel. */
 /* Small-M product C[m][n] = A[m][k] . W[n][k]^T (+ bias[n]) for the classifier head and its backward (m = the batch): one workgroup per
  * 32 x 32 output tile, four waves split k (k % 64 == 0), fragments straight from global memory.  out: fp32 (out_is_f32) or bf16, leading
  * dimension ldo.  Replaces the 16-workgroup implicit-GEMM launch of the fc layer (RobustART/model -> public ResNet-50 `fc`). */

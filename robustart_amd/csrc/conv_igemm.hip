@@ -25,6 +25,7 @@
 // Most ResNet-50 layers are HBM-bound at bf16 (K = 64..512), so the kernel is built around wide coalesced traffic first
 // and MFMA issue second (DESIGN.md 4.3 has the measured breakdown).
 #include "rart_common.h"
+#include "rart_lds_dma.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -605,6 +606,84 @@ __device__ __attribute__((aligned(16))) const uint32_t g_gemm_zero16[4] = {0u, 0
 constexpr int G2_TM = 256, G2_TN = 256, G2_STAGE = (G2_TM + G2_TN) * 128, G2_LDE = 68;
 static_assert(8 * 32 * G2_LDE * 4 <= 2 * G2_STAGE, "epilogue staging must fit the tile buffers");
 
+// Epilogue of a 256 x 256 tile of the transformer GEMMs (k_gemm256_bf16 and its ping-pong form): per wave, 32 rows x 64 columns at a time
+// through LDS -> 128-byte row segments; residual / GELU operands of a pass are requested before its transposition.  `lds`: the tile buffers
+// (free after the K loop); must be called by every thread.
+__device__ __forceinline__ void g2_epilogue(const RartGemm256Desc& d, uint8_t* lds, f32x16 (&acc)[4][2], int m0, int n0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, h = lane >> 5;
+  float* sE = reinterpret_cast<float*>(lds) + wave * 32 * G2_LDE;
+  const int cw = lane & 7, rw = lane >> 3;
+  const int col = n0 + wn * 64 + cw * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint4 rv[4], mv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = m0 + wm * 128 + i * 32 + q * 8 + rw;
+      rv[q] = make_uint4(0, 0, 0, 0);
+      mv[q] = make_uint4(0, 0, 0, 0);
+      if (row < d.M) {
+        const size_t e = (size_t)row * d.ldc + col;
+        if (d.res) rv[q] = *reinterpret_cast<const uint4*>(d.res + e);
+        if (d.flags & F_GELU_BWD) mv[q] = *reinterpret_cast<const uint4*>(d.mask + e);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sE[((r & 3) + 8 * (r >> 2) + 4 * h) * G2_LDE + j * 32 + fr] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = q * 8 + rw, row = m0 + wm * 128 + i * 32 + r;
+      const float4 v0 = *reinterpret_cast<const float4*>(sE + r * G2_LDE + cw * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(sE + r * G2_LDE + cw * 8 + 4);
+      if (row < d.M) {
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const uint32_t rr[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
+        const uint32_t mw[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
+        if (d.res) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] += __uint_as_float(rr[j] << 16);
+            v[2 * j + 1] += __uint_as_float(rr[j] & 0xFFFF0000u);
+          }
+        }
+        if (d.flags & F_GELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        }
+        if (d.flags & F_GELU_KEEP) {
+          // two outputs: the bf16 pre-activation u (the backward's GELU' operand) goes to `mask`, dst receives gelu(u) of the ROUNDED u --
+          // bit-identical to writing u and running k_gelu over it, without the second pass over the hidden tensor
+          const uint4 up = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+          *reinterpret_cast<uint4*>(const_cast<uint16_t*>(d.mask) + (size_t)row * d.ldc + col) = up;
+          const uint32_t uw[4] = {up.x, up.y, up.z, up.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] = gelu_erf(__uint_as_float(uw[j] << 16));
+            v[2 * j + 1] = gelu_erf(__uint_as_float(uw[j] & 0xFFFF0000u));
+          }
+        }
+        if (d.flags & F_GELU_BWD) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] *= gelu_grad_erf(__uint_as_float(mw[j] << 16));
+            v[2 * j + 1] *= gelu_grad_erf(__uint_as_float(mw[j] & 0xFFFF0000u));
+          }
+        }
+        *reinterpret_cast<uint4*>(d.c + (size_t)row * d.ldc + col) =
+            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(512, 1) void k_gemm256_bf16(const RartGemm256Desc d) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * G2_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
@@ -678,78 +757,150 @@ __global__ __launch_bounds__(512, 1) void k_gemm256_bf16(const RartGemm256Desc d
   }
 #undef RART_G2_ISSUE
 #undef RART_G2_DL
-  // ---- epilogue: per wave, 32 rows x 64 columns at a time through LDS -> 128-byte row segments; residual / GELU operands of a
-  //      pass are requested before its transposition
-  float* sE = reinterpret_cast<float*>(lds) + wave * 32 * G2_LDE;
-  const int cw = lane & 7, rw = lane >> 3;
-  const int col = n0 + wn * 64 + cw * 8;
+  g2_epilogue(d, lds, acc, m0, n0);
+}
+
+// ---- the same GEMM on the PING-PONG schedule (round 6; csrc/gemm_pair_pp.hip has the derivation and the measurements that led to it):
+//      the tile loads cost k_gemm256_bf16 a third of its time although nothing waits for them (1 244-1 342 TFLOP/s without them, 880-900
+//      with) -- all eight waves issue their eight LDS-DMA loads together, ~2 000 cycles of texture-address time in front of 2 048 cycles of
+//      matrix work per SIMD.  Here the two wave groups (rows 0-127 / 128-255 of the tile; waves w and w + 4 share a SIMD) run one barrier
+//      interval apart through  M0 | C0 | M1 | C1  per 64-deep K step: while one group issues 16 MFMAs (s_setprio 1) the other reads its
+//      fragments and issues its share of the next stages' loads; the loads are buffer_load ... lds with ONE constant per-lane byte offset
+//      and a scalar K offset (no vector instruction on the issue path, rows past M zero-filled by the range check, rart_lds_dma.h); every
+//      8 KB region (a group's half of the A rows, half of a group's W rows) is refilled in the slot after its last reader's barrier and
+//      waited for with a counted vmcnt one barrier before its first reader.  Same products in the same order, same epilogue:
+//      BIT-IDENTICAL to k_gemm256_bf16 (tests/test_vit_gpu.py).
+__device__ __forceinline__ void g2_slot_end() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__global__ __launch_bounds__(512, 1) void k_gemm256_pp(const RartGemm256Desc d) {
+  constexpr int PLANE = G2_TM * 128;                      // the A rows of a stage, then the W rows: 32 KB each
+  constexpr int NB = 4;                                   // loads of a wave per memory phase: 2 W pieces + 2 A pieces
+  constexpr int VM_ALPHA = 3 * NB, VM_BETA = 2 + NB, VM_GAMMA = 2 + NB;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * G2_STAGE];
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+  const int g = wm, w4 = wn, og = 1 - g;
+  const int n_tiles = d.N / G2_TN;
+  const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+  const int m_tile = (slot / n_tiles) * 8 + xcd, n_tile = slot % n_tiles;
+  if (m_tile * G2_TM >= d.M) return;
+  const int m0 = m_tile * G2_TM, n0 = n_tile * G2_TN;
+  // ---- loader: a piece = 8 rows x 128 B (lane -> row lane >> 3, slot lane & 7 <- the row's chunk (lane & 7) ^ ((row >> 1) & 7)).  A wave
+  //      loads A rows of the OTHER group only: pieces 2 w4, 2 w4 + 1 of its two 64-row regions (q = 0: half `og`, refilled in M0; q = 1:
+  //      half `g`, refilled in M1), and W pieces 4 w4 .. 4 w4 + 3 of its OWN group's 128 W rows (the first two in M1, the last two in M0)
+  uint32_t av[2][2], wv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    uint4 rv[4], mv[4];
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = m0 + wm * 128 + i * 32 + q * 8 + rw;
-      rv[q] = make_uint4(0, 0, 0, 0);
-      mv[q] = make_uint4(0, 0, 0, 0);
-      if (row < d.M) {
-        const size_t e = (size_t)row * d.ldc + col;
-        if (d.res) rv[q] = *reinterpret_cast<const uint4*>(d.res + e);
-        if (d.flags & F_GELU_BWD) mv[q] = *reinterpret_cast<const uint4*>(d.mask + e);
-      }
+    for (int p = 0; p < 2; ++p) {
+      const int r = og * 128 + (q == 0 ? og : g) * 64 + 8 * (2 * w4 + p) + (lane >> 3);
+      const int csrc = (lane & 7) ^ ((r >> 1) & 7);
+      av[q][p] = (m0 + r < d.M) ? (uint32_t)(((m0 + r) * d.lda + csrc * 8) * 2) : RART_DMA_OOR;
     }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = g * 128 + 8 * (4 * w4 + p) + (lane >> 3);
+    const int csrc = (lane & 7) ^ ((r >> 1) & 7);
+    wv[p] = (uint32_t)(((n0 + r) * d.K + csrc * 8) * 2);
+  }
+  const rart_srd_t srd_a = rart_dma_srd(d.a), srd_w = rart_dma_srd(d.w);
+  const int KT = d.K / 64;
+#define RART_G2P_ISSUE_A(Q, ST)                                                                                  \
+  {                                                                                                              \
+    const int s_ = (ST);                                                                                         \
+    const uint32_t dst_ = lds_base + (s_ & 1) * G2_STAGE + (og * 128 + ((Q) == 0 ? og : g) * 64 + 16 * w4) * 128; \
+    rart_dma_load16(av[Q][0], srd_a, (uint32_t)s_ * 128u, dst_);                                                 \
+    rart_dma_load16(av[Q][1], srd_a, (uint32_t)s_ * 128u, dst_ + 1024);                                          \
+  }
+#define RART_G2P_ISSUE_W(ST, P0, P1)                                                                             \
+  {                                                                                                              \
+    const int s_ = (ST);                                                                                         \
+    const uint32_t dst_ = lds_base + (s_ & 1) * G2_STAGE + PLANE + (g * 128 + 32 * w4) * 128;                    \
+    _Pragma("unroll") for (int p = (P0); p < (P1); ++p) rart_dma_load16(wv[p], srd_w, (uint32_t)s_ * 128u, dst_ + p * 1024); \
+  }
+  const int fr = lane & 31, h = lane >> 5;
+  uint32_t xo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xo[ks] = (uint32_t)(fr * 128 + (((2 * ks + h) ^ ((fr >> 1) & 7)) << 4));
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float bv = d.bias ? d.bias[n0 + wn * 64 + j * 32 + fr] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+  }
+  // ---- prologue: stage 0 whole, stage 1 except what the first M0 phases issue
+  RART_G2P_ISSUE_W(0, 0, 4)
+  RART_G2P_ISSUE_A(0, 0)
+  RART_G2P_ISSUE_A(1, 0)
+  if (KT > 1) {
+    RART_G2P_ISSUE_W(1, 0, 2)
+    RART_G2P_ISSUE_A(1, 1)
+    if (g) RART_G2P_ISSUE_A(0, 1)
+  }
+  rart_dma_wait<0>();
+  __syncthreads();
+  if (g) g2_slot_end();                     // the stagger: group 1 runs one slot behind group 0
+  bf16x8 af[2][4], bfr[2][4];
+#define RART_G2P_READ_A(HALF)                                                                                    \
+  _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)             \
+      af[ii][ks] = *reinterpret_cast<const bf16x8*>(Ab + ((HALF)*2 + ii) * 32 * 128 + xo[ks]);
+#define RART_G2P_MFMA(HALF)                                                                                      \
+  __builtin_amdgcn_s_setprio(1);                                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)             \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+          acc[(HALF)*2 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][ks], bfr[j][ks], acc[(HALF)*2 + ii][j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    const uint8_t* const Ab = lds + (kt & 1) * G2_STAGE + wm * 128 * 128;
+    const uint8_t* const Bb = lds + (kt & 1) * G2_STAGE + PLANE + wn * 64 * 128;
+    const int tail = kt + 2 >= KT;          // some refill of this K step is skipped: the counts below do not hold, drain instead
+    // ---- M0
+    if (kt + 1 < KT) RART_G2P_ISSUE_W(kt + 1, 2, 4)
+    if (kt + 1 + g < KT) RART_G2P_ISSUE_A(0, kt + 1 + g)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sE[((r & 3) + 8 * (r >> 2) + 4 * h) * G2_LDE + j * 32 + fr] = acc[i][j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = q * 8 + rw, row = m0 + wm * 128 + i * 32 + r;
-      const float4 v0 = *reinterpret_cast<const float4*>(sE + r * G2_LDE + cw * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(sE + r * G2_LDE + cw * 8 + 4);
-      if (row < d.M) {
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        const uint32_t rr[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
-        const uint32_t mw[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
-        if (d.res) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[2 * j] += __uint_as_float(rr[j] << 16);
-            v[2 * j + 1] += __uint_as_float(rr[j] & 0xFFFF0000u);
-          }
-        }
-        if (d.flags & F_GELU) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-        }
-        if (d.flags & F_GELU_KEEP) {
-          // two outputs: the bf16 pre-activation u (the backward's GELU' operand) goes to `mask`, dst receives gelu(u) of the ROUNDED u --
-          // bit-identical to writing u and running k_gelu over it, without the second pass over the hidden tensor
-          const uint4 up = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-          *reinterpret_cast<uint4*>(const_cast<uint16_t*>(d.mask) + (size_t)row * d.ldc + col) = up;
-          const uint32_t uw[4] = {up.x, up.y, up.z, up.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[2 * j] = gelu_erf(__uint_as_float(uw[j] << 16));
-            v[2 * j + 1] = gelu_erf(__uint_as_float(uw[j] & 0xFFFF0000u));
-          }
-        }
-        if (d.flags & F_GELU_BWD) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[2 * j] *= gelu_grad_erf(__uint_as_float(mw[j] << 16));
-            v[2 * j + 1] *= gelu_grad_erf(__uint_as_float(mw[j] & 0xFFFF0000u));
-          }
-        }
-        *reinterpret_cast<uint4*>(d.c + (size_t)row * d.ldc + col) =
-            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-      }
+      for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * 128 + xo[ks]);
+    RART_G2P_READ_A(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    g2_slot_end();
+    // ---- C0
+    RART_G2P_MFMA(0)
+    g2_slot_end();
+    // ---- M1
+    if (kt + 2 < KT) {
+      RART_G2P_ISSUE_W(kt + 2, 0, 2)
+      RART_G2P_ISSUE_A(1, kt + 2)
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    RART_G2P_READ_A(1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tail) rart_dma_wait<0>();
+    else if (g) rart_dma_wait<VM_GAMMA>();
+    else rart_dma_wait<VM_ALPHA>();
+    g2_slot_end();
+    // ---- C1
+    RART_G2P_MFMA(1)
+    if (!g) {
+      if (tail) rart_dma_wait<0>(); else rart_dma_wait<VM_BETA>();
+    }
+    g2_slot_end();
   }
+  if (!g) g2_slot_end();                    // group 0's closing barrier pairs with group 1's last one
+#undef RART_G2P_MFMA
+#undef RART_G2P_READ_A
+#undef RART_G2P_ISSUE_W
+#undef RART_G2P_ISSUE_A
+  rart_dma_wait<0>();
+  __syncthreads();
+  g2_epilogue(d, lds, acc, m0, n0);
 }
 }  // namespace
 
@@ -760,10 +911,11 @@ extern "C" int rart_igemm_set_bk64_min_k(long long k) {
   return RART_OK;
 }
 
-// tuning knob (tests / profiling): 0 keeps every problem on the 128 x 128 kernel
-static int g_gemm256_enabled = 1;
+// tuning knob (tests / profiling): 0 keeps every problem on the 128 x 128 kernel, 1 = the 256 x 256 x 64 kernel on round 2's two-stage loop,
+// 2 (default) = the same kernel on the ping-pong schedule of round 6 (bit-identical outputs)
+static int g_gemm256_enabled = 2;
 extern "C" int rart_igemm_set_gemm256(int enable) {
-  g_gemm256_enabled = enable ? 1 : 0;
+  g_gemm256_enabled = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   return RART_OK;
 }
 
@@ -810,7 +962,10 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
       g.mask = (const uint16_t*)h->mask; g.c = (uint16_t*)h->dst;
       g.M = (int)gm; g.N = h->n_cols; g.K = h->k_per_tap; g.lda = h->src_pix_stride; g.ldc = h->dst_pix_stride; g.flags = h->flags;
       const int m_tiles = (int)((gm + G2_TM - 1) / G2_TM), m8 = (m_tiles + 7) / 8 * 8;
-      hipLaunchKernelGGL(k_gemm256_bf16, dim3((uint32_t)(m8 * (g.N / G2_TN))), dim3(512), 0, (hipStream_t)stream, g);
+      // the ping-pong form addresses its operands with 32-bit byte offsets (planes below 2 GiB: gemm256_takes checked 2^31 ELEMENTS)
+      const bool pp = g_gemm256_enabled == 2 && gm * h->src_pix_stride < (1ll << 30) && (long long)g.N * g.K < (1ll << 30);
+      if (pp) hipLaunchKernelGGL(k_gemm256_pp, dim3((uint32_t)(m8 * (g.N / G2_TN))), dim3(512), 0, (hipStream_t)stream, g);
+      else hipLaunchKernelGGL(k_gemm256_bf16, dim3((uint32_t)(m8 * (g.N / G2_TN))), dim3(512), 0, (hipStream_t)stream, g);
       RART_CHECK_LAUNCH("rart_conv_igemm_bf16 (256 x 256 GEMM)");
       return RART_OK;
     }
