@@ -134,6 +134,37 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// Per-thread row of the A tile for the buffer loads of k_conv_igemm_bf16: vo = byte offset of the row's pixel at tap (0, 0) inside a source
+// plane (+ the thread's 16-byte chunk), nok = one bit per tap whose source pixel lies outside the image (all taps for a row past M).
+template <class D>
+__device__ __forceinline__ void row_setup(uint32_t m, uint32_t M, const D& d, int chunk_bytes, uint32_t& vo, uint32_t& nok) {
+  const bool ok = m < M;
+  const uint32_t mm = ok ? m : 0u;
+  const uint32_t t = fastdiv(mm, d.gw_magic, d.gw_shift);
+  const int ox = (int)(mm - t * (uint32_t)d.grid_w);
+  const int n = (int)fastdiv(t, d.gh_magic, d.gh_shift);
+  const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
+  const int by = oy * d.sy, bx = ox * d.sx;
+  vo = (uint32_t)(((n * d.src_h * d.src_w + by * d.src_w + bx) * d.src_pix_stride) * 2 + chunk_bytes);
+  nok = 0u;
+  for (int t2 = 0; t2 < d.n_taps; ++t2) {
+    const int iy = by + d.tap_dy[t2], ix = bx + d.tap_dx[t2];
+    if (!(ok && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w)) nok |= 1u << t2;
+  }
+}
+// The buffer resource of tap `tap`: the source plane shifted by the tap's pixel offset and its plane offset (64-bit, scalar; it may point
+// before the tensor: only lanes whose pixel is inside the image are in range)
+template <class D>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tap_rsrc(const uint16_t* p_src, const D& d, int tap) {
+  const uint16_t* base = p_src + d.tap_src_off[tap] + (long long)(d.tap_dy[tap] * d.src_w + d.tap_dx[tap]) * d.src_pix_stride;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+typedef unsigned int igemm_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  const igemm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // BK = 32: two register sets, loads two K steps ahead (memory-latency-bound 1x1 layers, 3 blocks/CU).
 // BK = 64: one register set, loads one (twice as long) K step ahead, half the barriers per FLOP
 //          (compute-bound 3x3 layers and transformer GEMMs; 73 KB of LDS -> 2 blocks/CU).
@@ -191,23 +222,15 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   const int n0 = n_tile * BN;
 
   // ---- per-thread gather rows (2 rows of the A tile) ----
+  // Round 6 (rart_lds_dma.h has the measurement): the tile loads are buffer loads -- a row's byte offset inside the source plane is ONE
+  // constant per thread (voffset), the tap moves the resource BASE (scalar), the K slice the scalar offset; a pixel outside the image
+  // for tap t has bit t of the row's `nok` mask set and its offset ORed with RART_DMA_OOR, which the range check zero-fills.  Rounds 1-5
+  // formed a 64-bit address per row and K step with ~12 vector instructions (bounds compares, multiply-adds, select): with two or three
+  // workgroups per CU they competed with the other workgroups' MFMAs for the SIMD's vector issue.
   const int chunk = tid & 3;  // which 16 B of the 64 B K-slice
-  int a_by[2], a_bx[2];
-  int a_img[2];   // pixel index of the image origin (host guarantees every tensor is < 2^31 elements)
-  bool a_ok[2];
+  uint32_t a_vo[2], a_nok[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const uint32_t m = m0 + (tid >> 2) + 64 * i;
-    a_ok[i] = m < M;
-    const uint32_t mm = a_ok[i] ? m : 0u;
-    const uint32_t t = fastdiv(mm, d.gw_magic, d.gw_shift);
-    const int ox = (int)(mm - t * (uint32_t)d.grid_w);
-    const int n = (int)fastdiv(t, d.gh_magic, d.gh_shift);
-    const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
-    a_by[i] = oy * d.sy;
-    a_bx[i] = ox * d.sx;
-    a_img[i] = n * d.src_h * d.src_w;
-  }
+  for (int i = 0; i < 2; ++i) row_setup((uint32_t)(m0 + (tid >> 2) + 64 * i), M, d, chunk * 16, a_vo[i], a_nok[i]);
   if (tid < BM) {
     const uint32_t m = m0 + tid;
     uint32_t off = 0xFFFFFFFFu;
@@ -226,6 +249,7 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   const int WRS = d.wgt_row_stride > 0 ? d.wgt_row_stride : K;   // weight row stride in elements
   const int KT = K / BK;
   const int tiles_per_tap = d.k_per_tap / BK;
+  const __amdgpu_buffer_rsrc_t w_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p_wgt), 0, 0x7FFFFFFF, 0x00020000);
 
   // accumulators start at the bias of their column (lane & 31 is the column of a 32x32 MFMA tile): the
   // epilogue then has no bias pass
@@ -259,30 +283,23 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
   // Two register sets: global loads run TWO K steps ahead of the MFMAs (the K step of a 1x1 layer is far
   // shorter than an HBM round trip, so one step of cover leaves the kernel latency-bound at 3 blocks/CU).
   // Written as macros over named register arrays so every index is static (no scratch).
+  uint32_t w_vo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + (tid >> 2) + 64 * i;
+    w_vo[i] = n < d.n_cols ? (uint32_t)((n * WRS + chunk * 8) * 2) : RART_DMA_OOR;        // rows past the table: zeros (they only reach columns never stored)
+  }
   uint4 ra0_0, ra0_1, ra1_0, ra1_1, rb0_0, rb0_1, rb1_0, rb1_1;   // set{0,1} x chunk{0,1}; explicit scalars
   rb0_1 = rb1_1 = make_uint4(0, 0, 0, 0);
   ra1_0 = ra1_1 = rb1_0 = make_uint4(0, 0, 0, 0);
-#define RART_LOAD_A(I, DST)                                                                                     \
-  {                                                                                                             \
-    const int iy = a_by[I] + dy, ix = a_bx[I] + dx;                                                             \
-    const bool ok = a_ok[I] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w;            \
-    const uint32_t eoff = (uint32_t)((a_img[I] + iy * d.src_w + ix) * d.src_pix_stride + kc);                   \
-    uint4 v = make_uint4(0, 0, 0, 0);                                                                           \
-    if (ok) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase) + (size_t)(eoff * 2u));    \
-    DST = v;                                                                                                    \
-  }
-#define RART_LOAD_B(I, DST)                                                                                     \
-  {                                                                                                             \
-    const uint32_t woff = (uint32_t)((n0 + (tid >> 2) + 64 * (I)) * WRS + kt_ * BK + chunk * 8);                  \
-    DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_wgt) + (size_t)(woff * 2u));         \
-  }
+#define RART_LOAD_A(I, DST) DST = buf_load16(srd_, a_vo[I] | ((uint32_t)__builtin_amdgcn_sbfe(a_nok[I], tap, 1) & RART_DMA_OOR), kc_);
+#define RART_LOAD_B(I, DST) DST = buf_load16(w_srd, w_vo[I], (uint32_t)(kt_ * BK * 2));
 #define RART_LOAD_TILE(KT_, SET)                                                                                \
   {                                                                                                             \
     const int kt_ = (KT_);                                                                                      \
-    const int tap = (int)fastdiv((uint32_t)kt_, d.tpt_magic, d.tpt_shift);                                                                        \
-    const int kc = (kt_ - tap * tiles_per_tap) * BK + chunk * 8;                                                \
-    const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];                                                           \
-    const uint16_t* sbase = p_src + d.tap_src_off[tap];                                                         \
+    const int tap = (int)fastdiv((uint32_t)kt_, d.tpt_magic, d.tpt_shift);                                      \
+    const uint32_t kc_ = (uint32_t)((kt_ - tap * tiles_per_tap) * BK * 2);                                      \
+    const __amdgpu_buffer_rsrc_t srd_ = tap_rsrc(p_src, d, tap);                                                \
     RART_LOAD_A(0, ra##SET##_0)                                                                                 \
     RART_LOAD_A(1, ra##SET##_1)                                                                                 \
     RART_LOAD_B(0, rb##SET##_0)                                                                                 \
@@ -320,44 +337,24 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
     // ---- BK = 64 pipeline: 8 chunks per row, 32 rows per pass ----
     constexpr int NA = BM / 32, NB = BN / 32;
     const int chunk8 = tid & 7, prow = tid >> 3;
-    int b_by[NA], b_bx[NA], b_img[NA];
-    bool b_ok[NA];
+    uint32_t b_vo[NA], b_nok[NA], w_vo[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const uint32_t m = m0 + prow + 32 * i;
-      b_ok[i] = m < M;
-      const uint32_t mm = b_ok[i] ? m : 0u;
-      const uint32_t t = fastdiv(mm, d.gw_magic, d.gw_shift);
-      const int ox = (int)(mm - t * (uint32_t)d.grid_w);
-      const int n = (int)fastdiv(t, d.gh_magic, d.gh_shift);
-      const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
-      b_by[i] = oy * d.sy;
-      b_bx[i] = ox * d.sx;
-      b_img[i] = n * d.src_h * d.src_w;
+    for (int i = 0; i < NA; ++i) row_setup((uint32_t)(m0 + prow + 32 * i), M, d, chunk8 * 16, b_vo[i], b_nok[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int n = n0 + prow + 32 * i;
+      w_vo[i] = n < d.n_cols ? (uint32_t)((n * WRS + chunk8 * 8) * 2) : RART_DMA_OOR;
     }
     uint4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;   // explicit scalars: uint4 arrays of 4 end up in scratch here
     qb2 = qb3 = make_uint4(0, 0, 0, 0);
-#define RART_LD64_A(I, DST)                                                                                     \
-  {                                                                                                             \
-    const int iy = b_by[I] + dy, ix = b_bx[I] + dx;                                                             \
-    const bool ok = b_ok[I] && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w;            \
-    const uint32_t eoff = (uint32_t)((b_img[I] + iy * d.src_w + ix) * d.src_pix_stride + kc);                   \
-    uint4 v = make_uint4(0, 0, 0, 0);                                                                           \
-    if (ok) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase) + (size_t)(eoff * 2u));    \
-    DST = v;                                                                                                    \
-  }
-#define RART_LD64_B(I, DST)                                                                                     \
-  {                                                                                                             \
-    const uint32_t woff = (uint32_t)((n0 + prow + 32 * (I)) * WRS + kt_ * BK + chunk8 * 8);                     \
-    DST = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p_wgt) + (size_t)(woff * 2u));         \
-  }
+#define RART_LD64_A(I, DST) DST = buf_load16(srd_, b_vo[I] | ((uint32_t)__builtin_amdgcn_sbfe(b_nok[I], tap, 1) & RART_DMA_OOR), kc_);
+#define RART_LD64_B(I, DST) DST = buf_load16(w_srd, w_vo[I], (uint32_t)(kt_ * BK * 2));
 #define RART_LOAD64(KT_)                                                                                        \
   {                                                                                                             \
     const int kt_ = (KT_);                                                                                      \
-    const int tap = (int)fastdiv((uint32_t)kt_, d.tpt_magic, d.tpt_shift);                                                                        \
-    const int kc = (kt_ - tap * tiles_per_tap) * BK + chunk8 * 8;                                               \
-    const int dy = d.tap_dy[tap], dx = d.tap_dx[tap];                                                           \
-    const uint16_t* sbase = p_src + d.tap_src_off[tap];                                                         \
+    const int tap = (int)fastdiv((uint32_t)kt_, d.tpt_magic, d.tpt_shift);                                      \
+    const uint32_t kc_ = (uint32_t)((kt_ - tap * tiles_per_tap) * BK * 2);                                      \
+    const __amdgpu_buffer_rsrc_t srd_ = tap_rsrc(p_src, d, tap);                                                \
     RART_LD64_A(0, qa0) RART_LD64_A(1, qa1) RART_LD64_A(2, qa2) RART_LD64_A(3, qa3)                             \
     RART_LD64_B(0, qb0) RART_LD64_B(1, qb1)                                                                     \
     if constexpr (NB > 2) { RART_LD64_B(2, qb2) RART_LD64_B(3, qb3) }                                           \
@@ -1022,8 +1019,13 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
   const long long src_elems = (long long)d.batch * d.src_h * d.src_w * d.src_pix_stride;
   const long long dst_elems = (long long)d.batch * d.dst_h * d.dst_w * d.dst_pix_stride;
   RART_CHECK_ARG(M < (1ll << 31), "rart_conv_igemm_bf16: row grid must stay below 2^31 rows");
-  RART_CHECK_ARG(src_elems < (1ll << 31) && dst_elems < (1ll << 31),
-                 "rart_conv_igemm_bf16: tensors must stay below 2^31 elements (split the batch)");
+  RART_CHECK_ARG(src_elems < (1ll << 30) && dst_elems < (1ll << 31),
+                 "rart_conv_igemm_bf16: a source plane must stay below 2 GiB (32-bit byte offsets of the buffer loads) and the destination below "
+                 "2^31 elements (split the batch)");
+  {
+    const long long w_elems = (long long)d.n_cols * (d.wgt_row_stride > 0 ? d.wgt_row_stride : (long long)d.k_per_tap * d.n_taps);
+    RART_CHECK_ARG(w_elems < (1ll << 30), "rart_conv_igemm_bf16: the weight table must stay below 2 GiB");
+  }
   const int m_tiles = (int)((M + BM - 1) / BM);
   const bool wide = d.n_cols > 64;
   const int bn = wide ? 128 : 64;
