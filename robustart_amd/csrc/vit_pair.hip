@@ -283,6 +283,11 @@ __global__ __launch_bounds__(kBlock) void k_unpatchify_from_f32(const float* __r
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int PATT_HD = 64, PATT_LDK = PATT_HD + 8;
+// Round 6: EIGHT waves per workgroup (512 threads) instead of four.  The LDS images keep these kernels at one workgroup per CU, so with four
+// waves every SIMD held ONE wave -- nothing ran beside its soft-max VALU work, its LDS gathers or its K / V staging, the matrix pipes were
+// busy 12-13 % of a launch (profiles/r05_x3_counters.json) -- and the seven 32-query tiles of ViT-B/16's 197 tokens took two rounds over
+// four waves.  With eight waves the seven tiles run in one round, two waves per SIMD, and one wave's MFMAs cover the other's vector work.
+constexpr int kAttBlock = 512;
 
 // (Round 5: the persistent form of k_vit_attention -- next item's K / V / Q of both planes prefetched into registers -- does not fit here: 112 score
 //  registers + 32 output + 64-96 of prefetch exceed the 256 a 7-wave workgroup has (98-132 VGPRs spilled); a split commit -- K after S = K Q^T, V at the
@@ -290,7 +295,7 @@ constexpr int PATT_HD = 64, PATT_LDK = PATT_HD + 8;
 //  score registers apart for the whole item.  What is left for this kernel (5 % of a reference-precision ViT-B/16 gradient evaluation) is a prefetch
 //  through LDS, i.e. K / V tiles small enough for two buffers.)
 template <int NKT>
-__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+__global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
                                                                   uint16_t* __restrict__ att_h, uint16_t* __restrict__ att_l, int T, int H,
                                                                   int ld, int D, float scale_log2e) {
   constexpr int TP = NKT * 32, LDV = TP + 4;     // 228-element rows: conflict-free 8-byte reads across 32 lanes
@@ -302,14 +307,14 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_pair(const uint16_t
   const uint16_t* const base[2] = {qkv_h + boff, qkv_l + boff};
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    for (int i = tid; i < TP * 8; i += kBlock) {                       // K rows: 16-byte chunks, coalesced
+    for (int i = tid; i < TP * 8; i += kAttBlock) {                       // K rows: 16-byte chunks, coalesced
       const int t = i >> 3, c = i & 7;
       uint4 kv = make_uint4(0, 0, 0, 0);
       if (t < T) kv = *reinterpret_cast<const uint4*>(base[p] + (size_t)t * ld + D + c * 8);
       *reinterpret_cast<uint4*>(&sK[p][t * PATT_LDK + c * 8]) = kv;
     }
     // V transposed: a thread takes 8 channels of FOUR consecutive tokens and writes eight 8-byte runs (one per channel)
-    for (int i = tid; i < (TP / 4) * 8; i += kBlock) {
+    for (int i = tid; i < (TP / 4) * 8; i += kAttBlock) {
       const int tq = i % (TP / 4), c = i / (TP / 4);
       uint32_t w[4][4];
 #pragma unroll
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_pair(const uint16_t
     }
   }
   __syncthreads();
-  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
+  for (int qt = wave; qt < NKT; qt += kAttBlock / 64) {
     const int q = qt * 32 + l31;
     bf16x8 bqh[4], bql[4];
 #pragma unroll
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_pair(const uint16_t
 // Every contraction is three MFMA products; the soft-max and its derivative are evaluated in fp32 registers.  Replaces, per layer, the
 // decomposition into five batched pair products with fp32 score-sized temporaries, two soft-max row kernels and ten transposes.
 __device__ __forceinline__ void patt_load_rows(uint16_t* s, const uint16_t* g, int T, int TP, int ld, int tid) {
-  for (int i = tid; i < TP * 8; i += kBlock) {                         // [t][72]: 16-byte chunks, coalesced
+  for (int i = tid; i < TP * 8; i += kAttBlock) {                         // [t][72]: 16-byte chunks, coalesced
     const int t = i >> 3, c = i & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (t < T) v = *reinterpret_cast<const uint4*>(g + (size_t)t * ld + c * 8);
@@ -467,7 +472,7 @@ __device__ __forceinline__ void patt_split8(const float* v, bf16x8& hi, bf16x8& 
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, ACC, 0, 0, 0);
 
 template <int NKT>
-__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd_q_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+__global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
                                                                         const uint16_t* __restrict__ o_h, const uint16_t* __restrict__ o_l,
                                                                         const uint16_t* __restrict__ do_h, const uint16_t* __restrict__ do_l,
                                                                         uint16_t* __restrict__ dq_h, uint16_t* __restrict__ dq_l,
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd_q_pair(const ui
     patt_load_rows(sV[p], qb[p] + 2 * D, T, TP, ld, tid);
   }
   __syncthreads();
-  for (int qt = wave; qt < NKT; qt += kBlock / 64) {
+  for (int qt = wave; qt < NKT; qt += kAttBlock / 64) {
     const int q = qt * 32 + l31;
     bf16x8 bq[2][4], bdo[2][4];
 #pragma unroll
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd_q_pair(const ui
 }
 
 template <int NKT>
-__global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd_kv_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+__global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_kv_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
                                                                          const uint16_t* __restrict__ do_h, const uint16_t* __restrict__ do_l,
                                                                          uint16_t* __restrict__ dq_h, uint16_t* __restrict__ dq_l,
                                                                          const float4* __restrict__ stats, int T, int H, int ld, int D, float scale,
@@ -620,9 +625,9 @@ __global__ __launch_bounds__(kBlock, 1) void k_vit_attention_bwd_kv_pair(const u
     patt_load_rows(sQ[p], qb[p], T, TP, ld, tid);
     patt_load_rows(sdO[p], db[p], T, TP, D, tid);
   }
-  for (int i = tid; i < TP; i += kBlock) sStat[i] = stats[(size_t)blockIdx.x * TP + i];
+  for (int i = tid; i < TP; i += kAttBlock) sStat[i] = stats[(size_t)blockIdx.x * TP + i];
   __syncthreads();
-  for (int kt = wave; kt < NKT; kt += kBlock / 64) {
+  for (int kt = wave; kt < NKT; kt += kAttBlock / 64) {
     const int key = kt * 32 + l31;
     const bool key_ok = key < T;
     bf16x8 bk[2][4], bv[2][4];
@@ -798,11 +803,11 @@ int rart_vit_attention_pair(const void* qkv_hi, const void* qkv_lo, void* out_hi
   const float scale_log2e = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
   const dim3 grid((uint32_t)(n * heads));
   hipStream_t st = (hipStream_t)stream;
-#define RART_PATT_CASE(N) case N: hipLaunchKernelGGL(k_vit_attention_pair<N>, grid, dim3(kBlock), 0, st, (const uint16_t*)qkv_hi, \
+#define RART_PATT_CASE(N) case N: hipLaunchKernelGGL(k_vit_attention_pair<N>, grid, dim3(kAttBlock), 0, st, (const uint16_t*)qkv_hi, \
     (const uint16_t*)qkv_lo, (uint16_t*)out_hi, (uint16_t*)out_lo, tokens, heads, 3 * D, D, scale_log2e); break;
   switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
     RART_PATT_CASE(1) RART_PATT_CASE(2) RART_PATT_CASE(3) RART_PATT_CASE(4) RART_PATT_CASE(5) RART_PATT_CASE(6)
-    default: hipLaunchKernelGGL(k_vit_attention_pair<7>, grid, dim3(kBlock), 0, st, (const uint16_t*)qkv_hi, (const uint16_t*)qkv_lo,
+    default: hipLaunchKernelGGL(k_vit_attention_pair<7>, grid, dim3(kAttBlock), 0, st, (const uint16_t*)qkv_hi, (const uint16_t*)qkv_lo,
                                 (uint16_t*)out_hi, (uint16_t*)out_lo, tokens, heads, 3 * D, D, scale_log2e); break;
   }
 #undef RART_PATT_CASE
@@ -826,9 +831,9 @@ int rart_vit_attention_bwd_pair(const void* qkv_hi, const void* qkv_lo, const vo
   uint16_t *gh = (uint16_t*)dqkv_hi, *gl = (uint16_t*)dqkv_lo;
   float4* s4 = (float4*)stats;
 #define RART_PATTB_CASE(N)                                                                                                              \
-  hipLaunchKernelGGL(k_vit_attention_bwd_q_pair<N>, grid, dim3(kBlock), 0, st, qh, ql, oh, ol, dh, dl, gh, gl, s4, tokens, heads, 3 * D, D, \
+  hipLaunchKernelGGL(k_vit_attention_bwd_q_pair<N>, grid, dim3(kAttBlock), 0, st, qh, ql, oh, ol, dh, dl, gh, gl, s4, tokens, heads, 3 * D, D, \
                      scale, sl2e);                                                                                                      \
-  hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair<N>, grid, dim3(kBlock), 0, st, qh, ql, dh, dl, gh, gl, (const float4*)s4, tokens, heads,  \
+  hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair<N>, grid, dim3(kAttBlock), 0, st, qh, ql, dh, dl, gh, gl, (const float4*)s4, tokens, heads,  \
                      3 * D, D, scale, sl2e);
   switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
     case 1: RART_PATTB_CASE(1) break;
