@@ -376,6 +376,16 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
       return RART_OK;
     }
   }
+  d.stagger_wgs = d.stagger_unit = 0;
+  {
+    static const double scale = getenv("RART_PP_STAGGER") ? atof(getenv("RART_PP_STAGGER")) : 0.0;
+    static const int min_rounds = getenv("RART_PP_STAGGER_ROUNDS") ? atoi(getenv("RART_PP_STAGGER_ROUNDS")) : 4;
+    const int cus = gp_cu_count();
+    if (scale > 0 && tm == 256 && blocks * nz >= (long long)min_rounds * cus) {
+      d.stagger_wgs = cus;
+      d.stagger_unit = (int)(scale * (d.K / GP_BK) * 900.0);
+    }
+  }
   if (tm == 256 && tn >= 128 && gp_schedule() >= 1 && rart_gemm_pair_pp_launch(&d, tn, conv, grid.x, grid.y, st)) {
     RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (ping-pong)");
     return RART_OK;

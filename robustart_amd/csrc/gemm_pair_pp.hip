@@ -50,6 +50,7 @@ __device__ __forceinline__ void pp_slot_end() {      // phase boundary: nothing 
 // rart_debug_pp_stamps, an export that exists in that build alone); -DRART_PP_KO_* knock one component out of the K loop.
 #ifdef RART_PP_STAMPS
 __device__ unsigned long long g_pp_stamps[2][16];
+__device__ unsigned long long g_pp_trace[4096][4];       // per workgroup (blockIdx.x < 4096): entry, K loop end, exit (s_memtime), HW_ID | XCC_ID << 32
 #define PP_T(V) const unsigned long long V = __builtin_amdgcn_s_memtime();
 #define PP_ACC(I, A, B) st_acc[I] += (B) - (A);
 #else
@@ -107,6 +108,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
     n_tile = blockIdx.x - m_tile * n_tiles;
   }
   const int m0 = m_tile * TM, n0 = n_tile * TN;
+  if (d.stagger_unit > 0 && (int)blockIdx.x < d.stagger_wgs && blockIdx.y == 0) {
+    const int ph = (blockIdx.x >> 3) & 3;
+    if (ph) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime(), dt = (unsigned long long)ph * (unsigned)d.stagger_unit;
+      while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(32);
+    }
+  }
 
   // ---- loader.  A wave only ever loads A rows of the OTHER group: piece w4 (16 rows) of its two 64-row regions -- q = 0: the region it
   //      refills in M0 (half `og` of group og), q = 1: the one it refills in M1 (half `g` of group og) -- and WQ pieces of ONE W plane
@@ -328,6 +336,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
     atomicAdd(&g_pp_stamps[g][13], t_loop0 - t_entry);      // prologue
     atomicAdd(&g_pp_stamps[g][14], t_exit - t_loop1);       // closing barrier + epilogue
     atomicAdd(&g_pp_stamps[g][15], 1ull);                   // workgroups
+  }
+  if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+    g_pp_trace[blockIdx.x][0] = t_entry; g_pp_trace[blockIdx.x][1] = t_loop1; g_pp_trace[blockIdx.x][2] = t_exit;
+    g_pp_trace[blockIdx.x][3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
   }
 #endif
 }
@@ -679,6 +691,10 @@ __attribute__((visibility("hidden"))) void rart_gemm_pair_ps_launch(const void* 
 }
 
 #ifdef RART_PP_STAMPS
+extern "C" int rart_debug_pp_trace(unsigned long long* out) {      // lab build only: out[4096][4] <- the per-workgroup trace of the last launch
+  if (hipDeviceSynchronize() != hipSuccess) return RART_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_trace), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? RART_OK : RART_ERR_HIP;
+}
 // lab build only: out[2][16] <- the stamp sums (cycles; [g][12] = K steps summed over workgroups), then cleared
 extern "C" int rart_debug_pp_stamps(unsigned long long* out) {
   if (hipDeviceSynchronize() != hipSuccess) return RART_ERR_HIP;

@@ -30,6 +30,7 @@ struct GemmPairDev {
   uint32_t gw_magic, gw_shift, gh_magic, gh_shift;      // exact division by multiply-shift for dividends < 2^31
   const uint8_t* mask_bits;                              // 1 bit per destination element (byte (off + col) / 8): v = 0 where clear
   uint8_t* sign_out;                                     // receives (output hi plane > 0), same indexing
+  int stagger_wgs, stagger_unit;                         // ping-pong kernel: the first stagger_wgs workgroups start phase * unit cycles late
 };
 __device__ __forceinline__ uint32_t gp_fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
@@ -41,11 +42,36 @@ __device__ __forceinline__ uint32_t gp_pack_bf16x2(float lo, float hi) {   // ro
   f2_t f = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2_t));
 }
-// exact (erf) GELU, timm's nn.GELU default; libm's erff (~1 ulp): this path is the reference-precision one
-__device__ __forceinline__ float gp_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// exact (erf) GELU, timm's nn.GELU default, at fp32 accuracy without libm's erff.  Round 6: the per-workgroup trace of the ping-pong
+// kernel (scratch/r6/vit_pp_trace.py) put the epilogue of ViT's fc1 tiles at 50 k cycles (forward, GELU) and 74 k (backward, GELU') against
+// 15 k for a plain tile and 95 k for the whole K loop -- erff (and expf) of libm are ~45 instructions with divergent range branches, 128
+// elements per lane, two waves per SIMD.  Here: 0.5 erfc(x) = t q(t) exp(-x^2), t = 1 / (1 + x / 2), q a degree-7 polynomial fitted over
+// x in [0, 6.6] (scratch/r6/fit_gelu_erfc.py: |erfc error| <= 2.5e-10 before rounding); Phi(u) = 0.5 erfc(|x|) for u < 0 -- no
+// cancellation in the tail -- and 1 - that for u >= 0.  In fp32 against fp64 over [-12, 12]: gelu max |error| 3.8e-7 (the libm form
+// 4.5e-7), relative L2 1.18e-8 (1.31e-8); gelu' max |error| 2.1e-7 (1.4e-7).  The exponential is shared with gelu'.
+__device__ __forceinline__ float gp_half_erfc_abs(float u, float& e) {     // 0.5 erfc(|u| / sqrt 2); e <- exp(-u^2 / 2)
+  const float x = fabsf(u) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, x, 1.0f));
+  float q = fmaf(-2.548219442e-02f, t, 1.698278524e-01f);
+  q = fmaf(q, t, -4.384240636e-01f);
+  q = fmaf(q, t, 4.869355765e-01f);
+  q = fmaf(q, t, -1.740313807e-01f);
+  q = fmaf(q, t, 2.156719095e-01f);
+  q = fmaf(q, t, 1.229157723e-01f);
+  q = fmaf(q, t, 1.425865282e-01f);
+  e = __builtin_amdgcn_exp2f(x * x * -1.4426950408889634f);
+  return q * t * e;
+}
+__device__ __forceinline__ float gp_gelu(float v) {
+  float e;
+  const float hc = gp_half_erfc_abs(v, e);
+  return v * (v < 0.f ? hc : 1.0f - hc);
+}
 // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
 __device__ __forceinline__ float gp_gelu_grad(float u) {
-  return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
+  float e;
+  const float hc = gp_half_erfc_abs(u, e);
+  return fmaf(u * 0.3989422804014327f, e, u < 0.f ? hc : 1.0f - hc);
 }
 __device__ __forceinline__ void gp_split8(const float* v, uint4& hi, uint4& lo) {
   uint32_t h[4], l[4];
