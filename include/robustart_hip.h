@@ -466,8 +466,11 @@ int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stre
  * sets the initial value) = ping-pong -- the two halves of the workgroup alternate memory and matrix phases, counted vmcnt, no drain in the
  * steady state; 2 (opt-in: measured slower than 1, see the kernel's header) = ping-pong, and one-tap problems (1x1 convolutions, plain
  * products without row re-basing / batching / GELU) with at least two 256 x 128 tiles per CU on the PERSISTENT kernel, which writes a tile
- * out under the next tile's K loop; 0 = the two-stage loop of round 4 everywhere.  Outputs are bit-identical under all three (same
- * products, same order, same point-wise code). */
+ * out under the next tile's K loop; 3 (opt-in: measured equal to 1) = ping-pong, and launches of more than one tile per CU WALKED by one
+ * workgroup per CU (the next tile's first stage requested before the epilogue); 0 = the two-stage loop of round 4 everywhere.  Under 1 - 3 a
+ * plain product whose 256 x 256 tiles fill every XCD's CUs a whole number of times and then less than half of them once more is issued as
+ * two launches, the remaining rows on 256 x 128 tiles (RART_PAIR_SPLIT=0 in the environment disables it).  Outputs are bit-identical under
+ * all of these (same products, same order, same point-wise code). */
 int rart_gemm_pair_set_schedule(int mode);
 int rart_gemm_pair_get_schedule(void);
 

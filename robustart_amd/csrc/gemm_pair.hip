@@ -228,6 +228,11 @@ int gp_schedule() {
   return g_pair_schedule;
 }
 
+int gp_split() {            // lab switch of the remainder split below (default on)
+  const char* e = getenv("RART_PAIR_SPLIT");
+  return e ? atoi(e) : 1;
+}
+
 void gp_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividends < 2^31
   uint32_t l = 0;
   while ((1ull << l) < dv) ++l;
@@ -236,7 +241,7 @@ void gp_magic(uint32_t dv, uint32_t& mg, uint32_t& sh) {   // exact for dividend
 }
 }  // namespace
 
-bool rart_gemm_pair_pp_launch(const void* dev_desc, int tn, bool conv, unsigned grid_x, unsigned grid_y, hipStream_t st);   // gemm_pair_pp.hip
+bool rart_gemm_pair_pp_launch(const void* dev_desc, int tn, bool conv, unsigned grid_x, unsigned grid_y, hipStream_t st, unsigned walk_wgs);   // gemm_pair_pp.hip
 void rart_gemm_pair_ps_launch(const void* dev_desc, bool conv, unsigned wgs, hipStream_t st);
 
 namespace {
@@ -253,7 +258,8 @@ int gp_cu_count() {      // compute units of the current device (the persistent 
 }  // namespace
 
 extern "C" int rart_gemm_pair_set_schedule(int mode) {
-  RART_CHECK_ARG(mode >= 0 && mode <= 2, "rart_gemm_pair_set_schedule: mode must be 0 (two-stage loop), 1 (ping-pong) or 2 (ping-pong + persistent)");
+  RART_CHECK_ARG(mode >= 0 && mode <= 3,
+                 "rart_gemm_pair_set_schedule: mode must be 0 (two-stage loop), 1 (ping-pong), 2 (ping-pong + deferred-epilogue persistent) or 3 (ping-pong, tiles walked)");
   g_pair_schedule = mode;
   return RART_OK;
 }
@@ -376,17 +382,41 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
       return RART_OK;
     }
   }
-  d.stagger_wgs = d.stagger_unit = 0;
-  {
-    static const double scale = getenv("RART_PP_STAGGER") ? atof(getenv("RART_PP_STAGGER")) : 0.0;
-    static const int min_rounds = getenv("RART_PP_STAGGER_ROUNDS") ? atoi(getenv("RART_PP_STAGGER_ROUNDS")) : 4;
-    const int cus = gp_cu_count();
-    if (scale > 0 && tm == 256 && blocks * nz >= (long long)min_rounds * cus) {
-      d.stagger_wgs = cus;
-      d.stagger_unit = (int)(scale * (d.K / GP_BK) * 900.0);
+  d.m_begin = 0;
+  if (!conv && tm == 256 && tn == 256 && gp_schedule() >= 1 && gp_split() && nz == 1 && h->tile_n == 0 && h->tile_m == 0) {
+    // Round 6 (scratch/r6/time_pair_rounds.py, GRBM_GUI_ACTIVE per launch): a 256-row launch is quantised in passes of ONE TILE PER CU PER XCD
+    // -- workgroup i goes to XCD i % 8, and the row-tile enumeration gives XCD x the row tiles x, x + 8, ... -- so ViT-B/16's 50432 x 768
+    // outputs (197 x 3 tiles, 75 per XCD of 32 CUs) take THREE tile times for 2.3 passes of work.  Such a launch is issued as two: the row
+    // tiles of the whole passes on 256 x 256 tiles, the remaining rows (m_begin) on 256 x 128 tiles, which take about half a tile time.
+    // Same products in the same order per output element: same bits.  Plain products only: on the convolutions of ResNet-50 (short K, epilogue-
+    // heavy tiles) the second launch costs what it saves (same-box A/B 19.53 vs 19.60 ms per gradient evaluation); ViT-B/16 66.9 -> 65.9 ms.
+    const int cx = gp_cu_count() / 8;                      // CUs per XCD
+    auto passes = [&](int mt, int nt) { return ((mt >= 16 ? (mt + 7) / 8 * nt : (mt * nt + 7) / 8) + cx - 1) / cx; };
+    const double half_cost = 0.8;                          // measured: the second launch costs ~0.8 tile times (it starts when the first has drained)
+    const int n128 = (d.N + 127) / 128;
+    double best = passes(m_tiles, n_tiles);
+    int best_ma = 0;
+    for (int pa = 1; pa < passes(m_tiles, n_tiles); ++pa) {
+      const int ma = pa * cx / n_tiles * 8;                // row tiles of the first launch: pa passes exactly on every XCD
+      if (ma < 16 || ma >= m_tiles) continue;
+      const double c = passes(ma, n_tiles) + half_cost * passes(m_tiles - ma, n128) + 0.05;
+      if (c < best - 0.1) { best = c; best_ma = ma; }
+    }
+    if (best_ma > 0) {
+      GemmPairDev da = d, db = d;
+      da.M = best_ma * 256;
+      db.m_begin = best_ma * 256;
+      const int mb = m_tiles - best_ma, mb_enum = mb >= 16 ? (mb + 7) / 8 * 8 : mb;
+      if (rart_gemm_pair_pp_launch(&da, 256, conv, (unsigned)(best_ma * n_tiles), 1, st, 0) &&
+          rart_gemm_pair_pp_launch(&db, 128, conv, (unsigned)(mb_enum * n128), 1, st, 0)) {
+        RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (ping-pong, remainder split)");
+        return RART_OK;
+      }
     }
   }
-  if (tm == 256 && tn >= 128 && gp_schedule() >= 1 && rart_gemm_pair_pp_launch(&d, tn, conv, grid.x, grid.y, st)) {
+  // schedule 3: launches of more than one tile per CU are WALKED by one workgroup per CU (k_gemm_pair_pp, OPT bit 1)
+  const unsigned walk_wgs = (gp_schedule() == 3 && nz == 1 && blocks > (long long)gp_cu_count()) ? (unsigned)(gp_cu_count() & ~7) : 0u;
+  if (tm == 256 && tn >= 128 && gp_schedule() >= 1 && rart_gemm_pair_pp_launch(&d, tn, conv, grid.x, grid.y, st, walk_wgs)) {
     RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (ping-pong)");
     return RART_OK;
   }

@@ -69,9 +69,15 @@ __device__ unsigned long long g_pp_trace[4096][4];       // per workgroup (block
 #endif
 
 // OPT bit 0: balanced refills (half of a wave's W pieces ride in M0: 16 pieces per slot instead of 8 / 8 / 24 / 24)
+// OPT bit 1: the workgroup WALKS tiles (grid = one workgroup per CU, tile = blockIdx.x + k gridDim.x -- the order the dispatcher would have
+//            used).  The per-workgroup trace of ViT-B/16's launches (scratch/r6/vit_pp_trace.py: s_memtime at entry / loop end / exit per CU)
+//            put 8-10 k cycles between one workgroup's exit and the next one's first instruction and 9 k of prologue beside a 92 k-cycle
+//            K loop (K = 768).  Walking removes the first; the second shrinks because the next tile's stage 0 is requested BEFORE the
+//            epilogue (which stages through the bytes after stage 0, so the tile buffer is STAGE + staging long) and lands while the
+//            epilogue's loads and stores run.  The epilogue itself is unchanged (gp_epilogue, in order): same bits.
 template <int TN, bool CONV, int OPT>
 __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
-  constexpr bool BAL = OPT & 1;
+  constexpr bool BAL = OPT & 1, WALK = OPT & 2;
   constexpr int TM = 256, NW = 8, WN = TN / 64, WM = NW / WN, RW = TM / WM, MI = RW / 32, MH = MI / 2;
   static_assert(TN == 256 || TN == 128, "column tiles of 256 or 128");
   constexpr int PLANE_A = TM * 64, PLANE_B = TN * 64, STAGE = 2 * PLANE_A + 2 * PLANE_B;
@@ -82,9 +88,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
                 VM_DELTA = 2 * N0 + N1;
   constexpr int GP_STAGING = NW * 32 * GP_LDE * 4;
   static_assert(GP_STAGING + TM * 4 <= 2 * STAGE, "epilogue staging + row table must fit the tile buffers");
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
+  constexpr int EP_OFF = WALK ? STAGE : 0;        // where the epilogue stages: WALK keeps stage 0 free for the next tile's first loads
+  constexpr int LDS_BYTES = (WALK && STAGE + GP_STAGING + TM * 4 > 2 * STAGE) ? STAGE + GP_STAGING + TM * 4 : 2 * STAGE;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
-  PP_T(t_entry)
+#ifdef RART_PP_STAMPS
+  unsigned long long t_tile = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
   const int g = wave >> 2, w4 = wave & 3, og = 1 - g;
@@ -96,24 +106,33 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
     a_hi += ao; a_lo += ao; w_hi += wo; w_lo += wo;
     c_off = zo * d.c_zo + zi * d.c_zi;
   }
-  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M + TM - 1) / TM;
-  int m_tile, n_tile;
-  if (m_tiles >= 16) {
-    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
-    m_tile = (slot / n_tiles) * 8 + xcd;
-    n_tile = slot % n_tiles;
-    if (m_tile >= m_tiles) return;
-  } else {
-    m_tile = blockIdx.x / n_tiles;
-    n_tile = blockIdx.x - m_tile * n_tiles;
+  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M - d.m_begin + TM - 1) / TM;
+  // tile of (virtual) block index BID: XCD-aware enumeration, rows in groups of 8; `ok_` false for the holes past the last row tile
+#define RART_PP_TILE_OF(BID, M0_, N0_, OK_)                                                                      \
+  {                                                                                                              \
+    const int bid_ = (BID);                                                                                      \
+    int mt_, nt_;                                                                                                \
+    if (m_tiles >= 16) {                                                                                         \
+      const int xcd_ = bid_ & 7, slot_ = bid_ >> 3;                                                              \
+      mt_ = (slot_ / n_tiles) * 8 + xcd_;                                                                        \
+      nt_ = slot_ % n_tiles;                                                                                     \
+    } else {                                                                                                     \
+      mt_ = bid_ / n_tiles;                                                                                      \
+      nt_ = bid_ - mt_ * n_tiles;                                                                                \
+    }                                                                                                            \
+    OK_ = mt_ < m_tiles;                                                                                         \
+    M0_ = d.m_begin + mt_ * TM; N0_ = nt_ * TN;                                                                              \
   }
-  const int m0 = m_tile * TM, n0 = n_tile * TN;
-  if (d.stagger_unit > 0 && (int)blockIdx.x < d.stagger_wgs && blockIdx.y == 0) {
-    const int ph = (blockIdx.x >> 3) & 3;
-    if (ph) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime(), dt = (unsigned long long)ph * (unsigned)d.stagger_unit;
-      while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(32);
+  const int n_blocks = (m_tiles >= 16 ? (m_tiles + 7) / 8 * 8 : m_tiles) * n_tiles;
+  int bid = blockIdx.x, m0 = 0, n0 = 0;
+  {
+    bool ok = false;
+    while (bid < n_blocks) {
+      RART_PP_TILE_OF(bid, m0, n0, ok)
+      if (ok || !WALK) break;
+      bid += gridDim.x;
     }
+    if (!ok) return;
   }
 
   // ---- loader.  A wave only ever loads A rows of the OTHER group: piece w4 (16 rows) of its two 64-row regions -- q = 0: the region it
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
     const int hh = q == 0 ? og : g;
     pr[q] = (WM == 2) ? og * 128 + hh * 64 + 16 * w4 : (2 * og + (w4 >> 1)) * 64 + hh * 32 + (w4 & 1) * 16;
   }
-  uint32_t avoff[2], nok[2] = {0u, 0u};
+  uint32_t avoff[2], nok[2];
   int tapreg = 0, tap_min = 0;
   const bool one_tap = !CONV || d.n_taps == 1;
   if (CONV) {
@@ -137,42 +156,47 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
     if (lane < d.n_taps) tapreg = (d.tap_dy[lane] * d.src_w + d.tap_dx[lane]) * d.lda * 2 - tap_min;
   }
   const uint32_t tap0 = CONV ? (uint32_t)__builtin_amdgcn_readfirstlane((d.tap_dy[0] * d.src_w + d.tap_dx[0]) * d.lda * 2 - tap_min) : 0u;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int r = pr[q] + (lane >> 2);
-    const int csrc = (lane & 3) ^ ((r >> 2) & 3);
-    const int m = m0 + r;
-    const bool ok = m < d.M;
-    if (CONV) {
-      const uint32_t mm = ok ? (uint32_t)m : 0u;
-      const uint32_t t = gp_fastdiv(mm, d.gw_magic, d.gw_shift);
-      const int ox = (int)(mm - t * (uint32_t)d.grid_w);
-      const int n = (int)gp_fastdiv(t, d.gh_magic, d.gh_shift);
-      const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);
-      const int by = oy * d.sy, bx = ox * d.sx;
-      avoff[q] = (uint32_t)((n * d.src_h * d.src_w + by * d.src_w + bx) * d.lda * 2 + csrc * 16);
-      for (int t2 = 0; t2 < d.n_taps; ++t2) {
-        const int iy = by + d.tap_dy[t2], ix = bx + d.tap_dx[t2];
-        if (!(ok && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w)) nok[q] |= 1u << t2;
-      }
-      if (one_tap && (nok[q] & 1u)) avoff[q] = PP_OOR;
-    } else {
-      long long srow = m;
-      if (d.map_rows) {
-        const int img = m / d.rpi;
-        srow = (long long)img * d.src_rpi + (m - img * d.rpi);
-      }
-      avoff[q] = ok ? (uint32_t)(((srow + d.src_off) * d.lda + csrc * 8) * 2) : PP_OOR;
-    }
-  }
   uint32_t wvoff[WQ];
-#pragma unroll
-  for (int q = 0; q < WQ; ++q) {
-    const int r = 16 * (w4 + 4 * q) + (lane >> 2);
-    const int csrc = (lane & 3) ^ ((r >> 2) & 3);
-    const int n = n0 + r;
-    wvoff[q] = n < d.w_rows ? (uint32_t)((n * d.ldw + csrc * 8) * 2) : PP_OOR;
+#define RART_PP_ADDR(M0_, N0_)                                                                                   \
+  {                                                                                                              \
+    nok[0] = nok[1] = 0u;                                                                                        \
+  _Pragma("unroll")                                                                                              \
+    for (int q = 0; q < 2; ++q) {                                                                                \
+      const int r = pr[q] + (lane >> 2);                                                                         \
+      const int csrc = (lane & 3) ^ ((r >> 2) & 3);                                                              \
+      const int m = (M0_) + r;                                                                                   \
+      const bool ok = m < d.M;                                                                                   \
+      if (CONV) {                                                                                                \
+        const uint32_t mm = ok ? (uint32_t)m : 0u;                                                               \
+        const uint32_t t = gp_fastdiv(mm, d.gw_magic, d.gw_shift);                                               \
+        const int ox = (int)(mm - t * (uint32_t)d.grid_w);                                                       \
+        const int n = (int)gp_fastdiv(t, d.gh_magic, d.gh_shift);                                                \
+        const int oy = (int)(t - (uint32_t)n * (uint32_t)d.grid_h);                                              \
+        const int by = oy * d.sy, bx = ox * d.sx;                                                                \
+        avoff[q] = (uint32_t)((n * d.src_h * d.src_w + by * d.src_w + bx) * d.lda * 2 + csrc * 16);              \
+        for (int t2 = 0; t2 < d.n_taps; ++t2) {                                                                  \
+          const int iy = by + d.tap_dy[t2], ix = bx + d.tap_dx[t2];                                              \
+          if (!(ok && (unsigned)iy < (unsigned)d.src_h && (unsigned)ix < (unsigned)d.src_w)) nok[q] |= 1u << t2; \
+        }                                                                                                        \
+        if (one_tap && (nok[q] & 1u)) avoff[q] = PP_OOR;                                                         \
+      } else {                                                                                                   \
+        long long srow = m;                                                                                      \
+        if (d.map_rows) {                                                                                        \
+          const int img = m / d.rpi;                                                                             \
+          srow = (long long)img * d.src_rpi + (m - img * d.rpi);                                                 \
+        }                                                                                                        \
+        avoff[q] = ok ? (uint32_t)(((srow + d.src_off) * d.lda + csrc * 8) * 2) : PP_OOR;                        \
+      }                                                                                                          \
+    }                                                                                                            \
+  _Pragma("unroll")                                                                                              \
+    for (int q = 0; q < WQ; ++q) {                                                                               \
+      const int r = 16 * (w4 + 4 * q) + (lane >> 2);                                                             \
+      const int csrc = (lane & 3) ^ ((r >> 2) & 3);                                                              \
+      const int n = (N0_) + r;                                                                                   \
+      wvoff[q] = n < d.w_rows ? (uint32_t)((n * d.ldw + csrc * 8) * 2) : PP_OOR;                                 \
+    }                                                                                                            \
   }
+  RART_PP_ADDR(m0, n0)
   const pp_srd_t srd_ah = pp_make_srd(reinterpret_cast<const char*>(a_hi) + tap_min), srd_al = pp_make_srd(reinterpret_cast<const char*>(a_lo) + tap_min);
   const pp_srd_t srd_w = pp_make_srd(g ? w_lo : w_hi);
   const int w_step = (d.flags & GP_W_INTERLEAVED) ? 128 : 64;
@@ -209,29 +233,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) xo[ks] = (uint32_t)(fr * 64 + (((2 * ks + h) ^ ((fr >> 2) & 3)) << 4));
   f32x16 acc[MI][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int bc = n0 + wn * 64 + j * 32 + fr;
-    const float bv = (d.bias && bc < d.N) ? d.bias[bc] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
-  }
-
-  // ---- prologue: stage 0 whole, stage 1 except what the first M0 phases issue
+  // ---- prologue, first part: stage 0 whole (WALK: for the following tiles this is issued before the previous tile's epilogue)
   RART_PP_ISSUE_W(0, 0, WQ)
   RART_PP_ISSUE_A(0, 0)
   RART_PP_ISSUE_A(1, 0)
-  if (KT > 1) {
-    RART_PP_ISSUE_W(1, 0, BAL ? WH : WQ)      // balanced form: the second half of stage 1's W pieces is issued by the first M0
-    RART_PP_ISSUE_A(1, 1)
-    if (g) RART_PP_ISSUE_A(0, 1)
-  }
-  pp_vmcnt<0>();
-  __syncthreads();
-  if (g) pp_slot_end();                     // the stagger: group 1 runs one slot behind group 0
-
   bf16x8 ah[MH][2], al[MH][2], bh[2][2], bl[2][2];
 #define RART_PP_READ_A(HALF)                                                                                     \
   _Pragma("unroll") for (int ii = 0; ii < MH; ++ii) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {         \
@@ -257,6 +262,25 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
 #ifdef RART_PP_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+  for (;;) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int bc = n0 + wn * 64 + j * 32 + fr;
+    const float bv = (d.bias && bc < d.N) ? d.bias[bc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+  }
+  // ---- prologue, second part: stage 1 except what the first M0 phases issue
+  if (KT > 1) {
+    RART_PP_ISSUE_W(1, 0, BAL ? WH : WQ)      // balanced form: the second half of stage 1's W pieces is issued by the first M0
+    RART_PP_ISSUE_A(1, 1)
+    if (g) RART_PP_ISSUE_A(0, 1)
+  }
+  pp_vmcnt<0>();
+  __syncthreads();
+  if (g) pp_slot_end();                     // the stagger: group 1 runs one slot behind group 0
   PP_T(t_loop0)
 
   for (int kt = 0; kt < KT; ++kt) {
@@ -320,28 +344,55 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
   }
   PP_T(t_loop1)
   if (!g) pp_slot_end();                    // group 0's closing barrier pairs with group 1's last one
-#undef RART_PP_MFMA
-#undef RART_PP_READ_A
-#undef RART_PP_ISSUE_W
-#undef RART_PP_ISSUE_A
   pp_vmcnt<0>();
   __syncthreads();
-  gp_epilogue<TM, TN, CONV, MI>(d, lds, acc, m0, n0, c_off);
+  const int m0e = m0, n0e = n0;
+#ifdef RART_PP_STAMPS
+  const int bide = bid;
+#endif
+  bool more = false;
+  if (WALK) {
+    bid += gridDim.x;
+    while (bid < n_blocks) {
+      RART_PP_TILE_OF(bid, m0, n0, more)
+      if (more) break;
+      bid += gridDim.x;
+    }
+    if (more) {                             // the next tile's stage 0 travels while this tile's epilogue runs (it stages past stage 0)
+      RART_PP_ADDR(m0, n0)
+      RART_PP_ISSUE_W(0, 0, WQ)
+      RART_PP_ISSUE_A(0, 0)
+      RART_PP_ISSUE_A(1, 0)
+    }
+  }
+  gp_epilogue<TM, TN, CONV, MI>(d, lds + EP_OFF, acc, m0e, n0e, c_off);
 #ifdef RART_PP_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
   PP_T(t_exit)
   if (lane == 0 && (wave & 3) == 0) {
-    for (int i = 0; i < 12; ++i) atomicAdd(&g_pp_stamps[g][i], st_acc[i]);
+    for (int i = 0; i < 12; ++i) { atomicAdd(&g_pp_stamps[g][i], st_acc[i]); st_acc[i] = 0; }
     atomicAdd(&g_pp_stamps[g][12], (unsigned long long)KT);
-    atomicAdd(&g_pp_stamps[g][13], t_loop0 - t_entry);      // prologue
+    atomicAdd(&g_pp_stamps[g][13], t_loop0 - t_tile);       // prologue
     atomicAdd(&g_pp_stamps[g][14], t_exit - t_loop1);       // closing barrier + epilogue
     atomicAdd(&g_pp_stamps[g][15], 1ull);                   // workgroups
   }
-  if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
-    g_pp_trace[blockIdx.x][0] = t_entry; g_pp_trace[blockIdx.x][1] = t_loop1; g_pp_trace[blockIdx.x][2] = t_exit;
-    g_pp_trace[blockIdx.x][3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  if (tid == 0 && bide < 4096 && blockIdx.y == 0) {
+    g_pp_trace[bide][0] = t_tile; g_pp_trace[bide][1] = t_loop1; g_pp_trace[bide][2] = t_exit;
+    g_pp_trace[bide][3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
   }
 #endif
+#ifdef RART_PP_STAMPS
+  t_tile = t_exit;
+#endif
+  if (!more) break;
+  __syncthreads();                          // every wave's staging reads are done: stage 1 may be refilled
+  }
+#undef RART_PP_MFMA
+#undef RART_PP_READ_A
+#undef RART_PP_ISSUE_W
+#undef RART_PP_ISSUE_A
+#undef RART_PP_ADDR
+#undef RART_PP_TILE_OF
 }
 
 // ---- PERSISTENT form (round 6; opt-in: rart_gemm_pair_set_schedule(2)): 256 x 128 tiles, one workgroup per CU walks a contiguous run of
@@ -655,7 +706,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_ps(const GemmPairDev d) {
 #define RART_PP_DEFAULT_OPT 1
 #endif
 template <int OPT>
-bool pp_launch_opt(const GemmPairDev& d, int tn, bool conv, dim3 grid, hipStream_t st) {
+bool pp_launch_opt(const GemmPairDev& d, int tn, bool conv, dim3 grid, hipStream_t st, unsigned walk_wgs = 0) {
+  if (walk_wgs && !(OPT & 2)) return pp_launch_opt<OPT | 2>(d, tn, conv, dim3(walk_wgs < grid.x ? walk_wgs : grid.x, 1), st);
   if (tn == 256) {
     if (conv) hipLaunchKernelGGL((k_gemm_pair_pp<256, true, OPT>), grid, dim3(512), 0, st, d);
     else hipLaunchKernelGGL((k_gemm_pair_pp<256, false, OPT>), grid, dim3(512), 0, st, d);
@@ -670,16 +722,17 @@ bool pp_launch_opt(const GemmPairDev& d, int tn, bool conv, dim3 grid, hipStream
 }  // namespace
 
 // Launch by column tile; `dev_desc` is gemm_pair.hip's filled GemmPairDev (same header, same layout).  Returns false when (tn) has no instance.
+// walk_wgs > 0 (grid_y == 1 only): that many workgroups walk the grid_x tiles (OPT bit 1).
 __attribute__((visibility("hidden"))) bool rart_gemm_pair_pp_launch(const void* dev_desc, int tn, bool conv, unsigned grid_x, unsigned grid_y,
-                                                                    hipStream_t st) {
+                                                                    hipStream_t st, unsigned walk_wgs) {
   const GemmPairDev& d = *static_cast<const GemmPairDev*>(dev_desc);
   const dim3 grid(grid_x, grid_y);
 #ifdef RART_PP_LAB              // lab build: both option values, chosen per call by RART_PP_OPT
   const char* e = getenv("RART_PP_OPT");
-  if ((e ? atoi(e) : RART_PP_DEFAULT_OPT) & 1) return pp_launch_opt<1>(d, tn, conv, grid, st);
-  return pp_launch_opt<0>(d, tn, conv, grid, st);
+  if ((e ? atoi(e) : RART_PP_DEFAULT_OPT) & 1) return pp_launch_opt<1>(d, tn, conv, grid, st, walk_wgs);
+  return pp_launch_opt<0>(d, tn, conv, grid, st, walk_wgs);
 #else
-  return pp_launch_opt<RART_PP_DEFAULT_OPT>(d, tn, conv, grid, st);
+  return pp_launch_opt<RART_PP_DEFAULT_OPT>(d, tn, conv, grid, st, walk_wgs);
 #endif
 }
 

@@ -30,7 +30,7 @@ struct GemmPairDev {
   uint32_t gw_magic, gw_shift, gh_magic, gh_shift;      // exact division by multiply-shift for dividends < 2^31
   const uint8_t* mask_bits;                              // 1 bit per destination element (byte (off + col) / 8): v = 0 where clear
   uint8_t* sign_out;                                     // receives (output hi plane > 0), same indexing
-  int stagger_wgs, stagger_unit;                         // ping-pong kernel: the first stagger_wgs workgroups start phase * unit cycles late
+  int m_begin;                                           // k_gemm_pair_pp only: the launch covers rows m_begin .. M - 1 (0 elsewhere)
 };
 __device__ __forceinline__ uint32_t gp_fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);

@@ -643,7 +643,76 @@ def test_pair_gemm_pingpong_schedule_is_bit_identical(conv, M, K, N, tile_n, bat
             assert torch.equal(sign, want_sign)
     finally:
         lib.rart_gemm_pair_set_schedule(old)
-    assert lib.rart_gemm_pair_set_schedule(3) != 0
+    assert lib.rart_gemm_pair_set_schedule(4) != 0
+
+
+@pytest.mark.parametrize('conv,M,K,N,tile_n', [
+    ((16, 64, 64, 64), 65536, 576, 512, 256),    # 3x3 gather, 18 K steps, 512 tiles: two per workgroup, zero padding in every tile
+    ((9, 60, 60, 32), 32400, 288, 640, 128),     # one K step per tap, 127 x 5 tiles of 256 x 128, ragged last row tile and column tile
+    (None, 70000, 96, 512, 128),                 # three K steps, 274 x 4 tiles of 256 x 128
+    (None, 66000, 32, 256, 256),                 # ONE K step per tile: the walk is prologue after prologue
+    (None, 66100, 64, 296, 256),                 # two K steps, a column tile with 40 valid columns, holes in the XCD enumeration
+])
+def test_pair_gemm_walked_tiles_are_bit_identical(conv, M, K, N, tile_n):
+    """Schedule 3 on forced 256-row tiles with taps / short K loops (the shapes the persistent cases above do not reach): a workgroup's second and
+    third tile start from the stage the PREVIOUS tile's epilogue ran beside."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    d, out, sign, keep = _pair_schedule_case(lib, _lib, conv, M, K, N, tile_n, False, seed=31)
+    old = lib.rart_gemm_pair_get_schedule()
+    try:
+        _lib.check(lib.rart_gemm_pair_set_schedule(0))
+        _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        want, want_sign = out.view(torch.int16).clone(), sign.clone()
+        assert torch.isfinite(out.float()).all()
+        _lib.check(lib.rart_gemm_pair_set_schedule(3))
+        hog_stream = torch.cuda.Stream()
+        hog = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+        for rep in range(5):
+            out.fill_(float('nan'))
+            sign.zero_()
+            if rep >= 2:
+                with torch.cuda.stream(hog_stream):
+                    for _ in range(4):
+                        hog.add_(1.0)
+            _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            bad = (out.view(torch.int16) != want).any(0).any(0)
+            assert not bad.any(), 'walked tiles differ from the two-stage loop (repetition %d): %d elements, first rows %s' % (
+                rep, int(bad.sum()), bad.any(1).nonzero().flatten()[:8].tolist())
+            assert torch.equal(sign, want_sign)
+    finally:
+        lib.rart_gemm_pair_set_schedule(old)
+
+
+@pytest.mark.parametrize('M,K,N', [
+    (197 * 256 - 37, 96, 768),       # ViT-B/16's geometry: 197 x 3 tiles = 75 per XCD -> 168 row tiles on 256 x 256, 29 (ragged) on 256 x 128
+    (100 * 256, 64, 1000),           # 100 x 4 tiles, a ragged column tile in both launches (232 / 104 valid columns)
+])
+def test_pair_gemm_remainder_split_is_bit_identical(M, K, N, monkeypatch):
+    """Round 6: a plain product that fills the CUs a whole number of times and then less than half of them once more is issued as two launches
+    (whole passes on 256 x 256 tiles, the remaining rows on 256 x 128 tiles: csrc/gemm_pair.hip).  Against the unsplit launch and against the
+    two-stage loop: equal bit for bit."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    d, out, sign, keep = _pair_schedule_case(lib, _lib, None, M, K, N, 0, False, seed=41)
+    d.tile_m = 0
+    old = lib.rart_gemm_pair_get_schedule()
+    try:
+        res = []
+        for sched, split in ((0, '0'), (1, '0'), (1, '1'), (1, '1')):
+            monkeypatch.setenv('RART_PAIR_SPLIT', split)
+            _lib.check(lib.rart_gemm_pair_set_schedule(sched))
+            out.fill_(float('nan'))
+            _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all()
+            res.append(out.view(torch.int16).clone())
+        for r in res[1:]:
+            assert torch.equal(r, res[0])
+    finally:
+        lib.rart_gemm_pair_set_schedule(old)
 
 
 def _pair_ps_case(_lib, conv, M, K, N, flags_relu, with_res, with_mask, seed):
@@ -691,8 +760,10 @@ def _pair_ps_case(_lib, conv, M, K, N, flags_relu, with_res, with_mask, seed):
     ((8, 28, 28, 2), 6272, 256, 2816, False, True, True),  # stride 2 with a 1-bit mask, 25 x 22 tiles
     (None, 131072 + 5, 256, 136, False, True, False),      # N = 136: a column tile with 8 valid columns
 ])
-def test_pair_gemm_persistent_kernel_is_bit_identical(conv, M, K, N, relu, res, mask):
-    """Round 6: the PERSISTENT form of the ping-pong GEMM (256 x 128 tiles, a workgroup per CU walks a run of tiles, the epilogue of a tile is
+@pytest.mark.parametrize('schedule', [2, 3])
+def test_pair_gemm_persistent_kernel_is_bit_identical(conv, M, K, N, relu, res, mask, schedule):
+    """Schedule 3 (round 6, the default for launches of more than one tile per CU): one workgroup per CU WALKS the tiles of the ping-pong
+    kernel, the next tile's first stage requested before the epilogue.  Schedule 2: the PERSISTENT form of the ping-pong GEMM (256 x 128 tiles, a workgroup per CU walks a run of tiles, the epilogue of a tile is
     deferred into the memory phases of the next tile's K loop) against round 4's two-stage loop with its ordinary epilogue: equal BIT FOR
     BIT, repeatedly, beside a bandwidth hog (the deferred epilogue mixes compiler-counted loads / stores with inline-asm LDS-DMA; a wrong
     wait shows as a rare wrong tile)."""
@@ -706,7 +777,7 @@ def test_pair_gemm_persistent_kernel_is_bit_identical(conv, M, K, N, relu, res, 
         torch.cuda.synchronize()
         want, want_sign = out.view(torch.int16).clone(), sign.clone()
         assert torch.isfinite(out.float()).all()
-        _lib.check(lib.rart_gemm_pair_set_schedule(2))
+        _lib.check(lib.rart_gemm_pair_set_schedule(schedule))
         hog_stream = torch.cuda.Stream()
         hog = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
         for rep in range(6):
