@@ -459,7 +459,7 @@ typedef struct rart_gemm_pair_desc {
   const void* mask_bits;
   void* sign_out;
   int tile_n;               /* 0 = automatic (64 / 128 / 256 by N); tests / sweeps force a column tile */
-  int tile_m;               /* 0 = automatic (256; 128 for short-K or small convolutions); 128 / 256 force a row tile */
+  int tile_m;               /* 0 = automatic (256; 128 for short-K or small convolutions; 224 where it saves a pass); 128 / 224 / 256 force it */
 } rart_gemm_pair_desc;
 int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stream);
 /* Schedule of the 256-row tiles with 128 / 256 columns (round 6, csrc/gemm_pair_pp.hip): 1 (default; RART_PAIR_SCHEDULE in the environment
@@ -469,7 +469,8 @@ int rart_gemm_pair_bf16(const rart_gemm_pair_desc* desc_host, rart_stream_t stre
  * out under the next tile's K loop; 3 (opt-in: measured equal to 1) = ping-pong, and launches of more than one tile per CU WALKED by one
  * workgroup per CU (the next tile's first stage requested before the epilogue); 0 = the two-stage loop of round 4 everywhere.  Under 1 - 3 a
  * plain product whose 256 x 256 tiles fill every XCD's CUs a whole number of times and then less than half of them once more is issued as
- * two launches, the remaining rows on 256 x 128 tiles (RART_PAIR_SPLIT=0 in the environment disables it).  Outputs are bit-identical under
+ * two launches, the remaining rows on 256 x 128 tiles (RART_PAIR_SPLIT=0 in the environment disables it), and a launch whose row tiles
+ * fill an XCD's 32 CUs badly runs tiles that step 224 rows (RART_PAIR_ROWS224=0 disables it).  Outputs are bit-identical under
  * all of these (same products, same order, same point-wise code). */
 int rart_gemm_pair_set_schedule(int mode);
 int rart_gemm_pair_get_schedule(void);

@@ -228,6 +228,10 @@ int gp_schedule() {
   return g_pair_schedule;
 }
 
+int gp_rows224() {          // lab switch of the 224-row tiles below (default on)
+  const char* e = getenv("RART_PAIR_ROWS224");
+  return e ? atoi(e) : 1;
+}
 int gp_split() {            // lab switch of the remainder split below (default on)
   const char* e = getenv("RART_PAIR_SPLIT");
   return e ? atoi(e) : 1;
@@ -364,6 +368,7 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   }
   if (h->tile_n == 64 || h->tile_n == 128 || h->tile_n == 256) tn = h->tile_n;
   if (h->tile_m == 128 || h->tile_m == 256) tm = h->tile_m;
+  if (h->tile_m == 224) tm = 256;            // the ping-pong kernel's 224-row form (below)
   const int m_tiles = (d.M + tm - 1) / tm, n_tiles = (d.N + tn - 1) / tn;
   const int m_enum = m_tiles >= 16 ? (m_tiles + 7) / 8 * 8 : m_tiles;     // the XCD remap enumerates row tiles in groups of 8
   const long long blocks = (long long)m_enum * n_tiles;
@@ -383,6 +388,23 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
     }
   }
   d.m_begin = 0;
+  d.tile_rows = 256;
+  if (tm == 256 && tn >= 128 && gp_schedule() >= 1 && nz == 1 && (h->tile_m == 224 || (h->tile_m == 0 && gp_rows224()))) {
+    // Round 6: 224-row tiles.  A launch runs in passes of one tile per CU and XCD (above); ResNet-50's 50176 / 12544 rows are 196 / 49 tiles
+    // of 256 rows = 25 / 7 of an XCD's 32 CUs in the fullest XCD.  A tile that steps 224 rows (the kernel leaves its last 32-row block out;
+    // loads, waits and barriers unchanged) makes 224 / 56 row tiles = 28 / 7 per XCD: the same passes, 7/8 of the matrix work per tile.
+    auto passes = [&](int mt, int nt) { const int cx = gp_cu_count() / 8; return ((mt >= 16 ? (mt + 7) / 8 * nt : (mt * nt + 7) / 8) + cx - 1) / cx; };
+    const int mt224 = (d.M + 223) / 224;
+    if (h->tile_m == 224 || passes(mt224, n_tiles) * 0.92 < passes(m_tiles, n_tiles) - 0.01) {
+      d.tile_rows = 224;
+      const int me = mt224 >= 16 ? (mt224 + 7) / 8 * 8 : mt224;
+      if (rart_gemm_pair_pp_launch(&d, tn, conv, (unsigned)(me * n_tiles), 1, st, 0)) {
+        RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (ping-pong, 224-row tiles)");
+        return RART_OK;
+      }
+      d.tile_rows = 256;
+    }
+  }
   if (!conv && tm == 256 && tn == 256 && gp_schedule() >= 1 && gp_split() && nz == 1 && h->tile_n == 0 && h->tile_m == 0) {
     // Round 6 (scratch/r6/time_pair_rounds.py, GRBM_GUI_ACTIVE per launch): a 256-row launch is quantised in passes of ONE TILE PER CU PER XCD
     // -- workgroup i goes to XCD i % 8, and the row-tile enumeration gives XCD x the row tiles x, x + 8, ... -- so ViT-B/16's 50432 x 768

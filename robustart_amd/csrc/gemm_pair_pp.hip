@@ -106,7 +106,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
     a_hi += ao; a_lo += ao; w_hi += wo; w_lo += wo;
     c_off = zo * d.c_zo + zi * d.c_zi;
   }
-  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M - d.m_begin + TM - 1) / TM;
+  const int TMV = d.tile_rows;                     // 256, or 224: a tile steps 224 rows and its last 32-row block is neither multiplied nor stored
+  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M - d.m_begin + TMV - 1) / TMV;
   // tile of (virtual) block index BID: XCD-aware enumeration, rows in groups of 8; `ok_` false for the holes past the last row tile
 #define RART_PP_TILE_OF(BID, M0_, N0_, OK_)                                                                      \
   {                                                                                                              \
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
       nt_ = bid_ - mt_ * n_tiles;                                                                                \
     }                                                                                                            \
     OK_ = mt_ < m_tiles;                                                                                         \
-    M0_ = d.m_begin + mt_ * TM; N0_ = nt_ * TN;                                                                              \
+    M0_ = d.m_begin + mt_ * TMV; N0_ = nt_ * TN;                                                                             \
   }
   const int n_blocks = (m_tiles >= 16 ? (m_tiles + 7) / 8 * 8 : m_tiles) * n_tiles;
   int bid = blockIdx.x, m0 = 0, n0 = 0;
@@ -238,8 +239,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
   RART_PP_ISSUE_A(0, 0)
   RART_PP_ISSUE_A(1, 0)
   bf16x8 ah[MH][2], al[MH][2], bh[2][2], bl[2][2];
+  const bool skip_last = wm * RW + MI * 32 > TMV;          // (wave-uniform) this wave's last row block lies past a 224-row tile
 #define RART_PP_READ_A(HALF)                                                                                     \
-  _Pragma("unroll") for (int ii = 0; ii < MH; ++ii) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {         \
+  _Pragma("unroll") for (int ii = 0; ii < MH; ++ii) if (!((HALF) == 1 && ii == MH - 1 && skip_last))           \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                        \
     ah[ii][ks] = *reinterpret_cast<const bf16x8*>(Ah + ((HALF)*MH + ii) * 32 * 64 + xo[ks]);                     \
     al[ii][ks] = *reinterpret_cast<const bf16x8*>(Ah + PLANE_A + ((HALF)*MH + ii) * 32 * 64 + xo[ks]);           \
   }
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
 #define RART_PP_MFMA(HALF)                                                                                       \
   __builtin_amdgcn_s_setprio(1);                                                                                 \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int ii = 0; ii < MH; ++ii)           \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                           \
+      if (!((HALF) == 1 && ii == MH - 1 && skip_last)) _Pragma("unroll") for (int j = 0; j < 2; ++j) {          \
     acc[(HALF)*MH + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ii][ks], bh[j][ks], acc[(HALF)*MH + ii][j], 0, 0, 0); \
     acc[(HALF)*MH + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ii][ks], bl[j][ks], acc[(HALF)*MH + ii][j], 0, 0, 0); \
     acc[(HALF)*MH + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ii][ks], bh[j][ks], acc[(HALF)*MH + ii][j], 0, 0, 0); \
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
       RART_PP_ISSUE_A(1, 0)
     }
   }
-  gp_epilogue<TM, TN, CONV, MI>(d, lds + EP_OFF, acc, m0e, n0e, c_off);
+  gp_epilogue<TM, TN, CONV, MI>(d, lds + EP_OFF, acc, m0e, n0e, c_off, TMV);
 #ifdef RART_PP_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
   PP_T(t_exit)

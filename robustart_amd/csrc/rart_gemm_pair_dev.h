@@ -31,6 +31,7 @@ struct GemmPairDev {
   const uint8_t* mask_bits;                              // 1 bit per destination element (byte (off + col) / 8): v = 0 where clear
   uint8_t* sign_out;                                     // receives (output hi plane > 0), same indexing
   int m_begin;                                           // k_gemm_pair_pp only: the launch covers rows m_begin .. M - 1 (0 elsewhere)
+  int tile_rows;                                         // k_gemm_pair_pp only: 256, or 224 = the last 32-row block of a tile is left out
 };
 __device__ __forceinline__ uint32_t gp_fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
   return (uint32_t)(((uint64_t)n * magic) >> shift);
@@ -164,7 +165,8 @@ __device__ __forceinline__ void gp_finish_segment(const GemmPairDev& d, int flag
 // Epilogue of a TM x TN tile whose accumulators acc[MI][2] follow k_gemm_pair's wave layout (wave = (wm, wn), a wave owns RW rows x 64
 // columns).  `lds` is the workgroup's tile buffer (free after the K loop).  Must be called by every thread of the workgroup.
 template <int TM, int TN, bool CONV, int MI>
-__device__ __forceinline__ void gp_epilogue(const GemmPairDev& d, uint8_t* lds, f32x16 (&acc)[MI][2], int m0, int n0, long long c_off) {
+__device__ __forceinline__ void gp_epilogue(const GemmPairDev& d, uint8_t* lds, f32x16 (&acc)[MI][2], int m0, int n0, long long c_off,
+                                            int tile_rows = TM) {
   constexpr int NW = TM / 32;
   constexpr int WN = (TN / 64 < NW) ? TN / 64 : NW, WM = NW / WN, RW = TM / WM;
   static_assert(MI == RW / 32, "accumulator blocks per wave");
@@ -198,6 +200,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmPairDev& d, uint8_t* lds, 
   const bool out_f32 = flags & GP_OUT_F32;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    if (wm * RW + i * 32 >= tile_rows) continue;          // (wave-uniform) a 224-row tile of k_gemm_pair_pp: the block belongs to the next tile
     long long eo[4];
     uint4 rh[4], rl[4], uh[4], ul[4];
     uint32_t mb[4];

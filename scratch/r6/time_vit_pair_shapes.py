@@ -36,8 +36,9 @@ tot = {}
 for key, (cnt, a, kw) in sorted(calls.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1][0]):
     M, N, K, flags, res, aux = key
     row = '%6d x %4d -> %4d flags %3d res %d aux %d x%3d:' % (M, K, N, flags, res, aux, cnt)
-    for s in (1, 3, 11):          # 11 = schedule 1 with the remainder split (RART_PAIR_SPLIT) on; 1 and 3 without
-        os.environ['RART_PAIR_SPLIT'] = '1' if s >= 10 else '0'
+    for s in (1, 11, 21):          # 1 = ping-pong alone; 11 = + remainder split (RART_PAIR_SPLIT); 21 = + 224-row tiles where they save a pass
+        os.environ['RART_PAIR_SPLIT'] = '1' if s == 11 else '0'
+        os.environ['RART_PAIR_ROWS224'] = '1' if s == 21 else '0'
         lib.rart_gemm_pair_set_schedule(s % 10)
         us = min(t_us(lambda: orig(*a, **kw)) for _ in range(3))
         tf = 6.0 * M * N * K / us / 1e6
@@ -46,6 +47,6 @@ for key, (cnt, a, kw) in sorted(calls.items(), key=lambda kv: -kv[0][0] * kv[0][
     by = (M * K + N * K + M * N * (1 + res + aux)) * 4
     row += '  %6.0f MB -> %4.0f us at 5 TB/s' % (by / 1e6, by / 5e6)
     lines.append(row); print(row, flush=True)
-lines.append('sum over a gradient evaluation: ping-pong %.1f ms, walked %.1f ms, ping-pong + remainder split %.1f ms' % (tot[1] / 1e3, tot[3] / 1e3, tot[11] / 1e3)); print(lines[-1])
+lines.append('sum over a gradient evaluation: ping-pong %.1f ms, + remainder split %.1f ms, + 224-row tiles %.1f ms' % (tot[1] / 1e3, tot[11] / 1e3, tot[21] / 1e3)); print(lines[-1])
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 open(os.path.join(ROOT, 'gpurun_out', 'r06_vit_pair_shapes.txt'), 'w').write('\n'.join(lines) + '\n')

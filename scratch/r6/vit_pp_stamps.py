@@ -10,6 +10,8 @@ from robustart_amd.model import get_model
 from robustart_amd.model.vit_engine import ViTEngine
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 lib = _lib.load()
+os.environ['RART_PAIR_SPLIT'] = '0'
+lib.rart_gemm_pair_set_schedule(int(os.environ.get('SCHED', 1)))
 torch.manual_seed(0)
 eng = ViTEngine(get_model({'type': 'vit_base_patch16_224'}).eval(), 'cuda', 'fp32x')
 x = torch.rand(256, 3, 224, 224, device='cuda'); y = torch.randint(0, 1000, (256,), device='cuda')

@@ -686,6 +686,40 @@ def test_pair_gemm_walked_tiles_are_bit_identical(conv, M, K, N, tile_n):
         lib.rart_gemm_pair_set_schedule(old)
 
 
+@pytest.mark.parametrize('conv,M,K,N,tile_n', [
+    ((4, 33, 32, 128), 4224, 1152, 512, 256),    # 3x3, 36 K steps, 19 tiles of 224 rows (the XCD enumeration), two column tiles
+    ((3, 12, 10, 32), 360, 288, 128, 128),       # two tiles, the second with 136 rows: its blocks past M AND its block past 224
+    (None, 224 * 9, 160, 256, 256),              # M a multiple of 224: the last tile is full
+    (None, 4103, 1024, 384, 128),                # 32 K steps, ragged rows and columns, 256 x 128 tiles
+    (None, 200, 64, 256, 256),                   # one tile shorter than 224 rows
+])
+def test_pair_gemm_224_row_tiles_are_bit_identical(conv, M, K, N, tile_n):
+    """Round 6: the ping-pong kernel with tiles that step 224 rows (tile_m = 224: the last 32-row block of a tile is neither multiplied nor
+    stored; chosen automatically where it saves a pass) against the two-stage loop on 256-row tiles: equal bit for bit, every row written
+    exactly once."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    d, out, sign, keep = _pair_schedule_case(lib, _lib, conv, M, K, N, tile_n, False, seed=51)
+    old = lib.rart_gemm_pair_get_schedule()
+    try:
+        _lib.check(lib.rart_gemm_pair_set_schedule(0))
+        _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        want, want_sign = out.view(torch.int16).clone(), sign.clone()
+        _lib.check(lib.rart_gemm_pair_set_schedule(1))
+        d.tile_m = 224
+        for rep in range(3):
+            out.fill_(float('nan'))
+            sign.zero_()
+            _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            bad = (out.view(torch.int16) != want).any(0).any(0)
+            assert not bad.any(), '224-row tiles differ (repetition %d): %d elements, first rows %s' % (rep, int(bad.sum()), bad.any(1).nonzero().flatten()[:8].tolist())
+            assert torch.equal(sign, want_sign)
+    finally:
+        lib.rart_gemm_pair_set_schedule(old)
+
+
 @pytest.mark.parametrize('M,K,N', [
     (197 * 256 - 37, 96, 768),       # ViT-B/16's geometry: 197 x 3 tiles = 75 per XCD -> 168 row tiles on 256 x 256, 29 (ragged) on 256 x 128
     (100 * 256, 64, 1000),           # 100 x 4 tiles, a ragged column tile in both launches (232 / 104 valid columns)
