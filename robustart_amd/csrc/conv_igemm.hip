@@ -598,6 +598,7 @@ struct RartGemm256Desc {
   const uint16_t* mask;   // F_GELU_BWD: the GELU's pre-activation [M][ldc]
   uint16_t* c;            // [M][ldc]
   int M, N, K, lda, ldc, flags;
+  int tile_rows;          // k_gemm256_pp: 256, or 224 = a tile steps 224 rows and leaves its last 32-row block out (csrc/gemm_pair.hip, round 6)
 };
 __device__ __attribute__((aligned(16))) const uint32_t g_gemm_zero16[4] = {0u, 0u, 0u, 0u};   // source of rows past M
 constexpr int G2_TM = 256, G2_TN = 256, G2_STAGE = (G2_TM + G2_TN) * 128, G2_LDE = 68;
@@ -606,7 +607,7 @@ static_assert(8 * 32 * G2_LDE * 4 <= 2 * G2_STAGE, "epilogue staging must fit th
 // Epilogue of a 256 x 256 tile of the transformer GEMMs (k_gemm256_bf16 and its ping-pong form): per wave, 32 rows x 64 columns at a time
 // through LDS -> 128-byte row segments; residual / GELU operands of a pass are requested before its transposition.  `lds`: the tile buffers
 // (free after the K loop); must be called by every thread.
-__device__ __forceinline__ void g2_epilogue(const RartGemm256Desc& d, uint8_t* lds, f32x16 (&acc)[4][2], int m0, int n0) {
+__device__ __forceinline__ void g2_epilogue(const RartGemm256Desc& d, uint8_t* lds, f32x16 (&acc)[4][2], int m0, int n0, int tile_rows = 256) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 31, h = lane >> 5;
   float* sE = reinterpret_cast<float*>(lds) + wave * 32 * G2_LDE;
@@ -614,6 +615,7 @@ __device__ __forceinline__ void g2_epilogue(const RartGemm256Desc& d, uint8_t* l
   const int col = n0 + wn * 64 + cw * 8;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (wm * 128 + i * 32 >= tile_rows) continue;         // (wave-uniform) a 224-row tile: the block belongs to the next tile
     uint4 rv[4], mv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -785,8 +787,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm256_pp(const RartGemm256Desc d) 
   const int n_tiles = d.N / G2_TN;
   const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
   const int m_tile = (slot / n_tiles) * 8 + xcd, n_tile = slot % n_tiles;
-  if (m_tile * G2_TM >= d.M) return;
-  const int m0 = m_tile * G2_TM, n0 = n_tile * G2_TN;
+  const int TMV = d.tile_rows;
+  if (m_tile * TMV >= d.M) return;
+  const int m0 = m_tile * TMV, n0 = n_tile * G2_TN;
+  const bool skip_last = wm == 1 && TMV < G2_TM;         // (wave-uniform) rows 224 .. 255 of a 224-row tile are the next tile's
   // ---- loader: a piece = 8 rows x 128 B (lane -> row lane >> 3, slot lane & 7 <- the row's chunk (lane & 7) ^ ((row >> 1) & 7)).  A wave
   //      loads A rows of the OTHER group only: pieces 2 w4, 2 w4 + 1 of its two 64-row regions (q = 0: half `og`, refilled in M0; q = 1:
   //      half `g`, refilled in M1), and W pieces 4 w4 .. 4 w4 + 3 of its OWN group's 128 W rows (the first two in M1, the last two in M0)
@@ -847,12 +851,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm256_pp(const RartGemm256Desc d) 
   if (g) g2_slot_end();                     // the stagger: group 1 runs one slot behind group 0
   bf16x8 af[2][4], bfr[2][4];
 #define RART_G2P_READ_A(HALF)                                                                                    \
-  _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)             \
-      af[ii][ks] = *reinterpret_cast<const bf16x8*>(Ab + ((HALF)*2 + ii) * 32 * 128 + xo[ks]);
+  _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) if (!((HALF) == 1 && ii == 1 && skip_last))                  \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                          \
+          af[ii][ks] = *reinterpret_cast<const bf16x8*>(Ab + ((HALF)*2 + ii) * 32 * 128 + xo[ks]);
 #define RART_G2P_MFMA(HALF)                                                                                      \
   __builtin_amdgcn_s_setprio(1);                                                                                 \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)             \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+      if (!((HALF) == 1 && ii == 1 && skip_last)) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
           acc[(HALF)*2 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][ks], bfr[j][ks], acc[(HALF)*2 + ii][j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);
   for (int kt = 0; kt < KT; ++kt) {
@@ -897,7 +902,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256_pp(const RartGemm256Desc d) 
 #undef RART_G2P_ISSUE_A
   rart_dma_wait<0>();
   __syncthreads();
-  g2_epilogue(d, lds, acc, m0, n0);
+  g2_epilogue(d, lds, acc, m0, n0, TMV);
 }
 }  // namespace
 
@@ -911,6 +916,7 @@ extern "C" int rart_igemm_set_bk64_min_k(long long k) {
 // tuning knob (tests / profiling): 0 keeps every problem on the 128 x 128 kernel, 1 = the 256 x 256 x 64 kernel on round 2's two-stage loop,
 // 2 (default) = the same kernel on the ping-pong schedule of round 6 (bit-identical outputs)
 static int g_gemm256_enabled = 2;
+static const int g_gemm256_rows224 = getenv("RART_GEMM256_ROWS224") ? atoi(getenv("RART_GEMM256_ROWS224")) : 1;    // lab switch
 extern "C" int rart_igemm_set_gemm256(int enable) {
   g_gemm256_enabled = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   return RART_OK;
@@ -958,9 +964,22 @@ extern "C" int rart_conv_igemm_bf16(const rart_conv_desc* h, rart_stream_t strea
       g.a = (const uint16_t*)h->src; g.w = (const uint16_t*)h->wgt; g.bias = h->bias; g.res = (const uint16_t*)h->res;
       g.mask = (const uint16_t*)h->mask; g.c = (uint16_t*)h->dst;
       g.M = (int)gm; g.N = h->n_cols; g.K = h->k_per_tap; g.lda = h->src_pix_stride; g.ldc = h->dst_pix_stride; g.flags = h->flags;
-      const int m_tiles = (int)((gm + G2_TM - 1) / G2_TM), m8 = (m_tiles + 7) / 8 * 8;
+      g.tile_rows = G2_TM;
+      int m_tiles = (int)((gm + G2_TM - 1) / G2_TM), m8 = (m_tiles + 7) / 8 * 8;
       // the ping-pong form addresses its operands with 32-bit byte offsets (planes below 2 GiB: gemm256_takes checked 2^31 ELEMENTS)
       const bool pp = g_gemm256_enabled == 2 && gm * h->src_pix_stride < (1ll << 30) && (long long)g.N * g.K < (1ll << 30);
+      if (pp && g_gemm256_rows224) {
+        // a launch runs in passes of one tile per CU and XCD (workgroup i -> XCD i % 8, 32 CUs each; csrc/gemm_pair.hip, round 6): tiles that
+        // step 224 rows where that does not add a pass -- ViT-B/16's 50432 x 768 outputs: 75 tiles of 256 rows or 87 of 224 per XCD, three
+        // passes either way, 7/8 of the matrix work per tile
+        const int n_t = g.N / G2_TN, mt224 = (int)((gm + 223) / 224);
+        auto passes = [&](int mt) { return ((mt + 7) / 8 * n_t + 31) / 32; };
+        if (passes(mt224) * 0.92 < passes(m_tiles) - 0.01) {
+          g.tile_rows = 224;
+          m_tiles = mt224;
+          m8 = (m_tiles + 7) / 8 * 8;
+        }
+      }
       if (pp) hipLaunchKernelGGL(k_gemm256_pp, dim3((uint32_t)(m8 * (g.N / G2_TN))), dim3(512), 0, (hipStream_t)stream, g);
       else hipLaunchKernelGGL(k_gemm256_bf16, dim3((uint32_t)(m8 * (g.N / G2_TN))), dim3(512), 0, (hipStream_t)stream, g);
       RART_CHECK_LAUNCH("rart_conv_igemm_bf16 (256 x 256 GEMM)");
