@@ -37,3 +37,16 @@ python $R/profiles/summarize_rocpd.py $(find /tmp/prof_vit -name "*.db" | head -
 python $R/scratch/r6/time_pair_pp.py > $O/r06_pair_pp.log 2>&1; cp $R/gpurun_out/r06_pair_pp.json $O/r06_pair_pp.json
 python $R/scratch/r6/time_gemm256.py > $O/r06_gemm256_pp.txt 2>&1
 ls -la $O
+# 11. (second half of round 6) ViT-B/16 reference precision: per-shape table of the pair GEMM (ping-pong / + remainder split / + 224-row tiles), kernel
+#     trace + SQ counters of three gradient evaluations; the pass-quantisation probes
+python $R/scratch/r6/time_vit_pair_shapes.py > /dev/null 2>&1; cp $R/gpurun_out/r06_vit_pair_shapes.txt $O/r06_vit_pair_shapes.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_vx -o v -- python $R/scratch/r6/one_vit_x3_grad_eval.py > /dev/null 2>&1
+python $R/profiles/summarize_rocpd.py $(find /tmp/prof_vx -name "*.db" | head -1) $O/r06_vit_x3_kernel_stats.csv > /dev/null
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/prof_vc -o c -- python $R/scratch/r6/one_vit_x3_grad_eval.py > /dev/null 2>&1
+python $R/profiles/summarize_counters.py $(find /tmp/prof_vc -name "*.db" | head -1) $O/r06_vit_x3_counters.json > /dev/null
+python $R/scratch/r6/time_pair_rounds.py > $O/r06_pair_rounds.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d /tmp/prof_rd -o c -- python $R/scratch/r6/pair_rounds_target.py > /dev/null 2>&1
+python $R/scratch/r6/pmc_per_dispatch.py $(find /tmp/prof_rd -name "*.db" | head -1) gemm_pair > $O/r06_pair_rounds_counters.txt
+python $R/scratch/r6/batch_sweep_x3.py 224 240 244 248 252 256 260 272 288 320 > $O/r06_batch_sweep_x3.txt 2>&1
+python $R/scratch/r6/vit_pp_trace.py > $O/r06_vit_pp_trace.txt 2>&1
+ls -la $O
