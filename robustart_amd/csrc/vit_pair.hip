@@ -294,6 +294,12 @@ constexpr int kAttBlock = 512;
 //  item boundary, the next Q into the registers the current Q released -- was written too and spilled 162: the allocator keeps the staged planes and the
 //  score registers apart for the whole item.  What is left for this kernel (5 % of a reference-precision ViT-B/16 gradient evaluation) is a prefetch
 //  through LDS, i.e. K / V tiles small enough for two buffers.)
+#ifdef RART_ATT_STAMPS
+__device__ unsigned long long g_att_stamps[4096][8][4];       // lab build, per workgroup and wave: [0] staging, [1] Q load + S, [2] soft-max + PV, [3] stores, [4] wave-tiles, [5] workgroups, [6] whole
+#define ATT_T(V) const unsigned long long V = __builtin_amdgcn_s_memtime();
+#else
+#define ATT_T(V)
+#endif
 template <int NKT>
 __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
                                                                   uint16_t* __restrict__ att_h, uint16_t* __restrict__ att_l, int T, int H,
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
   const size_t boff = (size_t)b * T * ld + h * PATT_HD;
   const uint16_t* const base[2] = {qkv_h + boff, qkv_l + boff};
+  ATT_T(t_a)
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     for (int i = tid; i < TP * 8; i += kAttBlock) {                       // K rows: 16-byte chunks, coalesced
@@ -334,7 +341,11 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint1
     }
   }
   __syncthreads();
+  ATT_T(t_b)
+#ifdef RART_ATT_STAMPS
+#endif
   for (int qt = wave; qt < NKT; qt += kAttBlock / 64) {
+    ATT_T(t_c)
     const int q = qt * 32 + l31;
     bf16x8 bqh[4], bql[4];
 #pragma unroll
@@ -364,6 +375,7 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint1
     }
     // sacc[kt][r] = q . k for key kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q.  Keys past the sequence must not win the maximum: only
     // the LAST key tile can hold any (the host picks NKT = ceil(T / 32))
+    ATT_T(t_d)
     float m = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -411,6 +423,7 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint1
       __builtin_amdgcn_sched_barrier(0);
     }
     sum += __shfl_xor(sum, 32, 64);
+    ATT_T(t_e)
     const float inv = 1.0f / sum;
     // o[nt][r] = O[query q][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]: a lane owns runs of four channels of ITS query -> 8-byte stores per plane
     if (q < T) {
@@ -426,6 +439,14 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint1
           *reinterpret_cast<uint2*>(att_l + ro + nt * 32 + 8 * g + 4 * hh) = vl;
         }
     }
+#ifdef RART_ATT_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    ATT_T(t_f)
+    if (lane == 0 && blockIdx.x < 4096) {
+      unsigned long long* o = g_att_stamps[blockIdx.x][wave];
+      o[0] = t_b - t_a; o[1] = t_d - t_c; o[2] = t_e - t_d; o[3] = t_f - t_e;
+    }
+#endif
   }
 }
 
@@ -850,3 +871,10 @@ int rart_vit_attention_bwd_pair(const void* qkv_hi, const void* qkv_lo, const vo
 }
 
 }  // extern "C"
+
+#ifdef RART_ATT_STAMPS
+extern "C" int rart_debug_att_stamps(unsigned long long* out) {      // lab build only: out[4096][8][4]
+  if (hipDeviceSynchronize() != hipSuccess) return RART_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_att_stamps), sizeof(unsigned long long) * 4096 * 8 * 4) == hipSuccess ? RART_OK : RART_ERR_HIP;
+}
+#endif
