@@ -61,7 +61,8 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
     a_hi += ao; a_lo += ao; w_hi += wo; w_lo += wo;
     c_off = zo * d.c_zo + zi * d.c_zi;
   }
-  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M + TM - 1) / TM;
+  const int TMV = d.tile_rows;                    // TM, or TM - 32 (round 6): a tile steps TMV rows, its last 32-row block is left out
+  const int n_tiles = (d.N + TN - 1) / TN, m_tiles = (d.M + TMV - 1) / TMV;
   int m_tile, n_tile;
   if (m_tiles >= 16) {
     // all column tiles of a row tile on one XCD (the A tile is re-read from its L2)
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
     m_tile = blockIdx.x / n_tiles;
     n_tile = blockIdx.x - m_tile * n_tiles;
   }
-  const int m0 = m_tile * TM, n0 = n_tile * TN;
+  const int m0 = m_tile * TMV, n0 = n_tile * TN;
 
   // ---- loader: a plane goes to LDS in 1 KiB pieces (16 rows x 64 B); wave w brings pieces w and w + 8; lane -> row (lane >> 2),
   //      LDS chunk (lane & 3) <- the row's chunk (lane & 3) ^ ((row >> 2) & 3).
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
   }
   const int KT = d.K / GP_BK;
+  const bool skip_last = wm * RW + MI * 32 > TMV;      // (wave-uniform) this wave's last row block lies past the tile's rows
   RART_GP_ISSUE(0, 0)
   rart_dma_wait<0>();
   __syncthreads();
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
       bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        if (i == MI - 1 && skip_last) continue;
         ah[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 32 * 64 + xo[ks]);
         al[i] = *reinterpret_cast<const bf16x8*>(Ah + GP_PLANE_A + i * 32 * 64 + xo[ks]);
       }
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          if (i == MI - 1 && skip_last) continue;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(TM * 2, 1) void k_gemm_pair(const GemmPairDev d) {
     __syncthreads();
   }
 #undef RART_GP_ISSUE
-  gp_epilogue<TM, TN, CONV, MI>(d, lds, acc, m0, n0, c_off);
+  gp_epilogue<TM, TN, CONV, MI>(d, lds, acc, m0, n0, c_off, TMV);
 }
 
 // 1 (default): the 256-row tiles with 128 / 256 columns run the ping-pong schedule of csrc/gemm_pair_pp.hip; 2 (opt-in, measured slower): as 1,
@@ -442,7 +446,19 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
     RART_CHECK_LAUNCH("rart_gemm_pair_bf16 (ping-pong)");
     return RART_OK;
   }
-#define RART_GP_LAUNCH(TM_, TN_, CONV_) hipLaunchKernelGGL((k_gemm_pair<TM_, TN_, CONV_>), grid, dim3(TM_ * 2), 0, st, d)
+  // the two-stage kernel: tiles that step tm - 32 rows where that saves work per pass (resident workgroups per CU by LDS: 2 x STAGE bytes each)
+  d.tile_rows = tm;
+  dim3 grid2 = grid;
+  if (gp_rows224() >= 2 && nz == 1 && h->tile_m == 0 && h->tile_n == 0 && gp_schedule() >= 1) {
+    const int lds = 2 * (2 * tm * 64 + 2 * tn * 64), res = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3), cx = gp_cu_count() / 8 * res;
+    auto passes = [&](int mt) { return ((mt >= 16 ? (mt + 7) / 8 * n_tiles : (mt * n_tiles + 7) / 8) + cx - 1) / cx; };
+    const int rows = tm - 32, mt2 = (d.M + rows - 1) / rows;
+    if (passes(mt2) * (double)rows / tm * 1.03 < passes(m_tiles)) {
+      d.tile_rows = rows;
+      grid2 = dim3((uint32_t)((mt2 >= 16 ? (mt2 + 7) / 8 * 8 : mt2) * n_tiles), nz);
+    }
+  }
+#define RART_GP_LAUNCH(TM_, TN_, CONV_) hipLaunchKernelGGL((k_gemm_pair<TM_, TN_, CONV_>), grid2, dim3(TM_ * 2), 0, st, d)
 #define RART_GP_BY_TN(TM_, CONV_)                                          \
   do {                                                                     \
     if (tn == 64) RART_GP_LAUNCH(TM_, 64, CONV_);                          \
