@@ -71,6 +71,42 @@ def _gelu64(v):
     return 0.5 * v * (1 + torch.erf(v / 2 ** 0.5))
 
 
+def test_pair_epilogue_gelu_and_its_derivative_on_a_dense_grid():
+    """Round 6: the GELU / GELU' of the pair GEMM's epilogue are a fitted erfc form (csrc/rart_gemm_pair_dev.h) instead of libm's erff.  Pin
+    the functions THEMSELVES on the GPU (v_rcp_f32 / v_exp_f32 included): the product is arranged to reproduce a controlled pre-activation u
+    exactly (one non-zero per row of A, unit weights: u is a pair, u . 1 has no rounding), u runs over a dense grid of [-12, 12] plus the
+    points around 0 and the tails; against fp64: |gelu error| <= 5e-7 + 2^-16 |gelu| (the output pair's rounding), same for gelu'."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    M, N, K = 1 << 16, 8, 32
+    u64 = torch.cat([torch.linspace(-12, 12, M - 2048, dtype=torch.float64), torch.linspace(-1e-3, 1e-3, 1024, dtype=torch.float64),
+                     torch.linspace(-6.7, -5.0, 512, dtype=torch.float64), torch.linspace(5.0, 6.7, 512, dtype=torch.float64)]).cuda()
+    a32 = torch.zeros(M, K, device='cuda')
+    a32[:, 0] = u64.float()
+    a = _split(a32)
+    u = _f64(a)[:, 0]                                        # the value the pair represents: what the epilogue sees
+    w32 = torch.zeros(N, K, device='cuda')
+    w32[:, 0] = 1.0
+    w = _split(w32)
+    out = torch.full((2, M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+    assert _gemm_pair(lib, a, w, out, M, N, K, K, N, flags=4) == 0
+    g = _f64(out)
+    want = _gelu64(u)[:, None]
+    err = (g - want).abs()
+    print('gelu: max |error| %.3e' % err.max().item())
+    assert (err <= 5e-7 + want.abs() * 2.0 ** -16).all()
+    assert (g[:, :1] == g).all()                             # every column saw the same u
+    # GELU': dst = (A . W) * gelu'(aux) with A . W = 1
+    ones32 = torch.zeros(M, K, device='cuda')
+    ones32[:, 0] = 1.0
+    aux = torch.stack([a[0][:, :1].expand(M, N).contiguous(), a[1][:, :1].expand(M, N).contiguous()])
+    assert _gemm_pair(lib, _split(ones32), w, out, M, N, K, K, N, flags=8, aux=aux) == 0
+    gp = 0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5
+    err = (_f64(out) - gp[:, None]).abs()
+    print("gelu': max |error| %.3e" % err.max().item())
+    assert (err <= 5e-7 + gp.abs()[:, None] * 2.0 ** -16).all()
+
+
 @pytest.mark.parametrize('M,N,K', [(700, 768, 768), (5000, 512, 96), (197, 200, 64)])
 def test_gemm_pair_kernel_vs_fp64(M, N, K):
     """rart_gemm_pair_bf16: plain product with bias + residual pair, the three GELU modes, fp32 output, against fp64 of the same hi / lo
