@@ -362,7 +362,8 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
     if (gp_schedule() >= 1 && d.N >= 256 && (d.K >= 512 || (d.K >= 256 && d.N <= 512))) {
       // round 6 (scratch/r6/time_pair_pp.py --tiles, profiles/r06_pair_pp.json): with the ping-pong schedule the 256-row tiles win wherever
       // the layer is at least 256 wide and 256 deep -- 256 x 256 unless that leaves fewer than 128 workgroups (layer4: 256 x 128); the one
-      // exception measured: K = 256 into >= 1024 columns (layer3's expansion: epilogue-bound, 155-165 us on 256 x 64 vs 166-176)
+      // exception measured: K = 256 into >= 1024 columns (layer3's expansion: epilogue-bound, 155-165 us on 256 x 64 vs 166-176).  128-column
+      // layers (layer2's 3 x 3 once its tail kernel is off) stay on the two-stage 128 x 128 tiles: 19.97 vs 20.14 ms on 256 x 128 ping-pong
       tm = 256;
       tn = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256) < 128 ? 128 : 256;
     } else if (d.K <= 256) { tm = 256; tn = 64; }

@@ -172,6 +172,10 @@ class ResNet50Engine:
         self.pair_tile = (0, 0)
         self.fused_next_pair = True      # reference-precision mode: ... and the neighbouring block's 1x1 reduction in the same launch; False: its own launch (cross-check)
         self.fused_next_channels = (64,)  # ... for these mid-channel counts (measured at B = 256: layer1 -0.35 ms per gradient evaluation; layer2's instance sits at 256 VGPRs and loses 0.6 ms)
+        # ... for 3x3 layers of these widths (layer1 = 64, layer2 = 128).  Round 6: layer2 left the list -- with the ping-pong kernels and the
+        # 224-row tiles its two launches are faster than its tail kernel at B = 256 (196 workgroups per XCD on 64 resident: 3.06 passes):
+        # 20.12 -> 19.98 ms per gradient evaluation, same bits (scratch/r6/tail_channels.py)
+        self.fused_tail_channels = (64,)
         self.fused_tail_pair = True      # reference-precision mode: 3x3 + 1x1 expansion of a Bottleneck as one launch (conv_tail_pair.hip); False: two launches (cross-check)
         self.pair_gemm_kernel = True     # reference-precision mode: False = the three products as 3 x the taps of the implicit GEMM (round 3; cross-check)
         self.blocks = []
@@ -986,7 +990,8 @@ class ResNet50Engine:
         pre_a = False            # this block's conv1 was already computed by the previous block's launch
         for bi, (ca, cb, cc, ds) in enumerate(self.blocks):
             ohw = (xhw[0] // cb.stride, xhw[1] // cb.stride)
-            tail = self.fused_tail_pair and getattr(cc, 'tail_fwd', None) is not None and self._fits32(B, ohw, cc.cout)
+            tail = (self.fused_tail_pair and cb.cout in self.fused_tail_channels and getattr(cc, 'tail_fwd', None) is not None
+                    and self._fits32(B, ohw, cc.cout))
             ya = self._get('x3_b%d_a' % bi, (2, B, xhw[0], xhw[1], ca.cout))
             yb = None if tail else self._get('x3_b%d_b' % bi, (2, B, ohw[0], ohw[1], cb.cout))
             yc = self._get('x3_b%d_c' % bi, (2, B, ohw[0], ohw[1], cc.cout))
@@ -1052,8 +1057,8 @@ class ResNet50Engine:
                 self._conv_bwd(cc, dz, ohw, dzb, ohw, mask=mb, pair=True)
             pre_b = False
             dx = self._get('x3_g_out_%d' % (bi - 1), tuple(x.shape))
-            if (self.fused_tail_pair and getattr(ca, 'tail_bwd', None) is not None and ma is not None and mx is not None
-                    and self._fits32(B, xhw, ca.cin)):
+            if (self.fused_tail_pair and cb.cin in self.fused_tail_channels and getattr(ca, 'tail_bwd', None) is not None and ma is not None
+                    and mx is not None and self._fits32(B, xhw, ca.cin)):
                 # conv2^T + mask + conv1^T + identity-skip gradient + mask in one launch
                 nxt = None
                 pc = self.blocks[bi - 1][2] if bi > 0 else None

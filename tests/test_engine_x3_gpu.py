@@ -509,6 +509,17 @@ def test_x3_fused_tail_matches_the_two_launch_path(setup):
     x = torch.rand(3, 3, 96, 128, generator=g).cuda()
     y = torch.randint(0, 1000, (3,), generator=g).cuda()
     assert eng.fused_tail_pair and getattr(eng.blocks[1][2], 'tail_fwd', None) is not None and getattr(eng.blocks[1][0], 'tail_bwd', None) is not None
+    # (round 6: the engine's default keeps layer2 on two launches -- faster at B = 256 -- so the test switches its tail kernel on)
+    default_channels = eng.fused_tail_channels
+    eng.fused_tail_channels = (64, 128)
+    request_restore = lambda: setattr(eng, 'fused_tail_channels', default_channels)
+    try:
+        _x3_fused_tail_body(eng, x, y)
+    finally:
+        request_restore()
+
+
+def _x3_fused_tail_body(eng, x, y):
     la, _, ga, _ = eng.forward_backward(x, MEAN, STD, y, 0)
     la, ga = la.clone(), ga.clone()
     signs_a = {k: v.clone() for k, v in eng._buf.items() if k.endswith('_sign')}
