@@ -801,7 +801,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm256_pp(const RartGemm256Desc d) 
     for (int p = 0; p < 2; ++p) {
       const int r = og * 128 + (q == 0 ? og : g) * 64 + 8 * (2 * w4 + p) + (lane >> 3);
       const int csrc = (lane & 7) ^ ((r >> 1) & 7);
-      av[q][p] = (m0 + r < d.M) ? (uint32_t)(((m0 + r) * d.lda + csrc * 8) * 2) : RART_DMA_OOR;
+      av[q][p] = (m0 + r < d.M && r < TMV) ? (uint32_t)(((m0 + r) * d.lda + csrc * 8) * 2) : RART_DMA_OOR;   // (rows past a 224-row tile: not fetched)
     }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pair_pp(const GemmPairDev d) {
       const int r = pr[q] + (lane >> 2);                                                                         \
       const int csrc = (lane & 3) ^ ((r >> 2) & 3);                                                              \
       const int m = (M0_) + r;                                                                                   \
-      const bool ok = m < d.M;                                                                                   \
+      const bool ok = m < d.M && r < TMV;      /* rows past a 224-row tile are the next tile's: zero-filled, not fetched */ \
       if (CONV) {                                                                                                \
         const uint32_t mm = ok ? (uint32_t)m : 0u;                                                               \
         const uint32_t t = gp_fastdiv(mm, d.gw_magic, d.gw_shift);                                               \
