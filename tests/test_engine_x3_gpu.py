@@ -731,6 +731,31 @@ def test_pair_gemm_224_row_tiles_are_bit_identical(conv, M, K, N, tile_n):
         lib.rart_gemm_pair_set_schedule(old)
 
 
+@pytest.mark.parametrize('M,K,N', [(25 * 256 + 70, 64, 1024), (3300, 256, 64), (17 * 128 + 5, 96, 192)])
+def test_pair_gemm_two_stage_short_row_tiles_are_bit_identical(M, K, N, monkeypatch):
+    """The lab level RART_PAIR_ROWS224=2 (tiles that step TM - 32 rows in the two-stage k_gemm_pair where the pass arithmetic says so; measured
+    slower on ResNet-50, off by default) must still produce the same bits: every row written exactly once, the block a tile leaves out
+    computed by the next tile."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    d, out, sign, keep = _pair_schedule_case(lib, _lib, None, M, K, N, 0, False, seed=61)
+    d.tile_m = 0
+    old = lib.rart_gemm_pair_get_schedule()
+    try:
+        res = []
+        for sched, level in ((0, '0'), (1, '2'), (1, '2')):
+            monkeypatch.setenv('RART_PAIR_ROWS224', level)
+            _lib.check(lib.rart_gemm_pair_set_schedule(sched))
+            out.fill_(float('nan'))
+            _lib.check(lib.rart_gemm_pair_bf16(ctypes.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all()
+            res.append(out.view(torch.int16).clone())
+        assert torch.equal(res[1], res[0]) and torch.equal(res[2], res[0])
+    finally:
+        lib.rart_gemm_pair_set_schedule(old)
+
+
 @pytest.mark.parametrize('M,K,N', [
     (197 * 256 - 37, 96, 768),       # ViT-B/16's geometry: 197 x 3 tiles = 75 per XCD -> 168 row tiles on 256 x 256, 29 (ragged) on 256 x 128
     (100 * 256, 64, 1000),           # 100 x 4 tiles, a ragged column tile in both launches (232 / 104 valid columns)
