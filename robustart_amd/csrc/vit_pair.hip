@@ -6,6 +6,8 @@
 // (exprs/exp/imagenet_c_loop_mini/config_vit_base.yaml:1-9: no precision key; adv/attack.py:20-23; autopgd_base.py:271-289); model
 // `vit_base` = timm ViT-B/16 (RobustART/model/__init__.py:1 -> absent submodule; robustart_amd/model/vit_torch.py).
 #include "rart_common.h"
+#include <stdlib.h>
+#include "rart_lds_dma.h"
 
 namespace {
 constexpr int kBlock = 256;
@@ -450,6 +452,176 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair(const uint1
   }
 }
 
+// ---- the forward again, WALKING (round 6): one workgroup per CU takes a run of (image, head) items; K and V of the NEXT item arrive while the
+//      current one computes.  The phase stamps of k_vit_attention_pair (scratch/r6/att_stamps.py) put 45 % of a workgroup's time in the K / V
+//      staging, with nothing running beside it: 16 k of 35 k cycles.  Here wave 7 -- the one without a query tile at 197 tokens -- is the loader:
+//      both operands go to LDS ROW-MAJOR ([token][72], the K image of the kernel above) with buffer_load ... lds (rart_lds_dma.h: lane -> 16-byte
+//      chunk c of the padded image, token c / 9, chunk c % 9, the ninth chunk and the tokens past T zero-filled by the range check; the
+//      per-lane offsets are item-invariant, the item moves the scalar offset), K of item i + 1 during soft-max + P V of item i, V of item i + 1
+//      during S = K Q^T of item i + 1, two barriers per item.  V is no longer transposed on the way in: the A fragments of O^T = V^T P^T are
+//      gathered from the row-major image with 2-byte reads (patt_tr_frag, as the backward kernels do).  Same products in the same order as
+//      k_vit_attention_pair: bit-identical output.  Taken for seven key tiles (193 .. 224 tokens) and at least four items per CU.
+__device__ __forceinline__ bf16x8 patt_tr_frag(const uint16_t* s, int t0, int d);
+template <int NKT>
+__global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair_walk(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+                                                                       uint16_t* __restrict__ att_h, uint16_t* __restrict__ att_l, int T, int H,
+                                                                       int ld, int D, float scale_log2e, int n_items) {
+  constexpr int TP = NKT * 32;
+  constexpr int NI = (TP * 9 + 63) / 64;                   // DMA instructions per plane (1 KiB of the padded image each)
+  constexpr int PLANE = NI * 1024 / 2;                     // elements per plane buffer (the last instruction's tail included)
+  static_assert(NKT <= 7, "wave 7 is the loader");
+  __shared__ __attribute__((aligned(16))) uint16_t sK[2][PLANE];
+  __shared__ __attribute__((aligned(16))) uint16_t sV[2][PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave == 7;
+  // items blockIdx.x, blockIdx.x + gridDim.x, ...: at any moment neighbouring workgroups hold the heads of ONE image (the 128-byte pieces of a
+  // token row they read lie in one DRAM page), as the dispatch order of the one-item kernel had it
+  const int first = blockIdx.x, last = n_items, step = gridDim.x;
+  if (first >= last) return;
+  const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sK[0][0];
+  const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sV[0][0];
+  const rart_srd_t srd_h = rart_dma_srd(qkv_h), srd_l = rart_dma_srd(qkv_l);
+  // byte offset of item `it`'s (image, head) block inside a plane
+#define RART_AW_ITEM_OFF(IT) ((uint32_t)((((long long)((IT) / H) * T) * ld + ((IT) % H) * PATT_HD) * 2))
+#define RART_AW_LOAD(LDS_, IT, COL)                                                                              \
+  {                                                                                                              \
+    const uint32_t so_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(RART_AW_ITEM_OFF(IT) + (uint32_t)((COL)*2)));   \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {      /* (the loader wave has nothing else to do: offsets on the fly) */ \
+      const int c_ = 64 * i + lane, t_ = c_ / 9, cc_ = c_ - 9 * t_;                                              \
+      const uint32_t vo_ = (cc_ < 8 && t_ < T) ? (uint32_t)((t_ * ld + cc_ * 8) * 2) : RART_DMA_OOR;             \
+      rart_dma_load16(vo_, srd_h, so_, (LDS_) + i * 1024);                                                       \
+      rart_dma_load16(vo_, srd_l, so_, (LDS_) + PLANE * 2 + i * 1024);                                           \
+    }                                                                                                            \
+  }
+#define RART_AW_BARRIER()                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+  __builtin_amdgcn_s_barrier();                                                                                  \
+  asm volatile("" ::: "memory");
+  if (loader) {
+    // ---- the loader wave: K and V of the first item, then per item K of the next one during phase 2 and its V during the next phase 1
+    RART_AW_LOAD(k_lds, first, D)
+    RART_AW_LOAD(v_lds, first, 2 * D)
+    rart_dma_wait<0>();
+    RART_AW_BARRIER()
+    for (int it = first; it < last; it += step) {
+      const bool more = it + step < last;
+      rart_dma_wait<0>();                               // V of this item
+      RART_AW_BARRIER()                                 // (B1) every wave is done with K; V is visible
+      if (more) RART_AW_LOAD(k_lds, it + step, D)
+      rart_dma_wait<0>();                               // K of the next item
+      RART_AW_BARRIER()                                 // (B2) every wave is done with V; the next K is visible
+      if (more) RART_AW_LOAD(v_lds, it + step, 2 * D)
+    }
+    return;
+  }
+  RART_AW_BARRIER()
+  const bool tile = wave < NKT;
+  const int q = wave * 32 + l31;
+  bf16x8 bqh[4], bql[4];                                // the wave's Q fragments of the CURRENT item (requested during the previous item's stores)
+#define RART_AW_LOAD_Q(IT)                                                                                       \
+  if (tile) {                                                                                                    \
+    const size_t bo_ = ((size_t)((IT) / H) * T) * ld + ((IT) % H) * PATT_HD;                                     \
+    _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                          \
+      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);                                            \
+      if (q < T) {                                                                                               \
+        vh = *reinterpret_cast<const uint4*>(qkv_h + bo_ + (size_t)q * ld + kb * 16 + hh * 8);                   \
+        vl = *reinterpret_cast<const uint4*>(qkv_l + bo_ + (size_t)q * ld + kb * 16 + hh * 8);                   \
+      }                                                                                                          \
+      bqh[kb] = *reinterpret_cast<bf16x8*>(&vh);                                                                 \
+      bql[kb] = *reinterpret_cast<bf16x8*>(&vl);                                                                 \
+    }                                                                                                            \
+  }
+  for (int it = first; it < last; it += step) {
+    RART_AW_LOAD_Q(it)
+    // ---- phase 1: S^T = K Q^T
+    f32x16 sacc[NKT];
+    if (tile) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sK[0][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sK[1][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqh[kb], sacc[kt], 0, 0, 0);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bql[kb], sacc[kt], 0, 0, 0);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqh[kb], sacc[kt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    RART_AW_BARRIER()                                   // (B1)
+    // ---- phase 2: soft-max + O^T = V^T P^T + stores
+    if (tile) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= T) sacc[NKT - 1][r] = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kt][r]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const float mneg = -m * scale_log2e;
+      float sum = 0.f;
+      f32x16 o[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        uint32_t ph[8], pl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][2 * j], scale_log2e, mneg));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][2 * j + 1], scale_log2e, mneg));
+          sum += e0 + e1;
+          ph[j] = pk2(e0, e1);
+          pl[j] = pk2(e0 - __uint_as_float(ph[j] << 16), e1 - __uint_as_float(ph[j] & 0xFFFF0000u));
+        }
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+          uint4 pvh = make_uint4(ph[4 * kb2], ph[4 * kb2 + 1], ph[4 * kb2 + 2], ph[4 * kb2 + 3]);
+          uint4 pvl = make_uint4(pl[4 * kb2], pl[4 * kb2 + 1], pl[4 * kb2 + 2], pl[4 * kb2 + 3]);
+          const bf16x8 pbh = *reinterpret_cast<bf16x8*>(&pvh), pbl = *reinterpret_cast<bf16x8*>(&pvl);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const bf16x8 ah = patt_tr_frag(sV[0], kt * 32 + 16 * kb2 + 4 * hh, nt * 32 + l31);
+            const bf16x8 al = patt_tr_frag(sV[1], kt * 32 + 16 * kb2 + 4 * hh, nt * 32 + l31);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pbh, o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pbl, o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pbh, o[nt], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+      if (q < T) {
+        const size_t ro = ((size_t)(it / H) * T + q) * D + (it % H) * PATT_HD;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float v[4] = {o[nt][4 * g] * inv, o[nt][4 * g + 1] * inv, o[nt][4 * g + 2] * inv, o[nt][4 * g + 3] * inv};
+            uint2 vh, vl;
+            split4(v, vh, vl);
+            *reinterpret_cast<uint2*>(att_h + ro + nt * 32 + 8 * g + 4 * hh) = vh;
+            *reinterpret_cast<uint2*>(att_l + ro + nt * 32 + 8 * g + 4 * hh) = vl;
+          }
+      }
+    }
+    RART_AW_BARRIER()                                   // (B2)
+  }
+#undef RART_AW_BARRIER
+#undef RART_AW_LOAD_Q
+#undef RART_AW_LOAD
+#undef RART_AW_ITEM_OFF
+}
+
 // ---- fused attention BACKWARD on pairs: two kernels, one workgroup per (image, head) each -----------------------------------------------
 // dQ, dK, dV of softmax(Q K^T / sqrt(d)) V from the Q, K, V, O (the forward's output) and dO pairs.  The bf16 kernel (k_vit_attention_bwd,
 // csrc/vit_aux.hip) keeps Q, K, V, dO and two transposed copies in 158 KB of LDS; as pairs that is twice what a CU has, so the two phases
@@ -824,6 +996,20 @@ int rart_vit_attention_pair(const void* qkv_hi, const void* qkv_lo, void* out_hi
   const float scale_log2e = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
   const dim3 grid((uint32_t)(n * heads));
   hipStream_t st = (hipStream_t)stream;
+  {
+    // round 6: the walking form (one workgroup per CU, the next item's K / V in flight) for the seven-key-tile shapes of a full batch
+    const char* we = getenv("RART_ATT_WALK");                                                // lab switch (read per call: tests flip it)
+    const int walk = we ? atoi(we) : 1;
+    int dev = 0, cus = 0;
+    if (walk && (tokens + 31) / 32 == 7 && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && (long long)n * heads >= 4ll * cus &&
+        (long long)n * tokens * 3 * D * 2 < (1ll << 31)) {
+      hipLaunchKernelGGL(k_vit_attention_pair_walk<7>, dim3((uint32_t)cus), dim3(kAttBlock), 0, st, (const uint16_t*)qkv_hi,
+                         (const uint16_t*)qkv_lo, (uint16_t*)out_hi, (uint16_t*)out_lo, tokens, heads, 3 * D, D, scale_log2e, n * heads);
+      RART_CHECK_LAUNCH("rart_vit_attention_pair (walking)");
+      return RART_OK;
+    }
+  }
 #define RART_PATT_CASE(N) case N: hipLaunchKernelGGL(k_vit_attention_pair<N>, grid, dim3(kAttBlock), 0, st, (const uint16_t*)qkv_hi, \
     (const uint16_t*)qkv_lo, (uint16_t*)out_hi, (uint16_t*)out_lo, tokens, heads, 3 * D, D, scale_log2e); break;
   switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial

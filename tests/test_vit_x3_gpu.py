@@ -465,3 +465,37 @@ def test_vit_engines_b256_match_small_batches_bit_for_bit(setup):
     ref = m((x[rows] - mean) / std)
     big3 = eng3.logits(x, MEAN, STD)
     assert (big3[rows] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('B,T', [(256, 197), (100, 197), (90, 224), (88, 193)])
+def test_walking_pair_attention_is_bit_identical(B, T, monkeypatch):
+    """Round 6: the forward pair attention with one workgroup per CU walking a run of (image, head) items -- wave 7 brings the next item's K
+    (during soft-max + P V) and V (during S = K Q^T) with buffer_load ... lds, V row-major and gathered -- against the one-item-per-workgroup
+    kernel: the same products in the same order, equal bit for bit; repeated beside a bandwidth hog (a missing wait of the loader shows as a
+    rare wrong item).  Uneven runs (100 x 12 items over 256 workgroups), full and minimal seventh key tiles."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    H, hd = 12, 64
+    g = torch.Generator().manual_seed(B + T)
+    qkv = _split((torch.randn(B * T, 3 * H * hd, generator=g) * 1.5).cuda())
+    sp = _lib.stream_ptr()
+
+    def run():
+        out = torch.full((2, B * T, H * hd), float('nan'), dtype=torch.bfloat16, device='cuda')
+        _lib.check(lib.rart_vit_attention_pair(_lib.ptr(qkv[0]), _lib.ptr(qkv[1]), _lib.ptr(out[0]), _lib.ptr(out[1]), B, T, H, hd, sp))
+        torch.cuda.synchronize()
+        return out
+    monkeypatch.setenv('RART_ATT_WALK', '0')
+    want = run()
+    assert torch.isfinite(want.float()).all()
+    monkeypatch.setenv('RART_ATT_WALK', '1')
+    hog_stream, hog = torch.cuda.Stream(), torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+    for rep in range(5):
+        if rep >= 2:
+            with torch.cuda.stream(hog_stream):
+                for _ in range(4):
+                    hog.add_(1.0)
+        got = run()
+        bad = (got.view(torch.int16) != want.view(torch.int16)).any(0)
+        assert not bad.any(), 'walking attention differs (repetition %d): %d elements, first rows %s' % (
+            rep, int(bad.sum()), bad.any(1).nonzero().flatten()[:8].tolist())
