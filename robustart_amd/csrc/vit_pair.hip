@@ -1000,9 +1000,13 @@ int rart_vit_attention_pair(const void* qkv_hi, const void* qkv_lo, void* out_hi
     // round 6: the walking form (one workgroup per CU, the next item's K / V in flight) for the seven-key-tile shapes of a full batch
     const char* we = getenv("RART_ATT_WALK");                                                // lab switch (read per call: tests flip it)
     const int walk = we ? atoi(we) : 1;
+    static int cu_cache[64] = {0};                     // compute units per device (the walking kernel's grid)
     int dev = 0, cus = 0;
-    if (walk && (tokens + 31) / 32 == 7 && hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && (long long)n * heads >= 4ll * cus &&
+    if (walk && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (cu_cache[dev] == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cu_cache[dev] = cus;
+      cus = cu_cache[dev];
+    }
+    if (walk && (tokens + 31) / 32 == 7 && cus > 0 && (long long)n * heads >= 4ll * cus &&
         (long long)n * tokens * 3 * D * 2 < (1ll << 31)) {
       hipLaunchKernelGGL(k_vit_attention_pair_walk<7>, dim3((uint32_t)cus), dim3(kAttBlock), 0, st, (const uint16_t*)qkv_hi,
                          (const uint16_t*)qkv_lo, (uint16_t*)out_hi, (uint16_t*)out_lo, tokens, heads, 3 * D, D, scale_log2e, n * heads);
