@@ -62,6 +62,16 @@ struct ConvTailDev {
   uint16_t *dstn_hi, *dstn_lo;
   int relu_next;
 };
+// round 6: the skip loads and the output stores are non-temporal accesses (see rart_gemm_pair_dev.h)
+typedef __attribute__((ext_vector_type(4))) uint32_t ct_u4;
+__device__ __forceinline__ uint4 ct_nt_load(const uint16_t* p) {
+  const ct_u4 v = __builtin_nontemporal_load(reinterpret_cast<const ct_u4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void ct_nt_store(uint16_t* p, const uint4& v) {
+  ct_u4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<ct_u4*>(p));
+}
 __device__ __forceinline__ uint32_t ct_fastdiv(uint32_t n, uint32_t magic, uint32_t shift) { return (uint32_t)(((uint64_t)n * magic) >> shift); }
 
 __device__ __forceinline__ uint32_t ct_pack_bf16x2(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
@@ -304,8 +314,8 @@ __global__ __launch_bounds__(256, (C == 64 && !NEXT) ? 3 : 2) void k_conv3x3_tai
         const int e = pp * NOUT + c * 64 + cw * 8;
         eo[q] = e;
         if (d.res_hi) {
-          rh[q] = *reinterpret_cast<const uint4*>(d.res_hi + e);
-          rl[q] = *reinterpret_cast<const uint4*>(d.res_lo + e);
+          rh[q] = ct_nt_load(d.res_hi + e);
+          rl[q] = ct_nt_load(d.res_lo + e);
         }
         if (d.mask_out) mb[q] = d.mask_out[e >> 3];
       }
@@ -371,8 +381,8 @@ __global__ __launch_bounds__(256, (C == 64 && !NEXT) ? 3 : 2) void k_conv3x3_tai
         }
         uint4 ph, pl;
         ct_split8(v, ph, pl);
-        *reinterpret_cast<uint4*>(d.dst_hi + e) = ph;
-        *reinterpret_cast<uint4*>(d.dst_lo + e) = pl;
+        ct_nt_store(d.dst_hi + e, ph);
+        ct_nt_store(d.dst_lo + e, pl);
         if (d.sign_out) d.sign_out[e >> 3] = (uint8_t)ct_sign_byte(ph);
         oph[q] = ph;
         opl[q] = pl;
@@ -433,8 +443,8 @@ __global__ __launch_bounds__(256, (C == 64 && !NEXT) ? 3 : 2) void k_conv3x3_tai
     if (p_ok) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        *reinterpret_cast<uint4*>(d.dstn_hi + (size_t)p * C + 16 * s + 8 * h) = fh[s];
-        *reinterpret_cast<uint4*>(d.dstn_lo + (size_t)p * C + 16 * s + 8 * h) = fl[s];
+        ct_nt_store(d.dstn_hi + (size_t)p * C + 16 * s + 8 * h, fh[s]);
+        ct_nt_store(d.dstn_lo + (size_t)p * C + 16 * s + 8 * h, fl[s]);
         if (d.sign_next) d.sign_next[(size_t)p * (C / 8) + 2 * s + h] = (uint8_t)ct_sign_byte(fh[s]);
       }
     }

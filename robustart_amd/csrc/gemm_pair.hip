@@ -348,6 +348,12 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   d.src_off = h->src_row_off; d.dst_off = h->dst_row_off;
   RART_CHECK_ARG(d.src_off >= 0 && d.dst_off >= 0, "rart_gemm_pair_bf16: row offsets must be >= 0");
   d.flags = h->flags;
+  {
+    // non-temporal epilogue streams for outputs that do not stay cached anyway (lab switch: RART_PAIR_NT_MIN_MB, the output pair's size)
+    const char* e = getenv("RART_PAIR_NT_MIN_MB");
+    const long long min_mb = e ? atoll(e) : 0;
+    d.nt = (long long)d.M * d.N * 4 >= min_mb * (1ll << 20) ? 1 : 0;
+  }
   const int nz = h->n_batched > 1 ? h->n_batched : 1;
   RART_CHECK_ARG(nz <= 65535, "rart_gemm_pair_bf16: n_batched must be <= 65535");
   d.z_inner = h->z_inner > 0 ? h->z_inner : 1;
