@@ -561,8 +561,11 @@ __global__ __launch_bounds__(kThreads, BK == 32 ? 3 : 2) void k_conv_igemm_bf16(
                                 (bits_from_halves(o[3]) << 6);
             p_sign[(off + (uint32_t)col) >> 3] = (uint8_t)sb;
           }
-          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col) =
-              make_uint4(o[0], o[1], o[2], o[3]);
+          {                      // (round 6) a non-temporal store: +1.5 % on adv_train, see csrc/train_convbn.hip
+            typedef __attribute__((ext_vector_type(4))) uint32_t ig_u4;
+            ig_u4 w_ = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(w_, reinterpret_cast<ig_u4*>(reinterpret_cast<uint16_t*>(d.dst) + p_dst_off + off + col));
+          }
         }
       }
     }

@@ -196,6 +196,11 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
 
 // The grid stride (gridDim.x * 256 vectors) is a multiple of the channel-group count (a power of two <= 256), so a
 // thread meets the same 8 channels in every iteration: its per-channel constants are loaded once, outside the loop.
+// round 6: the BatchNorm apply kernels' streams are non-temporal accesses (tensors of 100-800 MB read or written once per kernel):
+// adv_train 4 992 -> 5 069 images/s in a same-box A/B of lab builds (the implicit GEMM's bf16 output store likewise: 5 002 -> 5 077)
+typedef __attribute__((ext_vector_type(4))) uint32_t bn_u4;
+__device__ __forceinline__ uint4 bn_ld(const uint4* p) { const bn_u4 v = __builtin_nontemporal_load(reinterpret_cast<const bn_u4*>(p)); return make_uint4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void bn_st(uint4* p, const uint4& v) { bn_u4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<bn_u4*>(p)); }
 __global__ __launch_bounds__(kBlock) void k_bn_apply(const uint4* __restrict__ z, const uint4* __restrict__ res,
                                                      uint4* __restrict__ y, uint8_t* __restrict__ sign, size_t n8, int c8n,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
@@ -210,8 +215,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_apply(const uint4* __restrict__ z
   }
   for (size_t i = i0; i < n8; i += (size_t)gridDim.x * kBlock) {
     float zf[8], rf[8];
-    unpack8(z[i], zf);
-    if (res) unpack8(res[i], rf);
+    unpack8(bn_ld(z + i), zf);
+    if (res) unpack8(bn_ld(res + i), rf);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = fmaf(zf[j], sc[j], sh[j]);
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_apply(const uint4* __restrict__ z
       zf[j] = v;
     }
     const uint4 o = pack8(zf);
-    y[i] = o;
+    bn_st(y + i, o);
     if (sign) {             // (stored value > 0), one byte per 8 channels: the backward's ReLU mask at 1/16 of y's bytes
       bool kp[8];
       keep8(o, kp);
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(const uint4* __restrict
   }
   for (size_t i = i0; i < n8; i += (size_t)gridDim.x * kBlock) {
     float gf[8], zf[8];
-    unpack8(dy[i], gf);
-    unpack8(z[i], zf);
+    unpack8(bn_ld(dy + i), gf);
+    unpack8(bn_ld(z + i), zf);
     bool kp[8];
     if (ybits) keep8_bits(ybits[i], kp);
     else if (ymask) keep8(ymask[i], kp);
@@ -264,8 +269,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(const uint4* __restrict
       const float xh = (zf[j] - mu[j]) * is[j];
       zf[j] = sg[j] * (g - k1[j] - xh * k2[j]);
     }
-    dz[i] = pack8(zf);
-    if (g_out) g_out[i] = pack8(gf);
+    bn_st(dz + i, pack8(zf));
+    if (g_out) bn_st(g_out + i, pack8(gf));
   }
 }
 
