@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 1) void k_bottleneck7(const RartBneck7Desc d) 
               if (BWD) o[j] &= halves_from_bits(mb[q], j);
               else o[j] = relu_bf16x2(o[j]);
             }
-            *reinterpret_cast<uint4*>(d.out + eoff[q]) = make_uint4(o[0], o[1], o[2], o[3]);
+            RART_LAB_STORE16(d.out + eoff[q], make_uint4(o[0], o[1], o[2], o[3]));
             if (!BWD && d.m3) d.m3[eoff[q] >> 3] = (uint8_t)sign_byte(make_uint4(o[0], o[1], o[2], o[3]));
           }
         }

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
           const uint4 o = make_uint4(relu_bf16x2(pack_bf16x2(v0[0], v0[1])), relu_bf16x2(pack_bf16x2(v0[2], v0[3])),
                                      relu_bf16x2(pack_bf16x2(v1[0], v1[1])), relu_bf16x2(pack_bf16x2(v1[2], v1[3])));
           const long long e = (pb + r) * 256 + rd * 64 + cw * 8;
-          *reinterpret_cast<uint4*>(d.out + e) = o;
+          RART_LAB_STORE16(d.out + e, o);
           if (d.m3) d.m3[e >> 3] = (uint8_t)sign_byte(o);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
                                    pack_bf16x2(v0[2], v0[3]) & halves_from_bits(mbq[qd], 1),
                                    pack_bf16x2(v1[0], v1[1]) & halves_from_bits(mbq[qd], 2),
                                    pack_bf16x2(v1[2], v1[3]) & halves_from_bits(mbq[qd], 3));
-        *reinterpret_cast<uint4*>(d.out + (pb + r) * 64 + cw * 8) = o;
+        RART_LAB_STORE16(d.out + (pb + r) * 64 + cw * 8, o);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck56(const RartBneckDesc d) 
             else o[j] = relu_bf16x2(o[j]);
           }
           const long long e = (pb + r) * 256 + rd * 64 + cw * 8;
-          *reinterpret_cast<uint4*>(d.out + e) = make_uint4(o[0], o[1], o[2], o[3]);
+          RART_LAB_STORE16(d.out + e, make_uint4(o[0], o[1], o[2], o[3]));
           if (!BWD && d.m3) d.m3[e >> 3] = (uint8_t)sign_byte(make_uint4(o[0], o[1], o[2], o[3]));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2(con
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(sE + v * S2_LDE + cw * 8 + 4);
           const uint4 o = make_uint4(relu_bf16x2(pack_bf16x2(v0[0], v0[1])), relu_bf16x2(pack_bf16x2(v0[2], v0[3])),
                                      relu_bf16x2(pack_bf16x2(v1[0], v1[1])), relu_bf16x2(pack_bf16x2(v1[2], v1[3])));
-          *reinterpret_cast<uint4*>(d.out + eoff) = o;
+          RART_LAB_STORE16(d.out + eoff, o);
           if (d.m3) d.m3[eoff >> 3] = (uint8_t)sign_byte(o);
         }
       }
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(CM * 2, CM == 128 ? 2 : 1) void k_bottleneck_s2_bwd
             const uint32_t mb = d.m0 ? (uint32_t)d.m0[eoff >> 3] : 0xFFu;
             const uint4 o = make_uint4(pack_bf16x2(v0[0], v0[1]) & halves_from_bits(mb, 0), pack_bf16x2(v0[2], v0[3]) & halves_from_bits(mb, 1),
                                        pack_bf16x2(v1[0], v1[1]) & halves_from_bits(mb, 2), pack_bf16x2(v1[2], v1[3]) & halves_from_bits(mb, 3));
-            *reinterpret_cast<uint4*>(d.dx + eoff) = o;
+            RART_LAB_STORE16(d.dx + eoff, o);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -173,3 +173,22 @@ int rart_launch_stencil(int corruption_id, const RartCorruptArgs& a);
 size_t rart_ws_stencil(int corruption_id, int severity, int n, int h, int w);
 int rart_launch_composite(int corruption_id, const RartCorruptArgs& a);
 size_t rart_ws_composite(int corruption_id, int severity, int n, int h, int w);
+
+#ifdef __HIPCC__
+// 16-byte non-temporal accesses (round 6): for streams of hundreds of MB that a kernel reads or writes once.  RART_NT_LAB builds switch the
+// call sites marked "lab" in the fused bf16 kernels; the call sites of the pair GEMM / BatchNorm / implicit-GEMM epilogues use them always.
+typedef __attribute__((ext_vector_type(4))) uint32_t rart_u32x4;
+__device__ __forceinline__ void rart_nt_store16(void* p, const uint4& v) {
+  rart_u32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<rart_u32x4*>(p));
+}
+__device__ __forceinline__ uint4 rart_nt_load16(const void* p) {
+  const rart_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const rart_u32x4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#ifdef RART_NT_LAB
+#define RART_LAB_STORE16(P, V) rart_nt_store16((P), (V))
+#else
+#define RART_LAB_STORE16(P, V) (*reinterpret_cast<uint4*>(P) = (V))
+#endif
+#endif
