@@ -28,6 +28,10 @@ __device__ __forceinline__ rart_srd_t rart_dma_srd(const void* base) {
 __device__ __forceinline__ void rart_dma_load16(uint32_t voff, rart_srd_t srd, uint32_t soff, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
+// the same with the non-temporal cache policy: for operands no other workgroup reads (ViT's per-(image, head) K / V)
+__device__ __forceinline__ void rart_dma_load16_nt(uint32_t voff, rart_srd_t srd, uint32_t soff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen nt lds" : : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void rart_dma_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");

@@ -484,14 +484,20 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_pair_walk(const 
   const rart_srd_t srd_h = rart_dma_srd(qkv_h), srd_l = rart_dma_srd(qkv_l);
   // byte offset of item `it`'s (image, head) block inside a plane
 #define RART_AW_ITEM_OFF(IT) ((uint32_t)((((long long)((IT) / H) * T) * ld + ((IT) % H) * PATT_HD) * 2))
+#ifdef RART_ATT_NT       // lab build: dQ / dK / dV as non-temporal stores (measured: no change)
+#define RART_ATT_ST8(P, V) __builtin_nontemporal_store(*reinterpret_cast<const unsigned long long*>(&(V)), reinterpret_cast<unsigned long long*>(P))
+#else
+#define RART_ATT_ST8(P, V) (*reinterpret_cast<uint2*>(P) = (V))
+#endif
+#define RART_AW_DMA rart_dma_load16_nt      // K / V of an item: no other workgroup reads them (203 -> 199 us per launch)
 #define RART_AW_LOAD(LDS_, IT, COL)                                                                              \
   {                                                                                                              \
     const uint32_t so_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(RART_AW_ITEM_OFF(IT) + (uint32_t)((COL)*2)));   \
     _Pragma("unroll") for (int i = 0; i < NI; ++i) {      /* (the loader wave has nothing else to do: offsets on the fly) */ \
       const int c_ = 64 * i + lane, t_ = c_ / 9, cc_ = c_ - 9 * t_;                                              \
       const uint32_t vo_ = (cc_ < 8 && t_ < T) ? (uint32_t)((t_ * ld + cc_ * 8) * 2) : RART_DMA_OOR;             \
-      rart_dma_load16(vo_, srd_h, so_, (LDS_) + i * 1024);                                                       \
-      rart_dma_load16(vo_, srd_l, so_, (LDS_) + PLANE * 2 + i * 1024);                                           \
+      RART_AW_DMA(vo_, srd_h, so_, (LDS_) + i * 1024);                                                           \
+      RART_AW_DMA(vo_, srd_l, so_, (LDS_) + PLANE * 2 + i * 1024);                                               \
     }                                                                                                            \
   }
 #define RART_AW_BARRIER()                                                                                        \
@@ -791,8 +797,8 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair(const
           const float v[4] = {dq[nt][4 * g], dq[nt][4 * g + 1], dq[nt][4 * g + 2], dq[nt][4 * g + 3]};
           uint2 vh, vl;
           split4(v, vh, vl);
-          *reinterpret_cast<uint2*>(dq_h + ro + nt * 32 + 8 * g + 4 * hh) = vh;
-          *reinterpret_cast<uint2*>(dq_l + ro + nt * 32 + 8 * g + 4 * hh) = vl;
+          RART_ATT_ST8(dq_h + ro + nt * 32 + 8 * g + 4 * hh, vh);
+          RART_ATT_ST8(dq_l + ro + nt * 32 + 8 * g + 4 * hh, vl);
         }
     }
   }
@@ -897,10 +903,10 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_kv_pair(cons
           uint2 kh, kl, vh, vl;
           split4(vk, kh, kl);
           split4(vv, vh, vl);
-          *reinterpret_cast<uint2*>(dq_h + ro + D + nt * 32 + 8 * g + 4 * hh) = kh;
-          *reinterpret_cast<uint2*>(dq_l + ro + D + nt * 32 + 8 * g + 4 * hh) = kl;
-          *reinterpret_cast<uint2*>(dq_h + ro + 2 * D + nt * 32 + 8 * g + 4 * hh) = vh;
-          *reinterpret_cast<uint2*>(dq_l + ro + 2 * D + nt * 32 + 8 * g + 4 * hh) = vl;
+          RART_ATT_ST8(dq_h + ro + D + nt * 32 + 8 * g + 4 * hh, kh);
+          RART_ATT_ST8(dq_l + ro + D + nt * 32 + 8 * g + 4 * hh, kl);
+          RART_ATT_ST8(dq_h + ro + 2 * D + nt * 32 + 8 * g + 4 * hh, vh);
+          RART_ATT_ST8(dq_l + ro + 2 * D + nt * 32 + 8 * g + 4 * hh, vl);
         }
     }
   }
