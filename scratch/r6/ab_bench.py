@@ -5,9 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 if len(sys.argv) > 1 and sys.argv[1] == '--child':
     sys.path.insert(0, ROOT)
     from robustart_amd import _lib
-    if sys.argv[2] != 'product':
-        _lib.LIB_PATH = os.path.abspath(sys.argv[2])
-    sys.argv = ['bench.py', '--workload', sys.argv[3], '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-secondary', '--no-fast-mode']
+    if sys.argv[2].split(':')[0] != 'product':
+        _lib.LIB_PATH = os.path.abspath(sys.argv[2].split(':')[0])
+    sys.argv = ['bench.py'] + (['--workload', sys.argv[3]] if sys.argv[3] != 'headline' else []) + ['--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-secondary', '--no-fast-mode']
     import runpy
     runpy.run_path(os.path.join(ROOT, 'bench.py'), run_name='__main__')
     sys.exit(0)
@@ -17,7 +17,7 @@ res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
         o = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', l, wl], capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, RART_BENCH_NO_4X='1'))
+                           env=dict(os.environ, RART_BENCH_NO_4X='1', **{kv.split('=', 1)[0]: kv.split('=', 1)[1] for kv in l.split(':')[1:]}))
         try:
             d = json.loads([ln for ln in o.stdout.splitlines() if ln.startswith('{')][-1])
             res[l].append(d['value'])
