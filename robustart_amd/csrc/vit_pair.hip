@@ -653,6 +653,20 @@ __device__ __forceinline__ void patt_load_rows(uint16_t* s, const uint16_t* g, i
 }
 // A-operand fragment of the TRANSPOSE of a row-major [t][72] image: rows = channel d, k = the eight tokens t0 + {0,1,2,3,8,9,10,11}
 __device__ __forceinline__ bf16x8 patt_tr_frag(const uint16_t* s, int t0, int d) {
+#ifndef RART_PATT_GATHER
+  // round 6: two ds_read_b64_tr_b16 instead of eight 2-byte reads.  A 16-lane group reads a [4 tokens][16 channels] block of the row-major
+  // image -- lane a supplies the address of channels 4 (a & 3) .. + 3 of token a >> 2 -- and lane a receives channel a of the four tokens
+  // (the mapping csrc/wgrad_direct.hip uses; scratch/r4/probe_tr16.hip prints it).  Callers pass d = 32 nt + (lane & 31) and a t0 that is
+  // uniform over a 16-lane group, so a = d & 15 and the group's channel base is d - a.  144-byte rows: 8-byte aligned addresses.
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int a = d & 15;
+  const uint16_t* p = s + (t0 + (a >> 2)) * PATT_LDK + (d - a) + 4 * (a & 3);
+  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * PATT_LDK));
+  const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  return __builtin_bit_cast(bf16x8, r);
+#else
   const uint16_t* p = s + t0 * PATT_LDK + d;
   uint4 v;
   v.x = (uint32_t)p[0] | ((uint32_t)p[PATT_LDK] << 16);
@@ -660,6 +674,7 @@ __device__ __forceinline__ bf16x8 patt_tr_frag(const uint16_t* s, int t0, int d)
   v.z = (uint32_t)p[8 * PATT_LDK] | ((uint32_t)p[9 * PATT_LDK] << 16);
   v.w = (uint32_t)p[10 * PATT_LDK] | ((uint32_t)p[11 * PATT_LDK] << 16);
   return *reinterpret_cast<bf16x8*>(&v);
+#endif
 }
 __device__ __forceinline__ void patt_split8(const float* v, bf16x8& hi, bf16x8& lo) {
   uint4 h, l;
