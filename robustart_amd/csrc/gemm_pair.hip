@@ -456,7 +456,7 @@ extern "C" int rart_gemm_pair_bf16(const rart_gemm_pair_desc* h, rart_stream_t s
   // the two-stage kernel: tiles that step tm - 32 rows where that saves work per pass (resident workgroups per CU by LDS: 2 x STAGE bytes each)
   d.tile_rows = tm;
   dim3 grid2 = grid;
-  if (gp_rows224() >= 2 && nz == 1 && h->tile_m == 0 && h->tile_n == 0 && gp_schedule() >= 1) {
+  if ((gp_rows224() == 2 || (gp_rows224() == 3 && d.K >= 1024)) && nz == 1 && h->tile_m == 0 && h->tile_n == 0 && gp_schedule() >= 1) {   // (3: K-deep only)
     const int lds = 2 * (2 * tm * 64 + 2 * tn * 64), res = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3), cx = gp_cu_count() / 8 * res;
     auto passes = [&](int mt) { return ((mt >= 16 ? (mt + 7) / 8 * n_tiles : (mt * n_tiles + 7) / 8) + cx - 1) / cx; };
     const int rows = tm - 32, mt2 = (d.M + rows - 1) / rows;
