@@ -822,6 +822,178 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair(const
 }
 
 template <int NKT>
+__global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair_walk(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+                                                                        const uint16_t* __restrict__ o_h, const uint16_t* __restrict__ o_l,
+                                                                        const uint16_t* __restrict__ do_h, const uint16_t* __restrict__ do_l,
+                                                                        uint16_t* __restrict__ dq_h, uint16_t* __restrict__ dq_l,
+                                                                        float4* __restrict__ stats, int T, int H, int ld, int D, float scale,
+                                                                        float scale_log2e, int n_items) {
+  constexpr int TP = NKT * 32;
+  constexpr int NI = (TP * 9 + 63) / 64;                   // DMA instructions per plane of a padded [token][72] image
+  constexpr int PLANE = NI * 512;                          // elements per plane buffer (the last instruction's tail included)
+  static_assert(NKT == 7, "wave 7 is the loader: one query tile per compute wave");
+  __shared__ __attribute__((aligned(16))) uint16_t sK[2][PLANE];
+  __shared__ __attribute__((aligned(16))) uint16_t sV[2][PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int first = blockIdx.x, step = gridDim.x;          // items first, first + step, ...: neighbouring workgroups hold the heads of one image
+  if (first >= n_items) return;
+#define RART_BQ_BARRIER()                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+  __builtin_amdgcn_s_barrier();                                                                                  \
+  asm volatile("" ::: "memory");
+  if (wave == 7) {
+    // ---- the loader wave (see k_vit_attention_pair_walk): K, then V of an item; the compute waves start on K alone, V lands under S + soft-max
+    const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sK[0][0];
+    const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sV[0][0];
+    const rart_srd_t srd_h = rart_dma_srd(qkv_h), srd_l = rart_dma_srd(qkv_l);
+    for (int it = first; it < n_items; it += step) {
+      const uint32_t ib = (uint32_t)((((long long)(it / H) * T) * ld + (it % H) * PATT_HD) * 2);
+#define RART_BQ_LOAD(DST, COL)                                                                                    \
+      {                                                                                                          \
+        const uint32_t so_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ib + (uint32_t)((COL)*2)));          \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                        \
+          const int c_ = 64 * i + lane, t_ = c_ / 9, cc_ = c_ - 9 * t_;                                          \
+          const uint32_t vo_ = (cc_ < 8 && t_ < T) ? (uint32_t)((t_ * ld + cc_ * 8) * 2) : RART_DMA_OOR;         \
+          rart_dma_load16_nt(vo_, srd_h, so_, (DST) + i * 1024);                                                 \
+          rart_dma_load16_nt(vo_, srd_l, so_, (DST) + PLANE * 2 + i * 1024);                                     \
+        }                                                                                                        \
+      }
+      RART_BQ_LOAD(k_lds, D)
+      rart_dma_wait<0>();
+      RART_BQ_BARRIER()                                 // (B0) K visible: the compute waves start S = K Q^T
+      RART_BQ_LOAD(v_lds, 2 * D)                        // V travels under S + soft-max
+      rart_dma_wait<0>();
+      RART_BQ_BARRIER()                                 // (B1) V visible
+#undef RART_BQ_LOAD
+      RART_BQ_BARRIER()                                 // (B2) the item is done: K and V may be overwritten
+    }
+    return;
+  }
+  for (int it = first; it < n_items; it += step) {
+  const int b = it / H, h = it - b * H;
+  const size_t boff = (size_t)b * T * ld + h * PATT_HD, doff = (size_t)b * T * D + h * PATT_HD;
+  const uint16_t* const qb[2] = {qkv_h + boff, qkv_l + boff};
+  const uint16_t* const ob[2] = {o_h + doff, o_l + doff};
+  const uint16_t* const db[2] = {do_h + doff, do_l + doff};
+  RART_BQ_BARRIER()                                     // (B0)
+  {
+    const int q = wave * 32 + l31;
+    bf16x8 bq[2][4], bdo[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        uint4 vq = make_uint4(0, 0, 0, 0), vd = make_uint4(0, 0, 0, 0);
+        if (q < T) {
+          vq = *reinterpret_cast<const uint4*>(qb[p] + (size_t)q * ld + kb * 16 + hh * 8);
+          vd = *reinterpret_cast<const uint4*>(db[p] + (size_t)q * D + kb * 16 + hh * 8);
+        }
+        bq[p][kb] = *reinterpret_cast<bf16x8*>(&vq);
+        bdo[p][kb] = *reinterpret_cast<bf16x8*>(&vd);
+      }
+    // delta_q = sum_d dO[q][d] O[q][d]: a lane sums its half of the channels, one shuffle adds the halves
+    float delta = 0.f;
+    if (q < T) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float ov[8], dv[8];
+        join8(*reinterpret_cast<const uint4*>(ob[0] + (size_t)q * D + hh * 32 + c * 8), *reinterpret_cast<const uint4*>(ob[1] + (size_t)q * D + hh * 32 + c * 8), ov);
+        join8(*reinterpret_cast<const uint4*>(db[0] + (size_t)q * D + hh * 32 + c * 8), *reinterpret_cast<const uint4*>(db[1] + (size_t)q * D + hh * 32 + c * 8), dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta = fmaf(ov[j], dv[j], delta);
+      }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sK[0][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sK[1][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        RART_MFMA3(sacc[kt], ah, al, bq[0][kb], bq[1][kb])
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= T) sacc[NKT - 1][r] = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64)) * scale_log2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], scale_log2e, -m));
+        sacc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (hh == 0) stats[(size_t)it * TP + q] = make_float4(m, inv, delta, 0.f);
+    RART_BQ_BARRIER()                                   // (B1) V is in LDS
+    const float sinv = scale * inv;
+    f32x16 dq[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[nt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sV[0][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sV[1][(kt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8]);
+        RART_MFMA3(dp, ah, al, bdo[0][kb], bdo[1][kb])
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        float dsv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsv[j] = sinv * sacc[kt][8 * kb2 + j] * (dp[8 * kb2 + j] - delta);
+        bf16x8 dsh, dsl;
+        patt_split8(dsv, dsh, dsl);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int t0 = kt * 32 + 16 * kb2 + 4 * hh, dch = nt * 32 + l31;
+          const bf16x8 ah = patt_tr_frag(sK[0], t0, dch), al = patt_tr_frag(sK[1], t0, dch);
+          RART_MFMA3(dq[nt], ah, al, dsh, dsl)
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one key tile at a time
+    }
+    // dq[nt][r] = dQ[query q][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]
+    if (q < T) {
+      const size_t ro = boff + (size_t)q * ld;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v[4] = {dq[nt][4 * g], dq[nt][4 * g + 1], dq[nt][4 * g + 2], dq[nt][4 * g + 3]};
+          uint2 vh, vl;
+          split4(v, vh, vl);
+          RART_ATT_ST8(dq_h + ro + nt * 32 + 8 * g + 4 * hh, vh);
+          RART_ATT_ST8(dq_l + ro + nt * 32 + 8 * g + 4 * hh, vl);
+        }
+    }
+  }
+  RART_BQ_BARRIER()                                     // (B2)
+  }
+#undef RART_BQ_BARRIER
+}
+
+template <int NKT>
 __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_kv_pair(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
                                                                          const uint16_t* __restrict__ do_h, const uint16_t* __restrict__ do_l,
                                                                          uint16_t* __restrict__ dq_h, uint16_t* __restrict__ dq_l,
@@ -1069,6 +1241,24 @@ int rart_vit_attention_bwd_pair(const void* qkv_hi, const void* qkv_lo, const vo
                      scale, sl2e);                                                                                                      \
   hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair<N>, grid, dim3(kAttBlock), 0, st, qh, ql, dh, dl, gh, gl, (const float4*)s4, tokens, heads,  \
                      3 * D, D, scale, sl2e);
+  {
+    // round 6: the walking backward-q kernel (loader wave: V lands under S + soft-max) for the seven-key-tile shapes of a full batch
+    const char* we = getenv("RART_ATT_WALK");
+    int dev = 0, cus = 0;
+    static int cu_cache_b[64] = {0};
+    if ((we ? atoi(we) : 1) && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (cu_cache_b[dev] == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cu_cache_b[dev] = cus;
+      cus = cu_cache_b[dev];
+    }
+    if ((tokens + 31) / 32 == 7 && cus > 0 && (long long)n * heads >= 4ll * cus && (long long)n * tokens * 3 * D * 2 < (1ll << 31)) {
+      hipLaunchKernelGGL(k_vit_attention_bwd_q_pair_walk<7>, dim3((uint32_t)cus), dim3(kAttBlock), 0, st, qh, ql, oh, ol, dh, dl, gh, gl, s4, tokens,
+                         heads, 3 * D, D, scale, sl2e, n * heads);
+      hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair<7>, grid, dim3(kAttBlock), 0, st, qh, ql, dh, dl, gh, gl, (const float4*)s4, tokens, heads,
+                         3 * D, D, scale, sl2e);
+      RART_CHECK_LAUNCH("rart_vit_attention_bwd_pair (walking backward-q)");
+      return RART_OK;
+    }
+  }
   switch ((tokens + 31) / 32) {                   // key tiles: only the last one is partial
     case 1: RART_PATTB_CASE(1) break;
     case 2: RART_PATTB_CASE(2) break;

@@ -499,3 +499,42 @@ def test_walking_pair_attention_is_bit_identical(B, T, monkeypatch):
         bad = (got.view(torch.int16) != want.view(torch.int16)).any(0)
         assert not bad.any(), 'walking attention differs (repetition %d): %d elements, first rows %s' % (
             rep, int(bad.sum()), bad.any(1).nonzero().flatten()[:8].tolist())
+
+
+@pytest.mark.parametrize('B,T', [(256, 197), (100, 224), (90, 193)])
+def test_walking_pair_attention_backward_is_bit_identical(B, T, monkeypatch):
+    """Round 6: the backward pair attention with the backward-q kernel walking its items (loader wave: K by LDS-DMA, V under S + soft-max)
+    against the one-item-per-workgroup kernels: dQ / dK / dV and the per-query statistics equal bit for bit, repeatedly, beside a hog."""
+    from robustart_amd import _lib
+    lib = _lib.load()
+    H, hd = 12, 64
+    g = torch.Generator().manual_seed(7 * B + T)
+    qkv = _split((torch.randn(B * T, 3 * H * hd, generator=g) * 1.2).cuda())
+    dout = _split((torch.randn(B * T, H * hd, generator=g) * 0.1).cuda())
+    sp = _lib.stream_ptr()
+    out = torch.empty(2, B * T, H * hd, dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.rart_vit_attention_pair(_lib.ptr(qkv[0]), _lib.ptr(qkv[1]), _lib.ptr(out[0]), _lib.ptr(out[1]), B, T, H, hd, sp))
+    TP = (T + 31) // 32 * 32
+
+    def run():
+        dq = torch.full((2, B * T, 3 * H * hd), float('nan'), dtype=torch.bfloat16, device='cuda')
+        stats = torch.zeros(B * H * TP, 4, device='cuda')
+        _lib.check(lib.rart_vit_attention_bwd_pair(_lib.ptr(qkv[0]), _lib.ptr(qkv[1]), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(dout[0]),
+                                                   _lib.ptr(dout[1]), _lib.ptr(dq[0]), _lib.ptr(dq[1]), _lib.ptr(stats), B, T, H, hd, sp))
+        torch.cuda.synchronize()
+        return dq, stats
+    monkeypatch.setenv('RART_ATT_WALK', '0')
+    want, wstats = run()
+    assert torch.isfinite(want.float()).all()
+    monkeypatch.setenv('RART_ATT_WALK', '1')
+    hog_stream, hog = torch.cuda.Stream(), torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+    for rep in range(4):
+        if rep >= 2:
+            with torch.cuda.stream(hog_stream):
+                for _ in range(4):
+                    hog.add_(1.0)
+        got, gstats = run()
+        bad = (got.view(torch.int16) != want.view(torch.int16)).any(0)
+        assert not bad.any(), 'walking backward differs (repetition %d): %d elements, first rows %s' % (
+            rep, int(bad.sum()), bad.any(1).nonzero().flatten()[:8].tolist())
+        assert torch.equal(gstats.view(torch.int32)[:, :3], wstats.view(torch.int32)[:, :3])
