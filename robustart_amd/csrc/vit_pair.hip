@@ -1100,6 +1100,172 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_kv_pair(cons
     }
   }
 }
+template <int NKT>
+__global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_kv_pair_walk(const uint16_t* __restrict__ qkv_h, const uint16_t* __restrict__ qkv_l,
+                                                                         const uint16_t* __restrict__ do_h, const uint16_t* __restrict__ do_l,
+                                                                         uint16_t* __restrict__ dq_h, uint16_t* __restrict__ dq_l,
+                                                                         const float4* __restrict__ stats, int T, int H, int ld, int D, float scale,
+                                                                         float scale_log2e, int n_items) {
+  constexpr int TP = NKT * 32;
+  constexpr int NI = (TP * 9 + 63) / 64;                   // DMA instructions per plane of a padded [token][72] image
+  constexpr int PLANE = NI * 512;                          // elements per plane buffer
+  static_assert(NKT == 7 && NI == 32, "wave 7 is the loader; slices of 64 rows = 9 instructions, the last one 5");
+  __shared__ __attribute__((aligned(16))) uint16_t sQ[2][PLANE];
+  __shared__ __attribute__((aligned(16))) uint16_t sdO[2][PLANE];
+  __shared__ __attribute__((aligned(16))) float4 sStat2[2][TP];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int first = blockIdx.x, step = gridDim.x;
+  if (first >= n_items) return;
+#define RART_BK_BARRIER()                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+  __builtin_amdgcn_s_barrier();                                                                                  \
+  asm volatile("" ::: "memory");
+  if (wave == 7) {
+    // ---- the loader wave.  The compute waves consume Q and dO one 32-query tile at a time, in the same order, so the rows of a 64-row
+    //      slice are free once every wave is past its two tiles (barriers S1 / S3 / S5 below): the NEXT item's slice goes there while the
+    //      current item still works on the later ones; the last slice (rows 192 ..) follows the item boundary and has until tile 6.
+    const uint32_t q_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sQ[0][0];
+    const uint32_t d_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sdO[0][0];
+    const rart_srd_t sq_h = rart_dma_srd(qkv_h), sq_l = rart_dma_srd(qkv_l), sd_h = rart_dma_srd(do_h), sd_l = rart_dma_srd(do_l);
+#define RART_BK_SLICE(IT, I0, I1)                                                                                \
+    {                                                                                                            \
+      const int it_ = (IT);                                                                                      \
+      const uint32_t qo_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)((((long long)(it_ / H) * T) * ld + (it_ % H) * PATT_HD) * 2)); \
+      const uint32_t do_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)((((long long)(it_ / H) * T) * D + (it_ % H) * PATT_HD) * 2));  \
+      _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                                     \
+        const int c_ = 64 * i + lane, t_ = c_ / 9, cc_ = c_ - 9 * t_;                                            \
+        const bool ok_ = cc_ < 8 && t_ < T;                                                                      \
+        const uint32_t vq_ = ok_ ? (uint32_t)((t_ * ld + cc_ * 8) * 2) : RART_DMA_OOR;                           \
+        const uint32_t vd_ = ok_ ? (uint32_t)((t_ * D + cc_ * 8) * 2) : RART_DMA_OOR;                            \
+        rart_dma_load16_nt(vq_, sq_h, qo_, q_lds + i * 1024);                                                    \
+        rart_dma_load16_nt(vq_, sq_l, qo_, q_lds + PLANE * 2 + i * 1024);                                        \
+        rart_dma_load16_nt(vd_, sd_h, do_, d_lds + i * 1024);                                                    \
+        rart_dma_load16_nt(vd_, sd_l, do_, d_lds + PLANE * 2 + i * 1024);                                        \
+      }                                                                                                          \
+    }
+#define RART_BK_STATS(IT, PAR)                                                                                   \
+    for (int i = lane; i < TP; i += 64) sStat2[PAR][i] = stats[(size_t)(IT)*TP + i];
+    RART_BK_SLICE(first, 0, 27)
+    RART_BK_STATS(first, 0)
+    int par = 0;
+    for (int it = first; it < n_items; it += step) {
+      const bool more = it + step < n_items;
+      rart_dma_wait<0>();                               // rows 0 .. 191 of this item (and its statistics) are in LDS
+      RART_BK_BARRIER()                                 // (E) the item starts
+      RART_BK_SLICE(it, 27, 32)                         // rows 192 ..: free since the previous item's last tile
+      if (more) RART_BK_STATS(it + step, par ^ 1)
+      rart_dma_wait<0>();
+      RART_BK_BARRIER()                                 // (S1) tiles 0, 1 done everywhere; the last slice is visible
+      if (more) RART_BK_SLICE(it + step, 0, 9)
+      RART_BK_BARRIER()                                 // (S3)
+      if (more) RART_BK_SLICE(it + step, 9, 18)
+      RART_BK_BARRIER()                                 // (S5)
+      if (more) RART_BK_SLICE(it + step, 18, 27)
+      par ^= 1;
+    }
+    rart_dma_wait<0>();
+    return;
+#undef RART_BK_STATS
+#undef RART_BK_SLICE
+  }
+  int par = 0;
+  for (int it = first; it < n_items; it += step) {
+  const int b = it / H, h = it - b * H;
+  const size_t boff = (size_t)b * T * ld + h * PATT_HD;
+  const uint16_t* const qb[2] = {qkv_h + boff, qkv_l + boff};
+  const float4* const sStat = sStat2[par];
+  RART_BK_BARRIER()                                     // (E)
+  {
+    const int kt = wave;
+    const int key = kt * 32 + l31;
+    const bool key_ok = key < T;
+    bf16x8 bk[2][4], bv[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        uint4 vk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key_ok) {
+          vk = *reinterpret_cast<const uint4*>(qb[p] + (size_t)key * ld + D + kb * 16 + hh * 8);
+          vv = *reinterpret_cast<const uint4*>(qb[p] + (size_t)key * ld + 2 * D + kb * 16 + hh * 8);
+        }
+        bk[p][kb] = *reinterpret_cast<bf16x8*>(&vk);
+        bv[p][kb] = *reinterpret_cast<bf16x8*>(&vv);
+      }
+    // dV^T = dO^T . P and dK^T = Q^T . dS (operands swapped): lane = key, registers = channels
+    f32x16 dvv[2], dkk[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dvv[nt][r] = dkk[nt][r] = 0.f;
+#pragma unroll 1
+    for (int qt = 0; qt < NKT; ++qt) {
+      f32x16 sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int so = (qt * 32 + l31) * PATT_LDK + kb * 16 + hh * 8;
+        const bf16x8 qh = *reinterpret_cast<const bf16x8*>(&sQ[0][so]), ql = *reinterpret_cast<const bf16x8*>(&sQ[1][so]);
+        const bf16x8 dh = *reinterpret_cast<const bf16x8*>(&sdO[0][so]), dl = *reinterpret_cast<const bf16x8*>(&sdO[1][so]);
+        RART_MFMA3(sa, qh, ql, bk[0][kb], bk[1][kb])
+        RART_MFMA3(dp, dh, dl, bv[0][kb], bv[1][kb])
+      }
+      // lane = key kt*32 + l31; register r = query qt*32 + (r&3) + 8*(r>>2) + 4*hh (queries past the sequence have zero Q / dO rows:
+      // whatever probability they get multiplies zeros)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 st = sStat[qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+        const float pv = key_ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], scale_log2e, -st.x)) * st.y : 0.f;
+        sa[r] = pv;
+        dp[r] = scale * pv * (dp[r] - st.z);
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        float pw[8], dw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pw[j] = sa[8 * kb2 + j];
+          dw[j] = dp[8 * kb2 + j];
+        }
+        bf16x8 pbh, pbl, dbh, dbl;
+        patt_split8(pw, pbh, pbl);
+        patt_split8(dw, dbh, dbl);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int t0 = qt * 32 + 16 * kb2 + 4 * hh, dch = nt * 32 + l31;
+          const bf16x8 oh = patt_tr_frag(sdO[0], t0, dch), ol = patt_tr_frag(sdO[1], t0, dch);
+          const bf16x8 qh = patt_tr_frag(sQ[0], t0, dch), ql = patt_tr_frag(sQ[1], t0, dch);
+          RART_MFMA3(dvv[nt], oh, ol, pbh, pbl)
+          RART_MFMA3(dkk[nt], qh, ql, dbh, dbl)
+        }
+      }
+      if (qt == 1 || qt == 3 || qt == 5) { RART_BK_BARRIER() }       // (S1 / S3 / S5) a 64-row slice of Q and dO is free
+    }
+    // dkk / dvv[nt][r] = dK / dV[key][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]: 8-byte runs of the lane's own key row
+    if (key_ok) {
+      const size_t ro = boff + (size_t)key * ld;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float vk[4] = {dkk[nt][4 * g], dkk[nt][4 * g + 1], dkk[nt][4 * g + 2], dkk[nt][4 * g + 3]};
+          const float vv[4] = {dvv[nt][4 * g], dvv[nt][4 * g + 1], dvv[nt][4 * g + 2], dvv[nt][4 * g + 3]};
+          uint2 kh, kl, vh, vl;
+          split4(vk, kh, kl);
+          split4(vv, vh, vl);
+          RART_ATT_ST8(dq_h + ro + D + nt * 32 + 8 * g + 4 * hh, kh);
+          RART_ATT_ST8(dq_l + ro + D + nt * 32 + 8 * g + 4 * hh, kl);
+          RART_ATT_ST8(dq_h + ro + 2 * D + nt * 32 + 8 * g + 4 * hh, vh);
+          RART_ATT_ST8(dq_l + ro + 2 * D + nt * 32 + 8 * g + 4 * hh, vl);
+        }
+    }
+  }
+  par ^= 1;
+  }
+#undef RART_BK_BARRIER
+}
 #undef RART_MFMA3
 int grid_for(size_t items) { return rart_grid_for(items, kBlock, 256 * 16); }
 }  // namespace
@@ -1250,12 +1416,16 @@ int rart_vit_attention_bwd_pair(const void* qkv_hi, const void* qkv_lo, const vo
       if (cu_cache_b[dev] == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cu_cache_b[dev] = cus;
       cus = cu_cache_b[dev];
     }
-    if ((tokens + 31) / 32 == 7 && cus > 0 && (long long)n * heads >= 4ll * cus && (long long)n * tokens * 3 * D * 2 < (1ll << 31)) {
+    if ((tokens + 31) / 32 == 7 && cus > 0 && (long long)n * heads >= 4ll * cus && (long long)n * tokens * 3 * D * 2 < (1ll << 31)) {      // (dO: a third of that)
       hipLaunchKernelGGL(k_vit_attention_bwd_q_pair_walk<7>, dim3((uint32_t)cus), dim3(kAttBlock), 0, st, qh, ql, oh, ol, dh, dl, gh, gl, s4, tokens,
                          heads, 3 * D, D, scale, sl2e, n * heads);
-      hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair<7>, grid, dim3(kAttBlock), 0, st, qh, ql, dh, dl, gh, gl, (const float4*)s4, tokens, heads,
-                         3 * D, D, scale, sl2e);
-      RART_CHECK_LAUNCH("rart_vit_attention_bwd_pair (walking backward-q)");
+      if ((we ? atoi(we) : 1) >= 2 || !we)      // (RART_ATT_WALK=1: backward-q alone walks; lab)
+        hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair_walk<7>, dim3((uint32_t)cus), dim3(kAttBlock), 0, st, qh, ql, dh, dl, gh, gl,
+                           (const float4*)s4, tokens, heads, 3 * D, D, scale, sl2e, n * heads);
+      else
+        hipLaunchKernelGGL(k_vit_attention_bwd_kv_pair<7>, grid, dim3(kAttBlock), 0, st, qh, ql, dh, dl, gh, gl, (const float4*)s4, tokens, heads,
+                           3 * D, D, scale, sl2e);
+      RART_CHECK_LAUNCH("rart_vit_attention_bwd_pair (walking)");
       return RART_OK;
     }
   }

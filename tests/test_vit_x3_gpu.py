@@ -503,8 +503,9 @@ def test_walking_pair_attention_is_bit_identical(B, T, monkeypatch):
 
 @pytest.mark.parametrize('B,T', [(256, 197), (100, 224), (90, 193)])
 def test_walking_pair_attention_backward_is_bit_identical(B, T, monkeypatch):
-    """Round 6: the backward pair attention with the backward-q kernel walking its items (loader wave: K by LDS-DMA, V under S + soft-max)
-    against the one-item-per-workgroup kernels: dQ / dK / dV and the per-query statistics equal bit for bit, repeatedly, beside a hog."""
+    """Round 6: the backward pair attention with both kernels walking their items -- backward-q: loader wave, K by LDS-DMA, V under S + soft-max;
+    backward-kv: the next item's Q / dO arrive in 64-row slices as the current item's query tiles release them -- against the
+    one-item-per-workgroup kernels: dQ / dK / dV and the per-query statistics equal bit for bit, repeatedly, beside a hog."""
     from robustart_amd import _lib
     lib = _lib.load()
     H, hd = 12, 64
@@ -526,7 +527,7 @@ def test_walking_pair_attention_backward_is_bit_identical(B, T, monkeypatch):
     monkeypatch.setenv('RART_ATT_WALK', '0')
     want, wstats = run()
     assert torch.isfinite(want.float()).all()
-    monkeypatch.setenv('RART_ATT_WALK', '1')
+    monkeypatch.setenv('RART_ATT_WALK', '2')          # 2 (= the default with the variable unset): backward-q AND backward-kv walk; 1: backward-q alone
     hog_stream, hog = torch.cuda.Stream(), torch.empty(64 << 20, dtype=torch.float32, device='cuda')
     for rep in range(4):
         if rep >= 2:
