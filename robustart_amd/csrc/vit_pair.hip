@@ -843,32 +843,46 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair_walk(
   __builtin_amdgcn_s_barrier();                                                                                  \
   asm volatile("" ::: "memory");
   if (wave == 7) {
-    // ---- the loader wave (see k_vit_attention_pair_walk): K, then V of an item; the compute waves start on K alone, V lands under S + soft-max
+    // ---- the loader wave.  Phase B (dP, dS, dQ) walks the key tiles in order, every wave the same, and is the LAST reader of a key tile's
+    //      K and V rows: once all waves are past key tiles 2k, 2k + 1 (barriers S1 / S3 / S5) the NEXT item's 64-row slice of K and of V goes
+    //      there.  The last slice (rows 192 ..) follows the item boundary: K's is needed by the seventh key tile of S = K Q^T (barrier A6
+    //      in front of it), V's not before phase B.
     const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sK[0][0];
     const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&sV[0][0];
     const rart_srd_t srd_h = rart_dma_srd(qkv_h), srd_l = rart_dma_srd(qkv_l);
-    for (int it = first; it < n_items; it += step) {
-      const uint32_t ib = (uint32_t)((((long long)(it / H) * T) * ld + (it % H) * PATT_HD) * 2);
-#define RART_BQ_LOAD(DST, COL)                                                                                    \
-      {                                                                                                          \
-        const uint32_t so_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ib + (uint32_t)((COL)*2)));          \
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                        \
-          const int c_ = 64 * i + lane, t_ = c_ / 9, cc_ = c_ - 9 * t_;                                          \
-          const uint32_t vo_ = (cc_ < 8 && t_ < T) ? (uint32_t)((t_ * ld + cc_ * 8) * 2) : RART_DMA_OOR;         \
-          rart_dma_load16_nt(vo_, srd_h, so_, (DST) + i * 1024);                                                 \
-          rart_dma_load16_nt(vo_, srd_l, so_, (DST) + PLANE * 2 + i * 1024);                                     \
-        }                                                                                                        \
-      }
-      RART_BQ_LOAD(k_lds, D)
-      rart_dma_wait<0>();
-      RART_BQ_BARRIER()                                 // (B0) K visible: the compute waves start S = K Q^T
-      RART_BQ_LOAD(v_lds, 2 * D)                        // V travels under S + soft-max
-      rart_dma_wait<0>();
-      RART_BQ_BARRIER()                                 // (B1) V visible
-#undef RART_BQ_LOAD
-      RART_BQ_BARRIER()                                 // (B2) the item is done: K and V may be overwritten
+#define RART_BQ_SLICE(IT, I0, I1)                                                                                \
+    {                                                                                                            \
+      const int it_ = (IT);                                                                                      \
+      const uint32_t ib_ = (uint32_t)((((long long)(it_ / H) * T) * ld + (it_ % H) * PATT_HD) * 2);              \
+      const uint32_t ko_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ib_ + (uint32_t)(D * 2)));             \
+      const uint32_t vo2_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ib_ + (uint32_t)(D * 4)));            \
+      _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                                     \
+        const int c_ = 64 * i + lane, t_ = c_ / 9, cc_ = c_ - 9 * t_;                                            \
+        const uint32_t vo_ = (cc_ < 8 && t_ < T) ? (uint32_t)((t_ * ld + cc_ * 8) * 2) : RART_DMA_OOR;           \
+        rart_dma_load16_nt(vo_, srd_h, ko_, k_lds + i * 1024);                                                   \
+        rart_dma_load16_nt(vo_, srd_l, ko_, k_lds + PLANE * 2 + i * 1024);                                       \
+        rart_dma_load16_nt(vo_, srd_h, vo2_, v_lds + i * 1024);                                                  \
+        rart_dma_load16_nt(vo_, srd_l, vo2_, v_lds + PLANE * 2 + i * 1024);                                      \
+      }                                                                                                          \
     }
+    RART_BQ_SLICE(first, 0, 27)
+    for (int it = first; it < n_items; it += step) {
+      const bool more = it + step < n_items;
+      rart_dma_wait<0>();                               // rows 0 .. 191 of this item's K and V
+      RART_BQ_BARRIER()                                 // (E) the item starts
+      RART_BQ_SLICE(it, 27, NI)                         // rows 192 ..: free since the previous item's last key tile
+      rart_dma_wait<0>();
+      RART_BQ_BARRIER()                                 // (A6) in front of the seventh key tile of S = K Q^T
+      RART_BQ_BARRIER()                                 // (S1) phase B is past key tiles 0, 1
+      if (more) RART_BQ_SLICE(it + step, 0, 9)
+      RART_BQ_BARRIER()                                 // (S3)
+      if (more) RART_BQ_SLICE(it + step, 9, 18)
+      RART_BQ_BARRIER()                                 // (S5)
+      if (more) RART_BQ_SLICE(it + step, 18, 27)
+    }
+    rart_dma_wait<0>();
     return;
+#undef RART_BQ_SLICE
   }
   for (int it = first; it < n_items; it += step) {
   const int b = it / H, h = it - b * H;
@@ -876,7 +890,7 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair_walk(
   const uint16_t* const qb[2] = {qkv_h + boff, qkv_l + boff};
   const uint16_t* const ob[2] = {o_h + doff, o_l + doff};
   const uint16_t* const db[2] = {do_h + doff, do_l + doff};
-  RART_BQ_BARRIER()                                     // (B0)
+  RART_BQ_BARRIER()                                     // (E)
   {
     const int q = wave * 32 + l31;
     bf16x8 bq[2][4], bdo[2][4];
@@ -908,6 +922,7 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair_walk(
     f32x16 sacc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
+      if (kt == NKT - 1) { RART_BQ_BARRIER() }          // (A6) the last rows of K (and V) have landed
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
 #pragma unroll
@@ -939,7 +954,6 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair_walk(
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (hh == 0) stats[(size_t)it * TP + q] = make_float4(m, inv, delta, 0.f);
-    RART_BQ_BARRIER()                                   // (B1) V is in LDS
     const float sinv = scale * inv;
     f32x16 dq[2];
 #pragma unroll
@@ -972,6 +986,7 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair_walk(
         }
       }
       __builtin_amdgcn_sched_barrier(0);     // one key tile at a time
+      if (kt == 1 || kt == 3 || kt == 5) { RART_BQ_BARRIER() }      // (S1 / S3 / S5) a 64-row slice of K and of V is free
     }
     // dq[nt][r] = dQ[query q][d = nt*32 + (r&3) + 8*(r>>2) + 4*hh]
     if (q < T) {
@@ -988,7 +1003,6 @@ __global__ __launch_bounds__(kAttBlock, 1) void k_vit_attention_bwd_q_pair_walk(
         }
     }
   }
-  RART_BQ_BARRIER()                                     // (B2)
   }
 #undef RART_BQ_BARRIER
 }
