@@ -445,6 +445,9 @@ def measure_engine_roofline(path, images, labels):
                 'traffic_note': 'HBM bytes per launch (launch-weighted mean over the family\'s template instances) from the committed PMC pass '
                                 'profiles/%s (rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB units), not re-measured in this run'
                                 % getattr(pmc_traffic, 'source', '?')})
+    if x3:
+        out['clock_note'] = ('peaks are priced at the 2.4 GHz boost clock; this workload holds the part at its 1.32 kW package-power cap, where the '
+                             'shader clock reads 2.25 GHz (ResNet-50) / 1.91 GHz (ViT-B/16): profiles/r06_clock_under_load.txt, not re-measured in this run')
     out['other_mfma_kernels'] = {'%s, %d launches' % (KERNEL_NAMES.get(k, k), f['n']): block(k, f) for k, f in sorted(fam.items()) if k != dom}
     out['all_conv_launches'] = {'achieved': tot_f / tot_s / 1e12, 'unit': 'TFLOP/s', 'frac': tot_f / tot_s / MFMA_BF16_PEAK,
                                 'seconds_per_fwd_bwd': tot_s, 'launches': len(prof)}
